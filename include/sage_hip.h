@@ -1,0 +1,222 @@
+/*
+ * sage_hip.h — C ABI of the MI355X-native search-and-score engine (libsage_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of lazear/sage: `Scorer::score` /
+ * `score_chimera_fast` over `IndexedDatabase` (reference citations are relative to
+ * /root/reference/crates/sage/src unless a crate is named).  The reference has no FFI; the entry
+ * points below are what a Rust `extern "C"` shim inside sage-core would bind (INTEGRATION.md shows
+ * the shim).  Conventions:
+ *   - plain pointers and sizes only; the caller owns every input buffer for the duration of a call;
+ *     outputs are caller-allocated;
+ *   - every function returns a status code (SAGE_HIP_OK == 0) instead of panicking
+ *     (the reference panics at scoring.rs:261-267, 301-304, 466-468); sage_hip_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - one SageScorer handle may be used from one host thread at a time; use one handle per device
+ *     for multi-GPU (spectra sharded, index replicated, no collective on the data path).
+ *   - there is NO CPU fallback: scoring entry points fail with SAGE_HIP_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef SAGE_HIP_H
+#define SAGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGE_HIP_ABI_VERSION 1
+
+enum {
+    SAGE_HIP_OK = 0,
+    SAGE_HIP_ERR_INVALID = 1,     /* bad argument / contract violation (reference: panic!) */
+    SAGE_HIP_ERR_NO_DEVICE = 2,   /* no usable HIP device */
+    SAGE_HIP_ERR_HIP = 3,         /* a HIP runtime call failed */
+    SAGE_HIP_ERR_UNSUPPORTED = 4, /* valid in the reference, outside this build's device limits */
+    SAGE_HIP_ERR_OOM = 5
+};
+
+/* mass.rs:10-16  enum Tolerance { Ppm(f32,f32), Pct(f32,f32), Da(f32,f32) } */
+enum { SAGE_TOL_PPM = 0, SAGE_TOL_PCT = 1, SAGE_TOL_DA = 2 };
+typedef struct SageTolerance {
+    int32_t kind;
+    float lo, hi;
+} SageTolerance;
+
+/* ion_series.rs:6-15  enum Kind { A, B, C, X, Y, Z } */
+enum { SAGE_ION_A = 0, SAGE_ION_B = 1, SAGE_ION_C = 2, SAGE_ION_X = 3, SAGE_ION_Y = 4, SAGE_ION_Z = 5 };
+
+/* database.rs:378-382  struct Theoretical */
+typedef struct SageTheoretical {
+    uint32_t peptide_index; /* PeptideIx, database.rs:367-369 */
+    float fragment_mz;
+} SageTheoretical;
+
+/* ------------------------------------------------------------------------------------------
+ * Host side: database construction.  Replaces database.rs:59-139 (Builder / Parameters) and
+ * Parameters::build (database.rs:260-364).  Option<T> fields use -1 / NULL for None.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct SageDbParams {
+    uint64_t bucket_size;      /* 0 => 8192; rounded up to a power of two (database.rs:97) */
+    int32_t missed_cleavages;  /* EnzymeBuilder fields, database.rs:15-27 */
+    int32_t min_len, max_len;
+    const char* cleave_at;
+    const char* restrict_;
+    int32_t c_terminal;
+    int32_t semi_enzymatic;
+    int32_t enzyme_present;    /* 0 => the whole `enzyme` object is absent (database.rs:105) */
+    float peptide_min_mass, peptide_max_mass;
+    const uint8_t* ion_kinds;  /* SAGE_ION_* ; NULL/0 => [b, y] */
+    uint32_t n_ion_kinds;
+    uint64_t min_ion_index;
+    const char* const* static_mod_keys; /* "C", "^", "$K", "[", ... (modification.rs:66-104) */
+    const float* static_mod_masses;
+    uint32_t n_static_mods;
+    const char* const* var_mod_keys;    /* one entry per (key, mass) pair */
+    const float* var_mod_masses;
+    uint32_t n_var_mods;
+    uint64_t max_variable_mods;
+    const char* decoy_tag;
+    int32_t generate_decoys;
+} SageDbParams;
+
+/* Flat, read-only view of an IndexedDatabase (database.rs:384-395) + the Peptide fields the path
+ * reads (peptide.rs:12-31).  nterm/cterm: NaN == None. */
+typedef struct SageDbView {
+    const SageTheoretical* fragments; /* globally m/z sorted, then peptide-sorted inside each bucket */
+    uint64_t n_fragments;
+    const float* min_value;           /* [n_buckets] */
+    uint64_t n_buckets;
+    uint64_t bucket_size;
+    const float* pep_mono;            /* [n_peptides], ascending (total_cmp) */
+    const uint64_t* seq_off;          /* [n_peptides + 1] */
+    const uint8_t* seq;               /* residues, ASCII */
+    const float* mods;                /* per-residue modification mass, parallel to seq */
+    const float* nterm;
+    const float* cterm;
+    const uint8_t* decoy;
+    const uint8_t* missed_cleavages;
+    uint64_t n_peptides;
+    const uint8_t* ion_kinds;
+    uint32_t n_ion_kinds;
+} SageDbView;
+
+typedef struct SageHostDb SageHostDb;
+
+/* Parameters::build(Fasta::parse(text)) — database.rs:260-263, fasta.rs:16-56 */
+int sage_hip_hostdb_build(const char* fasta_text, const SageDbParams* params, SageHostDb** out);
+void sage_hip_hostdb_free(SageHostDb* db);
+int sage_hip_hostdb_view(const SageHostDb* db, SageDbView* out);
+/* Display string of peptide i ("[+42]-MEWK...", peptide.rs:391-408) and its ';'-joined proteins;
+ * return the required buffer size including NUL. */
+uint64_t sage_hip_hostdb_peptide_string(const SageHostDb* db, uint64_t i, char* out, uint64_t cap);
+uint64_t sage_hip_hostdb_peptide_proteins(const SageHostDb* db, uint64_t i, char* out, uint64_t cap);
+
+/* SpectrumProcessor::new(take_top_n, deisotope, min_deisotope_mz).process() for one centroided
+ * MS2 spectrum (spectrum.rs:279-412).  precursor_charge 0 == None.  out_* need capacity n.
+ * Returns the number of peaks kept. */
+uint64_t sage_hip_process_ms2(uint64_t take_top_n, int deisotope, float min_deisotope_mz, const float* mz,
+                              const float* intensity, uint64_t n, uint8_t precursor_charge, float* out_mass,
+                              float* out_intensity, float* out_tic);
+
+/* ------------------------------------------------------------------------------------------
+ * Device side.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct SageDeviceDb SageDeviceDb;
+typedef struct SageScorer SageScorer;
+typedef struct SageDeviceBatch SageDeviceBatch;
+
+int sage_hip_device_count(void);
+
+/* Upload an IndexedDatabase to HBM on `device` and derive the device layouts.
+ * Stands in for the `&'db IndexedDatabase` borrow of Scorer (scoring.rs:211). */
+int sage_hip_db_create(const SageDbView* view, int device, SageDeviceDb** out);
+void sage_hip_db_destroy(SageDeviceDb* db);
+uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db);
+
+/* scoring.rs:210-232  struct Scorer — every field, same meaning. */
+typedef struct SageScorerParams {
+    SageTolerance precursor_tol, fragment_tol;
+    uint16_t min_matched_peaks;
+    int8_t min_isotope_err, max_isotope_err;
+    uint8_t min_precursor_charge, max_precursor_charge;
+    uint8_t override_precursor_charge;
+    uint8_t chimera;
+    int16_t max_fragment_charge; /* Option<u8>: -1 == None */
+    uint8_t wide_window;
+    uint8_t annotate_matches;    /* not supported on device yet: must be 0 */
+    uint32_t report_psms;
+    int32_t score_type;          /* 0 SageHyperScore, 1 OpenMSHyperScore (scoring.rs:10-14) */
+} SageScorerParams;
+
+int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* params, SageScorer** out);
+void sage_hip_scorer_destroy(SageScorer* scorer);
+
+/* A batch of ProcessedSpectrum (spectrum.rs:57-79) + precursors[0] (spectrum.rs:46-55), SoA.
+ * All spectra must be MS2 (level == 2 is asserted by the reference at scoring.rs:301-304). */
+typedef struct SageSpectrumBatch {
+    uint32_t n_spectra;
+    const uint64_t* peak_off;          /* [n + 1] */
+    const float* masses;               /* ascending inside each spectrum */
+    const float* intensities;
+    const float* precursor_mz;         /* [n] precursors[0].mz */
+    const uint8_t* precursor_charge;   /* [n] 0 == None */
+    const float* isolation_lo;         /* [n] isolation_window = Tolerance::Da(lo, hi); NaN == None; may be NULL */
+    const float* isolation_hi;
+    const float* total_ion_current;    /* [n] */
+    const float* scan_start_time;      /* [n] may be NULL (0) */
+    const float* inverse_ion_mobility; /* [n] NaN == None; may be NULL */
+    const uint32_t* file_id;           /* [n] may be NULL (0) */
+} SageSpectrumBatch;
+
+/* scoring.rs:69-149  struct Feature — the fields the hot path computes (the rest are defaults the
+ * reference fills in later, scoring.rs:576-592).  psm_id (a global atomic, :163-167) is excluded. */
+typedef struct SageFeature {
+    uint32_t spec_index; /* position in the batch; stands in for spec_id */
+    uint32_t peptide_idx;
+    uint32_t rank;
+    int32_t label;
+    float expmass, calcmass, rt, ims, delta_mass, isotope_error, average_ppm;
+    float longest_y_pct, matched_intensity_pct, ms2_intensity;
+    double hyperscore, delta_next, delta_best, poisson;
+    uint32_t matched_peaks, longest_b, longest_y, scored_candidates;
+    uint32_t peptide_len, file_id;
+    uint8_t charge, missed_cleavages;
+    uint8_t pad[6];
+} SageFeature;
+
+/* Scorer::score for every spectrum of the batch (scoring.rs:300-309), results in input order:
+ * out[i*report_psms + r] for r < out_count[i].  Uploads, scores, downloads. */
+int sage_hip_score_batch(SageScorer* scorer, const SageSpectrumBatch* batch, SageFeature* out,
+                         uint32_t* out_count);
+
+/* The same split in two so a batch can stay resident in HBM across calls. */
+int sage_hip_batch_upload(SageScorer* scorer, const SageSpectrumBatch* batch, SageDeviceBatch** out);
+void sage_hip_batch_free(SageDeviceBatch* batch);
+int sage_hip_score_resident(SageScorer* scorer, SageDeviceBatch* batch, SageFeature* out, uint32_t* out_count);
+
+/* Scorer::initial_hits (scoring.rs:418-462) of every spectrum of a resident batch: the trimmed
+ * preliminary list in the reference's heap-layout order.  packed[i*cap + j] =
+ * matched<<48 | peptide<<16 | precursor_charge<<8 | (isotope_error+128); len[i] entries are valid. */
+int sage_hip_initial_hits(SageScorer* scorer, SageDeviceBatch* batch, uint64_t* packed, uint32_t cap,
+                          uint32_t* len, uint64_t* matched_peaks, uint64_t* scored_candidates);
+
+/* Timing of the last sage_hip_score_resident / sage_hip_score_batch call, from HIP events recorded
+ * on the scorer's own stream. */
+typedef struct SageTiming {
+    float prelim_ms;   /* fragment-match + k-select kernel(s) */
+    float rescore_ms;  /* rescoring + top-K + Feature kernel */
+    float total_ms;    /* first launch -> last kernel done (excludes H2D/D2H) */
+    uint32_t n_launches;
+    uint32_t n_wide;   /* spectra routed to the large-window path */
+} SageTiming;
+int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
+
+const char* sage_hip_last_error(void);
+int sage_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_HIP_H */

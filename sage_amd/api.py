@@ -1,0 +1,454 @@
+"""Host-side mirror of the sage-core API for the search-and-score path, over the C ABI.
+
+Names and argument meaning follow the reference (crates/sage/src):
+  DatabaseParameters  ~ database.rs:59-139   Builder / Parameters (JSON `database` section)
+  IndexedDatabase     ~ database.rs:384-395
+  SpectrumProcessor   ~ spectrum.rs:263-413
+  Scorer              ~ scoring.rs:210-309
+All compute happens in libsage_hip.so; nothing here falls back to Python arithmetic.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+@dataclass
+class Tolerance:  # mass.rs:10-16
+    kind: str  # "ppm" | "pct" | "da"
+    lo: float
+    hi: float
+
+    @staticmethod
+    def from_json(obj) -> "Tolerance":
+        (k, v), = obj.items()
+        return Tolerance(k, float(v[0]), float(v[1]))
+
+    def to_c(self):
+        return L.SageTolerance(L.TOL_KINDS[self.kind], self.lo, self.hi)
+
+
+@dataclass
+class DatabaseParameters:
+    """database.rs:59-93 Builder: None == field absent from the JSON."""
+    bucket_size: Optional[int] = None
+    enzyme: Optional[dict] = None  # keys: missed_cleavages,min_len,max_len,cleave_at,restrict,c_terminal,semi_enzymatic
+    peptide_min_mass: Optional[float] = None
+    peptide_max_mass: Optional[float] = None
+    ion_kinds: Optional[List[str]] = None
+    min_ion_index: Optional[int] = None
+    static_mods: Optional[Dict[str, float]] = None
+    variable_mods: Optional[Dict[str, List[float]]] = None
+    max_variable_mods: Optional[int] = None
+    decoy_tag: Optional[str] = None
+    generate_decoys: Optional[bool] = None
+    fasta: Optional[str] = None
+
+    @staticmethod
+    def from_json(obj: dict) -> "DatabaseParameters":
+        known = DatabaseParameters.__dataclass_fields__.keys()
+        return DatabaseParameters(**{k: v for k, v in obj.items() if k in known})  # unknown keys ignored (serde)
+
+    def to_c(self, struct_type=L.SageDbParams):
+        """Builder::make_parameters defaults (database.rs:96-115).  Returns (struct, keepalive)."""
+        keep = []
+        p = struct_type()
+        p.bucket_size = self.bucket_size if self.bucket_size is not None else 8192
+        e = self.enzyme
+        p.enzyme_present = 0 if e is None else 1
+        e = e or {}
+
+        def opt_int(key):
+            v = e.get(key)
+            return -1 if v is None else int(v)
+
+        def opt_str(key):
+            v = e.get(key)
+            if v is None:
+                return None
+            b = v.encode()
+            keep.append(b)
+            return b
+
+        p.missed_cleavages = opt_int("missed_cleavages")
+        p.min_len = opt_int("min_len")
+        p.max_len = opt_int("max_len")
+        p.cleave_at = opt_str("cleave_at")
+        p.restrict_ = opt_str("restrict")
+        p.c_terminal = opt_int("c_terminal")
+        p.semi_enzymatic = opt_int("semi_enzymatic")
+        p.peptide_min_mass = 500.0 if self.peptide_min_mass is None else self.peptide_min_mass
+        p.peptide_max_mass = 5000.0 if self.peptide_max_mass is None else self.peptide_max_mass
+        kinds = np.array([L.ION_KINDS[k] for k in (self.ion_kinds if self.ion_kinds is not None else ["b", "y"])],
+                         dtype=np.uint8)
+        keep.append(kinds)
+        p.ion_kinds = L.as_ptr(kinds, C.c_uint8)
+        p.n_ion_kinds = len(kinds)
+        p.min_ion_index = 2 if self.min_ion_index is None else self.min_ion_index
+        sm = list((self.static_mods or {}).items())
+        sk = (C.c_char_p * max(len(sm), 1))(*[k.encode() for k, _ in sm])
+        sv = np.array([v for _, v in sm], dtype=np.float32)
+        keep += [sk, sv]
+        p.static_mod_keys = sk
+        p.static_mod_masses = L.as_ptr(sv, C.c_float)
+        p.n_static_mods = len(sm)
+        vm = [(k, m) for k, ms in (self.variable_mods or {}).items()
+              for m in (ms if isinstance(ms, (list, tuple)) else [ms])]
+        vk = (C.c_char_p * max(len(vm), 1))(*[k.encode() for k, _ in vm])
+        vv = np.array([m for _, m in vm], dtype=np.float32)
+        keep += [vk, vv]
+        p.var_mod_keys = vk
+        p.var_mod_masses = L.as_ptr(vv, C.c_float)
+        p.n_var_mods = len(vm)
+        p.max_variable_mods = 2 if self.max_variable_mods is None else max(int(self.max_variable_mods), 1)
+        tag = (self.decoy_tag if self.decoy_tag is not None else "rev_").encode()
+        keep.append(tag)
+        p.decoy_tag = tag
+        p.generate_decoys = 1 if (self.generate_decoys is None or self.generate_decoys) else 0
+        return p, keep
+
+    def build(self, fasta_text: str) -> "IndexedDatabase":
+        """Parameters::build(Fasta::parse(..)) — database.rs:260-263."""
+        lib = L.load()
+        p, keep = self.to_c()
+        h = C.c_void_p()
+        L.check(lib.sage_hip_hostdb_build(fasta_text.encode(), C.byref(p), C.byref(h)))
+        return IndexedDatabase(h)
+
+
+def _view_array(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class IndexedDatabase:
+    """database.rs:384-395 — flat views over the host index built by libsage_hip."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib = L.load()
+        v = L.SageDbView()
+        L.check(lib.sage_hip_hostdb_view(self._h, C.byref(v)))
+        self._view = v
+        self.n_peptides = int(v.n_peptides)
+        self.n_fragments = int(v.n_fragments)
+        self.bucket_size = int(v.bucket_size)
+        self.fragments = _view_array(v.fragments, self.n_fragments, L.THEORETICAL_DTYPE)
+        self.min_value = _view_array(v.min_value, int(v.n_buckets), np.float32)
+        self.pep_mono = _view_array(v.pep_mono, self.n_peptides, np.float32)
+        self.seq_off = _view_array(v.seq_off, self.n_peptides + 1, np.uint64)
+        total = int(self.seq_off[-1]) if self.n_peptides else 0
+        self.seq = _view_array(v.seq, total, np.uint8)
+        self.mods = _view_array(v.mods, total, np.float32)
+        self.nterm = _view_array(v.nterm, self.n_peptides, np.float32)
+        self.cterm = _view_array(v.cterm, self.n_peptides, np.float32)
+        self.decoy = _view_array(v.decoy, self.n_peptides, np.uint8)
+        self.missed_cleavages = _view_array(v.missed_cleavages, self.n_peptides, np.uint8)
+        self.ion_kinds = _view_array(v.ion_kinds, int(v.n_ion_kinds), np.uint8)
+
+    def size(self):  # database.rs:427-429
+        return self.n_fragments
+
+    def buckets(self):  # database.rs:431-433
+        return self.min_value
+
+    def peptide_string(self, i: int) -> str:
+        lib = L.load()
+        n = lib.sage_hip_hostdb_peptide_string(self._h, i, None, 0)
+        buf = C.create_string_buffer(int(n))
+        lib.sage_hip_hostdb_peptide_string(self._h, i, buf, n)
+        return buf.value.decode()
+
+    def peptide_proteins(self, i: int) -> str:
+        lib = L.load()
+        n = lib.sage_hip_hostdb_peptide_proteins(self._h, i, None, 0)
+        buf = C.create_string_buffer(int(n))
+        lib.sage_hip_hostdb_peptide_proteins(self._h, i, buf, n)
+        return buf.value.decode()
+
+    def sequence(self, i: int) -> str:
+        return bytes(self.seq[int(self.seq_off[i]):int(self.seq_off[i + 1])]).decode()
+
+    def to_device(self, device: int = 0) -> "DeviceDatabase":
+        return DeviceDatabase(self, device)
+
+    def close(self):
+        if self._h:
+            L.load().sage_hip_hostdb_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceDatabase:
+    def __init__(self, host: IndexedDatabase, device: int = 0):
+        lib = L.load()
+        self.host = host
+        self.device = device
+        self._h = C.c_void_p()
+        L.check(lib.sage_hip_db_create(C.byref(host._view), device, C.byref(self._h)))
+        self.device_bytes = int(lib.sage_hip_db_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            L.load().sage_hip_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class RawSpectrum:  # spectrum.rs:81-106 (MS2, centroided)
+    mz: np.ndarray
+    intensity: np.ndarray
+    precursor_mz: float
+    precursor_charge: Optional[int] = None
+    isolation_window: Optional[Tuple[float, float]] = None  # Tolerance::Da(lo, hi)
+    scan_start_time: float = 0.0
+    inverse_ion_mobility: Optional[float] = None
+    file_id: int = 0
+    id: str = ""
+
+
+@dataclass
+class ProcessedSpectrum:  # spectrum.rs:57-79
+    masses: np.ndarray
+    intensities: np.ndarray
+    total_ion_current: float
+    precursor_mz: float
+    precursor_charge: Optional[int] = None
+    isolation_window: Optional[Tuple[float, float]] = None
+    scan_start_time: float = 0.0
+    inverse_ion_mobility: Optional[float] = None
+    file_id: int = 0
+    id: str = ""
+
+
+class SpectrumProcessor:  # spectrum.rs:263-413
+    def __init__(self, take_top_n: int, deisotope: bool, min_deisotope_mz: float = 0.0):
+        self.take_top_n = take_top_n
+        self.deisotope = deisotope
+        self.min_deisotope_mz = min_deisotope_mz
+
+    def process(self, raw: RawSpectrum) -> ProcessedSpectrum:
+        lib = L.load()
+        mz = np.ascontiguousarray(raw.mz, dtype=np.float32)
+        it = np.ascontiguousarray(raw.intensity, dtype=np.float32)
+        n = len(mz)
+        om = np.empty(max(n, 1), dtype=np.float32)
+        oi = np.empty(max(n, 1), dtype=np.float32)
+        tic = C.c_float()
+        k = lib.sage_hip_process_ms2(self.take_top_n, int(self.deisotope), self.min_deisotope_mz,
+                                     L.as_ptr(mz, C.c_float), L.as_ptr(it, C.c_float), n,
+                                     raw.precursor_charge or 0, L.as_ptr(om, C.c_float), L.as_ptr(oi, C.c_float),
+                                     C.byref(tic))
+        k = int(k)
+        return ProcessedSpectrum(om[:k].copy(), oi[:k].copy(), float(np.float32(tic.value)), raw.precursor_mz,
+                                 raw.precursor_charge, raw.isolation_window, raw.scan_start_time,
+                                 raw.inverse_ion_mobility, raw.file_id, raw.id)
+
+
+class SpectrumBatch:
+    """SoA batch of ProcessedSpectrum (SageSpectrumBatch)."""
+
+    def __init__(self, peak_off, masses, intensities, precursor_mz, precursor_charge, total_ion_current,
+                 isolation_lo=None, isolation_hi=None, scan_start_time=None, inverse_ion_mobility=None, file_id=None):
+        self.peak_off = np.ascontiguousarray(peak_off, dtype=np.uint64)
+        self.masses = np.ascontiguousarray(masses, dtype=np.float32)
+        self.intensities = np.ascontiguousarray(intensities, dtype=np.float32)
+        self.precursor_mz = np.ascontiguousarray(precursor_mz, dtype=np.float32)
+        self.precursor_charge = np.ascontiguousarray(precursor_charge, dtype=np.uint8)
+        self.total_ion_current = np.ascontiguousarray(total_ion_current, dtype=np.float32)
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        self.isolation_lo, self.isolation_hi = f32(isolation_lo), f32(isolation_hi)
+        self.scan_start_time, self.inverse_ion_mobility = f32(scan_start_time), f32(inverse_ion_mobility)
+        self.file_id = None if file_id is None else np.ascontiguousarray(file_id, dtype=np.uint32)
+        self.n = len(self.precursor_mz)
+        assert len(self.peak_off) == self.n + 1
+
+    @staticmethod
+    def from_spectra(spectra: Sequence[ProcessedSpectrum]) -> "SpectrumBatch":
+        n = len(spectra)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        for i, s in enumerate(spectra):
+            off[i + 1] = off[i] + len(s.masses)
+        cat = lambda xs: np.concatenate(xs).astype(np.float32) if n else np.zeros(0, np.float32)
+        nan = float("nan")
+        iso = [s.isolation_window for s in spectra]
+        return SpectrumBatch(
+            off, cat([s.masses for s in spectra]), cat([s.intensities for s in spectra]),
+            [s.precursor_mz for s in spectra], [s.precursor_charge or 0 for s in spectra],
+            [s.total_ion_current for s in spectra],
+            [w[0] if w else nan for w in iso], [w[1] if w else nan for w in iso],
+            [s.scan_start_time for s in spectra],
+            [nan if s.inverse_ion_mobility is None else s.inverse_ion_mobility for s in spectra],
+            [s.file_id for s in spectra])
+
+    def subset(self, idx) -> "SpectrumBatch":
+        idx = np.asarray(idx)
+        lens = (self.peak_off[1:] - self.peak_off[:-1])[idx].astype(np.int64)
+        off = np.zeros(len(idx) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        starts = self.peak_off[:-1][idx].astype(np.int64)
+        gather = (np.repeat(starts - off[:-1].astype(np.int64), lens) + np.arange(int(off[-1]))) if len(idx) else np.zeros(0, np.int64)
+        pick = lambda a: None if a is None else a[idx]
+        return SpectrumBatch(off, self.masses[gather], self.intensities[gather], self.precursor_mz[idx],
+                             self.precursor_charge[idx], self.total_ion_current[idx], pick(self.isolation_lo),
+                             pick(self.isolation_hi), pick(self.scan_start_time), pick(self.inverse_ion_mobility),
+                             pick(self.file_id))
+
+    def to_c(self, struct_type=L.SageSpectrumBatch):
+        b = struct_type()
+        b.n_spectra = self.n
+        p = lambda a, t: None if a is None else L.as_ptr(a, t)
+        b.peak_off = p(self.peak_off, C.c_uint64)
+        b.masses = p(self.masses, C.c_float)
+        b.intensities = p(self.intensities, C.c_float)
+        b.precursor_mz = p(self.precursor_mz, C.c_float)
+        b.precursor_charge = p(self.precursor_charge, C.c_uint8)
+        b.isolation_lo = p(self.isolation_lo, C.c_float)
+        b.isolation_hi = p(self.isolation_hi, C.c_float)
+        b.total_ion_current = p(self.total_ion_current, C.c_float)
+        b.scan_start_time = p(self.scan_start_time, C.c_float)
+        b.inverse_ion_mobility = p(self.inverse_ion_mobility, C.c_float)
+        b.file_id = p(self.file_id, C.c_uint32)
+        return b
+
+
+@dataclass
+class ScorerParams:
+    """scoring.rs:210-232 Scorer fields (minus db); defaults = sage-cli input.rs:355-385."""
+    precursor_tol: Tolerance = field(default_factory=lambda: Tolerance("ppm", -10.0, 10.0))
+    fragment_tol: Tolerance = field(default_factory=lambda: Tolerance("ppm", -10.0, 10.0))
+    min_matched_peaks: int = 4
+    min_isotope_err: int = 0
+    max_isotope_err: int = 0
+    min_precursor_charge: int = 2
+    max_precursor_charge: int = 4
+    override_precursor_charge: bool = False
+    max_fragment_charge: Optional[int] = None
+    chimera: bool = False
+    report_psms: int = 1
+    wide_window: bool = False
+    annotate_matches: bool = False
+    score_type: str = "SageHyperScore"
+
+    def to_c(self, struct_type=L.SageScorerParams):
+        p = struct_type()
+        p.precursor_tol = self.precursor_tol.to_c()
+        p.fragment_tol = self.fragment_tol.to_c()
+        p.min_matched_peaks = self.min_matched_peaks
+        p.min_isotope_err = self.min_isotope_err
+        p.max_isotope_err = self.max_isotope_err
+        p.min_precursor_charge = self.min_precursor_charge
+        p.max_precursor_charge = self.max_precursor_charge
+        p.override_precursor_charge = int(self.override_precursor_charge)
+        p.chimera = int(self.chimera)
+        p.max_fragment_charge = -1 if self.max_fragment_charge is None else self.max_fragment_charge
+        p.wide_window = int(self.wide_window)
+        p.annotate_matches = int(self.annotate_matches)
+        p.report_psms = self.report_psms
+        p.score_type = L.SCORE_TYPES[self.score_type]
+        return p
+
+
+class DeviceBatch:
+    def __init__(self, scorer: "Scorer", batch: SpectrumBatch):
+        lib = L.load()
+        self.n = batch.n
+        self._keep = batch
+        self._h = C.c_void_p()
+        cb = batch.to_c()
+        L.check(lib.sage_hip_batch_upload(scorer._h, C.byref(cb), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            L.load().sage_hip_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scorer:
+    """scoring.rs:210-309.  `score` takes a whole batch: a per-spectrum call cannot amortise a launch."""
+
+    def __init__(self, db: DeviceDatabase, params: ScorerParams):
+        lib = L.load()
+        self.db = db
+        self.params = params
+        self._h = C.c_void_p()
+        cp = params.to_c()
+        L.check(lib.sage_hip_scorer_create(db._h, C.byref(cp), C.byref(self._h)))
+
+    def upload(self, batch: SpectrumBatch) -> DeviceBatch:
+        return DeviceBatch(self, batch)
+
+    def _alloc_out(self, n):
+        feats = np.zeros(n * self.params.report_psms, dtype=L.FEATURE_DTYPE)
+        counts = np.zeros(n, dtype=np.uint32)
+        return feats, counts
+
+    def score_resident(self, dbatch: DeviceBatch):
+        lib = L.load()
+        feats, counts = self._alloc_out(dbatch.n)
+        L.check(lib.sage_hip_score_resident(self._h, dbatch._h, feats.ctypes.data_as(C.c_void_p),
+                                            L.as_ptr(counts, C.c_uint32)))
+        return feats.reshape(dbatch.n, self.params.report_psms), counts
+
+    def score(self, batch: SpectrumBatch):
+        """Vec<Feature> per spectrum: returns (features[n, report_psms], counts[n])."""
+        lib = L.load()
+        feats, counts = self._alloc_out(batch.n)
+        cb = batch.to_c()
+        L.check(lib.sage_hip_score_batch(self._h, C.byref(cb), feats.ctypes.data_as(C.c_void_p),
+                                         L.as_ptr(counts, C.c_uint32)))
+        return feats.reshape(batch.n, self.params.report_psms), counts
+
+    def initial_hits(self, dbatch: DeviceBatch):
+        lib = L.load()
+        cap = max(50, 2 * self.params.report_psms)
+        packed = np.zeros((dbatch.n, cap), dtype=np.uint64)
+        ln = np.zeros(dbatch.n, dtype=np.uint32)
+        mp = np.zeros(dbatch.n, dtype=np.uint64)
+        sc = np.zeros(dbatch.n, dtype=np.uint64)
+        L.check(lib.sage_hip_initial_hits(self._h, dbatch._h, L.as_ptr(packed, C.c_uint64), cap,
+                                          L.as_ptr(ln, C.c_uint32), L.as_ptr(mp, C.c_uint64),
+                                          L.as_ptr(sc, C.c_uint64)))
+        return packed, ln, mp, sc
+
+    def last_timing(self) -> dict:
+        t = L.SageTiming()
+        L.check(L.load().sage_hip_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.SageTiming._fields_}
+
+    def close(self):
+        if self._h:
+            L.load().sage_hip_scorer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count() -> int:
+    return int(L.load().sage_hip_device_count())

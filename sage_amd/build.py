@@ -1,0 +1,60 @@
+"""Build libsage_hip.so (HIP kernels + C ABI + host index builder) for gfx950, in-tree.
+
+    python -m sage_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off on EVERY translation unit: the reference's f32
+arithmetic (Tolerance::bounds, ion masses, ppm sums) decides matches, and hipcc/clang would otherwise
+contract a*b+c into an FMA.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsage_hip.so")
+SOURCES = ["kernels.hip", "capi.hip", "host_db.cpp"]
+HEADERS = ["core.h", "device_types.h", "host_db.hpp", os.path.join("..", "..", "include", "sage_hip.h")]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc(), f"--offload-arch={ARCH}", *common, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built", LIB)

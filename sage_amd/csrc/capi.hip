@@ -1,0 +1,485 @@
+// capi.hip — the C ABI declared in include/sage_hip.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "host_db.hpp"
+
+using namespace sagehip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP,           \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const T* src, size_t count) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess) return e;
+        return count ? hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct SageHostDb {
+    HostDb db;
+};
+
+struct SageDeviceDb {
+    int device = 0;
+    DevBuf<float> pep_mono;
+    DevBuf<SageTheoretical> pm_frag;
+    DevBuf<uint64_t> pm_off;
+    DevBuf<float> ions;
+    DevBuf<uint64_t> ion_off;
+    DevBuf<uint32_t> pep_info;
+    // the reference-shaped bucketed index, resident for the large-window path
+    DevBuf<SageTheoretical> fragments;
+    DevBuf<float> min_value;
+    uint64_t bucket_size = 0;
+    uint32_t max_ions = 0;
+    DevDbView view{};
+    uint64_t bytes = 0;
+};
+
+struct SageScorer {
+    SageDeviceDb* db = nullptr;
+    SageScorerParams params{};
+    DevScorer dev{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {};
+    DevBuf<double> lnfact;
+    DevBuf<uint32_t> wide_cnt;
+    uint32_t wide_blocks = 0;
+    SageTiming timing{};
+    // per-batch work buffers, grown on demand
+    DevBuf<uint64_t> cand;
+    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count;
+    DevBuf<SageFeature> features;
+    uint32_t work_n = 0;
+};
+
+struct SageDeviceBatch {
+    int device = 0;
+    uint32_t n = 0;
+    DevBuf<uint64_t> peak_off;
+    DevBuf<float> masses, intensities, precursor_mz, iso_lo, iso_hi, tic, rt, ims;
+    DevBuf<uint8_t> charge;
+    DevBuf<uint32_t> file_id;
+    DevBatchView view{};
+};
+
+extern "C" {
+
+const char* sage_hip_last_error(void) { return g_last_error.c_str(); }
+int sage_hip_abi_version(void) { return SAGE_HIP_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int sage_hip_hostdb_build(const char* fasta_text, const SageDbParams* params, SageHostDb** out) {
+    if (!fasta_text || !params || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    try {
+        auto h = std::make_unique<SageHostDb>();
+        h->db = build_database(fasta_text, config_from_params(*params));
+        *out = h.release();
+        return SAGE_HIP_OK;
+    } catch (const std::exception& e) {
+        return fail(SAGE_HIP_ERR_INVALID, e.what());
+    }
+}
+void sage_hip_hostdb_free(SageHostDb* db) { delete db; }
+int sage_hip_hostdb_view(const SageHostDb* db, SageDbView* out) {
+    if (!db || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    *out = db->db.view();
+    return SAGE_HIP_OK;
+}
+static uint64_t copy_out(const std::string& s, char* out, uint64_t cap) {
+    if (out && cap >= s.size() + 1) std::memcpy(out, s.c_str(), s.size() + 1);
+    return s.size() + 1;
+}
+uint64_t sage_hip_hostdb_peptide_string(const SageHostDb* db, uint64_t i, char* out, uint64_t cap) {
+    if (!db || i >= db->db.n_peptides()) return 0;
+    return copy_out(db->db.peptide_string(i), out, cap);
+}
+uint64_t sage_hip_hostdb_peptide_proteins(const SageHostDb* db, uint64_t i, char* out, uint64_t cap) {
+    if (!db || i >= db->db.n_peptides()) return 0;
+    return copy_out(db->db.peptide_proteins(i), out, cap);
+}
+uint64_t sage_hip_process_ms2(uint64_t take_top_n, int deisotope, float min_deisotope_mz, const float* mz,
+                              const float* intensity, uint64_t n, uint8_t precursor_charge, float* out_mass,
+                              float* out_intensity, float* out_tic) {
+    return process_ms2(take_top_n, deisotope != 0, min_deisotope_mz, mz, intensity, n, precursor_charge, out_mass,
+                       out_intensity, out_tic);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+int sage_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
+    if (!v || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (v->n_peptides >= 0xFFFFFFFFull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-2 peptides");
+    if (v->n_ion_kinds > 8) return fail(SAGE_HIP_ERR_INVALID, "more than 8 ion kinds");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SAGE_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SAGE_HIP_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    auto d = std::make_unique<SageDeviceDb>();
+    d->device = device;
+    const uint64_t np = v->n_peptides, nf = v->n_fragments;
+    const uint32_t nk = v->n_ion_kinds;
+
+    // peptide-major regrouping of IndexedDatabase.fragments (counting sort by peptide_index; inside
+    // a peptide the bucket order — ascending m/z — is kept)
+    std::vector<uint64_t> pm_off(np + 1, 0);
+    for (uint64_t i = 0; i < nf; i++) {
+        if (v->fragments[i].peptide_index >= np) return fail(SAGE_HIP_ERR_INVALID, "fragment peptide_index out of range");
+        pm_off[v->fragments[i].peptide_index + 1]++;
+    }
+    for (uint64_t i = 0; i < np; i++) pm_off[i + 1] += pm_off[i];
+    std::vector<SageTheoretical> pm(nf);
+    {
+        std::vector<uint64_t> cur(pm_off.begin(), pm_off.end() - 1);
+        for (uint64_t i = 0; i < nf; i++) pm[cur[v->fragments[i].peptide_index]++] = v->fragments[i];
+    }
+    // complete ion table for rescoring (IonSeries for every configured kind, ion_series.rs:36-85)
+    std::vector<uint64_t> ion_off(np + 1, 0);
+    std::vector<uint32_t> info(np);
+    uint32_t max_ions = 0;
+    for (uint64_t i = 0; i < np; i++) {
+        const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
+        if (len > 0xFFFF) return fail(SAGE_HIP_ERR_UNSUPPORTED, "peptide longer than 65535 residues");
+        const uint64_t cnt = (len ? len - 1 : 0) * nk;
+        ion_off[i + 1] = ion_off[i] + cnt;
+        max_ions = std::max<uint32_t>(max_ions, (uint32_t)cnt);
+        info[i] = (uint32_t)len | ((uint32_t)(v->decoy[i] ? 1 : 0) << 16) | ((uint32_t)v->missed_cleavages[i] << 24);
+    }
+    std::vector<float> ions(ion_off[np]);
+    parallel_for(np, 4096, [&](size_t ib, size_t ie, unsigned) {
+        for (size_t i = ib; i < ie; i++) {
+            const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
+            const uint64_t lm1 = len ? len - 1 : 0;
+            for (uint32_t k = 0; k < nk; k++)
+                ion_series_flat(v->seq + v->seq_off[i], v->mods + v->seq_off[i], len, v->nterm[i], v->pep_mono[i],
+                                v->ion_kinds[k], ions.data() + ion_off[i] + (uint64_t)k * lm1);
+        }
+    });
+    HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
+    HIP_TRY(d->pm_frag.upload(pm.data(), nf));
+    HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
+    HIP_TRY(d->ions.upload(ions.data(), ions.size()));
+    HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
+    HIP_TRY(d->pep_info.upload(info.data(), np));
+    HIP_TRY(d->fragments.upload(v->fragments, nf));
+    HIP_TRY(d->min_value.upload(v->min_value, v->n_buckets));
+    d->bucket_size = v->bucket_size;
+    d->max_ions = max_ions;
+    d->view.pep_mono = d->pep_mono.p;
+    d->view.np = (uint32_t)np;
+    d->view.pm_frag = d->pm_frag.p;
+    d->view.pm_off = d->pm_off.p;
+    d->view.ions = d->ions.p;
+    d->view.ion_off = d->ion_off.p;
+    d->view.pep_info = d->pep_info.p;
+    std::memset(d->view.ion_kinds, 0, sizeof d->view.ion_kinds);
+    for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
+    d->view.n_kinds = nk;
+    d->bytes = d->pep_mono.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
+               d->pep_info.bytes() + d->fragments.bytes() + d->min_value.bytes();
+    *out = d.release();
+    return SAGE_HIP_OK;
+}
+
+void sage_hip_db_destroy(SageDeviceDb* db) {
+    if (!db) return;
+    (void)hipSetDevice(db->device);
+    delete db;
+}
+uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db) { return db ? db->bytes : 0; }
+
+int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
+    if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (p->annotate_matches) return fail(SAGE_HIP_ERR_UNSUPPORTED, "annotate_matches is not available on device yet");
+    if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
+    if (p->report_psms > 32) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32 (k-select wider than one wavefront)");
+    if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
+    if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
+        return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
+    if (p->score_type != 0 && p->score_type != 1) return fail(SAGE_HIP_ERR_INVALID, "unknown score_type");
+    HIP_TRY(hipSetDevice(db->device));
+    auto s = std::make_unique<SageScorer>();
+    s->db = db;
+    s->params = *p;
+    DevScorer& d = s->dev;
+    d.precursor_tol = {p->precursor_tol.kind, p->precursor_tol.lo, p->precursor_tol.hi};
+    d.fragment_tol = {p->fragment_tol.kind, p->fragment_tol.lo, p->fragment_tol.hi};
+    d.min_matched_peaks = p->min_matched_peaks;
+    d.min_isotope_err = p->min_isotope_err;
+    d.max_isotope_err = p->max_isotope_err;
+    d.min_precursor_charge = p->min_precursor_charge;
+    d.max_precursor_charge = p->max_precursor_charge;
+    d.override_precursor_charge = p->override_precursor_charge;
+    d.max_fragment_charge = p->max_fragment_charge;
+    d.chimera = p->chimera;
+    d.report_psms = p->report_psms;
+    d.wide_window = p->wide_window;
+    d.score_type = p->score_type;
+    d.kmax = std::max<uint32_t>(50, 2 * p->report_psms);
+    const uint32_t n_iso = (uint32_t)(p->max_isotope_err - p->min_isotope_err) + 1;
+    const uint32_t n_z = (uint32_t)(p->max_precursor_charge - p->min_precursor_charge) + 1;
+    d.list_cap = d.kmax * (std::max(n_iso, n_z) + 1);
+    d.wcap = 4096;
+    if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::max(64, atoi(e));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    // lnfact (scoring.rs:170-177) tabulated with the host libm so the factorial terms are bit-identical
+    // to a CPU evaluation
+    std::vector<double> tbl(4096);
+    tbl[0] = 1.0;
+    for (uint32_t n = 1; n < tbl.size(); n++) {
+        const double x = (double)n;
+        tbl[n] = x * std::log(x) - x + 0.5 * std::log(x) + 0.5 * std::log(M_PI * 2.0 * x);
+    }
+    HIP_TRY(s->lnfact.upload(tbl.data(), tbl.size()));
+    s->wide_blocks = 64;
+    if (const char* e = getenv("SAGE_HIP_WIDE_BLOCKS")) s->wide_blocks = (uint32_t)std::max(1, atoi(e));
+    HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * ((size_t)db->view.np + 1)));
+    HIP_TRY(s->n_deferred.alloc(1));
+    *out = s.release();
+    return SAGE_HIP_OK;
+}
+
+void sage_hip_scorer_destroy(SageScorer* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->db->device);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceBatch** out) {
+    if (!s || !b || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (b->n_spectra && (!b->peak_off || !b->precursor_mz || !b->precursor_charge || !b->total_ion_current))
+        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
+    HIP_TRY(hipSetDevice(s->db->device));
+    auto d = std::make_unique<SageDeviceBatch>();
+    d->device = s->db->device;
+    const uint32_t n = b->n_spectra;
+    d->n = n;
+    const uint64_t total = n ? b->peak_off[n] : 0;
+    uint32_t pcap = 1, zmax = 0;
+    bool any_unknown = false;
+    for (uint32_t i = 0; i < n; i++) {
+        if (b->peak_off[i + 1] < b->peak_off[i]) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
+        pcap = std::max<uint32_t>(pcap, (uint32_t)(b->peak_off[i + 1] - b->peak_off[i]));
+        zmax = std::max<uint32_t>(zmax, b->precursor_charge[i]);
+        any_unknown = any_unknown || b->precursor_charge[i] == 0;
+    }
+    if (total && (!b->masses || !b->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
+    // largest fragment charge any spectrum of this batch can ask for (scoring.rs:239-247)
+    uint32_t fzcap = 1;
+    const SageScorerParams& p = s->params;
+    const bool ranged = p.wide_window || p.override_precursor_charge || any_unknown;
+    for (uint32_t z = 1; z <= 255; z++) {
+        const bool used = (ranged && z >= p.min_precursor_charge && z <= p.max_precursor_charge) ||
+                          (!p.wide_window && !p.override_precursor_charge && z <= zmax);
+        if (used) fzcap = std::max(fzcap, sagecore::max_fragment_charge(p.max_fragment_charge, z) - 1);
+    }
+    HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));
+    HIP_TRY(d->masses.upload(b->masses, total));
+    HIP_TRY(d->intensities.upload(b->intensities, total));
+    HIP_TRY(d->precursor_mz.upload(b->precursor_mz, n));
+    HIP_TRY(d->charge.upload(b->precursor_charge, n));
+    HIP_TRY(d->tic.upload(b->total_ion_current, n));
+    if (b->isolation_lo && b->isolation_hi) {
+        HIP_TRY(d->iso_lo.upload(b->isolation_lo, n));
+        HIP_TRY(d->iso_hi.upload(b->isolation_hi, n));
+    }
+    if (b->scan_start_time) HIP_TRY(d->rt.upload(b->scan_start_time, n));
+    if (b->inverse_ion_mobility) HIP_TRY(d->ims.upload(b->inverse_ion_mobility, n));
+    if (b->file_id) HIP_TRY(d->file_id.upload(b->file_id, n));
+    DevBatchView& v = d->view;
+    v.n = n;
+    v.peak_off = d->peak_off.p;
+    v.masses = d->masses.p;
+    v.intensities = d->intensities.p;
+    v.precursor_mz = d->precursor_mz.p;
+    v.precursor_charge = d->charge.p;
+    v.isolation_lo = d->iso_lo.p;
+    v.isolation_hi = d->iso_hi.p;
+    v.tic = d->tic.p;
+    v.rt = d->rt.p;
+    v.ims = d->ims.p;
+    v.file_id = d->file_id.p;
+    v.pcap = pcap;
+    v.fzcap = fzcap;
+    *out = d.release();
+    return SAGE_HIP_OK;
+}
+
+void sage_hip_batch_free(SageDeviceBatch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    delete b;
+}
+
+static int ensure_work(SageScorer* s, uint32_t n) {
+    if (n <= s->work_n) return SAGE_HIP_OK;
+    HIP_TRY(s->cand.alloc((size_t)n * s->dev.kmax));
+    HIP_TRY(s->cand_len.alloc(n));
+    HIP_TRY(s->totals.alloc((size_t)n * 2));
+    HIP_TRY(s->status.alloc(n));
+    HIP_TRY(s->out_count.alloc(n));
+    HIP_TRY(s->features.alloc((size_t)n * s->params.report_psms));
+    s->work_n = n;
+    return SAGE_HIP_OK;
+}
+
+static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
+    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    HIP_TRY(hipSetDevice(s->db->device));
+    int rc = ensure_work(s, b->n);
+    if (rc != SAGE_HIP_OK) return rc;
+    const size_t lds_p = prelim_lds_bytes(s->dev, b->view, false), lds_r = rescore_lds_bytes(s->dev, b->view, s->db->max_ions);
+    if (lds_p > 64 * 1024 || lds_r > 64 * 1024)
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
+    DevWork w;
+    w.cand = s->cand.p;
+    w.cand_len = s->cand_len.p;
+    w.totals = s->totals.p;
+    w.status = s->status.p;
+    w.n_deferred = s->n_deferred.p;
+    w.wide_cnt = s->wide_cnt.p;
+    w.wide_blocks = s->wide_blocks;
+    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 4, s->stream));
+    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+    launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
+    launch_prelim_wide(s->db->view, s->dev, b->view, w, s->stream);
+    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    if (with_rescore)
+        launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
+                       s->features.p, s->out_count.p, s->stream);
+    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
+    HIP_TRY(hipGetLastError());
+    return SAGE_HIP_OK;
+}
+
+static int finish_timing(SageScorer* s, bool with_rescore) {
+    HIP_TRY(hipEventSynchronize(s->ev[2]));
+    float a = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&c, s->ev[1], s->ev[2]));
+    uint32_t ndef = 0;
+    HIP_TRY(hipMemcpy(&ndef, s->n_deferred.p, 4, hipMemcpyDeviceToHost));
+    s->timing.prelim_ms = a;
+    s->timing.rescore_ms = with_rescore ? c : 0.f;
+    s->timing.total_ms = a + c;
+    s->timing.n_launches = with_rescore ? 3 : 2;
+    s->timing.n_wide = ndef;
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
+    if (!s || !b || !out || !out_count) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    int rc = run_kernels(s, b, true);
+    if (rc != SAGE_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
+                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = finish_timing(s, true);
+    if (rc != SAGE_HIP_OK) return rc;
+    std::vector<uint32_t> st(b->n);
+    HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < b->n; i++)
+        if (st[i] != ST_OK)
+            return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": preliminary pass status " +
+                                                      std::to_string(st[i]) + " (candidate list capacity)");
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* batch, SageFeature* out, uint32_t* out_count) {
+    SageDeviceBatch* d = nullptr;
+    int rc = sage_hip_batch_upload(s, batch, &d);
+    if (rc != SAGE_HIP_OK) return rc;
+    rc = sage_hip_score_resident(s, d, out, out_count);
+    sage_hip_batch_free(d);
+    return rc;
+}
+
+int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, uint32_t cap, uint32_t* len,
+                          uint64_t* matched_peaks, uint64_t* scored_candidates) {
+    if (!s || !b || !packed || !len) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (cap < s->dev.kmax) return fail(SAGE_HIP_ERR_INVALID, "cap must be >= max(50, 2*report_psms)");
+    int rc = run_kernels(s, b, false);
+    if (rc != SAGE_HIP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = finish_timing(s, false);
+    if (rc != SAGE_HIP_OK) return rc;
+    const uint32_t n = b->n, kmax = s->dev.kmax;
+    std::vector<uint64_t> c((size_t)n * kmax);
+    std::vector<uint32_t> tot((size_t)n * 2), st(n);
+    HIP_TRY(hipMemcpy(c.data(), s->cand.p, c.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(len, s->cand_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tot.data(), s->totals.p, tot.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        if (st[i] != ST_OK) return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": status " + std::to_string(st[i]));
+        for (uint32_t j = 0; j < len[i]; j++) packed[(size_t)i * cap + j] = c[(size_t)i * kmax + j];
+        if (matched_peaks) matched_peaks[i] = tot[2 * i];
+        if (scored_candidates) scored_candidates[i] = tot[2 * i + 1];
+    }
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_last_timing(const SageScorer* s, SageTiming* out) {
+    if (!s || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    *out = s->timing;
+    return SAGE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// core.h — arithmetic shared by the HIP kernels (device) and the host-side unit tests.
+//
+// Everything here is a pure function over plain pointers so that the same source compiles for
+// gfx950 (as __device__ code inside kernels.hip) and for the host (tests/hostemu), which lets the
+// order-sensitive f32 arithmetic, the k-select emulation and the rescoring loop be checked against
+// the oracle without a GPU.  All f32 expressions keep the reference's operation order; translation
+// units including this file MUST be compiled with -ffp-contract=off (no FMA contraction).
+//
+// Reference citations: /root/reference/crates/sage/src/<file>:<line>.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SAGE_HD __host__ __device__ __forceinline__
+#else
+#define SAGE_HD inline
+#endif
+
+namespace sagecore {
+
+constexpr float PROTON = 1.0072764f;  // mass.rs:6
+constexpr float NEUTRON = 1.00335f;   // mass.rs:7
+
+struct Tol {  // mass.rs:10-16
+    int kind; // 0 ppm, 1 pct, 2 da
+    float lo, hi;
+};
+
+// Tolerance::bounds, mass.rs:21-35 — (center*lo)/1e6 then center + delta, in f32
+SAGE_HD void tol_bounds(const Tol& t, float center, float& out_lo, float& out_hi) {
+    if (t.kind == 0) {
+        float dlo = center * t.lo / 1000000.0f;
+        float dhi = center * t.hi / 1000000.0f;
+        out_lo = center + dlo;
+        out_hi = center + dhi;
+    } else if (t.kind == 1) {
+        float dlo = center * t.lo / 100.0f;
+        float dhi = center * t.hi / 100.0f;
+        out_lo = center + dlo;
+        out_hi = center + dhi;
+    } else {
+        out_lo = center + t.lo;
+        out_hi = center + t.hi;
+    }
+}
+
+SAGE_HD Tol tol_scaled(const Tol& t, float rhs) {  // impl Mul<f32>, mass.rs:47-57
+    Tol r;
+    r.kind = t.kind;
+    r.lo = t.lo * rhs;
+    r.hi = t.hi * rhs;
+    return r;
+}
+
+// f32::total_cmp as an integer key: total_cmp(a,b) == compare(order_key(a), order_key(b))
+SAGE_HD int32_t order_key(float f) {
+    union { float f; int32_t i; } u;
+    u.f = f;
+    return u.i ^ (int32_t)(((uint32_t)(u.i >> 31)) >> 1);
+}
+SAGE_HD int64_t order_key64(double d) {
+    union { double d; int64_t i; } u;
+    u.d = d;
+    return u.i ^ (int64_t)(((uint64_t)(u.i >> 63)) >> 1);
+}
+
+// scoring.rs:239-247 — exclusive upper bound of the fragment charge loop; user < 0 == None
+SAGE_HD uint32_t max_fragment_charge(int user, uint32_t precursor_charge) {
+    uint32_t inner = user >= 0 ? (uint32_t)((user + 1) & 0xFF) : precursor_charge;
+    uint32_t m = precursor_charge < inner ? precursor_charge : inner;
+    return m < 2 ? 2 : m;
+}
+
+// ---- PreScore (scoring.rs:43-49) packed so that u64 compare == derived lexicographic Ord ------
+constexpr uint64_t PRESCORE_EMPTY = 0x0000FFFFFFFF0080ull;  // (0, u32::MAX, 0, 0)
+SAGE_HD uint64_t pack_prescore(uint32_t matched, uint32_t peptide, uint32_t charge, int iso) {
+    return ((uint64_t)(matched & 0xFFFF) << 48) | ((uint64_t)peptide << 16) | ((uint64_t)(charge & 0xFF) << 8) |
+           (uint64_t)((iso + 128) & 0xFF);
+}
+SAGE_HD uint32_t prescore_matched(uint64_t p) { return (uint32_t)(p >> 48); }
+SAGE_HD uint32_t prescore_peptide(uint64_t p) { return (uint32_t)((p >> 16) & 0xFFFFFFFFu); }
+SAGE_HD uint32_t prescore_charge(uint64_t p) { return (uint32_t)((p >> 8) & 0xFF); }
+SAGE_HD int prescore_iso(uint64_t p) { return (int)(p & 0xFF) - 128; }
+
+// trim_hits' k (scoring.rs:323-326): 50.clamp(min(2*report_psms, len), len)
+SAGE_HD uint32_t trim_k(uint64_t len, uint32_t report_psms) {
+    uint64_t lo = (uint64_t)report_psms * 2 < len ? (uint64_t)report_psms * 2 : len;
+    uint64_t k = 50 > lo ? 50 : lo;
+    return (uint32_t)(k < len ? k : len);
+}
+
+// heap.rs:40-60
+SAGE_HD void sift_down(uint64_t* h, uint32_t len, uint32_t index) {
+    for (;;) {
+        uint32_t l = index * 2 + 1;
+        if (l >= len) break;
+        uint32_t smallest = index;
+        if (h[l] < h[smallest]) smallest = l;
+        uint32_t r = l + 1;
+        if (r < len && h[r] < h[smallest]) smallest = r;
+        if (smallest == index) break;
+        uint64_t t = h[smallest];
+        h[smallest] = h[index];
+        h[index] = t;
+        index = smallest;
+    }
+}
+// first loop of bounded_min_heapify (heap.rs:13-15)
+SAGE_HD void heap_build(uint64_t* h, uint32_t k) {
+    for (uint32_t i = k / 2; i-- > 0;) sift_down(h, k, i);
+}
+// one step of the scan loop (heap.rs:21-27)
+SAGE_HD void heap_offer(uint64_t* h, uint32_t k, uint64_t v) {
+    if (k && v > h[0]) {
+        h[0] = v;  // slice.swap(i, 0): the displaced minimum lands beyond k and is truncated away
+        sift_down(h, k, 0);
+    }
+}
+
+// ---- CList: a compact stand-in for InitialHits.preliminary (scoring.rs:57) -------------------
+// The reference materialises every candidate slot of every precursor-window query, most of them
+// PreScore::default().  Only two things about that vector are observable downstream: its first
+// trim_k() entries verbatim (they seed the heap) and the order of the later non-empty entries
+// (empties can never displace a heap minimum, and are filtered at scoring.rs:489).  A CList keeps
+// exactly that: the first `kmax` logical entries verbatim, then non-empty entries only, plus the
+// logical length.  kmax = max(50, 2*report_psms) bounds every trim_k().
+struct CList {
+    uint64_t* items;
+    uint32_t stored;
+    uint32_t cap;
+    uint64_t len;  // logical Vec length
+};
+SAGE_HD void clist_clear(CList& c) { c.stored = 0; c.len = 0; }
+SAGE_HD bool clist_push(CList& c, uint64_t v, uint32_t kmax) {
+    if (c.len < kmax || v != PRESCORE_EMPTY) {
+        if (c.stored >= c.cap) return false;
+        c.items[c.stored++] = v;
+    }
+    c.len++;
+    return true;
+}
+SAGE_HD bool clist_push_empties(CList& c, uint64_t n, uint32_t kmax) {
+    while (n && c.len < kmax) {
+        if (c.stored >= c.cap) return false;
+        c.items[c.stored++] = PRESCORE_EMPTY;
+        c.len++;
+        n--;
+    }
+    c.len += n;
+    return true;
+}
+// trim_hits (scoring.rs:322-329) on a CList
+SAGE_HD void clist_trim(CList& c, uint32_t report_psms) {
+    uint32_t k = trim_k(c.len, report_psms);
+    if (c.len > k) {  // bounded_min_heapify(slice, k), heap.rs:7-28
+        heap_build(c.items, k);
+        for (uint32_t i = k; i < c.stored; i++) heap_offer(c.items, k, c.items[i]);
+    }
+    c.stored = k;  // truncate(k)
+    c.len = k;
+}
+
+// ---- fragment matching -------------------------------------------------------------------------
+// number of entries of sorted[0..n) that are <= v  (partition_point(|x| x <= v))
+SAGE_HD uint32_t count_le(const float* sorted, uint32_t n, float v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sorted[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// number of entries < v
+SAGE_HD uint32_t count_lt(const float* sorted, uint32_t n, float v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// How many experimental peaks i have frag in [win_lo[i], win_hi[i]]?  (the predicate at
+// database.rs:532-533 with the window built at database.rs:481 from scoring.rs:360.)  Requires both
+// arrays ascending and win_lo[i] <= win_hi[i]; the caller checks that and otherwise uses the scan.
+SAGE_HD uint32_t count_windows_sorted(const float* win_lo, const float* win_hi, uint32_t n, float frag) {
+    return count_le(win_lo, n, frag) - count_lt(win_hi, n, frag);
+}
+SAGE_HD uint32_t count_windows_scan(const float* win_lo, const float* win_hi, uint32_t n, float frag) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; i++) c += (frag >= win_lo[i] && frag <= win_hi[i]) ? 1u : 0u;
+    return c;
+}
+
+// ---- select_most_intense_peak (spectrum.rs:134-159) with offset == None ------------------------
+// binary_search_slice(masses, total_cmp, lo, hi) (database.rs:549-561) followed by the filtered scan.
+SAGE_HD int select_most_intense_peak(const float* masses, const float* intensities, uint32_t n, float center,
+                                     const Tol& tol) {
+    float lo, hi;
+    tol_bounds(tol, center, lo, hi);
+    const int32_t klo = order_key(lo), khi = order_key(hi);
+    uint32_t a = 0, b = n;
+    while (a < b) {  // partition_point(mass.total_cmp(lo) == Less)
+        uint32_t mid = (a + b) >> 1;
+        if (order_key(masses[mid]) < klo) a = mid + 1; else b = mid;
+    }
+    const uint32_t left = a ? a - 1 : 0;
+    a = left; b = n;
+    while (a < b) {  // partition_point(mass.total_cmp(hi) != Greater)
+        uint32_t mid = (a + b) >> 1;
+        if (order_key(masses[mid]) <= khi) a = mid + 1; else b = mid;
+    }
+    const uint32_t right = a;
+    int best = -1;
+    float max_int = 0.0f;
+    for (uint32_t idx = left; idx < right; idx++) {
+        const float m = masses[idx];
+        if (m >= lo && m <= hi) {
+            const float it = intensities[idx];
+            if (it >= max_int) {
+                max_int = it;
+                best = (int)idx;
+            }
+        }
+    }
+    return best;
+}
+
+// ---- Run (scoring.rs:771-793) -------------------------------------------------------------------
+struct Run {
+    uint32_t start, length, last, longest;
+};
+SAGE_HD void run_matched(Run& r, uint32_t index) {
+    if (r.last == index) return;
+    if (r.start + r.length == index) {
+        r.length += 1;
+        if (r.length > r.longest) r.longest = r.length;
+    } else {
+        r.start = index;
+        r.length = 1;
+        if (r.length > r.longest) r.longest = r.length;
+    }
+    r.last = index;
+}
+
+// ---- Score (scoring.rs:17-30) -------------------------------------------------------------------
+struct Score {
+    uint32_t peptide;
+    uint32_t matched_b, matched_y;  // u16 in the reference
+    float summed_b, summed_y;
+    uint32_t longest_b, longest_y;
+    float ppm_difference;
+    uint32_t precursor_charge;
+    int isotope_error;
+};
+
+// score_candidate's accumulation loop (scoring.rs:699-759) over a peptide's precomputed ion table:
+// ions[k*(L-1) + idx] is IonSeries(peptide, ion_kinds[k]).nth(idx) (ion_series.rs:68-85).
+SAGE_HD void score_candidate(Score& s, const float* ions, uint32_t lm1, const uint8_t* ion_kinds, uint32_t n_kinds,
+                             uint32_t max_fc, const float* masses, const float* intensities, uint32_t n_peaks,
+                             const Tol& fragment_tol) {
+    Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
+    s.matched_b = s.matched_y = 0;
+    s.summed_b = s.summed_y = 0.0f;
+    s.ppm_difference = 0.0f;
+    for (uint32_t k = 0; k < n_kinds; k++) {
+        const bool nterm_kind = ion_kinds[k] <= 2;  // A | B | C
+        const float* series = ions + (uint64_t)k * lm1;
+        for (uint32_t idx = 0; idx < lm1; idx++) {
+            const float frag = series[idx];
+            for (uint32_t charge = 1; charge < max_fc; charge++) {
+                const float mz = frag / (float)charge;
+                const int pk = select_most_intense_peak(masses, intensities, n_peaks, mz, fragment_tol);
+                if (pk < 0) continue;
+                const float peak_mass = masses[pk];
+                const float peak_intensity = intensities[pk];
+                const float d = __builtin_fabsf(mz - peak_mass);
+                s.ppm_difference += peak_intensity * d * 2E6f / (mz + peak_mass);
+                if (nterm_kind) {
+                    s.matched_b += 1;
+                    s.summed_b += peak_intensity;
+                    run_matched(b_run, idx);
+                } else {
+                    s.matched_y += 1;
+                    s.summed_y += peak_intensity;
+                    run_matched(y_run, idx);
+                }
+            }
+        }
+    }
+    s.longest_b = b_run.longest;
+    s.longest_y = y_run.longest;
+    s.ppm_difference /= s.summed_b + s.summed_y;
+}
+
+}  // namespace sagecore

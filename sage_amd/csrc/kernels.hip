@@ -1,0 +1,520 @@
+// kernels.hip — gfx950 kernels of the search-and-score path.
+//
+//   prelim_kernel  : Scorer::initial_hits (scoring.rs:418-462) = precursor-window query
+//                    (database.rs:402-425) + matched-fragment counting (scoring.rs:358-375 over
+//                    database.rs:480-536) + the nested trim_hits k-selects (scoring.rs:322-329).
+//   rescore_kernel : Scorer::build_features / score_candidate / score_chimera_fast
+//                    (scoring.rs:478-595, 675-767, 648-672, 598-644).
+//
+// One 64-lane wavefront owns one spectrum.  Spectrum peaks and their fragment-tolerance windows live
+// in LDS, candidate counters live in LDS (u16 pairs), the window's fragments are one contiguous
+// range of the peptide-major index and are streamed with coalesced 8-byte loads.  This is sparse
+// gather/compare/accumulate work: no MFMA.  Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+using namespace sagecore;
+
+namespace sagehip {
+
+namespace {
+
+constexpr uint32_t WAVE = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// partition_point over sorted a[lo..hi) of key(a[i]) < bound (STRICT) or <= bound, all 64 lanes
+// cooperating: 64 pivots per round (log_65 instead of log_2 dependent loads).
+template <bool STRICT>
+__device__ __forceinline__ uint32_t wave_partition_point(const float* __restrict__ a, uint32_t lo, uint32_t hi,
+                                                         int32_t bound) {
+    const uint32_t lane = lane_id();
+    while (hi - lo > WAVE) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = (span + WAVE) / (WAVE + 1);
+        const uint64_t pidx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+        bool t = false;
+        if (pidx < hi) {
+            const int32_t k = order_key(a[pidx]);
+            t = STRICT ? (k < bound) : (k <= bound);
+        }
+        const uint32_t c = (uint32_t)__popcll(__ballot(t));
+        const uint64_t nhi = (uint64_t)lo + (uint64_t)(c + 1) * step - 1;
+        const uint32_t new_lo = lo + c * step;
+        hi = nhi < hi ? (uint32_t)nhi : hi;
+        lo = new_lo;
+    }
+    bool t = false;
+    if (lo + lane < hi) {
+        const int32_t k = order_key(a[lo + lane]);
+        t = STRICT ? (k < bound) : (k <= bound);
+    }
+    return lo + (uint32_t)__popcll(__ballot(t));
+}
+
+// ---- candidate counters ---------------------------------------------------------------------
+// narrow path: u16 pairs in LDS;  large-window path: u32 in global scratch
+template <bool WIDE>
+struct Counters {
+    uint32_t* p;
+    __device__ __forceinline__ void zero(uint32_t n, uint32_t lane) {
+        if (WIDE) {
+            for (uint32_t i = lane; i < n; i += WAVE) p[i] = 0;
+        } else {
+            for (uint32_t i = lane; i < (n + 1) / 2; i += WAVE) p[i] = 0;
+        }
+    }
+    __device__ __forceinline__ void add(uint32_t idx, uint32_t c) {
+        if (WIDE) atomicAdd(&p[idx], c);
+        else atomicAdd(&p[idx >> 1], c << ((idx & 1) * 16));
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t idx) const {
+        if (WIDE) return __hip_atomic_load(&p[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (p[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu;
+    }
+};
+
+struct PrelimLds {
+    float* win_lo;
+    float* win_hi;
+    uint64_t* listA;
+    uint64_t* listB;
+    uint64_t* heap;
+    uint32_t* cnt;
+};
+
+__device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const DevScorer& sc, const DevBatchView& b) {
+    PrelimLds l;
+    size_t off = 0;
+    l.listA = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
+    l.listB = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
+    l.heap = (uint64_t*)(smem + off); off += (size_t)sc.kmax * 8;
+    l.win_lo = (float*)(smem + off); off += (size_t)b.fzcap * b.pcap * 4;
+    l.win_hi = (float*)(smem + off); off += (size_t)b.fzcap * b.pcap * 4;
+    l.cnt = (uint32_t*)(smem + off);
+    return l;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const PrelimLds L = carve_prelim(smem, sc, b);
+    Counters<WIDE> cnt;
+    cnt.p = WIDE ? (w.wide_cnt + (size_t)blockIdx.x * ((size_t)db.np + 1)) : L.cnt;
+    if (WIDE && *w.n_deferred == 0) return;
+
+    for (uint32_t spec = blockIdx.x; spec < b.n; spec += gridDim.x) {
+        if (WIDE && w.status[spec] != ST_DEFERRED) continue;
+        __syncthreads();
+        const uint64_t p0 = b.peak_off[spec];
+        const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+        const float* __restrict__ masses = b.masses + p0;
+        const uint32_t zraw = b.precursor_charge[spec];
+        uint32_t z0, z1;
+        if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {  // scoring.rs:423, 437, 442
+            z0 = sc.min_precursor_charge;
+            z1 = sc.max_precursor_charge;
+        } else {
+            z0 = z1 = zraw;
+        }
+        uint32_t nfz_max = 0;
+        for (uint32_t z = z0; z <= z1; z++) {
+            const uint32_t m = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+            nfz_max = m > nfz_max ? m : nfz_max;
+        }
+        if (nfz_max > b.fzcap) nfz_max = b.fzcap;  // (upload sized fzcap from the same rule)
+
+        // fragment-tolerance window of every (peak, fragment charge): database.rs:481 on the
+        // experimental mass peak*charge of scoring.rs:360
+        bool mono_ok = true;
+        for (uint32_t fz = 1; fz <= nfz_max; fz++) {
+            float* wl = L.win_lo + (size_t)(fz - 1) * b.pcap;
+            float* wh = L.win_hi + (size_t)(fz - 1) * b.pcap;
+            for (uint32_t i = lane; i < P; i += WAVE) {
+                float lo, hi;
+                tol_bounds(sc.fragment_tol, masses[i] * (float)fz, lo, hi);
+                wl[i] = lo;
+                wh[i] = hi;
+                if (i > 0) {
+                    float plo, phi;
+                    tol_bounds(sc.fragment_tol, masses[i - 1] * (float)fz, plo, phi);
+                    mono_ok = mono_ok && (plo <= lo) && (phi <= hi);
+                }
+                mono_ok = mono_ok && (lo <= hi);
+            }
+        }
+        const bool sorted_ok = __ballot(!mono_ok) == 0ull;
+        __syncthreads();
+
+        const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
+        Tol iso_tol;
+        iso_tol.kind = 2;
+        iso_tol.lo = -2.4f;
+        iso_tol.hi = 2.4f;  // scoring.rs:430
+        if (b.isolation_lo && b.isolation_hi) {
+            const float a = b.isolation_lo[spec], c = b.isolation_hi[spec];
+            if (a == a && c == c) { iso_tol.lo = a; iso_tol.hi = c; }
+        }
+        const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
+        const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+
+        CList A, B;  // meaningful on lane 0 only
+        A.items = L.listA; A.cap = sc.list_cap; clist_clear(A);
+        B.items = L.listB; B.cap = sc.list_cap; clist_clear(B);
+        bool ok = true;          // lane 0: list capacity respected
+        bool deferred = false;   // uniform
+        uint32_t tot_matched = 0, tot_scored = 0;  // uniform
+
+        for (uint32_t z = z0; z <= z1 && !deferred; z++) {
+            const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+            const float precursor_mass = mzp * (float)z;
+            const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
+            if (fold && lane == 0) clist_clear(A);
+            for (int iso = isoA; iso <= isoB && !deferred; iso++) {
+                // ---- IndexedDatabase::query, database.rs:402-425 ----
+                const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
+                float plo, phi;
+                tol_bounds(ptol, center, plo, phi);
+                uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
+                left = left ? left - 1 : 0;
+                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, db.np, order_key(phi));
+                const uint32_t potential = right - left + 1;  // scoring.rs:351
+                if (!WIDE && potential > sc.wcap) {
+                    deferred = true;
+                    break;
+                }
+                cnt.zero(potential, lane);
+                // edge rule of database.rs:526-531: interior indices are in range by construction
+                uint32_t first = left, end = right;
+                if (left < db.np && !(db.pep_mono[left] >= plo)) first = left + 1;
+                if (right < db.np && db.pep_mono[right] <= phi) end = right + 1;
+                __syncthreads();
+                uint32_t acc = 0;
+                if (first < end) {
+                    const uint64_t f0 = db.pm_off[first], f1 = db.pm_off[end];
+                    for (uint64_t j = f0 + lane; j < f1; j += WAVE) {
+                        const SageTheoretical fr = db.pm_frag[j];
+                        uint32_t c = 0;
+                        for (uint32_t fz = 0; fz < nfz; fz++) {
+                            const float* wl = L.win_lo + (size_t)fz * b.pcap;
+                            const float* wh = L.win_hi + (size_t)fz * b.pcap;
+                            c += sorted_ok ? count_windows_sorted(wl, wh, P, fr.fragment_mz)
+                                           : count_windows_scan(wl, wh, P, fr.fragment_mz);
+                        }
+                        if (c) {
+                            cnt.add(fr.peptide_index - left, c);
+                            acc += c;
+                        }
+                    }
+                }
+                const uint32_t matched = wave_sum(acc);
+                __syncthreads();
+                tot_matched += matched;
+                CList& target = fold ? A : B;
+                if (matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
+                    if (lane == 0) ok = clist_push_empties(target, potential, sc.kmax) && ok;
+                    continue;
+                }
+                // ---- trim_hits of this query, scoring.rs:380 ----
+                const uint32_t k = trim_k(potential, sc.report_psms);
+                uint32_t scored = 0;
+                if (potential <= k) {
+                    for (uint32_t base = 0; base < potential; base += WAVE) {
+                        const uint32_t i = base + lane;
+                        const uint32_t c = i < potential ? cnt.get(i) : 0;
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
+                    }
+                    if (lane == 0) {
+                        for (uint32_t i = 0; i < potential; i++) {
+                            const uint32_t c = cnt.get(i);
+                            ok = clist_push(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, sc.kmax) && ok;
+                        }
+                    }
+                } else {
+                    for (uint32_t i = lane; i < k; i += WAVE) {
+                        const uint32_t c = cnt.get(i);
+                        L.heap[i] = c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY;
+                        scored += c > 0;
+                    }
+                    scored = wave_sum(scored);
+                    __syncthreads();
+                    if (lane == 0) heap_build(L.heap, k);
+                    for (uint32_t base = k; base < potential; base += WAVE) {
+                        const uint32_t i = base + lane;
+                        const uint32_t c = i < potential ? cnt.get(i) : 0;
+                        uint64_t mask = __ballot(c > 0);
+                        scored += (uint32_t)__popcll(mask);
+                        if (lane == 0) {
+                            while (mask) {
+                                const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                                mask &= mask - 1;
+                                const uint32_t ii = base + bit;
+                                heap_offer(L.heap, k, pack_prescore(cnt.get(ii), left + ii, z, iso));
+                            }
+                        }
+                    }
+                    if (lane == 0) {
+                        for (uint32_t i = 0; i < k; i++) ok = clist_push(target, L.heap[i], sc.kmax) && ok;
+                    }
+                }
+                tot_scored += scored;
+                __syncthreads();
+            }
+            if (fold && !deferred && lane == 0) {  // scoring.rs:405 then `hits +=` at :432 / :450
+                clist_trim(A, sc.report_psms);
+                for (uint32_t i = 0; i < A.stored; i++) ok = clist_push(B, A.items[i], sc.kmax) && ok;
+            }
+        }
+        if (deferred) {
+            if (lane == 0) {
+                w.status[spec] = ST_DEFERRED;
+                atomicAdd(w.n_deferred, 1u);
+            }
+            continue;
+        }
+        if (lane == 0) {
+            clist_trim(B, sc.report_psms);  // scoring.rs:460
+            w.status[spec] = ok ? ST_OK : ST_OVERFLOW;
+            w.cand_len[spec] = B.stored;
+            w.totals[2 * spec] = tot_matched;
+            w.totals[2 * spec + 1] = tot_scored;
+        }
+        __syncthreads();
+        const uint32_t nst = __shfl(B.stored, 0, 64);
+        for (uint32_t i = lane; i < nst; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
+    }
+}
+
+// ---- rescoring -------------------------------------------------------------------------------
+__device__ __forceinline__ double lnfact_dev(uint32_t n, const double* __restrict__ table, uint32_t table_n) {
+    if (n < table_n) return table[n];
+    const double x = (double)n;  // scoring.rs:170-177
+    return x * log(x) - x + 0.5 * log(x) + 0.5 * log(3.14159265358979323846 * 2.0 * x);
+}
+
+__device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s, const double* table, uint32_t tn) {
+    double score;  // ScoreType::score, scoring.rs:179-201
+    if (score_type == 0) {
+        const double i = (double)(s.summed_b + 1.0f) * (double)(s.summed_y + 1.0f);
+        score = log(i) + lnfact_dev(s.matched_b, table, tn) + lnfact_dev(s.matched_y, table, tn);
+    } else {
+        const float si = s.summed_b + s.summed_y;
+        score = (double)log1pf(si) + lnfact_dev(s.matched_b, table, tn) + lnfact_dev(s.matched_y, table, tn);
+    }
+    return __builtin_isfinite(score) ? score : 255.0;
+}
+
+__global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+                                                     const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                     SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const uint32_t spec = blockIdx.x;
+    if (spec >= b.n) return;
+    // LDS: sorted hyperscores [64] f64 | sort keys [64] i64 | peak masses | intensities | remove flags x2
+    double* s_sorted = (double*)smem;
+    long long* s_key = (long long*)(smem + 64 * 8);
+    float* pm = (float*)(smem + 128 * 8);
+    float* pi = pm + b.pcap;
+    uint8_t* rm = (uint8_t*)(pi + b.pcap);
+    uint8_t* rm2 = rm + b.pcap;
+
+    if (w.status[spec] != ST_OK) {
+        if (lane == 0) out_count[spec] = 0;
+        return;
+    }
+    const uint64_t p0 = b.peak_off[spec];
+    uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        pm[i] = b.masses[p0 + i];
+        pi[i] = b.intensities[p0 + i];
+    }
+    float tic = b.tic[spec];
+    const uint32_t ncand = w.cand_len[spec];
+    const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
+    const uint32_t pep = prescore_peptide(mine);
+    const bool valid = pep != 0xFFFFFFFFu;  // scoring.rs:489
+    const uint32_t z = prescore_charge(mine);
+    const int iso = prescore_iso(mine);
+    const uint32_t mfc = max_fragment_charge(sc.max_fragment_charge, z);
+    const float* ions = nullptr;
+    uint32_t lm1 = 0, info = 0;
+    float calc = 0.f;
+    if (valid) {
+        const uint64_t o0 = db.ion_off[pep], o1 = db.ion_off[pep + 1];
+        ions = db.ions + o0;
+        lm1 = db.n_kinds ? (uint32_t)((o1 - o0) / db.n_kinds) : 0;
+        info = db.pep_info[pep];
+        calc = db.pep_mono[pep];
+    }
+    const double lambda = (double)w.totals[2 * spec] / (double)w.totals[2 * spec + 1];  // scoring.rs:499
+    const float mzp = b.precursor_mz[spec] - PROTON;                                   // scoring.rs:502
+    const float rt = b.rt ? b.rt[spec] : 0.0f;
+    float ims = 0.0f;
+    if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
+    const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
+    __syncthreads();
+
+    const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
+    const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
+    uint32_t n_emitted = 0;
+    for (uint32_t round = 0; round < rounds; round++) {
+        Score s;
+        s.peptide = pep;
+        s.precursor_charge = z;
+        s.isotope_error = iso;
+        double h = 0.0;
+        bool pass = false;
+        if (valid) {
+            score_candidate(s, ions, lm1, db.ion_kinds, db.n_kinds, mfc, pm, pi, P, sc.fragment_tol);
+            h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
+            pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
+        }
+        // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation
+        const long long key = order_key64(h);
+        s_key[lane] = key;
+        const uint64_t pmask = __ballot(pass);
+        const uint32_t npass = (uint32_t)__popcll(pmask);
+        __syncthreads();
+        uint32_t rank = 0;
+        if (pass) {
+            uint64_t m = pmask;
+            while (m) {
+                const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
+                m &= m - 1;
+                const long long kj = s_key[j];
+                rank += (kj > key) || (kj == key && j < lane);
+            }
+            s_sorted[rank] = h;
+        }
+        __syncthreads();
+        if (pass && rank < per_round) {  // scoring.rs:504-594
+            const double next = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
+            const double best = s_sorted[0];
+            const float precursor_mass = mzp * (float)z;
+            const uint32_t k = s.matched_b + s.matched_y;
+            const double log10_poisson =
+                ((double)k * log(lambda) - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
+            const float isotope_error = (float)iso * NEUTRON;
+            const float delta_mass =
+                (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
+            const uint32_t plen = info & 0xFFFF;
+            SageFeature f;
+            f.spec_index = spec;
+            f.peptide_idx = pep;
+            f.rank = sc.chimera ? round + 1 : rank + 1;  // scoring.rs:541, 664
+            f.label = ((info >> 16) & 0xFF) ? -1 : 1;
+            f.expmass = precursor_mass;
+            f.calcmass = calc;
+            f.rt = rt;
+            f.ims = ims;
+            f.delta_mass = delta_mass;
+            f.isotope_error = isotope_error;
+            f.average_ppm = s.ppm_difference;
+            f.longest_y_pct = (float)s.longest_y / (float)plen;
+            f.matched_intensity_pct = 100.0f * (s.summed_b + s.summed_y) / tic;
+            f.ms2_intensity = s.summed_b + s.summed_y;
+            f.hyperscore = h;
+            f.delta_next = h - next;
+            f.delta_best = best - h;
+            f.poisson = __builtin_isfinite(log10_poisson) ? log10_poisson : -__builtin_huge_val();
+            f.matched_peaks = k;
+            f.longest_b = s.longest_b;
+            f.longest_y = s.longest_y;
+            f.scored_candidates = w.totals[2 * spec + 1];
+            f.peptide_len = plen;
+            f.file_id = fid;
+            f.charge = (uint8_t)z;
+            f.missed_cleavages = (uint8_t)(info >> 24);
+            for (int q = 0; q < 6; q++) f.pad[q] = 0;
+            out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
+        }
+        const uint32_t emitted = npass < per_round ? npass : per_round;
+        n_emitted += emitted;
+        if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
+
+        // ---- remove_matched_peaks(winner), scoring.rs:598-644 ----
+        const uint64_t wmask = __ballot(pass && rank == 0);
+        const uint32_t wl = (uint32_t)__ffsll((long long)wmask) - 1;
+        const uint32_t wpep = __shfl(pep, wl, 64);
+        const uint32_t wmfc = __shfl(mfc, wl, 64);
+        const uint64_t wo0 = db.ion_off[wpep], wo1 = db.ion_off[wpep + 1];
+        const float* wions = db.ions + wo0;
+        const uint32_t n_items = (uint32_t)(wo1 - wo0) * (wmfc - 1);
+        for (uint32_t i = lane; i < P; i += WAVE) rm[i] = 0;
+        __syncthreads();
+        for (uint32_t t = lane; t < n_items; t += WAVE) {
+            const uint32_t ion = t / (wmfc - 1), charge = t % (wmfc - 1) + 1;
+            const int pk = select_most_intense_peak(pm, pi, P, wions[ion] / (float)charge, sc.fragment_tol);
+            if (pk >= 0) rm[pk] = 1;
+        }
+        __syncthreads();
+        // `to_remove.contains(&(mass, intensity))` compares values: equal pairs go together
+        for (uint32_t i = lane; i < P; i += WAVE) {
+            uint8_t r = rm[i];
+            const float mi = pm[i], ii = pi[i];
+            for (uint32_t j = i; !r && j-- > 0 && pm[j] == mi;) r = rm[j] && pi[j] == ii;
+            for (uint32_t j = i + 1; !r && j < P && pm[j] == mi; j++) r = rm[j] && pi[j] == ii;
+            rm2[i] = r;
+        }
+        __syncthreads();
+        uint32_t newP = 0;
+        for (uint32_t base = 0; base < P; base += WAVE) {
+            const uint32_t i = base + lane;
+            const bool keep = i < P && !rm2[i];
+            const float mi = i < P ? pm[i] : 0.f, ii = i < P ? pi[i] : 0.f;
+            const uint64_t km = __ballot(keep);
+            const uint32_t pos = newP + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (keep) { pm[pos] = mi; pi[pos] = ii; }
+            newP += (uint32_t)__popcll(km);
+            __syncthreads();
+        }
+        P = newP;
+        float t = 0.0f;  // total_ion_current = intensities.iter().sum::<f32>(), scoring.rs:643
+        if (lane == 0) for (uint32_t i = 0; i < P; i++) t += pi[i];
+        tic = __shfl(t, 0, 64);
+        __syncthreads();
+    }
+    if (lane == 0) out_count[spec] = n_emitted;
+}
+
+}  // namespace
+
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool wide) {
+    size_t n = (size_t)sc.list_cap * 16 + (size_t)sc.kmax * 8 + (size_t)b.fzcap * b.pcap * 8;
+    if (!wide) n += ((size_t)sc.wcap / 2 + 1) * 4;
+    return (n + 15) & ~(size_t)15;
+}
+size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t) {
+    size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
+    return (n + 15) & ~(size_t)15;
+}
+
+void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(prelim_kernel<false>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b, false), (hipStream_t)stream,
+                       db, sc, b, w);
+}
+void launch_prelim_wide(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+    if (b.n == 0 || w.wide_blocks == 0) return;
+    hipLaunchKernelGGL(prelim_kernel<true>, dim3(w.wide_blocks), dim3(64), prelim_lds_bytes(sc, b, true),
+                       (hipStream_t)stream, db, sc, b, w);
+}
+void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
+                    const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
+                    uint32_t* out_count, void* stream) {
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions), (hipStream_t)stream, db,
+                       sc, b, w, lnfact_table, lnfact_n, out, out_count);
+}
+
+}  // namespace sagehip

@@ -1,0 +1,107 @@
+"""Synthetic FASTA / MS2 generators for the BASELINE.json configs (recipes: SURVEY.md §8d).
+
+The reference ships no generator; these are ours.  All randomness comes from
+numpy.random.default_rng(seed) (PCG64), so workloads are reproducible across machines.
+"""
+import numpy as np
+
+from .api import IndexedDatabase, RawSpectrum
+
+# UniProtKB/Swiss-Prot background amino-acid frequencies (percent), 20 standard residues
+_AA = "ACDEFGHIKLMNPQRSTVWY"
+_FREQ = np.array([8.25, 1.38, 5.46, 6.72, 3.86, 7.07, 2.27, 5.91, 5.80, 9.65, 2.41, 4.06, 4.74, 3.93, 5.53, 6.65,
+                  5.36, 6.86, 1.10, 2.92])
+_FREQ = _FREQ / _FREQ.sum()
+
+# f64 residue masses for the generator only (the engine's own f32 table is in csrc/host_db.cpp)
+_MASS = {"A": 71.03711, "C": 103.00919, "D": 115.02694, "E": 129.04259, "F": 147.0684, "G": 57.02146,
+         "H": 137.05891, "I": 113.08406, "K": 128.09496, "L": 113.08406, "M": 131.0405, "N": 114.04293,
+         "P": 97.05276, "Q": 128.05858, "R": 156.1011, "S": 87.03203, "T": 101.04768, "V": 99.06841,
+         "W": 186.07932, "Y": 163.06332, "U": 150.95363, "O": 237.14774}
+_MASS_LUT = np.zeros(256)
+for _k, _v in _MASS.items():
+    _MASS_LUT[ord(_k)] = _v
+PROTON = 1.0072764
+H2O = 18.010565
+
+
+def synthetic_fasta(n_proteins: int, seed: int, mu: float = 6.0, sigma: float = 0.6, lo: int = 50, hi: int = 3000) -> str:
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.lognormal(mu, sigma, n_proteins).astype(np.int64), lo, hi)
+    letters = np.frombuffer(_AA.encode(), dtype=np.uint8)
+    out = []
+    for i, n in enumerate(lens):
+        seq = letters[rng.choice(len(_AA), size=int(n), p=_FREQ)].tobytes().decode()
+        out.append(f">sp|SYN{i:06d}|SYN{i:06d}_SYNTH synthetic protein {i}\n")
+        for j in range(0, len(seq), 60):
+            out.append(seq[j:j + 60] + "\n")
+    return "".join(out)
+
+
+def synthetic_spectra(db: IndexedDatabase, n_spectra: int, seed: int, noise_peaks: int = 80, pure_noise_frac: float = 0.10,
+                      keep_prob: float = 0.5, ppm_sigma: float = 3.0, charges=((2, 0.6), (3, 0.3), (4, 0.1)),
+                      annotate_charge: bool = True, mass_shift_frac: float = 0.0, chimeric: int = 1,
+                      isolation_half_width: float = None):
+    """Returns a list of RawSpectrum (centroided MS2).  Each spectrum is built from `chimeric` source
+    peptides drawn uniformly from the target peptides of `db` (b/y ions, z=1 plus z=2 copies when the
+    precursor charge is >= 3), fragment m/z error N(0, ppm_sigma), LogNormal intensities and uniform noise."""
+    rng = np.random.default_rng(seed)
+    targets = np.flatnonzero(db.decoy == 0)
+    zs = np.array([c for c, _ in charges])
+    zp = np.array([p for _, p in charges])
+    zp = zp / zp.sum()
+    spectra = []
+    seq_off = db.seq_off.astype(np.int64)
+    for i in range(n_spectra):
+        mzs, ints = [], []
+        pure_noise = rng.random() < pure_noise_frac
+        z = int(rng.choice(zs, p=zp))
+        first_mz = None
+        n_src = 1 if chimeric <= 1 else int(rng.integers(2, chimeric + 1))
+        for s in range(n_src):
+            pep = int(targets[rng.integers(len(targets))])
+            a, b = seq_off[pep], seq_off[pep + 1]
+            res = _MASS_LUT[db.seq[a:b]] + db.mods[a:b].astype(np.float64)
+            nterm = float(db.nterm[pep]) if not np.isnan(db.nterm[pep]) else 0.0
+            mono = float(db.pep_mono[pep])
+            prec_mz = (mono + z * PROTON) / z * (1.0 + rng.normal(0.0, ppm_sigma) * 1e-6)
+            if first_mz is None:
+                first_mz = prec_mz
+            elif isolation_half_width:
+                # co-isolated peptide: keep only those that fall inside the isolation window
+                if abs(prec_mz - first_mz) > isolation_half_width:
+                    pass  # still add its fragments: chimeric spectra are messy by construction
+            if pure_noise:
+                continue
+            bs = nterm + np.cumsum(res)[:-1]
+            ys = mono - bs
+            shift_site = None
+            if mass_shift_frac and rng.random() < mass_shift_frac:
+                delta = rng.uniform(-100.0, 400.0)
+                site = int(rng.integers(0, len(res)))
+                # an unknown modification of mass delta on residue `site`
+                bs = bs + (np.arange(len(bs)) >= site) * delta
+                ys = ys + (np.arange(len(ys)) < site) * delta
+                if s == 0:
+                    first_mz = (mono + delta + z * PROTON) / z * (1.0 + rng.normal(0.0, ppm_sigma) * 1e-6)
+            frag = np.concatenate([bs, ys])
+            cand = [frag + PROTON]
+            if z >= 3:
+                cand.append((frag + 2 * PROTON) / 2.0)
+            cand = np.concatenate(cand)
+            keep = rng.random(len(cand)) < keep_prob
+            cand = cand[keep] * (1.0 + rng.normal(0.0, ppm_sigma, keep.sum()) * 1e-6)
+            mzs.append(cand)
+            ints.append(rng.lognormal(8.0, 1.2, len(cand)))
+        mzs.append(rng.uniform(150.0, 1800.0, noise_peaks))
+        ints.append(rng.lognormal(6.5, 1.0, noise_peaks))
+        mz = np.concatenate(mzs)
+        it = np.concatenate(ints)
+        ok = (mz > 100.0) & (mz < 2500.0)
+        mz, it = mz[ok], it[ok]
+        order = np.argsort(mz, kind="stable")
+        iso = (-isolation_half_width, isolation_half_width) if isolation_half_width else None
+        spectra.append(RawSpectrum(mz[order].astype(np.float32), it[order].astype(np.float32), float(np.float32(first_mz)),
+                                   z if annotate_charge else None, iso, scan_start_time=float(np.float32(i * 0.01)),
+                                   file_id=0, id=f"scan={i + 1}"))
+    return spectra

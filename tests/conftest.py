@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        from sage_amd import device_count
+        return device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly rather than silently pass
+    pass
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    if not _has_gpu():
+        pytest.fail("this test needs a HIP device (run with -m gpu on the GPU box)")

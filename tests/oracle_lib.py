@@ -1,0 +1,210 @@
+"""ctypes wrapper over oracle/_build/liboracle.so — TEST INFRASTRUCTURE (the CPU restatement of the
+reference).  Struct layouts are shared with sage_amd._lib because oracle_capi.cpp mirrors sage_hip.h."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from sage_amd import _lib as L
+from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+SELFTEST = os.path.join(ORACLE_DIR, "_build", "oracle_selftest")
+
+
+class OrcWork(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("queries", "page_searches", "pages", "scanned", "hits", "peaks", "rescored",
+                                          "rescored_residues", "reported", "algorithmic_bytes")]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sage_oracle.cpp", "sage_oracle.hpp", "oracle_capi.cpp", "selftest.cpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs if os.path.exists(s)):
+        build()
+    lib = C.CDLL(LIB)
+    vp = C.c_void_p
+    lib.orc_db_build.restype = vp
+    lib.orc_db_build.argtypes = [C.c_char_p, C.POINTER(L.SageDbParams)]
+    lib.orc_db_from_arrays.restype = vp
+    lib.orc_db_from_arrays.argtypes = [L.c_u32_p, L.c_float_p, C.c_uint64, L.c_float_p, C.c_uint64, C.c_uint64,
+                                       L.c_float_p, L.c_u64_p, L.c_u8_p, L.c_float_p, L.c_float_p, L.c_float_p,
+                                       L.c_u8_p, L.c_u8_p, C.c_uint64, L.c_u8_p, C.c_uint32]
+    lib.orc_db_free.argtypes = [vp]
+    for f in ("orc_db_num_peptides", "orc_db_num_fragments", "orc_db_num_buckets", "orc_db_bucket_size",
+              "orc_db_total_residues"):
+        getattr(lib, f).restype = C.c_uint64
+        getattr(lib, f).argtypes = [vp]
+    lib.orc_db_copy_fragments.argtypes = [vp, L.c_u32_p, L.c_float_p]
+    lib.orc_db_copy_min_value.argtypes = [vp, L.c_float_p]
+    lib.orc_db_copy_peptides.argtypes = [vp, L.c_float_p, L.c_u8_p, L.c_u8_p, L.c_float_p, L.c_float_p, L.c_u64_p,
+                                         L.c_u8_p, L.c_float_p]
+    lib.orc_db_peptide_strings.restype = C.c_uint64
+    lib.orc_db_peptide_strings.argtypes = [vp, C.c_char_p, C.c_uint64]
+    lib.orc_db_peptide_proteins.restype = C.c_uint64
+    lib.orc_db_peptide_proteins.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64]
+    lib.orc_db_page_search.restype = C.c_uint64
+    lib.orc_db_page_search.argtypes = [vp, C.c_float, L.SageTolerance, L.SageTolerance, C.c_float, L.c_u64_p,
+                                       C.c_uint64, L.c_u64_p, L.c_u64_p]
+    lib.orc_process_ms2.restype = C.c_uint64
+    lib.orc_process_ms2.argtypes = [C.c_uint64, C.c_int, C.c_float, L.c_float_p, L.c_float_p, C.c_uint64, C.c_uint8,
+                                    L.c_float_p, L.c_float_p, L.c_float_p]
+    lib.orc_score_batch.restype = C.c_double
+    lib.orc_score_batch.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), vp, L.c_u32_p,
+                                    C.c_int, C.POINTER(OrcWork)]
+    lib.orc_initial_hits.restype = C.c_uint64
+    lib.orc_initial_hits.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_uint32,
+                                     C.POINTER(C.c_uint16), L.c_u32_p, L.c_u8_p, C.POINTER(C.c_int8), C.c_uint64,
+                                     L.c_u64_p, L.c_u64_p]
+    lib.orc_brute_force.restype = C.c_uint64
+    lib.orc_brute_force.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_uint32,
+                                    C.c_uint8, C.c_int8, L.c_u32_p, L.c_u32_p, C.POINTER(C.c_double), C.c_uint64]
+    lib.orc_tol_bounds.argtypes = [L.SageTolerance, C.c_float, L.c_float_p, L.c_float_p]
+    lib.orc_max_threads.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class OracleDb:
+    """An oracle IndexedDatabase, built from FASTA (its own builder) or adopted from flat arrays."""
+
+    def __init__(self, handle):
+        self.h = handle
+        lib = load()
+        self.n_peptides = int(lib.orc_db_num_peptides(self.h))
+        self.n_fragments = int(lib.orc_db_num_fragments(self.h))
+        self.n_buckets = int(lib.orc_db_num_buckets(self.h))
+        self.bucket_size = int(lib.orc_db_bucket_size(self.h))
+
+    @staticmethod
+    def build(fasta_text: str, params: DatabaseParameters) -> "OracleDb":
+        p, keep = params.to_c()
+        return OracleDb(C.c_void_p(load().orc_db_build(fasta_text.encode(), C.byref(p))))
+
+    @staticmethod
+    def from_product(db) -> "OracleDb":
+        """Adopt the arrays of a sage_amd.IndexedDatabase (same inputs for both legs of a comparison)."""
+        lib = load()
+        fp = np.ascontiguousarray(db.fragments["peptide_index"])
+        fm = np.ascontiguousarray(db.fragments["fragment_mz"])
+        h = lib.orc_db_from_arrays(L.as_ptr(fp, C.c_uint32), L.as_ptr(fm, C.c_float), len(fp),
+                                   L.as_ptr(db.min_value, C.c_float), len(db.min_value), db.bucket_size,
+                                   L.as_ptr(db.pep_mono, C.c_float), L.as_ptr(db.seq_off, C.c_uint64),
+                                   L.as_ptr(db.seq, C.c_uint8), L.as_ptr(db.mods, C.c_float),
+                                   L.as_ptr(db.nterm, C.c_float), L.as_ptr(db.cterm, C.c_float),
+                                   L.as_ptr(db.decoy, C.c_uint8), L.as_ptr(db.missed_cleavages, C.c_uint8),
+                                   db.n_peptides, L.as_ptr(db.ion_kinds, C.c_uint8), len(db.ion_kinds))
+        return OracleDb(C.c_void_p(h))
+
+    def arrays(self):
+        lib = load()
+        nf, np_, nb = self.n_fragments, self.n_peptides, self.n_buckets
+        tot = int(lib.orc_db_total_residues(self.h))
+        out = dict(frag_pep=np.zeros(nf, np.uint32), frag_mz=np.zeros(nf, np.float32), min_value=np.zeros(nb, np.float32),
+                   pep_mono=np.zeros(np_, np.float32), decoy=np.zeros(np_, np.uint8), missed=np.zeros(np_, np.uint8),
+                   nterm=np.zeros(np_, np.float32), cterm=np.zeros(np_, np.float32), seq_off=np.zeros(np_ + 1, np.uint64),
+                   seq=np.zeros(tot, np.uint8), mods=np.zeros(tot, np.float32))
+        lib.orc_db_copy_fragments(self.h, L.as_ptr(out["frag_pep"], C.c_uint32), L.as_ptr(out["frag_mz"], C.c_float))
+        lib.orc_db_copy_min_value(self.h, L.as_ptr(out["min_value"], C.c_float))
+        lib.orc_db_copy_peptides(self.h, L.as_ptr(out["pep_mono"], C.c_float), L.as_ptr(out["decoy"], C.c_uint8),
+                                 L.as_ptr(out["missed"], C.c_uint8), L.as_ptr(out["nterm"], C.c_float),
+                                 L.as_ptr(out["cterm"], C.c_float), L.as_ptr(out["seq_off"], C.c_uint64),
+                                 L.as_ptr(out["seq"], C.c_uint8), L.as_ptr(out["mods"], C.c_float))
+        return out
+
+    def peptide_strings(self):
+        lib = load()
+        n = lib.orc_db_peptide_strings(self.h, None, 0)
+        buf = C.create_string_buffer(int(n))
+        lib.orc_db_peptide_strings(self.h, buf, n)
+        s = buf.value.decode()
+        return s.split("\n")[:-1] if s else []
+
+    def peptide_proteins(self, i):
+        lib = load()
+        n = lib.orc_db_peptide_proteins(self.h, i, None, 0)
+        buf = C.create_string_buffer(int(n))
+        lib.orc_db_peptide_proteins(self.h, i, buf, n)
+        return buf.value.decode()
+
+    def page_search(self, precursor_mass, ptol, ftol, mass, cap=1 << 20):
+        lib = load()
+        idx = np.zeros(cap, np.uint64)
+        lo, hi = C.c_uint64(), C.c_uint64()
+        n = lib.orc_db_page_search(self.h, precursor_mass, ptol.to_c(), ftol.to_c(), mass, L.as_ptr(idx, C.c_uint64),
+                                   cap, C.byref(lo), C.byref(hi))
+        return idx[:int(n)].copy(), int(lo.value), int(hi.value)
+
+    def score(self, params: ScorerParams, batch: SpectrumBatch, threads: int = 0, work: bool = False):
+        """Scorer::score for each spectrum.  Returns (features[n, report], counts[n], elapsed_ms, work|None)."""
+        lib = load()
+        cp = params.to_c()
+        cb = batch.to_c()
+        feats = np.zeros(batch.n * params.report_psms, dtype=L.FEATURE_DTYPE)
+        counts = np.zeros(batch.n, np.uint32)
+        w = OrcWork()
+        ms = lib.orc_score_batch(self.h, C.byref(cp), C.byref(cb), feats.ctypes.data_as(C.c_void_p),
+                                 L.as_ptr(counts, C.c_uint32), threads, C.byref(w) if work else None)
+        wd = {k: getattr(w, k) for k, _ in OrcWork._fields_} if work else None
+        return feats.reshape(batch.n, params.report_psms), counts, float(ms), wd
+
+    def initial_hits(self, params: ScorerParams, batch: SpectrumBatch, i: int):
+        lib = load()
+        cap = 4096
+        m = np.zeros(cap, np.uint16); p = np.zeros(cap, np.uint32); z = np.zeros(cap, np.uint8); iso = np.zeros(cap, np.int8)
+        mp, sc = C.c_uint64(), C.c_uint64()
+        cp = params.to_c(); cb = batch.to_c()
+        n = int(lib.orc_initial_hits(self.h, C.byref(cp), C.byref(cb), i, m.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                     L.as_ptr(p, C.c_uint32), L.as_ptr(z, C.c_uint8),
+                                     iso.ctypes.data_as(C.POINTER(C.c_int8)), cap, C.byref(mp), C.byref(sc)))
+        packed = (m[:n].astype(np.uint64) << np.uint64(48)) | (p[:n].astype(np.uint64) << np.uint64(16)) | \
+                 (z[:n].astype(np.uint64) << np.uint64(8)) | ((iso[:n].astype(np.int64) + 128).astype(np.uint64))
+        return packed, int(mp.value), int(sc.value)
+
+    def brute_force(self, params: ScorerParams, batch: SpectrumBatch, i: int, charge: int, iso: int, cap=1 << 16):
+        lib = load()
+        p = np.zeros(cap, np.uint32); m = np.zeros(cap, np.uint32); h = np.zeros(cap, np.float64)
+        cp = params.to_c(); cb = batch.to_c()
+        n = int(lib.orc_brute_force(self.h, C.byref(cp), C.byref(cb), i, charge, iso, L.as_ptr(p, C.c_uint32),
+                                    L.as_ptr(m, C.c_uint32), h.ctypes.data_as(C.POINTER(C.c_double)), cap))
+        return p[:n], m[:n], h[:n]
+
+    def close(self):
+        if self.h:
+            load().orc_db_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def process_ms2(take_top_n, deisotope, min_deisotope_mz, mz, intensity, precursor_charge):
+    lib = load()
+    mz = np.ascontiguousarray(mz, np.float32); it = np.ascontiguousarray(intensity, np.float32)
+    n = len(mz)
+    om = np.zeros(max(n, 1), np.float32); oi = np.zeros(max(n, 1), np.float32); tic = C.c_float()
+    k = int(lib.orc_process_ms2(take_top_n, int(deisotope), min_deisotope_mz, L.as_ptr(mz, C.c_float),
+                                L.as_ptr(it, C.c_float), n, precursor_charge or 0, L.as_ptr(om, C.c_float),
+                                L.as_ptr(oi, C.c_float), C.byref(tic)))
+    return om[:k].copy(), oi[:k].copy(), float(np.float32(tic.value))
+
+
+def tol_bounds(tol, center):
+    lo, hi = C.c_float(), C.c_float()
+    load().orc_tol_bounds(tol.to_c(), center, C.byref(lo), C.byref(hi))
+    return np.float32(lo.value), np.float32(hi.value)

@@ -1,0 +1,96 @@
+"""Pins the CPU oracle (oracle/) to the reference's own known-answer tests.  CPU only."""
+import base64
+import json
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib
+from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch, Tolerance
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_c1():
+    d = json.load(open(os.path.join(HERE, "golden", "c1_fixture.json")))
+    s = d["spectra"][0]
+    mz = np.frombuffer(base64.b64decode(s["mz_f32_b64"]), dtype="<f4")
+    it = np.frombuffer(base64.b64decode(s["intensity_f32_b64"]), dtype="<f4")
+    return d, s, mz, it
+
+
+def c1_batch(process):
+    """The inputs of crates/sage-cli/tests/integration.rs:7-52, via `process` = a SpectrumProcessor(100, true, 0.0)."""
+    d, s, mz, it = load_c1()
+    charge = int(s["selected_ion"]["MS:1000041"])
+    prec_mz = np.float32(float(s["selected_ion"]["MS:1000744"]))  # parsed straight to f32, mzml.rs:244-248
+    masses, intens, tic = process(100, True, 0.0, mz, it, charge)
+    lo, hi = -np.float32(float(s["isolation"]["MS:1000828"])), np.float32(float(s["isolation"]["MS:1000829"]))
+    batch = SpectrumBatch([0, len(masses)], masses, intens, [prec_mz], [charge], [tic], [lo], [hi],
+                          [np.float32(float(s["scan_start_time"]))], None, [0])
+    return d, batch
+
+
+def integration_scorer():
+    return ScorerParams(precursor_tol=Tolerance("ppm", -50.0, 50.0), fragment_tol=Tolerance("ppm", -10.0, 10.0),
+                        min_matched_peaks=4, min_isotope_err=-1, max_isotope_err=3, min_precursor_charge=2,
+                        max_precursor_charge=4, override_precursor_charge=False, max_fragment_charge=1, chimera=False,
+                        report_psms=1, wide_window=False, score_type="SageHyperScore")
+
+
+def test_oracle_selftest_reference_unit_vectors():
+    """oracle/selftest.cpp restates the reference's unit tests (mass.rs:143-157, database.rs:569-671,
+    scoring.rs:799-830, ion_series.rs:129-328, heap.rs:62-100, spectrum.rs:419-627, enzyme.rs:401-700,
+    peptide.rs:429-720, crates/sage/tests/integration.rs:30-70)."""
+    oracle_lib.load()
+    r = subprocess.run([oracle_lib.SELFTEST], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout
+
+
+def test_oracle_c1_known_answer():
+    """crates/sage-cli/tests/integration.rs:47-49: exactly one PSM with matched_peaks == 21."""
+    d, batch = c1_batch(oracle_lib.process_ms2)
+    assert batch.n == 1 and len(batch.masses) <= 300
+    db = oracle_lib.OracleDb.build(d["fasta"], DatabaseParameters())  # Builder::default()
+    feats, counts, _, _ = db.score(integration_scorer(), batch)
+    assert counts[0] == d["known_answer"]["n_psm"] == 1
+    assert feats[0, 0]["matched_peaks"] == d["known_answer"]["matched_peaks"] == 21
+    # the PSM is LQSRPAAPPAPGPGQLTLR, z=3, isotope error 0
+    pep = db.peptide_strings()[feats[0, 0]["peptide_idx"]]
+    assert pep == "LQSRPAAPPAPGPGQLTLR"
+    assert feats[0, 0]["charge"] == 3 and feats[0, 0]["isotope_error"] == 0.0 and feats[0, 0]["label"] == 1
+
+
+def test_oracle_c1_config_json_runs():
+    """tests/config.json (C1 plumbing): missed_cleavages 1, bucket 16384, static C mod, isotope errors -1..3."""
+    d, batch = c1_batch(oracle_lib.process_ms2)
+    cfg = d["config_json"]
+    db = oracle_lib.OracleDb.build(d["fasta"], DatabaseParameters.from_json(cfg["database"]))
+    sp = ScorerParams(precursor_tol=Tolerance.from_json(cfg["precursor_tol"]),
+                      fragment_tol=Tolerance.from_json(cfg["fragment_tol"]), min_isotope_err=cfg["isotope_errors"][0],
+                      max_isotope_err=cfg["isotope_errors"][1], max_fragment_charge=cfg["max_fragment_charge"],
+                      report_psms=cfg["report_psms"], chimera=cfg["chimera"])
+    # the CLI uses max_peaks=150 (input.rs:366); the known answer above used 100 — both find the peptide
+    feats, counts, _, _ = db.score(sp, batch)
+    assert counts[0] == 1
+    assert db.peptide_strings()[feats[0, 0]["peptide_idx"]] == "LQSRPAAPPAPGPGQLTLR"
+    assert feats[0, 0]["matched_peaks"] == 21
+
+
+def test_oracle_index_vs_brute_force():
+    """index + k-select agree with scoring every in-window peptide directly."""
+    d, batch = c1_batch(oracle_lib.process_ms2)
+    db = oracle_lib.OracleDb.build(d["fasta"], DatabaseParameters())
+    sp = integration_scorer()
+    feats, counts, _, _ = db.score(sp, batch)
+    best = None
+    for iso in range(-1, 4):
+        p, m, h = db.brute_force(sp, batch, 0, 3, iso)
+        for pi, mi, hi in zip(p, m, h):
+            if mi >= 4 and (best is None or hi > best[2]):
+                best = (pi, mi, hi)
+    assert best is not None
+    assert best[0] == feats[0, 0]["peptide_idx"] and best[1] == feats[0, 0]["matched_peaks"]
+    assert best[2] == feats[0, 0]["hyperscore"]
