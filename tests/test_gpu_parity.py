@@ -1,0 +1,154 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on identical inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from parity_utils import assert_features_equal, assert_initial_hits_equal
+from sage_amd import _lib as L
+from sage_amd.api import (DatabaseParameters, DeviceDatabase, RawSpectrum, Scorer, ScorerParams, SpectrumBatch,
+                          SpectrumProcessor, Tolerance)
+from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
+from test_oracle_golden import c1_batch, integration_scorer
+
+pytestmark = pytest.mark.gpu
+
+
+def product_process(top_n, deiso, min_mz, mz, it, z):
+    out = SpectrumProcessor(top_n, deiso, min_mz).process(RawSpectrum(mz, it, 0.0, z or None))
+    return out.masses, out.intensities, out.total_ion_current
+
+
+class World:
+    def __init__(self, fasta, db_params, spectra_kwargs, n_spectra, seed, max_peaks=150):
+        self.host = db_params.build(fasta)
+        self.dev = DeviceDatabase(self.host, 0)
+        self.orc = oracle_lib.OracleDb.from_product(self.host)
+        raw = synthetic_spectra(self.host, n_spectra, seed, **spectra_kwargs)
+        sp = SpectrumProcessor(max_peaks, True, 0.0)
+        self.batch = SpectrumBatch.from_spectra([sp.process(r) for r in raw])
+
+    def check(self, params, context, hits=True, batch=None, every=1):
+        # OpenMSHyperScore goes through f32 ln_1p: device libm and glibc may differ by an f32 ulp (~6e-8
+        # relative); SageHyperScore only uses f64 ln and is held to 1e-12.  North-star tolerance: 1e-4.
+        rel_tol = 1e-6 if params.score_type == "OpenMSHyperScore" else None
+        batch = batch or self.batch
+        scorer = Scorer(self.dev, params)
+        dbatch = scorer.upload(batch)
+        if hits:
+            assert_initial_hits_equal(scorer, dbatch, self.orc, params, batch, context, every)
+        gf, gc = scorer.score_resident(dbatch)
+        of, oc, _, _ = self.orc.score(params, batch)
+        n = assert_features_equal(gf, gc, of, oc, context, rel_tol)
+        gf2, gc2 = scorer.score(batch)  # the upload+score+download entry point
+        assert_features_equal(gf2, gc2, of, oc, context + " (score_batch)", rel_tol)
+        t = scorer.last_timing()
+        return n, t
+
+
+@pytest.fixture(scope="module")
+def small_world(gpu_required):
+    fasta = synthetic_fasta(300, seed=11)
+    params = DatabaseParameters(bucket_size=2048, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                                static_mods={"C": 57.0215}, variable_mods={"M": [15.9949]})
+    return World(fasta, params, {}, 600, seed=21)
+
+
+def test_c1_known_answer_on_gpu(gpu_required):
+    """crates/sage-cli/tests/integration.rs:7-52 through the HIP path: 1 PSM, matched_peaks == 21."""
+    d, batch = c1_batch(product_process)
+    host = DatabaseParameters().build(d["fasta"])
+    dev = DeviceDatabase(host, 0)
+    params = integration_scorer()
+    scorer = Scorer(dev, params)
+    feats, counts = scorer.score(batch)
+    assert counts[0] == 1 and feats[0, 0]["matched_peaks"] == 21
+    assert host.peptide_string(int(feats[0, 0]["peptide_idx"])) == "LQSRPAAPPAPGPGQLTLR"
+    orc = oracle_lib.OracleDb.from_product(host)
+    of, oc, _, _ = orc.score(params, batch)
+    assert_features_equal(feats, counts, of, oc, "C1")
+    assert_initial_hits_equal(scorer, scorer.upload(batch), orc, params, batch, "C1")
+
+
+def test_narrow_search_known_charge(small_world):
+    n, t = small_world.check(ScorerParams(), "narrow ±10ppm")
+    assert n > 300  # most non-noise spectra are identified
+    assert t["n_wide"] == 0
+
+
+def test_report_psms_and_score_types(small_world):
+    small_world.check(ScorerParams(report_psms=5, precursor_tol=Tolerance("ppm", -50.0, 50.0)), "report_psms=5")
+    small_world.check(ScorerParams(score_type="OpenMSHyperScore", min_matched_peaks=2), "OpenMS score")
+    small_world.check(ScorerParams(report_psms=30, precursor_tol=Tolerance("da", -3.0, 3.0)), "report_psms=30 (k=60)")
+
+
+def test_isotope_errors_and_fragment_charge(small_world):
+    small_world.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, precursor_tol=Tolerance("ppm", -20.0, 20.0)),
+                      "isotope -1..3")
+    small_world.check(ScorerParams(min_isotope_err=1, max_isotope_err=1), "isotope 1..1 quirk (searches 0)")
+    small_world.check(ScorerParams(max_fragment_charge=1), "max_fragment_charge=1")
+    small_world.check(ScorerParams(max_fragment_charge=3, fragment_tol=Tolerance("da", -0.02, 0.02)), "frag Da tol")
+    small_world.check(ScorerParams(fragment_tol=Tolerance("pct", -0.001, 0.001)), "frag pct tol")
+
+
+def test_unknown_and_overridden_precursor_charge(small_world):
+    b = small_world.batch
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8),
+                            b.total_ion_current, b.isolation_lo, b.isolation_hi, b.scan_start_time,
+                            b.inverse_ion_mobility, b.file_id)
+    small_world.check(ScorerParams(), "charge None -> 2..4", batch=unknown)
+    small_world.check(ScorerParams(override_precursor_charge=True, min_precursor_charge=1, max_precursor_charge=5,
+                                   min_isotope_err=-1, max_isotope_err=1), "override charge 1..5 x iso -1..1")
+
+
+def test_wide_tolerance_hits_large_window_path(small_world):
+    """±150 Da on a small database: the window exceeds the LDS counter capacity for many spectra, so the
+    large-window kernel runs; results must still be identical."""
+    idx = np.arange(0, small_world.batch.n, 6)
+    sub = small_world.batch.subset(idx)
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -300.0, 300.0)), "open ±300 Da", batch=sub)
+    assert t["n_wide"] > 0
+
+
+def test_chimera_and_wide_window(gpu_required):
+    fasta = synthetic_fasta(150, seed=12)
+    params = DatabaseParameters(bucket_size=1024, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                                static_mods={"C": 57.0215})
+    w = World(fasta, params, dict(chimeric=3, isolation_half_width=6.0, annotate_charge=False), 200, seed=22)
+    w.check(ScorerParams(chimera=True, report_psms=5), "chimera, charge None")
+    w.check(ScorerParams(chimera=True, wide_window=True, report_psms=5), "chimera + wide_window (DIA-style)")
+    w.check(ScorerParams(wide_window=True, report_psms=3), "wide_window only")
+    no_iso = SpectrumBatch(w.batch.peak_off, w.batch.masses, w.batch.intensities, w.batch.precursor_mz,
+                           w.batch.precursor_charge, w.batch.total_ion_current)
+    w.check(ScorerParams(wide_window=True), "wide_window without isolation window (Da ±2.4 default)", batch=no_iso)
+
+
+def test_edge_cases(small_world):
+    b = small_world.batch
+    host = small_world.host
+    # empty spectrum, one-peak spectrum, precursor below / above every peptide, duplicated peaks
+    masses = [np.zeros(0, np.float32), np.array([500.0], np.float32), b.masses[:100].copy(), b.masses[:100].copy(),
+              np.repeat(b.masses[int(b.peak_off[5]):int(b.peak_off[6])], 2)]
+    intens = [np.zeros(0, np.float32), np.array([10.0], np.float32), b.intensities[:100].copy(),
+              b.intensities[:100].copy(), np.repeat(b.intensities[int(b.peak_off[5]):int(b.peak_off[6])], 2)]
+    masses[2] = np.sort(masses[2]); masses[3] = np.sort(masses[3])
+    prec = [600.0, 600.0, 50.0, 9000.0, float(b.precursor_mz[5])]
+    z = [2, 2, 2, 2, int(b.precursor_charge[5])]
+    off = np.cumsum([0] + [len(m) for m in masses])
+    eb = SpectrumBatch(off, np.concatenate(masses), np.concatenate(intens), prec, z,
+                       [float(np.sum(i, dtype=np.float32)) for i in intens])
+    small_world.check(ScorerParams(), "edge cases", batch=eb)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -5000.0, 5000.0), min_matched_peaks=1), "edge, all peptides",
+                      batch=eb)
+    # empty batch
+    scorer = Scorer(small_world.dev, ScorerParams())
+    feats, counts = scorer.score(SpectrumBatch([0], [], [], [], [], []))
+    assert feats.shape[0] == 0 and counts.shape[0] == 0
+
+
+def test_error_paths(small_world):
+    with pytest.raises(L.SageHipError):
+        Scorer(small_world.dev, ScorerParams(report_psms=0))
+    with pytest.raises(L.SageHipError):
+        Scorer(small_world.dev, ScorerParams(annotate_matches=True))
+    with pytest.raises(L.SageHipError):
+        Scorer(small_world.dev, ScorerParams(min_isotope_err=2, max_isotope_err=1))
