@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's rocpd sqlite output (gpurun_out/prof/*/…_results.db) into the small text summaries that
+are committed under profiles/.  Usage: python profiles/summarize_rocprof.py <tag> <trace.db> [<pmc.db> ...]"""
+import json
+import sqlite3
+import sys
+
+
+def main():
+    tag = sys.argv[1]
+    trace = sys.argv[2]
+    pmcs = sys.argv[3:]
+    out = []
+    con = sqlite3.connect(trace)
+    out.append(f"# rocprofv3 --kernel-trace --stats  ({tag})\n")
+    out.append(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'pct':>6}\n")
+    kernels = {}
+    for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        short = name.replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        kernels[short] = avg
+        out.append(f"{short:<70} {calls:>6} {total:>12.1f} {avg:>10.2f} {pct:>6.2f}\n")
+    out.append("\n# per-dispatch resources\n")
+    q = ("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, sgpr_count, count(*) "
+         "from kernels group by name, grid_x, workgroup_x, lds_size")
+    try:
+        for r in con.execute(q):
+            short = r[0].replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            out.append(f"{short:<40} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]} n={r[7]}\n")
+    except sqlite3.Error as e:
+        out.append(f"(resource query failed: {e})\n")
+    traffic = {}
+    for p in pmcs:
+        c = sqlite3.connect(p)
+        out.append(f"\n# rocprofv3 --pmc  ({p.split('/')[-2]})  values are per dispatch; FETCH_SIZE/WRITE_SIZE in KiB\n")
+        for name, ctr, n, avg, mn, mx in c.execute(
+                "select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+                "group by kernel_name, counter_name"):
+            short = name.replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            out.append(f"{short:<40} {ctr:<12} n={n:<4} avg={avg:>14.2f} min={mn:>14.2f} max={mx:>14.2f}\n")
+            traffic.setdefault(short, {})[ctr] = avg
+    # HBM bytes per launch, corrected as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE under-reports
+    # coalesced reads by 2x on gfx950 (x2), WRITE_SIZE taken as is; both counters are KiB.
+    tj = {}
+    for k, v in traffic.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+            key = "prelim" if k.startswith("prelim_kernel<false>") else ("rescore" if k.startswith("rescore") else None)
+            if key:
+                tj[key + "_bytes_per_launch"] = b
+                tj[key + "_raw"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}
+            out.append(f"HBM traffic {k:<40} (2*FETCH+WRITE)*1024 = {b/1e6:.1f} MB per launch\n")
+    open(f"profiles/{tag}_rocprof_summary.txt", "w").write("".join(out))
+    if tj:
+        tj["source"] = f"profiles/{tag}_rocprof_summary.txt"
+        json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
+    print("".join(out))
+
+
+if __name__ == "__main__":
+    main()
