@@ -101,7 +101,7 @@ struct SageDeviceBatch {
     DevBuf<uint64_t> peak_off;
     DevBuf<float> masses, intensities, precursor_mz, iso_lo, iso_hi, tic, rt, ims;
     DevBuf<uint8_t> charge;
-    DevBuf<uint32_t> file_id;
+    DevBuf<uint32_t> file_id, order;
     DevBatchView view{};
 };
 
@@ -271,7 +271,7 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     const uint32_t n_iso = (uint32_t)(p->max_isotope_err - p->min_isotope_err) + 1;
     const uint32_t n_z = (uint32_t)(p->max_precursor_charge - p->min_precursor_charge) + 1;
     d.list_cap = d.kmax * (std::max(n_iso, n_z) + 1);
-    d.wcap = 4096;
+    d.wcap = 1024;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::max(64, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -329,6 +329,19 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
                           (!p.wide_window && !p.override_precursor_charge && z <= zmax);
         if (used) fzcap = std::max(fzcap, sagecore::max_fragment_charge(p.max_fragment_charge, z) - 1);
     }
+    // schedule spectra by ascending neutral precursor mass: wavefronts resident together then read
+    // overlapping ranges of the peptide-major index and of the ion table (outputs keep input order)
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    {
+        std::vector<float> key(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t z = b->precursor_charge[i] ? b->precursor_charge[i] : p.min_precursor_charge;
+            key[i] = (b->precursor_mz[i] - sagecore::PROTON) * (float)z;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
+    }
+    HIP_TRY(d->order.upload(order.data(), n));
     HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));
     HIP_TRY(d->masses.upload(b->masses, total));
     HIP_TRY(d->intensities.upload(b->intensities, total));
@@ -355,6 +368,7 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
     v.rt = d->rt.p;
     v.ims = d->ims.p;
     v.file_id = d->file_id.p;
+    v.order = d->order.p;
     v.pcap = pcap;
     v.fzcap = fzcap;
     *out = d.release();

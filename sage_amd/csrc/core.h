@@ -191,6 +191,36 @@ SAGE_HD uint32_t count_windows_scan(const float* win_lo, const float* win_hi, ui
     return c;
 }
 
+// Lock-step variant of count_windows_sorted over NFZ fragment charges: all 2*NFZ binary searches
+// advance together through fixed power-of-two steps (no data-dependent branches), so their LDS loads
+// overlap instead of forming 2*NFZ serial chains.  `top` = largest power of two <= n (0 when n == 0).
+template <int NFZ>
+SAGE_HD uint32_t count_windows_lockstep(const float* win_lo, const float* win_hi, uint32_t stride, uint32_t n,
+                                        uint32_t top, float frag) {
+    uint32_t a[NFZ], b[NFZ];
+#pragma unroll
+    for (int z = 0; z < NFZ; z++) a[z] = b[z] = 0;
+    for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+        for (int z = 0; z < NFZ; z++) {
+            const uint32_t ia = a[z] + step, ib = b[z] + step;
+            const float va = win_lo[(uint32_t)z * stride + (ia < n ? ia : n) - 1];
+            const float vb = win_hi[(uint32_t)z * stride + (ib < n ? ib : n) - 1];
+            a[z] = (ia <= n && va <= frag) ? ia : a[z];   // a = #{lo <= frag}
+            b[z] = (ib <= n && vb < frag) ? ib : b[z];    // b = #{hi <  frag}
+        }
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int z = 0; z < NFZ; z++) c += a[z] - b[z];
+    return c;
+}
+SAGE_HD uint32_t pow2_floor(uint32_t n) {
+    uint32_t t = 0;
+    if (n) { t = 1; while ((t << 1) <= n && (t << 1)) t <<= 1; }
+    return t;
+}
+
 // ---- select_most_intense_peak (spectrum.rs:134-159) with offset == None ------------------------
 // binary_search_slice(masses, total_cmp, lo, hi) (database.rs:549-561) followed by the filtered scan.
 SAGE_HD int select_most_intense_peak(const float* masses, const float* intensities, uint32_t n, float center,
@@ -210,6 +240,38 @@ SAGE_HD int select_most_intense_peak(const float* masses, const float* intensiti
         if (order_key(masses[mid]) <= khi) a = mid + 1; else b = mid;
     }
     const uint32_t right = a;
+    int best = -1;
+    float max_int = 0.0f;
+    for (uint32_t idx = left; idx < right; idx++) {
+        const float m = masses[idx];
+        if (m >= lo && m <= hi) {
+            const float it = intensities[idx];
+            if (it >= max_int) {
+                max_int = it;
+                best = (int)idx;
+            }
+        }
+    }
+    return best;
+}
+
+// Same result as select_most_intense_peak, with the two partition points found in lock step
+// (`top` = pow2_floor(n)).  right = left + partition_point(slice[left..], <= hi) == max(left, #{m <= hi}).
+SAGE_HD int select_most_intense_peak_lockstep(const float* masses, const float* intensities, uint32_t n, uint32_t top,
+                                              float center, const Tol& tol) {
+    float lo, hi;
+    tol_bounds(tol, center, lo, hi);
+    const int32_t klo = order_key(lo), khi = order_key(hi);
+    uint32_t a = 0, b = 0;
+    for (uint32_t step = top; step; step >>= 1) {
+        const uint32_t ia = a + step, ib = b + step;
+        const int32_t ka = order_key(masses[(ia < n ? ia : n) - 1]);
+        const int32_t kb = order_key(masses[(ib < n ? ib : n) - 1]);
+        a = (ia <= n && ka < klo) ? ia : a;
+        b = (ib <= n && kb <= khi) ? ib : b;
+    }
+    const uint32_t left = a ? a - 1 : 0;
+    const uint32_t right = b > left ? b : left;
     int best = -1;
     float max_int = 0.0f;
     for (uint32_t idx = left; idx < right; idx++) {

@@ -52,6 +52,8 @@ struct DevBatchView {
     const float* rt;            // may be null
     const float* ims;           // may be null
     const uint32_t* file_id;    // may be null
+    const uint32_t* order;      // [n] block b scores spectrum order[b]: ascending precursor mass => neighbouring
+                                //     wavefronts stream overlapping index ranges (L2 reuse); results stay in input order
     uint32_t pcap;              // max peaks per spectrum in this batch
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
 };
@@ -70,6 +72,7 @@ enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2 };
 
 // launch wrappers (kernels.hip)
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool wide);
+uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions);
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 void launch_prelim_wide(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);

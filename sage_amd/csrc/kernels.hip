@@ -93,7 +93,8 @@ struct PrelimLds {
 __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const DevScorer& sc, const DevBatchView& b) {
     PrelimLds l;
     size_t off = 0;
-    l.listA = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    l.listA = (uint64_t*)(smem + off); off += fold ? (size_t)sc.list_cap * 8 : 0;
     l.listB = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
     l.heap = (uint64_t*)(smem + off); off += (size_t)sc.kmax * 8;
     l.win_lo = (float*)(smem + off); off += (size_t)b.fzcap * b.pcap * 4;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
     cnt.p = WIDE ? (w.wide_cnt + (size_t)blockIdx.x * ((size_t)db.np + 1)) : L.cnt;
     if (WIDE && *w.n_deferred == 0) return;
 
-    for (uint32_t spec = blockIdx.x; spec < b.n; spec += gridDim.x) {
+    for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
+        const uint32_t spec = b.order ? b.order[blk] : blk;
         if (WIDE && w.status[spec] != ST_DEFERRED) continue;
         __syncthreads();
         const uint64_t p0 = b.peak_off[spec];
@@ -134,25 +136,27 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
 
         // fragment-tolerance window of every (peak, fragment charge): database.rs:481 on the
         // experimental mass peak*charge of scoring.rs:360
-        bool mono_ok = true;
-        for (uint32_t fz = 1; fz <= nfz_max; fz++) {
-            float* wl = L.win_lo + (size_t)(fz - 1) * b.pcap;
-            float* wh = L.win_hi + (size_t)(fz - 1) * b.pcap;
-            for (uint32_t i = lane; i < P; i += WAVE) {
+        for (uint32_t i = lane; i < P; i += WAVE) {
+            const float m = masses[i];
+            for (uint32_t fz = 1; fz <= nfz_max; fz++) {
                 float lo, hi;
-                tol_bounds(sc.fragment_tol, masses[i] * (float)fz, lo, hi);
-                wl[i] = lo;
-                wh[i] = hi;
-                if (i > 0) {
-                    float plo, phi;
-                    tol_bounds(sc.fragment_tol, masses[i - 1] * (float)fz, plo, phi);
-                    mono_ok = mono_ok && (plo <= lo) && (phi <= hi);
-                }
-                mono_ok = mono_ok && (lo <= hi);
+                tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
+                L.win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
+                L.win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
+            }
+        }
+        __syncthreads();
+        bool mono_ok = true;  // the sorted-count shortcut needs ascending bounds and lo <= hi
+        for (uint32_t fz = 0; fz < nfz_max; fz++) {
+            const float* wl = L.win_lo + (size_t)fz * b.pcap;
+            const float* wh = L.win_hi + (size_t)fz * b.pcap;
+            for (uint32_t i = lane; i < P; i += WAVE) {
+                mono_ok = mono_ok && (wl[i] <= wh[i]);
+                if (i > 0) mono_ok = mono_ok && (wl[i - 1] <= wl[i]) && (wh[i - 1] <= wh[i]);
             }
         }
         const bool sorted_ok = __ballot(!mono_ok) == 0ull;
-        __syncthreads();
+        const uint32_t ptop = pow2_floor(P);
 
         const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
         Tol iso_tol;
@@ -185,7 +189,13 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 tol_bounds(ptol, center, plo, phi);
                 uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
                 left = left ? left - 1 : 0;
-                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, db.np, order_key(phi));
+                // the window is short in a narrow search: bracket it by galloping from `left` before searching
+                uint32_t ghi = left;
+                for (uint64_t span = WAVE;; span *= 16) {
+                    ghi = (uint64_t)left + span < db.np ? (uint32_t)(left + span) : db.np;
+                    if (ghi == db.np || order_key(db.pep_mono[ghi - 1]) > order_key(phi)) break;
+                }
+                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, ghi, order_key(phi));
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
                 if (!WIDE && potential > sc.wcap) {
                     deferred = true;
@@ -200,19 +210,35 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 uint32_t acc = 0;
                 if (first < end) {
                     const uint64_t f0 = db.pm_off[first], f1 = db.pm_off[end];
-                    for (uint64_t j = f0 + lane; j < f1; j += WAVE) {
-                        const SageTheoretical fr = db.pm_frag[j];
-                        uint32_t c = 0;
-                        for (uint32_t fz = 0; fz < nfz; fz++) {
-                            const float* wl = L.win_lo + (size_t)fz * b.pcap;
-                            const float* wh = L.win_hi + (size_t)fz * b.pcap;
-                            c += sorted_ok ? count_windows_sorted(wl, wh, P, fr.fragment_mz)
-                                           : count_windows_scan(wl, wh, P, fr.fragment_mz);
+                    auto count_one = [&](float frag) -> uint32_t {
+                        if (!sorted_ok) {
+                            uint32_t c = 0;
+                            for (uint32_t fz = 0; fz < nfz; fz++)
+                                c += count_windows_scan(L.win_lo + (size_t)fz * b.pcap, L.win_hi + (size_t)fz * b.pcap, P, frag);
+                            return c;
                         }
-                        if (c) {
-                            cnt.add(fr.peptide_index - left, c);
-                            acc += c;
+                        switch (nfz) {
+                            case 1: return count_windows_lockstep<1>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
+                            case 2: return count_windows_lockstep<2>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
+                            case 3: return count_windows_lockstep<3>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
+                            default: {
+                                uint32_t c = 0;
+                                for (uint32_t fz = 0; fz < nfz; fz++)
+                                    c += count_windows_sorted(L.win_lo + (size_t)fz * b.pcap, L.win_hi + (size_t)fz * b.pcap, P, frag);
+                                return c;
+                            }
                         }
+                    };
+                    // two fragments per lane per trip: both 8-byte loads are in flight before the LDS searches
+                    for (uint64_t j = f0 + lane; j < f1; j += 2 * WAVE) {
+                        const SageTheoretical fr0 = db.pm_frag[j];
+                        const bool has1 = j + WAVE < f1;
+                        SageTheoretical fr1 = fr0;
+                        if (has1) fr1 = db.pm_frag[j + WAVE];
+                        const uint32_t c0 = count_one(fr0.fragment_mz);
+                        const uint32_t c1 = has1 ? count_one(fr1.fragment_mz) : 0;
+                        if (c0) { cnt.add(fr0.peptide_index - left, c0); acc += c0; }
+                        if (c1) { cnt.add(fr1.peptide_index - left, c1); acc += c1; }
                     }
                 }
                 const uint32_t matched = wave_sum(acc);
@@ -227,16 +253,32 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 const uint32_t k = trim_k(potential, sc.report_psms);
                 uint32_t scored = 0;
                 if (potential <= k) {
+                    // no k-select: the slots go to the list verbatim (lane-parallel CList append)
+                    uint32_t st = __shfl(target.stored, 0, 64);
+                    uint64_t ln = (uint64_t)__shfl((uint32_t)target.len, 0, 64) |
+                                  ((uint64_t)__shfl((uint32_t)(target.len >> 32), 0, 64) << 32);
+                    bool fits = true;
                     for (uint32_t base = 0; base < potential; base += WAVE) {
                         const uint32_t i = base + lane;
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
-                        scored += (uint32_t)__popcll(__ballot(c > 0));
-                    }
-                    if (lane == 0) {
-                        for (uint32_t i = 0; i < potential; i++) {
-                            const uint32_t c = cnt.get(i);
-                            ok = clist_push(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, sc.kmax) && ok;
+                        const uint64_t nz = __ballot(c > 0);
+                        scored += (uint32_t)__popcll(nz);
+                        const bool store = i < potential && (ln + lane < sc.kmax || c > 0);  // clist_push's rule
+                        const uint64_t sm = __ballot(store);
+                        const uint32_t pos = st + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                        if (store) {
+                            if (pos < target.cap) target.items[pos] = c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY;
+                            else fits = false;
                         }
+                        st += (uint32_t)__popcll(sm);
+                        const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
+                        ln += nvalid;
+                    }
+                    fits = __ballot(!fits) == 0ull;
+                    if (lane == 0) {
+                        target.stored = st < target.cap ? st : target.cap;
+                        target.len = ln;
+                        ok = ok && fits;
                     }
                 } else {
                     for (uint32_t i = lane; i < k; i += WAVE) {
@@ -312,19 +354,32 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
     return __builtin_isfinite(score) ? score : 255.0;
 }
 
+// Rescoring is split in two phases per candidate chunk so that all 64 lanes stay busy and the
+// order-sensitive f32 sums still run in the reference's (kind, index, charge) order:
+//   A. every (candidate, ion, fragment charge) item of the chunk is matched in parallel
+//      (select_most_intense_peak, spectrum.rs:134-159) -> res[item] = peak index or NONE, in LDS;
+//   B. one lane per candidate walks ITS items in order and accumulates (scoring.rs:704-754).
+constexpr uint16_t RES_NONE = 0xFFFFu;
+
 __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                      const double* __restrict__ lnfact_table, uint32_t lnfact_n,
-                                                     SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+                                                     uint32_t tcap, SageFeature* __restrict__ out,
+                                                     uint32_t* __restrict__ out_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
-    const uint32_t spec = blockIdx.x;
-    if (spec >= b.n) return;
-    // LDS: sorted hyperscores [64] f64 | sort keys [64] i64 | peak masses | intensities | remove flags x2
-    double* s_sorted = (double*)smem;
-    long long* s_key = (long long*)(smem + 64 * 8);
-    float* pm = (float*)(smem + 128 * 8);
-    float* pi = pm + b.pcap;
-    uint8_t* rm = (uint8_t*)(pi + b.pcap);
+    if (blockIdx.x >= b.n) return;
+    const uint32_t spec = b.order ? b.order[blockIdx.x] : blockIdx.x;
+    // LDS carve
+    double* s_sorted = (double*)smem;                         // [64] hyperscores by rank
+    long long* s_key = (long long*)(smem + 64 * 8);           // [64] sort keys by lane
+    unsigned long long* s_ionbase = (unsigned long long*)(smem + 128 * 8);  // [64] ion table offset per candidate
+    uint32_t* s_incl = (uint32_t*)(smem + 192 * 8);           // [64] inclusive item prefix per candidate
+    uint32_t* s_nfz = s_incl + 64;                            // [64] fragment charges per candidate
+    float* pm = (float*)(s_nfz + 64);                         // [pcap] peak masses
+    float* pi = pm + b.pcap;                                  // [pcap] peak intensities
+    float* term = pi + b.pcap;                                // [tcap] ppm term per matched item
+    uint16_t* res = (uint16_t*)(term + tcap);                 // [tcap] matched peak index per item
+    uint8_t* rm = (uint8_t*)(res + tcap);                     // [pcap] chimera: peak selected by the winner
     uint8_t* rm2 = rm + b.pcap;
 
     if (w.status[spec] != ST_OK) {
@@ -345,36 +400,133 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     const uint32_t z = prescore_charge(mine);
     const int iso = prescore_iso(mine);
     const uint32_t mfc = max_fragment_charge(sc.max_fragment_charge, z);
-    const float* ions = nullptr;
+    const uint32_t nfz = mfc - 1;
+    uint64_t ion_base = 0;
     uint32_t lm1 = 0, info = 0;
     float calc = 0.f;
     if (valid) {
-        const uint64_t o0 = db.ion_off[pep], o1 = db.ion_off[pep + 1];
-        ions = db.ions + o0;
-        lm1 = db.n_kinds ? (uint32_t)((o1 - o0) / db.n_kinds) : 0;
+        const uint64_t o1 = db.ion_off[pep + 1];
+        ion_base = db.ion_off[pep];
+        lm1 = db.n_kinds ? (uint32_t)((o1 - ion_base) / db.n_kinds) : 0;
         info = db.pep_info[pep];
         calc = db.pep_mono[pep];
     }
+    // item bookkeeping: n_items per candidate and its inclusive prefix over lanes
+    const uint32_t n_items = valid ? db.n_kinds * lm1 * nfz : 0;
+    uint32_t incl = n_items;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - n_items;
+    s_incl[lane] = incl;
+    s_ionbase[lane] = ion_base;
+    s_nfz[lane] = nfz ? nfz : 1;
+
     const double lambda = (double)w.totals[2 * spec] / (double)w.totals[2 * spec + 1];  // scoring.rs:499
     const float mzp = b.precursor_mz[spec] - PROTON;                                   // scoring.rs:502
     const float rt = b.rt ? b.rt[spec] : 0.0f;
     float ims = 0.0f;
     if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
     const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
+    const uint32_t total_items = __shfl(incl, 63, 64);
     __syncthreads();
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
     const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
     uint32_t n_emitted = 0;
     for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t ptop = pow2_floor(P);
         Score s;
         s.peptide = pep;
         s.precursor_charge = z;
         s.isotope_error = iso;
+        s.matched_b = s.matched_y = 0;
+        s.summed_b = s.summed_y = 0.0f;
+        s.ppm_difference = 0.0f;
+        s.longest_b = s.longest_y = 0;
+        // ---- score_candidate over chunks of candidates whose items fit in res[] ----
+        uint32_t base = 0;  // item offset where the current chunk starts
+        while (base < total_items) {
+            // chunk = candidates with excl >= base and incl <= base + tcap (contiguous lanes)
+            const bool in_chunk = n_items && excl >= base && incl - base <= tcap;
+            uint32_t chunk_items = in_chunk ? incl - base : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(chunk_items, off, 64);
+                chunk_items = o > chunk_items ? o : chunk_items;
+            }
+            if (chunk_items == 0) break;  // a single candidate larger than tcap cannot happen (tcap >= max items)
+            // phase A: the ion mass of the NEXT item is fetched before the current one is matched, so the
+            // global-load latency overlaps the LDS searches
+            auto locate = [&](uint32_t t, uint32_t& charge) -> float {
+                const uint32_t g = base + t;  // global item index
+                uint32_t c = 0;               // first candidate with incl > g
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) {
+                    const uint32_t probe = c + step;
+                    c = (probe <= 64 && s_incl[probe - 1] <= g) ? probe : c;
+                }
+                const uint32_t local = g - (c ? s_incl[c - 1] : 0);
+                const uint32_t cz = s_nfz[c];
+                const uint32_t ion = local / cz;
+                charge = local - ion * cz + 1;
+                return db.ions[s_ionbase[c] + ion];
+            };
+            uint32_t charge = 1, ncharge = 1;
+            float frag = 0.0f, nfrag = 0.0f;
+            if (lane < chunk_items) frag = locate(lane, charge);
+            for (uint32_t t = lane; t < chunk_items; t += WAVE) {
+                if (t + WAVE < chunk_items) nfrag = locate(t + WAVE, ncharge);
+                const float mz = frag / (float)charge;
+                const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, mz, sc.fragment_tol);
+                if (pk >= 0) {
+                    const float peak_mass = pm[pk];
+                    res[t] = (uint16_t)pk;
+                    // the per-match ppm term of scoring.rs:719-720; only its accumulation is order-sensitive
+                    term[t] = pi[pk] * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
+                } else {
+                    res[t] = RES_NONE;
+                }
+                frag = nfrag;
+                charge = ncharge;
+            }
+            __syncthreads();
+            // phase B
+            if (in_chunk) {
+                Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
+                uint32_t t = excl - base;
+                for (uint32_t k = 0; k < db.n_kinds; k++) {
+                    const bool nterm_kind = db.ion_kinds[k] <= 2;
+                    for (uint32_t idx = 0; idx < lm1; idx++) {
+                        for (uint32_t c = 1; c < mfc; c++, t++) {
+                            const uint16_t r = res[t];
+                            if (r == RES_NONE) continue;
+                            const float peak_intensity = pi[r];
+                            s.ppm_difference += term[t];
+                            if (nterm_kind) {
+                                s.matched_b += 1;
+                                s.summed_b += peak_intensity;
+                                run_matched(b_run, idx);
+                            } else {
+                                s.matched_y += 1;
+                                s.summed_y += peak_intensity;
+                                run_matched(y_run, idx);
+                            }
+                        }
+                    }
+                }
+                s.longest_b = b_run.longest;
+                s.longest_y = y_run.longest;
+            }
+            __syncthreads();
+            base += chunk_items;
+        }
         double h = 0.0;
         bool pass = false;
         if (valid) {
-            score_candidate(s, ions, lm1, db.ion_kinds, db.n_kinds, mfc, pm, pi, P, sc.fragment_tol);
+            s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
             h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
             pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
         }
@@ -444,16 +596,15 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         // ---- remove_matched_peaks(winner), scoring.rs:598-644 ----
         const uint64_t wmask = __ballot(pass && rank == 0);
         const uint32_t wl = (uint32_t)__ffsll((long long)wmask) - 1;
-        const uint32_t wpep = __shfl(pep, wl, 64);
         const uint32_t wmfc = __shfl(mfc, wl, 64);
-        const uint64_t wo0 = db.ion_off[wpep], wo1 = db.ion_off[wpep + 1];
-        const float* wions = db.ions + wo0;
-        const uint32_t n_items = (uint32_t)(wo1 - wo0) * (wmfc - 1);
+        const uint32_t w_items = __shfl(n_items, wl, 64);
+        const unsigned long long w_base = s_ionbase[wl];
+        const float* wions = db.ions + w_base;
         for (uint32_t i = lane; i < P; i += WAVE) rm[i] = 0;
         __syncthreads();
-        for (uint32_t t = lane; t < n_items; t += WAVE) {
+        for (uint32_t t = lane; t < w_items; t += WAVE) {
             const uint32_t ion = t / (wmfc - 1), charge = t % (wmfc - 1) + 1;
-            const int pk = select_most_intense_peak(pm, pi, P, wions[ion] / (float)charge, sc.fragment_tol);
+            const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, wions[ion] / (float)charge, sc.fragment_tol);
             if (pk >= 0) rm[pk] = 1;
         }
         __syncthreads();
@@ -467,8 +618,8 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         }
         __syncthreads();
         uint32_t newP = 0;
-        for (uint32_t base = 0; base < P; base += WAVE) {
-            const uint32_t i = base + lane;
+        for (uint32_t bs = 0; bs < P; bs += WAVE) {
+            const uint32_t i = bs + lane;
             const bool keep = i < P && !rm2[i];
             const float mi = i < P ? pm[i] : 0.f, ii = i < P ? pi[i] : 0.f;
             const uint64_t km = __ballot(keep);
@@ -490,12 +641,18 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
 }  // namespace
 
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool wide) {
-    size_t n = (size_t)sc.list_cap * 16 + (size_t)sc.kmax * 8 + (size_t)b.fzcap * b.pcap * 8;
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 + (size_t)b.fzcap * b.pcap * 8;
     if (!wide) n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }
-size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t) {
-    size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
+uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions) {
+    // one candidate's items must always fit: (ions of the longest peptide) x (fragment charges)
+    const uint32_t need = max_ions * (b.fzcap ? b.fzcap : 1);
+    return need > 1024 ? need : 1024;
+}
+size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t max_ions) {
+    size_t n = 192 * 8 + 128 * 4 + (size_t)b.pcap * 8 + (size_t)rescore_item_cap(b, max_ions) * 6 + (size_t)b.pcap * 2;
     return (n + 15) & ~(size_t)15;
 }
 
@@ -514,7 +671,7 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     uint32_t* out_count, void* stream) {
     if (b.n == 0) return;
     hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions), (hipStream_t)stream, db,
-                       sc, b, w, lnfact_table, lnfact_n, out, out_count);
+                       sc, b, w, lnfact_table, lnfact_n, rescore_item_cap(b, max_ions), out, out_count);
 }
 
 }  // namespace sagehip
