@@ -213,6 +213,10 @@ typedef struct SageTiming {
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 
+/* Debug aid, only with SAGE_HIP_PHASE_CLOCKS=1 at scorer creation: cumulative shader cycles per kernel phase,
+ * out16[0..7] = preliminary kernel, out16[8..15] = rescoring kernel. */
+int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out16);
+
 const char* sage_hip_last_error(void);
 int sage_hip_abi_version(void);
 

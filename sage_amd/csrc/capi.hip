@@ -86,6 +86,7 @@ struct SageScorer {
     hipEvent_t ev[4] = {};
     DevBuf<double> lnfact;
     DevBuf<uint32_t> wide_cnt;
+    DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t wide_blocks = 0;
     SageTiming timing{};
     // per-batch work buffers, grown on demand
@@ -288,6 +289,12 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     if (const char* e = getenv("SAGE_HIP_WIDE_BLOCKS")) s->wide_blocks = (uint32_t)std::max(1, atoi(e));
     HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * ((size_t)db->view.np + 1)));
     HIP_TRY(s->n_deferred.alloc(1));
+    if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
+        if (atoi(e) > 0) {
+            HIP_TRY(s->dbg.alloc(4096 * 16));
+            HIP_TRY(hipMemset(s->dbg.p, 0, 4096 * 16 * 8));
+        }
+    }
     *out = s.release();
     return SAGE_HIP_OK;
 }
@@ -409,6 +416,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     w.n_deferred = s->n_deferred.p;
     w.wide_cnt = s->wide_cnt.p;
     w.wide_blocks = s->wide_blocks;
+    w.dbg = s->dbg.p;
     HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 4, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
@@ -487,6 +495,18 @@ int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, u
         if (matched_peaks) matched_peaks[i] = tot[2 * i];
         if (scored_candidates) scored_candidates[i] = tot[2 * i + 1];
     }
+    return SAGE_HIP_OK;
+}
+
+// debugging aid (not part of the drop-in surface): cumulative per-phase shader cycles, [2][8]
+int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out16) {
+    if (!s || !out16) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (!s->dbg.p) return fail(SAGE_HIP_ERR_INVALID, "set SAGE_HIP_PHASE_CLOCKS=1 before creating the scorer");
+    std::vector<unsigned long long> all(4096 * 16);
+    HIP_TRY(hipMemcpy(all.data(), s->dbg.p, all.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (size_t b = 0; b < 4096; b++)
+        for (int k = 0; k < 16; k++) out16[k] += all[b * 16 + k];
     return SAGE_HIP_OK;
 }
 

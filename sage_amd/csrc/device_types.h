@@ -66,6 +66,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* n_deferred;  // [1]
     uint32_t* wide_cnt;    // [wide_blocks * (np + 1)] global counter scratch for the large-window path
     uint32_t wide_blocks;
+    unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)
 };
 
 enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2 };

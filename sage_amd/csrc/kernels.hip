@@ -22,6 +22,25 @@ namespace {
 
 constexpr uint32_t WAVE = 64;
 
+// optional per-phase cycle accounting (DevWork::dbg != null): the first DBG_BLOCKS blocks of a launch
+// store clock deltas into their own slot [block][kernel*8 + phase] (no atomics: nothing is perturbed)
+constexpr uint32_t DBG_BLOCKS = 4096;
+struct PhaseClock {
+    unsigned long long* slot;
+    long long t;
+    __device__ __forceinline__ void start(unsigned long long* dbg, uint32_t blk, uint32_t kernel) {
+        slot = (dbg && blk < DBG_BLOCKS) ? dbg + (size_t)blk * 16 + kernel * 8 : nullptr;
+        if (slot) t = clock64();
+    }
+    __device__ __forceinline__ void mark(int phase) {
+        if (slot) {
+            const long long n = clock64();
+            if ((threadIdx.x & 63u) == 0) slot[phase] += (unsigned long long)(n - t);
+            t = n;
+        }
+    }
+};
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -81,6 +100,108 @@ struct Counters {
     }
 };
 
+// ---- k-select state kept in registers: lane i holds heap element i (k <= 64) -------------------
+// bounded_min_heapify (heap.rs:7-60) is inherently sequential, but every index it touches is
+// wave-uniform, so the heap can live one element per lane and be driven with v_readlane/v_writelane
+// (a few cycles each) instead of dependent LDS round trips.
+struct WaveHeap {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ uint64_t wh_get(const WaveHeap& h, uint32_t idx) {
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)h.hi, (int)idx) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)h.lo, (int)idx);
+}
+__device__ __forceinline__ void wh_set(WaveHeap& h, uint32_t idx, uint64_t v) {
+    const bool me = lane_id() == idx;  // v_writelane as compare + select (idx and v are wave-uniform)
+    h.lo = me ? (uint32_t)v : h.lo;
+    h.hi = me ? (uint32_t)(v >> 32) : h.hi;
+}
+__device__ __forceinline__ uint64_t lane_value(uint64_t v, uint32_t src_lane) {  // broadcast lane src_lane's v
+    src_lane = __builtin_amdgcn_readfirstlane(src_lane);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
+}
+__device__ __forceinline__ void wh_sift_down(WaveHeap& h, uint32_t len, uint32_t index) {  // heap.rs:40-60
+    const uint64_t moving = wh_get(h, index);
+    for (;;) {
+        const uint32_t l = index * 2 + 1;
+        if (l >= len) break;
+        uint32_t smallest = index;
+        uint64_t sv = moving;
+        const uint64_t vl = wh_get(h, l);
+        if (vl < sv) { smallest = l; sv = vl; }
+        const uint32_t r = l + 1;
+        if (r < len) {
+            const uint64_t vr = wh_get(h, r);
+            if (vr < sv) { smallest = r; sv = vr; }
+        }
+        if (smallest == index) break;
+        wh_set(h, index, sv);       // slice.swap(smallest, index)
+        wh_set(h, smallest, moving);
+        index = smallest;
+    }
+}
+__device__ __forceinline__ void wh_build(WaveHeap& h, uint32_t k) {  // heap.rs:13-15
+    for (uint32_t i = k / 2; i-- > 0;) wh_sift_down(h, k, i);
+}
+__device__ __forceinline__ void wh_offer(WaveHeap& h, uint32_t k, uint64_t v) {  // heap.rs:21-27
+    if (k && v > wh_get(h, 0)) {
+        wh_set(h, 0, v);
+        wh_sift_down(h, k, 0);
+    }
+}
+
+// CList (core.h) with wave-uniform bookkeeping: every lane holds the same stored/len, appends are
+// lane-parallel (ballot prefix), trims run on a WaveHeap.
+struct UList {
+    uint64_t* items;
+    uint32_t stored, cap;
+    uint64_t len;
+    bool ok;
+};
+// append `nvalid` (<= 64) logical entries, lane i supplying entry i (clist_push's rule per entry)
+__device__ __forceinline__ void ulist_append(UList& c, uint64_t v, uint32_t nvalid, uint32_t kmax) {
+    const uint32_t lane = lane_id();
+    const bool store = lane < nvalid && (c.len + lane < kmax || v != PRESCORE_EMPTY);
+    const uint64_t sm = __ballot(store);
+    const uint32_t pos = c.stored + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+    if (store && pos < c.cap) c.items[pos] = v;
+    const uint32_t total = c.stored + (uint32_t)__popcll(sm);
+    c.ok = c.ok && total <= c.cap;
+    c.stored = total <= c.cap ? total : c.cap;
+    c.len += nvalid;
+}
+__device__ __forceinline__ void ulist_append_empties(UList& c, uint64_t n, uint32_t kmax) {  // clist_push_empties
+    const uint64_t room = c.len < kmax ? kmax - c.len : 0;
+    const uint32_t lit = (uint32_t)(n < room ? n : room);  // < kmax <= 64
+    if (lit) ulist_append(c, PRESCORE_EMPTY, lit, kmax);
+    c.len += n - lit;
+}
+// trim_hits (scoring.rs:322-329)
+__device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms) {
+    const uint32_t lane = lane_id();
+    const uint32_t k = trim_k(c.len, report_psms);
+    if (c.len > k) {
+        __syncthreads();
+        WaveHeap h;
+        const uint64_t mine = lane < k ? c.items[lane] : PRESCORE_EMPTY;
+        h.lo = (uint32_t)mine;
+        h.hi = (uint32_t)(mine >> 32);
+        wh_build(h, k);
+        for (uint32_t base = k; base < c.stored; base += WAVE) {
+            const uint64_t v = base + lane < c.stored ? c.items[base + lane] : PRESCORE_EMPTY;
+            const uint32_t n = c.stored - base < WAVE ? c.stored - base : WAVE;
+            for (uint32_t j = 0; j < n; j++) wh_offer(h, k, lane_value(v, j));
+        }
+        __syncthreads();
+        if (lane < k) c.items[lane] = ((uint64_t)h.hi << 32) | h.lo;
+        __syncthreads();
+    }
+    c.stored = k;
+    c.len = k;
+}
+
 struct PrelimLds {
     float* win_lo;
     float* win_hi;
@@ -116,6 +237,8 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         const uint32_t spec = b.order ? b.order[blk] : blk;
         if (WIDE && w.status[spec] != ST_DEFERRED) continue;
         __syncthreads();
+        PhaseClock pc;
+        pc.start(WIDE ? nullptr : w.dbg, blk, 0);
         const uint64_t p0 = b.peak_off[spec];
         const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
         const float* __restrict__ masses = b.masses + p0;
@@ -157,6 +280,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         }
         const bool sorted_ok = __ballot(!mono_ok) == 0ull;
         const uint32_t ptop = pow2_floor(P);
+        pc.mark(0);
 
         const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
         Tol iso_tol;
@@ -170,18 +294,17 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
         const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
 
-        CList A, B;  // meaningful on lane 0 only
-        A.items = L.listA; A.cap = sc.list_cap; clist_clear(A);
-        B.items = L.listB; B.cap = sc.list_cap; clist_clear(B);
-        bool ok = true;          // lane 0: list capacity respected
-        bool deferred = false;   // uniform
+        UList A, B;  // wave-uniform state
+        A.items = L.listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
+        B.items = L.listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
+        bool deferred = false;                     // uniform
         uint32_t tot_matched = 0, tot_scored = 0;  // uniform
 
         for (uint32_t z = z0; z <= z1 && !deferred; z++) {
             const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
             const float precursor_mass = mzp * (float)z;
             const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
-            if (fold && lane == 0) clist_clear(A);
+            if (fold) { A.stored = 0; A.len = 0; }
             for (int iso = isoA; iso <= isoB && !deferred; iso++) {
                 // ---- IndexedDatabase::query, database.rs:402-425 ----
                 const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
@@ -201,6 +324,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                     deferred = true;
                     break;
                 }
+                pc.mark(1);
                 cnt.zero(potential, lane);
                 // edge rule of database.rs:526-531: interior indices are in range by construction
                 uint32_t first = left, end = right;
@@ -229,12 +353,18 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                             }
                         }
                     };
-                    // two fragments per lane per trip: both 8-byte loads are in flight before the LDS searches
-                    for (uint64_t j = f0 + lane; j < f1; j += 2 * WAVE) {
-                        const SageTheoretical fr0 = db.pm_frag[j];
+                    // software-pipelined stream over the window's fragments: the next trip's two 8-byte
+                    // loads are issued before this trip's LDS searches
+                    SageTheoretical n0{0, 0.f}, n1{0, 0.f};
+                    uint64_t j = f0 + lane;
+                    if (j < f1) n0 = db.pm_frag[j];
+                    if (j + WAVE < f1) n1 = db.pm_frag[j + WAVE];
+                    for (; j < f1; j += 2 * WAVE) {
+                        const SageTheoretical fr0 = n0, fr1 = n1;
                         const bool has1 = j + WAVE < f1;
-                        SageTheoretical fr1 = fr0;
-                        if (has1) fr1 = db.pm_frag[j + WAVE];
+                        const uint64_t jn = j + 2 * WAVE;
+                        if (jn < f1) n0 = db.pm_frag[jn];
+                        if (jn + WAVE < f1) n1 = db.pm_frag[jn + WAVE];
                         const uint32_t c0 = count_one(fr0.fragment_mz);
                         const uint32_t c1 = has1 ? count_one(fr1.fragment_mz) : 0;
                         if (c0) { cnt.add(fr0.peptide_index - left, c0); acc += c0; }
@@ -243,76 +373,61 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 }
                 const uint32_t matched = wave_sum(acc);
                 __syncthreads();
+                pc.mark(2);
                 tot_matched += matched;
-                CList& target = fold ? A : B;
+                UList& target = fold ? A : B;
                 if (matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
-                    if (lane == 0) ok = clist_push_empties(target, potential, sc.kmax) && ok;
+                    ulist_append_empties(target, potential, sc.kmax);
                     continue;
                 }
                 // ---- trim_hits of this query, scoring.rs:380 ----
                 const uint32_t k = trim_k(potential, sc.report_psms);
                 uint32_t scored = 0;
-                if (potential <= k) {
-                    // no k-select: the slots go to the list verbatim (lane-parallel CList append)
-                    uint32_t st = __shfl(target.stored, 0, 64);
-                    uint64_t ln = (uint64_t)__shfl((uint32_t)target.len, 0, 64) |
-                                  ((uint64_t)__shfl((uint32_t)(target.len >> 32), 0, 64) << 32);
-                    bool fits = true;
+                if (potential <= k) {  // no k-select: the slots go to the list verbatim
                     for (uint32_t base = 0; base < potential; base += WAVE) {
                         const uint32_t i = base + lane;
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
-                        const uint64_t nz = __ballot(c > 0);
-                        scored += (uint32_t)__popcll(nz);
-                        const bool store = i < potential && (ln + lane < sc.kmax || c > 0);  // clist_push's rule
-                        const uint64_t sm = __ballot(store);
-                        const uint32_t pos = st + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-                        if (store) {
-                            if (pos < target.cap) target.items[pos] = c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY;
-                            else fits = false;
-                        }
-                        st += (uint32_t)__popcll(sm);
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
                         const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
-                        ln += nvalid;
-                    }
-                    fits = __ballot(!fits) == 0ull;
-                    if (lane == 0) {
-                        target.stored = st < target.cap ? st : target.cap;
-                        target.len = ln;
-                        ok = ok && fits;
+                        ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
                     }
                 } else {
-                    for (uint32_t i = lane; i < k; i += WAVE) {
-                        const uint32_t c = cnt.get(i);
-                        L.heap[i] = c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY;
-                        scored += c > 0;
+                    WaveHeap h;
+                    {
+                        const uint32_t c = lane < k ? cnt.get(lane) : 0;
+                        const uint64_t v = c ? pack_prescore(c, left + lane, z, iso) : PRESCORE_EMPTY;
+                        h.lo = (uint32_t)v;
+                        h.hi = (uint32_t)(v >> 32);
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
                     }
-                    scored = wave_sum(scored);
-                    __syncthreads();
-                    if (lane == 0) heap_build(L.heap, k);
+                    wh_build(h, k);
                     for (uint32_t base = k; base < potential; base += WAVE) {
                         const uint32_t i = base + lane;
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
+                        const uint64_t v = pack_prescore(c, left + i, z, iso);
                         uint64_t mask = __ballot(c > 0);
                         scored += (uint32_t)__popcll(mask);
-                        if (lane == 0) {
-                            while (mask) {
-                                const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
-                                mask &= mask - 1;
-                                const uint32_t ii = base + bit;
-                                heap_offer(L.heap, k, pack_prescore(cnt.get(ii), left + ii, z, iso));
-                            }
+                        while (mask) {  // in slot order; empty slots can never displace the heap minimum
+                            const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            wh_offer(h, k, lane_value(v, bit));
                         }
                     }
-                    if (lane == 0) {
-                        for (uint32_t i = 0; i < k; i++) ok = clist_push(target, L.heap[i], sc.kmax) && ok;
-                    }
+                    ulist_append(target, ((uint64_t)h.hi << 32) | h.lo, k, sc.kmax);
                 }
                 tot_scored += scored;
                 __syncthreads();
+                pc.mark(3);
             }
-            if (fold && !deferred && lane == 0) {  // scoring.rs:405 then `hits +=` at :432 / :450
-                clist_trim(A, sc.report_psms);
-                for (uint32_t i = 0; i < A.stored; i++) ok = clist_push(B, A.items[i], sc.kmax) && ok;
+            if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
+                ulist_trim(A, sc.report_psms);
+                __syncthreads();
+                for (uint32_t base = 0; base < A.stored; base += WAVE) {
+                    const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
+                    const uint32_t nvalid = A.stored - base < WAVE ? A.stored - base : WAVE;
+                    ulist_append(B, v, nvalid, sc.kmax);
+                }
+                __syncthreads();
             }
         }
         if (deferred) {
@@ -322,16 +437,16 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
             }
             continue;
         }
+        ulist_trim(B, sc.report_psms);  // scoring.rs:460
+        __syncthreads();
         if (lane == 0) {
-            clist_trim(B, sc.report_psms);  // scoring.rs:460
-            w.status[spec] = ok ? ST_OK : ST_OVERFLOW;
+            w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
             w.cand_len[spec] = B.stored;
             w.totals[2 * spec] = tot_matched;
             w.totals[2 * spec + 1] = tot_scored;
         }
-        __syncthreads();
-        const uint32_t nst = __shfl(B.stored, 0, 64);
-        for (uint32_t i = lane; i < nst; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
+        for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
+        pc.mark(4);
     }
 }
 
@@ -386,6 +501,8 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         if (lane == 0) out_count[spec] = 0;
         return;
     }
+    PhaseClock pc;
+    pc.start(w.dbg, blockIdx.x, 1);
     const uint64_t p0 = b.peak_off[spec];
     uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
     for (uint32_t i = lane; i < P; i += WAVE) {
@@ -432,6 +549,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
     const uint32_t total_items = __shfl(incl, 63, 64);
     __syncthreads();
+    pc.mark(0);
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
     const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
@@ -493,6 +611,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
                 charge = ncharge;
             }
             __syncthreads();
+            pc.mark(1);
             // phase B
             if (in_chunk) {
                 Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
@@ -521,6 +640,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
                 s.longest_y = y_run.longest;
             }
             __syncthreads();
+            pc.mark(2);
             base += chunk_items;
         }
         double h = 0.0;
@@ -548,6 +668,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
             s_sorted[rank] = h;
         }
         __syncthreads();
+        pc.mark(3);
         if (pass && rank < per_round) {  // scoring.rs:504-594
             const double next = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
             const double best = s_sorted[0];
@@ -589,6 +710,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
             for (int q = 0; q < 6; q++) f.pad[q] = 0;
             out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
         }
+        pc.mark(4);
         const uint32_t emitted = npass < per_round ? npass : per_round;
         n_emitted += emitted;
         if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
