@@ -213,6 +213,11 @@ typedef struct SageTiming {
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 
+/* Page-locked host memory for `out` / `out_count`: results then arrive by DMA at full PCIe rate instead of
+ * through the runtime's staging copy.  Optional — any host pointer is accepted by the scoring calls. */
+int sage_hip_host_alloc(uint64_t bytes, void** out);
+void sage_hip_host_free(void* p);
+
 /* Debug aid, only with SAGE_HIP_PHASE_CLOCKS=1 at scorer creation: cumulative shader cycles per kernel phase,
  * out16[0..7] = preliminary kernel, out16[8..15] = rescoring kernel. */
 int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out16);

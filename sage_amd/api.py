@@ -401,9 +401,32 @@ class Scorer:
         return DeviceBatch(self, batch)
 
     def _alloc_out(self, n):
-        feats = np.zeros(n * self.params.report_psms, dtype=L.FEATURE_DTYPE)
-        counts = np.zeros(n, dtype=np.uint32)
+        """Output arrays in page-locked host memory (sage_hip_host_alloc), reused while the size is unchanged.
+        NOTE: a later call with the same batch size overwrites the arrays returned by the previous one."""
+        key = (n, self.params.report_psms)
+        cached = getattr(self, "_pinned", None)
+        if cached is None or cached[0] != key:
+            self._free_pinned()
+            lib = L.load()
+            nb_f = max(n * self.params.report_psms, 1) * L.FEATURE_DTYPE.itemsize
+            nb_c = max(n, 1) * 4
+            pf, pc = C.c_void_p(), C.c_void_p()
+            L.check(lib.sage_hip_host_alloc(nb_f, C.byref(pf)))
+            L.check(lib.sage_hip_host_alloc(nb_c, C.byref(pc)))
+            feats = np.frombuffer((C.c_char * nb_f).from_address(pf.value), dtype=L.FEATURE_DTYPE,
+                                  count=n * self.params.report_psms)
+            counts = np.frombuffer((C.c_char * nb_c).from_address(pc.value), dtype=np.uint32, count=n)
+            self._pinned = (key, pf, pc, feats, counts)
+        _, _, _, feats, counts = self._pinned
         return feats, counts
+
+    def _free_pinned(self):
+        cached = getattr(self, "_pinned", None)
+        if cached is not None:
+            lib = L.load()
+            lib.sage_hip_host_free(cached[1])
+            lib.sage_hip_host_free(cached[2])
+            self._pinned = None
 
     def score_resident(self, dbatch: DeviceBatch):
         lib = L.load()
@@ -440,6 +463,7 @@ class Scorer:
 
     def close(self):
         if self._h:
+            self._free_pinned()
             L.load().sage_hip_scorer_destroy(self._h)
             self._h = None
 

@@ -94,6 +94,7 @@ struct SageScorer {
     DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count;
     DevBuf<SageFeature> features;
     uint32_t work_n = 0;
+    uint32_t* h_counters = nullptr;  // pinned [2]: deferred, overflow
 };
 
 struct SageDeviceBatch {
@@ -288,7 +289,8 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     s->wide_blocks = 64;
     if (const char* e = getenv("SAGE_HIP_WIDE_BLOCKS")) s->wide_blocks = (uint32_t)std::max(1, atoi(e));
     HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * ((size_t)db->view.np + 1)));
-    HIP_TRY(s->n_deferred.alloc(1));
+    HIP_TRY(s->n_deferred.alloc(2));
+    HIP_TRY(hipHostMalloc((void**)&s->h_counters, 16, hipHostMallocDefault));
     if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
         if (atoi(e) > 0) {
             HIP_TRY(s->dbg.alloc(4096 * 16));
@@ -305,6 +307,7 @@ void sage_hip_scorer_destroy(SageScorer* s) {
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
     delete s;
 }
 
@@ -417,7 +420,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     w.wide_cnt = s->wide_cnt.p;
     w.wide_blocks = s->wide_blocks;
     w.dbg = s->dbg.p;
-    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 4, s->stream));
+    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 8, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
     launch_prelim_wide(s->db->view, s->dev, b->view, w, s->stream);
@@ -426,6 +429,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
         launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
                        s->features.p, s->out_count.p, s->stream);
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipGetLastError());
     return SAGE_HIP_OK;
 }
@@ -435,8 +439,7 @@ static int finish_timing(SageScorer* s, bool with_rescore) {
     float a = 0, c = 0;
     HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
     HIP_TRY(hipEventElapsedTime(&c, s->ev[1], s->ev[2]));
-    uint32_t ndef = 0;
-    HIP_TRY(hipMemcpy(&ndef, s->n_deferred.p, 4, hipMemcpyDeviceToHost));
+    const uint32_t ndef = s->h_counters[0];  // copied on the stream before the caller's synchronize
     s->timing.prelim_ms = a;
     s->timing.rescore_ms = with_rescore ? c : 0.f;
     s->timing.total_ms = a + c;
@@ -455,12 +458,14 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = finish_timing(s, true);
     if (rc != SAGE_HIP_OK) return rc;
-    std::vector<uint32_t> st(b->n);
-    HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < b->n; i++)
-        if (st[i] != ST_OK)
-            return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": preliminary pass status " +
-                                                      std::to_string(st[i]) + " (candidate list capacity)");
+    if (s->h_counters[1]) {  // rare: find the offending spectrum for the message
+        std::vector<uint32_t> st(b->n);
+        HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < b->n; i++)
+            if (st[i] != ST_OK)
+                return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": preliminary pass status " +
+                                                          std::to_string(st[i]) + " (candidate list capacity)");
+    }
     return SAGE_HIP_OK;
 }
 
@@ -508,6 +513,15 @@ int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out16) {
     for (size_t b = 0; b < 4096; b++)
         for (int k = 0; k < 16; k++) out16[k] += all[b * 16 + k];
     return SAGE_HIP_OK;
+}
+
+int sage_hip_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return SAGE_HIP_OK;
+}
+void sage_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int sage_hip_last_timing(const SageScorer* s, SageTiming* out) {

@@ -63,7 +63,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* cand_len;    // [n]
     uint32_t* totals;      // [n * 2] InitialHits.matched_peaks, .scored_candidates
     uint32_t* status;      // [n] 0 ok, 1 deferred to the large-window path, 2 list overflow
-    uint32_t* n_deferred;  // [1]
+    uint32_t* n_deferred;  // [2]: [0] spectra deferred to the large-window path, [1] list overflows
     uint32_t* wide_cnt;    // [wide_blocks * (np + 1)] global counter scratch for the large-window path
     uint32_t wide_blocks;
     unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)

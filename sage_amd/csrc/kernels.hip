@@ -440,6 +440,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         ulist_trim(B, sc.report_psms);  // scoring.rs:460
         __syncthreads();
         if (lane == 0) {
+            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + 1, 1u);
             w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
             w.cand_len[spec] = B.stored;
             w.totals[2 * spec] = tot_matched;
@@ -592,12 +593,18 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
                 charge = local - ion * cz + 1;
                 return db.ions[s_ionbase[c] + ion];
             };
-            uint32_t charge = 1, ncharge = 1;
-            float frag = 0.0f, nfrag = 0.0f;
-            if (lane < chunk_items) frag = locate(lane, charge);
+            // A0: gather every item's ion mass into term[] first — the loads of different trips are
+            //     independent, so several are in flight per lane; A1 then matches out of LDS and overwrites
+            //     term[t] (read and written by the same lane) with the ppm term.
+#pragma unroll 4
             for (uint32_t t = lane; t < chunk_items; t += WAVE) {
-                if (t + WAVE < chunk_items) nfrag = locate(t + WAVE, ncharge);
-                const float mz = frag / (float)charge;
+                uint32_t charge;
+                term[t] = locate(t, charge);
+                res[t] = (uint16_t)charge;
+            }
+            __syncthreads();
+            for (uint32_t t = lane; t < chunk_items; t += WAVE) {
+                const float mz = term[t] / (float)res[t];
                 const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, mz, sc.fragment_tol);
                 if (pk >= 0) {
                     const float peak_mass = pm[pk];
@@ -607,8 +614,6 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
                 } else {
                     res[t] = RES_NONE;
                 }
-                frag = nfrag;
-                charge = ncharge;
             }
             __syncthreads();
             pc.mark(1);
