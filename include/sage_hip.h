@@ -209,7 +209,8 @@ typedef struct SageTiming {
     float rescore_ms;  /* rescoring + top-K + Feature kernel */
     float total_ms;    /* first launch -> last kernel done (excludes H2D/D2H) */
     uint32_t n_launches;
-    uint32_t n_wide;   /* spectra routed to the large-window path */
+    uint32_t n_wide;   /* spectra routed to either large-window kernel */
+    uint32_t n_open;   /* ... of which to the m/z-major open-search kernel */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 
@@ -221,6 +222,7 @@ void sage_hip_host_free(void* p);
 /* Debug aid, only with SAGE_HIP_PHASE_CLOCKS=1 at scorer creation: cumulative shader cycles per kernel phase,
  * out16[0..7] = preliminary kernel, out16[8..15] = rescoring kernel. */
 int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out16);
+int sage_hip_debug_phase_raw(SageScorer* scorer, unsigned long long* out /* [nblocks][16] */, uint32_t nblocks);
 
 const char* sage_hip_last_error(void);
 int sage_hip_abi_version(void);

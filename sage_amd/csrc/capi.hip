@@ -72,6 +72,8 @@ struct SageDeviceDb {
     // the reference-shaped bucketed index, resident for the large-window path
     DevBuf<SageTheoretical> fragments;
     DevBuf<float> min_value;
+    DevBuf<SageTheoretical> mz_frag;  // m/z-major copy for the open-search kernel
+    DevBuf<uint32_t> mz_lut;
     uint64_t bucket_size = 0;
     uint32_t max_ions = 0;
     DevDbView view{};
@@ -85,7 +87,9 @@ struct SageScorer {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {};
     DevBuf<double> lnfact;
-    DevBuf<uint32_t> wide_cnt;
+    DevBuf<uint32_t> wide_cnt, open_cnt;
+    uint32_t open_blocks = 0;
+    uint64_t open_words = 0, wide_words = 0;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t wide_blocks = 0;
     SageTiming timing{};
@@ -209,6 +213,42 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
                                 v->ion_kinds[k], ions.data() + ion_off[i] + (uint64_t)k * lm1);
         }
     });
+    // m/z-major copy: the reference's buckets are already globally ordered by m/z (database.rs:301, 337-346);
+    // ordering each bucket by (m/z, peptide) restores the global sort.  mz_lut[b] = #fragments with m/z < b/scale.
+    if (nf >= 0xFFFFFFFFull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-2 fragments");
+    std::vector<SageTheoretical> mzs(v->fragments, v->fragments + nf);
+    {
+        const uint64_t bs = v->bucket_size ? v->bucket_size : nf;
+        const uint64_t nb = bs ? (nf + bs - 1) / bs : 0;
+        parallel_for(nb, 4, [&](size_t bb, size_t be, unsigned) {
+            for (size_t bk = bb; bk < be; bk++) {
+                const uint64_t a = bk * bs, e = std::min<uint64_t>(a + bs, nf);
+                std::sort(mzs.begin() + a, mzs.begin() + e, [](const SageTheoretical& x, const SageTheoretical& y) {
+                    const int32_t kx = sagecore::order_key(x.fragment_mz), ky = sagecore::order_key(y.fragment_mz);
+                    return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
+                });
+            }
+        });
+        for (uint64_t i = 1; i < nf; i++)
+            if (sagecore::order_key(mzs[i - 1].fragment_mz) > sagecore::order_key(mzs[i].fragment_mz))
+                return fail(SAGE_HIP_ERR_INVALID, "IndexedDatabase.fragments is not bucket-ordered by m/z (database.rs:301)");
+    }
+    const float lut_scale = 512.0f;  // 1/512 Da cells: ~10 MB of table for a 5000 Da fragment range
+    float max_mz = 0.0f;
+    for (uint64_t i = 0; i < nf; i++)
+        if (mzs[i].fragment_mz > max_mz && std::isfinite(mzs[i].fragment_mz)) max_mz = mzs[i].fragment_mz;
+    const uint32_t lut_n = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
+    std::vector<uint32_t> lut(lut_n);
+    {
+        uint64_t pos = 0;
+        for (uint32_t bn = 0; bn < lut_n; bn++) {
+            const double edge = (double)bn / (double)lut_scale;
+            while (pos < nf && (double)mzs[pos].fragment_mz < edge) pos++;
+            lut[bn] = (uint32_t)pos;
+        }
+    }
+    HIP_TRY(d->mz_frag.upload(mzs.data(), nf));
+    HIP_TRY(d->mz_lut.upload(lut.data(), lut_n));
     HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
     HIP_TRY(d->pm_frag.upload(pm.data(), nf));
     HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
@@ -226,11 +266,16 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     d->view.ions = d->ions.p;
     d->view.ion_off = d->ion_off.p;
     d->view.pep_info = d->pep_info.p;
+    d->view.mz_frag = d->mz_frag.p;
+    d->view.mz_lut = d->mz_lut.p;
+    d->view.lut_n = lut_n;
+    d->view.lut_scale = lut_scale;
+    d->view.nf = nf;
     std::memset(d->view.ion_kinds, 0, sizeof d->view.ion_kinds);
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
     d->bytes = d->pep_mono.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
-               d->pep_info.bytes() + d->fragments.bytes() + d->min_value.bytes();
+               d->pep_info.bytes() + d->fragments.bytes() + d->min_value.bytes() + d->mz_frag.bytes() + d->mz_lut.bytes();
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -274,6 +319,10 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     const uint32_t n_z = (uint32_t)(p->max_precursor_charge - p->min_precursor_charge) + 1;
     d.list_cap = d.kmax * (std::max(n_iso, n_z) + 1);
     d.wcap = 1024;
+    d.dbg_flags = 0;
+    if (const char* e = getenv("SAGE_HIP_DEBUG_FLAGS")) d.dbg_flags = (uint32_t)atoi(e);
+    d.open_thresh = 2048;
+    if (const char* e = getenv("SAGE_HIP_OPEN_THRESH")) d.open_thresh = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::max(64, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -286,10 +335,21 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
         tbl[n] = x * std::log(x) - x + 0.5 * std::log(x) + 0.5 * std::log(M_PI * 2.0 * x);
     }
     HIP_TRY(s->lnfact.upload(tbl.data(), tbl.size()));
-    s->wide_blocks = 64;
+    // mid-window kernel: windows above wcap but not above open_thresh (when the open-search kernel exists they
+    // never exceed open_thresh slots)
+    s->wide_blocks = 2048;
     if (const char* e = getenv("SAGE_HIP_WIDE_BLOCKS")) s->wide_blocks = (uint32_t)std::max(1, atoi(e));
-    HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * ((size_t)db->view.np + 1)));
-    HIP_TRY(s->n_deferred.alloc(2));
+    s->wide_words = std::min<uint64_t>((uint64_t)db->view.np + 1, (uint64_t)d.open_thresh + 1);
+    HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * s->wide_words));
+    if ((uint64_t)db->view.np + 1 > d.open_thresh) {  // otherwise no window can ever exceed the threshold
+        s->open_words = (((uint64_t)db->view.np + 2 + 4 * 64) / 2 + 1) & ~1ull;
+        const uint64_t budget = 24ull << 30;  // HBM set aside for counter slabs (288 GB per GPU)
+        s->open_blocks = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, budget / (s->open_words * 4)));
+        if (const char* e = getenv("SAGE_HIP_OPEN_BLOCKS")) s->open_blocks = (uint32_t)std::max(1, atoi(e));
+        HIP_TRY(s->open_cnt.alloc((size_t)s->open_blocks * s->open_words));
+        HIP_TRY(hipMemset(s->open_cnt.p, 0, (size_t)s->open_blocks * s->open_words * 4));
+    }
+    HIP_TRY(s->n_deferred.alloc(4));
     HIP_TRY(hipHostMalloc((void**)&s->h_counters, 16, hipHostMallocDefault));
     if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
         if (atoi(e) > 0) {
@@ -419,17 +479,22 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     w.n_deferred = s->n_deferred.p;
     w.wide_cnt = s->wide_cnt.p;
     w.wide_blocks = s->wide_blocks;
+    w.wide_words = s->wide_words;
+    w.open_cnt = s->open_cnt.p;
+    w.open_blocks = s->open_blocks;
+    w.open_words = s->open_words;
     w.dbg = s->dbg.p;
-    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 8, s->stream));
+    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 16, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
     launch_prelim_wide(s->db->view, s->dev, b->view, w, s->stream);
+    launch_prelim_open(s->db->view, s->dev, b->view, w, s->stream);
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (with_rescore)
         launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
                        s->features.p, s->out_count.p, s->stream);
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, 16, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipGetLastError());
     return SAGE_HIP_OK;
 }
@@ -439,12 +504,13 @@ static int finish_timing(SageScorer* s, bool with_rescore) {
     float a = 0, c = 0;
     HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
     HIP_TRY(hipEventElapsedTime(&c, s->ev[1], s->ev[2]));
-    const uint32_t ndef = s->h_counters[0];  // copied on the stream before the caller's synchronize
+    const uint32_t ndef = s->h_counters[0] + s->h_counters[2];  // copied on the stream before the caller's synchronize
     s->timing.prelim_ms = a;
     s->timing.rescore_ms = with_rescore ? c : 0.f;
     s->timing.total_ms = a + c;
-    s->timing.n_launches = with_rescore ? 3 : 2;
+    s->timing.n_launches = (with_rescore ? 3 : 2) + (s->open_blocks ? 1 : 0);
     s->timing.n_wide = ndef;
+    s->timing.n_open = s->h_counters[2];
     return SAGE_HIP_OK;
 }
 
@@ -512,6 +578,13 @@ int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out16) {
     for (int k = 0; k < 16; k++) out16[k] = 0;
     for (size_t b = 0; b < 4096; b++)
         for (int k = 0; k < 16; k++) out16[k] += all[b * 16 + k];
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_debug_phase_raw(SageScorer* s, unsigned long long* out, uint32_t nblocks) {
+    if (!s || !out || nblocks > 4096) return fail(SAGE_HIP_ERR_INVALID, "bad argument");
+    if (!s->dbg.p) return fail(SAGE_HIP_ERR_INVALID, "set SAGE_HIP_PHASE_CLOCKS=1 before creating the scorer");
+    HIP_TRY(hipMemcpy(out, s->dbg.p, (size_t)nblocks * 16 * 8, hipMemcpyDeviceToHost));
     return SAGE_HIP_OK;
 }
 

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
     const uint32_t lane = lane_id();
     const PrelimLds L = carve_prelim(smem, sc, b);
     Counters<WIDE> cnt;
-    cnt.p = WIDE ? (w.wide_cnt + (size_t)blockIdx.x * ((size_t)db.np + 1)) : L.cnt;
+    cnt.p = WIDE ? (w.wide_cnt + (size_t)blockIdx.x * w.wide_words) : L.cnt;
     if (WIDE && *w.n_deferred == 0) return;
 
     for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         UList A, B;  // wave-uniform state
         A.items = L.listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
         B.items = L.listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
-        bool deferred = false;                     // uniform
+        bool deferred = false, deferred_open = false;  // uniform
         uint32_t tot_matched = 0, tot_scored = 0;  // uniform
 
         for (uint32_t z = z0; z <= z1 && !deferred; z++) {
@@ -322,6 +322,12 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
                 if (!WIDE && potential > sc.wcap) {
                     deferred = true;
+                    deferred_open = potential > sc.open_thresh && w.open_blocks > 0;
+                    break;
+                }
+                if (WIDE && potential > w.wide_words) {  // a later query of this spectrum is an open-search window
+                    deferred = true;
+                    deferred_open = true;
                     break;
                 }
                 pc.mark(1);
@@ -432,8 +438,8 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         }
         if (deferred) {
             if (lane == 0) {
-                w.status[spec] = ST_DEFERRED;
-                atomicAdd(w.n_deferred, 1u);
+                w.status[spec] = deferred_open ? ST_DEFERRED_OPEN : ST_DEFERRED;
+                atomicAdd(w.n_deferred + (deferred_open ? 2 : 0), 1u);
             }
             continue;
         }
@@ -448,6 +454,213 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         }
         for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
         pc.mark(4);
+    }
+}
+
+
+// ---- open / wide-window searches ------------------------------------------------------------------
+// When the precursor window holds 10^4..10^6 candidates, streaming all of their fragments (peptide-major)
+// is the wrong loop order.  Here every (peak, fragment charge) window is looked up in the m/z-major copy
+// of the index: one table lookup gives a start position, then the wavefront streams the few hundred
+// fragments of that m/z window with coalesced 8-byte loads and bumps a u16 counter per in-window
+// peptide.  Counters live in a per-block slab in HBM that is all-zero between spectra: the k-select
+// scan clears what it reads.  Same predicate as database.rs:526-533, so the counts are identical.
+__global__ __launch_bounds__(64) void prelim_open_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    if (w.n_deferred[2] == 0) return;
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
+    uint64_t* listA = (uint64_t*)smem;
+    uint64_t* listB = listA + (fold ? sc.list_cap : 0);
+    uint32_t* cnt = w.open_cnt + (size_t)blockIdx.x * w.open_words;
+
+    for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
+        const uint32_t spec = b.order ? b.order[blk] : blk;
+        if (w.status[spec] != ST_DEFERRED_OPEN) continue;
+        __syncthreads();
+        PhaseClock pc;
+        pc.start(w.dbg, blk, 0);
+        const uint64_t p0 = b.peak_off[spec];
+        const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+        const float* __restrict__ masses = b.masses + p0;
+        const uint32_t zraw = b.precursor_charge[spec];
+        uint32_t z0, z1;
+        if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {
+            z0 = sc.min_precursor_charge;
+            z1 = sc.max_precursor_charge;
+        } else {
+            z0 = z1 = zraw;
+        }
+        const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
+        Tol iso_tol;
+        iso_tol.kind = 2;
+        iso_tol.lo = -2.4f;
+        iso_tol.hi = 2.4f;  // scoring.rs:430
+        if (b.isolation_lo && b.isolation_hi) {
+            const float a = b.isolation_lo[spec], c = b.isolation_hi[spec];
+            if (a == a && c == c) { iso_tol.lo = a; iso_tol.hi = c; }
+        }
+        const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+        UList A, B;
+        A.items = listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
+        B.items = listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
+        uint32_t tot_matched = 0, tot_scored = 0;
+
+        for (uint32_t z = z0; z <= z1; z++) {
+            const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+            const float precursor_mass = mzp * (float)z;
+            const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
+            if (fold) { A.stored = 0; A.len = 0; }
+            for (int iso = isoA; iso <= isoB; iso++) {
+                const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
+                float plo, phi;
+                tol_bounds(ptol, center, plo, phi);
+                uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
+                left = left ? left - 1 : 0;
+                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, db.np, order_key(phi));
+                const uint32_t potential = right - left + 1;  // scoring.rs:351
+                uint32_t first = left, end = right;           // database.rs:526-531
+                if (left < db.np && !(db.pep_mono[left] >= plo)) first = left + 1;
+                if (right < db.np && db.pep_mono[right] <= phi) end = right + 1;
+
+                // ---- matched-fragment counting, scoring.rs:358-375 ----
+                pc.mark(5);
+                uint32_t acc = 0;
+                if (first < end) {
+                    for (uint32_t i = 0; i < P; i++) {
+                        const float m = masses[i];
+                        for (uint32_t fz = 1; fz <= nfz; fz++) {
+                            float lo, hi;
+                            tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
+                            // conservative start: one table cell below the cell of `lo`
+                            float cell = floorf(lo * db.lut_scale) - 1.0f;
+                            cell = cell > 0.0f ? cell : 0.0f;  // also maps NaN to 0
+                            const uint32_t bin = cell < (float)(db.lut_n - 1) ? (uint32_t)cell : db.lut_n - 1;
+                            // four 8-byte loads per lane are in flight per trip (2 KiB per wavefront)
+                            for (uint64_t j = (uint64_t)db.mz_lut[bin] + lane;; j += 4 * WAVE) {
+                                SageTheoretical fr[4];
+                                bool in[4];
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    in[q] = j + (uint64_t)q * WAVE < db.nf;
+                                    fr[q] = SageTheoretical{0, 0.f};
+                                    if (in[q]) fr[q] = db.mz_frag[j + (uint64_t)q * WAVE];
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const bool hit = in[q] && fr[q].fragment_mz >= lo && fr[q].fragment_mz <= hi &&
+                                                     fr[q].peptide_index >= first && fr[q].peptide_index < end;
+                                    if (hit) {
+                                        const uint32_t idx = fr[q].peptide_index - left;
+                                        if (!(sc.dbg_flags & 2)) atomicAdd(&cnt[idx >> 1], 1u << ((idx & 1) * 16));
+                                        acc++;
+                                    }
+                                }
+                                // ascending m/z: done once the last quarter holds nothing at or below `hi`
+                                if (__ballot(in[3] && !(fr[3].fragment_mz > hi)) == 0ull) break;
+                            }
+                        }
+                    }
+                }
+                const uint32_t matched = wave_sum(acc);
+                // the counters are only ever touched by this wavefront, through L2 (atomics, sc1 loads, write-through
+                // stores): ordering needs the earlier operations to have completed, not an L2 write-back
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pc.mark(6);
+                tot_matched += matched;
+                UList& target = fold ? A : B;
+                if (matched == 0) {  // scoring.rs:376-378 (no counter was touched: the slab is still zero)
+                    ulist_append_empties(target, potential, sc.kmax);
+                    continue;
+                }
+                // ---- trim_hits, scoring.rs:380: one pass over the slots, 4 per lane, clearing as it goes ----
+                const uint32_t k = trim_k(potential, sc.report_psms);
+                const bool select = potential > k;
+                WaveHeap h{0, 0};
+                uint32_t scored = 0;
+                for (uint32_t base = 0; base < ((sc.dbg_flags & 4) ? 256u : potential); base += 4 * WAVE) {
+                    const uint32_t s0 = base + 4 * lane;  // this lane's first slot
+                    uint32_t* wp = cnt + (s0 >> 1);
+                    const uint32_t w0 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t w1 = __hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w0) wp[0] = 0;
+                    if (w1) wp[1] = 0;
+                    uint32_t c[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (s0 + q >= potential) c[q] = 0;
+                        scored += (uint32_t)__popcll(__ballot(c[q] > 0));
+                    }
+                    if (!select) {  // potential <= k <= 64: every slot goes to the list verbatim, in slot order
+                        // slot i sits in lane i/4, sub i%4
+                        uint32_t ci = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t v = __shfl(c[q], (int)(lane >> 2), 64);
+                            if ((lane & 3u) == (uint32_t)q) ci = v;
+                        }
+                        const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
+                        ulist_append(target, ci ? pack_prescore(ci, left + base + lane, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
+                        continue;  // (potential <= 64 => single trip)
+                    }
+                    uint32_t from = 0;  // first slot of this chunk that is offered (slots < k seed the heap)
+                    if (base == 0) {
+                        uint32_t ci = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t v = __shfl(c[q], (int)(lane >> 2), 64);
+                            if ((lane & 3u) == (uint32_t)q) ci = v;
+                        }
+                        const uint64_t v = (lane < k && ci) ? pack_prescore(ci, left + lane, z, iso) : PRESCORE_EMPTY;
+                        h.lo = (uint32_t)v;
+                        h.hi = (uint32_t)(v >> 32);
+                        wh_build(h, k);
+                        from = k;
+                    }
+                    // offers in slot order; a slot can only enter if its count reaches the heap minimum's
+                    const uint32_t hmin = prescore_matched(wh_get(h, 0));
+                    bool cand = false;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cand = cand || (c[q] > 0 && c[q] >= hmin && s0 + q >= from);
+                    uint64_t mask = __ballot(cand);
+                    if (sc.dbg_flags & 1) mask = 0;
+                    while (mask) {
+                        const uint32_t src = (uint32_t)__ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)c[q], (int)__builtin_amdgcn_readfirstlane(src));
+                            const uint32_t slot = base + 4 * src + q;
+                            if (cq && slot >= from) wh_offer(h, k, pack_prescore(cq, left + slot, z, iso));
+                        }
+                    }
+                }
+                if (select) ulist_append(target, ((uint64_t)h.hi << 32) | h.lo, k, sc.kmax);
+                tot_scored += scored;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pc.mark(7);
+            }
+            if (fold) {  // scoring.rs:405 then `hits +=`
+                ulist_trim(A, sc.report_psms);
+                __syncthreads();
+                for (uint32_t base = 0; base < A.stored; base += WAVE) {
+                    const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
+                    const uint32_t nvalid = A.stored - base < WAVE ? A.stored - base : WAVE;
+                    ulist_append(B, v, nvalid, sc.kmax);
+                }
+                __syncthreads();
+            }
+        }
+        ulist_trim(B, sc.report_psms);  // scoring.rs:460
+        __syncthreads();
+        if (lane == 0) {
+            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + 1, 1u);
+            w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
+            w.cand_len[spec] = B.stored;
+            w.totals[2 * spec] = tot_matched;
+            w.totals[2 * spec + 1] = tot_scored;
+        }
+        for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
     }
 }
 
@@ -792,6 +1005,12 @@ void launch_prelim_wide(const DevDbView& db, const DevScorer& sc, const DevBatch
     if (b.n == 0 || w.wide_blocks == 0) return;
     hipLaunchKernelGGL(prelim_kernel<true>, dim3(w.wide_blocks), dim3(64), prelim_lds_bytes(sc, b, true),
                        (hipStream_t)stream, db, sc, b, w);
+}
+void launch_prelim_open(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+    if (b.n == 0 || w.open_blocks == 0) return;
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    const size_t lds = ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(prelim_open_kernel, dim3(w.open_blocks), dim3(64), lds, (hipStream_t)stream, db, sc, b, w);
 }
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,

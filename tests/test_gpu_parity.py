@@ -109,6 +109,28 @@ def test_wide_tolerance_hits_large_window_path(small_world):
     assert t["n_wide"] > 0
 
 
+def test_open_search_kernel_mz_major_path(small_world, monkeypatch):
+    """Force the m/z-major (open-search) kernel with a low threshold: ±500 Da, isotope folding, unknown charge,
+    report_psms > 1 — every branch of the nested k-selects on the dense-counter scan."""
+    monkeypatch.setenv("SAGE_HIP_OPEN_THRESH", "200")
+    idx = np.arange(0, small_world.batch.n, 5)
+    sub = small_world.batch.subset(idx)
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0)), "open -500/+100 Da", batch=sub)
+    assert t["n_open"] > 0 and n > 50
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -40.0, 40.0), min_isotope_err=-1, max_isotope_err=2,
+                                   report_psms=4), "open ±40 Da x iso -1..2", batch=sub)
+    b = sub
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8),
+                            b.total_ion_current)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -60.0, 60.0), max_fragment_charge=2), "open, charge None",
+                      batch=unknown)
+    # windows between wcap and the threshold still take the peptide-major global-counter kernel
+    monkeypatch.setenv("SAGE_HIP_OPEN_THRESH", "800")
+    monkeypatch.setenv("SAGE_HIP_WCAP", "64")
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -20.0, 20.0)), "mixed narrow/mid/open routing", batch=sub)
+    assert 0 < t["n_open"] < t["n_wide"]
+
+
 def test_chimera_and_wide_window(gpu_required):
     fasta = synthetic_fasta(150, seed=12)
     params = DatabaseParameters(bucket_size=1024, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
