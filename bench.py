@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — spectra/sec of the fragment-index search-and-score path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 50 000 synthetic MS2 spectra against a synthetic yeast-sized
-tryptic digest (6 000 proteins, 1 missed cleavage, static C+57.0215, decoys on), ±10 ppm precursor and
-fragment tolerance, report_psms 1.  One "step" = Scorer::score over the whole resident batch
-(preliminary fragment matching + k-select + rescoring + Feature assembly + D2H of the PSM records).
-Spectra are sharded across ranks, the index is replicated per GPU, no collective on the data path
-(weak scaling: every rank scores its own 50 000 spectra).
+Default workload = BASELINE.json configs[2] ("C3", the configuration the metric is quoted on: human tryptic
+narrow search): synthetic human-sized tryptic digest (20 400 proteins, 1 missed cleavage, static C+57.0215,
+variable M+15.9949 and protein-N-term +42.0106, decoys on), ±10 ppm precursor and fragment tolerance,
+report_psms 1, 62 500 synthetic MS2 spectra per GPU (= 500 000 at 8 GPUs).  --config C2 | C4 | C5 select the
+other BASELINE.json configurations.  One "step" = Scorer::score over the whole resident batch (preliminary
+fragment matching + k-select + rescoring + Feature assembly + D2H of the PSM records).  Spectra are sharded
+across ranks, the index is replicated per GPU, no collective on the data path (weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -22,14 +23,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+_ENZ1 = dict(missed_cleavages=1, min_len=5, max_len=50, cleave_at="KR", restrict="P")
+_ENZ2 = dict(missed_cleavages=2, min_len=5, max_len=50, cleave_at="KR", restrict="P")
+_DB = dict(bucket_size=8192, peptide_min_mass=500.0, peptide_max_mass=5000.0, static_mods={"C": 57.0215}, generate_decoys=True)
+
+# BASELINE.json configs[1..4] (recipes: SURVEY.md §8d).  `spectra` is the size the config names; `per_gpu` is what ONE
+# rank scores (weak scaling: at --gpus 8 the whole job is exactly the named size for C3/C4/C5).
 CONFIGS = {
-    # BASELINE.json configs[1]
     "C2": dict(name="C2: 50k synthetic MS2 x yeast-like tryptic digest, ±10 ppm narrow search", proteins=6000,
-               fasta_seed=1001, spectra=50000, spectra_seed=2001,
-               db=dict(bucket_size=8192, enzyme=dict(missed_cleavages=1, min_len=5, max_len=50, cleave_at="KR", restrict="P"),
-                       peptide_min_mass=500.0, peptide_max_mass=5000.0, static_mods={"C": 57.0215}, generate_decoys=True),
-               scorer=dict(), spectra_kwargs=dict()),
+               fasta_seed=1001, spectra=50000, per_gpu=50000, spectra_seed=2001, db=dict(_DB, enzyme=_ENZ1),
+               scorer=dict(), spectra_kwargs=dict(), cpu_sample=50000,
+               metric="spectra/sec (whole node), fragment-index search-and-score, narrow search"),
+    "C3": dict(name="C3: 500k synthetic MS2 x human-like tryptic digest + 2 variable mods (M+15.9949, protein N-term "
+                    "+42.0106), ±10 ppm narrow search, 62 500 spectra per GPU", proteins=20400,
+               fasta_seed=1002, spectra=500000, per_gpu=62500, spectra_seed=2002,
+               db=dict(_DB, enzyme=_ENZ1, variable_mods={"M": [15.9949], "[": [42.010565]}, max_variable_mods=2),
+               scorer=dict(), spectra_kwargs=dict(varmod_frac=0.15), cpu_sample=62500,
+               metric="spectra/sec (whole node), fragment-index search-and-score, human tryptic narrow search"),
+    "C4": dict(name="C4: 100k synthetic MS2 x human-like tryptic digest (2 missed cleavages, variable M+15.9949), open "
+                    "search da[-500,100], 12 500 spectra per GPU", proteins=20400,
+               fasta_seed=1002, spectra=100000, per_gpu=12500, spectra_seed=2004,
+               db=dict(_DB, enzyme=_ENZ2, variable_mods={"M": [15.9949]}, max_variable_mods=2),
+               scorer=dict(precursor_tol=("da", -500.0, 100.0)), spectra_kwargs=dict(mass_shift_frac=0.3),
+               cpu_sample=2048,
+               metric="spectra/sec (whole node), fragment-index search-and-score, open search"),
+    "C5": dict(name="C5: 200k chimeric synthetic MS2 (2-3 peptides per 12 Th isolation window, no charge annotation) x "
+                    "human-like tryptic digest + 2 variable mods, wide_window + chimera, report_psms 5, 25 000 spectra per GPU",
+               proteins=20400, fasta_seed=1002, spectra=200000, per_gpu=25000, spectra_seed=2005,
+               db=dict(_DB, enzyme=_ENZ1, variable_mods={"M": [15.9949], "[": [42.010565]}, max_variable_mods=2),
+               scorer=dict(wide_window=True, chimera=True, report_psms=5, min_precursor_charge=2, max_precursor_charge=4),
+               spectra_kwargs=dict(chimeric=3, isolation_half_width=6.0, annotate_charge=False), cpu_sample=4096,
+               metric="spectra/sec (whole node), fragment-index search-and-score, chimeric wide-window search"),
 }
+DEFAULT_CONFIG = "C3"  # BASELINE.json's metric is quoted on the human tryptic narrow search; it fits one GPU
+
+
+def _scorer_params(cfg):
+    from sage_amd.api import ScorerParams, Tolerance
+    kw = dict(cfg["scorer"])
+    for k in ("precursor_tol", "fragment_tol"):
+        if k in kw:
+            kw[k] = Tolerance(*kw[k])
+    return ScorerParams(**kw)
+
+
+def _tol_str(t):
+    return f"{t.kind}[{t.lo:g},{t.hi:g}]"
 
 
 def main():
@@ -37,11 +76,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2")
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
     ap.add_argument("--spectra", type=int, default=0, help="override the number of spectra per rank (smoke runs)")
     ap.add_argument("--proteins", type=int, default=0, help="override the number of proteins (smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="override the number of spectra the CPU baseline scores")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,12 +101,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from sage_amd.api import DatabaseParameters, DeviceDatabase, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor
+    from sage_amd.api import DatabaseParameters, DeviceDatabase, Scorer, SpectrumBatch, SpectrumProcessor
     from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
 
     cfg = CONFIGS[args.config]
     n_prot = args.proteins or cfg["proteins"]
-    n_spec = args.spectra or cfg["spectra"]
+    n_spec = args.spectra or cfg["per_gpu"]
+    full_size = not args.spectra and not args.proteins
     t0 = time.time()
     fasta = synthetic_fasta(n_prot, cfg["fasta_seed"])
     host = DatabaseParameters(**cfg["db"]).build(fasta)
@@ -80,8 +121,10 @@ def main():
     t_spec = time.time() - t0
     del raw, proc
 
-    params = ScorerParams(**cfg["scorer"])
+    params = _scorer_params(cfg)
+    t0 = time.time()
     dev = DeviceDatabase(host, local_rank)
+    t_dev = time.time() - t0
     scorer = Scorer(dev, params)
     dbatch = scorer.upload(batch)  # inputs resident in HBM before the timed region
 
@@ -103,6 +146,7 @@ def main():
         rescore_ms.append(t["rescore_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
+    last_t = scorer.last_timing()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -117,43 +161,53 @@ def main():
 
     if rank == 0:
         n_psm = int(counts.sum())
+        feats, counts = feats.copy(), counts.copy()  # the pinned result buffers are reused by the next call
+        # PCIe-inclusive rate (host buffers in, host records out) — reported beside `value`, never as `value`
+        t0 = time.perf_counter()
+        for _ in range(3):
+            scorer.score(batch)
+        pcie_value = batch.n * 3 / (time.perf_counter() - t0)
         # ---- cpu_baseline + algorithmic bytes: the oracle (restated reference CPU path), rank 0, N=1 only
         cpu = None
         bytes_per_spec = None
         work = None
         cache = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")
+        cached = json.load(open(cache)) if os.path.exists(cache) else {}
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
             from parity_utils import assert_features_equal
             orc = oracle_lib.OracleDb.from_product(host)
             threads = os.cpu_count() or 1
+            n_cpu = min(batch.n, args.cpu_sample or cfg["cpu_sample"])
+            sample = batch if n_cpu == batch.n else batch.subset(np.arange(n_cpu))
             runs = []
-            for r in range(args.cpu_repeats + 1):  # first run = warm-up
-                of, oc, ms, work = orc.score(params, batch, threads=threads, work=(r == 0))
+            for r in range(args.cpu_repeats + 1):  # first run = warm-up (and the work counters)
+                of, oc, ms, wk = orc.score(params, sample, threads=threads, work=(r == 0))
                 if r:
-                    runs.append(batch.n * 1000.0 / (ms + 1.0))  # runner.rs:327-330
+                    runs.append(sample.n * 1000.0 / (ms + 1.0))  # runner.rs:327-330
                 else:
-                    work0 = work
-            work = work0
-            parity_psms = assert_features_equal(feats, counts, of, oc, "bench parity")  # same run, same inputs
+                    work = wk
+            parity_psms = assert_features_equal(feats[:n_cpu], counts[:n_cpu], of, oc, "bench parity")  # same inputs
+            what = f"all {batch.n} spectra of the workload" if n_cpu == batch.n else \
+                f"the first {n_cpu} of the {batch.n} spectra of the workload"
             cpu = {"value": float(np.median(runs)), "unit": "spectra/s", "cores": threads, "kind": "port",
-                   "sample": f"all {batch.n} spectra of the workload, median of {args.cpu_repeats} passes after 1 warm-up, "
-                             f"{threads} OpenMP threads, dynamic schedule (restated reference CPU path, not Sage itself)",
+                   "sample": f"{what}, median of {args.cpu_repeats} passes after 1 warm-up, {threads} OpenMP threads, "
+                             f"dynamic schedule (restated reference CPU path, not Sage itself)",
                    "parity": f"{parity_psms} PSMs identical to the GPU result (ints/f32 exact, f64 within 1e-12)"}
             rescore_bytes = 4 * work["rescored"] + 5 * work["rescored_residues"] + 64 * work["reported"]
-            bytes_per_spec = {"total": work["algorithmic_bytes"] / batch.n,
-                              "prelim": (work["algorithmic_bytes"] - rescore_bytes) / batch.n,
-                              "rescore": rescore_bytes / batch.n}
-            if args.config == "C2" and not args.spectra and not args.proteins:
+            bytes_per_spec = {"total": work["algorithmic_bytes"] / sample.n,
+                              "prelim": (work["algorithmic_bytes"] - rescore_bytes) / sample.n,
+                              "rescore": rescore_bytes / sample.n}
+            if full_size:
                 try:
+                    cached[args.config] = {"bytes_per_spectrum": bytes_per_spec, "work": work, "n_spectra": sample.n}
                     os.makedirs(os.path.dirname(cache), exist_ok=True)
-                    json.dump({"config": args.config, "bytes_per_spectrum": bytes_per_spec, "work": work,
-                               "n_spectra": batch.n}, open(cache, "w"), indent=1)
+                    json.dump(cached, open(cache, "w"), indent=1)
                 except OSError:
                     pass
-        elif os.path.exists(cache):
-            bytes_per_spec = json.load(open(cache))["bytes_per_spectrum"]
+        elif args.config in cached:
+            bytes_per_spec = cached[args.config]["bytes_per_spectrum"]
 
         pm, rm = float(np.mean(prelim_ms)), float(np.mean(rescore_ms))
         dom = "prelim" if pm >= rm else "rescore"
@@ -163,25 +217,31 @@ def main():
             achieved = bytes_per_spec[dom] * batch.n / (dom_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom + "_bytes_per_launch")
-            roof = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            if os.path.exists(tpath) and full_size:
+                traffic = json.load(open(tpath)).get(args.config, {}).get(dom + "_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel_ms": {"prelim": pm, "rescore": rm},
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
-                    "note": "narrow-window search is probe/latency bound: few algorithmic bytes per spectrum by construction"}
+                    "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"]},
+                    "note": "prelim = fragment matching + k-select kernels (HIP events on the scorer's stream); narrow-window "
+                            "searches are probe/latency bound: few algorithmic bytes per spectrum by construction"}
         out = {
-            "metric": "spectra/sec (whole node), fragment-index search-and-score, narrow search",
+            "metric": cfg["metric"],
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "spectra_per_gpu": batch.n, "peptides": host.n_peptides,
-                       "fragments": host.n_fragments, "precursor_tol": "ppm[-10,10]", "fragment_tol": "ppm[-10,10]",
-                       "report_psms": params.report_psms, "parallelism": f"spectra sharded x{world}, index replicated",
-                       "psms_per_step_rank0": n_psm, "setup_s": {"db_build": round(t_db, 2), "spectra": round(t_spec, 2)},
+                       "fragments": host.n_fragments, "precursor_tol": _tol_str(params.precursor_tol),
+                       "fragment_tol": _tol_str(params.fragment_tol), "report_psms": params.report_psms,
+                       "chimera": params.chimera, "wide_window": params.wide_window,
+                       "parallelism": f"spectra sharded x{world}, index replicated",
+                       "psms_per_step_rank0": n_psm,
+                       "setup_s": {"db_build": round(t_db, 2), "spectra": round(t_spec, 2), "index_to_device": round(t_dev, 2)},
                        "index_device_bytes": dev.device_bytes},
             "roofline": roof, "cpu_baseline": cpu,
+            "pcie_inclusive_value": pcie_value,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAGE_HIP_ABI_VERSION 1
+#define SAGE_HIP_ABI_VERSION 2
 
 enum {
     SAGE_HIP_OK = 0,
@@ -209,8 +209,8 @@ typedef struct SageTiming {
     float rescore_ms;  /* rescoring + top-K + Feature kernel */
     float total_ms;    /* first launch -> last kernel done (excludes H2D/D2H) */
     uint32_t n_launches;
-    uint32_t n_wide;   /* spectra routed to either large-window kernel */
-    uint32_t n_open;   /* ... of which to the m/z-major open-search kernel */
+    uint32_t n_wide;   /* spectra routed to the tiled large-window kernels */
+    uint32_t arena_entries; /* 4-byte entries of the large-window candidate arena this call used */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 
@@ -219,10 +219,10 @@ int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 int sage_hip_host_alloc(uint64_t bytes, void** out);
 void sage_hip_host_free(void* p);
 
-/* Debug aid, only with SAGE_HIP_PHASE_CLOCKS=1 at scorer creation: cumulative shader cycles per kernel phase,
- * out16[0..7] = preliminary kernel, out16[8..15] = rescoring kernel. */
-int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out16);
-int sage_hip_debug_phase_raw(SageScorer* scorer, unsigned long long* out /* [nblocks][16] */, uint32_t nblocks);
+/* Debug aid, only with SAGE_HIP_PHASE_CLOCKS=1 at scorer creation: cumulative shader cycles per kernel phase over the
+ * first 4096 work items, out32[8*k + phase]: k = 0 narrow preliminary kernel, 1 rescoring kernel, 2 large-window count
+ * kernel, 3 large-window replay kernel. */
+int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out32);
 
 const char* sage_hip_last_error(void);
 int sage_hip_abi_version(void);

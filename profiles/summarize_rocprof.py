@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3's rocpd sqlite output (gpurun_out/prof/*/…_results.db) into the small text summaries that
-are committed under profiles/.  Usage: python profiles/summarize_rocprof.py <tag> <trace.db> [<pmc.db> ...]"""
+are committed under profiles/.
+Usage: python profiles/summarize_rocprof.py <tag> <config> <trace.db> [<pmc.db> ...]
+Also updates profiles/traffic.json[<config>] (PMC-derived HBM bytes per launch, read back by bench.py)."""
 import json
 import sqlite3
 import sys
@@ -8,8 +10,9 @@ import sys
 
 def main():
     tag = sys.argv[1]
-    trace = sys.argv[2]
-    pmcs = sys.argv[3:]
+    config = sys.argv[2]
+    trace = sys.argv[3]
+    pmcs = sys.argv[4:]
     out = []
     con = sqlite3.connect(trace)
     out.append(f"# rocprofv3 --kernel-trace --stats  ({tag})\n")
@@ -44,15 +47,22 @@ def main():
     for k, v in traffic.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-            key = "prelim" if k.startswith("prelim_kernel<false>") else ("rescore" if k.startswith("rescore") else None)
+            # bench.py's prelim_ms spans all three preliminary kernels (narrow / mid-window / open-search)
+            key = "prelim" if k.startswith("prelim_") else ("rescore" if k.startswith("rescore") else None)
             if key:
-                tj[key + "_bytes_per_launch"] = b
-                tj[key + "_raw"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}
+                tj[key + "_bytes_per_launch"] = tj.get(key + "_bytes_per_launch", 0.0) + b
+                tj.setdefault(key + "_raw", {})[k] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}
             out.append(f"HBM traffic {k:<40} (2*FETCH+WRITE)*1024 = {b/1e6:.1f} MB per launch\n")
     open(f"profiles/{tag}_rocprof_summary.txt", "w").write("".join(out))
     if tj:
         tj["source"] = f"profiles/{tag}_rocprof_summary.txt"
-        json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
+        try:
+            allt = json.load(open("profiles/traffic.json"))
+        except (OSError, ValueError):
+            allt = {}
+        allt = {k: v for k, v in allt.items() if isinstance(v, dict) and k.startswith("C")}
+        allt[config] = tj
+        json.dump(allt, open("profiles/traffic.json", "w"), indent=1)
     print("".join(out))
 
 

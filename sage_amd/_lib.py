@@ -113,7 +113,7 @@ class SageTiming(C.Structure):
         ("total_ms", C.c_float),
         ("n_launches", C.c_uint32),
         ("n_wide", C.c_uint32),
-        ("n_open", C.c_uint32),
+        ("arena_entries", C.c_uint32),
     ]
 
 
@@ -183,7 +183,6 @@ def load():
         "sage_hip_initial_hits": (C.c_int, [vp, vp, c_u64_p, C.c_uint32, c_u32_p, c_u64_p, c_u64_p]),
         "sage_hip_last_timing": (C.c_int, [vp, C.POINTER(SageTiming)]),
         "sage_hip_debug_phase_cycles": (C.c_int, [vp, c_u64_p]),
-        "sage_hip_debug_phase_raw": (C.c_int, [vp, c_u64_p, C.c_uint32]),
         "sage_hip_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(vp)]),
         "sage_hip_host_free": (None, [vp]),
     }
@@ -201,7 +200,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_score_resident", "sage_hip_initial_hits",
-    "sage_hip_last_timing", "sage_hip_debug_phase_cycles", "sage_hip_debug_phase_raw", "sage_hip_host_alloc", "sage_hip_host_free",
+    "sage_hip_last_timing", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
 ]
 
 

@@ -69,12 +69,8 @@ struct SageDeviceDb {
     DevBuf<float> ions;
     DevBuf<uint64_t> ion_off;
     DevBuf<uint32_t> pep_info;
-    // the reference-shaped bucketed index, resident for the large-window path
-    DevBuf<SageTheoretical> fragments;
-    DevBuf<float> min_value;
-    DevBuf<SageTheoretical> mz_frag;  // m/z-major copy for the open-search kernel
-    DevBuf<uint32_t> mz_lut;
-    uint64_t bucket_size = 0;
+    DevBuf<SageTheoretical> tm_frag;  // tile-major copy + position table for the large-window kernel
+    DevBuf<uint32_t> tm_lut;
     uint32_t max_ions = 0;
     DevDbView view{};
     uint64_t bytes = 0;
@@ -87,15 +83,19 @@ struct SageScorer {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {};
     DevBuf<double> lnfact;
-    DevBuf<uint32_t> wide_cnt, open_cnt;
-    uint32_t open_blocks = 0;
-    uint64_t open_words = 0, wide_words = 0;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
-    uint32_t wide_blocks = 0;
+    uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel
     SageTiming timing{};
     // per-batch work buffers, grown on demand
     DevBuf<uint64_t> cand;
-    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count;
+    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count, queue;
+    // large-window pipeline scratch (device_types.h: DevWork)
+    DevBuf<QueryRec> qrec;
+    DevBuf<uint16_t> seeds;
+    DevBuf<uint64_t> qres;
+    DevBuf<uint32_t> arena;
+    DevBuf<TileParams> tile_params;
+    uint32_t qmax = 1;
     DevBuf<SageFeature> features;
     uint32_t work_n = 0;
     uint32_t* h_counters = nullptr;  // pinned [2]: deferred, overflow
@@ -213,51 +213,55 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
                                 v->ion_kinds[k], ions.data() + ion_off[i] + (uint64_t)k * lm1);
         }
     });
-    // m/z-major copy: the reference's buckets are already globally ordered by m/z (database.rs:301, 337-346);
-    // ordering each bucket by (m/z, peptide) restores the global sort.  mz_lut[b] = #fragments with m/z < b/scale.
-    if (nf >= 0xFFFFFFFFull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-2 fragments");
-    std::vector<SageTheoretical> mzs(v->fragments, v->fragments + nf);
-    {
-        const uint64_t bs = v->bucket_size ? v->bucket_size : nf;
-        const uint64_t nb = bs ? (nf + bs - 1) / bs : 0;
-        parallel_for(nb, 4, [&](size_t bb, size_t be, unsigned) {
-            for (size_t bk = bb; bk < be; bk++) {
-                const uint64_t a = bk * bs, e = std::min<uint64_t>(a + bs, nf);
-                std::sort(mzs.begin() + a, mzs.begin() + e, [](const SageTheoretical& x, const SageTheoretical& y) {
-                    const int32_t kx = sagecore::order_key(x.fragment_mz), ky = sagecore::order_key(y.fragment_mz);
-                    return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
-                });
-            }
-        });
-        for (uint64_t i = 1; i < nf; i++)
-            if (sagecore::order_key(mzs[i - 1].fragment_mz) > sagecore::order_key(mzs[i].fragment_mz))
-                return fail(SAGE_HIP_ERR_INVALID, "IndexedDatabase.fragments is not bucket-ordered by m/z (database.rs:301)");
-    }
-    const float lut_scale = 512.0f;  // 1/512 Da cells: ~10 MB of table for a 5000 Da fragment range
+    // tile-major copy for large precursor windows: tile = peptide_index >> tile_shift, (m/z, peptide) order inside a
+    // tile, and a per-tile position table tm_lut[t][c] = first position of tile t with m/z >= c / lut_scale.
+    if (nf >= 0xFFFFFFF0ull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-16 fragments");
+    uint32_t tile_shift = 15;
+    if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(16, std::max(11, atoi(e)));
+    const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
+    std::vector<uint64_t> tile_off(n_tiles + 1, 0);
+    for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
+    std::vector<SageTheoretical> tm(pm.begin(), pm.end());  // peptide-major == tile-grouped already
+    tm.resize(nf + 2, SageTheoretical{0xFFFFFFFFu, 0.0f});
+    parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
+        for (size_t t = tb; t < te; t++)
+            std::sort(tm.begin() + tile_off[t], tm.begin() + tile_off[t + 1], [](const SageTheoretical& x, const SageTheoretical& y) {
+                const int32_t kx = sagecore::order_key(x.fragment_mz), ky = sagecore::order_key(y.fragment_mz);
+                return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
+            });
+    });
+    // 1/256 Da cells.  The scale is a power of two, so `m/z * scale` is exact in f32 and a fragment-tolerance window
+    // [lo, hi] maps to the cell range [floor(lo*scale), floor(hi*scale)] with no safety margin.
+    const float lut_scale = 256.0f;
     float max_mz = 0.0f;
     for (uint64_t i = 0; i < nf; i++)
-        if (mzs[i].fragment_mz > max_mz && std::isfinite(mzs[i].fragment_mz)) max_mz = mzs[i].fragment_mz;
-    const uint32_t lut_n = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
-    std::vector<uint32_t> lut(lut_n);
-    {
-        uint64_t pos = 0;
-        for (uint32_t bn = 0; bn < lut_n; bn++) {
-            const double edge = (double)bn / (double)lut_scale;
-            while (pos < nf && (double)mzs[pos].fragment_mz < edge) pos++;
-            lut[bn] = (uint32_t)pos;
+        if (pm[i].fragment_mz > max_mz && std::isfinite(pm[i].fragment_mz)) max_mz = pm[i].fragment_mz;
+    const uint32_t lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
+    if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
+    std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
+    parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
+        for (size_t t = tb; t < te; t++) {
+            uint64_t pos = tile_off[t];
+            const uint64_t tend = tile_off[t + 1];
+            uint32_t* row = lut.data() + t * lut_stride;
+            for (uint32_t c = 0; c < lut_stride; c++) {
+                const double edge = (double)c / (double)lut_scale;
+                // NaN and m/z beyond the table (non-finite or > 250 kDa) compare false and stay in the last cell's run
+                while (pos < tend && (double)tm[pos].fragment_mz < edge) pos++;
+                row[c] = (uint32_t)pos;
+            }
+            row[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
+            row[lut_stride - 1] = (uint32_t)tend;
         }
-    }
-    HIP_TRY(d->mz_frag.upload(mzs.data(), nf));
-    HIP_TRY(d->mz_lut.upload(lut.data(), lut_n));
+    });
+    HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));
+    HIP_TRY(d->tm_lut.upload(lut.data(), lut.size()));
     HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
     HIP_TRY(d->pm_frag.upload(pm.data(), nf));
     HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
     HIP_TRY(d->ions.upload(ions.data(), ions.size()));
     HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
     HIP_TRY(d->pep_info.upload(info.data(), np));
-    HIP_TRY(d->fragments.upload(v->fragments, nf));
-    HIP_TRY(d->min_value.upload(v->min_value, v->n_buckets));
-    d->bucket_size = v->bucket_size;
     d->max_ions = max_ions;
     d->view.pep_mono = d->pep_mono.p;
     d->view.np = (uint32_t)np;
@@ -266,16 +270,18 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     d->view.ions = d->ions.p;
     d->view.ion_off = d->ion_off.p;
     d->view.pep_info = d->pep_info.p;
-    d->view.mz_frag = d->mz_frag.p;
-    d->view.mz_lut = d->mz_lut.p;
-    d->view.lut_n = lut_n;
+    d->view.tm_frag = d->tm_frag.p;
+    d->view.tm_lut = d->tm_lut.p;
+    d->view.tile_shift = tile_shift;
+    d->view.n_tiles = (uint32_t)n_tiles;
+    d->view.lut_stride = lut_stride;
     d->view.lut_scale = lut_scale;
     d->view.nf = nf;
     std::memset(d->view.ion_kinds, 0, sizeof d->view.ion_kinds);
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
     d->bytes = d->pep_mono.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
-               d->pep_info.bytes() + d->fragments.bytes() + d->min_value.bytes() + d->mz_frag.bytes() + d->mz_lut.bytes();
+               d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes();
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -321,8 +327,6 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     d.wcap = 1024;
     d.dbg_flags = 0;
     if (const char* e = getenv("SAGE_HIP_DEBUG_FLAGS")) d.dbg_flags = (uint32_t)atoi(e);
-    d.open_thresh = 2048;
-    if (const char* e = getenv("SAGE_HIP_OPEN_THRESH")) d.open_thresh = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::max(64, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -335,26 +339,24 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
         tbl[n] = x * std::log(x) - x + 0.5 * std::log(x) + 0.5 * std::log(M_PI * 2.0 * x);
     }
     HIP_TRY(s->lnfact.upload(tbl.data(), tbl.size()));
-    // mid-window kernel: windows above wcap but not above open_thresh (when the open-search kernel exists they
-    // never exceed open_thresh slots)
-    s->wide_blocks = 2048;
-    if (const char* e = getenv("SAGE_HIP_WIDE_BLOCKS")) s->wide_blocks = (uint32_t)std::max(1, atoi(e));
-    s->wide_words = std::min<uint64_t>((uint64_t)db->view.np + 1, (uint64_t)d.open_thresh + 1);
-    HIP_TRY(s->wide_cnt.alloc((size_t)s->wide_blocks * s->wide_words));
-    if ((uint64_t)db->view.np + 1 > d.open_thresh) {  // otherwise no window can ever exceed the threshold
-        s->open_words = (((uint64_t)db->view.np + 2 + 4 * 64) / 2 + 1) & ~1ull;
-        const uint64_t budget = 24ull << 30;  // HBM set aside for counter slabs (288 GB per GPU)
-        s->open_blocks = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, budget / (s->open_words * 4)));
-        if (const char* e = getenv("SAGE_HIP_OPEN_BLOCKS")) s->open_blocks = (uint32_t)std::max(1, atoi(e));
-        HIP_TRY(s->open_cnt.alloc((size_t)s->open_blocks * s->open_words));
-        HIP_TRY(hipMemset(s->open_cnt.p, 0, (size_t)s->open_blocks * s->open_words * 4));
+    // large-window kernel: persistent workgroups, as many as the LDS tiles allow to be resident
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, db->device));
+        const size_t tile_lds = ((size_t)1 << db->view.tile_shift) * 2 + 12 * 1024;  // counters + bitmap + windows (typical)
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / tile_lds));
+        s->tile_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+        if (const char* e = getenv("SAGE_HIP_TILE_BLOCKS")) s->tile_blocks = (uint32_t)std::max(1, atoi(e));
+        HIP_TRY((hipError_t)tile_kernel_prepare(160 * 1024));
     }
-    HIP_TRY(s->n_deferred.alloc(4));
-    HIP_TRY(hipHostMalloc((void**)&s->h_counters, 16, hipHostMallocDefault));
+    s->qmax = queries_per_spectrum(d);
+    HIP_TRY(s->n_deferred.alloc(CTR_COUNT));
+    HIP_TRY(s->tile_params.alloc(1));
+    HIP_TRY(hipHostMalloc((void**)&s->h_counters, CTR_COUNT * 4, hipHostMallocDefault));
     if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
         if (atoi(e) > 0) {
-            HIP_TRY(s->dbg.alloc(4096 * 16));
-            HIP_TRY(hipMemset(s->dbg.p, 0, 4096 * 16 * 8));
+            HIP_TRY(s->dbg.alloc(4096 * 32));
+            HIP_TRY(hipMemset(s->dbg.p, 0, 4096 * 32 * 8));
         }
     }
     *out = s.release();
@@ -457,7 +459,18 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     HIP_TRY(s->cand_len.alloc(n));
     HIP_TRY(s->totals.alloc((size_t)n * 2));
     HIP_TRY(s->status.alloc(n));
+    HIP_TRY(s->queue.alloc(n));
     HIP_TRY(s->out_count.alloc(n));
+    // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
+    // (16 Ki entries = 64 KiB per spectrum on average; an exhausted arena is reported, never silently truncated)
+    HIP_TRY(s->qrec.alloc((size_t)n * s->qmax));
+    HIP_TRY(s->seeds.alloc((size_t)n * s->qmax * 64));
+    HIP_TRY(s->qres.alloc((size_t)n * s->qmax * 64));
+    // + two 64 Ki-entry chunks per resident workgroup (each takes its arena space a chunk at a time)
+    uint64_t arena_entries = std::max<uint64_t>((uint64_t)n * 16384, 16ull << 20) + (uint64_t)std::min(n, s->tile_blocks) * (2u << 16);
+    arena_entries = std::min<uint64_t>(arena_entries, 0xFFFFFFF0ull);
+    if (const char* e = getenv("SAGE_HIP_ARENA_MB")) arena_entries = std::min<uint64_t>((uint64_t)std::max(1, atoi(e)) << 18, 0xFFFFFFF0ull);
+    if (arena_entries > s->arena.n) HIP_TRY(s->arena.alloc(arena_entries));
     HIP_TRY(s->features.alloc((size_t)n * s->params.report_psms));
     s->work_n = n;
     return SAGE_HIP_OK;
@@ -468,8 +481,9 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     HIP_TRY(hipSetDevice(s->db->device));
     int rc = ensure_work(s, b->n);
     if (rc != SAGE_HIP_OK) return rc;
-    const size_t lds_p = prelim_lds_bytes(s->dev, b->view, false), lds_r = rescore_lds_bytes(s->dev, b->view, s->db->max_ions);
-    if (lds_p > 64 * 1024 || lds_r > 64 * 1024)
+    const size_t lds_p = prelim_lds_bytes(s->dev, b->view), lds_r = rescore_lds_bytes(s->dev, b->view, s->db->max_ions);
+    const size_t lds_t = tile_lds_bytes(s->db->view, s->dev, b->view);
+    if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
     DevWork w;
     w.cand = s->cand.p;
@@ -477,24 +491,30 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     w.totals = s->totals.p;
     w.status = s->status.p;
     w.n_deferred = s->n_deferred.p;
-    w.wide_cnt = s->wide_cnt.p;
-    w.wide_blocks = s->wide_blocks;
-    w.wide_words = s->wide_words;
-    w.open_cnt = s->open_cnt.p;
-    w.open_blocks = s->open_blocks;
-    w.open_words = s->open_words;
+    w.queue = s->queue.p;
+    w.tile_blocks = s->tile_blocks;
+    w.qrec = s->qrec.p;
+    w.seeds = s->seeds.p;
+    w.qres = s->qres.p;
+    w.arena = s->arena.p;
+    w.arena_cap = (uint32_t)s->arena.n;
+    w.qmax = s->qmax;
     w.dbg = s->dbg.p;
-    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, 16, s->stream));
+    w.tile_params = s->tile_params.p;
+    {
+        TileParams tp{s->db->view, s->dev, b->view, w};
+        HIP_TRY(hipMemcpyAsync(s->tile_params.p, &tp, sizeof tp, hipMemcpyHostToDevice, s->stream));  // (small: staged at call time)
+    }
+    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, CTR_COUNT * 4, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
-    launch_prelim_wide(s->db->view, s->dev, b->view, w, s->stream);
-    launch_prelim_open(s->db->view, s->dev, b->view, w, s->stream);
+    launch_prelim_tile(s->db->view, s->dev, b->view, w, s->stream);
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (with_rescore)
         launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
                        s->features.p, s->out_count.p, s->stream);
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, 16, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipGetLastError());
     return SAGE_HIP_OK;
 }
@@ -504,13 +524,15 @@ static int finish_timing(SageScorer* s, bool with_rescore) {
     float a = 0, c = 0;
     HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
     HIP_TRY(hipEventElapsedTime(&c, s->ev[1], s->ev[2]));
-    const uint32_t ndef = s->h_counters[0] + s->h_counters[2];  // copied on the stream before the caller's synchronize
     s->timing.prelim_ms = a;
     s->timing.rescore_ms = with_rescore ? c : 0.f;
     s->timing.total_ms = a + c;
-    s->timing.n_launches = (with_rescore ? 3 : 2) + (s->open_blocks ? 1 : 0);
-    s->timing.n_wide = ndef;
-    s->timing.n_open = s->h_counters[2];
+    s->timing.n_launches = with_rescore ? 5 : 4;
+    s->timing.n_wide = s->h_counters[CTR_QUEUED];  // copied on the stream before the caller's synchronize
+    s->timing.arena_entries = s->h_counters[CTR_ARENA_PTR];
+    if (s->h_counters[CTR_ARENA_OVERFLOW])
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->arena.n >> 18) +
+                                                  " MiB): score this batch in smaller pieces or raise SAGE_HIP_ARENA_MB");
     return SAGE_HIP_OK;
 }
 
@@ -524,7 +546,7 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = finish_timing(s, true);
     if (rc != SAGE_HIP_OK) return rc;
-    if (s->h_counters[1]) {  // rare: find the offending spectrum for the message
+    if (s->h_counters[CTR_LIST_OVERFLOW]) {  // rare: find the offending spectrum for the message
         std::vector<uint32_t> st(b->n);
         HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < b->n; i++)
@@ -569,22 +591,15 @@ int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, u
     return SAGE_HIP_OK;
 }
 
-// debugging aid (not part of the drop-in surface): cumulative per-phase shader cycles, [2][8]
-int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out16) {
-    if (!s || !out16) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+// debugging aid (not part of the drop-in surface): cumulative per-phase shader cycles, [4 kernels][8 phases]
+int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out32) {
+    if (!s || !out32) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (!s->dbg.p) return fail(SAGE_HIP_ERR_INVALID, "set SAGE_HIP_PHASE_CLOCKS=1 before creating the scorer");
-    std::vector<unsigned long long> all(4096 * 16);
+    std::vector<unsigned long long> all(4096 * 32);
     HIP_TRY(hipMemcpy(all.data(), s->dbg.p, all.size() * 8, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (int k = 0; k < 32; k++) out32[k] = 0;
     for (size_t b = 0; b < 4096; b++)
-        for (int k = 0; k < 16; k++) out16[k] += all[b * 16 + k];
-    return SAGE_HIP_OK;
-}
-
-int sage_hip_debug_phase_raw(SageScorer* s, unsigned long long* out, uint32_t nblocks) {
-    if (!s || !out || nblocks > 4096) return fail(SAGE_HIP_ERR_INVALID, "bad argument");
-    if (!s->dbg.p) return fail(SAGE_HIP_ERR_INVALID, "set SAGE_HIP_PHASE_CLOCKS=1 before creating the scorer");
-    HIP_TRY(hipMemcpy(out, s->dbg.p, (size_t)nblocks * 16 * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 32; k++) out32[k] += all[b * 32 + k];
     return SAGE_HIP_OK;
 }
 

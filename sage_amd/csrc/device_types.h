@@ -19,11 +19,16 @@ struct DevDbView {
     const float* ions;
     const uint64_t* ion_off;         // [np + 1]
     const uint32_t* pep_info;        // [np] len | decoy<<16 | missed_cleavages<<24
-    // m/z-major copy of the fragments (globally ascending m/z) + a position table for open / wide-window
-    // searches: mz_lut[b] = #fragments with m/z < b / lut_scale
-    const SageTheoretical* mz_frag;  // [nf]
-    const uint32_t* mz_lut;          // [lut_n]
-    uint32_t lut_n;
+    // tile-major copy of the fragments for large precursor windows: tile = peptide_index >> tile_shift,
+    // ascending m/z inside a tile, plus a per-tile position table:
+    //   tm_lut[t * lut_stride + c] = position in tm_frag of tile t's first fragment with m/z >= c / lut_scale
+    // (the last cell of a tile is its end position).  A (peak window, tile) lookup is two table reads and a
+    // short contiguous run of entries; the tile's candidate counters fit in LDS.
+    const SageTheoretical* tm_frag;  // [nf + 2]
+    const uint32_t* tm_lut;          // [n_tiles * lut_stride]
+    uint32_t tile_shift;
+    uint32_t n_tiles;
+    uint32_t lut_stride;
     float lut_scale;
     uint64_t nf;
     uint8_t ion_kinds[8];
@@ -43,9 +48,9 @@ struct DevScorer {
     int score_type;
     uint32_t kmax;       // max(50, 2*report_psms): upper bound of every trim_k()
     uint32_t list_cap;   // capacity (entries) of each of the two CLists
-    uint32_t wcap;       // candidate-slot capacity of the LDS counter array (narrow path)
-    uint32_t dbg_flags;    // timing experiments only (SAGE_HIP_DEBUG_FLAGS): results are WRONG when non-zero
-    uint32_t open_thresh;  // windows with more candidate slots than this use the m/z-major (open-search) kernel
+    uint32_t wcap;       // candidate-slot capacity of the LDS counter array of the narrow kernel: spectra with a
+                         // larger precursor window go to the tiled large-window kernel
+    uint32_t dbg_flags;  // timing experiments only (SAGE_HIP_DEBUG_FLAGS): results are WRONG when non-zero
 };
 
 struct DevBatchView {
@@ -71,27 +76,53 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint64_t* cand;        // [n * kmax] packed PreScore in the reference's heap-layout order
     uint32_t* cand_len;    // [n]
     uint32_t* totals;      // [n * 2] InitialHits.matched_peaks, .scored_candidates
-    uint32_t* status;      // [n] 0 ok, 1 deferred to the large-window path, 2 list overflow
-    uint32_t* n_deferred;  // [4]: [0] spectra deferred to the mid-window kernel, [1] list overflows,
-                           //      [2] spectra deferred to the open-search kernel
-    uint32_t* wide_cnt;    // [wide_blocks * (np + 1)] global counter scratch for the large-window path
-    uint32_t wide_blocks;
-    uint64_t wide_words;   // counter slots per mid-window block
-    uint32_t* open_cnt;    // [open_blocks * open_words] u16-pair counters, all-zero between spectra
-    uint32_t open_blocks;
-    uint64_t open_words;
+    uint32_t* status;      // [n] 0 ok, 1 deferred to the large-window kernel, 2 list overflow
+    uint32_t* n_deferred;  // [8]: [0] spectra queued for the large-window kernels, [1] list overflows,
+                           //      [2] queue head (next entry a large-window workgroup takes),
+                           //      [3] candidate-arena bump pointer, [4] candidate-arena overflows
+    uint32_t* queue;       // [n] spectra queued for the large-window kernels
+    uint32_t tile_blocks;  // persistent workgroups of the large-window counting kernel
+    // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
+    struct QueryRec* qrec; // [n * qmax]
+    uint16_t* seeds;       // [n * qmax * 64] matched counts of the first min(k, potential) candidate slots
+    uint64_t* qres;        // [n * qmax * 64] heap of each k-selected query, in the reference's layout order
+    const struct TileParams* tile_params;  // device copy of {db, scorer, batch, work} for the count kernel
+    uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
+    uint32_t arena_cap;    // entries
+    uint32_t qmax;
     unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)
 };
 
-enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_DEFERRED_OPEN = 3 };
+enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2 };
+enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_COUNT = 8 };
+
+// one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
+struct QueryRec {
+    uint32_t left;        // pre_idx_lo: candidate slot s <-> peptide left + s
+    uint32_t potential;   // number of candidate slots (scoring.rs:351); 0 == query not evaluated
+    uint32_t matched;     // InitialHits.matched_peaks of this query
+    uint32_t scored;      // InitialHits.scored_candidates of this query
+    uint32_t head;        // first candidate segment in the arena (0xFFFFFFFF: none)
+    uint32_t z_iso;       // precursor charge | (isotope error + 128) << 8
+    uint32_t pad[2];
+};
+
+struct TileParams {
+    DevDbView db;
+    DevScorer sc;
+    DevBatchView b;
+    DevWork w;
+};
 
 // launch wrappers (kernels.hip)
-size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool wide);
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b);
+int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
 uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions);
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
-void launch_prelim_wide(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
-void launch_prelim_open(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
+void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
+uint32_t queries_per_spectrum(const DevScorer& sc);
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, void* stream);

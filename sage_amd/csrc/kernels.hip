@@ -22,14 +22,15 @@ namespace {
 
 constexpr uint32_t WAVE = 64;
 
-// optional per-phase cycle accounting (DevWork::dbg != null): the first DBG_BLOCKS blocks of a launch
-// store clock deltas into their own slot [block][kernel*8 + phase] (no atomics: nothing is perturbed)
+// optional per-phase cycle accounting (DevWork::dbg != null): the first DBG_BLOCKS work items of a launch
+// store clock deltas into their own slot [item][kernel*8 + phase] (no atomics: nothing is perturbed);
+// kernel 0 = narrow preliminary, 1 = rescoring, 2 = large-window count, 3 = large-window replay
 constexpr uint32_t DBG_BLOCKS = 4096;
 struct PhaseClock {
     unsigned long long* slot;
     long long t;
     __device__ __forceinline__ void start(unsigned long long* dbg, uint32_t blk, uint32_t kernel) {
-        slot = (dbg && blk < DBG_BLOCKS) ? dbg + (size_t)blk * 16 + kernel * 8 : nullptr;
+        slot = (dbg && blk < DBG_BLOCKS) ? dbg + (size_t)blk * 32 + kernel * 8 : nullptr;
         if (slot) t = clock64();
     }
     __device__ __forceinline__ void mark(int phase) {
@@ -42,6 +43,22 @@ struct PhaseClock {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// wave-uniform values that come out of memory land in VGPRs; these move them to SGPRs (the value must be uniform)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+
+// wave64 sum through DPP row operations (no LDS crossbar round trips); the total is broadcast from lane 63
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8 -> every lane holds its row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, false);  // row_bcast:15 (rows without a source add 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, false);  // row_bcast:31 -> lane 63 holds the total
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -78,27 +95,23 @@ __device__ __forceinline__ uint32_t wave_partition_point(const float* __restrict
     return lo + (uint32_t)__popcll(__ballot(t));
 }
 
-// ---- candidate counters ---------------------------------------------------------------------
-// narrow path: u16 pairs in LDS;  large-window path: u32 in global scratch
-template <bool WIDE>
+// ---- candidate counters: u16 pairs in LDS ------------------------------------------------------
 struct Counters {
     uint32_t* p;
     __device__ __forceinline__ void zero(uint32_t n, uint32_t lane) {
-        if (WIDE) {
-            for (uint32_t i = lane; i < n; i += WAVE) p[i] = 0;
-        } else {
-            for (uint32_t i = lane; i < (n + 1) / 2; i += WAVE) p[i] = 0;
-        }
+        for (uint32_t i = lane; i < (n + 1) / 2; i += WAVE) p[i] = 0;
     }
-    __device__ __forceinline__ void add(uint32_t idx, uint32_t c) {
-        if (WIDE) atomicAdd(&p[idx], c);
-        else atomicAdd(&p[idx >> 1], c << ((idx & 1) * 16));
-    }
-    __device__ __forceinline__ uint32_t get(uint32_t idx) const {
-        if (WIDE) return __hip_atomic_load(&p[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (p[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu;
-    }
+    __device__ __forceinline__ void add(uint32_t idx, uint32_t c) { atomicAdd(&p[idx >> 1], c << ((idx & 1) * 16)); }
+    __device__ __forceinline__ uint32_t get(uint32_t idx) const { return (p[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu; }
 };
+
+// LDS written by some lanes of a wavefront and read by others of the SAME wavefront: DS operations of one
+// wavefront complete in order, so only the compiler has to be kept from reordering / caching across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // ---- k-select state kept in registers: lane i holds heap element i (k <= 64) -------------------
 // bounded_min_heapify (heap.rs:7-60) is inherently sequential, but every index it touches is
@@ -178,12 +191,12 @@ __device__ __forceinline__ void ulist_append_empties(UList& c, uint64_t n, uint3
     if (lit) ulist_append(c, PRESCORE_EMPTY, lit, kmax);
     c.len += n - lit;
 }
-// trim_hits (scoring.rs:322-329)
+// trim_hits (scoring.rs:322-329); called by one whole wavefront (the list lives in LDS)
 __device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms) {
     const uint32_t lane = lane_id();
     const uint32_t k = trim_k(c.len, report_psms);
     if (c.len > k) {
-        __syncthreads();
+        wave_sync();
         WaveHeap h;
         const uint64_t mine = lane < k ? c.items[lane] : PRESCORE_EMPTY;
         h.lo = (uint32_t)mine;
@@ -194,9 +207,9 @@ __device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms) {
             const uint32_t n = c.stored - base < WAVE ? c.stored - base : WAVE;
             for (uint32_t j = 0; j < n; j++) wh_offer(h, k, lane_value(v, j));
         }
-        __syncthreads();
+        wave_sync();
         if (lane < k) c.items[lane] = ((uint64_t)h.hi << 32) | h.lo;
-        __syncthreads();
+        wave_sync();
     }
     c.stored = k;
     c.len = k;
@@ -224,38 +237,86 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     return l;
 }
 
-template <bool WIDE>
+// ---- shared by both preliminary kernels ----------------------------------------------------------
+struct SpecInfo {
+    uint64_t p0;
+    uint32_t P, z0, z1, nfz_max;
+    float mzp;
+    Tol iso_tol;
+};
+__device__ __forceinline__ SpecInfo load_spec(const DevScorer& sc, const DevBatchView& b, uint32_t spec) {
+    SpecInfo s;
+    s.p0 = uni64(b.peak_off[spec]);
+    s.P = (uint32_t)(uni64(b.peak_off[spec + 1]) - s.p0);
+    const uint32_t zraw = uni(b.precursor_charge[spec]);
+    if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {  // scoring.rs:423, 437, 442
+        s.z0 = sc.min_precursor_charge;
+        s.z1 = sc.max_precursor_charge;
+    } else {
+        s.z0 = s.z1 = zraw;
+    }
+    s.nfz_max = 0;
+    for (uint32_t z = s.z0; z <= s.z1; z++) {
+        const uint32_t m = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+        s.nfz_max = m > s.nfz_max ? m : s.nfz_max;
+    }
+    if (s.nfz_max > b.fzcap) s.nfz_max = b.fzcap;  // (upload sized fzcap from the same rule)
+    s.mzp = unif(b.precursor_mz[spec]) - PROTON;  // scoring.rs:420
+    s.iso_tol.kind = 2;
+    s.iso_tol.lo = -2.4f;
+    s.iso_tol.hi = 2.4f;  // scoring.rs:430
+    if (b.isolation_lo && b.isolation_hi) {
+        const float a = unif(b.isolation_lo[spec]), c = unif(b.isolation_hi[spec]);
+        if (a == a && c == c) { s.iso_tol.lo = a; s.iso_tol.hi = c; }
+    }
+    return s;
+}
+
+// IndexedDatabase::query (database.rs:402-425) by one wavefront: [left, right] candidate slots and the
+// [first, end) peptide range after the edge rule of database.rs:526-531
+struct Window {
+    uint32_t left, right, first, end;
+};
+template <bool GALLOP>
+__device__ __forceinline__ Window query_window(const DevDbView& db, const Tol& ptol, float center) {
+    float plo, phi;
+    tol_bounds(ptol, center, plo, phi);
+    Window q;
+    uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
+    left = left ? left - 1 : 0;
+    uint32_t ghi = db.np;
+    if (GALLOP) {  // the window is short in a narrow search: bracket it by galloping from `left` before searching
+        for (uint64_t span = WAVE;; span *= 16) {
+            ghi = (uint64_t)left + span < db.np ? (uint32_t)(left + span) : db.np;
+            if (ghi == db.np || order_key(db.pep_mono[ghi - 1]) > order_key(phi)) break;
+        }
+    }
+    const uint32_t right = wave_partition_point<false>(db.pep_mono, left, ghi, order_key(phi));
+    q.left = left;
+    q.right = right;
+    q.first = left;
+    q.end = right;
+    if (left < db.np && !(db.pep_mono[left] >= plo)) q.first = left + 1;
+    if (right < db.np && db.pep_mono[right] <= phi) q.end = right + 1;
+    return q;
+}
+
+// ---- narrow windows: one wavefront per spectrum, peptide-major stream, counters in LDS -------------
 __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     const PrelimLds L = carve_prelim(smem, sc, b);
-    Counters<WIDE> cnt;
-    cnt.p = WIDE ? (w.wide_cnt + (size_t)blockIdx.x * w.wide_words) : L.cnt;
-    if (WIDE && *w.n_deferred == 0) return;
+    Counters cnt;
+    cnt.p = L.cnt;
 
     for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
-        const uint32_t spec = b.order ? b.order[blk] : blk;
-        if (WIDE && w.status[spec] != ST_DEFERRED) continue;
+        const uint32_t spec = b.order ? uni(b.order[blk]) : blk;
         __syncthreads();
         PhaseClock pc;
-        pc.start(WIDE ? nullptr : w.dbg, blk, 0);
-        const uint64_t p0 = b.peak_off[spec];
-        const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
-        const float* __restrict__ masses = b.masses + p0;
-        const uint32_t zraw = b.precursor_charge[spec];
-        uint32_t z0, z1;
-        if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {  // scoring.rs:423, 437, 442
-            z0 = sc.min_precursor_charge;
-            z1 = sc.max_precursor_charge;
-        } else {
-            z0 = z1 = zraw;
-        }
-        uint32_t nfz_max = 0;
-        for (uint32_t z = z0; z <= z1; z++) {
-            const uint32_t m = max_fragment_charge(sc.max_fragment_charge, z) - 1;
-            nfz_max = m > nfz_max ? m : nfz_max;
-        }
-        if (nfz_max > b.fzcap) nfz_max = b.fzcap;  // (upload sized fzcap from the same rule)
+        pc.start(w.dbg, blk, 0);
+        const SpecInfo si = load_spec(sc, b, spec);
+        const uint32_t P = si.P, nfz_max = si.nfz_max;
+        const float* __restrict__ masses = b.masses + si.p0;
 
         // fragment-tolerance window of every (peak, fragment charge): database.rs:481 on the
         // experimental mass peak*charge of scoring.rs:360
@@ -282,64 +343,35 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         const uint32_t ptop = pow2_floor(P);
         pc.mark(0);
 
-        const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
-        Tol iso_tol;
-        iso_tol.kind = 2;
-        iso_tol.lo = -2.4f;
-        iso_tol.hi = 2.4f;  // scoring.rs:430
-        if (b.isolation_lo && b.isolation_hi) {
-            const float a = b.isolation_lo[spec], c = b.isolation_hi[spec];
-            if (a == a && c == c) { iso_tol.lo = a; iso_tol.hi = c; }
-        }
         const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
         const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
 
         UList A, B;  // wave-uniform state
         A.items = L.listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
         B.items = L.listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
-        bool deferred = false, deferred_open = false;  // uniform
+        bool deferred = false;                     // uniform
         uint32_t tot_matched = 0, tot_scored = 0;  // uniform
 
-        for (uint32_t z = z0; z <= z1 && !deferred; z++) {
+        for (uint32_t z = si.z0; z <= si.z1 && !deferred; z++) {
             const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
-            const float precursor_mass = mzp * (float)z;
-            const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
+            const float precursor_mass = si.mzp * (float)z;
+            const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
             if (fold) { A.stored = 0; A.len = 0; }
             for (int iso = isoA; iso <= isoB && !deferred; iso++) {
-                // ---- IndexedDatabase::query, database.rs:402-425 ----
                 const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
-                float plo, phi;
-                tol_bounds(ptol, center, plo, phi);
-                uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
-                left = left ? left - 1 : 0;
-                // the window is short in a narrow search: bracket it by galloping from `left` before searching
-                uint32_t ghi = left;
-                for (uint64_t span = WAVE;; span *= 16) {
-                    ghi = (uint64_t)left + span < db.np ? (uint32_t)(left + span) : db.np;
-                    if (ghi == db.np || order_key(db.pep_mono[ghi - 1]) > order_key(phi)) break;
-                }
-                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, ghi, order_key(phi));
-                const uint32_t potential = right - left + 1;  // scoring.rs:351
-                if (!WIDE && potential > sc.wcap) {
+                const Window q = query_window<true>(db, ptol, center);
+                const uint32_t left = q.left;
+                const uint32_t potential = q.right - q.left + 1;  // scoring.rs:351
+                if (potential > sc.wcap) {
                     deferred = true;
-                    deferred_open = potential > sc.open_thresh && w.open_blocks > 0;
-                    break;
-                }
-                if (WIDE && potential > w.wide_words) {  // a later query of this spectrum is an open-search window
-                    deferred = true;
-                    deferred_open = true;
                     break;
                 }
                 pc.mark(1);
                 cnt.zero(potential, lane);
-                // edge rule of database.rs:526-531: interior indices are in range by construction
-                uint32_t first = left, end = right;
-                if (left < db.np && !(db.pep_mono[left] >= plo)) first = left + 1;
-                if (right < db.np && db.pep_mono[right] <= phi) end = right + 1;
                 __syncthreads();
                 uint32_t acc = 0;
-                if (first < end) {
-                    const uint64_t f0 = db.pm_off[first], f1 = db.pm_off[end];
+                if (q.first < q.end) {
+                    const uint64_t f0 = db.pm_off[q.first], f1 = db.pm_off[q.end];
                     auto count_one = [&](float frag) -> uint32_t {
                         if (!sorted_ok) {
                             uint32_t c = 0;
@@ -436,17 +468,17 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 __syncthreads();
             }
         }
-        if (deferred) {
+        if (deferred) {  // some precursor window of this spectrum is too large for the LDS counters
             if (lane == 0) {
-                w.status[spec] = deferred_open ? ST_DEFERRED_OPEN : ST_DEFERRED;
-                atomicAdd(w.n_deferred + (deferred_open ? 2 : 0), 1u);
+                w.status[spec] = ST_DEFERRED;
+                w.queue[atomicAdd(w.n_deferred + CTR_QUEUED, 1u)] = spec;
             }
             continue;
         }
         ulist_trim(B, sc.report_psms);  // scoring.rs:460
         __syncthreads();
         if (lane == 0) {
-            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + 1, 1u);
+            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
             w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
             w.cand_len[spec] = B.stored;
             w.totals[2 * spec] = tot_matched;
@@ -457,211 +489,662 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
     }
 }
 
+// ---- large windows (open search, wide-window / DIA, mid-size tolerances) ---------------------------
+// A window of 10^3..10^6 candidates is walked in TILES of 2^tile_shift consecutive peptides.  The index has a
+// tile-major copy (device_types.h): inside a tile the fragments are m/z-sorted and a position table turns a
+// fragment-tolerance window into a short contiguous run.  Three kernels:
+//   count    : one workgroup per spectrum.  Every (peak, fragment charge) window is looked up by an 8-lane
+//              group — 2 table reads, then the run is read 16 entries per step — and each entry inside both
+//              the m/z window and the precursor window bumps a u16 counter of the tile IN LDS (no counter
+//              traffic to HBM).  After each tile all wavefronts scan the counters in slot order and append
+//              the slots that can still enter the k-select to a candidate segment in HBM.  "Can still enter":
+//              count >= the k-th largest count of all EARLIER tiles (a histogram), which is a lower bound of
+//              the heap minimum at that point of heap.rs:21-27 — pruning with it never changes the replay.
+//   replay   : trim_hits' bounded_min_heapify (heap.rs:7-28) is inherently sequential per query, so ONE LANE
+//              replays one query (heap in LDS, first k slots verbatim, build, offers in slot order): 64
+//              queries per wavefront instead of one.
+//   assemble : one wavefront per spectrum concatenates / folds the per-query lists exactly as
+//              scoring.rs:384-462 does and writes the final preliminary list.
+// Same predicate as database.rs:526-533, so counts — and everything downstream — are identical.
+constexpr uint32_t TILE_THREADS = 512;
+constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
+constexpr uint32_t GROUP = 8;                         // lanes per (peak, fragment charge) window
+constexpr uint32_t NGROUP = TILE_THREADS / GROUP;     // windows in flight per pass
+constexpr uint32_t HIST_BINS = 64;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
-// ---- open / wide-window searches ------------------------------------------------------------------
-// When the precursor window holds 10^4..10^6 candidates, streaming all of their fragments (peptide-major)
-// is the wrong loop order.  Here every (peak, fragment charge) window is looked up in the m/z-major copy
-// of the index: one table lookup gives a start position, then the wavefront streams the few hundred
-// fragments of that m/z window with coalesced 8-byte loads and bumps a u16 counter per in-window
-// peptide.  Counters live in a per-block slab in HBM that is all-zero between spectra: the k-select
-// scan clears what it reads.  Same predicate as database.rs:526-533, so the counts are identical.
-__global__ __launch_bounds__(64) void prelim_open_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+struct TileLds {
+    uint32_t* cnt;      // [tile_size / 2] u16 pairs
+    uint32_t* bm;       // [tile_size / 64] one bit per counter word: touched since the last scan
+    float* win_lo;      // [fzcap * pcap]
+    float* win_hi;
+    uint32_t* hist;     // [HIST_BINS] non-empty slots of the query so far, by matched count
+    uint32_t* wsum;     // [TILE_WAVES]
+    uint32_t* sh;       // [16] workgroup-shared scalars
+};
+__host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem) {
+    size_t off = 0;
+    if (l) l->cnt = (uint32_t*)(smem + off);
+    off += ((size_t)1 << tile_shift) * 2;
+    if (l) l->bm = (uint32_t*)(smem + off);
+    off += ((size_t)1 << tile_shift) / 64 * 4;
+    if (l) l->win_lo = (float*)(smem + off);
+    off += (size_t)b.fzcap * b.pcap * 4;
+    if (l) l->win_hi = (float*)(smem + off);
+    off += (size_t)b.fzcap * b.pcap * 4;
+    if (l) l->hist = (uint32_t*)(smem + off);
+    off += HIST_BINS * 4;
+    if (l) l->wsum = (uint32_t*)(smem + off);
+    off += TILE_WAVES * 4;
+    if (l) l->sh = (uint32_t*)(smem + off);
+    off += 16 * 4;
+    return (off + 15) & ~(size_t)15;
+}
+
+enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_HMIN, SH_HMIN_NEXT, SH_HEAD, SH_PREV,
+       SH_CHUNK_CUR, SH_CHUNK_LIM };
+constexpr uint32_t ARENA_CHUNK = 1u << 16;  // entries a workgroup takes from the global arena at a time
+
+__device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecInfo& si, uint32_t z, int iso) {
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    const uint32_t n_iso = fold ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
+    return (z - si.z0) * n_iso + (uint32_t)(iso - (fold ? sc.min_isotope_err : 0));
+}
+
+constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group kept in registers
+
+__device__ __forceinline__ void tile_hit(const TileLds& L, uint32_t x, uint32_t& acc) {
+    // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
+    atomicAdd(&L.cnt[x >> 1], 1u << ((x & 1) * 16));
+    atomicOr(&L.bm[x >> 6], 1u << ((x >> 1) & 31u));
+    acc++;
+}
+__device__ __forceinline__ void tile_test2(const TileLds& L, const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo,
+                                           float hi, uint32_t first, uint32_t end, uint32_t tb, uint32_t& acc) {
+    const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
+    if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= first && e.x < end) tile_hit(L, e.x - tb, acc);
+    if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= first && e.z < end) tile_hit(L, e.z - tb, acc);
+}
+
+// (parameters through memory: ~300 bytes of by-value arguments would all be live in SGPRs and spill)
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams* __restrict__ kp) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t lane = lane_id();
-    if (w.n_deferred[2] == 0) return;
+    const DevDbView& db = kp->db;
+    const DevScorer& sc = kp->sc;
+    const DevBatchView& b = kp->b;
+    const DevWork& w = kp->w;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool w0 = wave == 0;
+    const uint32_t n_queued = uni(w.n_deferred[CTR_QUEUED]);
+    if (n_queued == 0) return;
+    TileLds L;
+    tile_lds_layout(db.tile_shift, b, &L, smem);
+    const uint32_t TSH = db.tile_shift, TS = 1u << TSH;
+    const uint32_t n_bm = TS / 64;                                 // bitmap words of a tile
+    const uint32_t bw_per = n_bm > TILE_THREADS ? n_bm / TILE_THREADS : 1;  // ... owned by one thread, contiguous: slot order == thread order
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
-    uint64_t* listA = (uint64_t*)smem;
-    uint64_t* listB = listA + (fold ? sc.list_cap : 0);
-    uint32_t* cnt = w.open_cnt + (size_t)blockIdx.x * w.open_words;
+    const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+    const uint32_t grp = tid / GROUP, sub = tid % GROUP;
+    const float cell_max = (float)(db.lut_stride - 1);
+    const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
 
-    for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
-        const uint32_t spec = b.order ? b.order[blk] : blk;
-        if (w.status[spec] != ST_DEFERRED_OPEN) continue;
+    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) L.cnt[i] = 0;  // all-zero between tiles: the scan clears what it reads
+    for (uint32_t i = tid; i < n_bm; i += TILE_THREADS) L.bm[i] = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (tid == 0) {  // first arena chunk of this workgroup
+        const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
+        const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
+        const bool fits = (uint64_t)got + chunk <= w.arena_cap;
+        L.sh[SH_CHUNK_CUR] = fits ? got : NONE32;
+        L.sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
+    }
+
+    for (;;) {
         __syncthreads();
+        if (tid == 0) L.sh[SH_ITEM] = atomicAdd(w.n_deferred + CTR_QUEUE_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = uni(L.sh[SH_ITEM]);
+        if (item >= n_queued) break;
+        const uint32_t spec = uni(w.queue[item]);
         PhaseClock pc;
-        pc.start(w.dbg, blk, 0);
-        const uint64_t p0 = b.peak_off[spec];
-        const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
-        const float* __restrict__ masses = b.masses + p0;
-        const uint32_t zraw = b.precursor_charge[spec];
-        uint32_t z0, z1;
-        if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {
-            z0 = sc.min_precursor_charge;
-            z1 = sc.max_precursor_charge;
-        } else {
-            z0 = z1 = zraw;
+        pc.start(w0 ? w.dbg : nullptr, item, 2);
+        const SpecInfo si = load_spec(sc, b, spec);
+        const uint32_t P = si.P;
+        const float* __restrict__ masses = b.masses + si.p0;
+        for (uint32_t i = tid; i < P; i += TILE_THREADS) {  // database.rs:481 on peak*charge (scoring.rs:360)
+            const float m = masses[i];
+            for (uint32_t fz = 1; fz <= si.nfz_max; fz++) {
+                float lo, hi;
+                tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
+                L.win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
+                L.win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
+            }
         }
-        const float mzp = b.precursor_mz[spec] - PROTON;  // scoring.rs:420
-        Tol iso_tol;
-        iso_tol.kind = 2;
-        iso_tol.lo = -2.4f;
-        iso_tol.hi = 2.4f;  // scoring.rs:430
-        if (b.isolation_lo && b.isolation_hi) {
-            const float a = b.isolation_lo[spec], c = b.isolation_hi[spec];
-            if (a == a && c == c) { iso_tol.lo = a; iso_tol.hi = c; }
-        }
-        const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
-        UList A, B;
-        A.items = listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
-        B.items = listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
-        uint32_t tot_matched = 0, tot_scored = 0;
+        if (tid < w.qmax) w.qrec[(size_t)item * w.qmax + tid].potential = 0;  // queries this spectrum does not run
 
-        for (uint32_t z = z0; z <= z1; z++) {
+        for (uint32_t z = si.z0; z <= si.z1; z++) {
             const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
-            const float precursor_mass = mzp * (float)z;
-            const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
-            if (fold) { A.stored = 0; A.len = 0; }
+            const uint32_t nprobe = P * (nfz < si.nfz_max ? nfz : si.nfz_max);
+            const float precursor_mass = si.mzp * (float)z;
+            const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
             for (int iso = isoA; iso <= isoB; iso++) {
-                const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
-                float plo, phi;
-                tol_bounds(ptol, center, plo, phi);
-                uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
-                left = left ? left - 1 : 0;
-                const uint32_t right = wave_partition_point<false>(db.pep_mono, left, db.np, order_key(phi));
+                const size_t qid = (size_t)item * w.qmax + query_index(sc, si, z, iso);
+                // ---- IndexedDatabase::query by wavefront 0, shared through LDS ----
+                if (w0) {
+                    const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
+                    if (lane == 0) {
+                        L.sh[SH_LEFT] = q.left; L.sh[SH_RIGHT] = q.right; L.sh[SH_FIRST] = q.first; L.sh[SH_END] = q.end;
+                        L.sh[SH_MATCHED] = 0; L.sh[SH_SCORED] = 0; L.sh[SH_HMIN] = 0; L.sh[SH_HEAD] = NONE32; L.sh[SH_PREV] = NONE32;
+                    }
+                    L.hist[lane] = 0;
+                    w.seeds[qid * 64 + lane] = 0;
+                }
+                __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
+                const uint32_t left = uni(L.sh[SH_LEFT]), right = uni(L.sh[SH_RIGHT]), first = uni(L.sh[SH_FIRST]), end = uni(L.sh[SH_END]);
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
-                uint32_t first = left, end = right;           // database.rs:526-531
-                if (left < db.np && !(db.pep_mono[left] >= plo)) first = left + 1;
-                if (right < db.np && db.pep_mono[right] <= phi) end = right + 1;
-
-                // ---- matched-fragment counting, scoring.rs:358-375 ----
-                pc.mark(5);
+                const uint32_t k = trim_k(potential, sc.report_psms);
+                const bool select = potential > k;
+                const uint32_t nseed = select ? k : potential;  // slots kept verbatim (<= 64)
                 uint32_t acc = 0;
-                if (first < end) {
-                    for (uint32_t i = 0; i < P; i++) {
-                        const float m = masses[i];
-                        for (uint32_t fz = 1; fz <= nfz; fz++) {
+                // a window's bounds (LDS) and its table cells: lut_scale is a power of two, so the products are exact —
+                // entries >= lo start at cell floor(lo*scale) and entries <= hi end before cell floor(hi*scale) + 1
+                auto probe_bounds = [&](uint32_t pr, float& lo, float& hi) {
+                    lo = 1.0f; hi = 0.0f;  // inactive: empty window
+                    if (pr < nprobe && first < end) {
+                        const uint32_t fz = pr / P, i = pr - fz * P;
+                        lo = L.win_lo[(size_t)fz * b.pcap + i];
+                        hi = L.win_hi[(size_t)fz * b.pcap + i];
+                    }
+                };
+                auto probe_cells = [&](float lo, float hi, uint32_t& icl, uint32_t& ich) {
+                    float cl = floorf(lo * db.lut_scale);
+                    float ch = floorf(hi * db.lut_scale) + 1.0f;
+                    cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
+                    ch = ch > 0.0f ? ch : 0.0f;
+                    icl = cl < cell_max ? (uint32_t)cl : db.lut_stride - 1;
+                    ich = ch < cell_max ? (uint32_t)ch : db.lut_stride - 1;
+                    if (!(lo <= hi)) icl = ich = 0;  // empty run
+                };
+                pc.mark(0);
+                const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it
+                const uint32_t t0 = left >> TSH, t1 = db.np ? (last_pep >> TSH) : 0;
+                // table reads of the group's first PROBE_CACHE windows run one tile ahead of their use
+                uint32_t p0n[PROBE_CACHE], p1n[PROBE_CACHE];
+                auto lut_fetch = [&](uint32_t t) {
+                    const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
+#pragma unroll
+                    for (uint32_t u = 0; u < PROBE_CACHE; u++) {
+                        float lo, hi;
+                        uint32_t icl, ich;
+                        probe_bounds(grp + u * NGROUP, lo, hi);
+                        probe_cells(lo, hi, icl, ich);
+                        p0n[u] = lut[icl];
+                        p1n[u] = lut[ich];
+                    }
+                };
+                lut_fetch(t0);
+                for (uint32_t t = t0; t <= t1; t++) {
+                    const uint32_t tb = t << TSH;
+                    // ---- stream: scoring.rs:358-375 over database.rs:480-536 ----
+                    {
+                        uint32_t(&p0)[PROBE_CACHE] = p0n;  // (fetched during the previous tile)
+                        uint32_t(&p1)[PROBE_CACHE] = p1n;
+#pragma unroll
+                        for (uint32_t h = 0; h < PROBE_CACHE; h += 4) {
+                            uint4 e[4][2];
+                            uint32_t j0[4];
+#pragma unroll
+                            for (uint32_t u = 0; u < 4; u++) {  // the first two 16-entry steps of four windows in flight together
+                                j0[u] = (p0[h + u] & ~1u) + 2 * sub;
+#pragma unroll
+                                for (uint32_t st = 0; st < 2; st++) {
+                                    const uint32_t j = j0[u] + st * 2 * GROUP;
+                                    e[u][st] = make_uint4(0u, 0u, 0u, 0u);
+                                    if (j < p1[h + u]) e[u][st] = frag2[j >> 1];  // (tm_frag is padded by 2 entries)
+                                }
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < 4; u++) {
+                                float lo, hi;
+                                probe_bounds(grp + (h + u) * NGROUP, lo, hi);
+#pragma unroll
+                                for (uint32_t st = 0; st < 2; st++)
+                                    tile_test2(L, e[u][st], j0[u] + st * 2 * GROUP, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
+                                for (uint32_t j = j0[u] + 4 * GROUP; j < p1[h + u]; j += 2 * GROUP)
+                                    tile_test2(L, frag2[j >> 1], j, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
+                            }
+                        }
+                        if (t < t1) lut_fetch(t + 1);  // lands while this tile is scanned
+                        // more windows than the register cache holds (> 512 per query): the plain loop
+                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
+                        for (uint32_t pr = grp + PROBE_CACHE * NGROUP; pr < nprobe; pr += NGROUP) {
                             float lo, hi;
-                            tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
-                            // conservative start: one table cell below the cell of `lo`
-                            float cell = floorf(lo * db.lut_scale) - 1.0f;
-                            cell = cell > 0.0f ? cell : 0.0f;  // also maps NaN to 0
-                            const uint32_t bin = cell < (float)(db.lut_n - 1) ? (uint32_t)cell : db.lut_n - 1;
-                            // four 8-byte loads per lane are in flight per trip (2 KiB per wavefront)
-                            for (uint64_t j = (uint64_t)db.mz_lut[bin] + lane;; j += 4 * WAVE) {
-                                SageTheoretical fr[4];
-                                bool in[4];
+                            uint32_t icl, ich;
+                            probe_bounds(pr, lo, hi);
+                            probe_cells(lo, hi, icl, ich);
+                            const uint32_t q0 = lut[icl], q1 = lut[ich];
+                            for (uint32_t j = (q0 & ~1u) + 2 * sub; j < q1; j += 2 * GROUP)
+                                tile_test2(L, frag2[j >> 1], j, q0, q1, lo, hi, first, end, tb, acc);
+                        }
+                    }
+                    pc.mark(1);
+                    __syncthreads();
+                    pc.mark(2);
+                    // ---- scan pass 1: each thread walks the touched counter words of its share of the tile, in slot order ----
+                    const uint32_t hmin = uni(L.sh[SH_HMIN]);  // lower bound of the heap minimum's count for this tile
+                    const uint32_t bw0 = tid * bw_per;
+                    uint32_t nne = 0, ncand = 0, h12 = 0, h34 = 0;
+                    auto slot_stats = [&](uint32_t c, uint32_t x) {
+                        if (c == 0) return;
+                        nne++;
+                        if (c <= 2) h12 += c == 1 ? 1u : 0x10000u;
+                        else if (c <= 4) h34 += c == 3 ? 1u : 0x10000u;
+                        else atomicAdd(&L.hist[c < HIST_BINS ? c : HIST_BINS - 1], 1u);
+                        if (select && c >= hmin && (uint64_t)tb + x >= (uint64_t)left + nseed) ncand++;
+                    };
+                    if (bw0 < n_bm) {
+                        for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
+                            uint32_t m = L.bm[bwi];
+                            while (m) {  // four touched words per trip: their LDS reads overlap
+                                uint32_t wd[4], v[4];
 #pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    in[q] = j + (uint64_t)q * WAVE < db.nf;
-                                    fr[q] = SageTheoretical{0, 0.f};
-                                    if (in[q]) fr[q] = db.mz_frag[j + (uint64_t)q * WAVE];
+                                for (int i = 0; i < 4; i++) {
+                                    wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
+                                    m &= m - 1;  // (0 stays 0)
                                 }
 #pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const bool hit = in[q] && fr[q].fragment_mz >= lo && fr[q].fragment_mz <= hi &&
-                                                     fr[q].peptide_index >= first && fr[q].peptide_index < end;
-                                    if (hit) {
-                                        const uint32_t idx = fr[q].peptide_index - left;
-                                        if (!(sc.dbg_flags & 2)) atomicAdd(&cnt[idx >> 1], 1u << ((idx & 1) * 16));
-                                        acc++;
-                                    }
+                                for (int i = 0; i < 4; i++) v[i] = wd[i] != NONE32 ? L.cnt[wd[i]] : 0;
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    if (v[i] == 0) continue;
+                                    slot_stats(v[i] & 0xFFFFu, 2 * wd[i]);
+                                    slot_stats(v[i] >> 16, 2 * wd[i] + 1);
                                 }
-                                // ascending m/z: done once the last quarter holds nothing at or below `hi`
-                                if (__ballot(in[3] && !(fr[3].fragment_mz > hi)) == 0ull) break;
                             }
                         }
                     }
-                }
-                const uint32_t matched = wave_sum(acc);
-                // the counters are only ever touched by this wavefront, through L2 (atomics, sc1 loads, write-through
-                // stores): ordering needs the earlier operations to have completed, not an L2 write-back
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pc.mark(6);
-                tot_matched += matched;
-                UList& target = fold ? A : B;
-                if (matched == 0) {  // scoring.rs:376-378 (no counter was touched: the slab is still zero)
-                    ulist_append_empties(target, potential, sc.kmax);
-                    continue;
-                }
-                // ---- trim_hits, scoring.rs:380: one pass over the slots, 4 per lane, clearing as it goes ----
-                const uint32_t k = trim_k(potential, sc.report_psms);
-                const bool select = potential > k;
-                WaveHeap h{0, 0};
-                uint32_t scored = 0;
-                for (uint32_t base = 0; base < ((sc.dbg_flags & 4) ? 256u : potential); base += 4 * WAVE) {
-                    const uint32_t s0 = base + 4 * lane;  // this lane's first slot
-                    uint32_t* wp = cnt + (s0 >> 1);
-                    const uint32_t w0 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t w1 = __hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w0) wp[0] = 0;
-                    if (w1) wp[1] = 0;
-                    uint32_t c[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        if (s0 + q >= potential) c[q] = 0;
-                        scored += (uint32_t)__popcll(__ballot(c[q] > 0));
+                    // wavefront totals of the non-empty slot count and of histogram bins 1..4 (16-bit fields: <= 64 * 64)
+                    nne = wave_sum_dpp(nne);
+                    h12 = wave_sum_dpp(h12);
+                    h34 = wave_sum_dpp(h34);
+                    if (lane == 0 && nne) {
+                        atomicAdd(&L.sh[SH_SCORED], nne);
+                        if (h12 & 0xFFFFu) atomicAdd(&L.hist[1], h12 & 0xFFFFu);
+                        if (h12 >> 16) atomicAdd(&L.hist[2], h12 >> 16);
+                        if (h34 & 0xFFFFu) atomicAdd(&L.hist[3], h34 & 0xFFFFu);
+                        if (h34 >> 16) atomicAdd(&L.hist[4], h34 >> 16);
                     }
-                    if (!select) {  // potential <= k <= 64: every slot goes to the list verbatim, in slot order
-                        // slot i sits in lane i/4, sub i%4
-                        uint32_t ci = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t v = __shfl(c[q], (int)(lane >> 2), 64);
-                            if ((lane & 3u) == (uint32_t)q) ci = v;
-                        }
-                        const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
-                        ulist_append(target, ci ? pack_prescore(ci, left + base + lane, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
-                        continue;  // (potential <= 64 => single trip)
+                    // exclusive prefix of ncand over the lanes, bit-sliced through ballots (no cross-lane data movement)
+                    uint32_t lane_off = 0, wave_total = 0;
+                    for (uint32_t bit = 0; __ballot((ncand >> bit) != 0) != 0ull; bit++) {
+                        const uint64_t m = __ballot(((ncand >> bit) & 1u) != 0);
+                        lane_off += (uint32_t)__popcll(m & lt_mask) << bit;
+                        wave_total += (uint32_t)__popcll(m) << bit;
                     }
-                    uint32_t from = 0;  // first slot of this chunk that is offered (slots < k seed the heap)
-                    if (base == 0) {
-                        uint32_t ci = 0;
+                    if (lane == 0) L.wsum[wave] = wave_total;
+                    pc.mark(3);
+                    __syncthreads();
+                    if (t < t1) {  // warm L2 with the next tile's runs while this tile is scanned (the values are not used)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t v = __shfl(c[q], (int)(lane >> 2), 64);
-                            if ((lane & 3u) == (uint32_t)q) ci = v;
-                        }
-                        const uint64_t v = (lane < k && ci) ? pack_prescore(ci, left + lane, z, iso) : PRESCORE_EMPTY;
-                        h.lo = (uint32_t)v;
-                        h.hi = (uint32_t)(v >> 32);
-                        wh_build(h, k);
-                        from = k;
-                    }
-                    // offers in slot order; a slot can only enter if its count reaches the heap minimum's
-                    const uint32_t hmin = prescore_matched(wh_get(h, 0));
-                    bool cand = false;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cand = cand || (c[q] > 0 && c[q] >= hmin && s0 + q >= from);
-                    uint64_t mask = __ballot(cand);
-                    if (sc.dbg_flags & 1) mask = 0;
-                    while (mask) {
-                        const uint32_t src = (uint32_t)__ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)c[q], (int)__builtin_amdgcn_readfirstlane(src));
-                            const uint32_t slot = base + 4 * src + q;
-                            if (cq && slot >= from) wh_offer(h, k, pack_prescore(cq, left + slot, z, iso));
+                        for (uint32_t u = 0; u < PROBE_CACHE; u++) {
+                            const uint32_t j = (p0n[u] & ~1u) + 2 * sub;
+                            if (j < p1n[u]) {
+                                uint32_t sink;
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(frag2 + (j >> 1)) : "memory");
+                            }
+                            if (j + 2 * GROUP < p1n[u]) {
+                                uint32_t sink;
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(frag2 + ((j + 2 * GROUP) >> 1)) : "memory");
+                            }
                         }
                     }
+                    uint32_t woff = 0, total = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < TILE_WAVES; i++) {
+                        const uint32_t v = L.wsum[i];
+                        woff += i < wave ? v : 0;
+                        total += v;
+                    }
+                    // one candidate segment per tile, carved from this workgroup's arena chunk (room for a whole tile is
+                    // reserved ahead of time, see below): {next, n, tile_base, 0} + entries, 16-byte aligned
+                    total = uni(total);
+                    const uint32_t seg = total ? uni(L.sh[SH_CHUNK_CUR]) : NONE32;  // (NONE32 when the arena is exhausted)
+                    if (w0) {
+                        // the k-th largest count seen so far bounds the heap minimum for every LATER slot
+                        uint32_t suffix = L.hist[lane];
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const uint32_t o = __shfl_down(suffix, off, 64);
+                            if ((int)lane + off < 64) suffix += o;
+                        }
+                        const uint64_t ok = __ballot(lane >= 1 && suffix >= k);
+                        if (lane == 0) {
+                            L.sh[SH_HMIN_NEXT] = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
+                            if (seg != NONE32) {
+                                *(uint4*)(w.arena + seg) = make_uint4(NONE32, total, tb, 0u);
+                                const uint32_t prev = L.sh[SH_PREV];
+                                if (prev == NONE32) L.sh[SH_HEAD] = seg;
+                                else w.arena[prev] = seg;
+                                L.sh[SH_PREV] = seg;
+                            }
+                        }
+                    }
+                    pc.mark(4);
+                    // ---- scan pass 2: write candidates and the verbatim slots, clear counters and bitmap ----
+                    if (bw0 < n_bm) {
+                        uint32_t pos = seg + 4 + woff + lane_off;
+                        auto slot_emit = [&](uint32_t c, uint32_t x) {
+                            if (c == 0) return;
+                            const uint64_t g = (uint64_t)tb + x - left;  // candidate slot
+                            if (g < nseed) w.seeds[qid * 64 + g] = (uint16_t)c;
+                            else if (select && c >= hmin && seg != NONE32) w.arena[pos++] = (c << 16) | x;
+                        };
+                        for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
+                            uint32_t m = L.bm[bwi];
+                            if (m) L.bm[bwi] = 0;
+                            while (m) {
+                                uint32_t wd[4], v[4];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
+                                    m &= m - 1;
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    v[i] = 0;
+                                    if (wd[i] != NONE32) {
+                                        v[i] = L.cnt[wd[i]];
+                                        L.cnt[wd[i]] = 0;
+                                    }
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    if (v[i] == 0) continue;
+                                    slot_emit(v[i] & 0xFFFFu, 2 * wd[i]);
+                                    slot_emit(v[i] >> 16, 2 * wd[i] + 1);
+                                }
+                            }
+                        }
+                    }
+                    pc.mark(5);
+                    __syncthreads();
+                    pc.mark(6);
+                    if (tid == 0) {  // (read again only after the next tile's first barrier)
+                        L.sh[SH_HMIN] = L.sh[SH_HMIN_NEXT];
+                        uint32_t cur = L.sh[SH_CHUNK_CUR];
+                        if (seg != NONE32) cur += ((total + 3u) & ~3u) + 4u;
+                        else if (total && cur == NONE32) atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);  // candidates were dropped
+                        // keep room for a whole tile's worth of candidates, so that every thread can take the segment base
+                        // from LDS without waiting for a global allocation
+                        if (cur == NONE32 || L.sh[SH_CHUNK_LIM] - cur < TS + 8u) {
+                            const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
+                            const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
+                            if ((uint64_t)got + chunk > w.arena_cap) {
+                                cur = NONE32;
+                            } else {
+                                cur = got;
+                                L.sh[SH_CHUNK_LIM] = got + chunk;
+                            }
+                        }
+                        L.sh[SH_CHUNK_CUR] = cur;
+                    }
                 }
-                if (select) ulist_append(target, ((uint64_t)h.hi << 32) | h.lo, k, sc.kmax);
-                tot_scored += scored;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                pc.mark(7);
-            }
-            if (fold) {  // scoring.rs:405 then `hits +=`
-                ulist_trim(A, sc.report_psms);
+                // ---- totals of this query ----
+                acc = wave_sum_dpp(acc);
+                if (lane == 0 && acc) atomicAdd(&L.sh[SH_MATCHED], acc);
                 __syncthreads();
-                for (uint32_t base = 0; base < A.stored; base += WAVE) {
-                    const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
-                    const uint32_t nvalid = A.stored - base < WAVE ? A.stored - base : WAVE;
-                    ulist_append(B, v, nvalid, sc.kmax);
+                if (tid == 0) {
+                    QueryRec r;
+                    r.left = left;
+                    r.potential = potential;
+                    r.matched = L.sh[SH_MATCHED];
+                    r.scored = L.sh[SH_SCORED];
+                    r.head = L.sh[SH_HEAD];
+                    r.z_iso = z | ((uint32_t)(iso + 128) << 8);
+                    r.pad[0] = L.hist[HIST_BINS - 1] != 0;  // some slot matched >= 63 peaks: the replay keeps 64-bit keys
+                    r.pad[1] = 0;
+                    w.qrec[qid] = r;
                 }
-                __syncthreads();
             }
         }
-        ulist_trim(B, sc.report_psms);  // scoring.rs:460
-        __syncthreads();
-        if (lane == 0) {
-            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + 1, 1u);
-            w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
-            w.cand_len[spec] = B.stored;
-            w.totals[2 * spec] = tot_matched;
-            w.totals[2 * spec + 1] = tot_scored;
-        }
-        for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
     }
+}
+
+// strided sift_down (heap.rs:40-60): element i of this lane's heap lives at hp[i * 64]
+template <typename K>
+__device__ __forceinline__ void sift_down_strided(K* hp, uint32_t len, uint32_t index, K moving) {
+    for (;;) {
+        const uint32_t l = index * 2 + 1;
+        if (l >= len) break;
+        const uint32_t r = l + 1;
+        const K vl = hp[l * 64];
+        const K vr = r < len ? hp[r * 64] : (K)~(K)0;
+        uint32_t smallest = index;
+        K sv = moving;
+        if (vl < sv) { smallest = l; sv = vl; }
+        if (r < len && vr < sv) { smallest = r; sv = vr; }
+        if (smallest == index) break;
+        hp[index * 64] = sv;  // slice.swap(smallest, index)
+        index = smallest;
+    }
+    hp[index * 64] = moving;
+}
+
+// Replace the root by `v` and sift it down (heap.rs:24-25 + :40-60) in ONE LDS round trip.  sift_down always
+// descends to the smaller child (the left one on a tie) — a path that does not depend on the value being sifted —
+// so with one bit per internal node ("the right child is the smaller one") the whole root-to-leaf path is known
+// from registers, its values and their siblings are fetched together, and `v` stops at the first path value
+// that is not smaller (values along a heap path never decrease).
+constexpr uint32_t HEAP_LEVELS = 6;  // k <= 64
+template <typename K>
+__device__ __forceinline__ void replace_root_path(K* hp, uint32_t k, uint32_t& rightmin, K v, bool active) {
+    const K INF = (K)~(K)0;
+    uint32_t p[HEAP_LEVELS + 1];
+    K pv[HEAP_LEVELS + 2], sv[HEAP_LEVELS + 1];
+    bool valid[HEAP_LEVELS + 1];
+    p[0] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < HEAP_LEVELS; j++) {
+        const uint32_t l = 2 * p[j] + 1;
+        valid[j + 1] = (j == 0 ? active : valid[j]) && l < k;
+        p[j + 1] = valid[j + 1] ? l + ((rightmin >> p[j]) & 1u) : 0;
+    }
+#pragma unroll
+    for (uint32_t j = 1; j <= HEAP_LEVELS; j++) {
+        const uint32_t sib = (p[j] & 1u) ? p[j] + 1 : p[j] - 1;  // the other child of p[j-1]
+        pv[j] = valid[j] ? hp[p[j] * 64] : INF;
+        sv[j] = (valid[j] && sib < k) ? hp[sib * 64] : INF;
+    }
+    pv[HEAP_LEVELS + 1] = INF;
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t j = 1; j <= HEAP_LEVELS; j++)
+        if (valid[j] && d == j - 1 && pv[j] < v) d = j;
+    if (!active) return;
+#pragma unroll
+    for (uint32_t j = 0; j <= HEAP_LEVELS; j++) {
+        if (j < d) {
+            hp[p[j] * 64] = pv[j + 1];  // slice.swap(smallest, index), one level at a time
+            const K nv = j + 1 < d ? pv[j + 2] : v;  // what ends up at p[j+1]
+            const bool child_is_left = (p[j + 1] & 1u) != 0;
+            const K left = child_is_left ? nv : sv[j + 1], right = child_is_left ? sv[j + 1] : nv;
+            const uint32_t bit = 1u << p[j];
+            rightmin = right < left ? (rightmin | bit) : (rightmin & ~bit);
+        } else if (j == d) {
+            hp[p[j] * 64] = v;
+        }
+    }
+}
+
+// Heap keys.  K = u64: the packed PreScore itself.  K = u32: within ONE query charge and isotope error are constant, so
+// PreScore's order is (matched, peptide) = (matched, candidate slot): `matched << 21 | slot`, EMPTY == 0.  Valid when the
+// window has at most 2^21 slots and every count is below 63 (QueryRec.pad[0] == 0).
+constexpr uint32_t K32_SLOT_BITS = 21;
+template <typename K> struct ReplayKey;
+template <> struct ReplayKey<uint64_t> {
+    static __device__ __forceinline__ uint64_t make(uint32_t c, uint32_t slot, uint32_t left, uint32_t z, int iso) {
+        return c ? pack_prescore(c, left + slot, z, iso) : PRESCORE_EMPTY;
+    }
+    static __device__ __forceinline__ uint64_t unpack(uint64_t v, uint32_t, uint32_t, int) { return v; }
+    static __device__ __forceinline__ uint32_t matched(uint64_t v) { return prescore_matched(v); }
+};
+template <> struct ReplayKey<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t c, uint32_t slot, uint32_t, uint32_t, int) {
+        return c ? (c << K32_SLOT_BITS) | slot : 0u;
+    }
+    static __device__ __forceinline__ uint64_t unpack(uint32_t v, uint32_t left, uint32_t z, int iso) {
+        return v ? pack_prescore(v >> K32_SLOT_BITS, left + (v & ((1u << K32_SLOT_BITS) - 1u)), z, iso) : PRESCORE_EMPTY;
+    }
+    static __device__ __forceinline__ uint32_t matched(uint32_t v) { return v >> K32_SLOT_BITS; }
+};
+
+// one lane = one query; every round each lane looks at ONE candidate entry (entries are fetched four at a time, one
+// load ahead) and the lanes whose entry can enter — heap.rs:22: later slots have larger peptide indices, so
+// `slice[i] > slice[0]` <=> count >= the root's count — replace their root and sift down together
+template <typename K>
+__device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const QueryRec& rec, uint64_t qid, uint32_t k, bool live,
+                                               uint32_t z, int iso, PhaseClock& pc) {
+    typedef ReplayKey<K> RK;
+    uint32_t rightmin = 0;  // bit p: the right child of node p is strictly smaller than the left one
+    uint32_t hmin = 0;
+    if (live) {
+        for (uint32_t i = 0; i < k; i++) hp[i * 64] = RK::make(w.seeds[qid * 64 + i], i, rec.left, z, iso);  // first k slots verbatim
+        for (uint32_t i = k / 2; i-- > 0;) sift_down_strided<K>(hp, k, i, hp[i * 64]);                       // heap.rs:13-15
+        for (uint32_t p = 0; 2 * p + 2 < k; p++)
+            if (hp[(2 * p + 2) * 64] < hp[(2 * p + 1) * 64]) rightmin |= 1u << p;
+        hmin = RK::matched(hp[0]);
+    }
+    // The candidate stream of a query is a chain of segments {header cell, entry cells...} (one 16-byte cell = a header or
+    // four entries).  A workgroup of the count kernel carves consecutive segments of a query from one chunk, so the chain is
+    // almost always contiguous: cells are consumed linearly with the next cell always in flight, and only a chunk boundary
+    // costs a dependent load.
+    uint32_t nextseg = live ? rec.head : NONE32;  // header position of the next segment
+    uint32_t pos = 0;                               // position of the cell in flight (pf)
+    uint32_t rem = 0, q = 4, tb = 0;                // entries left in the segment, next entry of the current cell
+    bool done = nextseg == NONE32;
+    uint4 cell = make_uint4(0u, 0u, 0u, 0u), pf = make_uint4(0u, 0u, 0u, 0u);
+    if (!done) {
+        pos = nextseg;
+        pf = *(const uint4*)(w.arena + pos);
+    }
+    auto take_cell = [&]() {
+        cell = pf;
+        pos += 4;
+        if (pos + 4 <= w.arena_cap) pf = *(const uint4*)(w.arena + pos);
+    };
+    pc.mark(0);
+    while (__ballot(!done) != 0ull) {
+        bool have = false;
+        uint32_t e = 0;
+        if (!done) {
+            if (rem == 0) {  // the next cell is a header (or the chain ends)
+                if (nextseg == NONE32) {
+                    done = true;
+                } else {
+                    if (nextseg != pos) {  // chunk boundary: not the cell in flight
+                        pos = nextseg;
+                        pf = *(const uint4*)(w.arena + pos);
+                    }
+                    take_cell();
+                    nextseg = cell.x; rem = cell.y; tb = cell.z;
+                    q = 4;
+                }
+            } else {
+                if (q == 4) {
+                    take_cell();
+                    q = 0;
+                }
+                e = q == 0 ? cell.x : q == 1 ? cell.y : q == 2 ? cell.z : cell.w;
+                q++;
+                rem--;
+                have = (e >> 16) >= hmin;
+            }
+        }
+        if (__ballot(have) == 0ull) continue;
+        replace_root_path<K>(hp, k, rightmin, RK::make(e >> 16, tb + (e & 0xFFFFu) - rec.left, rec.left, z, iso), have);
+        if (have) hmin = RK::matched(hp[0]);
+    }
+    pc.mark(1);
+    if (live)
+        for (uint32_t i = 0; i < k; i++) w.qres[qid * 64 + i] = RK::unpack(hp[i * 64], rec.left, z, iso);
+}
+
+__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w) {
+    __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
+    const uint32_t lane = lane_id();
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    if ((uint64_t)blockIdx.x * 64 >= n_q) return;
+    const uint64_t qid = (uint64_t)blockIdx.x * 64 + lane;
+    PhaseClock pc;
+    pc.start(w.dbg, blockIdx.x, 3);
+    QueryRec rec{};
+    if (qid < n_q) rec = w.qrec[qid];
+    const uint32_t k = trim_k(rec.potential, sc.report_psms);
+    const bool live = rec.potential > k && rec.matched != 0;  // else no k-select: the assembler takes the slots verbatim
+    const uint32_t z = rec.z_iso & 0xFFu;
+    const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
+    const bool small_keys = !(sc.dbg_flags & 2u) &&  // (SAGE_HIP_DEBUG_FLAGS=2: tests force the 64-bit path)
+                            __ballot(live && (rec.potential > (1u << K32_SLOT_BITS) || rec.pad[0] != 0)) == 0ull;
+    if (small_keys) replay_queries<uint32_t>((uint32_t*)heap + lane, w, rec, qid, k, live, z, iso, pc);
+    else replay_queries<uint64_t>(heap + lane, w, rec, qid, k, live, z, iso, pc);
+}
+
+__global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const uint32_t item = blockIdx.x;
+    if (item >= w.n_deferred[CTR_QUEUED]) return;
+    const uint32_t spec = w.queue[item];
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
+    const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+    uint64_t* listA = (uint64_t*)smem;
+    uint64_t* listB = listA + (fold ? sc.list_cap : 0);
+    const SpecInfo si = load_spec(sc, b, spec);
+    UList A, B;
+    A.items = listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
+    B.items = listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
+    uint32_t tot_matched = 0, tot_scored = 0;
+    for (uint32_t z = si.z0; z <= si.z1; z++) {
+        if (fold) { A.stored = 0; A.len = 0; }
+        for (int iso = isoA; iso <= isoB; iso++) {
+            const size_t qid = (size_t)item * w.qmax + query_index(sc, si, z, iso);
+            const QueryRec rec = w.qrec[qid];
+            const uint32_t k = trim_k(rec.potential, sc.report_psms);
+            tot_matched += rec.matched;
+            UList& target = fold ? A : B;
+            if (rec.matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
+                ulist_append_empties(target, rec.potential, sc.kmax);
+                continue;
+            }
+            tot_scored += rec.scored;
+            if (rec.potential > k) {  // trim_hits of this query (scoring.rs:380), replayed by tile_replay_kernel
+                ulist_append(target, lane < k ? w.qres[qid * 64 + lane] : PRESCORE_EMPTY, k, sc.kmax);
+            } else {
+                const uint32_t c = lane < rec.potential ? w.seeds[qid * 64 + lane] : 0;
+                ulist_append(target, c ? pack_prescore(c, rec.left + lane, z, iso) : PRESCORE_EMPTY, rec.potential, sc.kmax);
+            }
+        }
+        if (fold) {  // scoring.rs:405 then `hits +=` at :432 / :450
+            ulist_trim(A, sc.report_psms);
+            wave_sync();
+            for (uint32_t base = 0; base < A.stored; base += WAVE) {
+                const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
+                const uint32_t nvalid = A.stored - base < WAVE ? A.stored - base : WAVE;
+                ulist_append(B, v, nvalid, sc.kmax);
+            }
+            wave_sync();
+        }
+    }
+    ulist_trim(B, sc.report_psms);  // scoring.rs:460
+    wave_sync();
+    if (lane == 0) {
+        if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
+        w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
+        w.cand_len[spec] = B.stored;
+        w.totals[2 * spec] = tot_matched;
+        w.totals[2 * spec + 1] = tot_scored;
+    }
+    for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
 }
 
 // ---- rescoring -------------------------------------------------------------------------------
@@ -980,11 +1463,22 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
 
 }  // namespace
 
-size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool wide) {
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
     size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 + (size_t)b.fzcap * b.pcap * 8;
-    if (!wide) n += ((size_t)sc.wcap / 2 + 1) * 4;
+    n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
+}
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b) {
+    return tile_lds_layout(db.tile_shift, b, nullptr, nullptr);
+}
+int tile_kernel_prepare(size_t max_lds_bytes) {
+    return (int)hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)max_lds_bytes);
+}
+uint32_t queries_per_spectrum(const DevScorer& sc) {
+    const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
+    return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
 uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions) {
     // one candidate's items must always fit: (ions of the longest peptide) x (fragment charges)
@@ -998,19 +1492,17 @@ size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t max_i
 
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(prelim_kernel<false>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b, false), (hipStream_t)stream,
-                       db, sc, b, w);
+    hipLaunchKernelGGL(prelim_kernel, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
 }
-void launch_prelim_wide(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
-    if (b.n == 0 || w.wide_blocks == 0) return;
-    hipLaunchKernelGGL(prelim_kernel<true>, dim3(w.wide_blocks), dim3(64), prelim_lds_bytes(sc, b, true),
-                       (hipStream_t)stream, db, sc, b, w);
-}
-void launch_prelim_open(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
-    if (b.n == 0 || w.open_blocks == 0) return;
+void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+    if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    const size_t lds = ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(prelim_open_kernel, dim3(w.open_blocks), dim3(64), lds, (hipStream_t)stream, db, sc, b, w);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
+                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+    const uint64_t nq = (uint64_t)b.n * w.qmax;
+    hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
+    hipLaunchKernelGGL(tile_assemble_kernel, dim3(b.n), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
+                       (hipStream_t)stream, sc, b, w);
 }
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,

@@ -41,12 +41,22 @@ def synthetic_fasta(n_proteins: int, seed: int, mu: float = 6.0, sigma: float = 
 def synthetic_spectra(db: IndexedDatabase, n_spectra: int, seed: int, noise_peaks: int = 80, pure_noise_frac: float = 0.10,
                       keep_prob: float = 0.5, ppm_sigma: float = 3.0, charges=((2, 0.6), (3, 0.3), (4, 0.1)),
                       annotate_charge: bool = True, mass_shift_frac: float = 0.0, chimeric: int = 1,
-                      isolation_half_width: float = None):
+                      isolation_half_width: float = None, varmod_frac: float = None, varmod_residues: str = "M"):
     """Returns a list of RawSpectrum (centroided MS2).  Each spectrum is built from `chimeric` source
     peptides drawn uniformly from the target peptides of `db` (b/y ions, z=1 plus z=2 copies when the
     precursor charge is >= 3), fragment m/z error N(0, ppm_sigma), LogNormal intensities and uniform noise."""
     rng = np.random.default_rng(seed)
     targets = np.flatnonzero(db.decoy == 0)
+    plain = modded = None
+    if varmod_frac is not None:
+        # a source peptide "carries a variable mod" when it has a terminal mod or a modified `varmod_residues` residue
+        flag = np.zeros(len(db.seq) + 1, dtype=np.int64)
+        flag[:-1] = np.isin(db.seq, np.frombuffer(varmod_residues.encode(), np.uint8)) & (db.mods != 0)
+        per_pep = np.add.reduceat(flag, db.seq_off[:-1].astype(np.int64)) if db.n_peptides else np.zeros(0, np.int64)
+        is_mod = (per_pep > 0) | (np.nan_to_num(db.nterm) != 0) | (np.nan_to_num(db.cterm) != 0)
+        plain, modded = targets[~is_mod[targets]], targets[is_mod[targets]]
+        if len(plain) == 0 or len(modded) == 0:
+            plain = modded = None
     zs = np.array([c for c, _ in charges])
     zp = np.array([p for _, p in charges])
     zp = zp / zp.sum()
@@ -59,7 +69,11 @@ def synthetic_spectra(db: IndexedDatabase, n_spectra: int, seed: int, noise_peak
         first_mz = None
         n_src = 1 if chimeric <= 1 else int(rng.integers(2, chimeric + 1))
         for s in range(n_src):
-            pep = int(targets[rng.integers(len(targets))])
+            if plain is not None:
+                pool = modded if rng.random() < varmod_frac else plain
+                pep = int(pool[rng.integers(len(pool))])
+            else:
+                pep = int(targets[rng.integers(len(targets))])
             a, b = seq_off[pep], seq_off[pep + 1]
             res = _MASS_LUT[db.seq[a:b]] + db.mods[a:b].astype(np.float64)
             nterm = float(db.nterm[pep]) if not np.isnan(db.nterm[pep]) else 0.0

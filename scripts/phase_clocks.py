@@ -11,7 +11,7 @@ sp=SpectrumProcessor(150,True,0.0)
 batch=SpectrumBatch.from_spectra([p for p in (sp.process(r) for r in synthetic_spectra(host, 20000, cfg["spectra_seed"])) if len(p.masses)>=15])
 scorer=Scorer(DeviceDatabase(host,0), ScorerParams()); db=scorer.upload(batch)
 for _ in range(3): scorer.score_resident(db)
-out=np.zeros(16,np.uint64); L.check(L.load().sage_hip_debug_phase_cycles(scorer._h, L.as_ptr(out,C.c_uint64)))
+out=np.zeros(32,np.uint64); L.check(L.load().sage_hip_debug_phase_cycles(scorer._h, L.as_ptr(out,C.c_uint64)))
 n=3*min(batch.n,4096)
 print("prelim  cycles/spectrum: staging %d search %d match %d trim %d output %d" % tuple(out[:5]//n))
 print("rescore cycles/spectrum: setup %d phaseA %d phaseB %d rank %d emit %d" % tuple(out[8:13]//n))

@@ -27,12 +27,12 @@ class World:
         sp = SpectrumProcessor(max_peaks, True, 0.0)
         self.batch = SpectrumBatch.from_spectra([sp.process(r) for r in raw])
 
-    def check(self, params, context, hits=True, batch=None, every=1):
+    def check(self, params, context, hits=True, batch=None, every=1, dev=None):
         # OpenMSHyperScore goes through f32 ln_1p: device libm and glibc may differ by an f32 ulp (~6e-8
         # relative); SageHyperScore only uses f64 ln and is held to 1e-12.  North-star tolerance: 1e-4.
         rel_tol = 1e-6 if params.score_type == "OpenMSHyperScore" else None
         batch = batch or self.batch
-        scorer = Scorer(self.dev, params)
+        scorer = Scorer(dev or self.dev, params)
         dbatch = scorer.upload(batch)
         if hits:
             assert_initial_hits_equal(scorer, dbatch, self.orc, params, batch, context, every)
@@ -109,26 +109,37 @@ def test_wide_tolerance_hits_large_window_path(small_world):
     assert t["n_wide"] > 0
 
 
-def test_open_search_kernel_mz_major_path(small_world, monkeypatch):
-    """Force the m/z-major (open-search) kernel with a low threshold: ±500 Da, isotope folding, unknown charge,
-    report_psms > 1 — every branch of the nested k-selects on the dense-counter scan."""
-    monkeypatch.setenv("SAGE_HIP_OPEN_THRESH", "200")
+@pytest.mark.parametrize("tile_shift", [11, 12, 15])
+def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift):
+    """The tiled large-window kernel with small tiles (2048 / 4096 peptides) so that every window spans many
+    tiles, the first k slots straddle tile boundaries, and partial first/last tiles occur: ±500 Da, isotope
+    folding, unknown charge, report_psms > 1 — every branch of the nested k-selects."""
+    monkeypatch.setenv("SAGE_HIP_TILE_SHIFT", str(tile_shift))
+    monkeypatch.setenv("SAGE_HIP_WCAP", "64")
+    dev = DeviceDatabase(small_world.host, 0)
     idx = np.arange(0, small_world.batch.n, 5)
     sub = small_world.batch.subset(idx)
-    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0)), "open -500/+100 Da", batch=sub)
-    assert t["n_open"] > 0 and n > 50
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0)), "open -500/+100 Da", batch=sub, dev=dev)
+    assert t["n_wide"] > 0 and n > 50
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -40.0, 40.0), min_isotope_err=-1, max_isotope_err=2,
-                                   report_psms=4), "open ±40 Da x iso -1..2", batch=sub)
+                                   report_psms=4), "open ±40 Da x iso -1..2", batch=sub, dev=dev)
     b = sub
     unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8),
                             b.total_ion_current)
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -60.0, 60.0), max_fragment_charge=2), "open, charge None",
-                      batch=unknown)
-    # windows between wcap and the threshold still take the peptide-major global-counter kernel
-    monkeypatch.setenv("SAGE_HIP_OPEN_THRESH", "800")
-    monkeypatch.setenv("SAGE_HIP_WCAP", "64")
-    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -20.0, 20.0)), "mixed narrow/mid/open routing", batch=sub)
-    assert 0 < t["n_open"] < t["n_wide"]
+                      batch=unknown, dev=dev)
+    # windows around the narrow kernel's capacity: both kernels in one batch
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0)), "mixed narrow / tiled routing",
+                             batch=sub, dev=dev)
+    assert 0 < t["n_wide"] < sub.n
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -5000.0, 5000.0), min_matched_peaks=1,
+                                   report_psms=30), "every peptide in the window, k = 60", batch=small_world.batch.subset(np.arange(0, 40)),
+                      dev=dev)
+    # the replay kernel's 64-bit key path (taken by itself for windows above 2^21 slots or counts >= 63)
+    monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", "2")
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, 64-bit replay keys",
+                      batch=sub, dev=dev)
+    dev.close()
 
 
 def test_chimera_and_wide_window(gpu_required):
