@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsage_hip.so")
+LIB = os.environ.get("SAGE_HIP_LIB") or os.path.join(HERE, "libsage_hip.so")  # (override: kernel experiments)
 SOURCES = ["kernels.hip", "capi.hip", "host_db.cpp"]
 HEADERS = ["core.h", "device_types.h", "host_db.hpp", os.path.join("..", "..", "include", "sage_hip.h")]
 ARCH = "gfx950"
@@ -38,8 +38,9 @@ def build(force=False, verbose=True):
         return LIB
     objs = []
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+    common += os.environ.get("SAGE_HIP_EXTRA_FLAGS", "").split()
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + os.environ.get("SAGE_HIP_OBJ_SUFFIX", "") + ".o")
         cmd = [hipcc(), f"--offload-arch={ARCH}", *common, "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")

@@ -113,6 +113,10 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wavefront (vmcnt(0)), which would serialise loads issued ahead of a barrier on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- k-select state kept in registers: lane i holds heap element i (k <= 64) -------------------
 // bounded_min_heapify (heap.rs:7-60) is inherently sequential, but every index it touches is
 // wave-uniform, so the heap can live one element per lane and be driven with v_readlane/v_writelane
@@ -551,7 +555,7 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
     return (z - si.z0) * n_iso + (uint32_t)(iso - (fold ? sc.min_isotope_err : 0));
 }
 
-constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group kept in registers
+constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group whose table reads are in flight together
 
 __device__ __forceinline__ void tile_hit(const TileLds& L, uint32_t x, uint32_t& acc) {
     // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         L.sh[SH_MATCHED] = 0; L.sh[SH_SCORED] = 0; L.sh[SH_HMIN] = 0; L.sh[SH_HEAD] = NONE32; L.sh[SH_PREV] = NONE32;
                     }
                     L.hist[lane] = 0;
-                    w.seeds[qid * 64 + lane] = 0;
+                    w.seeds[qid * 64 + lane] = 0;  // (pass 2 of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
                 const uint32_t left = uni(L.sh[SH_LEFT]), right = uni(L.sh[SH_RIGHT]), first = uni(L.sh[SH_FIRST]), end = uni(L.sh[SH_END]);
@@ -668,67 +672,51 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 pc.mark(0);
                 const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it
                 const uint32_t t0 = left >> TSH, t1 = db.np ? (last_pep >> TSH) : 0;
-                // table reads of the group's first PROBE_CACHE windows run one tile ahead of their use
-                uint32_t p0n[PROBE_CACHE], p1n[PROBE_CACHE];
-                auto lut_fetch = [&](uint32_t t) {
-                    const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
-#pragma unroll
-                    for (uint32_t u = 0; u < PROBE_CACHE; u++) {
-                        float lo, hi;
-                        uint32_t icl, ich;
-                        probe_bounds(grp + u * NGROUP, lo, hi);
-                        probe_cells(lo, hi, icl, ich);
-                        p0n[u] = lut[icl];
-                        p1n[u] = lut[ich];
-                    }
-                };
-                lut_fetch(t0);
                 for (uint32_t t = t0; t <= t1; t++) {
                     const uint32_t tb = t << TSH;
                     // ---- stream: scoring.rs:358-375 over database.rs:480-536 ----
                     {
-                        uint32_t(&p0)[PROBE_CACHE] = p0n;  // (fetched during the previous tile)
-                        uint32_t(&p1)[PROBE_CACHE] = p1n;
+                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
+                        for (uint32_t prb = grp; prb < nprobe; prb += PROBE_CACHE * NGROUP) {
+                            uint32_t p0[PROBE_CACHE], p1[PROBE_CACHE];
 #pragma unroll
-                        for (uint32_t h = 0; h < PROBE_CACHE; h += 4) {
-                            uint4 e[4][2];
-                            uint32_t j0[4];
+                            for (uint32_t u = 0; u < PROBE_CACHE; u++) {  // all table reads in flight together
+                                float lo, hi;
+                                uint32_t icl, ich;
+                                probe_bounds(prb + u * NGROUP, lo, hi);
+                                probe_cells(lo, hi, icl, ich);
+                                p0[u] = lut[icl];
+                                p1[u] = lut[ich];
+                            }
 #pragma unroll
-                            for (uint32_t u = 0; u < 4; u++) {  // the first two 16-entry steps of four windows in flight together
-                                j0[u] = (p0[h + u] & ~1u) + 2 * sub;
+                            for (uint32_t h = 0; h < PROBE_CACHE; h += 4) {
+                                uint4 e[4][2];
+                                uint32_t j0[4];
 #pragma unroll
-                                for (uint32_t st = 0; st < 2; st++) {
-                                    const uint32_t j = j0[u] + st * 2 * GROUP;
-                                    e[u][st] = make_uint4(0u, 0u, 0u, 0u);
-                                    if (j < p1[h + u]) e[u][st] = frag2[j >> 1];  // (tm_frag is padded by 2 entries)
+                                for (uint32_t u = 0; u < 4; u++) {  // the first two 16-entry steps of four windows in flight together
+                                    j0[u] = (p0[h + u] & ~1u) + 2 * sub;
+#pragma unroll
+                                    for (uint32_t st = 0; st < 2; st++) {
+                                        const uint32_t j = j0[u] + st * 2 * GROUP;
+                                        e[u][st] = make_uint4(0u, 0u, 0u, 0u);
+                                        if (j < p1[h + u]) e[u][st] = frag2[j >> 1];  // (tm_frag is padded by 2 entries)
+                                    }
+                                }
+#pragma unroll
+                                for (uint32_t u = 0; u < 4; u++) {
+                                    float lo, hi;
+                                    probe_bounds(prb + (h + u) * NGROUP, lo, hi);
+#pragma unroll
+                                    for (uint32_t st = 0; st < 2; st++)
+                                        tile_test2(L, e[u][st], j0[u] + st * 2 * GROUP, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
+                                    for (uint32_t j = j0[u] + 4 * GROUP; j < p1[h + u]; j += 2 * GROUP)
+                                        tile_test2(L, frag2[j >> 1], j, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
                                 }
                             }
-#pragma unroll
-                            for (uint32_t u = 0; u < 4; u++) {
-                                float lo, hi;
-                                probe_bounds(grp + (h + u) * NGROUP, lo, hi);
-#pragma unroll
-                                for (uint32_t st = 0; st < 2; st++)
-                                    tile_test2(L, e[u][st], j0[u] + st * 2 * GROUP, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
-                                for (uint32_t j = j0[u] + 4 * GROUP; j < p1[h + u]; j += 2 * GROUP)
-                                    tile_test2(L, frag2[j >> 1], j, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
-                            }
-                        }
-                        if (t < t1) lut_fetch(t + 1);  // lands while this tile is scanned
-                        // more windows than the register cache holds (> 512 per query): the plain loop
-                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
-                        for (uint32_t pr = grp + PROBE_CACHE * NGROUP; pr < nprobe; pr += NGROUP) {
-                            float lo, hi;
-                            uint32_t icl, ich;
-                            probe_bounds(pr, lo, hi);
-                            probe_cells(lo, hi, icl, ich);
-                            const uint32_t q0 = lut[icl], q1 = lut[ich];
-                            for (uint32_t j = (q0 & ~1u) + 2 * sub; j < q1; j += 2 * GROUP)
-                                tile_test2(L, frag2[j >> 1], j, q0, q1, lo, hi, first, end, tb, acc);
                         }
                     }
                     pc.mark(1);
-                    __syncthreads();
+                    lds_barrier();
                     pc.mark(2);
                     // ---- scan pass 1: each thread walks the touched counter words of its share of the tile, in slot order ----
                     const uint32_t hmin = uni(L.sh[SH_HMIN]);  // lower bound of the heap minimum's count for this tile
@@ -746,16 +734,17 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
                             uint32_t m = L.bm[bwi];
                             while (m) {  // four touched words per trip: their LDS reads overlap
-                                uint32_t wd[4], v[4];
+                                constexpr int SB = 4;
+                                uint32_t wd[SB], v[SB];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
+                                for (int i = 0; i < SB; i++) {
                                     wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
                                     m &= m - 1;  // (0 stays 0)
                                 }
 #pragma unroll
-                                for (int i = 0; i < 4; i++) v[i] = wd[i] != NONE32 ? L.cnt[wd[i]] : 0;
+                                for (int i = 0; i < SB; i++) v[i] = wd[i] != NONE32 ? L.cnt[wd[i]] : 0;
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
+                                for (int i = 0; i < SB; i++) {
                                     if (v[i] == 0) continue;
                                     slot_stats(v[i] & 0xFFFFu, 2 * wd[i]);
                                     slot_stats(v[i] >> 16, 2 * wd[i] + 1);
@@ -783,21 +772,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     }
                     if (lane == 0) L.wsum[wave] = wave_total;
                     pc.mark(3);
-                    __syncthreads();
-                    if (t < t1) {  // warm L2 with the next tile's runs while this tile is scanned (the values are not used)
-#pragma unroll
-                        for (uint32_t u = 0; u < PROBE_CACHE; u++) {
-                            const uint32_t j = (p0n[u] & ~1u) + 2 * sub;
-                            if (j < p1n[u]) {
-                                uint32_t sink;
-                                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(frag2 + (j >> 1)) : "memory");
-                            }
-                            if (j + 2 * GROUP < p1n[u]) {
-                                uint32_t sink;
-                                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(frag2 + ((j + 2 * GROUP) >> 1)) : "memory");
-                            }
-                        }
-                    }
+                    lds_barrier();
                     uint32_t woff = 0, total = 0;
 #pragma unroll
                     for (uint32_t i = 0; i < TILE_WAVES; i++) {
@@ -843,14 +818,15 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             uint32_t m = L.bm[bwi];
                             if (m) L.bm[bwi] = 0;
                             while (m) {
-                                uint32_t wd[4], v[4];
+                                constexpr int SB = 4;
+                                uint32_t wd[SB], v[SB];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
+                                for (int i = 0; i < SB; i++) {
                                     wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
                                     m &= m - 1;
                                 }
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
+                                for (int i = 0; i < SB; i++) {
                                     v[i] = 0;
                                     if (wd[i] != NONE32) {
                                         v[i] = L.cnt[wd[i]];
@@ -858,7 +834,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                                     }
                                 }
 #pragma unroll
-                                for (int i = 0; i < 4; i++) {
+                                for (int i = 0; i < SB; i++) {
                                     if (v[i] == 0) continue;
                                     slot_emit(v[i] & 0xFFFFu, 2 * wd[i]);
                                     slot_emit(v[i] >> 16, 2 * wd[i] + 1);
@@ -867,7 +843,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         }
                     }
                     pc.mark(5);
-                    __syncthreads();
+                    lds_barrier();  // (the candidate / verbatim-slot stores of pass 2 stay in flight)
                     pc.mark(6);
                     if (tid == 0) {  // (read again only after the next tile's first barrier)
                         L.sh[SH_HMIN] = L.sh[SH_HMIN_NEXT];
