@@ -64,11 +64,12 @@ struct SageHostDb {
 struct SageDeviceDb {
     int device = 0;
     DevBuf<float> pep_mono;
-    DevBuf<SageTheoretical> pm_frag;
-    DevBuf<uint64_t> pm_off;
     DevBuf<float> ions;
     DevBuf<uint64_t> ion_off;
     DevBuf<uint32_t> pep_info;
+    DevBuf<SageTheoretical> pm_frag;  // peptide-major copy (narrow kernel, small windows)
+    DevBuf<uint64_t> pm_off;
+    std::vector<float> h_pep_mono;    // host copy: window-size estimate at batch upload
     DevBuf<SageTheoretical> tm_frag;  // tile-major copy + position table for the large-window kernel
     DevBuf<uint32_t> tm_lut;
     uint32_t max_ions = 0;
@@ -178,19 +179,21 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     const uint64_t np = v->n_peptides, nf = v->n_fragments;
     const uint32_t nk = v->n_ion_kinds;
 
-    // peptide-major regrouping of IndexedDatabase.fragments (counting sort by peptide_index; inside
-    // a peptide the bucket order — ascending m/z — is kept)
+    // group IndexedDatabase.fragments by peptide (counting sort): tiles are runs of 2^tile_shift consecutive peptides
     std::vector<uint64_t> pm_off(np + 1, 0);
     for (uint64_t i = 0; i < nf; i++) {
         if (v->fragments[i].peptide_index >= np) return fail(SAGE_HIP_ERR_INVALID, "fragment peptide_index out of range");
         pm_off[v->fragments[i].peptide_index + 1]++;
     }
     for (uint64_t i = 0; i < np; i++) pm_off[i + 1] += pm_off[i];
-    std::vector<SageTheoretical> pm(nf);
+    std::vector<SageTheoretical> tm(nf + 2, SageTheoretical{0xFFFFFFFFu, 0.0f});
     {
         std::vector<uint64_t> cur(pm_off.begin(), pm_off.end() - 1);
-        for (uint64_t i = 0; i < nf; i++) pm[cur[v->fragments[i].peptide_index]++] = v->fragments[i];
+        for (uint64_t i = 0; i < nf; i++) tm[cur[v->fragments[i].peptide_index]++] = v->fragments[i];
     }
+    HIP_TRY(d->pm_frag.upload(tm.data(), nf));  // (before the tiles are re-sorted by m/z below)
+    HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
+    d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
     // complete ion table for rescoring (IonSeries for every configured kind, ion_series.rs:36-85)
     std::vector<uint64_t> ion_off(np + 1, 0);
     std::vector<uint32_t> info(np);
@@ -221,8 +224,6 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
     std::vector<uint64_t> tile_off(n_tiles + 1, 0);
     for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
-    std::vector<SageTheoretical> tm(pm.begin(), pm.end());  // peptide-major == tile-grouped already
-    tm.resize(nf + 2, SageTheoretical{0xFFFFFFFFu, 0.0f});
     parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
         for (size_t t = tb; t < te; t++)
             std::sort(tm.begin() + tile_off[t], tm.begin() + tile_off[t + 1], [](const SageTheoretical& x, const SageTheoretical& y) {
@@ -235,7 +236,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     const float lut_scale = 256.0f;
     float max_mz = 0.0f;
     for (uint64_t i = 0; i < nf; i++)
-        if (pm[i].fragment_mz > max_mz && std::isfinite(pm[i].fragment_mz)) max_mz = pm[i].fragment_mz;
+        if (tm[i].fragment_mz > max_mz && std::isfinite(tm[i].fragment_mz)) max_mz = tm[i].fragment_mz;
     const uint32_t lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
     if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
     std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
@@ -257,8 +258,6 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));
     HIP_TRY(d->tm_lut.upload(lut.data(), lut.size()));
     HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
-    HIP_TRY(d->pm_frag.upload(pm.data(), nf));
-    HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
     HIP_TRY(d->ions.upload(ions.data(), ions.size()));
     HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
     HIP_TRY(d->pep_info.upload(info.data(), np));
@@ -327,7 +326,7 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     d.wcap = 1024;
     d.dbg_flags = 0;
     if (const char* e = getenv("SAGE_HIP_DEBUG_FLAGS")) d.dbg_flags = (uint32_t)atoi(e);
-    if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     // lnfact (scoring.rs:170-177) tabulated with the host libm so the factorial terms are bit-identical
@@ -412,6 +411,32 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
             key[i] = (b->precursor_mz[i] - sagecore::PROTON) * (float)z;
         }
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
+    }
+    // narrow-kernel variant for this batch: mean candidate-window size of (a sample of) its spectra, first query each
+    {
+        const std::vector<float>& pm = s->db->h_pep_mono;
+        const uint32_t step = std::max<uint32_t>(1, n / 2048);
+        double sum = 0.0;
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < n; i += step, cnt++) {
+            const uint32_t z = b->precursor_charge[i] ? b->precursor_charge[i] : p.min_precursor_charge;
+            const float center = (b->precursor_mz[i] - sagecore::PROTON) * (float)z;
+            sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
+            if (p.wide_window) {
+                float lo = -2.4f, hi = 2.4f;
+                if (b->isolation_lo && b->isolation_hi && b->isolation_lo[i] == b->isolation_lo[i] && b->isolation_hi[i] == b->isolation_hi[i]) {
+                    lo = b->isolation_lo[i];
+                    hi = b->isolation_hi[i];
+                }
+                tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
+            }
+            float lo, hi;
+            sagecore::tol_bounds(tol, center, lo, hi);
+            sum += (double)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
+        }
+        const double mean_window = cnt ? sum / cnt : 0.0;
+        d->view.probe = mean_window > 96.0 ? 1u : 0u;
+        if (const char* e = getenv("SAGE_HIP_NARROW")) d->view.probe = std::string(e) == "probe" ? 1u : std::string(e) == "stream" ? 0u : d->view.probe;
     }
     HIP_TRY(d->order.upload(order.data(), n));
     HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));

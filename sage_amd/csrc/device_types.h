@@ -11,8 +11,8 @@ namespace sagehip {
 struct DevDbView {
     const float* pep_mono;        // [np]   peptide masses, ascending — the precursor-window search key
     uint32_t np;
-    // peptide-major copy of IndexedDatabase.fragments: the same (peptide_index, fragment_mz) entries,
-    // grouped by peptide so that a precursor window is ONE contiguous, coalesced range
+    // peptide-major copy of IndexedDatabase.fragments: the same (peptide_index, fragment_mz) entries grouped by
+    // peptide, so that a precursor window is ONE contiguous, coalesced range (narrow kernel, small windows)
     const SageTheoretical* pm_frag;  // [nf]
     const uint64_t* pm_off;          // [np + 1]
     // complete ion table for rescoring: ions[ion_off[p] + k*(L-1) + idx] = IonSeries(p, kinds[k])[idx]
@@ -68,6 +68,7 @@ struct DevBatchView {
     const uint32_t* file_id;    // may be null
     const uint32_t* order;      // [n] block b scores spectrum order[b]: ascending precursor mass => neighbouring
                                 //     wavefronts stream overlapping index ranges (L2 reuse); results stay in input order
+    uint32_t probe;             // narrow kernel variant: 1 = per-peak table lookups (large windows), 0 = peptide-major stream
     uint32_t pcap;              // max peaks per spectrum in this batch
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
 };

@@ -139,34 +139,86 @@ __device__ __forceinline__ uint64_t lane_value(uint64_t v, uint32_t src_lane) { 
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
 }
-__device__ __forceinline__ void wh_sift_down(WaveHeap& h, uint32_t len, uint32_t index) {  // heap.rs:40-60
-    const uint64_t moving = wh_get(h, index);
-    for (;;) {
-        const uint32_t l = index * 2 + 1;
-        if (l >= len) break;
-        uint32_t smallest = index;
-        uint64_t sv = moving;
-        const uint64_t vl = wh_get(h, l);
-        if (vl < sv) { smallest = l; sv = vl; }
-        const uint32_t r = l + 1;
-        if (r < len) {
-            const uint64_t vr = wh_get(h, r);
-            if (vr < sv) { smallest = r; sv = vr; }
-        }
-        if (smallest == index) break;
-        wh_set(h, index, sv);       // slice.swap(smallest, index)
-        wh_set(h, smallest, moving);
-        index = smallest;
+// sift_down (heap.rs:40-60) of value `moving` placed at `index`.  sift_down always descends to the smaller child
+// (the left one on a tie), a path that does not depend on the value being sifted: every lane compares ITS two
+// children once (two cross-lane reads), a ballot turns that into one bit per node, the path is then walked with
+// scalar bit operations, its values are read with v_readlane, and — values along a heap path never decrease —
+// `moving` stops at the first path value that is not smaller.  All control flow is wave-uniform.
+__device__ __forceinline__ void wh_sift_from(WaveHeap& h, uint32_t len, uint32_t index, uint64_t moving) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = 2 * lane + 1, r = l + 1;
+    const uint32_t lo_l = (uint32_t)__shfl((int)h.lo, (int)(l & 63u), 64), hi_l = (uint32_t)__shfl((int)h.hi, (int)(l & 63u), 64);
+    const uint32_t lo_r = (uint32_t)__shfl((int)h.lo, (int)(r & 63u), 64), hi_r = (uint32_t)__shfl((int)h.hi, (int)(r & 63u), 64);
+    const uint64_t vl = ((uint64_t)hi_l << 32) | lo_l, vr = ((uint64_t)hi_r << 32) | lo_r;
+    const uint64_t rightmin = __ballot(r < len && vr < vl);  // bit p: the right child of node p is strictly smaller
+    index = __builtin_amdgcn_readfirstlane(index);
+    uint32_t path[7];
+    uint64_t pv[7];
+    uint32_t n = 0;  // nodes below `index` on the path that hold a value smaller than `moving`
+    path[0] = index;
+    uint32_t dst = index;  // where `moving` ends up
+    bool go = true;
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        const uint32_t lc = 2 * path[j] + 1;
+        go = go && lc < len;
+        path[j + 1] = go ? lc + (uint32_t)((rightmin >> (path[j] & 63u)) & 1ull) : 0;
+        pv[j + 1] = go ? wh_get(h, path[j + 1]) : ~0ull;
+        go = go && pv[j + 1] < moving;
+        n += go ? 1u : 0u;
+        dst = go ? path[j + 1] : dst;
     }
+    // shift the path up by one level and drop `moving` where it stopped (slice.swap at every level)
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++)
+        if (j < n) wh_set(h, path[j], pv[j + 1]);
+    wh_set(h, dst, moving);
 }
 __device__ __forceinline__ void wh_build(WaveHeap& h, uint32_t k) {  // heap.rs:13-15
-    for (uint32_t i = k / 2; i-- > 0;) wh_sift_down(h, k, i);
+    for (uint32_t i = k / 2; i-- > 0;) wh_sift_from(h, k, i, wh_get(h, i));
 }
 __device__ __forceinline__ void wh_offer(WaveHeap& h, uint32_t k, uint64_t v) {  // heap.rs:21-27
-    if (k && v > wh_get(h, 0)) {
-        wh_set(h, 0, v);
-        wh_sift_down(h, k, 0);
+    if (k && v > wh_get(h, 0)) wh_sift_from(h, k, 0, v);  // slice.swap(i, 0): the displaced minimum is truncated away
+}
+
+// The same heap with 32-bit keys, for the k-select of ONE precursor-window query of the narrow kernel: charge and isotope
+// error are constant inside a query, so PreScore's order is (matched, peptide) = (matched, candidate slot), and with at
+// most 65536 slots `matched << 16 | slot` orders identically (an empty slot is key 0).  Scalar compares, one readlane per
+// node, half the cross-lane traffic.
+__device__ __forceinline__ uint32_t wh32_get(uint32_t h, uint32_t idx) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)h, (int)__builtin_amdgcn_readfirstlane(idx));
+}
+__device__ __forceinline__ void wh32_sift_from(uint32_t& h, uint32_t len, uint32_t index, uint32_t moving) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = 2 * lane + 1, r = l + 1;
+    const uint32_t vl = (uint32_t)__shfl((int)h, (int)(l & 63u), 64), vr = (uint32_t)__shfl((int)h, (int)(r & 63u), 64);
+    const uint64_t rightmin = __ballot(r < len && vr < vl);  // bit p: the right child of node p is strictly smaller
+    index = __builtin_amdgcn_readfirstlane(index);
+    moving = __builtin_amdgcn_readfirstlane(moving);
+    uint32_t path[7], pv[7];
+    uint32_t n = 0, dst = index;
+    path[0] = index;
+    bool go = true;
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++) {
+        const uint32_t lc = 2 * path[j] + 1;
+        go = go && lc < len;
+        path[j + 1] = go ? lc + (uint32_t)((rightmin >> (path[j] & 63u)) & 1ull) : 0;
+        pv[j + 1] = go ? wh32_get(h, path[j + 1]) : 0xFFFFFFFFu;
+        go = go && pv[j + 1] < moving;
+        n += go ? 1u : 0u;
+        dst = go ? path[j + 1] : dst;
     }
+#pragma unroll
+    for (uint32_t j = 0; j < 6; j++)
+        if (j < n) h = lane == path[j] ? pv[j + 1] : h;
+    h = lane == dst ? moving : h;
+}
+__device__ __forceinline__ void wh32_build(uint32_t& h, uint32_t k) {  // heap.rs:13-15
+    for (uint32_t i = k / 2; i-- > 0;) wh32_sift_from(h, k, i, wh32_get(h, i));
+}
+__device__ __forceinline__ void wh32_offer(uint32_t& h, uint32_t k, uint32_t v) {  // heap.rs:21-27
+    if (k && v > wh32_get(h, 0)) wh32_sift_from(h, k, 0, v);
 }
 
 // CList (core.h) with wave-uniform bookkeeping: every lane holds the same stored/len, appends are
@@ -305,7 +357,16 @@ __device__ __forceinline__ Window query_window(const DevDbView& db, const Tol& p
     return q;
 }
 
-// ---- narrow windows: one wavefront per spectrum, peptide-major stream, counters in LDS -------------
+// ---- narrow windows: one wavefront per spectrum, counters in LDS -----------------------------------
+// Two ways to count the matched fragments of a precursor window, same predicate (database.rs:526-533), same counts:
+//   PROBE == false : stream the window's fragments from the peptide-major copy of the index (one contiguous, coalesced
+//                    range) and count, per fragment, the experimental windows that contain it (binary searches in LDS).
+//                    Cost ~ candidates x fragments per peptide: best for windows of a few dozen candidates.
+//   PROBE == true  : one lane per (peak, fragment charge) window looks its run up in the tile-major copy (two table
+//                    reads + ~10-20 entries).  Cost ~ peaks x fragment charges, independent of the window: best from
+//                    ~100 candidates up.
+// The C ABI picks per batch from the mean window size (capi.hip: sage_hip_batch_upload).
+template <bool PROBE>
 __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
@@ -334,17 +395,21 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
             }
         }
         __syncthreads();
-        bool mono_ok = true;  // the sorted-count shortcut needs ascending bounds and lo <= hi
-        for (uint32_t fz = 0; fz < nfz_max; fz++) {
-            const float* wl = L.win_lo + (size_t)fz * b.pcap;
-            const float* wh = L.win_hi + (size_t)fz * b.pcap;
-            for (uint32_t i = lane; i < P; i += WAVE) {
-                mono_ok = mono_ok && (wl[i] <= wh[i]);
-                if (i > 0) mono_ok = mono_ok && (wl[i - 1] <= wl[i]) && (wh[i - 1] <= wh[i]);
+        bool sorted_ok = true;  // (stream) the sorted-count shortcut needs ascending bounds and lo <= hi
+        uint32_t ptop = 0;
+        if (!PROBE) {
+            bool mono_ok = true;
+            for (uint32_t fz = 0; fz < nfz_max; fz++) {
+                const float* wl = L.win_lo + (size_t)fz * b.pcap;
+                const float* wh = L.win_hi + (size_t)fz * b.pcap;
+                for (uint32_t i = lane; i < P; i += WAVE) {
+                    mono_ok = mono_ok && (wl[i] <= wh[i]);
+                    if (i > 0) mono_ok = mono_ok && (wl[i - 1] <= wl[i]) && (wh[i - 1] <= wh[i]);
+                }
             }
+            sorted_ok = __ballot(!mono_ok) == 0ull;
+            ptop = pow2_floor(P);
         }
-        const bool sorted_ok = __ballot(!mono_ok) == 0ull;
-        const uint32_t ptop = pow2_floor(P);
         pc.mark(0);
 
         const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
@@ -371,10 +436,11 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                     break;
                 }
                 pc.mark(1);
+                if (pc.slot && lane == 0) { pc.slot[6] += potential; pc.slot[7] += 1; }
                 cnt.zero(potential, lane);
                 __syncthreads();
                 uint32_t acc = 0;
-                if (q.first < q.end) {
+                if (!PROBE && q.first < q.end) {
                     const uint64_t f0 = db.pm_off[q.first], f1 = db.pm_off[q.end];
                     auto count_one = [&](float frag) -> uint32_t {
                         if (!sorted_ok) {
@@ -413,6 +479,68 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                         if (c1) { cnt.add(fr1.peptide_index - left, c1); acc += c1; }
                     }
                 }
+                if (PROBE && q.first < q.end) {
+                    // One lane per (peak, fragment charge) window: two reads of the tile's position table give the run of
+                    // index entries inside the fragment tolerance, the few entries of the run are tested against the
+                    // precursor window (database.rs:526-533) and hits bump the LDS counters.  ~10 entries per window
+                    // instead of a binary search per fragment of every candidate peptide.
+                    const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;
+                    const float cell_max = (float)(db.lut_stride - 1);
+                    const uint32_t t0 = q.first >> db.tile_shift, t1 = (q.end - 1) >> db.tile_shift;
+                    auto test2 = [&](const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo, float hi) {
+                        const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
+                        if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= q.first && e.x < q.end) { cnt.add(e.x - left, 1); acc++; }
+                        if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= q.first && e.z < q.end) { cnt.add(e.z - left, 1); acc++; }
+                    };
+                    const uint32_t nprobe = P * nfz;
+                    for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
+                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
+                        // the table reads of the next 64 windows are issued before this trip's entries are tested
+                        float lo = 1.0f, hi = 0.0f, lo_n = 1.0f, hi_n = 0.0f;
+                        uint32_t p0 = 0, p1 = 0, p0_n = 0, p1_n = 0;
+                        auto fetch = [&](uint32_t pr, float& flo, float& fhi, uint32_t& fp0, uint32_t& fp1) {
+                            flo = 1.0f; fhi = 0.0f;  // (inactive lane: empty window, empty run)
+                            if (pr < nprobe) {
+                                const uint32_t fz = pr / P, i = pr - fz * P;
+                                flo = L.win_lo[(size_t)fz * b.pcap + i];
+                                fhi = L.win_hi[(size_t)fz * b.pcap + i];
+                            }
+                            // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
+                            float cl = floorf(flo * db.lut_scale), ch = floorf(fhi * db.lut_scale) + 1.0f;
+                            cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
+                            ch = ch > 0.0f ? ch : 0.0f;
+                            uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut_stride - 1;
+                            uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut_stride - 1;
+                            if (!(flo <= fhi)) icl = ich = 0;
+                            fp0 = lut[icl];
+                            fp1 = lut[ich];
+                        };
+                        fetch(lane, lo_n, hi_n, p0_n, p1_n);
+                        for (uint32_t pb = 0; pb < nprobe; pb += WAVE) {
+                            lo = lo_n; hi = hi_n; p0 = p0_n; p1 = p1_n;
+                            if (pb + WAVE < nprobe) fetch(pb + WAVE + lane, lo_n, hi_n, p0_n, p1_n);
+                            const uint32_t j0 = p0 & ~1u;
+                            uint4 e[8];
+#pragma unroll
+                            for (uint32_t st = 0; st < 8; st++) {  // sixteen entries in flight per lane
+                                e[st] = make_uint4(0u, 0u, 0u, 0u);
+                                if (j0 + 2 * st < p1) e[st] = frag2[(j0 >> 1) + st];
+                            }
+#pragma unroll
+                            for (uint32_t st = 0; st < 8; st++) test2(e[st], j0 + 2 * st, p0, p1, lo, hi);
+                            for (uint32_t j = j0 + 16; j < p1; j += 8) {  // long runs: four more loads per trip
+                                uint4 f[4];
+#pragma unroll
+                                for (uint32_t st = 0; st < 4; st++) {
+                                    f[st] = make_uint4(0u, 0u, 0u, 0u);
+                                    if (j + 2 * st < p1) f[st] = frag2[(j >> 1) + st];
+                                }
+#pragma unroll
+                                for (uint32_t st = 0; st < 4; st++) test2(f[st], j + 2 * st, p0, p1, lo, hi);
+                            }
+                        }
+                    }
+                }
                 const uint32_t matched = wave_sum(acc);
                 __syncthreads();
                 pc.mark(2);
@@ -434,28 +562,30 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                         ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
                     }
                 } else {
-                    WaveHeap h;
+                    // keys `matched << 16 | slot` (potential <= wcap <= 65536): same order as PreScore inside one query
+                    uint32_t h;
                     {
                         const uint32_t c = lane < k ? cnt.get(lane) : 0;
-                        const uint64_t v = c ? pack_prescore(c, left + lane, z, iso) : PRESCORE_EMPTY;
-                        h.lo = (uint32_t)v;
-                        h.hi = (uint32_t)(v >> 32);
+                        h = c ? (c << 16) | lane : 0u;
                         scored += (uint32_t)__popcll(__ballot(c > 0));
                     }
-                    wh_build(h, k);
+                    wh32_build(h, k);
                     for (uint32_t base = k; base < potential; base += WAVE) {
                         const uint32_t i = base + lane;
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
-                        const uint64_t v = pack_prescore(c, left + i, z, iso);
-                        uint64_t mask = __ballot(c > 0);
-                        scored += (uint32_t)__popcll(mask);
-                        while (mask) {  // in slot order; empty slots can never displace the heap minimum
+                        const uint32_t v = (c << 16) | i;
+                        // in slot order; a slot can only enter if its count reaches the heap minimum's (heap.rs:22: later
+                        // slots have larger peptide indices, so equal counts do enter)
+                        uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> 16));
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
+                        if (pc.slot && lane == 0) pc.slot[5] += (unsigned long long)__popcll(mask);
+                        while (mask) {
                             const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                             mask &= mask - 1;
-                            wh_offer(h, k, lane_value(v, bit));
+                            wh32_offer(h, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
                         }
                     }
-                    ulist_append(target, ((uint64_t)h.hi << 32) | h.lo, k, sc.kmax);
+                    ulist_append(target, h ? pack_prescore(h >> 16, left + (h & 0xFFFFu), z, iso) : PRESCORE_EMPTY, k, sc.kmax);
                 }
                 tot_scored += scored;
                 __syncthreads();
@@ -1468,7 +1598,10 @@ size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t max_i
 
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(prelim_kernel, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
+    if (b.probe)
+        hipLaunchKernelGGL(prelim_kernel<true>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
+    else
+        hipLaunchKernelGGL(prelim_kernel<false>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0 || w.tile_blocks == 0) return;

@@ -75,6 +75,21 @@ def test_narrow_search_known_charge(small_world):
     assert t["n_wide"] == 0
 
 
+@pytest.mark.parametrize("variant", ["stream", "probe"])
+def test_narrow_kernel_variants(small_world, monkeypatch, variant):
+    """Both fragment-matching strategies of the narrow kernel (peptide-major stream / per-peak table lookups; the C ABI
+    normally picks one per batch from the mean window size), with windows from a handful to ~1000 candidates,
+    isotope folding and unknown charge."""
+    monkeypatch.setenv("SAGE_HIP_NARROW", variant)
+    small_world.check(ScorerParams(), f"{variant}: narrow ±10ppm")
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -1.5, 1.5), report_psms=3), f"{variant}: ±1.5 Da")
+    small_world.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, precursor_tol=Tolerance("ppm", -20.0, 20.0),
+                                   max_fragment_charge=3), f"{variant}: isotope -1..3, fragment charge 3")
+    b = small_world.batch
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -0.5, 0.5)), f"{variant}: charge None", batch=unknown)
+
+
 def test_report_psms_and_score_types(small_world):
     small_world.check(ScorerParams(report_psms=5, precursor_tol=Tolerance("ppm", -50.0, 50.0)), "report_psms=5")
     small_world.check(ScorerParams(score_type="OpenMSHyperScore", min_matched_peaks=2), "OpenMS score")
