@@ -145,7 +145,7 @@ typedef struct SageScorerParams {
     uint8_t chimera;
     int16_t max_fragment_charge; /* Option<u8>: -1 == None */
     uint8_t wide_window;
-    uint8_t annotate_matches;    /* not supported on device yet: must be 0 */
+    uint8_t annotate_matches;    /* the Fragments themselves are fetched with sage_hip_annotate_resident */
     uint32_t report_psms;
     int32_t score_type;          /* 0 SageHyperScore, 1 OpenMSHyperScore (scoring.rs:10-14) */
 } SageScorerParams;
@@ -201,6 +201,31 @@ int sage_hip_score_resident(SageScorer* scorer, SageDeviceBatch* batch, SageFeat
  * matched<<48 | peptide<<16 | precursor_charge<<8 | (isotope_error+128); len[i] entries are valid. */
 int sage_hip_initial_hits(SageScorer* scorer, SageDeviceBatch* batch, uint64_t* packed, uint32_t cap,
                           uint32_t* len, uint64_t* matched_peaks, uint64_t* scored_candidates);
+
+/* scoring.rs:152-161  struct Fragments of every reported PSM (Scorer.annotate_matches, scoring.rs:722-752), flattened:
+ * PSM r of spectrum i is slot s = i * report_psms + r and owns entries [psm_off[s], psm_off[s + 1]) of each array, in the
+ * reference's push order (ion kind, ion index, fragment charge).  A slot's length equals its Feature.matched_peaks, so the
+ * caller can size the arrays from the features; `capacity` is the number of entries available in each array. */
+typedef struct SageFragments {
+    uint64_t capacity;
+    uint64_t* psm_off;            /* [n_spectra * report_psms + 1] */
+    uint8_t* kinds;               /* SAGE_ION_* */
+    int32_t* charges;
+    int32_t* fragment_ordinals;
+    float* intensities;
+    float* mz_calculated;
+    float* mz_experimental;
+} SageFragments;
+/* Annotate the PSMs `features` / `counts` that sage_hip_score_resident returned for this resident batch with this scorer
+ * (with chimera, the winner's peaks are removed between PSMs exactly as score_chimera_fast does).  Fails with
+ * SAGE_HIP_ERR_INVALID when `capacity` is too small; out->psm_off is filled either way. */
+int sage_hip_annotate_resident(SageScorer* scorer, SageDeviceBatch* batch, const SageFeature* features,
+                               const uint32_t* counts, SageFragments* out);
+
+/* Scorer::quick_score (scoring.rs:255-298) for every spectrum of a resident batch — the first pass of the `prefilter`
+ * flow (sage-cli runner.rs:143-240).  keep: host array [n_peptides] standing in for the reference's &[AtomicBool];
+ * identified peptides are OR-ed in (keep[i] = 1). */
+int sage_hip_quick_score_resident(SageScorer* scorer, SageDeviceBatch* batch, int prefilter_low_memory, uint8_t* keep);
 
 /* Timing of the last sage_hip_score_resident / sage_hip_score_batch call, from HIP events recorded
  * on the scorer's own stream. */

@@ -413,6 +413,52 @@ uint64_t orc_brute_force(void* h, const OrcScorerParams* sp, const OrcSpectrumBa
     return v.size();
 }
 
+// Scorer::score with annotate_matches = true (scoring.rs:739-752): the Fragments of every reported PSM, flattened.
+// psm_off[i * report_psms + r] .. psm_off[i * report_psms + r + 1] delimit PSM r of spectrum i (empty for r >= count).
+// Returns the total number of entries (arrays are filled up to `cap`).
+uint64_t orc_annotate_batch(void* h, const OrcScorerParams* sp, const OrcSpectrumBatch* batch, uint64_t* psm_off,
+                            uint8_t* kinds, int32_t* charges, int32_t* ordinals, float* intensities, float* mz_calculated,
+                            float* mz_experimental, uint64_t cap) {
+    auto* db = (IndexedDatabase*)h;
+    Scorer scorer = make_scorer(db, sp);
+    scorer.annotate_matches = true;
+    uint64_t total = 0;
+    const uint32_t n = batch->n_spectra, rp = sp->report_psms;
+    for (uint32_t i = 0; i < n; i++) {
+        ProcessedSpectrum q = make_spectrum(batch, i);
+        std::vector<Feature> feats = scorer.score(q);
+        for (uint32_t r = 0; r < rp; r++) {
+            psm_off[(size_t)i * rp + r] = total;
+            if (r >= feats.size() || !feats[r].fragments) continue;
+            const Fragments& f = *feats[r].fragments;
+            for (size_t j = 0; j < f.kinds.size(); j++, total++) {
+                if (total >= cap) continue;
+                kinds[total] = (uint8_t)f.kinds[j];
+                charges[total] = f.charges[j];
+                ordinals[total] = f.fragment_ordinals[j];
+                intensities[total] = f.intensities[j];
+                mz_calculated[total] = f.mz_calculated[j];
+                mz_experimental[total] = f.mz_experimental[j];
+            }
+        }
+    }
+    psm_off[(size_t)n * rp] = total;
+    return total;
+}
+
+// Scorer::quick_score (scoring.rs:255-298) over a batch: keep[peptide] |= identified
+void orc_quick_score(void* h, const OrcScorerParams* sp, const OrcSpectrumBatch* batch, int prefilter_low_memory,
+                     uint8_t* keep) {
+    auto* db = (IndexedDatabase*)h;
+    Scorer scorer = make_scorer(db, sp);
+    std::vector<uint8_t> k(db->peptides.size(), 0);
+    for (uint32_t i = 0; i < batch->n_spectra; i++) {
+        ProcessedSpectrum q = make_spectrum(batch, i);
+        scorer.quick_score(q, prefilter_low_memory != 0, k);
+    }
+    for (size_t i = 0; i < k.size(); i++) keep[i] |= k[i];
+}
+
 void orc_tol_bounds(OrcTolerance t, float center, float* lo, float* hi) {
     auto b = tol(t).bounds(center);
     *lo = b.first;

@@ -106,6 +106,19 @@ class SageSpectrumBatch(C.Structure):
     ]
 
 
+class SageFragments(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_uint64),
+        ("psm_off", c_u64_p),
+        ("kinds", c_u8_p),
+        ("charges", C.POINTER(C.c_int32)),
+        ("fragment_ordinals", C.POINTER(C.c_int32)),
+        ("intensities", c_float_p),
+        ("mz_calculated", c_float_p),
+        ("mz_experimental", c_float_p),
+    ]
+
+
 class SageTiming(C.Structure):
     _fields_ = [
         ("prelim_ms", C.c_float),
@@ -182,6 +195,8 @@ def load():
         "sage_hip_score_resident": (C.c_int, [vp, vp, vp, c_u32_p]),
         "sage_hip_initial_hits": (C.c_int, [vp, vp, c_u64_p, C.c_uint32, c_u32_p, c_u64_p, c_u64_p]),
         "sage_hip_last_timing": (C.c_int, [vp, C.POINTER(SageTiming)]),
+        "sage_hip_annotate_resident": (C.c_int, [vp, vp, vp, c_u32_p, C.POINTER(SageFragments)]),
+        "sage_hip_quick_score_resident": (C.c_int, [vp, vp, C.c_int, c_u8_p]),
         "sage_hip_debug_phase_cycles": (C.c_int, [vp, c_u64_p]),
         "sage_hip_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(vp)]),
         "sage_hip_host_free": (None, [vp]),
@@ -200,7 +215,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_score_resident", "sage_hip_initial_hits",
-    "sage_hip_last_timing", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
+    "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
 ]
 
 

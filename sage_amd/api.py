@@ -444,6 +444,37 @@ class Scorer:
                                          L.as_ptr(counts, C.c_uint32)))
         return feats.reshape(batch.n, self.params.report_psms), counts
 
+    def annotate(self, dbatch: DeviceBatch, feats: np.ndarray, counts: np.ndarray):
+        """Fragments (scoring.rs:152-161) of the PSMs that score_resident returned for this batch (annotate_matches).
+        Returns (psm_off[n * report_psms + 1], dict of flat arrays); PSM r of spectrum i is slot i * report_psms + r."""
+        lib = L.load()
+        rp = self.params.report_psms
+        feats = np.ascontiguousarray(feats).reshape(dbatch.n * rp)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        valid = (np.arange(rp)[None, :] < counts[:, None]).reshape(-1)
+        total = int(feats["matched_peaks"][valid].sum())
+        off = np.zeros(dbatch.n * rp + 1, dtype=np.uint64)
+        arr = dict(kinds=np.zeros(total, np.uint8), charges=np.zeros(total, np.int32), fragment_ordinals=np.zeros(total, np.int32),
+                   intensities=np.zeros(total, np.float32), mz_calculated=np.zeros(total, np.float32),
+                   mz_experimental=np.zeros(total, np.float32))
+        fr = L.SageFragments(total, L.as_ptr(off, C.c_uint64), L.as_ptr(arr["kinds"], C.c_uint8),
+                             arr["charges"].ctypes.data_as(C.POINTER(C.c_int32)),
+                             arr["fragment_ordinals"].ctypes.data_as(C.POINTER(C.c_int32)),
+                             L.as_ptr(arr["intensities"], C.c_float), L.as_ptr(arr["mz_calculated"], C.c_float),
+                             L.as_ptr(arr["mz_experimental"], C.c_float))
+        L.check(lib.sage_hip_annotate_resident(self._h, dbatch._h, feats.ctypes.data_as(C.c_void_p),
+                                               L.as_ptr(counts, C.c_uint32), C.byref(fr)))
+        return off, arr
+
+    def quick_score(self, dbatch: DeviceBatch, prefilter_low_memory: bool, keep: Optional[np.ndarray] = None) -> np.ndarray:
+        """Scorer::quick_score (scoring.rs:255-298) over the batch; `keep` ([n_peptides] u8) is OR-updated and returned."""
+        lib = L.load()
+        if keep is None:
+            keep = np.zeros(self.db.host.n_peptides, dtype=np.uint8)
+        assert keep.dtype == np.uint8 and len(keep) == self.db.host.n_peptides
+        L.check(lib.sage_hip_quick_score_resident(self._h, dbatch._h, int(prefilter_low_memory), L.as_ptr(keep, C.c_uint8)))
+        return keep
+
     def initial_hits(self, dbatch: DeviceBatch):
         lib = L.load()
         cap = max(50, 2 * self.params.report_psms)

@@ -294,7 +294,6 @@ uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db) { return db ? db->byte
 
 int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
     if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    if (p->annotate_matches) return fail(SAGE_HIP_ERR_UNSUPPORTED, "annotate_matches is not available on device yet");
     if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
     if (p->report_psms > 32) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32 (k-select wider than one wavefront)");
     if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
@@ -501,6 +500,8 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     return SAGE_HIP_OK;
 }
 
+static DevWork make_work(SageScorer* s);
+
 static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
     HIP_TRY(hipSetDevice(s->db->device));
@@ -510,22 +511,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     const size_t lds_t = tile_lds_bytes(s->db->view, s->dev, b->view);
     if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
-    DevWork w;
-    w.cand = s->cand.p;
-    w.cand_len = s->cand_len.p;
-    w.totals = s->totals.p;
-    w.status = s->status.p;
-    w.n_deferred = s->n_deferred.p;
-    w.queue = s->queue.p;
-    w.tile_blocks = s->tile_blocks;
-    w.qrec = s->qrec.p;
-    w.seeds = s->seeds.p;
-    w.qres = s->qres.p;
-    w.arena = s->arena.p;
-    w.arena_cap = (uint32_t)s->arena.n;
-    w.qmax = s->qmax;
-    w.dbg = s->dbg.p;
-    w.tile_params = s->tile_params.p;
+    DevWork w = make_work(s);
     {
         TileParams tp{s->db->view, s->dev, b->view, w};
         HIP_TRY(hipMemcpyAsync(s->tile_params.p, &tp, sizeof tp, hipMemcpyHostToDevice, s->stream));  // (small: staged at call time)
@@ -537,7 +523,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (with_rescore)
         launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
-                       s->features.p, s->out_count.p, s->stream);
+                       s->features.p, s->out_count.p, nullptr, s->stream);
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipGetLastError());
@@ -559,6 +545,26 @@ static int finish_timing(SageScorer* s, bool with_rescore) {
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->arena.n >> 18) +
                                                   " MiB): score this batch in smaller pieces or raise SAGE_HIP_ARENA_MB");
     return SAGE_HIP_OK;
+}
+
+static DevWork make_work(SageScorer* s) {
+    DevWork w{};
+    w.cand = s->cand.p;
+    w.cand_len = s->cand_len.p;
+    w.totals = s->totals.p;
+    w.status = s->status.p;
+    w.n_deferred = s->n_deferred.p;
+    w.queue = s->queue.p;
+    w.tile_blocks = s->tile_blocks;
+    w.qrec = s->qrec.p;
+    w.seeds = s->seeds.p;
+    w.qres = s->qres.p;
+    w.arena = s->arena.p;
+    w.arena_cap = (uint32_t)s->arena.n;
+    w.qmax = s->qmax;
+    w.dbg = s->dbg.p;
+    w.tile_params = s->tile_params.p;
+    return w;
 }
 
 int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
@@ -589,6 +595,81 @@ int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* batch, SageFeat
     rc = sage_hip_score_resident(s, d, out, out_count);
     sage_hip_batch_free(d);
     return rc;
+}
+
+int sage_hip_annotate_resident(SageScorer* s, SageDeviceBatch* b, const SageFeature* features, const uint32_t* counts,
+                               SageFragments* out) {
+    if (!s || !b || !features || !counts || !out || !out->psm_off) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    HIP_TRY(hipSetDevice(s->db->device));
+    const uint32_t n = b->n, rp = s->params.report_psms;
+    const size_t slots = (size_t)n * rp;
+    // a PSM's Fragments hold exactly matched_b + matched_y entries (scoring.rs:725-752) == Feature.matched_peaks
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t r = 0; r < rp; r++) {
+            out->psm_off[(size_t)i * rp + r] = total;
+            if (r < counts[i]) {
+                if (features[(size_t)i * rp + r].peptide_idx >= s->db->view.np) return fail(SAGE_HIP_ERR_INVALID, "feature peptide_idx out of range");
+                total += features[(size_t)i * rp + r].matched_peaks;
+            }
+        }
+    out->psm_off[slots] = total;
+    if (total > out->capacity) return fail(SAGE_HIP_ERR_INVALID, "SageFragments.capacity is smaller than the sum of matched_peaks");
+    if (total && (!out->kinds || !out->charges || !out->fragment_ordinals || !out->intensities || !out->mz_calculated || !out->mz_experimental))
+        return fail(SAGE_HIP_ERR_INVALID, "missing SageFragments arrays");
+    if (n == 0 || total == 0) return SAGE_HIP_OK;
+    DevBuf<SageFeature> d_feats;
+    DevBuf<uint32_t> d_counts;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint8_t> d_kinds;
+    DevBuf<int32_t> d_charges, d_ord;
+    DevBuf<float> d_int, d_calc, d_exp;
+    HIP_TRY(d_feats.upload(features, slots));
+    HIP_TRY(d_counts.upload(counts, n));
+    HIP_TRY(d_off.upload(out->psm_off, slots + 1));
+    HIP_TRY(d_kinds.alloc(total));
+    HIP_TRY(d_charges.alloc(total));
+    HIP_TRY(d_ord.alloc(total));
+    HIP_TRY(d_int.alloc(total));
+    HIP_TRY(d_calc.alloc(total));
+    HIP_TRY(d_exp.alloc(total));
+    DevFragments df{total, d_kinds.p, d_charges.p, d_ord.p, d_int.p, d_calc.p, d_exp.p};
+    launch_annotate(s->db->view, s->dev, b->view, d_feats.p, d_counts.p, d_off.p, df, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out->kinds, d_kinds.p, total, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->charges, d_charges.p, total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->fragment_ordinals, d_ord.p, total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->intensities, d_int.p, total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->mz_calculated, d_calc.p, total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->mz_experimental, d_exp.p, total * 4, hipMemcpyDeviceToHost));
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_quick_score_resident(SageScorer* s, SageDeviceBatch* b, int prefilter_low_memory, uint8_t* keep) {
+    if (!s || !b || !keep) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    int rc = run_kernels(s, b, false);  // Scorer::initial_hits
+    if (rc != SAGE_HIP_OK) return rc;
+    const uint64_t np = s->db->view.np;
+    DevBuf<uint8_t> d_keep;
+    HIP_TRY(d_keep.alloc(np));
+    HIP_TRY(hipMemsetAsync(d_keep.p, 0, std::max<uint64_t>(np, 1), s->stream));
+    const DevWork w = make_work(s);
+    if (prefilter_low_memory)
+        launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, s->features.p,
+                       s->out_count.p, d_keep.p, s->stream);
+    else
+        launch_quick_mark(s->dev, b->view, w, d_keep.p, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = finish_timing(s, false);
+    if (rc != SAGE_HIP_OK) return rc;
+    if (s->h_counters[CTR_LIST_OVERFLOW]) return fail(SAGE_HIP_ERR_UNSUPPORTED, "preliminary candidate list capacity exceeded");
+    std::vector<uint8_t> h(np);
+    HIP_TRY(hipMemcpy(h.data(), d_keep.p, np, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < np; i++) keep[i] |= h[i];
+    return SAGE_HIP_OK;
 }
 
 int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, uint32_t cap, uint32_t* len,

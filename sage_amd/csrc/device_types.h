@@ -108,6 +108,17 @@ struct QueryRec {
     uint32_t pad[2];
 };
 
+// device-side SageFragments (sage_hip.h)
+struct DevFragments {
+    uint64_t capacity;
+    uint8_t* kinds;
+    int32_t* charges;
+    int32_t* fragment_ordinals;
+    float* intensities;
+    float* mz_calculated;
+    float* mz_experimental;
+};
+
 struct TileParams {
     DevDbView db;
     DevScorer sc;
@@ -126,6 +137,9 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
 uint32_t queries_per_spectrum(const DevScorer& sc);
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
-                    uint32_t* out_count, void* stream);
+                    uint32_t* out_count, uint8_t* keep, void* stream);
+void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream);
+void launch_annotate(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const SageFeature* feats,
+                     const uint32_t* counts, const uint64_t* psm_off, const DevFragments& out, void* stream);
 
 }  // namespace sagehip

@@ -1279,10 +1279,79 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 //   B. one lane per candidate walks ITS items in order and accumulates (scoring.rs:704-754).
 constexpr uint16_t RES_NONE = 0xFFFFu;
 
+// remove_matched_peaks (scoring.rs:598-644) on the LDS copy of the spectrum: drop every peak whose (mass, intensity)
+// equals a peak matched by the winner's ions, keep order, re-sum the TIC in order.  One wavefront.
+__device__ __forceinline__ void remove_matched_peaks_dev(float* pm, float* pi, uint8_t* rm, uint8_t* rm2, uint32_t& P, float& tic,
+                                                         const float* __restrict__ wions, uint32_t w_items, uint32_t wmfc,
+                                                         const Tol& fragment_tol) {
+    const uint32_t lane = lane_id();
+    const uint32_t ptop = pow2_floor(P);
+    for (uint32_t i = lane; i < P; i += WAVE) rm[i] = 0;
+    __syncthreads();
+    for (uint32_t t = lane; t < w_items; t += WAVE) {
+        const uint32_t ion = t / (wmfc - 1), charge = t % (wmfc - 1) + 1;
+        const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, wions[ion] / (float)charge, fragment_tol);
+        if (pk >= 0) rm[pk] = 1;
+    }
+    __syncthreads();
+    // `to_remove.contains(&(mass, intensity))` compares values: equal pairs go together
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        uint8_t r = rm[i];
+        const float mi = pm[i], ii = pi[i];
+        for (uint32_t j = i; !r && j-- > 0 && pm[j] == mi;) r = rm[j] && pi[j] == ii;
+        for (uint32_t j = i + 1; !r && j < P && pm[j] == mi; j++) r = rm[j] && pi[j] == ii;
+        rm2[i] = r;
+    }
+    __syncthreads();
+    uint32_t newP = 0;
+    for (uint32_t bs = 0; bs < P; bs += WAVE) {
+        const uint32_t i = bs + lane;
+        const bool kept = i < P && !rm2[i];
+        const float mi = i < P ? pm[i] : 0.f, ii = i < P ? pi[i] : 0.f;
+        const uint64_t km = __ballot(kept);
+        const uint32_t pos = newP + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (kept) { pm[pos] = mi; pi[pos] = ii; }
+        newP += (uint32_t)__popcll(km);
+        __syncthreads();
+    }
+    P = newP;
+    float t = 0.0f;  // total_ion_current = intensities.iter().sum::<f32>(), scoring.rs:643
+    if (lane == 0) for (uint32_t i = 0; i < P; i++) t += pi[i];
+    tic = __shfl(t, 0, 64);
+    __syncthreads();
+}
+
+// the fields of Score (scoring.rs:17-30) in declaration order == the order of its derived PartialOrd
+struct QuickKey {
+    uint32_t peptide, matched_b, matched_y;
+    float summed_b, summed_y;
+    uint32_t longest_b, longest_y;
+    double hyperscore;
+    float ppm_difference;
+    uint32_t charge;
+    int iso;
+};
+// `a > b` under the derived PartialOrd: the first field that differs decides; a NaN makes the pair unordered (false)
+__device__ __forceinline__ bool quick_gt(const QuickKey& a, const QuickKey& b) {
+    if (a.peptide != b.peptide) return a.peptide > b.peptide;
+    if (a.matched_b != b.matched_b) return a.matched_b > b.matched_b;
+    if (a.matched_y != b.matched_y) return a.matched_y > b.matched_y;
+    if (!(a.summed_b == b.summed_b)) return a.summed_b > b.summed_b;
+    if (!(a.summed_y == b.summed_y)) return a.summed_y > b.summed_y;
+    if (a.longest_b != b.longest_b) return a.longest_b > b.longest_b;
+    if (a.longest_y != b.longest_y) return a.longest_y > b.longest_y;
+    if (!(a.hyperscore == b.hyperscore)) return a.hyperscore > b.hyperscore;
+    if (!(a.ppm_difference == b.ppm_difference)) return a.ppm_difference > b.ppm_difference;
+    if (a.charge != b.charge) return a.charge > b.charge;
+    return a.iso > b.iso;
+}
+
 __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                      const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                      uint32_t tcap, SageFeature* __restrict__ out,
-                                                     uint32_t* __restrict__ out_count) {
+                                                     uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
+    // keep != nullptr: Scorer::quick_score with prefilter_low_memory (scoring.rs:270-289) instead of build_features
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     if (blockIdx.x >= b.n) return;
@@ -1301,7 +1370,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     uint8_t* rm2 = rm + b.pcap;
 
     if (w.status[spec] != ST_OK) {
-        if (lane == 0) out_count[spec] = 0;
+        if (lane == 0 && !keep) out_count[spec] = 0;
         return;
     }
     PhaseClock pc;
@@ -1457,6 +1526,33 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
             h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
             pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
         }
+        if (keep) {
+            // quick_score, prefilter_low_memory (scoring.rs:270-289): bounded_min_heapify(&mut scores, k) keeps the k
+            // largest elements.  heap.rs compares with `<` / `>`, i.e. the DERIVED PartialOrd of Score — lexicographic
+            // in field order, peptide first (scoring.rs:17-30) — not its hyperscore Ord.  The set of the k largest does
+            // not depend on the heap's internal order, so rank each passing candidate by that order directly.
+            QuickKey* qk = (QuickKey*)term;  // (term[] / res[] are free once the candidates are scored)
+            QuickKey mine;
+            mine.peptide = pep; mine.matched_b = s.matched_b; mine.matched_y = s.matched_y;
+            mine.summed_b = s.summed_b; mine.summed_y = s.summed_y; mine.longest_b = s.longest_b; mine.longest_y = s.longest_y;
+            mine.hyperscore = h; mine.ppm_difference = s.ppm_difference; mine.charge = z; mine.iso = iso;
+            qk[lane] = mine;
+            const uint64_t pmask = __ballot(pass);
+            const uint32_t npass = (uint32_t)__popcll(pmask);
+            const uint32_t kq = sc.report_psms < npass ? sc.report_psms : npass;  // scoring.rs:284
+            __syncthreads();
+            if (pass) {
+                uint32_t above = 0;
+                uint64_t m = pmask;
+                while (m) {
+                    const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    above += j != lane && quick_gt(qk[j], mine);
+                }
+                if (above < kq) keep[pep] = 1;
+            }
+            return;
+        }
         // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation
         const long long key = order_key64(h);
         s_key[lane] = key;
@@ -1529,42 +1625,85 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         const uint32_t w_items = __shfl(n_items, wl, 64);
         const unsigned long long w_base = s_ionbase[wl];
         const float* wions = db.ions + w_base;
-        for (uint32_t i = lane; i < P; i += WAVE) rm[i] = 0;
-        __syncthreads();
-        for (uint32_t t = lane; t < w_items; t += WAVE) {
-            const uint32_t ion = t / (wmfc - 1), charge = t % (wmfc - 1) + 1;
-            const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, wions[ion] / (float)charge, sc.fragment_tol);
-            if (pk >= 0) rm[pk] = 1;
-        }
-        __syncthreads();
-        // `to_remove.contains(&(mass, intensity))` compares values: equal pairs go together
-        for (uint32_t i = lane; i < P; i += WAVE) {
-            uint8_t r = rm[i];
-            const float mi = pm[i], ii = pi[i];
-            for (uint32_t j = i; !r && j-- > 0 && pm[j] == mi;) r = rm[j] && pi[j] == ii;
-            for (uint32_t j = i + 1; !r && j < P && pm[j] == mi; j++) r = rm[j] && pi[j] == ii;
-            rm2[i] = r;
-        }
-        __syncthreads();
-        uint32_t newP = 0;
-        for (uint32_t bs = 0; bs < P; bs += WAVE) {
-            const uint32_t i = bs + lane;
-            const bool keep = i < P && !rm2[i];
-            const float mi = i < P ? pm[i] : 0.f, ii = i < P ? pi[i] : 0.f;
-            const uint64_t km = __ballot(keep);
-            const uint32_t pos = newP + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-            __syncthreads();
-            if (keep) { pm[pos] = mi; pi[pos] = ii; }
-            newP += (uint32_t)__popcll(km);
-            __syncthreads();
-        }
-        P = newP;
-        float t = 0.0f;  // total_ion_current = intensities.iter().sum::<f32>(), scoring.rs:643
-        if (lane == 0) for (uint32_t i = 0; i < P; i++) t += pi[i];
-        tic = __shfl(t, 0, 64);
-        __syncthreads();
+        remove_matched_peaks_dev(pm, pi, rm, rm2, P, tic, wions, w_items, wmfc, sc.fragment_tol);
     }
     if (lane == 0) out_count[spec] = n_emitted;
+}
+
+// quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
+__global__ __launch_bounds__(256) void quick_mark_kernel(DevScorer sc, uint32_t n, DevWork w, uint8_t* __restrict__ keep) {
+    const uint32_t spec = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63u;
+    if (spec >= n || w.status[spec] != ST_OK) return;
+    if (lane < w.cand_len[spec]) {
+        const uint32_t pep = prescore_peptide(w.cand[(size_t)spec * sc.kmax + lane]);
+        if (pep != 0xFFFFFFFFu) keep[pep] = 1;
+    }
+}
+
+// Fragments of the reported PSMs (annotate_matches, scoring.rs:722-752): one wavefront per spectrum replays
+// score_candidate's (kind, ion index, fragment charge) loop for every reported PSM and writes the matches in that
+// order; with chimera the winner's peaks are removed before the next PSM exactly as score_chimera_fast does.
+__global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc, DevBatchView b, const SageFeature* __restrict__ feats,
+                                                      const uint32_t* __restrict__ counts, const uint64_t* __restrict__ psm_off,
+                                                      DevFragments out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const uint32_t spec = blockIdx.x;
+    if (spec >= b.n) return;
+    float* pm = (float*)smem;
+    float* pi = pm + b.pcap;
+    uint8_t* rm = (uint8_t*)(pi + b.pcap);
+    uint8_t* rm2 = rm + b.pcap;
+    const uint64_t p0 = b.peak_off[spec];
+    uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        pm[i] = b.masses[p0 + i];
+        pi[i] = b.intensities[p0 + i];
+    }
+    __syncthreads();
+    float tic = 0.0f;
+    const uint32_t count = counts[spec];
+    for (uint32_t r = 0; r < count; r++) {
+        const size_t slot = (size_t)spec * sc.report_psms + r;
+        const SageFeature f = feats[slot];
+        const uint32_t pep = f.peptide_idx;
+        const uint32_t mfc = max_fragment_charge(sc.max_fragment_charge, f.charge), nfz = mfc - 1;
+        const uint64_t ion_base = db.ion_off[pep];
+        const uint32_t lm1 = db.n_kinds ? (uint32_t)((db.ion_off[pep + 1] - ion_base) / db.n_kinds) : 0;
+        const uint32_t n_items = db.n_kinds * lm1 * nfz;
+        const uint32_t ptop = pow2_floor(P);
+        uint64_t pos = psm_off[slot];
+        for (uint32_t base = 0; base < n_items; base += WAVE) {
+            const uint32_t t = base + lane;
+            int pk = -1;
+            uint32_t ion = 0, charge = 1;
+            float mz = 0.0f;
+            if (t < n_items) {
+                ion = t / nfz;
+                charge = t - ion * nfz + 1;
+                mz = db.ions[ion_base + ion] / (float)charge;
+                pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, mz, sc.fragment_tol);
+            }
+            const uint64_t m = __ballot(pk >= 0);
+            if (pk >= 0) {
+                const uint64_t o = pos + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (o < out.capacity) {
+                    const uint32_t kidx = ion / lm1, idx = ion - kidx * lm1;
+                    const uint8_t kind = db.ion_kinds[kidx];
+                    out.kinds[o] = kind;
+                    out.charges[o] = (int32_t)charge;
+                    // scoring.rs:739-744: b-like ions count from the N-terminus, y-like from the C-terminus
+                    out.fragment_ordinals[o] = kind <= 2 ? (int32_t)idx + 1 : (int32_t)lm1 - (int32_t)idx;
+                    out.intensities[o] = pi[pk];
+                    out.mz_calculated[o] = mz + PROTON;       // scoring.rs:723
+                    out.mz_experimental[o] = pm[pk] + PROTON;  // scoring.rs:722
+                }
+            }
+            pos += (uint64_t)__popcll(m);
+        }
+        if (sc.chimera && r + 1 < count)
+            remove_matched_peaks_dev(pm, pi, rm, rm2, P, tic, db.ions + ion_base, n_items, mfc, sc.fragment_tol);
+    }
 }
 
 }  // namespace
@@ -1615,10 +1754,20 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
 }
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
-                    uint32_t* out_count, void* stream) {
+                    uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
     hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions), (hipStream_t)stream, db,
-                       sc, b, w, lnfact_table, lnfact_n, rescore_item_cap(b, max_ions), out, out_count);
+                       sc, b, w, lnfact_table, lnfact_n, rescore_item_cap(b, max_ions), out, out_count, keep);
+}
+void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(quick_mark_kernel, dim3((b.n + 3) / 4), dim3(256), 0, (hipStream_t)stream, sc, b.n, w, keep);
+}
+void launch_annotate(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const SageFeature* feats,
+                     const uint32_t* counts, const uint64_t* psm_off, const DevFragments& out, void* stream) {
+    if (b.n == 0) return;
+    const size_t lds = ((size_t)b.pcap * 10 + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(annotate_kernel, dim3(b.n), dim3(64), lds, (hipStream_t)stream, db, sc, b, feats, counts, psm_off, out);
 }
 
 }  // namespace sagehip

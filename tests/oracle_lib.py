@@ -71,6 +71,11 @@ def load():
     lib.orc_brute_force.restype = C.c_uint64
     lib.orc_brute_force.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_uint32,
                                     C.c_uint8, C.c_int8, L.c_u32_p, L.c_u32_p, C.POINTER(C.c_double), C.c_uint64]
+    lib.orc_annotate_batch.restype = C.c_uint64
+    lib.orc_annotate_batch.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), L.c_u64_p, L.c_u8_p,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), L.c_float_p, L.c_float_p, L.c_float_p,
+                                       C.c_uint64]
+    lib.orc_quick_score.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_int, L.c_u8_p]
     lib.orc_tol_bounds.argtypes = [L.SageTolerance, C.c_float, L.c_float_p, L.c_float_p]
     lib.orc_max_threads.restype = C.c_int
     _lib = lib
@@ -159,6 +164,29 @@ class OracleDb:
                                  L.as_ptr(counts, C.c_uint32), threads, C.byref(w) if work else None)
         wd = {k: getattr(w, k) for k, _ in OrcWork._fields_} if work else None
         return feats.reshape(batch.n, params.report_psms), counts, float(ms), wd
+
+    def annotate(self, params: ScorerParams, batch: SpectrumBatch, cap: int = 1 << 22):
+        """Fragments (scoring.rs:152-161) of every reported PSM: (psm_off[n*report+1], dict of flat arrays)."""
+        lib = load()
+        cp = params.to_c(); cb = batch.to_c()
+        off = np.zeros(batch.n * params.report_psms + 1, np.uint64)
+        out = dict(kinds=np.zeros(cap, np.uint8), charges=np.zeros(cap, np.int32), fragment_ordinals=np.zeros(cap, np.int32),
+                   intensities=np.zeros(cap, np.float32), mz_calculated=np.zeros(cap, np.float32),
+                   mz_experimental=np.zeros(cap, np.float32))
+        n = int(lib.orc_annotate_batch(self.h, C.byref(cp), C.byref(cb), L.as_ptr(off, C.c_uint64), L.as_ptr(out["kinds"], C.c_uint8),
+                                       out["charges"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                       out["fragment_ordinals"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                       L.as_ptr(out["intensities"], C.c_float), L.as_ptr(out["mz_calculated"], C.c_float),
+                                       L.as_ptr(out["mz_experimental"], C.c_float), cap))
+        assert n <= cap
+        return off, {k: v[:n].copy() for k, v in out.items()}
+
+    def quick_score(self, params: ScorerParams, batch: SpectrumBatch, prefilter_low_memory: bool):
+        lib = load()
+        cp = params.to_c(); cb = batch.to_c()
+        keep = np.zeros(self.n_peptides, np.uint8)
+        lib.orc_quick_score(self.h, C.byref(cp), C.byref(cb), int(prefilter_low_memory), L.as_ptr(keep, C.c_uint8))
+        return keep
 
     def initial_hits(self, params: ScorerParams, batch: SpectrumBatch, i: int):
         lib = load()

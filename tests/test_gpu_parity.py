@@ -193,10 +193,48 @@ def test_edge_cases(small_world):
     assert feats.shape[0] == 0 and counts.shape[0] == 0
 
 
+def _check_annotation(world, params, batch, context):
+    scorer = Scorer(world.dev, params)
+    dbatch = scorer.upload(batch)
+    gf, gc = scorer.score_resident(dbatch)
+    gf, gc = gf.copy(), gc.copy()
+    goff, garr = scorer.annotate(dbatch, gf, gc)
+    ooff, oarr = world.orc.annotate(params, batch)
+    np.testing.assert_array_equal(goff, ooff, err_msg=f"{context}: PSM offsets")
+    for k in ("kinds", "charges", "fragment_ordinals", "intensities", "mz_calculated", "mz_experimental"):
+        np.testing.assert_array_equal(garr[k], oarr[k], err_msg=f"{context}: Fragments.{k}")  # f32 values bit-exact
+    assert len(garr["kinds"]) == int(goff[-1]) > 0
+    return int(goff[-1])
+
+
+def test_annotate_matches_fragments(small_world):
+    """Scorer.annotate_matches (scoring.rs:722-752): kinds / charges / ordinals / intensities / m/z of every matched
+    fragment of every reported PSM, in the reference's push order."""
+    _check_annotation(small_world, ScorerParams(annotate_matches=True), small_world.batch, "annotate, report 1")
+    _check_annotation(small_world, ScorerParams(annotate_matches=True, report_psms=4, max_fragment_charge=3,
+                                                precursor_tol=Tolerance("da", -2.0, 2.0)), small_world.batch,
+                      "annotate, report 4, fragment charge 3")
+    _check_annotation(small_world, ScorerParams(annotate_matches=True, chimera=True, report_psms=3), small_world.batch,
+                      "annotate + chimera (peaks removed between PSMs)")
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_quick_score_prefilter(small_world, low_memory):
+    """Scorer::quick_score (scoring.rs:255-298), both flavours; the low-memory one keeps the report_psms largest
+    scores under Score's DERIVED ordering (peptide index first), as heap.rs's `<` / `>` do."""
+    for params, ctx in ((ScorerParams(report_psms=2), "narrow"),
+                        (ScorerParams(report_psms=3, precursor_tol=Tolerance("da", -3.0, 3.0), min_isotope_err=-1, max_isotope_err=1), "±3 Da x iso"),
+                        (ScorerParams(precursor_tol=Tolerance("da", -300.0, 300.0)), "open (large-window kernels)")):
+        batch = small_world.batch.subset(np.arange(0, small_world.batch.n, 4 if ctx.startswith("open") else 1))
+        scorer = Scorer(small_world.dev, params)
+        gk = scorer.quick_score(scorer.upload(batch), low_memory)
+        ok = small_world.orc.quick_score(params, batch, low_memory)
+        np.testing.assert_array_equal(gk, ok, err_msg=f"quick_score low_memory={low_memory} {ctx}")
+        assert gk.sum() > 10
+
+
 def test_error_paths(small_world):
     with pytest.raises(L.SageHipError):
         Scorer(small_world.dev, ScorerParams(report_psms=0))
-    with pytest.raises(L.SageHipError):
-        Scorer(small_world.dev, ScorerParams(annotate_matches=True))
     with pytest.raises(L.SageHipError):
         Scorer(small_world.dev, ScorerParams(min_isotope_err=2, max_isotope_err=1))
