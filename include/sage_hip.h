@@ -112,6 +112,8 @@ int sage_hip_hostdb_view(const SageHostDb* db, SageDbView* out);
  * return the required buffer size including NUL. */
 uint64_t sage_hip_hostdb_peptide_string(const SageHostDb* db, uint64_t i, char* out, uint64_t cap);
 uint64_t sage_hip_hostdb_peptide_proteins(const SageHostDb* db, uint64_t i, char* out, uint64_t cap);
+/* Peptide.proteins.len() and Peptide.semi_enzymatic (peptide.rs:28-30) — columns of results.sage.tsv */
+int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num_proteins, uint8_t* semi_enzymatic);
 
 /* SpectrumProcessor::new(take_top_n, deisotope, min_deisotope_mz).process() for one centroided
  * MS2 spectrum (spectrum.rs:279-412).  precursor_charge 0 == None.  out_* need capacity n.

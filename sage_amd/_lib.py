@@ -181,6 +181,7 @@ def load():
         "sage_hip_hostdb_view": (C.c_int, [vp, C.POINTER(SageDbView)]),
         "sage_hip_hostdb_peptide_string": (C.c_uint64, [vp, C.c_uint64, C.c_char_p, C.c_uint64]),
         "sage_hip_hostdb_peptide_proteins": (C.c_uint64, [vp, C.c_uint64, C.c_char_p, C.c_uint64]),
+        "sage_hip_hostdb_peptide_info": (C.c_int, [vp, C.c_uint64, c_u32_p, c_u8_p]),
         "sage_hip_process_ms2": (C.c_uint64, [C.c_uint64, C.c_int, C.c_float, c_float_p, c_float_p, C.c_uint64,
                                               C.c_uint8, c_float_p, c_float_p, c_float_p]),
         "sage_hip_device_count": (C.c_int, []),
@@ -212,7 +213,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "sage_hip_last_error", "sage_hip_abi_version", "sage_hip_hostdb_build", "sage_hip_hostdb_free",
     "sage_hip_hostdb_view", "sage_hip_hostdb_peptide_string", "sage_hip_hostdb_peptide_proteins",
-    "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
+    "sage_hip_hostdb_peptide_info", "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",

@@ -171,6 +171,12 @@ class IndexedDatabase:
         lib.sage_hip_hostdb_peptide_proteins(self._h, i, buf, n)
         return buf.value.decode()
 
+    def peptide_info(self, i: int):
+        """(Peptide.proteins.len(), Peptide.semi_enzymatic)"""
+        n, semi = C.c_uint32(), C.c_uint8()
+        L.check(L.load().sage_hip_hostdb_peptide_info(self._h, i, C.byref(n), C.byref(semi)))
+        return int(n.value), int(semi.value)
+
     def sequence(self, i: int) -> str:
         return bytes(self.seq[int(self.seq_off[i]):int(self.seq_off[i + 1])]).decode()
 

@@ -1,0 +1,141 @@
+"""JSON-config command line for the search-and-score path — the drop-in for `sage config.json [mzML ...]`.
+
+    python -m sage_amd.cli config.json [-o OUTPUT_DIRECTORY] [-f FASTA] [--annotate-matches] [mzml ...]
+
+Mirrors sage-cli for this path and nothing else: the JSON schema and defaults of
+crates/sage-cli/src/input.rs (Input -> Search, :298-385; `database` = sage-core Builder, database.rs:59-139), the per-file
+flow of runner.rs (read mzML -> SpectrumProcessor::process -> keep MS2 with >= min_peaks peaks -> Scorer::score,
+:311-325, :398-461) and the `results.sage.tsv` / `matched_fragments.sage.tsv` writers (:687-935).  Everything downstream
+of Scorer::score — LDA rescoring, q-values, protein grouping, LFQ/TMT, parquet, cloud IO — is out of scope: those columns
+carry the defaults a Feature is born with (scoring.rs:576-592).  The search itself runs on the GPU through
+libsage_hip.so; there is no CPU fallback.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import output
+from .api import (DatabaseParameters, DeviceDatabase, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor, Tolerance,
+                  device_count)
+from .mzml import read_mzml
+
+
+def search_parameters(cfg: dict) -> dict:
+    """Input::build (input.rs:298-385): defaults of every key the path reads."""
+    pc = cfg.get("precursor_charge") or [2, 4]
+    if pc[0] > pc[1]:
+        raise SystemExit(f"Precursor charges should be specified [low, high], user provided: [{pc[0]}, {pc[1]}]")
+    iso = cfg.get("isotope_errors") or [0, 0]
+    return dict(
+        precursor_tol=Tolerance.from_json(cfg["precursor_tol"]), fragment_tol=Tolerance.from_json(cfg["fragment_tol"]),
+        report_psms=cfg.get("report_psms") or 1, max_peaks=cfg.get("max_peaks") or 150,
+        min_peaks=15 if cfg.get("min_peaks") is None else cfg["min_peaks"],
+        min_matched_peaks=4 if cfg.get("min_matched_peaks") is None else cfg["min_matched_peaks"],
+        max_fragment_charge=cfg.get("max_fragment_charge"), annotate_matches=bool(cfg.get("annotate_matches", False)),
+        precursor_charge=(int(pc[0]), int(pc[1])), override_precursor_charge=bool(cfg.get("override_precursor_charge", False)),
+        isotope_errors=(int(iso[0]), int(iso[1])), deisotope=True if cfg.get("deisotope") is None else bool(cfg["deisotope"]),
+        chimera=bool(cfg.get("chimera", False)), wide_window=bool(cfg.get("wide_window", False)),
+        score_type=cfg.get("score_type") or "SageHyperScore")
+
+
+def scorer_params(sp: dict) -> ScorerParams:
+    """The Scorer struct literal of runner.rs:492-508."""
+    return ScorerParams(precursor_tol=sp["precursor_tol"], fragment_tol=sp["fragment_tol"],
+                        min_matched_peaks=sp["min_matched_peaks"], min_isotope_err=sp["isotope_errors"][0],
+                        max_isotope_err=sp["isotope_errors"][1], min_precursor_charge=sp["precursor_charge"][0],
+                        max_precursor_charge=sp["precursor_charge"][1],
+                        override_precursor_charge=sp["override_precursor_charge"], max_fragment_charge=sp["max_fragment_charge"],
+                        chimera=sp["chimera"], report_psms=sp["report_psms"], wide_window=sp["wide_window"],
+                        annotate_matches=sp["annotate_matches"], score_type=sp["score_type"])
+
+
+def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print) -> dict:
+    if device_count() <= 0:
+        raise SystemExit("sage_amd.cli: no HIP device visible — libsage_hip has no CPU fallback")
+    sp = search_parameters(cfg)
+    dbp = DatabaseParameters.from_json(cfg["database"])
+    if not dbp.fasta:
+        raise SystemExit("`database.fasta` must be set. For more information try '--help'")
+    t0 = time.time()
+    host = dbp.build(open(dbp.fasta).read())
+    dev = DeviceDatabase(host, device)
+    log(f"generated {host.n_fragments} fragments, {host.n_peptides} peptides in {int((time.time() - t0) * 1000)}ms")
+    params = scorer_params(sp)
+    scorer = Scorer(dev, params)
+    processor = SpectrumProcessor(sp["max_peaks"], sp["deisotope"], 0.0)  # (no TMT reporter cut-off: quant is out of scope)
+    os.makedirs(output_directory, exist_ok=True)
+    rows, frag_rows = [], []
+    psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
+    n_searched = 0
+    search_ms = 0.0
+    for file_id, path in enumerate(mzml_paths):
+        t0 = time.time()
+        raw = read_mzml(path, file_id=file_id, ms_level=2)
+        processed = [processor.process(r) for r in raw]
+        processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]  # runner.rs:313
+        log(f"- file IO: {int((time.time() - t0) * 1000):8d} ms")
+        if not processed:
+            continue
+        batch = SpectrumBatch.from_spectra(processed)
+        t0 = time.time()
+        dbatch = scorer.upload(batch)
+        feats, counts = scorer.score_resident(dbatch)
+        feats, counts = feats.copy(), counts.copy()
+        dt = (time.time() - t0) * 1000.0
+        search_ms += dt
+        n_searched += batch.n
+        log(f"- search:  {int(dt):8d} ms ({int(batch.n * 1000 / (dt + 1))} spectra/s)")  # runner.rs:327-330
+        off = arr = None
+        if sp["annotate_matches"]:
+            off, arr = scorer.annotate(dbatch, feats, counts)
+        name = os.path.basename(path)
+        for i in range(batch.n):
+            for r in range(int(counts[i])):
+                rows.append(output.feature_row(psm_id, feats[i, r], host, name, processed[i].id))
+                if arr is not None:
+                    s = i * params.report_psms + r
+                    frag_rows += output.fragment_rows(psm_id, int(off[s]), int(off[s + 1]), arr)
+                psm_id += 1
+        dbatch.close()
+    results = os.path.join(output_directory, "results.sage.tsv")
+    output.write_features(results, rows)
+    paths = [results]
+    if sp["annotate_matches"]:
+        fp = os.path.join(output_directory, "matched_fragments.sage.tsv")
+        output.write_fragments(fp, frag_rows)
+        paths.append(fp)
+    summary = {"version": "sage-hip 0.1 (search-and-score path of sage 0.15.0-beta.2)", "psms": len(rows),
+               "spectra_searched": n_searched, "search_ms": search_ms, "output_paths": paths}
+    with open(os.path.join(output_directory, "results.json"), "w") as fh:
+        json.dump(dict(cfg, output_paths=paths, summary=summary), fh, indent=2, default=str)
+    return summary
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="sage_amd.cli", description="GPU search-and-score path of Sage (JSON-config CLI)")
+    ap.add_argument("parameters", help="path to configuration parameters (JSON file)")
+    ap.add_argument("mzml_paths", nargs="*", help="paths to mzML files to process. Overrides mzML files listed in the configuration file.")
+    ap.add_argument("-f", "--fasta", help="path to FASTA database. Overrides the FASTA file specified in the configuration file.")
+    ap.add_argument("-o", "--output_directory", help="where to place output files. Overrides the directory specified in the configuration file.")
+    ap.add_argument("--annotate-matches", action="store_true", help="write matched fragments output file")
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+    cfg = json.load(open(args.parameters))
+    if args.fasta:
+        cfg.setdefault("database", {})["fasta"] = args.fasta
+    if args.annotate_matches:
+        cfg["annotate_matches"] = True
+    mzml = args.mzml_paths or cfg.get("mzml_paths")
+    if not mzml:
+        raise SystemExit("'mzml_paths' must be provided!")
+    out = args.output_directory or cfg.get("output_directory") or os.getcwd()
+    summary = run(cfg, mzml, out, args.device)
+    print(json.dumps(summary))
+
+
+if __name__ == "__main__":
+    main()

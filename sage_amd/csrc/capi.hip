@@ -149,6 +149,12 @@ uint64_t sage_hip_hostdb_peptide_proteins(const SageHostDb* db, uint64_t i, char
     if (!db || i >= db->db.n_peptides()) return 0;
     return copy_out(db->db.peptide_proteins(i), out, cap);
 }
+int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num_proteins, uint8_t* semi_enzymatic) {
+    if (!db || i >= db->db.n_peptides()) return fail(SAGE_HIP_ERR_INVALID, "peptide index out of range");
+    if (num_proteins) *num_proteins = (uint32_t)(db->db.pep_protein_off[i + 1] - db->db.pep_protein_off[i]);
+    if (semi_enzymatic) *semi_enzymatic = db->db.semi[i];
+    return SAGE_HIP_OK;
+}
 uint64_t sage_hip_process_ms2(uint64_t take_top_n, int deisotope, float min_deisotope_mz, const float* mz,
                               const float* intensity, uint64_t n, uint8_t precursor_charge, float* out_mass,
                               float* out_intensity, float* out_tic) {

@@ -89,6 +89,7 @@ struct Pep {
     uint8_t missed = 0;
     uint8_t pos = kInternal;
     bool decoy = false;
+    bool semi = false;  // peptide.rs:28 semi_enzymatic
     std::vector<uint32_t> proteins;
 };
 
@@ -533,6 +534,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
             base.missed = ref.missed;
             base.pos = ref.pos;
             base.decoy = ref.decoy;
+            base.semi = ref.semi;
             for (size_t i = group_start[g]; i < group_start[g + 1]; i++) base.proteins.push_back(cuts[i].protein);
             forms.clear();
             expand_mods(base, cfg, forms);
@@ -600,6 +602,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
     db.cterm.resize(np);
     db.decoy.resize(np);
     db.missed.resize(np);
+    db.semi.resize(np);
     db.seq_off.resize(np + 1);
     db.pep_protein_off.resize(np + 1);
     uint64_t off = 0, poff = 0;
@@ -622,6 +625,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
         db.cterm[i] = p.cterm;
         db.decoy[i] = p.decoy;
         db.missed[i] = p.missed;
+        db.semi[i] = p.semi;
         std::memcpy(db.seq.data() + db.seq_off[i], p.seq.data(), p.seq.size());
         std::memcpy(db.mods.data() + db.seq_off[i], p.mods.data(), p.mods.size() * 4);
         // proteins.sort_unstable() on names (database.rs:248-250); ids are in FASTA order, so sort by name

@@ -46,7 +46,7 @@ struct HostDb {
     std::vector<uint8_t> seq;
     std::vector<float> mods;
     std::vector<float> nterm, cterm;
-    std::vector<uint8_t> decoy, missed;
+    std::vector<uint8_t> decoy, missed, semi;
     std::vector<uint8_t> ion_kinds;
     // protein bookkeeping (not used by the scoring path; kept so writers can be added later)
     std::vector<std::string> protein_names;

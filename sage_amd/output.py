@@ -1,0 +1,103 @@
+"""results.sage.tsv / matched_fragments.sage.tsv writers (host side).
+
+Column order and number formatting follow the reference byte for byte where the hot path owns the value:
+sage-cli/src/runner.rs:687-780 (serialize_feature), :782-828 (serialize_fragments), :830-935 (headers).  Integers are
+written with `itoa`, floats with `ryu` (shortest digits that round-trip, Rust `ryu::Buffer::format`), reproduced by
+`ryu_f32` / `ryu_f64` below.  Columns the path does not compute (rescoring / FDR outputs) carry the defaults Feature
+gets in build_features (scoring.rs:576-592): discriminant 0.0, posterior_error 1.0, q-values 1.0, predicted_rt 0.0,
+aligned_rt = rt, delta_rt_model / delta_ims_model 0.999.
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+HEADERS = ["psm_id", "peptide", "proteins", "protein_groups", "num_proteins", "num_protein_groups", "filename", "scannr",
+           "rank", "label", "expmass", "calcmass", "charge", "peptide_len", "missed_cleavages", "semi_enzymatic",
+           "isotope_error", "precursor_ppm", "fragment_ppm", "hyperscore", "delta_next", "delta_best", "rt", "aligned_rt",
+           "predicted_rt", "delta_rt_model", "ion_mobility", "predicted_mobility", "delta_mobility", "matched_peaks",
+           "longest_b", "longest_y", "longest_y_pct", "matched_intensity_pct", "scored_candidates", "poisson",
+           "sage_discriminant_score", "posterior_error", "spectrum_q", "peptide_q", "protein_q", "protein_group_q",
+           "ms2_intensity"]
+FRAGMENT_HEADERS = ["psm_id", "fragment_type", "fragment_ordinals", "fragment_charge", "fragment_mz_calculated",
+                    "fragment_mz_experimental", "fragment_intensity"]
+ION_NAMES = "abcxyz"
+
+
+def _ryu(x, f32: bool) -> str:
+    """ryu::Buffer::format: shortest round-trip digits, laid out as ryu's pretty printer does (ryu/src/pretty/mod.rs:
+    plain decimals while the decimal point stays within 16 (f64) / 13 (f32) digits and the value is >= 1e-5 (f64) /
+    1e-6 (f32); otherwise d.ddde[-]x)."""
+    x = np.float32(x) if f32 else np.float64(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    if x == 0:
+        return "-0.0" if np.signbit(x) else "0.0"
+    sci = np.format_float_scientific(x, unique=True, trim="-", exp_digits=1)  # e.g. '1.2345e+3', '-5e-7'
+    sign = "-" if sci[0] == "-" else ""
+    mant, exp = sci.lstrip("-").split("e")
+    digits = mant.replace(".", "")
+    e10 = int(exp)
+    length = len(digits)
+    kk = e10 + 1            # 10^(kk-1) <= |x| < 10^kk
+    k = kk - length         # x = digits * 10^k
+    hi = 13 if f32 else 16
+    lo = -6 if f32 else -5
+    if 0 <= k and kk <= hi:
+        return sign + digits + "0" * k + ".0"
+    if 0 < kk <= hi:
+        return sign + digits[:kk] + "." + digits[kk:]
+    if lo < kk <= 0:
+        return sign + "0." + "0" * (-kk) + digits
+    if length == 1:
+        return sign + digits + "e" + str(kk - 1)
+    return sign + digits[0] + "." + digits[1:] + "e" + str(kk - 1)
+
+
+def ryu_f32(x) -> str:
+    return _ryu(x, True)
+
+
+def ryu_f64(x) -> str:
+    return _ryu(x, False)
+
+
+def feature_row(psm_id: int, f, db, filename: str, scannr: str) -> List[str]:
+    """serialize_feature (runner.rs:687-780) for one SageFeature record `f` (numpy void of FEATURE_DTYPE)."""
+    pep = int(f["peptide_idx"])
+    num_proteins, semi = db.peptide_info(pep)
+    rt = f["rt"]
+    return [
+        str(psm_id), db.peptide_string(pep), db.peptide_proteins(pep), "", str(num_proteins), "0", filename, scannr,
+        str(int(f["rank"])), str(int(f["label"])), ryu_f32(f["expmass"]), ryu_f32(f["calcmass"]), str(int(f["charge"])),
+        str(int(f["peptide_len"])), str(int(f["missed_cleavages"])), str(semi), ryu_f32(f["isotope_error"]),
+        ryu_f32(f["delta_mass"]), ryu_f32(f["average_ppm"]), ryu_f64(f["hyperscore"]), ryu_f64(f["delta_next"]),
+        ryu_f64(f["delta_best"]), ryu_f32(rt), ryu_f32(rt), ryu_f32(0.0), ryu_f32(0.999), ryu_f32(f["ims"]), ryu_f32(0.0),
+        ryu_f32(0.999), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
+        ryu_f32(f["longest_y_pct"]), ryu_f32(f["matched_intensity_pct"]), str(int(f["scored_candidates"])),
+        ryu_f64(f["poisson"]), ryu_f32(0.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0),
+        ryu_f32(f["ms2_intensity"]),
+    ]
+
+
+def write_features(path: str, rows: Sequence[List[str]]) -> None:
+    """write_features (runner.rs:830-905): tab-separated, header first."""
+    with open(path, "w", newline="") as fh:
+        fh.write("\t".join(HEADERS) + "\n")
+        for r in rows:
+            fh.write("\t".join(r) + "\n")
+
+
+def fragment_rows(psm_id: int, lo: int, hi: int, arr) -> List[List[str]]:
+    """serialize_fragments (runner.rs:782-828) for entries [lo, hi) of the flat Fragments arrays."""
+    return [[str(psm_id), ION_NAMES[int(arr["kinds"][j])], str(int(arr["fragment_ordinals"][j])), str(int(arr["charges"][j])),
+             ryu_f32(arr["mz_calculated"][j]), ryu_f32(arr["mz_experimental"][j]), ryu_f32(arr["intensities"][j])]
+            for j in range(lo, hi)]
+
+
+def write_fragments(path: str, rows: Sequence[List[str]]) -> None:
+    with open(path, "w", newline="") as fh:
+        fh.write("\t".join(FRAGMENT_HEADERS) + "\n")
+        for r in rows:
+            fh.write("\t".join(r) + "\n")

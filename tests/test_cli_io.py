@@ -1,0 +1,163 @@
+"""mzML reader / writer, results.sage.tsv formatting and the JSON-config CLI.
+CPU tests cover the host logic; the end-to-end CLI runs are GPU tests (the search has no CPU fallback)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from sage_amd import cli, output
+from sage_amd.api import DatabaseParameters, RawSpectrum, SpectrumBatch, SpectrumProcessor
+from sage_amd.mzml import _f32, read_mzml, write_mzml
+from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
+from test_oracle_golden import load_c1
+
+REF_MZML = "/root/reference/tests/LQSRPAAPPAPGPGQLTLR.mzML"
+
+
+def c1_raw():
+    d, s, mz, it = load_c1()
+    iso = (-float(np.float32(float(s["isolation"]["MS:1000828"]))), float(np.float32(float(s["isolation"]["MS:1000829"]))))
+    return d, RawSpectrum(mz, it, _f32(s["selected_ion"]["MS:1000744"]), int(s["selected_ion"]["MS:1000041"]), iso,
+                          _f32(s["scan_start_time"]), None, 0, s["id"])
+
+
+def test_f32_parse_is_a_single_rounding():
+    assert _f32("643.0344") == float(np.float32(643.0344))
+    assert _f32("0.1") == float(np.float32(0.1))
+    # 16777217 is exactly between two f32s: ties to even
+    assert _f32("16777217") == 16777216.0 and _f32("16777219") == 16777220.0
+    # a decimal just above a tie: float() rounds it to the tie in f64 and a second rounding would go DOWN
+    assert _f32("16777217.00000000001") == 16777218.0
+
+
+def test_mzml_round_trip_and_reader_semantics(tmp_path):
+    d, raw = c1_raw()
+    p = str(tmp_path / "c1.mzML")
+    write_mzml(p, [raw])
+    back = read_mzml(p, file_id=3)
+    assert len(back) == 1
+    b = back[0]
+    np.testing.assert_array_equal(b.mz, raw.mz)
+    np.testing.assert_array_equal(b.intensity, raw.intensity)
+    assert np.float32(b.precursor_mz) == np.float32(raw.precursor_mz) and b.precursor_charge == 3
+    assert b.isolation_window == raw.isolation_window and b.file_id == 3 and b.id == raw.id
+    assert np.float32(b.scan_start_time) == np.float32(raw.scan_start_time)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MZML), reason="reference checkout not mounted (GPU box)")
+def test_reader_on_the_reference_fixture_matches_the_committed_decode():
+    """The reference's own test file, read by read_mzml, equals tests/golden/c1_fixture.json (decoded independently
+    by tests/golden/make_c1_fixture.py)."""
+    d, raw = c1_raw()
+    got = read_mzml(REF_MZML)[0]
+    np.testing.assert_array_equal(got.mz, raw.mz)
+    np.testing.assert_array_equal(got.intensity, raw.intensity)
+    assert got.precursor_mz == raw.precursor_mz and got.precursor_charge == raw.precursor_charge
+    assert got.isolation_window == raw.isolation_window and got.id == raw.id
+    assert np.float32(got.scan_start_time) == np.float32(raw.scan_start_time)
+
+
+def test_ryu_number_formatting():
+    f32 = [(1.0, "1.0"), (0.1, "0.1"), (1e-5, "0.00001"), (1e-6, "0.000001"), (1e-7, "1e-7"), (1234.5678, "1234.5677"),
+           (1e12, "1000000000000.0"), (1e13, "1e13"), (3.4028235e38, "3.4028235e38"), (-2.5, "-2.5"), (0.999, "0.999"),
+           (float("inf"), "inf"), (float("nan"), "NaN"), (0.0, "0.0")]
+    for v, e in f32:
+        assert output.ryu_f32(v) == e, (v, output.ryu_f32(v), e)
+    f64 = [(1e16, "1e16"), (1e15, "1000000000000000.0"), (0.3, "0.3"), (1e-5, "0.00001"), (1e-6, "1e-6"),
+           (123456.789, "123456.789"), (1.7976931348623157e308, "1.7976931348623157e308"), (5e-324, "5e-324"),
+           (float("-inf"), "-inf"), (42.125, "42.125")]
+    for v, e in f64:
+        assert output.ryu_f64(v) == e, (v, output.ryu_f64(v), e)
+    # every formatted value parses back to the same float (shortest round-trip digits)
+    rng = np.random.default_rng(7)
+    for x in rng.lognormal(0, 8, 200):
+        assert np.float32(float(output.ryu_f32(np.float32(x)))) == np.float32(x)
+        assert float(output.ryu_f64(x)) == x
+
+
+def test_search_parameter_defaults():
+    """input.rs:355-385"""
+    sp = cli.search_parameters({"precursor_tol": {"ppm": [-10, 10]}, "fragment_tol": {"da": [-0.02, 0.02]}})
+    assert (sp["report_psms"], sp["max_peaks"], sp["min_peaks"], sp["min_matched_peaks"]) == (1, 150, 15, 4)
+    assert sp["precursor_charge"] == (2, 4) and sp["isotope_errors"] == (0, 0) and sp["deisotope"] is True
+    assert not sp["chimera"] and not sp["wide_window"] and sp["max_fragment_charge"] is None
+    assert sp["fragment_tol"].kind == "da" and sp["score_type"] == "SageHyperScore"
+    with pytest.raises(SystemExit):
+        cli.search_parameters({"precursor_tol": {"ppm": [-10, 10]}, "fragment_tol": {"ppm": [-10, 10]}, "precursor_charge": [4, 2]})
+
+
+def _read_tsv(path):
+    lines = open(path).read().splitlines()
+    return lines[0].split("\t"), [l.split("\t") for l in lines[1:]]
+
+
+@pytest.mark.gpu
+def test_cli_on_the_reference_config(tmp_path, gpu_required):
+    """`sage tests/config.json` (BASELINE.json configs[0]) end to end through the GPU path: one PSM, LQSRPAAPPAPGPGQLTLR,
+    and a results.sage.tsv whose columns / formatting follow runner.rs:687-935.  (The CLI keeps max_peaks = 150 peaks,
+    input.rs:366, where the reference's integration test keeps 100 and counts 21 matched peaks; with 150 it is 22.)"""
+    d, raw = c1_raw()
+    mz = str(tmp_path / "LQSRPAAPPAPGPGQLTLR.mzML")
+    fa = str(tmp_path / "Q99536.fasta")
+    write_mzml(mz, [raw])
+    open(fa, "w").write(d["fasta"])
+    cfg = dict(d["config_json"])
+    cfg["database"] = dict(cfg["database"], fasta=fa)
+    cfg["mzml_paths"] = [mz]
+    cfg["annotate_matches"] = True
+    cp = str(tmp_path / "config.json")
+    json.dump(cfg, open(cp, "w"))
+    out = str(tmp_path / "out")
+    cli.main([cp, "-o", out])
+    hdr, rows = _read_tsv(os.path.join(out, "results.sage.tsv"))
+    assert hdr == output.HEADERS and len(rows) == 1
+    r = dict(zip(hdr, rows[0]))
+    assert r["psm_id"] == "1" and r["peptide"] == "LQSRPAAPPAPGPGQLTLR" and r["proteins"] == "sp|Q99536|VAT1_HUMAN"
+    assert r["charge"] == "3" and r["rank"] == "1" and r["label"] == "1"
+    assert r["filename"] == "LQSRPAAPPAPGPGQLTLR.mzML" and r["scannr"] == raw.id
+    assert r["spectrum_q"] == "1.0" and r["delta_rt_model"] == "0.999" and r["sage_discriminant_score"] == "0.0"
+    # the numbers are the oracle's, formatted by ryu
+    db = oracle_lib.OracleDb.build(d["fasta"], DatabaseParameters.from_json(d["config_json"]["database"]))
+    sp = SpectrumProcessor(150, True, 0.0)
+    batch = SpectrumBatch.from_spectra([sp.process(raw)])
+    of, oc, _, _ = db.score(cli.scorer_params(cli.search_parameters(cfg)), batch)
+    assert oc[0] == 1 and r["matched_peaks"] == str(int(of[0, 0]["matched_peaks"])) == "22"
+    assert r["hyperscore"] == output.ryu_f64(of[0, 0]["hyperscore"]) and r["expmass"] == output.ryu_f32(of[0, 0]["expmass"])
+    assert r["precursor_ppm"] == output.ryu_f32(of[0, 0]["delta_mass"]) and r["poisson"] == output.ryu_f64(of[0, 0]["poisson"])
+    fh, frows = _read_tsv(os.path.join(out, "matched_fragments.sage.tsv"))
+    assert fh == output.FRAGMENT_HEADERS and len(frows) == 22 and all(x[0] == "1" for x in frows)
+    assert {x[1] for x in frows} <= {"b", "y"}
+
+
+@pytest.mark.gpu
+def test_cli_synthetic_two_files(tmp_path, gpu_required):
+    fasta = synthetic_fasta(80, seed=31)
+    fa = str(tmp_path / "db.fasta")
+    open(fa, "w").write(fasta)
+    dbj = {"enzyme": {"missed_cleavages": 1, "cleave_at": "KR", "restrict": "P"}, "static_mods": {"C": 57.0215}, "fasta": fa}
+    host = DatabaseParameters.from_json(dbj).build(fasta)
+    files = []
+    for k in range(2):
+        p = str(tmp_path / f"run{k}.mzML")
+        write_mzml(p, synthetic_spectra(host, 60, seed=40 + k))
+        files.append(p)
+    cfg = {"database": dbj, "precursor_tol": {"ppm": [-10, 10]}, "fragment_tol": {"ppm": [-10, 10]}, "report_psms": 2,
+           "mzml_paths": files}
+    cp = str(tmp_path / "c.json")
+    json.dump(cfg, open(cp, "w"))
+    out = str(tmp_path / "o")
+    cli.main([cp, "--output_directory", out])
+    hdr, rows = _read_tsv(os.path.join(out, "results.sage.tsv"))
+    assert len(rows) > 60 and [r[0] for r in rows] == [str(i + 1) for i in range(len(rows))]  # psm_id counts from 1
+    assert {r[hdr.index("filename")] for r in rows} == {"run0.mzML", "run1.mzML"}
+    # same spectra scored by the oracle: identical hyperscore column
+    sp = SpectrumProcessor(150, True, 0.0)
+    orc = oracle_lib.OracleDb.from_product(host)
+    want = []
+    for k, p in enumerate(files):
+        proc = [q for q in (sp.process(r) for r in read_mzml(p, k)) if len(q.masses) >= 15]
+        of, oc, _, _ = orc.score(cli.scorer_params(cli.search_parameters(cfg)), SpectrumBatch.from_spectra(proc))
+        want += [output.ryu_f64(of[i, r]["hyperscore"]) for i in range(len(proc)) for r in range(int(oc[i]))]
+    assert [r[hdr.index("hyperscore")] for r in rows] == want
