@@ -198,6 +198,33 @@ int sage_hip_batch_upload(SageScorer* scorer, const SageSpectrumBatch* batch, Sa
 void sage_hip_batch_free(SageDeviceBatch* batch);
 int sage_hip_score_resident(SageScorer* scorer, SageDeviceBatch* batch, SageFeature* out, uint32_t* out_count);
 
+/* Raw centroided MS2 spectra (spectrum.rs:81-106 RawSpectrum + precursors[0]), SoA — the input of
+ * SpectrumProcessor::process.  Same conventions as SageSpectrumBatch; mz ascending inside each spectrum. */
+typedef struct SageRawBatch {
+    uint32_t n_spectra;
+    const uint64_t* peak_off;          /* [n + 1] */
+    const float* mz;
+    const float* intensities;
+    const float* precursor_mz;         /* [n] */
+    const uint8_t* precursor_charge;   /* [n] 0 == None (then fragments are deisotoped up to z = 3, spectrum.rs:289-293) */
+    const float* isolation_lo;         /* [n] may be NULL */
+    const float* isolation_hi;
+    const float* scan_start_time;      /* [n] may be NULL */
+    const float* inverse_ion_mobility; /* [n] may be NULL */
+    const uint32_t* file_id;           /* [n] may be NULL */
+} SageRawBatch;
+
+/* SpectrumProcessor::new(take_top_n, deisotope, min_deisotope_mz).process() (spectrum.rs:279-412) for every spectrum of
+ * the batch ON THE DEVICE, leaving the ProcessedSpectrum arrays resident for sage_hip_score_resident: raw peaks in, PSMs
+ * out, no host round trip in between.  Spectra that keep fewer than `min_peaks` peaks are not searched (sage-cli
+ * runner.rs:313): they stay in the batch with zero peaks and yield no PSM.  out_npeaks (optional, [n]) receives the
+ * number of peaks each spectrum kept before that filter. */
+int sage_hip_batch_process_upload(SageScorer* scorer, const SageRawBatch* raw, uint64_t take_top_n, int deisotope,
+                                  float min_deisotope_mz, uint32_t min_peaks, SageDeviceBatch** out, uint32_t* out_npeaks);
+/* Copy a resident batch's ProcessedSpectrum arrays back (tests, writers).  peak_off: [n + 1]; masses / intensities need
+ * peak_off[n] entries — call once with masses == NULL to get peak_off first. */
+int sage_hip_batch_download(SageDeviceBatch* batch, uint64_t* peak_off, float* masses, float* intensities, float* tic);
+
 /* Scorer::initial_hits (scoring.rs:418-462) of every spectrum of a resident batch: the trimmed
  * preliminary list in the reference's heap-layout order.  packed[i*cap + j] =
  * matched<<48 | peptide<<16 | precursor_charge<<8 | (isotope_error+128); len[i] entries are valid. */

@@ -119,6 +119,22 @@ class SageFragments(C.Structure):
     ]
 
 
+class SageRawBatch(C.Structure):
+    _fields_ = [
+        ("n_spectra", C.c_uint32),
+        ("peak_off", c_u64_p),
+        ("mz", c_float_p),
+        ("intensities", c_float_p),
+        ("precursor_mz", c_float_p),
+        ("precursor_charge", c_u8_p),
+        ("isolation_lo", c_float_p),
+        ("isolation_hi", c_float_p),
+        ("scan_start_time", c_float_p),
+        ("inverse_ion_mobility", c_float_p),
+        ("file_id", c_u32_p),
+    ]
+
+
 class SageTiming(C.Structure):
     _fields_ = [
         ("prelim_ms", C.c_float),
@@ -193,6 +209,9 @@ def load():
         "sage_hip_score_batch": (C.c_int, [vp, C.POINTER(SageSpectrumBatch), vp, c_u32_p]),
         "sage_hip_batch_upload": (C.c_int, [vp, C.POINTER(SageSpectrumBatch), C.POINTER(vp)]),
         "sage_hip_batch_free": (None, [vp]),
+        "sage_hip_batch_process_upload": (C.c_int, [vp, C.POINTER(SageRawBatch), C.c_uint64, C.c_int, C.c_float, C.c_uint32,
+                                                    C.POINTER(vp), c_u32_p]),
+        "sage_hip_batch_download": (C.c_int, [vp, c_u64_p, c_float_p, c_float_p, c_float_p]),
         "sage_hip_score_resident": (C.c_int, [vp, vp, vp, c_u32_p]),
         "sage_hip_initial_hits": (C.c_int, [vp, vp, c_u64_p, C.c_uint32, c_u32_p, c_u64_p, c_u64_p]),
         "sage_hip_last_timing": (C.c_int, [vp, C.POINTER(SageTiming)]),
@@ -215,7 +234,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_hostdb_view", "sage_hip_hostdb_peptide_string", "sage_hip_hostdb_peptide_proteins",
     "sage_hip_hostdb_peptide_info", "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
-    "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_score_resident", "sage_hip_initial_hits",
+    "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
 ]
 

@@ -371,14 +371,67 @@ class ScorerParams:
         return p
 
 
+class RawBatch:
+    """SoA batch of RawSpectrum (SageRawBatch): centroided MS2 peaks + precursors[0]."""
+
+    def __init__(self, spectra: Sequence[RawSpectrum]):
+        n = len(spectra)
+        self.n = n
+        self.ids = [s.id for s in spectra]
+        self.peak_off = np.zeros(n + 1, dtype=np.uint64)
+        for i, s in enumerate(spectra):
+            self.peak_off[i + 1] = self.peak_off[i] + len(s.mz)
+        cat = lambda xs: np.ascontiguousarray(np.concatenate(xs), dtype=np.float32) if n else np.zeros(0, np.float32)
+        self.mz = cat([np.asarray(s.mz, np.float32) for s in spectra])
+        self.intensities = cat([np.asarray(s.intensity, np.float32) for s in spectra])
+        f32 = lambda xs: np.ascontiguousarray(xs, dtype=np.float32)
+        nan = float("nan")
+        self.precursor_mz = f32([s.precursor_mz for s in spectra])
+        self.precursor_charge = np.ascontiguousarray([s.precursor_charge or 0 for s in spectra], dtype=np.uint8)
+        self.isolation_lo = f32([s.isolation_window[0] if s.isolation_window else nan for s in spectra])
+        self.isolation_hi = f32([s.isolation_window[1] if s.isolation_window else nan for s in spectra])
+        self.scan_start_time = f32([s.scan_start_time for s in spectra])
+        self.inverse_ion_mobility = f32([nan if s.inverse_ion_mobility is None else s.inverse_ion_mobility for s in spectra])
+        self.file_id = np.ascontiguousarray([s.file_id for s in spectra], dtype=np.uint32)
+
+    def to_c(self):
+        b = L.SageRawBatch()
+        b.n_spectra = self.n
+        b.peak_off = L.as_ptr(self.peak_off, C.c_uint64)
+        b.mz = L.as_ptr(self.mz, C.c_float)
+        b.intensities = L.as_ptr(self.intensities, C.c_float)
+        b.precursor_mz = L.as_ptr(self.precursor_mz, C.c_float)
+        b.precursor_charge = L.as_ptr(self.precursor_charge, C.c_uint8)
+        b.isolation_lo = L.as_ptr(self.isolation_lo, C.c_float)
+        b.isolation_hi = L.as_ptr(self.isolation_hi, C.c_float)
+        b.scan_start_time = L.as_ptr(self.scan_start_time, C.c_float)
+        b.inverse_ion_mobility = L.as_ptr(self.inverse_ion_mobility, C.c_float)
+        b.file_id = L.as_ptr(self.file_id, C.c_uint32)
+        return b
+
+
 class DeviceBatch:
-    def __init__(self, scorer: "Scorer", batch: SpectrumBatch):
+    def __init__(self, scorer: "Scorer", batch: Optional[SpectrumBatch], handle=None, n: int = 0):
         lib = L.load()
-        self.n = batch.n
         self._keep = batch
+        if handle is not None:  # adopted (Scorer.process_upload)
+            self._h, self.n = handle, n
+            return
+        self.n = batch.n
         self._h = C.c_void_p()
         cb = batch.to_c()
         L.check(lib.sage_hip_batch_upload(scorer._h, C.byref(cb), C.byref(self._h)))
+
+    def download(self):
+        """(peak_off[n+1], masses, intensities, total_ion_current[n]) of the resident ProcessedSpectrum arrays."""
+        lib = L.load()
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        L.check(lib.sage_hip_batch_download(self._h, L.as_ptr(off, C.c_uint64), None, None, None))
+        total = int(off[-1])
+        m, it, tic = np.zeros(max(total, 1), np.float32), np.zeros(max(total, 1), np.float32), np.zeros(max(self.n, 1), np.float32)
+        L.check(lib.sage_hip_batch_download(self._h, L.as_ptr(off, C.c_uint64), L.as_ptr(m, C.c_float), L.as_ptr(it, C.c_float),
+                                            L.as_ptr(tic, C.c_float)))
+        return off, m[:total], it[:total], tic[:self.n]
 
     def close(self):
         if self._h:
@@ -405,6 +458,18 @@ class Scorer:
 
     def upload(self, batch: SpectrumBatch) -> DeviceBatch:
         return DeviceBatch(self, batch)
+
+    def process_upload(self, raw: "RawBatch", take_top_n: int = 150, deisotope: bool = True, min_deisotope_mz: float = 0.0,
+                       min_peaks: int = 15):
+        """SpectrumProcessor::process (spectrum.rs:279-412) + the min_peaks filter of runner.rs:313 on the device; the
+        processed batch stays resident.  Returns (DeviceBatch, peaks kept per spectrum before the filter)."""
+        lib = L.load()
+        h = C.c_void_p()
+        npk = np.zeros(max(raw.n, 1), dtype=np.uint32)
+        cb = raw.to_c()
+        L.check(lib.sage_hip_batch_process_upload(self._h, C.byref(cb), take_top_n, int(deisotope), min_deisotope_mz, min_peaks,
+                                                  C.byref(h), L.as_ptr(npk, C.c_uint32)))
+        return DeviceBatch(self, None, handle=h, n=raw.n), npk[:raw.n]
 
     def _alloc_out(self, n):
         """Output arrays in page-locked host memory (sage_hip_host_alloc), reused while the size is unchanged.

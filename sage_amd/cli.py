@@ -19,8 +19,8 @@ import time
 import numpy as np
 
 from . import output
-from .api import (DatabaseParameters, DeviceDatabase, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor, Tolerance,
-                  device_count)
+from .api import (DatabaseParameters, DeviceDatabase, RawBatch, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor,
+                  Tolerance, device_count)
 from .mzml import read_mzml
 
 
@@ -53,7 +53,7 @@ def scorer_params(sp: dict) -> ScorerParams:
                         annotate_matches=sp["annotate_matches"], score_type=sp["score_type"])
 
 
-def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print) -> dict:
+def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print, host_preprocess: bool = False) -> dict:
     if device_count() <= 0:
         raise SystemExit("sage_amd.cli: no HIP device visible — libsage_hip has no CPU fallback")
     sp = search_parameters(cfg)
@@ -75,27 +75,34 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     for file_id, path in enumerate(mzml_paths):
         t0 = time.time()
         raw = read_mzml(path, file_id=file_id, ms_level=2)
-        processed = [processor.process(r) for r in raw]
-        processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]  # runner.rs:313
         log(f"- file IO: {int((time.time() - t0) * 1000):8d} ms")
-        if not processed:
+        if not raw:
             continue
-        batch = SpectrumBatch.from_spectra(processed)
         t0 = time.time()
-        dbatch = scorer.upload(batch)
+        if host_preprocess:  # SpectrumProcessor::process on the host (C++), spectra below min_peaks dropped (runner.rs:313)
+            processed = [processor.process(r) for r in raw]
+            processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]
+            if not processed:
+                continue
+            ids = [p.id for p in processed]
+            dbatch = scorer.upload(SpectrumBatch.from_spectra(processed))
+        else:  # ... or on the device: raw peaks in, PSMs out; spectra below min_peaks stay in the batch with zero peaks
+            ids = [r.id for r in raw]
+            dbatch, _ = scorer.process_upload(RawBatch(raw), sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
+        n_batch = dbatch.n
         feats, counts = scorer.score_resident(dbatch)
         feats, counts = feats.copy(), counts.copy()
         dt = (time.time() - t0) * 1000.0
         search_ms += dt
-        n_searched += batch.n
-        log(f"- search:  {int(dt):8d} ms ({int(batch.n * 1000 / (dt + 1))} spectra/s)")  # runner.rs:327-330
+        n_searched += n_batch
+        log(f"- search:  {int(dt):8d} ms ({int(n_batch * 1000 / (dt + 1))} spectra/s)")  # runner.rs:327-330
         off = arr = None
         if sp["annotate_matches"]:
             off, arr = scorer.annotate(dbatch, feats, counts)
         name = os.path.basename(path)
-        for i in range(batch.n):
+        for i in range(n_batch):
             for r in range(int(counts[i])):
-                rows.append(output.feature_row(psm_id, feats[i, r], host, name, processed[i].id))
+                rows.append(output.feature_row(psm_id, feats[i, r], host, name, ids[i]))
                 if arr is not None:
                     s = i * params.report_psms + r
                     frag_rows += output.fragment_rows(psm_id, int(off[s]), int(off[s + 1]), arr)
@@ -123,6 +130,7 @@ def main(argv=None):
     ap.add_argument("-o", "--output_directory", help="where to place output files. Overrides the directory specified in the configuration file.")
     ap.add_argument("--annotate-matches", action="store_true", help="write matched fragments output file")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--host-preprocess", action="store_true", help="run SpectrumProcessor::process on the host instead of the device")
     args = ap.parse_args(argv)
     cfg = json.load(open(args.parameters))
     if args.fasta:
@@ -133,7 +141,7 @@ def main(argv=None):
     if not mzml:
         raise SystemExit("'mzml_paths' must be provided!")
     out = args.output_directory or cfg.get("output_directory") or os.getcwd()
-    summary = run(cfg, mzml, out, args.device)
+    summary = run(cfg, mzml, out, args.device, host_preprocess=args.host_preprocess)
     print(json.dumps(summary))
 
 

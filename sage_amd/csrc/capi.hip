@@ -377,25 +377,16 @@ void sage_hip_scorer_destroy(SageScorer* s) {
     delete s;
 }
 
-int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceBatch** out) {
-    if (!s || !b || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    if (b->n_spectra && (!b->peak_off || !b->precursor_mz || !b->precursor_charge || !b->total_ion_current))
-        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
-    HIP_TRY(hipSetDevice(s->db->device));
-    auto d = std::make_unique<SageDeviceBatch>();
-    d->device = s->db->device;
-    const uint32_t n = b->n_spectra;
-    d->n = n;
-    const uint64_t total = n ? b->peak_off[n] : 0;
-    uint32_t pcap = 1, zmax = 0;
+// precursor-side arrays, launch schedule, kernel variant and the view of a batch whose peak arrays are already on the device
+static int finish_batch(SageScorer* s, SageDeviceBatch* d, uint32_t n, const float* precursor_mz, const uint8_t* precursor_charge,
+                        const float* isolation_lo, const float* isolation_hi, const float* scan_start_time,
+                        const float* inverse_ion_mobility, const uint32_t* file_id, uint32_t pcap) {
+    uint32_t zmax = 0;
     bool any_unknown = false;
     for (uint32_t i = 0; i < n; i++) {
-        if (b->peak_off[i + 1] < b->peak_off[i]) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
-        pcap = std::max<uint32_t>(pcap, (uint32_t)(b->peak_off[i + 1] - b->peak_off[i]));
-        zmax = std::max<uint32_t>(zmax, b->precursor_charge[i]);
-        any_unknown = any_unknown || b->precursor_charge[i] == 0;
+        zmax = std::max<uint32_t>(zmax, precursor_charge[i]);
+        any_unknown = any_unknown || precursor_charge[i] == 0;
     }
-    if (total && (!b->masses || !b->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
     // largest fragment charge any spectrum of this batch can ask for (scoring.rs:239-247)
     uint32_t fzcap = 1;
     const SageScorerParams& p = s->params;
@@ -406,14 +397,14 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
         if (used) fzcap = std::max(fzcap, sagecore::max_fragment_charge(p.max_fragment_charge, z) - 1);
     }
     // schedule spectra by ascending neutral precursor mass: wavefronts resident together then read
-    // overlapping ranges of the peptide-major index and of the ion table (outputs keep input order)
+    // overlapping ranges of the index and of the ion table (outputs keep input order)
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; i++) order[i] = i;
     {
         std::vector<float> key(n);
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t z = b->precursor_charge[i] ? b->precursor_charge[i] : p.min_precursor_charge;
-            key[i] = (b->precursor_mz[i] - sagecore::PROTON) * (float)z;
+            const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
+            key[i] = (precursor_mz[i] - sagecore::PROTON) * (float)z;
         }
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
     }
@@ -424,14 +415,14 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
         double sum = 0.0;
         uint32_t cnt = 0;
         for (uint32_t i = 0; i < n; i += step, cnt++) {
-            const uint32_t z = b->precursor_charge[i] ? b->precursor_charge[i] : p.min_precursor_charge;
-            const float center = (b->precursor_mz[i] - sagecore::PROTON) * (float)z;
+            const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
+            const float center = (precursor_mz[i] - sagecore::PROTON) * (float)z;
             sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
             if (p.wide_window) {
                 float lo = -2.4f, hi = 2.4f;
-                if (b->isolation_lo && b->isolation_hi && b->isolation_lo[i] == b->isolation_lo[i] && b->isolation_hi[i] == b->isolation_hi[i]) {
-                    lo = b->isolation_lo[i];
-                    hi = b->isolation_hi[i];
+                if (isolation_lo && isolation_hi && isolation_lo[i] == isolation_lo[i] && isolation_hi[i] == isolation_hi[i]) {
+                    lo = isolation_lo[i];
+                    hi = isolation_hi[i];
                 }
                 tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
             }
@@ -444,19 +435,15 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
         if (const char* e = getenv("SAGE_HIP_NARROW")) d->view.probe = std::string(e) == "probe" ? 1u : std::string(e) == "stream" ? 0u : d->view.probe;
     }
     HIP_TRY(d->order.upload(order.data(), n));
-    HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));
-    HIP_TRY(d->masses.upload(b->masses, total));
-    HIP_TRY(d->intensities.upload(b->intensities, total));
-    HIP_TRY(d->precursor_mz.upload(b->precursor_mz, n));
-    HIP_TRY(d->charge.upload(b->precursor_charge, n));
-    HIP_TRY(d->tic.upload(b->total_ion_current, n));
-    if (b->isolation_lo && b->isolation_hi) {
-        HIP_TRY(d->iso_lo.upload(b->isolation_lo, n));
-        HIP_TRY(d->iso_hi.upload(b->isolation_hi, n));
+    HIP_TRY(d->precursor_mz.upload(precursor_mz, n));
+    HIP_TRY(d->charge.upload(precursor_charge, n));
+    if (isolation_lo && isolation_hi) {
+        HIP_TRY(d->iso_lo.upload(isolation_lo, n));
+        HIP_TRY(d->iso_hi.upload(isolation_hi, n));
     }
-    if (b->scan_start_time) HIP_TRY(d->rt.upload(b->scan_start_time, n));
-    if (b->inverse_ion_mobility) HIP_TRY(d->ims.upload(b->inverse_ion_mobility, n));
-    if (b->file_id) HIP_TRY(d->file_id.upload(b->file_id, n));
+    if (scan_start_time) HIP_TRY(d->rt.upload(scan_start_time, n));
+    if (inverse_ion_mobility) HIP_TRY(d->ims.upload(inverse_ion_mobility, n));
+    if (file_id) HIP_TRY(d->file_id.upload(file_id, n));
     DevBatchView& v = d->view;
     v.n = n;
     v.peak_off = d->peak_off.p;
@@ -473,7 +460,110 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
     v.order = d->order.p;
     v.pcap = pcap;
     v.fzcap = fzcap;
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceBatch** out) {
+    if (!s || !b || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (b->n_spectra && (!b->peak_off || !b->precursor_mz || !b->precursor_charge || !b->total_ion_current))
+        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
+    HIP_TRY(hipSetDevice(s->db->device));
+    auto d = std::make_unique<SageDeviceBatch>();
+    d->device = s->db->device;
+    const uint32_t n = b->n_spectra;
+    d->n = n;
+    const uint64_t total = n ? b->peak_off[n] : 0;
+    uint32_t pcap = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (b->peak_off[i + 1] < b->peak_off[i]) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
+        pcap = std::max<uint32_t>(pcap, (uint32_t)(b->peak_off[i + 1] - b->peak_off[i]));
+    }
+    if (total && (!b->masses || !b->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
+    HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));
+    HIP_TRY(d->masses.upload(b->masses, total));
+    HIP_TRY(d->intensities.upload(b->intensities, total));
+    HIP_TRY(d->tic.upload(b->total_ion_current, n));
+    int rc = finish_batch(s, d.get(), n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi,
+                          b->scan_start_time, b->inverse_ion_mobility, b->file_id, pcap);
+    if (rc != SAGE_HIP_OK) return rc;
     *out = d.release();
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64_t take_top_n, int deisotope,
+                                  float min_deisotope_mz, uint32_t min_peaks, SageDeviceBatch** out, uint32_t* out_npeaks) {
+    if (!s || !raw || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    const uint32_t n = raw->n_spectra;
+    if (n && (!raw->peak_off || !raw->precursor_mz || !raw->precursor_charge))
+        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
+    if (take_top_n == 0 || take_top_n > 0xFFFFu) return fail(SAGE_HIP_ERR_INVALID, "take_top_n must be in [1, 65535]");
+    HIP_TRY(hipSetDevice(s->db->device));
+    auto d = std::make_unique<SageDeviceBatch>();
+    d->device = s->db->device;
+    d->n = n;
+    const uint64_t total = n ? raw->peak_off[n] : 0;
+    uint32_t rcap = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (raw->peak_off[i + 1] < raw->peak_off[i]) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
+        rcap = std::max<uint32_t>(rcap, (uint32_t)(raw->peak_off[i + 1] - raw->peak_off[i]));
+    }
+    if (total && (!raw->mz || !raw->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
+    uint32_t rpow2 = 1;
+    while (rpow2 < rcap) rpow2 <<= 1;
+    const size_t lds = process_lds_bytes(rcap, rpow2);
+    if (lds > 160 * 1024)
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "a spectrum has more raw peaks than the LDS staging holds (" + std::to_string(rcap) +
+                                                  "): preprocess it with sage_hip_process_ms2");
+    HIP_TRY((hipError_t)process_kernel_prepare(160 * 1024));
+    const uint32_t stride = (uint32_t)std::min<uint64_t>(take_top_n, rcap);
+    DevBuf<uint64_t> raw_off;
+    DevBuf<float> raw_mz, raw_int, sm, si;
+    DevBuf<uint8_t> zbuf;
+    DevBuf<uint32_t> cnt;
+    HIP_TRY(raw_off.upload(raw->peak_off, n ? (size_t)n + 1 : 0));
+    HIP_TRY(raw_mz.upload(raw->mz, total));
+    HIP_TRY(raw_int.upload(raw->intensities, total));
+    HIP_TRY(zbuf.upload(raw->precursor_charge, n));
+    HIP_TRY(sm.alloc((size_t)n * stride));
+    HIP_TRY(si.alloc((size_t)n * stride));
+    HIP_TRY(cnt.alloc(n));
+    HIP_TRY(d->tic.alloc(n));
+    launch_process(n, raw_off.p, raw_mz.p, raw_int.p, zbuf.p, (uint32_t)take_top_n, deisotope != 0, min_deisotope_mz, rcap, rpow2,
+                   stride, sm.p, si.p, d->tic.p, cnt.p, s->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> counts(n);
+    HIP_TRY(hipMemcpyAsync(counts.data(), cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (out_npeaks) std::copy(counts.begin(), counts.end(), out_npeaks);
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    uint32_t pcap = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = counts[i] >= min_peaks ? counts[i] : 0;  // runner.rs:313: too few peaks -> not searched
+        off[i + 1] = off[i] + c;
+        pcap = std::max(pcap, c);
+    }
+    HIP_TRY(d->peak_off.upload(off.data(), n ? (size_t)n + 1 : 0));
+    HIP_TRY(d->masses.alloc(off[n]));
+    HIP_TRY(d->intensities.alloc(off[n]));
+    launch_compact(n, d->peak_off.p, stride, sm.p, si.p, d->masses.p, d->intensities.p, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    int rc = finish_batch(s, d.get(), n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi,
+                          raw->scan_start_time, raw->inverse_ion_mobility, raw->file_id, pcap);
+    if (rc != SAGE_HIP_OK) return rc;
+    *out = d.release();
+    return SAGE_HIP_OK;
+}
+
+int sage_hip_batch_download(SageDeviceBatch* b, uint64_t* peak_off, float* masses, float* intensities, float* tic) {
+    if (!b || !peak_off) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n) HIP_TRY(hipMemcpy(peak_off, b->peak_off.p, ((size_t)b->n + 1) * 8, hipMemcpyDeviceToHost));
+    else peak_off[0] = 0;
+    const uint64_t total = b->n ? peak_off[b->n] : 0;
+    if (masses && total) HIP_TRY(hipMemcpy(masses, b->masses.p, total * 4, hipMemcpyDeviceToHost));
+    if (intensities && total) HIP_TRY(hipMemcpy(intensities, b->intensities.p, total * 4, hipMemcpyDeviceToHost));
+    if (tic && b->n) HIP_TRY(hipMemcpy(tic, b->tic.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
     return SAGE_HIP_OK;
 }
 

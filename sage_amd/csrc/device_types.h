@@ -135,6 +135,14 @@ size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t ma
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 uint32_t queries_per_spectrum(const DevScorer& sc);
+// process.hip
+size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
+int process_kernel_prepare(size_t max_lds_bytes);
+void launch_process(uint32_t n, const uint64_t* raw_off, const float* raw_mz, const float* raw_int, const uint8_t* charge,
+                    uint32_t take_top_n, bool deisotope, float min_deisotope_mz, uint32_t rcap, uint32_t rpow2, uint32_t stride,
+                    float* out_mass, float* out_int, float* out_tic, uint32_t* out_count, void* stream);
+void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const float* sm, const float* si, float* masses,
+                    float* intens, void* stream);
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream);

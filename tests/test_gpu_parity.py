@@ -5,7 +5,7 @@ import pytest
 import oracle_lib
 from parity_utils import assert_features_equal, assert_initial_hits_equal
 from sage_amd import _lib as L
-from sage_amd.api import (DatabaseParameters, DeviceDatabase, RawSpectrum, Scorer, ScorerParams, SpectrumBatch,
+from sage_amd.api import (DatabaseParameters, DeviceDatabase, RawBatch, RawSpectrum, Scorer, ScorerParams, SpectrumBatch,
                           SpectrumProcessor, Tolerance)
 from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
 from test_oracle_golden import c1_batch, integration_scorer
@@ -231,6 +231,61 @@ def test_quick_score_prefilter(small_world, low_memory):
         ok = small_world.orc.quick_score(params, batch, low_memory)
         np.testing.assert_array_equal(gk, ok, err_msg=f"quick_score low_memory={low_memory} {ctx}")
         assert gk.sum() > 10
+
+
+def _raw_edge_cases(world, rng):
+    """Raw spectra that stress SpectrumProcessor::process: isotope envelopes at charges 1-3, duplicated peaks, equal
+    intensities, fewer peaks than take_top_n, a single peak, an empty spectrum, unknown precursor charge."""
+    raws = synthetic_spectra(world.host, 40, seed=77)
+    out = list(raws)
+    for k, r in enumerate(raws[:12]):
+        mz, it = [r.mz], [r.intensity]
+        for z in (1, 2, 3):  # C13 satellites below the monoisotopic intensity, plus one ABOVE it (not merged)
+            pick = rng.choice(len(r.mz), 12, replace=False)
+            mz.append((r.mz[pick] + np.float32(1.00335 / z)).astype(np.float32))
+            it.append((r.intensity[pick] * np.float32(0.6 if k % 2 else 1.4)).astype(np.float32))
+        mz, it = np.concatenate(mz), np.concatenate(it)
+        if k % 3 == 0:  # exact duplicates of (m/z, intensity) and ties in intensity
+            mz, it = np.concatenate([mz, mz[:20]]), np.concatenate([it, it[:20]])
+            it[30:60] = it[30]
+        o = np.argsort(mz, kind="stable")
+        out.append(RawSpectrum(mz[o], it[o], r.precursor_mz, None if k % 4 == 0 else r.precursor_charge, r.isolation_window,
+                               r.scan_start_time, None, 0, f"edge={k}"))
+    out.append(RawSpectrum(raws[0].mz[:7], raws[0].intensity[:7], 500.0, 2, None, 0.0, None, 0, "few"))
+    out.append(RawSpectrum(np.array([300.5], np.float32), np.array([10.0], np.float32), 500.0, 2, None, 0.0, None, 0, "one"))
+    out.append(RawSpectrum(np.zeros(0, np.float32), np.zeros(0, np.float32), 500.0, 2, None, 0.0, None, 0, "empty"))
+    return out
+
+
+@pytest.mark.parametrize("deisotope,top_n", [(True, 150), (True, 40), (False, 150), (False, 25)])
+def test_device_spectrum_processing(small_world, deisotope, top_n):
+    """SpectrumProcessor::process on the device (spectrum.rs:179-227, 279-412) against the CPU oracle: masses,
+    intensities and total ion current bit-exact, then the same PSMs from the resident processed batch."""
+    raws = _raw_edge_cases(small_world, np.random.default_rng(5))
+    scorer = Scorer(small_world.dev, ScorerParams())
+    dbatch, npk = scorer.process_upload(RawBatch(raws), take_top_n=top_n, deisotope=deisotope, min_deisotope_mz=0.0, min_peaks=0)
+    off, m, it, tic = dbatch.download()
+    for i, r in enumerate(raws):
+        om, oi, otic = oracle_lib.process_ms2(top_n, deisotope, 0.0, r.mz, r.intensity, r.precursor_charge)
+        a, b = int(off[i]), int(off[i + 1])
+        assert b - a == len(om) == npk[i], f"spectrum {r.id}: {b - a} peaks vs oracle {len(om)}"
+        np.testing.assert_array_equal(m[a:b], om, err_msg=f"masses of {r.id}")
+        np.testing.assert_array_equal(it[a:b], oi, err_msg=f"intensities of {r.id}")
+        assert np.float32(tic[i]) == np.float32(otic), f"TIC of {r.id}"
+    # scoring the device-processed batch == scoring the host-processed spectra (min_peaks filter of runner.rs:313)
+    dbatch2, _ = scorer.process_upload(RawBatch(raws), take_top_n=top_n, deisotope=deisotope, min_peaks=15)
+    gf, gc = scorer.score_resident(dbatch2)
+    gf, gc = gf.copy(), gc.copy()
+    sp = SpectrumProcessor(top_n, deisotope, 0.0)
+    proc = [sp.process(r) for r in raws]
+    keep = [i for i, p_ in enumerate(proc) if len(p_.masses) >= 15]
+    hb = SpectrumBatch.from_spectra([proc[i] for i in keep])
+    of, oc, _, _ = small_world.orc.score(ScorerParams(), hb)
+    assert gc.sum() == oc.sum() and all(gc[i] == 0 for i in range(len(raws)) if i not in keep)
+    sub_f, sub_c = gf[keep], gc[keep]
+    sub_f = sub_f.copy()
+    sub_f["spec_index"] = np.where(np.arange(sub_f.shape[1])[None, :] < sub_c[:, None], np.arange(len(keep))[:, None], sub_f["spec_index"])
+    assert_features_equal(sub_f, sub_c, of, oc, "device-processed batch")
 
 
 def test_error_paths(small_world):
