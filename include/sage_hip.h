@@ -79,6 +79,8 @@ typedef struct SageDbParams {
     uint64_t max_variable_mods;
     const char* decoy_tag;
     int32_t generate_decoys;
+    int32_t peptides_only;     /* 1 => stop after reorder_peptides (database.rs:221-258): no fragments / min_value; the index is
+                                  then generated on the device by sage_hip_db_create (build_from_peptides, :265-346) */
 } SageDbParams;
 
 /* Flat, read-only view of an IndexedDatabase (database.rs:384-395) + the Peptide fields the path
@@ -100,6 +102,7 @@ typedef struct SageDbView {
     uint64_t n_peptides;
     const uint8_t* ion_kinds;
     uint32_t n_ion_kinds;
+    uint64_t min_ion_index;           /* read only when fragments == NULL (device-side build_from_peptides) */
 } SageDbView;
 
 typedef struct SageHostDb SageHostDb;
@@ -132,7 +135,9 @@ typedef struct SageDeviceBatch SageDeviceBatch;
 int sage_hip_device_count(void);
 
 /* Upload an IndexedDatabase to HBM on `device` and derive the device layouts.
- * Stands in for the `&'db IndexedDatabase` borrow of Scorer (scoring.rs:211). */
+ * Stands in for the `&'db IndexedDatabase` borrow of Scorer (scoring.rs:211).
+ * With view->fragments == NULL the fragment index is generated ON THE DEVICE from the peptide list
+ * (Parameters::build_from_peptides, database.rs:265-346: ion series, stored-ion filter by view->min_ion_index, sort). */
 int sage_hip_db_create(const SageDbView* view, int device, SageDeviceDb** out);
 void sage_hip_db_destroy(SageDeviceDb* db);
 uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db);

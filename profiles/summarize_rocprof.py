@@ -47,8 +47,8 @@ def main():
     for k, v in traffic.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-            # bench.py's prelim_ms spans all three preliminary kernels (narrow / mid-window / open-search)
-            key = "prelim" if k.startswith("prelim_") else ("rescore" if k.startswith("rescore") else None)
+            # bench.py's prelim_ms spans all preliminary kernels (narrow + the tiled count / replay / assemble pipeline)
+            key = "prelim" if (k.startswith("prelim_") or k.startswith("tile_")) else ("rescore" if k.startswith("rescore") else None)
             if key:
                 tj[key + "_bytes_per_launch"] = tj.get(key + "_bytes_per_launch", 0.0) + b
                 tj.setdefault(key + "_raw", {})[k] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}

@@ -46,6 +46,7 @@ class SageDbParams(C.Structure):
         ("max_variable_mods", C.c_uint64),
         ("decoy_tag", C.c_char_p),
         ("generate_decoys", C.c_int32),
+        ("peptides_only", C.c_int32),
     ]
 
 
@@ -67,6 +68,7 @@ class SageDbView(C.Structure):
         ("n_peptides", C.c_uint64),
         ("ion_kinds", c_u8_p),
         ("n_ion_kinds", C.c_uint32),
+        ("min_ion_index", C.c_uint64),
     ]
 
 

@@ -182,24 +182,9 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     HIP_TRY(hipSetDevice(device));
     auto d = std::make_unique<SageDeviceDb>();
     d->device = device;
-    const uint64_t np = v->n_peptides, nf = v->n_fragments;
+    const uint64_t np = v->n_peptides;
     const uint32_t nk = v->n_ion_kinds;
 
-    // group IndexedDatabase.fragments by peptide (counting sort): tiles are runs of 2^tile_shift consecutive peptides
-    std::vector<uint64_t> pm_off(np + 1, 0);
-    for (uint64_t i = 0; i < nf; i++) {
-        if (v->fragments[i].peptide_index >= np) return fail(SAGE_HIP_ERR_INVALID, "fragment peptide_index out of range");
-        pm_off[v->fragments[i].peptide_index + 1]++;
-    }
-    for (uint64_t i = 0; i < np; i++) pm_off[i + 1] += pm_off[i];
-    std::vector<SageTheoretical> tm(nf + 2, SageTheoretical{0xFFFFFFFFu, 0.0f});
-    {
-        std::vector<uint64_t> cur(pm_off.begin(), pm_off.end() - 1);
-        for (uint64_t i = 0; i < nf; i++) tm[cur[v->fragments[i].peptide_index]++] = v->fragments[i];
-    }
-    HIP_TRY(d->pm_frag.upload(tm.data(), nf));  // (before the tiles are re-sorted by m/z below)
-    HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
-    d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
     // complete ion table for rescoring (IonSeries for every configured kind, ion_series.rs:36-85)
     std::vector<uint64_t> ion_off(np + 1, 0);
     std::vector<uint32_t> info(np);
@@ -212,61 +197,124 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         max_ions = std::max<uint32_t>(max_ions, (uint32_t)cnt);
         info[i] = (uint32_t)len | ((uint32_t)(v->decoy[i] ? 1 : 0) << 16) | ((uint32_t)v->missed_cleavages[i] << 24);
     }
-    std::vector<float> ions(ion_off[np]);
-    parallel_for(np, 4096, [&](size_t ib, size_t ie, unsigned) {
-        for (size_t i = ib; i < ie; i++) {
-            const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
-            const uint64_t lm1 = len ? len - 1 : 0;
-            for (uint32_t k = 0; k < nk; k++)
-                ion_series_flat(v->seq + v->seq_off[i], v->mods + v->seq_off[i], len, v->nterm[i], v->pep_mono[i],
-                                v->ion_kinds[k], ions.data() + ion_off[i] + (uint64_t)k * lm1);
-        }
-    });
-    // tile-major copy for large precursor windows: tile = peptide_index >> tile_shift, (m/z, peptide) order inside a
-    // tile, and a per-tile position table tm_lut[t][c] = first position of tile t with m/z >= c / lut_scale.
-    if (nf >= 0xFFFFFFF0ull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-16 fragments");
     uint32_t tile_shift = 15;
     if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(16, std::max(11, atoi(e)));
     const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
-    std::vector<uint64_t> tile_off(n_tiles + 1, 0);
-    for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
-    parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
-        for (size_t t = tb; t < te; t++)
-            std::sort(tm.begin() + tile_off[t], tm.begin() + tile_off[t + 1], [](const SageTheoretical& x, const SageTheoretical& y) {
-                const int32_t kx = sagecore::order_key(x.fragment_mz), ky = sagecore::order_key(y.fragment_mz);
-                return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
-            });
-    });
     // 1/256 Da cells.  The scale is a power of two, so `m/z * scale` is exact in f32 and a fragment-tolerance window
     // [lo, hi] maps to the cell range [floor(lo*scale), floor(hi*scale)] with no safety margin.
     const float lut_scale = 256.0f;
-    float max_mz = 0.0f;
-    for (uint64_t i = 0; i < nf; i++)
-        if (tm[i].fragment_mz > max_mz && std::isfinite(tm[i].fragment_mz)) max_mz = tm[i].fragment_mz;
-    const uint32_t lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
-    if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
-    std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
-    parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
-        for (size_t t = tb; t < te; t++) {
-            uint64_t pos = tile_off[t];
-            const uint64_t tend = tile_off[t + 1];
-            uint32_t* row = lut.data() + t * lut_stride;
-            for (uint32_t c = 0; c < lut_stride; c++) {
-                const double edge = (double)c / (double)lut_scale;
-                // NaN and m/z beyond the table (non-finite or > 250 kDa) compare false and stay in the last cell's run
-                while (pos < tend && (double)tm[pos].fragment_mz < edge) pos++;
-                row[c] = (uint32_t)pos;
-            }
-            row[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
-            row[lut_stride - 1] = (uint32_t)tend;
+    uint32_t lut_stride = 0;
+    uint64_t nf = v->n_fragments;
+    d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
+    if (!v->fragments) {
+        // ---- Parameters::build_from_peptides (database.rs:265-346) on the device: index_build.hip ----
+        std::vector<uint64_t> pm_off(np + 1, 0);
+        for (uint64_t i = 0; i < np; i++) {
+            const uint64_t len = v->seq_off[i + 1] - v->seq_off[i], lm1 = len ? len - 1 : 0;
+            pm_off[i + 1] = pm_off[i] + (lm1 > v->min_ion_index ? lm1 - v->min_ion_index : 0) * nk;  // database.rs:281-292
         }
-    });
-    HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));
-    HIP_TRY(d->tm_lut.upload(lut.data(), lut.size()));
-    HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
-    HIP_TRY(d->ions.upload(ions.data(), ions.size()));
-    HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
-    HIP_TRY(d->pep_info.upload(info.data(), np));
+        nf = pm_off[np];
+        if (nf >= 0xFFFFFFF0ull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-16 fragments");
+        std::vector<uint64_t> tile_off(n_tiles + 1, 0);
+        for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
+        const uint64_t total_res = np ? v->seq_off[np] : 0;
+        DevBuf<uint64_t> d_seq_off, d_tile_off;
+        DevBuf<uint8_t> d_seq, d_kinds;
+        DevBuf<float> d_mods, d_nterm;
+        HIP_TRY(d_seq_off.upload(v->seq_off, np + 1));
+        HIP_TRY(d_seq.upload(v->seq, total_res));
+        HIP_TRY(d_mods.upload(v->mods, total_res));
+        HIP_TRY(d_nterm.upload(v->nterm, np));
+        HIP_TRY(d_kinds.upload(v->ion_kinds, nk));
+        HIP_TRY(d_tile_off.upload(tile_off.data(), n_tiles + 1));
+        HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
+        HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
+        HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
+        HIP_TRY(d->ions.alloc(ion_off[np]));
+        HIP_TRY(d->pm_frag.alloc(nf));
+        HIP_TRY(d->tm_frag.alloc(nf + 2));
+        uint32_t* lut_p = nullptr;
+        const hipError_t be = (hipError_t)build_index_on_device(np, nk, d_kinds.p, d_seq_off.p, d_seq.p, d_mods.p, d_nterm.p,
+                                                                d->pep_mono.p, v->min_ion_index, d->ion_off.p, d->pm_off.p, nf, tile_shift,
+                                                                (uint32_t)n_tiles, d_tile_off.p, lut_scale, d->ions.p, d->pm_frag.p,
+                                                                d->tm_frag.p, &lut_p, &lut_stride, nullptr);
+        if (be != hipSuccess)
+            return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
+        d->tm_lut.p = lut_p;
+        d->tm_lut.n = (size_t)n_tiles * lut_stride;
+        HIP_TRY(d->pep_info.upload(info.data(), np));
+    } else {
+        // group IndexedDatabase.fragments by peptide (counting sort): tiles are runs of 2^tile_shift consecutive peptides
+        std::vector<uint64_t> pm_off(np + 1, 0);
+        for (uint64_t i = 0; i < nf; i++) {
+            if (v->fragments[i].peptide_index >= np) return fail(SAGE_HIP_ERR_INVALID, "fragment peptide_index out of range");
+            pm_off[v->fragments[i].peptide_index + 1]++;
+        }
+        for (uint64_t i = 0; i < np; i++) pm_off[i + 1] += pm_off[i];
+        std::vector<SageTheoretical> tm(nf + 2, SageTheoretical{0xFFFFFFFFu, 0.0f});
+        {
+            std::vector<uint64_t> cur(pm_off.begin(), pm_off.end() - 1);
+            for (uint64_t i = 0; i < nf; i++) tm[cur[v->fragments[i].peptide_index]++] = v->fragments[i];
+        }
+        HIP_TRY(d->pm_frag.upload(tm.data(), nf));  // (before the tiles are re-sorted by m/z below)
+        HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
+        d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
+        std::vector<float> ions(ion_off[np]);
+        parallel_for(np, 4096, [&](size_t ib, size_t ie, unsigned) {
+            for (size_t i = ib; i < ie; i++) {
+                const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
+                const uint64_t lm1 = len ? len - 1 : 0;
+                for (uint32_t k = 0; k < nk; k++)
+                    ion_series_flat(v->seq + v->seq_off[i], v->mods + v->seq_off[i], len, v->nterm[i], v->pep_mono[i],
+                                    v->ion_kinds[k], ions.data() + ion_off[i] + (uint64_t)k * lm1);
+            }
+        });
+        // tile-major copy for large precursor windows: tile = peptide_index >> tile_shift, (m/z, peptide) order inside a
+        // tile, and a per-tile position table tm_lut[t][c] = first position of tile t with m/z >= c / lut_scale.
+        if (nf >= 0xFFFFFFF0ull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-16 fragments");
+        uint32_t tile_shift = 15;
+        if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(16, std::max(11, atoi(e)));
+        const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
+        std::vector<uint64_t> tile_off(n_tiles + 1, 0);
+        for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
+        parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
+            for (size_t t = tb; t < te; t++)
+                std::sort(tm.begin() + tile_off[t], tm.begin() + tile_off[t + 1], [](const SageTheoretical& x, const SageTheoretical& y) {
+                    const int32_t kx = sagecore::order_key(x.fragment_mz), ky = sagecore::order_key(y.fragment_mz);
+                    return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
+                });
+        });
+        // 1/256 Da cells.  The scale is a power of two, so `m/z * scale` is exact in f32 and a fragment-tolerance window
+        // [lo, hi] maps to the cell range [floor(lo*scale), floor(hi*scale)] with no safety margin.
+        const float lut_scale = 256.0f;
+        float max_mz = 0.0f;
+        for (uint64_t i = 0; i < nf; i++)
+            if (tm[i].fragment_mz > max_mz && std::isfinite(tm[i].fragment_mz)) max_mz = tm[i].fragment_mz;
+        const uint32_t lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
+        if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
+        std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
+        parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
+            for (size_t t = tb; t < te; t++) {
+                uint64_t pos = tile_off[t];
+                const uint64_t tend = tile_off[t + 1];
+                uint32_t* row = lut.data() + t * lut_stride;
+                for (uint32_t c = 0; c < lut_stride; c++) {
+                    const double edge = (double)c / (double)lut_scale;
+                    // NaN and m/z beyond the table (non-finite or > 250 kDa) compare false and stay in the last cell's run
+                    while (pos < tend && (double)tm[pos].fragment_mz < edge) pos++;
+                    row[c] = (uint32_t)pos;
+                }
+                row[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
+                row[lut_stride - 1] = (uint32_t)tend;
+            }
+        });
+        HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));
+        HIP_TRY(d->tm_lut.upload(lut.data(), lut.size()));
+        HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
+        HIP_TRY(d->ions.upload(ions.data(), ions.size()));
+        HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
+        HIP_TRY(d->pep_info.upload(info.data(), np));
+    }
     d->max_ions = max_ions;
     d->view.pep_mono = d->pep_mono.p;
     d->view.np = (uint32_t)np;

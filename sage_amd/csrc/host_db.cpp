@@ -435,6 +435,7 @@ DbBuildConfig config_from_params(const SageDbParams& p) {  // Builder::make_para
     c.max_variable_mods = std::max<uint64_t>(p.max_variable_mods, 1);
     c.decoy_tag = p.decoy_tag ? p.decoy_tag : "rev_";
     c.generate_decoys = p.generate_decoys != 0;
+    c.peptides_only = p.peptides_only != 0;
     return c;
 }
 
@@ -466,6 +467,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
     db.ion_kinds = cfg.ion_kinds;
     db.decoy_tag = cfg.decoy_tag;
     db.generate_decoys = cfg.generate_decoys;
+    db.min_ion_index = cfg.min_ion_index;
 
     std::vector<std::string> prot_seqs;
     parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, db.protein_names, prot_seqs);
@@ -636,6 +638,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
       }
     });
     std::vector<Pep>().swap(uniq);
+    if (cfg.peptides_only) return db;  // the device builds the fragment index (index_build.hip)
 
     // 6. theoretical fragments (database.rs:272-297)
     const size_t nk = cfg.ion_kinds.size();
@@ -715,6 +718,8 @@ SageDbView HostDb::view() const {
     v.n_peptides = pep_mono.size();
     v.ion_kinds = ion_kinds.data();
     v.n_ion_kinds = (uint32_t)ion_kinds.size();
+    v.min_ion_index = min_ion_index;
+    if (fragments.empty()) v.fragments = nullptr;
     return v;
 }
 

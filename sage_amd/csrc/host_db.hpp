@@ -34,6 +34,7 @@ struct DbBuildConfig {  // database.rs:122-139 after Builder::make_parameters (:
     size_t max_variable_mods = 2;
     std::string decoy_tag = "rev_";
     bool generate_decoys = true;
+    bool peptides_only = false;  // stop after reorder_peptides: the device generates the fragment index
 };
 DbBuildConfig config_from_params(const SageDbParams& p);
 
@@ -54,6 +55,7 @@ struct HostDb {
     std::vector<uint32_t> pep_protein_ids;
     std::string decoy_tag;
     bool generate_decoys = true;
+    uint64_t min_ion_index = 2;
 
     uint64_t n_peptides() const { return pep_mono.size(); }
     SageDbView view() const;

@@ -1,0 +1,201 @@
+// index_build.hip — Parameters::build_from_peptides (database.rs:265-346) on the device.
+//
+// Given the mass-sorted, deduplicated peptide list (the string-heavy part of the build — digestion, modification,
+// decoys, reorder_peptides — stays on the host), everything the search kernels read is generated in HBM:
+//   * the complete ion table (IonSeries of every peptide and configured kind, ion_series.rs:36-85, same f32 running sum);
+//   * the peptide-major fragment list: the entries the reference stores (b3.., y..3 under the default min_ion_index,
+//     database.rs:281-292), grouped by peptide;
+//   * the tile-major list: the same entries ordered by (tile, m/z, peptide) with ONE radix sort of 64-bit keys — the key
+//     is `tile | f32 order key | peptide-in-tile`, 32 - s + 32 + s bits, so the sorted keys ARE the entries;
+//   * the per-tile position table (one binary search per cell).
+// The reference's global m/z sort + bucketing (database.rs:301-346) is never materialised: the device layouts hold the
+// same set of (peptide, m/z) entries, which is all the matching predicate sees.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device_types.h"
+
+using namespace sagecore;
+
+namespace sagehip {
+
+namespace {
+
+// mass.rs:64-68 (A..Z); zeros for B, J, X, Z
+__constant__ float kResidueDev[26] = {71.03711f,  0.0f,       103.00919f, 115.02694f, 129.04259f, 147.0684f,  57.02146f,
+                                      137.05891f, 113.08406f, 0.0f,       128.09496f, 113.08406f, 131.0405f,  114.04293f,
+                                      237.14774f, 97.05276f,  128.05858f, 156.1011f,  87.03203f,  101.04768f, 150.95363f,
+                                      99.06841f,  186.07932f, 0.0f,       163.06332f, 0.0f};
+
+// one thread per (peptide, ion kind): IonSeries::new(peptide, kind) (ion_series.rs:36-85) into the ion table, and the
+// stored subset (database.rs:281-292) into the peptide-major fragment list
+__global__ __launch_bounds__(256) void ion_kernel(uint64_t np, uint32_t nk, const uint8_t* __restrict__ kinds,
+                                                  const uint64_t* __restrict__ seq_off, const uint8_t* __restrict__ seq,
+                                                  const float* __restrict__ mods, const float* __restrict__ nterm,
+                                                  const float* __restrict__ mono, uint64_t min_ion_index,
+                                                  const uint64_t* __restrict__ ion_off, const uint64_t* __restrict__ pm_off,
+                                                  float* __restrict__ ions, SageTheoretical* __restrict__ pm_frag) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= np * nk) return;
+    const uint64_t p = gid / nk;
+    const uint32_t k = (uint32_t)(gid - p * nk);
+    const uint8_t kind = kinds[k];
+    const uint64_t s0 = seq_off[p];
+    const uint64_t len = seq_off[p + 1] - s0, lm1 = len ? len - 1 : 0;
+    const float C = 12.0f, O = 15.994914f, H = 1.007825f, PRO = 1.0072764f, N = 14.003074f;
+    const float NH3 = N + H * 2.0f + PRO;
+    const float ntv = nterm[p];
+    const float nt = ntv == ntv ? ntv : 0.0f;  // NaN == None
+    const float m = mono[p];
+    float cum;
+    switch (kind) {
+        case SAGE_ION_A: cum = nt - (C + O); break;
+        case SAGE_ION_B: cum = nt; break;
+        case SAGE_ION_C: cum = nt + NH3; break;
+        case SAGE_ION_X: cum = m - nt + (C + O - NH3 + N + H); break;
+        case SAGE_ION_Y: cum = m - nt; break;
+        default: cum = m - nt - NH3; break;
+    }
+    const bool forward = kind <= SAGE_ION_C;
+    const uint64_t kept = lm1 > min_ion_index ? lm1 - min_ion_index : 0;
+    float* out = ions + ion_off[p] + (uint64_t)k * lm1;
+    SageTheoretical* fr = pm_frag + pm_off[p] + (uint64_t)k * kept;
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < lm1; i++) {
+        const uint8_t aa = seq[s0 + i];
+        const float r = (aa >= 'A' && aa <= 'Z') ? kResidueDev[aa - 'A'] : 0.0f;
+        const float step = r + mods[s0 + i];
+        cum += forward ? step : -step;
+        out[i] = cum;
+        const bool keep = forward ? (i + 1) > min_ion_index : (lm1 - i) > min_ion_index;
+        if (keep) fr[w++] = SageTheoretical{(uint32_t)p, cum};
+    }
+}
+
+__global__ __launch_bounds__(256) void encode_kernel(uint64_t nf, uint32_t tile_shift, const SageTheoretical* __restrict__ pm,
+                                                     uint64_t* __restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const SageTheoretical e = pm[i];
+    const uint32_t mzkey = (uint32_t)order_key(e.fragment_mz) ^ 0x80000000u;  // unsigned order == f32::total_cmp
+    const uint64_t tile = e.peptide_index >> tile_shift, low = e.peptide_index & ((1u << tile_shift) - 1u);
+    keys[i] = (tile << (32 + tile_shift)) | ((uint64_t)mzkey << tile_shift) | low;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(uint64_t nf, uint32_t tile_shift, const uint64_t* __restrict__ keys,
+                                                     SageTheoretical* __restrict__ tm) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf + 2) return;
+    if (i >= nf) {  // padding read (never matched) by the 16-byte loads of the search kernels
+        tm[i] = SageTheoretical{0xFFFFFFFFu, 0.0f};
+        return;
+    }
+    const uint64_t k = keys[i];
+    const uint32_t pep = (uint32_t)((k >> (32 + tile_shift)) << tile_shift) | (uint32_t)(k & ((1u << tile_shift) - 1u));
+    int32_t o = (int32_t)((uint32_t)(k >> tile_shift) ^ 0x80000000u);
+    o ^= (int32_t)(((uint32_t)(o >> 31)) >> 1);  // inverse of order_key
+    tm[i] = SageTheoretical{pep, __int_as_float(o)};
+}
+
+// tm_lut[t][c] = first position of tile t whose m/z is >= c / scale (row[0] = tile start, row[last] = tile end)
+__global__ __launch_bounds__(256) void lut_kernel(uint32_t n_tiles, uint32_t lut_stride, float lut_scale,
+                                                  const uint64_t* __restrict__ tile_off, const SageTheoretical* __restrict__ tm,
+                                                  uint32_t* __restrict__ lut) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_tiles * lut_stride) return;
+    const uint32_t t = (uint32_t)(gid / lut_stride), c = (uint32_t)(gid - (uint64_t)t * lut_stride);
+    uint64_t lo = tile_off[t], hi = tile_off[t + 1];
+    if (c == 0) { lut[gid] = (uint32_t)lo; return; }
+    if (c == lut_stride - 1) { lut[gid] = (uint32_t)hi; return; }
+    const double edge = (double)c / (double)lut_scale;
+    while (lo < hi) {  // partition_point(m/z < edge); NaN compares false and stays at the end
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((double)tm[mid].fragment_mz < edge) lo = mid + 1; else hi = mid;
+    }
+    lut[gid] = (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheoretical* __restrict__ pm, uint32_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.0f;
+    if (i < nf) {
+        const float m = pm[i].fragment_mz;
+        if (m == m && m < 3.0e38f && m > 0.0f) v = m;
+    }
+    // positive floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63u) == 0 && v > 0.0f) atomicMax(out, __float_as_uint(v));
+}
+
+}  // namespace
+
+#define BUILD_TRY(expr)                  \
+    do {                                 \
+        hipError_t _e = (expr);          \
+        if (_e != hipSuccess) return _e; \
+    } while (0)
+
+// Returns a hipError_t.  All pointers are device pointers; ions / pm_frag / tm_frag are allocated by the caller, tm_lut by this
+// function (its size depends on the largest fragment m/z).
+int build_index_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,
+                          const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
+                          const uint64_t* d_ion_off, const uint64_t* d_pm_off, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
+                          const uint64_t* d_tile_off, float lut_scale, float* d_ions, SageTheoretical* d_pm_frag,
+                          SageTheoretical* d_tm_frag, uint32_t** d_lut_out, uint32_t* lut_stride_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint64_t nthreads = np * nk;
+    if (nthreads) hipLaunchKernelGGL(ion_kernel, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, stream, np, nk, d_kinds,
+                                     d_seq_off, d_seq, d_mods, d_nterm, d_mono, min_ion_index, d_ion_off, d_pm_off, d_ions, d_pm_frag);
+    BUILD_TRY(hipGetLastError());
+    // largest finite fragment m/z -> table width
+    uint32_t* d_max = nullptr;
+    BUILD_TRY(hipMalloc((void**)&d_max, 4));
+    BUILD_TRY(hipMemsetAsync(d_max, 0, 4, stream));
+    if (nf) hipLaunchKernelGGL(maxmz_kernel, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, stream, nf, d_pm_frag, d_max);
+    uint32_t max_bits = 0;
+    BUILD_TRY(hipMemcpyAsync(&max_bits, d_max, 4, hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(d_max);
+    float max_mz;
+    memcpy(&max_mz, &max_bits, 4);
+    const double cells = ceil((double)max_mz * lut_scale) + 3.0;
+    const uint32_t lut_stride = (uint32_t)(cells < 64.0e6 ? cells : 64.0e6);
+    if ((double)n_tiles * lut_stride > 4.0e9) return (int)hipErrorInvalidValue;
+    // (tile, m/z, peptide) order: one radix sort of 64-bit keys
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    BUILD_TRY(hipMalloc((void**)&k_in, (nf ? nf : 1) * 8));
+    BUILD_TRY(hipMalloc((void**)&k_out, (nf ? nf : 1) * 8));
+    if (nf) {
+        hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, stream, nf, tile_shift, d_pm_frag, k_in);
+        BUILD_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, k_in, k_out, nf, 0, 64, stream));
+        BUILD_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+        BUILD_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, k_in, k_out, nf, 0, 64, stream));
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3((uint32_t)((nf + 2 + 255) / 256)), dim3(256), 0, stream, nf, tile_shift, k_out, d_tm_frag);
+    BUILD_TRY(hipGetLastError());
+    uint32_t* d_lut = nullptr;
+    const uint64_t lut_n = (uint64_t)n_tiles * lut_stride;
+    BUILD_TRY(hipMalloc((void**)&d_lut, (lut_n ? lut_n : 1) * 4));
+    hipLaunchKernelGGL(lut_kernel, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
+                       d_tile_off, d_tm_frag, d_lut);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(k_in);
+    (void)hipFree(k_out);
+    if (tmp) (void)hipFree(tmp);
+    *d_lut_out = d_lut;
+    *lut_stride_out = lut_stride;
+    return (int)hipSuccess;
+}
+
+}  // namespace sagehip
