@@ -46,6 +46,7 @@ class DatabaseParameters:
     decoy_tag: Optional[str] = None
     generate_decoys: Optional[bool] = None
     fasta: Optional[str] = None
+    peptides_only: bool = False  # ours: stop after reorder_peptides; the fragment index is then built on the device
 
     @staticmethod
     def from_json(obj: dict) -> "DatabaseParameters":
@@ -108,12 +109,16 @@ class DatabaseParameters:
         keep.append(tag)
         p.decoy_tag = tag
         p.generate_decoys = 1 if (self.generate_decoys is None or self.generate_decoys) else 0
+        p.peptides_only = int(self.peptides_only)
         return p, keep
 
-    def build(self, fasta_text: str) -> "IndexedDatabase":
-        """Parameters::build(Fasta::parse(..)) — database.rs:260-263."""
+    def build(self, fasta_text: str, peptides_only: Optional[bool] = None) -> "IndexedDatabase":
+        """Parameters::build(Fasta::parse(..)) — database.rs:260-263.  peptides_only: digest / modify / sort / dedup on the
+        host and leave build_from_peptides (fragments, sort) to DeviceDatabase (index_build.hip)."""
         lib = L.load()
         p, keep = self.to_c()
+        if peptides_only is not None:
+            p.peptides_only = int(peptides_only)
         h = C.c_void_p()
         L.check(lib.sage_hip_hostdb_build(fasta_text.encode(), C.byref(p), C.byref(h)))
         return IndexedDatabase(h)
@@ -138,7 +143,9 @@ class IndexedDatabase:
         self.n_peptides = int(v.n_peptides)
         self.n_fragments = int(v.n_fragments)
         self.bucket_size = int(v.bucket_size)
-        self.fragments = _view_array(v.fragments, self.n_fragments, L.THEORETICAL_DTYPE)
+        self.has_fragments = bool(v.fragments)
+        self.fragments = _view_array(v.fragments, self.n_fragments, L.THEORETICAL_DTYPE) if self.has_fragments else \
+            np.zeros(0, dtype=L.THEORETICAL_DTYPE)
         self.min_value = _view_array(v.min_value, int(v.n_buckets), np.float32)
         self.pep_mono = _view_array(v.pep_mono, self.n_peptides, np.float32)
         self.seq_off = _view_array(v.seq_off, self.n_peptides + 1, np.uint64)
@@ -196,12 +203,20 @@ class IndexedDatabase:
 
 
 class DeviceDatabase:
-    def __init__(self, host: IndexedDatabase, device: int = 0):
+    def __init__(self, host: IndexedDatabase, device: int = 0, build_on_device: bool = False):
+        """build_on_device: ignore the host's fragments (if any) and generate the index from the peptide list on the GPU
+        (Parameters::build_from_peptides, database.rs:265-346); implied when the host database is peptides-only."""
         lib = L.load()
         self.host = host
         self.device = device
         self._h = C.c_void_p()
-        L.check(lib.sage_hip_db_create(C.byref(host._view), device, C.byref(self._h)))
+        view = host._view
+        if build_on_device and host.has_fragments:
+            view = L.SageDbView()
+            C.memmove(C.byref(view), C.byref(host._view), C.sizeof(L.SageDbView))
+            view.fragments = None
+            view.n_fragments = 0
+        L.check(lib.sage_hip_db_create(C.byref(view), device, C.byref(self._h)))
         self.device_bytes = int(lib.sage_hip_db_device_bytes(self._h))
 
     def close(self):

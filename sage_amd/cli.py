@@ -61,9 +61,9 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     if not dbp.fasta:
         raise SystemExit("`database.fasta` must be set. For more information try '--help'")
     t0 = time.time()
-    host = dbp.build(open(dbp.fasta).read())
-    dev = DeviceDatabase(host, device)
-    log(f"generated {host.n_fragments} fragments, {host.n_peptides} peptides in {int((time.time() - t0) * 1000)}ms")
+    host = dbp.build(open(dbp.fasta).read(), peptides_only=True)  # digest / modify / sort / dedup on the host ...
+    dev = DeviceDatabase(host, device)                            # ... build_from_peptides on the device (index_build.hip)
+    log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms")
     params = scorer_params(sp)
     scorer = Scorer(dev, params)
     processor = SpectrumProcessor(sp["max_peaks"], sp["deisotope"], 0.0)  # (no TMT reporter cut-off: quant is out of scope)

@@ -272,9 +272,6 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         // tile-major copy for large precursor windows: tile = peptide_index >> tile_shift, (m/z, peptide) order inside a
         // tile, and a per-tile position table tm_lut[t][c] = first position of tile t with m/z >= c / lut_scale.
         if (nf >= 0xFFFFFFF0ull) return fail(SAGE_HIP_ERR_UNSUPPORTED, "more than 2^32-16 fragments");
-        uint32_t tile_shift = 15;
-        if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(16, std::max(11, atoi(e)));
-        const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
         std::vector<uint64_t> tile_off(n_tiles + 1, 0);
         for (uint64_t t = 0; t < n_tiles; t++) tile_off[t + 1] = pm_off[std::min<uint64_t>(np, (t + 1) << tile_shift)];
         parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
@@ -284,13 +281,10 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
                     return kx != ky ? kx < ky : x.peptide_index < y.peptide_index;
                 });
         });
-        // 1/256 Da cells.  The scale is a power of two, so `m/z * scale` is exact in f32 and a fragment-tolerance window
-        // [lo, hi] maps to the cell range [floor(lo*scale), floor(hi*scale)] with no safety margin.
-        const float lut_scale = 256.0f;
         float max_mz = 0.0f;
         for (uint64_t i = 0; i < nf; i++)
             if (tm[i].fragment_mz > max_mz && std::isfinite(tm[i].fragment_mz)) max_mz = tm[i].fragment_mz;
-        const uint32_t lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
+        lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
         if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
         std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
         parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {

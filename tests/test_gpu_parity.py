@@ -233,6 +233,30 @@ def test_quick_score_prefilter(small_world, low_memory):
         assert gk.sum() > 10
 
 
+def test_index_built_on_device(small_world):
+    """Parameters::build_from_peptides (database.rs:265-346) on the device: an index generated in HBM from the peptide list
+    gives the same PSMs as the host-built one — narrow (both matching variants), tiled large-window and rescoring paths —
+    also for a, c, x, z ion kinds and another min_ion_index, and from a peptides-only host database."""
+    dev2 = DeviceDatabase(small_world.host, 0, build_on_device=True)
+    assert dev2.device_bytes == small_world.dev.device_bytes
+    sub = small_world.batch.subset(np.arange(0, small_world.batch.n, 3))
+    small_world.check(ScorerParams(), "device-built index, narrow", dev=dev2)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0), report_psms=3, min_isotope_err=-1, max_isotope_err=1),
+                      "device-built index, ±2 Da x iso", dev=dev2)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0)), "device-built index, open", batch=sub, dev=dev2)
+    dev2.close()
+    fasta = synthetic_fasta(120, seed=13)
+    kw = dict(bucket_size=1024, enzyme=dict(missed_cleavages=2, cleave_at="KR", restrict="P"), static_mods={"C": 57.0215},
+              variable_mods={"M": [15.9949], "[": [42.010565]}, ion_kinds=["a", "b", "c", "x", "y", "z"], min_ion_index=1)
+    w = World(fasta, DatabaseParameters(**kw), {}, 150, seed=23)
+    pep_only = DatabaseParameters(**kw).build(fasta, peptides_only=True)
+    assert not pep_only.has_fragments and pep_only.n_peptides == w.host.n_peptides
+    dev3 = DeviceDatabase(pep_only, 0)
+    w.check(ScorerParams(), "six ion kinds, peptides-only host db", dev=dev3)
+    w.check(ScorerParams(precursor_tol=Tolerance("da", -100.0, 100.0), report_psms=2), "six ion kinds, wide", dev=dev3)
+    dev3.close()
+
+
 def _raw_edge_cases(world, rng):
     """Raw spectra that stress SpectrumProcessor::process: isotope envelopes at charges 1-3, duplicated peaks, equal
     intensities, fewer peaks than take_top_n, a single peak, an empty spectrum, unknown precursor charge."""
