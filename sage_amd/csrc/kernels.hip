@@ -22,21 +22,21 @@ namespace {
 
 constexpr uint32_t WAVE = 64;
 
-// optional per-phase cycle accounting (DevWork::dbg != null): the first DBG_BLOCKS work items of a launch
-// store clock deltas into their own slot [item][kernel*8 + phase] (no atomics: nothing is perturbed);
+// optional per-phase cycle accounting (DevWork::dbg != null): every work item of a launch adds its clock deltas to slot
+// [item mod DBG_BLOCKS][kernel*8 + phase] (debug builds of the numbers only; atomics, so slightly perturbing);
 // kernel 0 = narrow preliminary, 1 = rescoring, 2 = large-window count, 3 = large-window replay
 constexpr uint32_t DBG_BLOCKS = 4096;
 struct PhaseClock {
     unsigned long long* slot;
     long long t;
     __device__ __forceinline__ void start(unsigned long long* dbg, uint32_t blk, uint32_t kernel) {
-        slot = (dbg && blk < DBG_BLOCKS) ? dbg + (size_t)blk * 32 + kernel * 8 : nullptr;
+        slot = dbg ? dbg + (size_t)(blk % DBG_BLOCKS) * 32 + kernel * 8 : nullptr;
         if (slot) t = clock64();
     }
     __device__ __forceinline__ void mark(int phase) {
         if (slot) {
             const long long n = clock64();
-            if ((threadIdx.x & 63u) == 0) slot[phase] += (unsigned long long)(n - t);
+            if ((threadIdx.x & 63u) == 0) atomicAdd(&slot[phase], (unsigned long long)(n - t));
             t = n;
         }
     }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                     break;
                 }
                 pc.mark(1);
-                if (pc.slot && lane == 0) { pc.slot[6] += potential; pc.slot[7] += 1; }
+                if (pc.slot && lane == 0) { atomicAdd(&pc.slot[6], (unsigned long long)potential); atomicAdd(&pc.slot[7], 1ull); }
                 cnt.zero(potential, lane);
                 __syncthreads();
                 uint32_t acc = 0;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                         // slots have larger peptide indices, so equal counts do enter)
                         uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> 16));
                         scored += (uint32_t)__popcll(__ballot(c > 0));
-                        if (pc.slot && lane == 0) pc.slot[5] += (unsigned long long)__popcll(mask);
+                        if (pc.slot && lane == 0) atomicAdd(&pc.slot[5], (unsigned long long)__popcll(mask));
                         while (mask) {
                             const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                             mask &= mask - 1;
@@ -1279,6 +1279,63 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 //   B. one lane per candidate walks ITS items in order and accumulates (scoring.rs:704-754).
 constexpr uint16_t RES_NONE = 0xFFFFu;
 
+// select_most_intense_peak (spectrum.rs:134-159) with the two partition points found through a direct-index table
+// instead of binary searches: plut[b] = number of peaks with mass < b * W.  W is a power of two, so bin(lo) = floor(lo / W)
+// and b * W are exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same
+// [left, right) and the same filtered scan as core.h's select_most_intense_peak.
+constexpr uint32_t PLUT_BINS = 256;
+__device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, const float* pm, uint32_t P) {
+    const uint32_t lane = lane_id();
+    const float top = P ? pm[P - 1] : 0.0f;
+    float w = 1.0f;  // bin width: smallest power of two with PLUT_BINS * w > largest mass
+    while (top == top && (float)PLUT_BINS * w <= top && w < 1.0e30f) w *= 2.0f;
+    inv_w = 1.0f / w;
+    for (uint32_t b = lane; b < PLUT_BINS; b += WAVE) {
+        const int32_t edge = order_key((float)b * w);
+        uint32_t lo = 0, hi = P;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (order_key(pm[mid]) < edge) lo = mid + 1; else hi = mid;
+        }
+        plut[b] = lo;
+    }
+}
+__device__ __forceinline__ int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w,
+                                               float center, const Tol& tol) {
+    float lo, hi;
+    tol_bounds(tol, center, lo, hi);
+    float fb = floorf(lo * inv_w);
+    fb = fb > 0.0f ? fb : 0.0f;  // also maps NaN to 0
+    const uint32_t bin = fb < (float)(PLUT_BINS - 1) ? (uint32_t)fb : PLUT_BINS - 1;
+    // Every peak with lo <= mass <= hi lies at or after plut[bin] (all earlier masses are < bin * W <= lo), and the
+    // reference's scan over [left, right) keeps exactly those peaks (spectrum.rs:147-157: `mass >= lo && mass <= hi`,
+    // most intense wins, the last one on ties).  Walk forward four peaks at a time — their LDS reads are independent —
+    // until a mass exceeds hi (masses ascend).
+    int best = -1;
+    float max_int = 0.0f;
+    for (uint32_t a = plut[bin]; a < P; a += 4) {
+        float m[4], it[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t i = a + j < P ? a + j : P - 1;
+            m[j] = pm[i];
+            it[j] = pi[i];
+        }
+        bool past = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const bool in = a + j < P && m[j] >= lo && m[j] <= hi;
+            if (in && it[j] >= max_int) {
+                max_int = it[j];
+                best = (int)(a + j);
+            }
+            past = past || (a + j < P && order_key(m[j]) > order_key(hi));
+        }
+        if (past) break;
+    }
+    return best;
+}
+
 // remove_matched_peaks (scoring.rs:598-644) on the LDS copy of the spectrum: drop every peak whose (mass, intensity)
 // equals a peak matched by the winner's ions, keep order, re-sum the TIC in order.  One wavefront.
 __device__ __forceinline__ void remove_matched_peaks_dev(float* pm, float* pi, uint8_t* rm, uint8_t* rm2, uint32_t& P, float& tic,
@@ -1368,6 +1425,8 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     uint16_t* res = (uint16_t*)(term + tcap);                 // [tcap] matched peak index per item
     uint8_t* rm = (uint8_t*)(res + tcap);                     // [pcap] chimera: peak selected by the winner
     uint8_t* rm2 = rm + b.pcap;
+    uint32_t* plut = (uint32_t*)(smem + (((size_t)(rm2 + b.pcap - smem) + 3) & ~(size_t)3));  // [PLUT_BINS] peak position table
+    uint32_t* mbits = plut + PLUT_BINS;                       // [tcap / 32 + 1] one bit per item of the chunk: matched a peak
 
     if (w.status[spec] != ST_OK) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -1425,9 +1484,13 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
     const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
+    uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
+    for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
     for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t ptop = pow2_floor(P);
+        float inv_w;
+        build_peak_lut(plut, inv_w, pm, P);
+        __syncthreads();
         Score s;
         s.peptide = pep;
         s.precursor_charge = z;
@@ -1448,67 +1511,87 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
                 chunk_items = o > chunk_items ? o : chunk_items;
             }
             if (chunk_items == 0) break;  // a single candidate larger than tcap cannot happen (tcap >= max items)
-            // phase A: the ion mass of the NEXT item is fetched before the current one is matched, so the
-            // global-load latency overlaps the LDS searches
-            auto locate = [&](uint32_t t, uint32_t& charge) -> float {
-                const uint32_t g = base + t;  // global item index
-                uint32_t c = 0;               // first candidate with incl > g
+            // phase A0: gather every item's ion mass into term[] (the loads of different trips are independent, so several
+            //     are in flight per lane).  Item -> candidate: a lane's items grow by 64 per trip, so its candidate index
+            //     only moves forward — one binary search for the first item, then a short walk.
+            uint32_t cw = 0;  // candidate of this lane's current item: first c with s_incl[c] > base + t
+            {
+                const uint32_t g = base + lane;
 #pragma unroll
                 for (uint32_t step = 32; step; step >>= 1) {
-                    const uint32_t probe = c + step;
-                    c = (probe <= 64 && s_incl[probe - 1] <= g) ? probe : c;
+                    const uint32_t probe = cw + step;
+                    cw = (probe <= 64 && s_incl[probe - 1] <= g) ? probe : cw;
                 }
-                const uint32_t local = g - (c ? s_incl[c - 1] : 0);
-                const uint32_t cz = s_nfz[c];
-                const uint32_t ion = local / cz;
-                charge = local - ion * cz + 1;
-                return db.ions[s_ionbase[c] + ion];
-            };
-            // A0: gather every item's ion mass into term[] first — the loads of different trips are
-            //     independent, so several are in flight per lane; A1 then matches out of LDS and overwrites
-            //     term[t] (read and written by the same lane) with the ppm term.
-#pragma unroll 4
-            for (uint32_t t = lane; t < chunk_items; t += WAVE) {
-                uint32_t charge;
-                term[t] = locate(t, charge);
-                res[t] = (uint16_t)charge;
+            }
+            for (uint32_t i = lane; i < (chunk_items + 31) / 32 + 1; i += WAVE) mbits[i] = 0;
+            for (uint32_t tb = 0; tb < chunk_items; tb += 8 * WAVE) {  // eight trips per batch: their global loads overlap
+                float v[8];
+                uint32_t zq[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t t = tb + j * WAVE + lane;
+                    v[j] = 0.0f;
+                    zq[j] = 1;
+                    if (t < chunk_items) {
+                        const uint32_t g = base + t;
+                        while (cw < 63 && s_incl[cw] <= g) cw++;
+                        const uint32_t local = g - (cw ? s_incl[cw - 1] : 0);
+                        const uint32_t cz = s_nfz[cw];
+                        const uint32_t ion = local / cz;
+                        zq[j] = local - ion * cz + 1;  // fragment charge
+                        v[j] = db.ions[s_ionbase[cw] + ion];
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t t = tb + j * WAVE + lane;
+                    if (t < chunk_items) {
+                        term[t] = v[j];
+                        res[t] = (uint16_t)zq[j];
+                    }
+                }
             }
             __syncthreads();
+            pc.mark(5);
             for (uint32_t t = lane; t < chunk_items; t += WAVE) {
                 const float mz = term[t] / (float)res[t];
-                const int pk = select_most_intense_peak_lockstep(pm, pi, P, ptop, mz, sc.fragment_tol);
+                const int pk = select_peak_lut(pm, pi, P, plut, inv_w, mz, sc.fragment_tol);
                 if (pk >= 0) {
                     const float peak_mass = pm[pk];
                     res[t] = (uint16_t)pk;
                     // the per-match ppm term of scoring.rs:719-720; only its accumulation is order-sensitive
                     term[t] = pi[pk] * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
-                } else {
-                    res[t] = RES_NONE;
+                    atomicOr(&mbits[t >> 5], 1u << (t & 31u));
                 }
             }
             __syncthreads();
             pc.mark(1);
-            // phase B
-            if (in_chunk) {
+            // phase B: one lane per candidate accumulates ITS matched items in (kind, index, charge) order — only the
+            //     matched ones are visited, through the chunk's match bitmap
+            if (in_chunk && n_items) {
                 Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
-                uint32_t t = excl - base;
-                for (uint32_t k = 0; k < db.n_kinds; k++) {
-                    const bool nterm_kind = db.ion_kinds[k] <= 2;
-                    for (uint32_t idx = 0; idx < lm1; idx++) {
-                        for (uint32_t c = 1; c < mfc; c++, t++) {
-                            const uint16_t r = res[t];
-                            if (r == RES_NONE) continue;
-                            const float peak_intensity = pi[r];
-                            s.ppm_difference += term[t];
-                            if (nterm_kind) {
-                                s.matched_b += 1;
-                                s.summed_b += peak_intensity;
-                                run_matched(b_run, idx);
-                            } else {
-                                s.matched_y += 1;
-                                s.summed_y += peak_intensity;
-                                run_matched(y_run, idx);
-                            }
+                const uint32_t t0 = excl - base, t1 = incl - base;  // this candidate's items
+                const uint32_t per_kind = lm1 * nfz;
+                for (uint32_t wd = t0 >> 5; wd <= (t1 - 1) >> 5; wd++) {
+                    uint32_t m = mbits[wd];
+                    if (wd == (t0 >> 5)) m &= ~0u << (t0 & 31u);
+                    if (wd == ((t1 - 1) >> 5) && (t1 & 31u)) m &= ~0u >> (32u - (t1 & 31u));
+                    while (m) {
+                        const uint32_t t = (wd << 5) + (uint32_t)__ffs((int)m) - 1;
+                        m &= m - 1;
+                        const uint32_t local = t - t0;
+                        const uint32_t k = local / per_kind;
+                        const uint32_t idx = (local - k * per_kind) / nfz;
+                        const float peak_intensity = pi[res[t]];
+                        s.ppm_difference += term[t];
+                        if ((nterm_mask >> k) & 1u) {
+                            s.matched_b += 1;
+                            s.summed_b += peak_intensity;
+                            run_matched(b_run, idx);
+                        } else {
+                            s.matched_y += 1;
+                            s.summed_y += peak_intensity;
+                            run_matched(y_run, idx);
                         }
                     }
                 }
@@ -1732,6 +1815,7 @@ uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions) {
 }
 size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t max_ions) {
     size_t n = 192 * 8 + 128 * 4 + (size_t)b.pcap * 8 + (size_t)rescore_item_cap(b, max_ions) * 6 + (size_t)b.pcap * 2;
+    n = ((n + 3) & ~(size_t)3) + PLUT_BINS * 4 + ((size_t)rescore_item_cap(b, max_ions) / 32 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }
 

@@ -16,8 +16,8 @@ batch = SpectrumBatch.from_spectra([p for p in (sp.process(r) for r in synthetic
 scorer = Scorer(DeviceDatabase(host, 0), bench._scorer_params(cfg)); db = scorer.upload(batch)
 for _ in range(3): scorer.score_resident(db)
 out = np.zeros(32, np.uint64); L.check(L.load().sage_hip_debug_phase_cycles(scorer._h, L.as_ptr(out, C.c_uint64)))
-nn = 3 * min(batch.n, 4096)
+nn = 3 * batch.n
 print("prelim  cycles/spectrum: staging %d search %d match %d trim %d output %d" % tuple(out[:5] // nn))
 print("prelim  per spectrum: offers %.1f  potential %.1f  queries %.2f" % tuple(out[5:8] / nn))
-print("rescore cycles/spectrum: setup %d phaseA %d phaseB %d rank %d emit %d" % tuple(out[8:13] // nn))
+print("rescore cycles/spectrum: setup %d phaseA1(match) %d phaseB %d rank %d emit %d phaseA0(gather) %d" % tuple(out[8:14] // nn))
 print(scorer.last_timing())

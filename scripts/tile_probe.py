@@ -26,7 +26,7 @@ scorer.score_resident(db)
 t0 = time.perf_counter(); f, c = scorer.score_resident(db); dt = time.perf_counter() - t0
 print(mode, scorer.last_timing(), "spectra/s %.4g" % (batch.n / dt), "psms", int(c.sum()))
 out = np.zeros(32, np.uint64); L.check(L.load().sage_hip_debug_phase_cycles(scorer._h, L.as_ptr(out, C.c_uint64)))
-nn = 2.0 * min(batch.n, 4096)
+nn = 2.0 * batch.n
 print("  count kernel cycles/spectrum (wave 0): query %d stream %d wait1 %d pass1 %d wait2+alloc %d pass2 %d wait3 %d" % tuple(out[16:23] / nn), "arena entries/spectrum %.0f" % (scorer.last_timing()["arena_entries"] / batch.n))
 nb = 2.0 * ((batch.n * 1 + 63) // 64)
 print("  replay kernel per wave: build %d replay %d cycles" % tuple(out[24:26] / nb))
