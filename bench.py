@@ -226,7 +226,8 @@ def main():
                     "kernel_ms": {"prelim": pm, "rescore": rm},
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
-                    "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"]},
+                    "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],
+                                "exact_retry_for_tied_hyperscores": last_t["n_retry"]},
                     "note": "prelim = fragment matching + k-select kernels (HIP events on the scorer's stream); narrow-window "
                             "searches are probe/latency bound: few algorithmic bytes per spectrum by construction"}
         out = {

@@ -270,6 +270,7 @@ typedef struct SageTiming {
     uint32_t n_launches;
     uint32_t n_wide;   /* spectra routed to the tiled large-window kernels */
     uint32_t arena_entries; /* 4-byte entries of the large-window candidate arena this call used */
+    uint32_t n_retry;  /* spectra with equal hyperscores at a reported rank, re-run with exact heap layouts */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 

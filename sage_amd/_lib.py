@@ -145,6 +145,7 @@ class SageTiming(C.Structure):
         ("n_launches", C.c_uint32),
         ("n_wide", C.c_uint32),
         ("arena_entries", C.c_uint32),
+        ("n_retry", C.c_uint32),
     ]
 
 

@@ -89,7 +89,8 @@ struct SageScorer {
     SageTiming timing{};
     // per-batch work buffers, grown on demand
     DevBuf<uint64_t> cand;
-    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count, queue;
+    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count, queue, retry;
+    bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
     // large-window pipeline scratch (device_types.h: DevWork)
     DevBuf<QueryRec> qrec;
     DevBuf<uint16_t> seeds;
@@ -373,6 +374,8 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     d.wcap = 1024;
     d.dbg_flags = 0;
     if (const char* e = getenv("SAGE_HIP_DEBUG_FLAGS")) d.dbg_flags = (uint32_t)atoi(e);
+    d.exact = 0;
+    if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
@@ -622,6 +625,7 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     HIP_TRY(s->totals.alloc((size_t)n * 2));
     HIP_TRY(s->status.alloc(n));
     HIP_TRY(s->queue.alloc(n));
+    HIP_TRY(s->retry.alloc(n));
     HIP_TRY(s->out_count.alloc(n));
     // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
     // (16 Ki entries = 64 KiB per spectrum on average; an exhausted arena is reported, never silently truncated)
@@ -640,27 +644,32 @@ static int ensure_work(SageScorer* s, uint32_t n) {
 
 static DevWork make_work(SageScorer* s);
 
-static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore) {
+// One pass of the kernels over `view` (the whole resident batch, or — `exact` retry pass — the spectra listed in view.order).
+// exact: every trim replays bounded_min_heapify (reference heap layouts); otherwise the order-free trims.
+static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore, bool exact, const DevBatchView* sub = nullptr) {
     if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
     HIP_TRY(hipSetDevice(s->db->device));
     int rc = ensure_work(s, b->n);
     if (rc != SAGE_HIP_OK) return rc;
-    const size_t lds_p = prelim_lds_bytes(s->dev, b->view), lds_r = rescore_lds_bytes(s->dev, b->view, s->db->max_ions);
-    const size_t lds_t = tile_lds_bytes(s->db->view, s->dev, b->view);
+    const DevBatchView& view = sub ? *sub : b->view;
+    DevScorer sc = s->dev;
+    sc.exact = exact ? 1u : 0u;
+    const size_t lds_p = prelim_lds_bytes(sc, view), lds_r = rescore_lds_bytes(sc, view, s->db->max_ions);
+    const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
     if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
     DevWork w = make_work(s);
     {
-        TileParams tp{s->db->view, s->dev, b->view, w};
+        TileParams tp{s->db->view, sc, view, w};
         HIP_TRY(hipMemcpyAsync(s->tile_params.p, &tp, sizeof tp, hipMemcpyHostToDevice, s->stream));  // (small: staged at call time)
     }
     HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, CTR_COUNT * 4, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    launch_prelim(s->db->view, s->dev, b->view, w, s->stream);
-    launch_prelim_tile(s->db->view, s->dev, b->view, w, s->stream);
+    launch_prelim(s->db->view, sc, view, w, s->stream);
+    launch_prelim_tile(s->db->view, sc, view, w, s->stream);
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (with_rescore)
-        launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
+        launch_rescore(s->db->view, sc, view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
                        s->features.p, s->out_count.p, nullptr, s->stream);
     HIP_TRY(hipEventRecord(s->ev[2], s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
@@ -676,9 +685,10 @@ static int finish_timing(SageScorer* s, bool with_rescore) {
     s->timing.prelim_ms = a;
     s->timing.rescore_ms = with_rescore ? c : 0.f;
     s->timing.total_ms = a + c;
-    s->timing.n_launches = with_rescore ? 5 : 4;
+    s->timing.n_launches = with_rescore ? 6 : 5;
     s->timing.n_wide = s->h_counters[CTR_QUEUED];  // copied on the stream before the caller's synchronize
     s->timing.arena_entries = s->h_counters[CTR_ARENA_PTR];
+    s->timing.n_retry = 0;
     if (s->h_counters[CTR_ARENA_OVERFLOW])
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->arena.n >> 18) +
                                                   " MiB): score this batch in smaller pieces or raise SAGE_HIP_ARENA_MB");
@@ -693,6 +703,7 @@ static DevWork make_work(SageScorer* s) {
     w.status = s->status.p;
     w.n_deferred = s->n_deferred.p;
     w.queue = s->queue.p;
+    w.retry = s->retry.p;
     w.tile_blocks = s->tile_blocks;
     w.qrec = s->qrec.p;
     w.seeds = s->seeds.p;
@@ -707,7 +718,8 @@ static DevWork make_work(SageScorer* s) {
 
 int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
     if (!s || !b || !out || !out_count) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    int rc = run_kernels(s, b, true);
+    const bool exact = s->exact_always;
+    int rc = run_kernels(s, b, true, exact);
     if (rc != SAGE_HIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
@@ -715,6 +727,31 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = finish_timing(s, true);
     if (rc != SAGE_HIP_OK) return rc;
+    const uint32_t n_retry = exact ? 0 : s->h_counters[CTR_RETRY];
+    if (n_retry && !s->h_counters[CTR_LIST_OVERFLOW]) {
+        // Some spectra have equal hyperscores at a reported rank: there the heap layout of the preliminary list decides
+        // the order (the stable sort of scoring.rs:495), so exactly those spectra go through the kernels again with every
+        // trim replaying bounded_min_heapify.
+        const SageTiming first = s->timing;
+        DevBatchView sub = b->view;
+        sub.order = s->retry.p;  // filled by the rescoring kernel, in no particular order
+        sub.n = n_retry;
+        rc = run_kernels(s, b, true, true, &sub);
+        if (rc != SAGE_HIP_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
+                               hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        rc = finish_timing(s, true);
+        if (rc != SAGE_HIP_OK) return rc;
+        s->timing.prelim_ms += first.prelim_ms;
+        s->timing.rescore_ms += first.rescore_ms;
+        s->timing.total_ms += first.total_ms;
+        s->timing.n_launches += first.n_launches;
+        s->timing.n_wide = first.n_wide;
+        s->timing.arena_entries = std::max(s->timing.arena_entries, first.arena_entries);
+        s->timing.n_retry = n_retry;
+    }
     if (s->h_counters[CTR_LIST_OVERFLOW]) {  // rare: find the offending spectrum for the message
         std::vector<uint32_t> st(b->n);
         HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
@@ -787,7 +824,7 @@ int sage_hip_annotate_resident(SageScorer* s, SageDeviceBatch* b, const SageFeat
 
 int sage_hip_quick_score_resident(SageScorer* s, SageDeviceBatch* b, int prefilter_low_memory, uint8_t* keep) {
     if (!s || !b || !keep) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    int rc = run_kernels(s, b, false);  // Scorer::initial_hits
+    int rc = run_kernels(s, b, false, false);  // Scorer::initial_hits; which peptides survive each trim does not depend on heap layouts
     if (rc != SAGE_HIP_OK) return rc;
     const uint64_t np = s->db->view.np;
     DevBuf<uint8_t> d_keep;
@@ -814,7 +851,7 @@ int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, u
                           uint64_t* matched_peaks, uint64_t* scored_candidates) {
     if (!s || !b || !packed || !len) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (cap < s->dev.kmax) return fail(SAGE_HIP_ERR_INVALID, "cap must be >= max(50, 2*report_psms)");
-    int rc = run_kernels(s, b, false);
+    int rc = run_kernels(s, b, false, true);  // the reference's heap layouts
     if (rc != SAGE_HIP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = finish_timing(s, false);

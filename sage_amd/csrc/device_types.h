@@ -50,7 +50,11 @@ struct DevScorer {
     uint32_t list_cap;   // capacity (entries) of each of the two CLists
     uint32_t wcap;       // candidate-slot capacity of the LDS counter array of the narrow kernel: spectra with a
                          // larger precursor window go to the tiled large-window kernel
-    uint32_t dbg_flags;  // timing experiments only (SAGE_HIP_DEBUG_FLAGS): results are WRONG when non-zero
+    uint32_t dbg_flags;  // timing experiments only (SAGE_HIP_DEBUG_FLAGS)
+    uint32_t exact;      // 1: every trim_hits replays bounded_min_heapify, so the preliminary list has the reference's heap
+                         //    layout.  0: each trim keeps the same SET of candidates (the k largest) without replaying the
+                         //    heap; the layout is only observable through equal hyperscores at a reported rank, which the
+                         //    rescoring kernel detects and sends back through the exact path
 };
 
 struct DevBatchView {
@@ -82,6 +86,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
                            //      [2] queue head (next entry a large-window workgroup takes),
                            //      [3] candidate-arena bump pointer, [4] candidate-arena overflows
     uint32_t* queue;       // [n] spectra queued for the large-window kernels
+    uint32_t* retry;       // [n] spectra whose reported ranks tie in hyperscore: re-run with exact heap layouts
     uint32_t tile_blocks;  // persistent workgroups of the large-window counting kernel
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
@@ -94,8 +99,9 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)
 };
 
-enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2 };
-enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_COUNT = 8 };
+enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3 };
+enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
+       CTR_COUNT = 8 };
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
 struct QueryRec {

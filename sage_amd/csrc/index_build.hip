@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheor
         const float o = __shfl_xor(v, off, 64);
         v = o > v ? o : v;
     }
-    if ((threadIdx.x & 63u) == 0 && v > 0.0f) atomicMax(out, __float_as_uint(v));
+    if ((threadIdx.x & 63u) == 0 && v > 0.0f) atomicMax(out + (blockIdx.x & 255u), __float_as_uint(v));  // (256 slots: no hot address)
 }
 
 }  // namespace
@@ -157,13 +157,15 @@ int build_index_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, cons
     BUILD_TRY(hipGetLastError());
     // largest finite fragment m/z -> table width
     uint32_t* d_max = nullptr;
-    BUILD_TRY(hipMalloc((void**)&d_max, 4));
-    BUILD_TRY(hipMemsetAsync(d_max, 0, 4, stream));
+    BUILD_TRY(hipMalloc((void**)&d_max, 256 * 4));
+    BUILD_TRY(hipMemsetAsync(d_max, 0, 256 * 4, stream));
     if (nf) hipLaunchKernelGGL(maxmz_kernel, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, stream, nf, d_pm_frag, d_max);
-    uint32_t max_bits = 0;
-    BUILD_TRY(hipMemcpyAsync(&max_bits, d_max, 4, hipMemcpyDeviceToHost, stream));
+    uint32_t max_slots[256] = {};
+    BUILD_TRY(hipMemcpyAsync(max_slots, d_max, 256 * 4, hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
     (void)hipFree(d_max);
+    uint32_t max_bits = 0;  // positive floats order like their bit patterns
+    for (uint32_t v : max_slots) max_bits = v > max_bits ? v : max_bits;
     float max_mz;
     memcpy(&max_mz, &max_bits, 4);
     const double cells = ceil((double)max_mz * lut_scale) + 3.0;

@@ -247,11 +247,13 @@ __device__ __forceinline__ void ulist_append_empties(UList& c, uint64_t n, uint3
     if (lit) ulist_append(c, PRESCORE_EMPTY, lit, kmax);
     c.len += n - lit;
 }
-// trim_hits (scoring.rs:322-329); called by one whole wavefront (the list lives in LDS)
-__device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms) {
+// trim_hits (scoring.rs:322-329); called by one whole wavefront (the list lives in LDS).
+// exact: replay bounded_min_heapify, the list ends up in the reference's heap layout.  !exact: keep the same k entries
+// (the k largest; equal entries are interchangeable) in descending order, by ranking every stored entry.
+__device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms, bool exact) {
     const uint32_t lane = lane_id();
     const uint32_t k = trim_k(c.len, report_psms);
-    if (c.len > k) {
+    if (c.len > k && exact) {
         wave_sync();
         WaveHeap h;
         const uint64_t mine = lane < k ? c.items[lane] : PRESCORE_EMPTY;
@@ -265,6 +267,30 @@ __device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms) {
         }
         wave_sync();
         if (lane < k) c.items[lane] = ((uint64_t)h.hi << 32) | h.lo;
+        wave_sync();
+    } else if (c.len > k) {
+        // (entries of the logical list that are not stored are PreScore::default(): the smallest value there is)
+        wave_sync();
+        uint64_t keep_v[4];   // list_cap <= 4 * 64 entries (capi.hip sizes it; larger lists take the exact path)
+        uint32_t keep_r[4];
+        const uint32_t nst = c.stored;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t i = q * WAVE + lane;
+            keep_v[q] = i < nst ? c.items[i] : 0ull;
+            uint32_t rank = 0;
+            if (i < nst)
+                for (uint32_t j = 0; j < nst; j++) {
+                    const uint64_t o = c.items[j];  // (same address in every lane: an LDS broadcast)
+                    rank += (o > keep_v[q]) || (o == keep_v[q] && j < i);
+                }
+            keep_r[q] = i < nst ? rank : 0xFFFFFFFFu;
+        }
+        wave_sync();
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++)
+            if (keep_r[q] < k) c.items[keep_r[q]] = keep_v[q];
+        for (uint32_t i = nst + lane; i < k; i += WAVE) c.items[i] = PRESCORE_EMPTY;  // fewer stored than k: defaults fill up
         wave_sync();
     }
     c.stored = k;
@@ -355,6 +381,58 @@ __device__ __forceinline__ Window query_window(const DevDbView& db, const Tol& p
     if (left < db.np && !(db.pep_mono[left] >= plo)) q.first = left + 1;
     if (right < db.np && db.pep_mono[right] <= phi) q.end = right + 1;
     return q;
+}
+
+// trim_hits of one precursor-window query WITHOUT replaying the heap: the same k slots — the k largest by (matched count,
+// slot); bounded_min_heapify keeps exactly that set — appended in slot order.  A 64-bin histogram of the counts gives the
+// k-th largest count T; every slot above T is kept, and of the slots equal to T the LAST ones (larger peptide index wins
+// a tie in PreScore's order).  Returns false (nothing appended) when a count does not fit the histogram.
+__device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& cnt, uint32_t potential, uint32_t k, uint32_t left,
+                                            uint32_t z, int iso, uint32_t kmax, UList& target, uint32_t& scored) {
+    const uint32_t lane = lane_id();
+    uint32_t* hist = (uint32_t*)L.heap;  // (kmax * 8 >= 400 bytes: 64 bins, then reused for the selected entries)
+    wave_sync();
+    hist[lane] = 0;
+    wave_sync();
+    for (uint32_t base = 0; base < potential; base += WAVE) {
+        const uint32_t i = base + lane;
+        const uint32_t c = i < potential ? cnt.get(i) : 0;
+        if (c) atomicAdd(&hist[c < 63 ? c : 63], 1u);
+    }
+    wave_sync();
+    const uint32_t mine = hist[lane];
+    uint32_t suffix = mine;  // number of slots with count >= lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(suffix, off, 64);
+        if ((int)lane + off < 64) suffix += o;
+    }
+    if (__shfl(mine, 63, 64) != 0) return false;  // a count >= 63: keep the exact path
+    scored = __shfl(suffix, 1, 64);               // slots with count > 0
+    const uint64_t okm = __ballot(lane >= 1 && suffix >= k);
+    const uint32_t T = okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u;  // k-th largest count (0: fewer than k non-empty)
+    const uint32_t n_gt = __shfl(suffix, (int)(T + 1 < 64 ? T + 1 : 63), 64);  // (T <= 62 here)
+    const uint32_t n_eq = T ? __shfl(mine, (int)T, 64) : 0;
+    const uint32_t take_eq = T ? k - n_gt : 0, skip_eq = n_eq - take_eq;
+    wave_sync();
+    uint64_t* sel = L.heap;
+    uint32_t nsel = 0, eq_seen = 0;
+    for (uint32_t base = 0; base < potential; base += WAVE) {
+        const uint32_t i = base + lane;
+        const uint32_t c = i < potential ? cnt.get(i) : 0;
+        const uint64_t eqm = __ballot(T != 0 && c == T);
+        const uint32_t eq_idx = eq_seen + (uint32_t)__popcll(eqm & ((1ull << lane) - 1ull));
+        const bool take = c > T || (T != 0 && c == T && eq_idx >= skip_eq);
+        const uint64_t tm = __ballot(take);
+        if (take) sel[nsel + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull))] = pack_prescore(c, left + i, z, iso);
+        nsel += (uint32_t)__popcll(tm);
+        eq_seen += (uint32_t)__popcll(eqm);
+    }
+    wave_sync();
+    // nsel == k, or fewer when the window holds fewer than k non-empty slots: PreScore::default() entries fill up
+    ulist_append(target, lane < nsel ? sel[lane] : PRESCORE_EMPTY, k, kmax);
+    wave_sync();
+    return true;
 }
 
 // ---- narrow windows: one wavefront per spectrum, counters in LDS -----------------------------------
@@ -561,8 +639,11 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                         const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
                         ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
                     }
+                } else if (!sc.exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
+                    // (done: the k largest slots by (count, slot) without replaying the heap)
                 } else {
                     // keys `matched << 16 | slot` (potential <= wcap <= 65536): same order as PreScore inside one query
+                    scored = 0;
                     uint32_t h;
                     {
                         const uint32_t c = lane < k ? cnt.get(lane) : 0;
@@ -592,7 +673,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                 pc.mark(3);
             }
             if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
-                ulist_trim(A, sc.report_psms);
+                ulist_trim(A, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);
                 __syncthreads();
                 for (uint32_t base = 0; base < A.stored; base += WAVE) {
                     const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
@@ -609,7 +690,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
             }
             continue;
         }
-        ulist_trim(B, sc.report_psms);  // scoring.rs:460
+        ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
         __syncthreads();
         if (lane == 0) {
             if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
@@ -999,17 +1080,33 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 acc = wave_sum_dpp(acc);
                 if (lane == 0 && acc) atomicAdd(&L.sh[SH_MATCHED], acc);
                 __syncthreads();
-                if (tid == 0) {
-                    QueryRec r;
-                    r.left = left;
-                    r.potential = potential;
-                    r.matched = L.sh[SH_MATCHED];
-                    r.scored = L.sh[SH_SCORED];
-                    r.head = L.sh[SH_HEAD];
-                    r.z_iso = z | ((uint32_t)(iso + 128) << 8);
-                    r.pad[0] = L.hist[HIST_BINS - 1] != 0;  // some slot matched >= 63 peaks: the replay keeps 64-bit keys
-                    r.pad[1] = 0;
-                    w.qrec[qid] = r;
+                if (w0) {
+                    // the k-th largest count T of the whole window and how many of the slots equal to T (the first ones) do
+                    // NOT make the cut: all an order-free trim_hits needs (tile_select_kernel)
+                    const uint32_t hmine = L.hist[lane];
+                    uint32_t suffix = hmine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t o = __shfl_down(suffix, off, 64);
+                        if ((int)lane + off < 64) suffix += o;
+                    }
+                    const uint64_t okm = __ballot(lane >= 1 && suffix >= k);
+                    const uint32_t T = okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u;
+                    const uint32_t n_gt = __shfl(suffix, (int)(T + 1 < 64 ? T + 1 : 63), 64);
+                    const uint32_t n_eq = T ? __shfl(hmine, (int)(T < 64 ? T : 63), 64) : 0;
+                    const uint32_t big = __shfl(hmine, 63, 64) != 0;  // some slot matched >= 63 peaks: bins are clipped
+                    if (lane == 0) {
+                        QueryRec r;
+                        r.left = left;
+                        r.potential = potential;
+                        r.matched = L.sh[SH_MATCHED];
+                        r.scored = L.sh[SH_SCORED];
+                        r.head = L.sh[SH_HEAD];
+                        r.z_iso = z | ((uint32_t)(iso + 128) << 8);
+                        r.pad[0] = big | (T << 8);                        // bit 0: the heap replay must keep 64-bit keys / no fast select
+                        r.pad[1] = T ? n_eq - (k - n_gt) : 0;             // slots equal to T to skip
+                        w.qrec[qid] = r;
+                    }
                 }
             }
         }
@@ -1186,13 +1283,116 @@ __global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w
     QueryRec rec{};
     if (qid < n_q) rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
-    const bool live = rec.potential > k && rec.matched != 0;  // else no k-select: the assembler takes the slots verbatim
+    bool live = rec.potential > k && rec.matched != 0;  // else no k-select: the assembler takes the slots verbatim
     const uint32_t z = rec.z_iso & 0xFFu;
     const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
+    // order-free mode: the heap is only replayed for queries tile_select_kernel cannot take (clipped histogram)
+    if (!sc.exact && !(rec.pad[0] & 1u)) live = false;
+    if (__ballot(live) == 0ull) return;
     const bool small_keys = !(sc.dbg_flags & 2u) &&  // (SAGE_HIP_DEBUG_FLAGS=2: tests force the 64-bit path)
-                            __ballot(live && (rec.potential > (1u << K32_SLOT_BITS) || rec.pad[0] != 0)) == 0ull;
+                            __ballot(live && (rec.potential > (1u << K32_SLOT_BITS) || (rec.pad[0] & 1u) != 0)) == 0ull;
     if (small_keys) replay_queries<uint32_t>((uint32_t*)heap + lane, w, rec, qid, k, live, z, iso, pc);
     else replay_queries<uint64_t>(heap + lane, w, rec, qid, k, live, z, iso, pc);
+}
+
+// trim_hits of a large-window query WITHOUT replaying the heap (DevScorer::exact == 0): one wavefront walks the verbatim
+// slots and the candidate stream in slot order and keeps every slot above the k-th largest count T, plus the last
+// (k - #above) slots equal to T — the same k candidates bounded_min_heapify keeps — in slot order.
+__global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w) {
+    const uint32_t lane = lane_id();
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    const uint64_t qid = blockIdx.x;
+    if (qid >= n_q) return;
+    const QueryRec rec = w.qrec[qid];
+    const uint32_t k = trim_k(rec.potential, sc.report_psms);
+    if (rec.potential <= k || rec.matched == 0 || (rec.pad[0] & 1u)) return;
+    const uint32_t z = rec.z_iso & 0xFFu;
+    const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
+    const uint32_t T = rec.pad[0] >> 8, skip_eq = rec.pad[1];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t* out = w.qres + qid * 64;
+    uint32_t nsel = 0, eq_seen = 0;
+    auto offer = [&](uint32_t c, uint32_t pep) {  // one slot per lane (c == 0: none), lanes in slot order
+        const uint64_t eqm = __ballot(T != 0 && c == T);
+        const uint32_t eq_idx = eq_seen + (uint32_t)__popcll(eqm & lt);
+        const bool take = c > T || (T != 0 && c == T && eq_idx >= skip_eq);
+        const uint64_t tm = __ballot(take);
+        const uint32_t pos = nsel + (uint32_t)__popcll(tm & lt);
+        if (take && pos < k) out[pos] = pack_prescore(c, pep, z, iso);
+        nsel += (uint32_t)__popcll(tm);
+        eq_seen += (uint32_t)__popcll(eqm);
+    };
+    offer(lane < k ? w.seeds[qid * 64 + lane] : 0u, rec.left + lane);  // the first k slots
+    for (uint32_t seg = rec.head; seg != NONE32;) {
+        const uint4 hdr = *(const uint4*)(w.arena + seg);
+        for (uint32_t j = 0; j < hdr.y; j += WAVE) {
+            const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+            offer(e >> 16, hdr.z + (e & 0xFFFFu));
+        }
+        seg = hdr.x;
+    }
+    for (uint32_t i = (nsel < k ? nsel : k) + lane; i < k; i += WAVE) out[i] = PRESCORE_EMPTY;  // fewer than k non-empty slots
+}
+
+// The same replay with ONE WAVEFRONT per query (heap one element per lane, wh32_* / wh_* above): ~10x more work per
+// query than the lane-per-query kernel, but every query proceeds in parallel — the better choice while the batch has
+// fewer queries than the GPU has wavefront slots (an open search of ~10^4 spectra, or an exact retry pass).
+__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w) {
+    const uint32_t lane = lane_id();
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    const uint64_t qid = blockIdx.x;
+    if (qid >= n_q) return;
+    const QueryRec rec = w.qrec[qid];
+    const uint32_t k = trim_k(rec.potential, sc.report_psms);
+    if (rec.potential <= k || rec.matched == 0) return;        // no k-select: the assembler takes the slots verbatim
+    if (!sc.exact && !(rec.pad[0] & 1u)) return;               // order-free mode: tile_select_kernel took it
+    const uint32_t z = rec.z_iso & 0xFFu;
+    const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
+    const bool small_keys = !(sc.dbg_flags & 2u) && rec.potential <= (1u << K32_SLOT_BITS) && !(rec.pad[0] & 1u);
+    const uint32_t seed_c = lane < k ? w.seeds[qid * 64 + lane] : 0u;
+    if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
+        uint32_t h = seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u;
+        wh32_build(h, k);
+        for (uint32_t seg = rec.head; seg != NONE32;) {
+            const uint4 hdr = *(const uint4*)(w.arena + seg);
+            for (uint32_t j = 0; j < hdr.y; j += WAVE) {
+                const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+                const uint32_t c = e >> 16;
+                const uint32_t v = (c << K32_SLOT_BITS) | (hdr.z + (e & 0xFFFFu) - rec.left);
+                // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
+                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> K32_SLOT_BITS));
+                while (mask) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    wh32_offer(h, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                }
+            }
+            seg = hdr.x;
+        }
+        if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(h, rec.left, z, iso);
+    } else {
+        WaveHeap h;
+        const uint64_t sv = seed_c ? pack_prescore(seed_c, rec.left + lane, z, iso) : PRESCORE_EMPTY;
+        h.lo = (uint32_t)sv;
+        h.hi = (uint32_t)(sv >> 32);
+        wh_build(h, k);
+        for (uint32_t seg = rec.head; seg != NONE32;) {
+            const uint4 hdr = *(const uint4*)(w.arena + seg);
+            for (uint32_t j = 0; j < hdr.y; j += WAVE) {
+                const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+                const uint32_t c = e >> 16;
+                const uint64_t v = pack_prescore(c, hdr.z + (e & 0xFFFFu), z, iso);
+                uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
+                while (mask) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    wh_offer(h, k, lane_value(v, bit));
+                }
+            }
+            seg = hdr.x;
+        }
+        if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
+    }
 }
 
 __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
@@ -1231,7 +1431,7 @@ __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatc
             }
         }
         if (fold) {  // scoring.rs:405 then `hits +=` at :432 / :450
-            ulist_trim(A, sc.report_psms);
+            ulist_trim(A, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);
             wave_sync();
             for (uint32_t base = 0; base < A.stored; base += WAVE) {
                 const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
@@ -1241,7 +1441,7 @@ __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatc
             wave_sync();
         }
     }
-    ulist_trim(B, sc.report_psms);  // scoring.rs:460
+    ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
     wave_sync();
     if (lane == 0) {
         if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
@@ -1655,6 +1855,20 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         }
         __syncthreads();
         pc.mark(3);
+        if (!sc.exact) {
+            // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two
+            // equal hyperscores meet at a reported rank (i, i+1 with i < per_round).  Otherwise: back through the exact path.
+            const bool tie = pass && rank < per_round && rank + 1 < npass &&
+                             __double_as_longlong(s_sorted[rank]) == __double_as_longlong(s_sorted[rank + 1]);
+            if (__ballot(tie) != 0ull) {
+                if (lane == 0) {
+                    w.status[spec] = ST_RETRY;
+                    w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+                    out_count[spec] = 0;
+                }
+                return;
+            }
+        }
         if (pass && rank < per_round) {  // scoring.rs:504-594
             const double next = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
             const double best = s_sorted[0];
@@ -1832,7 +2046,14 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
                        tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
     const uint64_t nq = (uint64_t)b.n * w.qmax;
-    hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
+    if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
+    // bounded_min_heapify replay: a wavefront per query while queries are fewer than wavefront slots, else a lane per query
+    uint32_t wave_max = 32768;
+    if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint32_t)atoi(e);
+    if (nq <= wave_max)
+        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
+    else
+        hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
     hipLaunchKernelGGL(tile_assemble_kernel, dim3(b.n), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
                        (hipStream_t)stream, sc, b, w);
 }

@@ -124,13 +124,15 @@ def test_wide_tolerance_hits_large_window_path(small_world):
     assert t["n_wide"] > 0
 
 
-@pytest.mark.parametrize("tile_shift", [11, 12, 15])
-def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift):
+@pytest.mark.parametrize("tile_shift,replay", [(11, "wave"), (12, "lane"), (15, "wave"), (15, "lane")])
+def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     """The tiled large-window kernel with small tiles (2048 / 4096 peptides) so that every window spans many
     tiles, the first k slots straddle tile boundaries, and partial first/last tiles occur: ±500 Da, isotope
     folding, unknown charge, report_psms > 1 — every branch of the nested k-selects."""
     monkeypatch.setenv("SAGE_HIP_TILE_SHIFT", str(tile_shift))
     monkeypatch.setenv("SAGE_HIP_WCAP", "64")
+    if replay == "lane":  # the heap replay kernel with one lane per query (normally picked for > 32768 queries)
+        monkeypatch.setenv("SAGE_HIP_REPLAY_WAVE_MAX", "0")
     dev = DeviceDatabase(small_world.host, 0)
     idx = np.arange(0, small_world.batch.n, 5)
     sub = small_world.batch.subset(idx)
@@ -231,6 +233,28 @@ def test_quick_score_prefilter(small_world, low_memory):
         ok = small_world.orc.quick_score(params, batch, low_memory)
         np.testing.assert_array_equal(gk, ok, err_msg=f"quick_score low_memory={low_memory} {ctx}")
         assert gk.sum() > 10
+
+
+def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
+    """Order-free trims (the default) are only valid while no two equal hyperscores meet at a reported rank; isoleucine /
+    leucine twins (identical masses and fragments) tie exactly, so those spectra must come back through the exact heap
+    replay — and still equal the oracle, whose order is the reference's heap layout."""
+    monkeypatch.delenv("SAGE_HIP_EXACT", raising=False)
+    fasta = synthetic_fasta(60, seed=17)
+    twin = fasta.replace("I", "#").replace("L", "I").replace("#", "L").replace(">sp|SYN", ">sp|TWN")
+    params = DatabaseParameters(bucket_size=1024, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                                static_mods={"C": 57.0215})
+    w = World(fasta + twin, params, {}, 300, seed=29)
+    n, t = w.check(ScorerParams(report_psms=2), "I/L twins, narrow")
+    assert t["n_retry"] > 50
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -200.0, 200.0), report_psms=3), "I/L twins, large windows",
+                   batch=w.batch.subset(np.arange(0, 300, 3)))
+    assert t["n_retry"] > 10 and t["n_wide"] > 0
+    n, t = w.check(ScorerParams(chimera=True, report_psms=3), "I/L twins, chimera")
+    assert t["n_retry"] > 50
+    monkeypatch.setenv("SAGE_HIP_EXACT", "1")  # every trim replays the heap: no retries by construction
+    n, t = w.check(ScorerParams(report_psms=2), "I/L twins, exact mode")
+    assert t["n_retry"] == 0
 
 
 def test_index_built_on_device(small_world):
