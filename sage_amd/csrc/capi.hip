@@ -72,6 +72,8 @@ struct SageDeviceDb {
     std::vector<float> h_pep_mono;    // host copy: window-size estimate at batch upload
     DevBuf<SageTheoretical> tm_frag;  // tile-major copy + position table for the large-window kernel
     DevBuf<uint32_t> tm_lut;
+    DevBuf<SageTheoretical> tm2_frag; // small-tile copy + table for the narrow kernel's per-peak lookups
+    DevBuf<uint32_t> tm2_lut;
     uint32_t max_ions = 0;
     DevDbView view{};
     uint64_t bytes = 0;
@@ -206,6 +208,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     const float lut_scale = 256.0f;
     uint32_t lut_stride = 0;
     uint64_t nf = v->n_fragments;
+    std::vector<uint64_t> host_pm_off;  // fragment offset of every peptide (either branch)
     d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
     if (!v->fragments) {
         // ---- Parameters::build_from_peptides (database.rs:265-346) on the device: index_build.hip ----
@@ -234,15 +237,17 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         HIP_TRY(d->ions.alloc(ion_off[np]));
         HIP_TRY(d->pm_frag.alloc(nf));
         HIP_TRY(d->tm_frag.alloc(nf + 2));
+        hipError_t be = (hipError_t)generate_fragments_on_device(np, nk, d_kinds.p, d_seq_off.p, d_seq.p, d_mods.p, d_nterm.p, d->pep_mono.p,
+                                                                v->min_ion_index, d->ion_off.p, d->pm_off.p, d->ions.p, d->pm_frag.p, nullptr);
         uint32_t* lut_p = nullptr;
-        const hipError_t be = (hipError_t)build_index_on_device(np, nk, d_kinds.p, d_seq_off.p, d_seq.p, d_mods.p, d_nterm.p,
-                                                                d->pep_mono.p, v->min_ion_index, d->ion_off.p, d->pm_off.p, nf, tile_shift,
-                                                                (uint32_t)n_tiles, d_tile_off.p, lut_scale, d->ions.p, d->pm_frag.p,
-                                                                d->tm_frag.p, &lut_p, &lut_stride, nullptr);
+        if (be == hipSuccess)
+            be = (hipError_t)build_tile_copy_on_device(d->pm_frag.p, nf, tile_shift, (uint32_t)n_tiles, d_tile_off.p, lut_scale,
+                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr);
         if (be != hipSuccess)
             return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
         d->tm_lut.p = lut_p;
         d->tm_lut.n = (size_t)n_tiles * lut_stride;
+        host_pm_off.swap(pm_off);
         HIP_TRY(d->pep_info.upload(info.data(), np));
     } else {
         // group IndexedDatabase.fragments by peptide (counting sort): tiles are runs of 2^tile_shift consecutive peptides
@@ -309,6 +314,33 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         HIP_TRY(d->ions.upload(ions.data(), ions.size()));
         HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
         HIP_TRY(d->pep_info.upload(info.data(), np));
+        host_pm_off.swap(pm_off);
+    }
+    {
+        // small-tile copy for the narrow kernel (device_types.h: tm2_*), sorted on the device from the peptide-major list
+        uint32_t tile2_shift = 12;
+        if (const char* e = getenv("SAGE_HIP_TILE2_SHIFT")) tile2_shift = (uint32_t)std::min(16, std::max(6, atoi(e)));
+        const float lut2_scale = 32.0f;  // (a power of two, like lut_scale)
+        const uint64_t n_tiles2 = std::max<uint64_t>(1, (np + (1ull << tile2_shift) - 1) >> tile2_shift);
+        std::vector<uint64_t> tile2_off(n_tiles2 + 1, 0);
+        for (uint64_t t = 0; t < n_tiles2; t++) tile2_off[t + 1] = host_pm_off[std::min<uint64_t>(np, (t + 1) << tile2_shift)];
+        DevBuf<uint64_t> d_tile2_off;
+        HIP_TRY(d_tile2_off.upload(tile2_off.data(), n_tiles2 + 1));
+        HIP_TRY(d->tm2_frag.alloc(nf + 2));
+        uint32_t* lut2_p = nullptr;
+        uint32_t lut2_stride = 0;
+        const hipError_t be = (hipError_t)build_tile_copy_on_device(d->pm_frag.p, nf, tile2_shift, (uint32_t)n_tiles2, d_tile2_off.p,
+                                                                    lut2_scale, d->tm2_frag.p, &lut2_p, &lut2_stride, nullptr);
+        if (be != hipSuccess)
+            return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
+        d->tm2_lut.p = lut2_p;
+        d->tm2_lut.n = (size_t)n_tiles2 * lut2_stride;
+        d->view.tm2_frag = d->tm2_frag.p;
+        d->view.tm2_lut = d->tm2_lut.p;
+        d->view.tile2_shift = tile2_shift;
+        d->view.n_tiles2 = (uint32_t)n_tiles2;
+        d->view.lut2_stride = lut2_stride;
+        d->view.lut2_scale = lut2_scale;
     }
     d->max_ions = max_ions;
     d->view.pep_mono = d->pep_mono.p;
@@ -329,7 +361,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
     d->bytes = d->pep_mono.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
-               d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes();
+               d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes() + d->tm2_frag.bytes() + d->tm2_lut.bytes();
     *out = d.release();
     return SAGE_HIP_OK;
 }

@@ -30,6 +30,14 @@ struct DevDbView {
     uint32_t n_tiles;
     uint32_t lut_stride;
     float lut_scale;
+    // a second tile-major copy with SMALL tiles (2^tile2_shift peptides, coarser cells) for the narrow kernel's per-peak
+    // lookups: a +-10 ppm window holds a few hundred candidates, and a run of a small tile is ~3 entries instead of ~30
+    const SageTheoretical* tm2_frag;  // [nf + 2]
+    const uint32_t* tm2_lut;          // [n_tiles2 * lut2_stride]
+    uint32_t tile2_shift;
+    uint32_t n_tiles2;
+    uint32_t lut2_stride;
+    float lut2_scale;
     uint64_t nf;
     uint8_t ion_kinds[8];
     uint32_t n_kinds;
@@ -141,12 +149,14 @@ size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t ma
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 uint32_t queries_per_spectrum(const DevScorer& sc);
-// index_build.hip (returns a hipError_t)
-int build_index_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,
-                          const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
-                          const uint64_t* d_ion_off, const uint64_t* d_pm_off, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
-                          const uint64_t* d_tile_off, float lut_scale, float* d_ions, SageTheoretical* d_pm_frag,
-                          SageTheoretical* d_tm_frag, uint32_t** d_lut_out, uint32_t* lut_stride_out, void* stream);
+// index_build.hip (both return a hipError_t)
+int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,
+                                 const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
+                                 const uint64_t* d_ion_off, const uint64_t* d_pm_off, float* d_ions, SageTheoretical* d_pm_frag,
+                                 void* stream);
+int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
+                              const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
+                              uint32_t* lut_stride_out, void* stream);
 // process.hip
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
 int process_kernel_prepare(size_t max_lds_bytes);

@@ -143,18 +143,27 @@ __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheor
         if (_e != hipSuccess) return _e; \
     } while (0)
 
-// Returns a hipError_t.  All pointers are device pointers; ions / pm_frag / tm_frag are allocated by the caller, tm_lut by this
-// function (its size depends on the largest fragment m/z).
-int build_index_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,
-                          const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
-                          const uint64_t* d_ion_off, const uint64_t* d_pm_off, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
-                          const uint64_t* d_tile_off, float lut_scale, float* d_ions, SageTheoretical* d_pm_frag,
-                          SageTheoretical* d_tm_frag, uint32_t** d_lut_out, uint32_t* lut_stride_out, void* stream_) {
+// Both functions return a hipError_t; all pointers are device pointers.
+
+// IonSeries of every peptide and kind -> d_ions; the stored subset -> d_pm_frag (peptide-major).  Buffers are the caller's.
+int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,
+                                 const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
+                                 const uint64_t* d_ion_off, const uint64_t* d_pm_off, float* d_ions, SageTheoretical* d_pm_frag,
+                                 void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const uint64_t nthreads = np * nk;
     if (nthreads) hipLaunchKernelGGL(ion_kernel, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, stream, np, nk, d_kinds,
                                      d_seq_off, d_seq, d_mods, d_nterm, d_mono, min_ion_index, d_ion_off, d_pm_off, d_ions, d_pm_frag);
-    BUILD_TRY(hipGetLastError());
+    return (int)hipGetLastError();
+}
+
+// A tile-major copy of the peptide-major list for tiles of 2^tile_shift peptides (d_tile_off: [n_tiles + 1] fragment
+// offsets of the tile boundaries) + its position table at `lut_scale` cells per Da.  d_tm_frag ([nf + 2]) is the caller's,
+// the table is allocated here (its width depends on the largest fragment m/z).
+int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
+                              const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
+                              uint32_t* lut_stride_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     // largest finite fragment m/z -> table width
     uint32_t* d_max = nullptr;
     BUILD_TRY(hipMalloc((void**)&d_max, 256 * 4));

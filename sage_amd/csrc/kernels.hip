@@ -558,13 +558,13 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                     }
                 }
                 if (PROBE && q.first < q.end) {
-                    // One lane per (peak, fragment charge) window: two reads of the tile's position table give the run of
-                    // index entries inside the fragment tolerance, the few entries of the run are tested against the
-                    // precursor window (database.rs:526-533) and hits bump the LDS counters.  ~10 entries per window
+                    // One lane per (peak, fragment charge) window: two reads of the (small) tile's position table give the run
+                    // of index entries inside the fragment tolerance, the few entries of the run are tested against the
+                    // precursor window (database.rs:526-533) and hits bump the LDS counters.  ~3 entries per window
                     // instead of a binary search per fragment of every candidate peptide.
-                    const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;
-                    const float cell_max = (float)(db.lut_stride - 1);
-                    const uint32_t t0 = q.first >> db.tile_shift, t1 = (q.end - 1) >> db.tile_shift;
+                    const uint4* __restrict__ frag2 = (const uint4*)db.tm2_frag;
+                    const float cell_max = (float)(db.lut2_stride - 1);
+                    const uint32_t t0 = q.first >> db.tile2_shift, t1 = (q.end - 1) >> db.tile2_shift;
                     auto test2 = [&](const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo, float hi) {
                         const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
                         if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= q.first && e.x < q.end) { cnt.add(e.x - left, 1); acc++; }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                     };
                     const uint32_t nprobe = P * nfz;
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
-                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
+                        const uint32_t* __restrict__ lut = db.tm2_lut + (size_t)t * db.lut2_stride;
                         // the table reads of the next 64 windows are issued before this trip's entries are tested
                         float lo = 1.0f, hi = 0.0f, lo_n = 1.0f, hi_n = 0.0f;
                         uint32_t p0 = 0, p1 = 0, p0_n = 0, p1_n = 0;
@@ -584,11 +584,11 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                                 fhi = L.win_hi[(size_t)fz * b.pcap + i];
                             }
                             // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
-                            float cl = floorf(flo * db.lut_scale), ch = floorf(fhi * db.lut_scale) + 1.0f;
+                            float cl = floorf(flo * db.lut2_scale), ch = floorf(fhi * db.lut2_scale) + 1.0f;
                             cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
                             ch = ch > 0.0f ? ch : 0.0f;
-                            uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut_stride - 1;
-                            uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut_stride - 1;
+                            uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut2_stride - 1;
+                            uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut2_stride - 1;
                             if (!(flo <= fhi)) icl = ich = 0;
                             fp0 = lut[icl];
                             fp1 = lut[ich];
