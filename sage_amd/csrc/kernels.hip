@@ -1500,38 +1500,40 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
         plut[b] = lo;
     }
 }
+// Tolerance::bounds (mass.rs:21-35) with one division instead of two when the tolerance is symmetric (lo == -hi):
+// center * -h == -(center * h) and x / 1e6 is sign-symmetric, so the lower delta is exactly the negated upper one.
+__device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, float center, float& lo, float& hi) {
+    if (symmetric && t.kind == 0) {
+        const float d = center * t.hi / 1000000.0f;
+        lo = center + -d;
+        hi = center + d;
+    } else {
+        tol_bounds(t, center, lo, hi);
+    }
+}
+
 __device__ __forceinline__ int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w,
-                                               float center, const Tol& tol) {
-    float lo, hi;
-    tol_bounds(tol, center, lo, hi);
+                                               float lo, float hi) {
     float fb = floorf(lo * inv_w);
     fb = fb > 0.0f ? fb : 0.0f;  // also maps NaN to 0
     const uint32_t bin = fb < (float)(PLUT_BINS - 1) ? (uint32_t)fb : PLUT_BINS - 1;
     // Every peak with lo <= mass <= hi lies at or after plut[bin] (all earlier masses are < bin * W <= lo), and the
     // reference's scan over [left, right) keeps exactly those peaks (spectrum.rs:147-157: `mass >= lo && mass <= hi`,
-    // most intense wins, the last one on ties).  Walk forward four peaks at a time — their LDS reads are independent —
-    // until a mass exceeds hi (masses ascend).
+    // most intense wins, the last one on ties).  Walk forward two peaks at a time — their LDS reads are independent —
+    // until a mass exceeds hi (masses ascend); intensities are only read for peaks inside the window.
     int best = -1;
     float max_int = 0.0f;
-    for (uint32_t a = plut[bin]; a < P; a += 4) {
-        float m[4], it[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const uint32_t i = a + j < P ? a + j : P - 1;
-            m[j] = pm[i];
-            it[j] = pi[i];
+    for (uint32_t a = plut[bin]; a < P; a += 2) {
+        const float m0 = pm[a], m1 = pm[a + 1 < P ? a + 1 : a];
+        if (m0 >= lo && m0 <= hi) {
+            const float it = pi[a];
+            if (it >= max_int) { max_int = it; best = (int)a; }
         }
-        bool past = false;
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
-            const bool in = a + j < P && m[j] >= lo && m[j] <= hi;
-            if (in && it[j] >= max_int) {
-                max_int = it[j];
-                best = (int)(a + j);
-            }
-            past = past || (a + j < P && order_key(m[j]) > order_key(hi));
+        if (a + 1 < P && m1 >= lo && m1 <= hi) {
+            const float it = pi[a + 1];
+            if (it >= max_int) { max_int = it; best = (int)(a + 1); }
         }
-        if (past) break;
+        if (m0 > hi || m1 > hi || !(hi == hi)) break;
     }
     return best;
 }
@@ -1606,7 +1608,7 @@ __device__ __forceinline__ bool quick_gt(const QuickKey& a, const QuickKey& b) {
 
 __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                      const double* __restrict__ lnfact_table, uint32_t lnfact_n,
-                                                     uint32_t tcap, SageFeature* __restrict__ out,
+                                                     SageFeature* __restrict__ out,
                                                      uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
     // keep != nullptr: Scorer::quick_score with prefilter_low_memory (scoring.rs:270-289) instead of build_features
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1616,17 +1618,12 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     // LDS carve
     double* s_sorted = (double*)smem;                         // [64] hyperscores by rank
     long long* s_key = (long long*)(smem + 64 * 8);           // [64] sort keys by lane
-    unsigned long long* s_ionbase = (unsigned long long*)(smem + 128 * 8);  // [64] ion table offset per candidate
-    uint32_t* s_incl = (uint32_t*)(smem + 192 * 8);           // [64] inclusive item prefix per candidate
-    uint32_t* s_nfz = s_incl + 64;                            // [64] fragment charges per candidate
-    float* pm = (float*)(s_nfz + 64);                         // [pcap] peak masses
+    float* pm = (float*)(smem + 128 * 8);                     // [pcap] peak masses
     float* pi = pm + b.pcap;                                  // [pcap] peak intensities
-    float* term = pi + b.pcap;                                // [tcap] ppm term per matched item
-    uint16_t* res = (uint16_t*)(term + tcap);                 // [tcap] matched peak index per item
-    uint8_t* rm = (uint8_t*)(res + tcap);                     // [pcap] chimera: peak selected by the winner
+    uint8_t* rm = (uint8_t*)(pi + b.pcap);                    // [pcap] chimera: peak selected by the winner
     uint8_t* rm2 = rm + b.pcap;
-    uint32_t* plut = (uint32_t*)(smem + (((size_t)(rm2 + b.pcap - smem) + 3) & ~(size_t)3));  // [PLUT_BINS] peak position table
-    uint32_t* mbits = plut + PLUT_BINS;                       // [tcap / 32 + 1] one bit per item of the chunk: matched a peak
+    uint32_t* plut = (uint32_t*)(smem + (((size_t)(rm2 + b.pcap - smem) + 7) & ~(size_t)7));  // [PLUT_BINS] peak position table
+    QuickKey* qkeys = (QuickKey*)(plut + PLUT_BINS);          // [64] quick_score only
 
     if (w.status[spec] != ST_OK) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -1659,18 +1656,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         info = db.pep_info[pep];
         calc = db.pep_mono[pep];
     }
-    // item bookkeeping: n_items per candidate and its inclusive prefix over lanes
-    const uint32_t n_items = valid ? db.n_kinds * lm1 * nfz : 0;
-    uint32_t incl = n_items;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl += t;
-    }
-    const uint32_t excl = incl - n_items;
-    s_incl[lane] = incl;
-    s_ionbase[lane] = ion_base;
-    s_nfz[lane] = nfz ? nfz : 1;
+    const uint32_t n_items = valid ? db.n_kinds * lm1 * nfz : 0;  // (ion, fragment charge) pairs of this candidate
 
     const double lambda = (double)w.totals[2 * spec] / (double)w.totals[2 * spec + 1];  // scoring.rs:499
     const float mzp = b.precursor_mz[spec] - PROTON;                                   // scoring.rs:502
@@ -1678,12 +1664,12 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
     float ims = 0.0f;
     if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
     const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
-    const uint32_t total_items = __shfl(incl, 63, 64);
     __syncthreads();
     pc.mark(0);
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
     const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
+    const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
@@ -1699,108 +1685,54 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         s.summed_b = s.summed_y = 0.0f;
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
-        // ---- score_candidate over chunks of candidates whose items fit in res[] ----
-        uint32_t base = 0;  // item offset where the current chunk starts
-        while (base < total_items) {
-            // chunk = candidates with excl >= base and incl <= base + tcap (contiguous lanes)
-            const bool in_chunk = n_items && excl >= base && incl - base <= tcap;
-            uint32_t chunk_items = in_chunk ? incl - base : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(chunk_items, off, 64);
-                chunk_items = o > chunk_items ? o : chunk_items;
-            }
-            if (chunk_items == 0) break;  // a single candidate larger than tcap cannot happen (tcap >= max items)
-            // phase A0: gather every item's ion mass into term[] (the loads of different trips are independent, so several
-            //     are in flight per lane).  Item -> candidate: a lane's items grow by 64 per trip, so its candidate index
-            //     only moves forward — one binary search for the first item, then a short walk.
-            uint32_t cw = 0;  // candidate of this lane's current item: first c with s_incl[c] > base + t
-            {
-                const uint32_t g = base + lane;
-#pragma unroll
-                for (uint32_t step = 32; step; step >>= 1) {
-                    const uint32_t probe = cw + step;
-                    cw = (probe <= 64 && s_incl[probe - 1] <= g) ? probe : cw;
-                }
-            }
-            for (uint32_t i = lane; i < (chunk_items + 31) / 32 + 1; i += WAVE) mbits[i] = 0;
-            for (uint32_t tb = 0; tb < chunk_items; tb += 8 * WAVE) {  // eight trips per batch: their global loads overlap
-                float v[8];
-                uint32_t zq[8];
-#pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t t = tb + j * WAVE + lane;
-                    v[j] = 0.0f;
-                    zq[j] = 1;
-                    if (t < chunk_items) {
-                        const uint32_t g = base + t;
-                        while (cw < 63 && s_incl[cw] <= g) cw++;
-                        const uint32_t local = g - (cw ? s_incl[cw - 1] : 0);
-                        const uint32_t cz = s_nfz[cw];
-                        const uint32_t ion = local / cz;
-                        zq[j] = local - ion * cz + 1;  // fragment charge
-                        v[j] = db.ions[s_ionbase[cw] + ion];
-                    }
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t t = tb + j * WAVE + lane;
-                    if (t < chunk_items) {
-                        term[t] = v[j];
-                        res[t] = (uint16_t)zq[j];
-                    }
-                }
-            }
-            __syncthreads();
-            pc.mark(5);
-            for (uint32_t t = lane; t < chunk_items; t += WAVE) {
-                const float mz = term[t] / (float)res[t];
-                const int pk = select_peak_lut(pm, pi, P, plut, inv_w, mz, sc.fragment_tol);
-                if (pk >= 0) {
-                    const float peak_mass = pm[pk];
-                    res[t] = (uint16_t)pk;
-                    // the per-match ppm term of scoring.rs:719-720; only its accumulation is order-sensitive
-                    term[t] = pi[pk] * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
-                    atomicOr(&mbits[t >> 5], 1u << (t & 31u));
-                }
-            }
-            __syncthreads();
-            pc.mark(1);
-            // phase B: one lane per candidate accumulates ITS matched items in (kind, index, charge) order — only the
-            //     matched ones are visited, through the chunk's match bitmap
-            if (in_chunk && n_items) {
+        {
+            // ---- score_candidate (scoring.rs:699-759), one lane per candidate, in the reference's (kind, index, charge)
+            //      order; the candidate's ion masses are fetched four ahead of their use, peaks are matched through the
+            //      direct-index table.  (SAGE_HIP_DEBUG_FLAGS=8 selects the item-parallel two-phase variant below.)
+            if (valid && lm1) {
                 Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
-                const uint32_t t0 = excl - base, t1 = incl - base;  // this candidate's items
-                const uint32_t per_kind = lm1 * nfz;
-                for (uint32_t wd = t0 >> 5; wd <= (t1 - 1) >> 5; wd++) {
-                    uint32_t m = mbits[wd];
-                    if (wd == (t0 >> 5)) m &= ~0u << (t0 & 31u);
-                    if (wd == ((t1 - 1) >> 5) && (t1 & 31u)) m &= ~0u >> (32u - (t1 & 31u));
-                    while (m) {
-                        const uint32_t t = (wd << 5) + (uint32_t)__ffs((int)m) - 1;
-                        m &= m - 1;
-                        const uint32_t local = t - t0;
-                        const uint32_t k = local / per_kind;
-                        const uint32_t idx = (local - k * per_kind) / nfz;
-                        const float peak_intensity = pi[res[t]];
-                        s.ppm_difference += term[t];
-                        if ((nterm_mask >> k) & 1u) {
-                            s.matched_b += 1;
-                            s.summed_b += peak_intensity;
-                            run_matched(b_run, idx);
-                        } else {
-                            s.matched_y += 1;
-                            s.summed_y += peak_intensity;
-                            run_matched(y_run, idx);
+                const float* __restrict__ my = db.ions + ion_base;
+                const uint32_t nions = db.n_kinds * lm1;
+                float nxt[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) nxt[u] = u < nions ? my[u] : 0.0f;
+                uint32_t kind_i = 0, idx = 0;  // ion j = kind_i * lm1 + idx
+                for (uint32_t j0 = 0; j0 < nions; j0 += 4) {
+                    float cur[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        cur[u] = nxt[u];
+                        nxt[u] = j0 + 4 + u < nions ? my[j0 + 4 + u] : 0.0f;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if (j0 + u >= nions) break;
+                        const bool nterm_kind = (nterm_mask >> kind_i) & 1u;
+                        for (uint32_t c = 1; c < mfc; c++) {
+                            const float mz = c == 1 ? cur[u] : cur[u] / (float)c;  // (x / 1.0 == x)
+                            float flo, fhi;
+                            tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                            const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
+                            if (pk < 0) continue;
+                            const float peak_mass = pm[pk], peak_intensity = pi[pk];
+                            s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
+                            if (nterm_kind) {
+                                s.matched_b += 1;
+                                s.summed_b += peak_intensity;
+                                run_matched(b_run, idx);
+                            } else {
+                                s.matched_y += 1;
+                                s.summed_y += peak_intensity;
+                                run_matched(y_run, idx);
+                            }
                         }
+                        if (++idx == lm1) { idx = 0; kind_i++; }
                     }
                 }
                 s.longest_b = b_run.longest;
                 s.longest_y = y_run.longest;
             }
-            __syncthreads();
-            pc.mark(2);
-            base += chunk_items;
+            pc.mark(1);
         }
         double h = 0.0;
         bool pass = false;
@@ -1814,7 +1746,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
             // largest elements.  heap.rs compares with `<` / `>`, i.e. the DERIVED PartialOrd of Score — lexicographic
             // in field order, peptide first (scoring.rs:17-30) — not its hyperscore Ord.  The set of the k largest does
             // not depend on the heap's internal order, so rank each passing candidate by that order directly.
-            QuickKey* qk = (QuickKey*)term;  // (term[] / res[] are free once the candidates are scored)
+            QuickKey* qk = qkeys;
             QuickKey mine;
             mine.peptide = pep; mine.matched_b = s.matched_b; mine.matched_y = s.matched_y;
             mine.summed_b = s.summed_b; mine.summed_y = s.summed_y; mine.longest_b = s.longest_b; mine.longest_y = s.longest_y;
@@ -1920,7 +1852,8 @@ __global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc,
         const uint32_t wl = (uint32_t)__ffsll((long long)wmask) - 1;
         const uint32_t wmfc = __shfl(mfc, wl, 64);
         const uint32_t w_items = __shfl(n_items, wl, 64);
-        const unsigned long long w_base = s_ionbase[wl];
+        const unsigned long long w_base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(ion_base >> 32), (int)wl, 64) << 32) |
+                                          (uint32_t)__shfl((int)(uint32_t)ion_base, (int)wl, 64);
         const float* wions = db.ions + w_base;
         remove_matched_peaks_dev(pm, pi, rm, rm2, P, tic, wions, w_items, wmfc, sc.fragment_tol);
     }
@@ -2022,14 +1955,9 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
-uint32_t rescore_item_cap(const DevBatchView& b, uint32_t max_ions) {
-    // one candidate's items must always fit: (ions of the longest peptide) x (fragment charges)
-    const uint32_t need = max_ions * (b.fzcap ? b.fzcap : 1);
-    return need > 1024 ? need : 1024;
-}
-size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t max_ions) {
-    size_t n = 192 * 8 + 128 * 4 + (size_t)b.pcap * 8 + (size_t)rescore_item_cap(b, max_ions) * 6 + (size_t)b.pcap * 2;
-    n = ((n + 3) & ~(size_t)3) + PLUT_BINS * 4 + ((size_t)rescore_item_cap(b, max_ions) / 32 + 1) * 4;
+size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t) {
+    size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
+    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + 64 * sizeof(QuickKey);
     return (n + 15) & ~(size_t)15;
 }
 
@@ -2062,7 +1990,7 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
     hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions), (hipStream_t)stream, db,
-                       sc, b, w, lnfact_table, lnfact_n, rescore_item_cap(b, max_ions), out, out_count, keep);
+                       sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
