@@ -721,10 +721,8 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
 //   assemble : one wavefront per spectrum concatenates / folds the per-query lists exactly as
 //              scoring.rs:384-462 does and writes the final preliminary list.
 // Same predicate as database.rs:526-533, so counts — and everything downstream — are identical.
-constexpr uint32_t TILE_THREADS = 512;
-constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
+constexpr uint32_t TILE_WAVES_MAX = 16;  // workgroups of 512 threads (two per CU, 2^15-peptide tiles) or 1024 (one per CU, 2^16)
 constexpr uint32_t GROUP = 8;                         // lanes per (peak, fragment charge) window
-constexpr uint32_t NGROUP = TILE_THREADS / GROUP;     // windows in flight per pass
 constexpr uint32_t HIST_BINS = 64;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
@@ -734,7 +732,7 @@ struct TileLds {
     float* win_lo;      // [fzcap * pcap]
     float* win_hi;
     uint32_t* hist;     // [HIST_BINS] non-empty slots of the query so far, by matched count
-    uint32_t* wsum;     // [TILE_WAVES]
+    uint32_t* wsum;     // [TILE_WAVES_MAX]
     uint32_t* sh;       // [16] workgroup-shared scalars
 };
 __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem) {
@@ -750,7 +748,7 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     if (l) l->hist = (uint32_t*)(smem + off);
     off += HIST_BINS * 4;
     if (l) l->wsum = (uint32_t*)(smem + off);
-    off += TILE_WAVES * 4;
+    off += TILE_WAVES_MAX * 4;
     if (l) l->sh = (uint32_t*)(smem + off);
     off += 16 * 4;
     return (off + 15) & ~(size_t)15;
@@ -766,7 +764,6 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
     return (z - si.z0) * n_iso + (uint32_t)(iso - (fold ? sc.min_isotope_err : 0));
 }
 
-constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group whose table reads are in flight together
 
 __device__ __forceinline__ void tile_hit(const TileLds& L, uint32_t x, uint32_t& acc) {
     // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
@@ -782,7 +779,11 @@ __device__ __forceinline__ void tile_test2(const TileLds& L, const uint4 e, uint
 }
 
 // (parameters through memory: ~300 bytes of by-value arguments would all be live in SGPRs and spill)
+template <uint32_t TILE_THREADS>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams* __restrict__ kp) {
+    constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
+    constexpr uint32_t NGROUP = TILE_THREADS / GROUP;  // windows in flight per pass
+    constexpr uint32_t PROBE_CACHE = 4096 / TILE_THREADS;  // windows per 8-lane group whose table reads are in flight together
     extern __shared__ __align__(16) unsigned char smem[];
     const DevDbView& db = kp->db;
     const DevScorer& sc = kp->sc;
@@ -1948,8 +1949,10 @@ size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView&
     return tile_lds_layout(db.tile_shift, b, nullptr, nullptr);
 }
 int tile_kernel_prepare(size_t max_lds_bytes) {
-    return (int)hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)max_lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)tile_count_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)tile_count_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    return (int)e;
 }
 uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
@@ -1971,8 +1974,12 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
-                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+    if (db.tile_shift >= 16)
+        hipLaunchKernelGGL(tile_count_kernel<1024>, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(1024),
+                           tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+    else
+        hipLaunchKernelGGL(tile_count_kernel<512>, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(512),
+                           tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query while queries are fewer than wavefront slots, else a lane per query
