@@ -201,7 +201,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         info[i] = (uint32_t)len | ((uint32_t)(v->decoy[i] ? 1 : 0) << 16) | ((uint32_t)v->missed_cleavages[i] << 24);
     }
     uint32_t tile_shift = 15;
-    if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(16, std::max(11, atoi(e)));
+    if (const char* e = getenv("SAGE_HIP_TILE_SHIFT")) tile_shift = (uint32_t)std::min(15, std::max(11, atoi(e)));
     const uint64_t n_tiles = std::max<uint64_t>(1, (np + (1ull << tile_shift) - 1) >> tile_shift);
     // 1/256 Da cells.  The scale is a power of two, so `m/z * scale` is exact in f32 and a fragment-tolerance window
     // [lo, hi] maps to the cell range [floor(lo*scale), floor(hi*scale)] with no safety margin.
@@ -698,7 +698,9 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore, boo
     HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, CTR_COUNT * 4, s->stream));
     HIP_TRY(hipEventRecord(s->ev[0], s->stream));
     launch_prelim(s->db->view, sc, view, w, s->stream);
+    HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
     launch_prelim_tile(s->db->view, sc, view, w, s->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], s->stream));
     if (with_rescore)
         launch_rescore(s->db->view, sc, view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,

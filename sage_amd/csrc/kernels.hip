@@ -721,8 +721,10 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
 //   assemble : one wavefront per spectrum concatenates / folds the per-query lists exactly as
 //              scoring.rs:384-462 does and writes the final preliminary list.
 // Same predicate as database.rs:526-533, so counts — and everything downstream — are identical.
-constexpr uint32_t TILE_WAVES_MAX = 16;  // workgroups of 512 threads (two per CU, 2^15-peptide tiles) or 1024 (one per CU, 2^16)
+constexpr uint32_t TILE_THREADS = 512;
+constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
 constexpr uint32_t GROUP = 8;                         // lanes per (peak, fragment charge) window
+constexpr uint32_t NGROUP = TILE_THREADS / GROUP;     // windows in flight per pass
 constexpr uint32_t HIST_BINS = 64;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
@@ -732,7 +734,7 @@ struct TileLds {
     float* win_lo;      // [fzcap * pcap]
     float* win_hi;
     uint32_t* hist;     // [HIST_BINS] non-empty slots of the query so far, by matched count
-    uint32_t* wsum;     // [TILE_WAVES_MAX]
+    uint32_t* wsum;     // [TILE_WAVES]
     uint32_t* sh;       // [16] workgroup-shared scalars
 };
 __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem) {
@@ -748,7 +750,7 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     if (l) l->hist = (uint32_t*)(smem + off);
     off += HIST_BINS * 4;
     if (l) l->wsum = (uint32_t*)(smem + off);
-    off += TILE_WAVES_MAX * 4;
+    off += TILE_WAVES * 4;
     if (l) l->sh = (uint32_t*)(smem + off);
     off += 16 * 4;
     return (off + 15) & ~(size_t)15;
@@ -764,6 +766,7 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
     return (z - si.z0) * n_iso + (uint32_t)(iso - (fold ? sc.min_isotope_err : 0));
 }
 
+constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group whose table reads are in flight together
 
 __device__ __forceinline__ void tile_hit(const TileLds& L, uint32_t x, uint32_t& acc) {
     // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
@@ -779,11 +782,7 @@ __device__ __forceinline__ void tile_test2(const TileLds& L, const uint4 e, uint
 }
 
 // (parameters through memory: ~300 bytes of by-value arguments would all be live in SGPRs and spill)
-template <uint32_t TILE_THREADS>
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams* __restrict__ kp) {
-    constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
-    constexpr uint32_t NGROUP = TILE_THREADS / GROUP;  // windows in flight per pass
-    constexpr uint32_t PROBE_CACHE = 4096 / TILE_THREADS;  // windows per 8-lane group whose table reads are in flight together
     extern __shared__ __align__(16) unsigned char smem[];
     const DevDbView& db = kp->db;
     const DevScorer& sc = kp->sc;
@@ -1114,6 +1113,17 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     }
 }
 
+// Candidate chains are walked defensively: a link outside the arena or an absurd number of hops (a count kernel that did
+// not run, a stale record) ends the walk instead of hanging the GPU.
+constexpr uint32_t MAX_SEGMENTS = 1u << 18;
+__device__ __forceinline__ bool seg_ok(const DevWork& w, uint32_t seg, uint32_t hops) {
+    return seg != NONE32 && (uint64_t)seg + 4 <= w.arena_cap && hops < MAX_SEGMENTS;
+}
+__device__ __forceinline__ uint32_t seg_len(const DevWork& w, uint32_t seg, uint32_t n) {
+    const uint64_t room = (uint64_t)w.arena_cap - seg - 4;
+    return (uint64_t)n <= room ? n : (uint32_t)room;
+}
+
 // strided sift_down (heap.rs:40-60): element i of this lane's heap lives at hp[i * 64]
 template <typename K>
 __device__ __forceinline__ void sift_down_strided(K* hp, uint32_t len, uint32_t index, K moving) {
@@ -1224,7 +1234,7 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
     // costs a dependent load.
     uint32_t nextseg = live ? rec.head : NONE32;  // header position of the next segment
     uint32_t pos = 0;                               // position of the cell in flight (pf)
-    uint32_t rem = 0, q = 4, tb = 0;                // entries left in the segment, next entry of the current cell
+    uint32_t rem = 0, q = 4, tb = 0, hops = 0;      // entries left in the segment, next entry of the current cell
     bool done = nextseg == NONE32;
     uint4 cell = make_uint4(0u, 0u, 0u, 0u), pf = make_uint4(0u, 0u, 0u, 0u);
     if (!done) {
@@ -1242,15 +1252,16 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
         uint32_t e = 0;
         if (!done) {
             if (rem == 0) {  // the next cell is a header (or the chain ends)
-                if (nextseg == NONE32) {
+                if (!seg_ok(w, nextseg, hops++)) {
                     done = true;
                 } else {
                     if (nextseg != pos) {  // chunk boundary: not the cell in flight
                         pos = nextseg;
                         pf = *(const uint4*)(w.arena + pos);
                     }
+                    const uint32_t at = pos;
                     take_cell();
-                    nextseg = cell.x; rem = cell.y; tb = cell.z;
+                    nextseg = cell.x; rem = seg_len(w, at, cell.y); tb = cell.z;
                     q = 4;
                 }
             } else {
@@ -1324,10 +1335,11 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
         eq_seen += (uint32_t)__popcll(eqm);
     };
     offer(lane < k ? w.seeds[qid * 64 + lane] : 0u, rec.left + lane);  // the first k slots
-    for (uint32_t seg = rec.head; seg != NONE32;) {
+    for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
         const uint4 hdr = *(const uint4*)(w.arena + seg);
-        for (uint32_t j = 0; j < hdr.y; j += WAVE) {
-            const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+        const uint32_t n = seg_len(w, seg, hdr.y);
+        for (uint32_t j = 0; j < n; j += WAVE) {
+            const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
             offer(e >> 16, hdr.z + (e & 0xFFFFu));
         }
         seg = hdr.x;
@@ -1354,10 +1366,11 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
     if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
         uint32_t h = seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u;
         wh32_build(h, k);
-        for (uint32_t seg = rec.head; seg != NONE32;) {
+        for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
             const uint4 hdr = *(const uint4*)(w.arena + seg);
-            for (uint32_t j = 0; j < hdr.y; j += WAVE) {
-                const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+            const uint32_t n = seg_len(w, seg, hdr.y);
+            for (uint32_t j = 0; j < n; j += WAVE) {
+                const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
                 const uint32_t c = e >> 16;
                 const uint32_t v = (c << K32_SLOT_BITS) | (hdr.z + (e & 0xFFFFu) - rec.left);
                 // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
@@ -1377,10 +1390,11 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
         h.lo = (uint32_t)sv;
         h.hi = (uint32_t)(sv >> 32);
         wh_build(h, k);
-        for (uint32_t seg = rec.head; seg != NONE32;) {
+        for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
             const uint4 hdr = *(const uint4*)(w.arena + seg);
-            for (uint32_t j = 0; j < hdr.y; j += WAVE) {
-                const uint32_t e = j + lane < hdr.y ? w.arena[seg + 4 + j + lane] : 0u;
+            const uint32_t n = seg_len(w, seg, hdr.y);
+            for (uint32_t j = 0; j < n; j += WAVE) {
+                const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
                 const uint32_t c = e >> 16;
                 const uint64_t v = pack_prescore(c, hdr.z + (e & 0xFFFFu), z, iso);
                 uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
@@ -1949,10 +1963,8 @@ size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView&
     return tile_lds_layout(db.tile_shift, b, nullptr, nullptr);
 }
 int tile_kernel_prepare(size_t max_lds_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)tile_count_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)tile_count_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
-    return (int)e;
+    return (int)hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)max_lds_bytes);
 }
 uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
@@ -1974,18 +1986,16 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    if (db.tile_shift >= 16)
-        hipLaunchKernelGGL(tile_count_kernel<1024>, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(1024),
-                           tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
-    else
-        hipLaunchKernelGGL(tile_count_kernel<512>, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(512),
-                           tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
+                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+    if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
-    // bounded_min_heapify replay: a wavefront per query while queries are fewer than wavefront slots, else a lane per query
+    // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
+    // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query
     uint32_t wave_max = 32768;
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint32_t)atoi(e);
-    if (nq <= wave_max)
+    if ((!sc.exact && wave_max) || nq <= wave_max)
         hipLaunchKernelGGL(tile_replay_wave_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
     else
         hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
