@@ -1,9 +1,9 @@
 // core.h — arithmetic shared by the HIP kernels (device) and the host-side unit tests.
 //
 // Everything here is a pure function over plain pointers so that the same source compiles for
-// gfx950 (as __device__ code inside kernels.hip) and for the host (tests/hostemu), which lets the
-// order-sensitive f32 arithmetic, the k-select emulation and the rescoring loop be checked against
-// the oracle without a GPU.  All f32 expressions keep the reference's operation order; translation
+// gfx950 (as __device__ code inside kernels.hip) and for the host (tests/hostemu/core_emu.cpp,
+// tests/test_core_emulation.py), which lets the order-sensitive f32 arithmetic, the k-select emulation
+// and the peak matching be checked without a GPU.  All f32 expressions keep the reference's operation order; translation
 // units including this file MUST be compiled with -ffp-contract=off (no FMA contraction).
 //
 // Reference citations: /root/reference/crates/sage/src/<file>:<line>.

@@ -1,0 +1,53 @@
+// Host build of sage_amd/csrc/core.h — the arithmetic the HIP kernels share with the host — behind a tiny C ABI so that the
+// CPU test-suite can exercise it without a GPU (tests/test_core_emulation.py).  TEST INFRASTRUCTURE.
+#include <cstdint>
+#include <vector>
+
+#include "../../sage_amd/csrc/core.h"
+
+using namespace sagecore;
+
+extern "C" {
+
+void emu_tol_bounds(int kind, float tlo, float thi, float center, float* lo, float* hi) {
+    Tol t{kind, tlo, thi};
+    tol_bounds(t, center, *lo, *hi);
+}
+uint32_t emu_trim_k(uint64_t len, uint32_t report_psms) { return trim_k(len, report_psms); }
+uint32_t emu_max_fragment_charge(int user, uint32_t z) { return max_fragment_charge(user, z); }
+int32_t emu_order_key(float f) { return order_key(f); }
+
+// bounded_min_heapify(slice, k) + truncate on packed PreScores (heap.rs:7-28), through CList
+uint32_t emu_clist_trim(uint64_t* items, uint32_t n, uint32_t kmax, uint32_t report_psms) {
+    std::vector<uint64_t> buf(n + 8);
+    CList c{buf.data(), 0, (uint32_t)buf.size(), 0};
+    for (uint32_t i = 0; i < n; i++) clist_push(c, items[i], kmax);
+    clist_trim(c, report_psms);
+    for (uint32_t i = 0; i < c.stored; i++) items[i] = c.items[i];
+    return c.stored;
+}
+
+uint32_t emu_count_windows(const float* lo, const float* hi, uint32_t n, float frag, int variant) {
+    if (variant == 0) return count_windows_scan(lo, hi, n, frag);
+    if (variant == 1) return count_windows_sorted(lo, hi, n, frag);
+    return count_windows_lockstep<1>(lo, hi, n, n, pow2_floor(n), frag);
+}
+
+int emu_select_peak(const float* masses, const float* intens, uint32_t n, float center, int kind, float tlo, float thi, int lockstep) {
+    Tol t{kind, tlo, thi};
+    return lockstep ? select_most_intense_peak_lockstep(masses, intens, n, pow2_floor(n), center, t)
+                    : select_most_intense_peak(masses, intens, n, center, t);
+}
+
+// score_candidate's accumulation loop (scoring.rs:699-759) on a precomputed ion table
+void emu_score_candidate(const float* ions, uint32_t lm1, const uint8_t* kinds, uint32_t n_kinds, uint32_t max_fc,
+                         const float* masses, const float* intens, uint32_t n_peaks, int kind, float tlo, float thi,
+                         uint32_t* out_u32 /*matched_b, matched_y, longest_b, longest_y*/, float* out_f32 /*summed_b, summed_y, ppm*/) {
+    Tol t{kind, tlo, thi};
+    Score s{};
+    score_candidate(s, ions, lm1, kinds, n_kinds, max_fc, masses, intens, n_peaks, t);
+    out_u32[0] = s.matched_b; out_u32[1] = s.matched_y; out_u32[2] = s.longest_b; out_u32[3] = s.longest_y;
+    out_f32[0] = s.summed_b; out_f32[1] = s.summed_y; out_f32[2] = s.ppm_difference;
+}
+
+}  // extern "C"
