@@ -755,9 +755,7 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
     const bool exact = s->exact_always;
     int rc = run_kernels(s, b, true, exact);
     if (rc != SAGE_HIP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
-                           hipMemcpyDeviceToHost, s->stream));
+    // the counters (copied on the stream by run_kernels) decide whether a second pass is needed before anything is downloaded
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = finish_timing(s, true);
     if (rc != SAGE_HIP_OK) return rc;
@@ -772,9 +770,6 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
         sub.n = n_retry;
         rc = run_kernels(s, b, true, true, &sub);
         if (rc != SAGE_HIP_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
-                               hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         rc = finish_timing(s, true);
         if (rc != SAGE_HIP_OK) return rc;
@@ -786,6 +781,10 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
         s->timing.arena_entries = std::max(s->timing.arena_entries, first.arena_entries);
         s->timing.n_retry = n_retry;
     }
+    HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
+                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->h_counters[CTR_LIST_OVERFLOW]) {  // rare: find the offending spectrum for the message
         std::vector<uint32_t> st(b->n);
         HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
