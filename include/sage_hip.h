@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAGE_HIP_ABI_VERSION 2
+#define SAGE_HIP_ABI_VERSION 3
 
 enum {
     SAGE_HIP_OK = 0,
@@ -283,6 +283,56 @@ void sage_hip_host_free(void* p);
  * first 4096 work items, out32[8*k + phase]: k = 0 narrow preliminary kernel, 1 rescoring kernel, 2 large-window count
  * kernel, 3 large-window replay kernel. */
 int sage_hip_debug_phase_cycles(SageScorer* scorer, unsigned long long* out32);
+
+/* ---- post-search rescoring --------------------------------------------------------------
+ * The step that consumes the Feature records of ALL searched files (sage-cli runner.rs:536-541):
+ *   spectrum_fdr  (runner.rs:281-292)  = ml::linear_discriminant::score_psms (linear_discriminant.rs:133-231: mass-error KDE,
+ *                                        20-feature LDA, Gauss-Jordan solve, projection, KDE posterior error) or the heuristic
+ *                                        fall-back, then the sort by discriminant and ml::qvalue::spectrum_q_value (qvalue.rs:8-36)
+ *   fdr::picked_peptide / picked_protein (fdr.rs:123-187) = Competition::assign_q_value (fdr.rs:60-120)
+ * Row-parallel work (feature rows, class sums, scatter matrices, projection, kernel-density sums, sorts, scans) runs on the
+ * device; the 20x20 solve and the bandwidth scalars are host arithmetic.  Retention-time / ion-mobility models
+ * (ml/retention_model.rs, mobility_model.rs) are not part of this call: their outputs enter through the optional arrays. */
+typedef struct SageRescoreInput {
+    uint64_t n;                    /* Features of the whole run */
+    const SageFeature* features;   /* host, [n] */
+    const float* aligned_rt;       /* [n] or NULL: features[i].rt (Feature default, scoring.rs:576-592) */
+    const float* delta_rt_model;   /* [n] or NULL: 0.999 */
+    const float* delta_ims_model;  /* [n] or NULL: 0.999 */
+    SageTolerance precursor_tol;   /* Ppm or Da (Pct is unreachable in the reference, linear_discriminant.rs:142) */
+    /* picked competitions: dense ids 0..n_keys-1 (every id used at least once) of the map key the reference builds —
+     * peptide: the sequence string, reversed for generated decoys (fdr.rs:126-132); protein: the proteins vector, only for
+     * peptides with exactly one protein (fdr.rs:158-160), 0xFFFFFFFF otherwise (protein_q stays 1.0).
+     * sage_hip_hostdb_competition_keys() produces both. */
+    const uint32_t* peptide_key;   /* [n] */
+    uint32_t n_peptide_keys;
+    const uint32_t* protein_key;   /* [n] */
+    uint32_t n_protein_keys;
+} SageRescoreInput;
+
+typedef struct SageRescoreOutput {
+    /* caller-allocated host arrays [n], INPUT order */
+    float* discriminant_score;
+    float* posterior_error;        /* log10 PEP; 1.0 (the Feature default) when the linear model could not be fitted */
+    float* spectrum_q;
+    float* peptide_q;
+    float* protein_q;
+    uint32_t* order;               /* [n] or NULL: order[j] = input index of the j-th best PSM — the order the reference
+                                      leaves `features` in (runner.rs:290) and writes them out */
+    /* filled by the call */
+    uint64_t passing_spectrum;     /* PSMs with q <= 0.01 (targets and decoys, qvalue.rs:31) */
+    uint64_t passing_peptide;      /* target peptides at 1 % (fdr.rs:105) */
+    uint64_t passing_protein;
+    int32_t lda_fitted;            /* 0: heuristic discriminant of runner.rs:285-288 */
+    double coef[20];               /* LDA coefficients, FEATURE_NAMES order (linear_discriminant.rs:20-41) */
+    float device_ms;               /* HIP-event time of all kernels of the call */
+} SageRescoreOutput;
+
+int sage_hip_rescore(int device, const SageRescoreInput* in, SageRescoreOutput* out);
+
+/* The competition keys of SageRescoreInput for `n` PSMs given their peptide indices (host work: string keys). */
+int sage_hip_hostdb_competition_keys(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key,
+                                 uint32_t* n_peptide_keys, uint32_t* protein_key, uint32_t* n_protein_keys);
 
 const char* sage_hip_last_error(void);
 int sage_hip_abi_version(void);

@@ -172,6 +172,19 @@ TOL_KINDS = {"ppm": 0, "pct": 1, "da": 2}
 SCORE_TYPES = {"SageHyperScore": 0, "OpenMSHyperScore": 1}
 
 
+class SageRescoreInput(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("features", C.c_void_p), ("aligned_rt", c_float_p), ("delta_rt_model", c_float_p),
+                ("delta_ims_model", c_float_p), ("precursor_tol", SageTolerance), ("peptide_key", c_u32_p),
+                ("n_peptide_keys", C.c_uint32), ("protein_key", c_u32_p), ("n_protein_keys", C.c_uint32)]
+
+
+class SageRescoreOutput(C.Structure):
+    _fields_ = [("discriminant_score", c_float_p), ("posterior_error", c_float_p), ("spectrum_q", c_float_p),
+                ("peptide_q", c_float_p), ("protein_q", c_float_p), ("order", c_u32_p), ("passing_spectrum", C.c_uint64),
+                ("passing_peptide", C.c_uint64), ("passing_protein", C.c_uint64), ("lda_fitted", C.c_int32),
+                ("coef", C.c_double * 20), ("device_ms", C.c_float)]
+
+
 class SageHipError(RuntimeError):
     pass
 
@@ -223,6 +236,8 @@ def load():
         "sage_hip_debug_phase_cycles": (C.c_int, [vp, c_u64_p]),
         "sage_hip_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(vp)]),
         "sage_hip_host_free": (None, [vp]),
+        "sage_hip_rescore": (C.c_int, [C.c_int, C.POINTER(SageRescoreInput), C.POINTER(SageRescoreOutput)]),
+        "sage_hip_hostdb_competition_keys": (C.c_int, [vp, c_u32_p, C.c_uint64, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
@@ -239,6 +254,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
+    "sage_hip_rescore", "sage_hip_hostdb_competition_keys",
 ]
 
 

@@ -184,6 +184,16 @@ class IndexedDatabase:
         L.check(L.load().sage_hip_hostdb_peptide_info(self._h, i, C.byref(n), C.byref(semi)))
         return int(n.value), int(semi.value)
 
+    def competition_keys(self, peptide_idx):
+        """Map keys of fdr::picked_peptide / picked_protein (fdr.rs:126-132, :158-161) for PSMs of the given peptides:
+        (peptide_key[n], n_peptide_keys, protein_key[n], n_protein_keys), dense ids, 0xFFFFFFFF = shared peptide."""
+        idx = np.ascontiguousarray(peptide_idx, dtype=np.uint32)
+        pk, prk = np.empty(len(idx), np.uint32), np.empty(len(idx), np.uint32)
+        npk, nprk = C.c_uint32(), C.c_uint32()
+        L.check(L.load().sage_hip_hostdb_competition_keys(self._h, L.as_ptr(idx, C.c_uint32), len(idx), L.as_ptr(pk, C.c_uint32),
+                                                          C.byref(npk), L.as_ptr(prk, C.c_uint32), C.byref(nprk)))
+        return pk, int(npk.value), prk, int(nprk.value)
+
     def sequence(self, i: int) -> str:
         return bytes(self.seq[int(self.seq_off[i]):int(self.seq_off[i + 1])]).decode()
 
@@ -589,6 +599,44 @@ class Scorer:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class RescoreResult:
+    """Outputs of sage_hip_rescore, input order (Feature fields of scoring.rs:124-136) + the reference's output order."""
+    discriminant_score: np.ndarray
+    posterior_error: np.ndarray
+    spectrum_q: np.ndarray
+    peptide_q: np.ndarray
+    protein_q: np.ndarray
+    order: np.ndarray
+    passing_spectrum: int
+    passing_peptide: int
+    passing_protein: int
+    lda_fitted: bool
+    coef: np.ndarray
+    device_ms: float
+
+
+def rescore(features: np.ndarray, precursor_tol: Tolerance, peptide_key, n_peptide_keys: int, protein_key,
+            n_protein_keys: int, aligned_rt=None, delta_rt_model=None, delta_ims_model=None, device: int = 0) -> RescoreResult:
+    """spectrum_fdr + picked_peptide + picked_protein (sage-cli runner.rs:536-541) over ALL Features of a run, on the
+    device (rescore.hip).  `features`: 1-D array of FEATURE_DTYPE."""
+    f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
+    n = len(f)
+    pk = np.ascontiguousarray(peptide_key, dtype=np.uint32)
+    prk = np.ascontiguousarray(protein_key, dtype=np.uint32)
+    assert len(pk) == n and len(prk) == n
+    opt = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (aligned_rt, delta_rt_model, delta_ims_model)]
+    outs = [np.empty(n, np.float32) for _ in range(5)]
+    order = np.empty(n, np.uint32)
+    cin = L.SageRescoreInput(n, f.ctypes.data, *[None if a is None else L.as_ptr(a, C.c_float) for a in opt],
+                             precursor_tol.to_c(), L.as_ptr(pk, C.c_uint32), n_peptide_keys, L.as_ptr(prk, C.c_uint32),
+                             n_protein_keys)
+    cout = L.SageRescoreOutput(*[L.as_ptr(a, C.c_float) for a in outs], L.as_ptr(order, C.c_uint32))
+    L.check(L.load().sage_hip_rescore(device, C.byref(cin), C.byref(cout)))
+    return RescoreResult(*outs, order, int(cout.passing_spectrum), int(cout.passing_peptide), int(cout.passing_protein),
+                         bool(cout.lda_fitted), np.array(cout.coef[:], dtype=np.float64), float(cout.device_ms))
 
 
 def device_count() -> int:

@@ -6,8 +6,9 @@ Mirrors sage-cli for this path and nothing else: the JSON schema
 crates/sage-cli/src/input.rs (Input -> Search, :298-385; `database` = sage-core Builder, database.rs:59-139), the per-file
 flow of runner.rs (read mzML -> SpectrumProcessor::process -> keep MS2 with >= min_peaks peaks -> Scorer::score,
 :311-325, :398-461) and the `results.sage.tsv` / `matched_fragments.sage.tsv` writers (:687-935).  Everything downstream
-of Scorer::score — LDA rescoring, q-values, protein grouping, LFQ/TMT, parquet, cloud IO — is out of scope: those columns
-carry the defaults a Feature is born with (scoring.rs:576-592).  The search itself runs on the GPU through
+of Scorer::score is limited to the LDA rescoring, q-values and picked peptide / protein FDR (runner.rs:536-541, on the
+device: rescore.hip) and the optional percolator .pin file; retention-time / mobility prediction, protein grouping, LFQ/TMT,
+parquet, cloud IO are out of scope and their columns carry the defaults a Feature is born with (scoring.rs:576-592).  The search itself runs on the GPU through
 libsage_hip.so; there is no CPU fallback.
 """
 import argparse
@@ -19,8 +20,9 @@ import time
 import numpy as np
 
 from . import output
+from ._lib import FEATURE_DTYPE as L_FEATURE_DTYPE
 from .api import (DatabaseParameters, DeviceDatabase, RawBatch, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor,
-                  Tolerance, device_count)
+                  Tolerance, device_count, rescore)
 from .mzml import read_mzml
 
 
@@ -53,7 +55,8 @@ def scorer_params(sp: dict) -> ScorerParams:
                         annotate_matches=sp["annotate_matches"], score_type=sp["score_type"])
 
 
-def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print, host_preprocess: bool = False) -> dict:
+def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print, host_preprocess: bool = False,
+        write_pin: bool = False) -> dict:
     if device_count() <= 0:
         raise SystemExit("sage_amd.cli: no HIP device visible — libsage_hip has no CPU fallback")
     sp = search_parameters(cfg)
@@ -68,7 +71,7 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     scorer = Scorer(dev, params)
     processor = SpectrumProcessor(sp["max_peaks"], sp["deisotope"], 0.0)  # (no TMT reporter cut-off: quant is out of scope)
     os.makedirs(output_directory, exist_ok=True)
-    rows, frag_rows = [], []
+    feats_all, meta, frags = [], [], []  # per PSM: (filename, spectrum id); matched-fragment rows
     psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
     n_searched = 0
     search_ms = 0.0
@@ -102,21 +105,55 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         name = os.path.basename(path)
         for i in range(n_batch):
             for r in range(int(counts[i])):
-                rows.append(output.feature_row(psm_id, feats[i, r], host, name, ids[i]))
+                f = feats[i, r].copy()
+                f["file_id"] = file_id
+                feats_all.append(f)
+                meta.append((psm_id, name, ids[i]))
                 if arr is not None:
                     s = i * params.report_psms + r
-                    frag_rows += output.fragment_rows(psm_id, int(off[s]), int(off[s + 1]), arr)
+                    frags.append(output.fragment_rows(psm_id, int(off[s]), int(off[s + 1]), arr))
                 psm_id += 1
         dbatch.close()
+    # runner.rs:536-541: spectrum_fdr (LDA or heuristic, sort, q-values), picked_peptide, picked_protein — on the device.
+    # (predict_rt / protein grouping are outside this path: their columns keep the defaults, see output.py)
+    flat = np.array(feats_all, dtype=feats_all[0].dtype) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
+    post = None
+    order = range(len(flat))
+    rescore_summary = {}
+    if len(flat):
+        t0 = time.time()
+        pk, npk, prk, npr = host.competition_keys(flat["peptide_idx"])
+        res = rescore(flat, sp["precursor_tol"], pk, npk, prk, npr, device=device)
+        if not res.lda_fitted:
+            log("linear model fitting failed, falling back to heuristic discriminant score")  # runner.rs:285
+        post = res
+        order = [int(i) for i in res.order]
+        log(f"discovered {res.passing_spectrum} target peptide-spectrum matches at 1% FDR")  # runner.rs:576-587
+        log(f"discovered {res.passing_peptide} target peptides at 1% FDR")
+        log(f"discovered {res.passing_protein} target proteins (supported by proteotypic peptides only) at 1% FDR")
+        rescore_summary = {"lda_fitted": res.lda_fitted, "q_spectrum": res.passing_spectrum, "q_peptide": res.passing_peptide,
+                           "q_protein": res.passing_protein, "rescore_ms": (time.time() - t0) * 1000.0,
+                           "rescore_device_ms": res.device_ms}
+
+    def post_of(i):
+        return None if post is None else dict(discriminant_score=post.discriminant_score[i], posterior_error=post.posterior_error[i],
+                                              spectrum_q=post.spectrum_q[i], peptide_q=post.peptide_q[i],
+                                              protein_q=post.protein_q[i])
+
+    rows = [output.feature_row(meta[i][0], flat[i], host, meta[i][1], meta[i][2], post_of(i)) for i in order]
     results = os.path.join(output_directory, "results.sage.tsv")
     output.write_features(results, rows)
     paths = [results]
     if sp["annotate_matches"]:
         fp = os.path.join(output_directory, "matched_fragments.sage.tsv")
-        output.write_fragments(fp, frag_rows)
+        output.write_fragments(fp, [r for i in order for r in frags[i]])
         paths.append(fp)
+    if write_pin:  # runner.rs:655-660
+        pp = os.path.join(output_directory, "results.sage.pin")
+        output.write_pin(pp, [output.pin_row(meta[i][0], flat[i], host, meta[i][1], meta[i][2], post_of(i)) for i in order])
+        paths.append(pp)
     summary = {"version": "sage-hip 0.1 (search-and-score path of sage 0.15.0-beta.2)", "psms": len(rows),
-               "spectra_searched": n_searched, "search_ms": search_ms, "output_paths": paths}
+               "spectra_searched": n_searched, "search_ms": search_ms, "output_paths": paths, **rescore_summary}
     with open(os.path.join(output_directory, "results.json"), "w") as fh:
         json.dump(dict(cfg, output_paths=paths, summary=summary), fh, indent=2, default=str)
     return summary
@@ -129,6 +166,7 @@ def main(argv=None):
     ap.add_argument("-f", "--fasta", help="path to FASTA database. Overrides the FASTA file specified in the configuration file.")
     ap.add_argument("-o", "--output_directory", help="where to place output files. Overrides the directory specified in the configuration file.")
     ap.add_argument("--annotate-matches", action="store_true", help="write matched fragments output file")
+    ap.add_argument("--write-pin", action="store_true", help="write percolator-compatible `.pin` output files")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--host-preprocess", action="store_true", help="run SpectrumProcessor::process on the host instead of the device")
     args = ap.parse_args(argv)
@@ -141,7 +179,8 @@ def main(argv=None):
     if not mzml:
         raise SystemExit("'mzml_paths' must be provided!")
     out = args.output_directory or cfg.get("output_directory") or os.getcwd()
-    summary = run(cfg, mzml, out, args.device, host_preprocess=args.host_preprocess)
+    summary = run(cfg, mzml, out, args.device, host_preprocess=args.host_preprocess,
+                  write_pin=args.write_pin or bool(cfg.get("write_pin", False)))
     print(json.dumps(summary))
 
 

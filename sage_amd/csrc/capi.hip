@@ -117,6 +117,26 @@ struct SageDeviceBatch {
 
 extern "C" {
 
+// post-search rescoring (rescore.hip)
+int sage_hip_rescore(int device, const SageRescoreInput* in, SageRescoreOutput* out) {
+    if (!in || !out) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_rescore: null argument");
+    if (sage_hip_device_count() <= 0) return fail(SAGE_HIP_ERR_NO_DEVICE, "sage_hip_rescore: no HIP device (there is no CPU fallback)");
+    if (in->n >= (1ull << 31)) return fail(SAGE_HIP_ERR_UNSUPPORTED, "sage_hip_rescore: more than 2^31 features");
+    if (in->precursor_tol.kind != SAGE_TOL_PPM && in->precursor_tol.kind != SAGE_TOL_DA)
+        return fail(SAGE_HIP_ERR_INVALID, "sage_hip_rescore: Pct tolerance should never be used on mz");  // linear_discriminant.rs:142
+    out->passing_spectrum = out->passing_peptide = out->passing_protein = 0;
+    out->lda_fitted = 0;
+    out->device_ms = 0.0f;
+    std::memset(out->coef, 0, sizeof(out->coef));
+    if (in->n == 0) return SAGE_HIP_OK;
+    if (!in->features || !in->peptide_key || !in->protein_key || !out->discriminant_score || !out->posterior_error ||
+        !out->spectrum_q || !out->peptide_q || !out->protein_q)
+        return fail(SAGE_HIP_ERR_INVALID, "sage_hip_rescore: null array");
+    std::string err;
+    const int rc = rescore_on_device(device, *in, *out, err);
+    return rc == SAGE_HIP_OK ? rc : fail(rc, err);
+}
+
 const char* sage_hip_last_error(void) { return g_last_error.c_str(); }
 int sage_hip_abi_version(void) { return SAGE_HIP_ABI_VERSION; }
 
@@ -156,6 +176,15 @@ int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num
     if (!db || i >= db->db.n_peptides()) return fail(SAGE_HIP_ERR_INVALID, "peptide index out of range");
     if (num_proteins) *num_proteins = (uint32_t)(db->db.pep_protein_off[i + 1] - db->db.pep_protein_off[i]);
     if (semi_enzymatic) *semi_enzymatic = db->db.semi[i];
+    return SAGE_HIP_OK;
+}
+int sage_hip_hostdb_competition_keys(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key,
+                                     uint32_t* n_peptide_keys, uint32_t* protein_key, uint32_t* n_protein_keys) {
+    if (!db || (n && (!peptide_idx || !peptide_key || !protein_key)) || !n_peptide_keys || !n_protein_keys)
+        return fail(SAGE_HIP_ERR_INVALID, "sage_hip_hostdb_competition_keys: null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        if (peptide_idx[i] >= db->db.n_peptides()) return fail(SAGE_HIP_ERR_INVALID, "peptide index out of range");
+    db->db.competition_keys(peptide_idx, n, peptide_key, *n_peptide_keys, protein_key, *n_protein_keys);
     return SAGE_HIP_OK;
 }
 uint64_t sage_hip_process_ms2(uint64_t take_top_n, int deisotope, float min_deisotope_mz, const float* mz,

@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/sage_hip.h"
 #include "core.h"
 
@@ -156,6 +158,8 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
                               uint32_t* lut_stride_out, void* stream);
+// rescore.hip
+int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err);
 // process.hip
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
 int process_kernel_prepare(size_t max_lds_bytes);

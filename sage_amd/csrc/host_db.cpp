@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <string_view>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 
 namespace sagehip {
@@ -741,6 +742,46 @@ std::string HostDb::peptide_string(uint64_t i) const {
     }
     if (!std::isnan(cterm[i])) s += "-[" + signed_mass(cterm[i]) + "]";
     return s;
+}
+
+// The map keys of the picked competitions (fdr.rs:123-187) as dense ids in order of first appearance.
+// peptide: `peptide.to_string()`, of `peptide.reverse()` for generated decoys (fdr.rs:126-132; reverse() flips
+// sequence[1..len-1] and the residue modifications with it, peptide.rs:307-318) — a target and the decoy derived from it
+// share a key.  protein: the `proteins` vector of peptides with exactly one protein (fdr.rs:158-161), i.e. the protein id.
+void HostDb::competition_keys(const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key, uint32_t& n_peptide_keys,
+                              uint32_t* protein_key, uint32_t& n_protein_keys) const {
+    std::unordered_map<std::string, uint32_t> pep_ids;
+    std::unordered_map<uint32_t, uint32_t> prot_ids;
+    std::unordered_map<uint32_t, uint32_t> seen;  // peptide index -> key (PSMs of one peptide are common)
+    for (uint64_t f = 0; f < n; f++) {
+        const uint64_t i = peptide_idx[f];
+        auto hit = seen.find((uint32_t)i);
+        if (hit != seen.end()) {
+            peptide_key[f] = hit->second;
+        } else {
+            std::string s;
+            const uint64_t lo = seq_off[i], len = seq_off[i + 1] - lo, last = len ? len - 1 : 0;
+            const bool flip = generate_decoys && decoy[i] && last > 1;
+            if (!std::isnan(nterm[i])) s += "[" + signed_mass(nterm[i]) + "]-";
+            for (uint64_t j = 0; j < len; j++) {
+                const uint64_t src = lo + ((flip && j >= 1 && j < last) ? last - j : j);  // s[1..last].reverse()
+                s += (char)seq[src];
+                if (mods[src] != 0.0f) s += "[" + signed_mass(mods[src]) + "]";
+            }
+            if (!std::isnan(cterm[i])) s += "-[" + signed_mass(cterm[i]) + "]";
+            const uint32_t id = pep_ids.emplace(std::move(s), (uint32_t)pep_ids.size()).first->second;
+            seen.emplace((uint32_t)i, id);
+            peptide_key[f] = id;
+        }
+        if (pep_protein_off[i + 1] - pep_protein_off[i] == 1) {
+            const uint32_t prot = pep_protein_ids[pep_protein_off[i]];
+            protein_key[f] = prot_ids.emplace(prot, (uint32_t)prot_ids.size()).first->second;
+        } else {
+            protein_key[f] = 0xFFFFFFFFu;
+        }
+    }
+    n_peptide_keys = (uint32_t)pep_ids.size();
+    n_protein_keys = (uint32_t)prot_ids.size();
 }
 
 std::string HostDb::peptide_proteins(uint64_t i) const {  // Peptide::proteins, peptide.rs:81-97

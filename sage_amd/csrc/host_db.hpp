@@ -61,6 +61,8 @@ struct HostDb {
     SageDbView view() const;
     std::string peptide_string(uint64_t i) const;
     std::string peptide_proteins(uint64_t i) const;
+    void competition_keys(const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key, uint32_t& n_peptide_keys,
+                          uint32_t* protein_key, uint32_t& n_protein_keys) const;
 };
 
 unsigned host_threads();

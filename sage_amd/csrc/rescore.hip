@@ -1,0 +1,900 @@
+// rescore.hip — post-search rescoring on the device: the consumer of the Feature records.
+//
+//   score_psms            crates/sage/src/ml/linear_discriminant.rs:133-231
+//   LDA::train / score    linear_discriminant.rs:57-133        (two streaming passes: class means, within-class scatter)
+//   Gauss::solve          ml/gauss.rs:27-165                   (host: 20x20)
+//   kde::Builder::build   ml/kde.rs:85-133, Estimator::posterior_error :143-168
+//   spectrum_fdr          sage-cli/src/runner.rs:281-292, ml/qvalue.rs:8-36
+//   picked_peptide/protein, Competition::assign_q_value        fdr.rs:60-187
+//
+// What runs where.  Everything that is O(n) or O(n x bins) is a kernel: the 20-column design (f64, never leaves HBM), the
+// per-class sums and the 2 x 20 x 20 scatter accumulation, the projection, the kernel-density sums (bins x samples Gaussian
+// evaluations — the only compute-heavy part), the descending sorts (rocprim radix sort on the f32 total order), the
+// decoy/target prefix counts and the suffix minimum of the q-values, the per-key maxima of the picked competitions.  The
+// host does the scalar glue between kernels: final addition of per-block partials, bandwidths, the Gauss-Jordan solve.
+//
+// Reductions are deterministic (fixed block count, fixed tree, partials added in block order) but are not the reference's
+// left-to-right sums; results agree with the CPU restatement to f64 rounding, not bit for bit (the reference itself sums
+// Kde::pdf in rayon's arbitrary order).  The one sum the reference keeps in f32 — `decoy += pep` of fdr.rs:93-101 — is
+// evaluated strictly in order (seq_cumsum_kernel), because f32 rounding of a long running sum is order dependent at the
+// 1e-4 level.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/sage_hip.h"
+
+namespace sagehip {
+
+namespace {
+
+constexpr int NF = 20;           // FEATURES, linear_discriminant.rs:19
+constexpr int RB = 256;          // threads of a row-parallel block
+constexpr int MAX_BLOCKS = 512;  // partials per reduction
+constexpr int KDE_BINS_PER_BLOCK = 8;
+constexpr int KDE_SLICES = 32;
+constexpr int SCATTER_THREADS = 448;  // >= 400 matrix entries, whole waves
+constexpr int SCATTER_STAGE = 64;     // rows staged in LDS at a time
+
+struct KdeDev {  // kde::Estimator on the device
+    const double* bins;
+    double min_score, score_step;
+    uint32_t nbins;
+};
+
+// Estimator::posterior_error, kde.rs:146-168 (`as usize` saturates, NaN -> 0)
+__device__ inline double kde_posterior_error(const KdeDev& e, double score) {
+    const uint32_t last = e.nbins ? e.nbins - 1 : 0;
+    const double r = floor((score - e.min_score) / e.score_step);
+    const uint32_t lo = (!(r == r) || r <= 0.0) ? 0u : (r >= (double)last ? last : (uint32_t)r);
+    const uint32_t hi = lo + 1 < last ? lo + 1 : last;
+    const double lower = e.bins[lo], upper = e.bins[hi];
+    const double lo_score = (double)lo * e.score_step + e.min_score;
+    const double linear = (score - lo_score) / e.score_step;
+    return lower + ((upper - lower) * linear);
+}
+
+__device__ inline uint32_t total_order_key(float f) {  // ascending u32 order == f32::total_cmp
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ inline float from_total_order_key(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+struct OpSum {
+    __device__ double operator()(double a, double b) const { return a + b; }
+};
+struct OpMin {
+    __device__ double operator()(double a, double b) const { return fmin(a, b); }
+};
+struct OpMax {
+    __device__ double operator()(double a, double b) const { return fmax(a, b); }
+};
+
+// fixed-tree block reduction (wave shuffles, then the wave results through LDS); result valid in thread 0
+template <class Op>
+__device__ inline double block_reduce(double v, Op op, double* lds /* >= blockDim/64 doubles */) {
+    for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_down(v, o, 64));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < nw; ++w) v = op(v, lds[w]);
+    return v;
+}
+
+// label -> decoy flag and the mass error of linear_discriminant.rs:140-144
+__global__ __launch_bounds__(RB) void prep_kernel(const SageFeature* __restrict__ f, uint64_t n, int tol_kind,
+                                                  uint8_t* __restrict__ decoy, double* __restrict__ dmass) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    decoy[i] = f[i].label == -1;
+    dmass[i] = tol_kind == SAGE_TOL_PPM ? (double)f[i].delta_mass : (double)(f[i].expmass - f[i].calcmass);
+}
+
+// partial[b] = {count_d, count_t, sum_d, sum_t, min, max}  (ml/mod.rs:22-24, kde.rs:105-111)
+__global__ __launch_bounds__(RB) void stats1_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
+                                                    double* __restrict__ partial) {
+    __shared__ double lds[RB / 64];
+    double c[2] = {0, 0}, s[2] = {0, 0};
+    double mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
+    for (uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RB) {
+        const double v = x[i];
+        const int cls = decoy[i] ? 0 : 1;
+        c[cls] += 1.0;
+        s[cls] += v;
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+    }
+    double r[6] = {block_reduce(c[0], OpSum(), lds), block_reduce(c[1], OpSum(), lds), block_reduce(s[0], OpSum(), lds),
+                   block_reduce(s[1], OpSum(), lds), block_reduce(mn, OpMin(), lds),   block_reduce(mx, OpMax(), lds)};
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) partial[blockIdx.x * 6 + k] = r[k];
+}
+
+// partial[b] = {sum (x - mean_d)^2 over decoys, sum (x - mean_t)^2 over targets}  (ml/mod.rs:26-30)
+__global__ __launch_bounds__(RB) void stats2_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
+                                                    double mean_d, double mean_t, double* __restrict__ partial) {
+    __shared__ double lds[RB / 64];
+    double s[2] = {0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RB) {
+        const int cls = decoy[i] ? 0 : 1;
+        const double d = x[i] - (cls ? mean_t : mean_d);
+        s[cls] += d * d;
+    }
+    const double r0 = block_reduce(s[0], OpSum(), lds), r1 = block_reduce(s[1], OpSum(), lds);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = r0;
+        partial[blockIdx.x * 2 + 1] = r1;
+    }
+}
+
+// Kde::pdf numerators (kde.rs:34-50) for a tile of bins over one slice of the sample:
+// partial[(slice * nbins + bin) * 2 + cls] = sum_i exp(-0.5 ((score_bin - x_i) / h_cls)^2).
+// Each sample is loaded once per tile and serves KDE_BINS_PER_BLOCK bins from registers.
+__global__ __launch_bounds__(RB) void kde_pdf_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
+                                                     double min_score, double score_step, uint32_t nbins, double h_d,
+                                                     double h_t, double* __restrict__ partial) {
+    __shared__ double lds[RB / 64];
+    const uint32_t bin0 = blockIdx.x * KDE_BINS_PER_BLOCK, slice = blockIdx.y;
+    double centre[KDE_BINS_PER_BLOCK], acc[KDE_BINS_PER_BLOCK][2];
+#pragma unroll
+    for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
+        centre[b] = ((double)(bin0 + b) * score_step) + min_score;
+        acc[b][0] = acc[b][1] = 0.0;
+    }
+    const uint64_t per = (n + gridDim.y - 1) / gridDim.y, lo = slice * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += RB) {
+        const double xi = x[i];
+        const bool dec = decoy[i] != 0;
+        const double h = dec ? h_d : h_t;
+#pragma unroll
+        for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
+            const double u = (centre[b] - xi) / h;
+            const double k = exp(-0.5 * (u * u));
+            acc[b][0] += dec ? k : 0.0;
+            acc[b][1] += dec ? 0.0 : k;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
+        const double r0 = block_reduce(acc[b][0], OpSum(), lds), r1 = block_reduce(acc[b][1], OpSum(), lds);
+        if (threadIdx.x == 0 && bin0 + b < nbins) {
+            partial[((uint64_t)slice * nbins + bin0 + b) * 2] = r0;
+            partial[((uint64_t)slice * nbins + bin0 + b) * 2 + 1] = r1;
+        }
+    }
+}
+
+// bins[b] = decoy_pdf * pi / (target_pdf * (1 - pi) + decoy_pdf * pi), then the monotone fold (kde.rs:113-126). One block.
+__global__ __launch_bounds__(1024) void kde_finish_kernel(const double* __restrict__ partial, uint32_t n_slices, uint32_t nbins,
+                                                          double const_d, double const_t, double pi, int monotonic,
+                                                          double* __restrict__ bins) {
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) {
+        double sd = 0.0, st = 0.0;
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            sd += partial[((uint64_t)s * nbins + b) * 2];
+            st += partial[((uint64_t)s * nbins + b) * 2 + 1];
+        }
+        const double d = (sd / const_d) * pi;
+        const double t = (st / const_t) * (1.0 - pi);
+        bins[b] = d / (t + d);
+    }
+    __syncthreads();
+    if (monotonic && threadIdx.x == 0) {
+        double acc = bins[nbins - 1];
+        for (uint32_t b = nbins; b-- > 0;) {
+            acc = fmax(acc, bins[b]);
+            bins[b] = acc;
+        }
+    }
+}
+
+// compute_features, linear_discriminant.rs:162-195: one 20-column f64 row per Feature
+__global__ __launch_bounds__(RB) void rows_kernel(const SageFeature* __restrict__ f, uint64_t n, const double* __restrict__ dmass,
+                                                  KdeDev mass_model, const float* __restrict__ aligned_rt,
+                                                  const float* __restrict__ delta_rt, const float* __restrict__ delta_ims,
+                                                  double* __restrict__ rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    const SageFeature p = f[i];
+    double poisson = log1p(-p.poisson);
+    if (!isfinite(poisson)) poisson = 3.5;
+    double* r = rows + i * NF;
+    r[0] = (double)p.rank;
+    r[1] = (double)p.charge;
+    r[2] = log1p(p.hyperscore);
+    r[3] = log1p(p.delta_next);
+    r[4] = log1p(p.delta_best);
+    r[5] = kde_posterior_error(mass_model, dmass[i]);
+    r[6] = (double)p.isotope_error;
+    r[7] = (double)p.average_ppm;
+    r[8] = poisson;
+    r[9] = log1p((double)p.matched_intensity_pct);
+    r[10] = (double)p.matched_peaks;
+    r[11] = log1p((double)p.longest_b);
+    r[12] = log1p((double)p.longest_y);
+    r[13] = (double)p.longest_y / (double)p.peptide_len;
+    r[14] = log1p((double)p.peptide_len);
+    r[15] = (double)p.missed_cleavages;
+    r[16] = (double)(aligned_rt ? aligned_rt[i] : p.rt);
+    r[17] = (double)p.ims;
+    const double drt = (double)(delta_rt ? delta_rt[i] : 0.999f), dims = (double)(delta_ims ? delta_ims[i] : 0.999f);
+    r[18] = sqrt(drt < 0.001 ? 0.001 : (drt > 0.999 ? 0.999 : drt));  // f64::clamp: NaN stays NaN
+    r[19] = sqrt(dims < 0.001 ? 0.001 : (dims > 0.999 ? 0.999 : dims));
+}
+
+// pass 1 of train (linear_discriminant.rs:70-82): partial[b][cls][j] = sum of column j over the block's rows of class cls.
+// Thread t of a block owns (cls, column) = (t / 20, t % 20) for t < 40; rows are walked in order.
+__global__ __launch_bounds__(64) void class_sum_kernel(const double* __restrict__ rows, const uint8_t* __restrict__ decoy,
+                                                       uint64_t n, double* __restrict__ partial) {
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    if (threadIdx.x >= 2 * NF) return;
+    const int cls = threadIdx.x / NF, j = threadIdx.x % NF;
+    double s = 0.0;
+    for (uint64_t i = lo; i < hi; ++i)
+        if ((decoy[i] ? 0 : 1) == cls) s += rows[i * NF + j];
+    partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = s;
+}
+
+// pass 2 of train (:92-103): partial[b][cls][j][k] = sum over the block's rows of class cls of (x_j - mu_j)(x_k - mu_k).
+// Thread (j, k) owns one matrix entry of both classes; centred rows are staged through LDS 64 at a time.
+__global__ __launch_bounds__(SCATTER_THREADS) void scatter_kernel(const double* __restrict__ rows,
+                                                                  const uint8_t* __restrict__ decoy, uint64_t n,
+                                                                  const double* __restrict__ class_mean /* [2][20] */,
+                                                                  double* __restrict__ partial) {
+    __shared__ double stage[SCATTER_STAGE][NF];
+    __shared__ uint8_t stage_cls[SCATTER_STAGE];
+    __shared__ double mu[2][NF];
+    if (threadIdx.x < 2 * NF) mu[threadIdx.x / NF][threadIdx.x % NF] = class_mean[threadIdx.x];
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const int j = threadIdx.x / NF, k = threadIdx.x % NF;
+    double acc[2] = {0.0, 0.0};
+    for (uint64_t base = lo; base < hi; base += SCATTER_STAGE) {
+        const uint32_t cnt = (uint32_t)(hi - base < SCATTER_STAGE ? hi - base : SCATTER_STAGE);
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < cnt * NF; e += SCATTER_THREADS) {
+            const uint32_t r = e / NF, c = e % NF;
+            const int cls = decoy[base + r] ? 0 : 1;
+            stage[r][c] = rows[(base + r) * NF + c] - mu[cls][c];
+            if (c == 0) stage_cls[r] = (uint8_t)cls;
+        }
+        __syncthreads();
+        if (threadIdx.x < NF * NF)
+            for (uint32_t r = 0; r < cnt; ++r) {
+                const double v = stage[r][j] * stage[r][k];
+                if (stage_cls[r]) acc[1] += v;
+                else acc[0] += v;
+            }
+    }
+    if (threadIdx.x < NF * NF) {
+        partial[((uint64_t)blockIdx.x * 2 + 0) * NF * NF + threadIdx.x] = acc[0];
+        partial[((uint64_t)blockIdx.x * 2 + 1) * NF * NF + threadIdx.x] = acc[1];
+    }
+}
+
+// out[c] = sum over blocks (in block order) of partial[b][c]
+__global__ __launch_bounds__(RB) void fold_partials_kernel(const double* __restrict__ partial, uint32_t n_blocks, uint32_t width,
+                                                           double* __restrict__ out) {
+    const uint32_t c = blockIdx.x * RB + threadIdx.x;
+    if (c >= width) return;
+    double s = 0.0;
+    for (uint32_t b = 0; b < n_blocks; ++b) s += partial[(uint64_t)b * width + c];
+    out[c] = s;
+}
+
+struct Coef {
+    double w[NF];
+};
+
+// lda.score (:130-133): left-to-right sum from 0.0, identical to the reference given identical rows and coefficients
+__global__ __launch_bounds__(RB) void project_kernel(const double* __restrict__ rows, uint64_t n, Coef coef,
+                                                     double* __restrict__ disc) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) s += coef.w[j] * rows[i * NF + j];
+    disc[i] = s;
+}
+
+// :219-229
+__global__ __launch_bounds__(RB) void pep_kernel(const double* __restrict__ disc, uint64_t n, KdeDev kde,
+                                                 float* __restrict__ discriminant, float* __restrict__ posterior_error) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    discriminant[i] = (float)disc[i];
+    float pe = (float)log10(kde_posterior_error(kde, disc[i]));
+    if (isinf(pe)) pe = -324.0f;
+    posterior_error[i] = pe;
+}
+
+// runner.rs:285-288 heuristic when the model cannot be fitted; posterior_error keeps the Feature default 1.0
+__global__ __launch_bounds__(RB) void heuristic_kernel(const SageFeature* __restrict__ f, uint64_t n,
+                                                       float* __restrict__ discriminant, float* __restrict__ posterior_error) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    discriminant[i] = log1pf((float)(-f[i].poisson)) + f[i].longest_y_pct / 3.0f;
+    posterior_error[i] = 1.0f;
+}
+
+__global__ __launch_bounds__(RB) void sort_keys_kernel(const float* __restrict__ score, uint32_t n, uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = total_order_key(score[i]);
+    idx[i] = i;
+}
+
+// qvalue.rs:16-24 on the sorted order: q[j] = (1 + decoys in [0, j]) / (targets in [0, j]).  One block; every thread owns a
+// contiguous chunk, chunk totals are prefixed through LDS.
+__global__ __launch_bounds__(1024) void count_q_kernel(const uint32_t* __restrict__ order, const uint8_t* __restrict__ decoy,
+                                                       uint32_t n, float* __restrict__ q) {
+    __shared__ uint32_t cd[1024], ct[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t d = 0, t = 0;
+    for (uint32_t j = lo; j < hi; ++j) {
+        if (decoy[order[j]]) ++d;
+        else ++t;
+    }
+    cd[threadIdx.x] = d;
+    ct[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sd = 0, st = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const uint32_t a = cd[k], b = ct[k];
+            cd[k] = sd;
+            ct[k] = st;
+            sd += a;
+            st += b;
+        }
+    }
+    __syncthreads();
+    d = cd[threadIdx.x] + 1;  // `let mut decoy = 1`
+    t = ct[threadIdx.x];
+    for (uint32_t j = lo; j < hi; ++j) {
+        if (decoy[order[j]]) ++d;
+        else ++t;
+        q[j] = (float)d / (float)t;
+    }
+}
+
+// the reverse cumulative minimum of qvalue.rs:27-35 / fdr.rs:104-112, in place, and the passing count:
+// q_min starts at 1.0; passing counts rows with q_min <= threshold (and, when `row_decoy` is given, not decoy).
+__global__ __launch_bounds__(1024) void suffix_min_kernel(float* __restrict__ q, uint32_t n, const uint8_t* __restrict__ row_decoy,
+                                                          float threshold, unsigned long long* __restrict__ passing) {
+    __shared__ float cm[1024];
+    __shared__ uint32_t cp[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+    float m = 1.0f;
+    for (uint32_t j = lo; j < hi; ++j) m = fminf(m, q[j]);
+    cm[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // cm[k] <- minimum over all LATER chunks
+        float carry = 1.0f;
+        for (int k = 1023; k >= 0; --k) {
+            const float own = cm[k];
+            cm[k] = carry;
+            carry = fminf(carry, own);
+        }
+    }
+    __syncthreads();
+    m = cm[threadIdx.x];
+    uint32_t pass = 0;
+    for (uint32_t j = hi; j-- > lo;) {
+        m = fminf(m, q[j]);
+        q[j] = m;
+        if (m <= threshold && !(row_decoy && row_decoy[j])) ++pass;
+    }
+    cp[threadIdx.x] = pass;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int k = 0; k < 1024; ++k) s += cp[k];
+        *passing = s;
+    }
+}
+
+__global__ __launch_bounds__(RB) void scatter_by_order_kernel(const uint32_t* __restrict__ order, const float* __restrict__ q,
+                                                              uint32_t n, float* __restrict__ out) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j < n) out[order[j]] = q[j];
+}
+
+// ---- picked competitions (fdr.rs) --------------------------------------------------------------------------------------
+// side[2 * key + s] (s = 0 forward, 1 reverse) holds the total-order key of the best discriminant of that side, 0 = absent
+// (0 is the key of a negative NaN with full payload; every real score maps above it).
+__global__ __launch_bounds__(RB) void picked_max_kernel(const uint32_t* __restrict__ key, const uint8_t* __restrict__ decoy,
+                                                        const float* __restrict__ score, uint64_t n, uint32_t* __restrict__ side) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n || key[i] == 0xFFFFFFFFu) return;
+    float s = score[i];
+    if (!(s == s)) s = -std::numeric_limits<float>::max();  // f32::max(f32::MIN, NaN) == f32::MIN (fdr.rs:137,141)
+    s = fmaxf(s, -std::numeric_limits<float>::max());
+    atomicMax(&side[2ull * key[i] + (decoy[i] ? 1 : 0)], total_order_key(s));
+}
+
+// per key: the winner of the competition for the KDE fit (Competition::score / is_decoy, fdr.rs:42-49) and the sort keys of
+// its rows in (key, forward-before-reverse) order
+__global__ __launch_bounds__(RB) void picked_rows_kernel(const uint32_t* __restrict__ side, uint32_t n_keys,
+                                                         double* __restrict__ winner, uint8_t* __restrict__ winner_decoy,
+                                                         uint32_t* __restrict__ row_key, uint32_t* __restrict__ row_id,
+                                                         uint32_t* __restrict__ counters /* [0] rows present, [1] unused keys */) {
+    const uint32_t g = blockIdx.x * RB + threadIdx.x;
+    if (g >= n_keys) return;
+    const uint32_t kf = side[2 * g], kr = side[2 * g + 1];
+    const float FMIN = -std::numeric_limits<float>::max();
+    const float fwd = kf ? from_total_order_key(kf) : FMIN, rev = kr ? from_total_order_key(kr) : FMIN;
+    winner[g] = (double)fmaxf(fwd, rev);
+    winner_decoy[g] = rev >= fwd;
+    row_key[2 * g] = kf;
+    row_key[2 * g + 1] = kr;
+    row_id[2 * g] = 2 * g;
+    row_id[2 * g + 1] = 2 * g + 1;
+    const uint32_t present = (kf != 0) + (kr != 0);
+    if (present) atomicAdd(&counters[0], present);
+    else atomicAdd(&counters[1], 1u);
+}
+
+// rows in sorted order: their posterior error (fdr.rs:94) and side
+__global__ __launch_bounds__(RB) void picked_pep_kernel(const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
+                                                        uint32_t m, KdeDev est, float* __restrict__ pep, uint8_t* __restrict__ row_decoy) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j >= m) return;
+    pep[j] = (float)kde_posterior_error(est, (double)from_total_order_key(sorted_key[j]));
+    row_decoy[j] = sorted_id[j] & 1;
+}
+
+// fdr.rs:91-101: decoy = 1.0; target = 0.0; for row { decoy += pep; if !row.decoy { target += 1.0 }; q = decoy / target }
+// — f32 running sums, strictly in row order.  One wavefront: 64 rows are loaded at once, the two sums are carried through
+// the 64 lanes with readlane (uniform adds), lane k keeps the sums as they stood after row k.
+__global__ __launch_bounds__(64) void seq_cumsum_kernel(const float* __restrict__ pep, const uint8_t* __restrict__ row_decoy,
+                                                        uint32_t m, float* __restrict__ q) {
+    const uint32_t lane = threadIdx.x;
+    float d = 1.0f, t = 0.0f;
+    for (uint32_t base = 0; base < m; base += 64) {
+        const uint32_t j = base + lane;
+        const float p = j < m ? pep[j] : 0.0f;
+        const float one = (j < m && !row_decoy[j]) ? 1.0f : 0.0f;
+        float dk = 0.0f, tk = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            d = d + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), k));
+            t = t + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, one), k));
+            if (lane == (uint32_t)k) {
+                dk = d;
+                tk = t;
+            }
+        }
+        if (j < m) q[j] = dk / tk;
+    }
+}
+
+__global__ __launch_bounds__(RB) void picked_scatter_kernel(const uint32_t* __restrict__ sorted_id, const float* __restrict__ q,
+                                                            uint32_t m, float* __restrict__ side_q) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j < m) side_q[sorted_id[j]] = q[j];
+}
+
+__global__ __launch_bounds__(RB) void picked_gather_kernel(const uint32_t* __restrict__ key, const uint8_t* __restrict__ decoy,
+                                                           uint64_t n, const float* __restrict__ side_q, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    out[i] = key[i] == 0xFFFFFFFFu ? 1.0f : side_q[2ull * key[i] + (decoy[i] ? 1 : 0)];
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+
+template <class T>
+struct Buf {
+    T* p = nullptr;
+    Buf() = default;
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t count) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+};
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    std::string err;
+    int code = SAGE_HIP_OK;
+    bool check(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        code = e == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+};
+#define RS_TRY(expr)                         \
+    do {                                     \
+        if (!cx.check((expr), #expr)) return false; \
+    } while (0)
+
+uint32_t grid_for(uint64_t n, uint32_t block) { return (uint32_t)std::max<uint64_t>(1, (n + block - 1) / block); }
+uint32_t blocks_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(MAX_BLOCKS, std::max<uint64_t>(1, (n + RB - 1) / RB)); }
+
+struct KdeFit {
+    Buf<double> bins;
+    KdeDev dev{};
+};
+
+// kde::Builder{monotonic, bins, bw_adjust = x * bw_mult}.build(scores, decoys)  (kde.rs:85-133)
+bool kde_build(Ctx& cx, const double* d_scores, const uint8_t* d_decoy, uint64_t n, bool monotonic, uint32_t nbins,
+               double bw_mult, KdeFit& fit) {
+    const uint32_t nb = blocks_for(n);
+    Buf<double> partial;
+    RS_TRY(partial.alloc((size_t)nb * 6));
+    std::vector<double> h((size_t)nb * 6);
+    stats1_kernel<<<nb, RB, 0, cx.stream>>>(d_scores, d_decoy, n, partial.p);
+    RS_TRY(hipMemcpyAsync(h.data(), partial.p, h.size() * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    double cnt[2] = {0, 0}, sum[2] = {0, 0};
+    double mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
+    for (uint32_t b = 0; b < nb; ++b) {
+        cnt[0] += h[b * 6 + 0];
+        cnt[1] += h[b * 6 + 1];
+        sum[0] += h[b * 6 + 2];
+        sum[1] += h[b * 6 + 3];
+        mn = std::fmin(mn, h[b * 6 + 4]);
+        mx = std::fmax(mx, h[b * 6 + 5]);
+    }
+    const double mean_d = sum[0] / cnt[0], mean_t = sum[1] / cnt[1];
+    stats2_kernel<<<nb, RB, 0, cx.stream>>>(d_scores, d_decoy, n, mean_d, mean_t, partial.p);
+    RS_TRY(hipMemcpyAsync(h.data(), partial.p, (size_t)nb * 2 * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    double ss[2] = {0, 0};
+    for (uint32_t b = 0; b < nb; ++b) {
+        ss[0] += h[b * 2];
+        ss[1] += h[b * 2 + 1];
+    }
+    // Kde::new (kde.rs:21-32)
+    double bw[2], constant[2];
+    for (int c = 0; c < 2; ++c) {
+        const double sigma = std::sqrt(ss[c] / cnt[c]);
+        bw[c] = (sigma * std::pow((4.0 / 3.0) / cnt[c], 1.0 / 5.0)) * bw_mult;
+        constant[c] = std::sqrt(2.0 * M_PI) * bw[c] * cnt[c];
+    }
+    const double pi = cnt[0] / (double)n;
+    const double step = (mx - mn) / (double)(nbins - 1);
+    const uint32_t tiles = (nbins + KDE_BINS_PER_BLOCK - 1) / KDE_BINS_PER_BLOCK;
+    const uint32_t slices = (uint32_t)std::min<uint64_t>(KDE_SLICES, std::max<uint64_t>(1, n / (4 * RB)));
+    Buf<double> pdf_partial;
+    RS_TRY(pdf_partial.alloc((size_t)slices * nbins * 2));
+    RS_TRY(fit.bins.alloc(nbins));
+    kde_pdf_kernel<<<dim3(tiles, slices), RB, 0, cx.stream>>>(d_scores, d_decoy, n, mn, step, nbins, bw[0], bw[1], pdf_partial.p);
+    kde_finish_kernel<<<1, 1024, 0, cx.stream>>>(pdf_partial.p, slices, nbins, constant[0], constant[1], pi, monotonic ? 1 : 0,
+                                                fit.bins.p);
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));  // pdf_partial is freed on return
+    fit.dev = KdeDev{fit.bins.p, mn, step, nbins};
+    return true;
+}
+
+// Gauss::solve (gauss.rs:27-165) for the 20 x 20 system: the identical elimination order and epsilon ladder, because the
+// solution of the regularised system depends on both
+struct Dense {
+    std::vector<double> a;
+    size_t rows, cols;
+    Dense(size_t r, size_t c) : a(r * c, 0.0), rows(r), cols(c) {}
+    double& at(size_t i, size_t j) { return a[i * cols + j]; }
+    void swap_rows(size_t i, size_t j) {
+        for (size_t k = 0; k < cols; ++k) std::swap(at(i, k), at(j, k));
+    }
+};
+
+bool gauss_attempt(Dense left, Dense right, double eps, std::vector<double>& out) {
+    const size_t m = left.rows, n = left.cols;
+    for (size_t i = 0; i < n; ++i) left.at(i, i) += eps;  // fill_zero, :62-66
+    size_t h = 0, k = 0;                                  // echelon, :89-124
+    while (h < m && k < n) {
+        size_t piv = 0;
+        double best = std::numeric_limits<double>::lowest();
+        for (size_t i = h; i < m; ++i)
+            if (left.at(i, k) >= best) {
+                piv = i;
+                best = left.at(i, k);
+            }
+        if (left.at(piv, k) == 0.0) {
+            ++k;
+            continue;
+        }
+        if (h != piv) {
+            left.swap_rows(h, piv);
+            right.swap_rows(h, piv);
+        }
+        for (size_t i = h + 1; i < m; ++i) {
+            const double factor = left.at(i, k) / left.at(h, k);
+            left.at(i, k) = 0.0;
+            for (size_t j = k + 1; j < n; ++j) left.at(i, j) -= left.at(h, j) * factor;
+            for (size_t j = 0; j < right.cols; ++j) right.at(i, j) -= right.at(h, j) * factor;
+        }
+        ++h;
+        ++k;
+    }
+    for (size_t i = m; i-- > 0;)  // reduce, :127-143
+        for (size_t j = 0; j < n; ++j) {
+            const double x = left.at(i, j);
+            if (x == 0.0) continue;
+            for (size_t c = j; c < n; ++c) left.at(i, c) /= x;
+            for (size_t c = 0; c < right.cols; ++c) right.at(i, c) /= x;
+            break;
+        }
+    for (size_t i = m; i-- > 0;)  // backfill, :146-164
+        for (size_t j = 0; j < n; ++j) {
+            if (left.at(i, j) == 0.0) continue;
+            for (size_t r = 0; r < i; ++r) {
+                const double factor = left.at(r, j) / left.at(i, j);
+                for (size_t c = 0; c < n; ++c) left.at(r, c) -= left.at(i, c) * factor;
+                for (size_t c = 0; c < right.cols; ++c) right.at(r, c) -= right.at(i, c) * factor;
+            }
+            break;
+        }
+    for (size_t i = 0; i < n; ++i)  // left_solved, :69-87
+        for (size_t j = 0; j < n; ++j) {
+            const double x = left.at(i, j);
+            if (i == j) {
+                if (x != 1.0 && x != 0.0) return false;
+            } else if (x > 1e-8) {
+                return false;
+            }
+        }
+    out = right.a;
+    return true;
+}
+
+bool gauss_solve(const Dense& left, const Dense& right, std::vector<double>& out) {  // :43-52
+    for (double eps = 1e-8; eps <= 1.0; eps *= 10.0)
+        if (gauss_attempt(left, right, eps, out)) return true;
+    return false;
+}
+
+// descending stable sort of `n` f32 scores given as total-order keys; order_out[j] = index of the j-th best
+bool sort_desc(Ctx& cx, uint32_t* d_keys_in, uint32_t* d_idx_in, uint32_t n, uint32_t* d_keys_out, uint32_t* d_idx_out) {
+    size_t temp_bytes = 0;
+    RS_TRY(rocprim::radix_sort_pairs_desc((void*)nullptr, temp_bytes, d_keys_in, d_keys_out, d_idx_in, d_idx_out, n, 0, 32,
+                                          cx.stream));
+    Buf<uint8_t> temp;
+    RS_TRY(temp.alloc(temp_bytes));
+    RS_TRY(rocprim::radix_sort_pairs_desc((void*)temp.p, temp_bytes, d_keys_in, d_keys_out, d_idx_in, d_idx_out, n, 0, 32,
+                                          cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    return true;
+}
+
+// Competition::assign_q_value over dense keys (fdr.rs:60-120) and the write-back of fdr.rs:146-148 / :179-185
+bool picked(Ctx& cx, const uint32_t* d_key, uint32_t n_keys, const uint8_t* d_decoy, const float* d_score, uint64_t n,
+            float* d_q_out, uint64_t& passing) {
+    passing = 0;
+    if (n_keys == 0) {  // no feature takes part: every q stays 1.0
+        Buf<float> dummy;
+        RS_TRY(dummy.alloc(2));
+        picked_gather_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_key, d_decoy, n, dummy.p, d_q_out);
+        RS_TRY(hipStreamSynchronize(cx.stream));
+        return true;
+    }
+    const uint32_t n_rows = 2 * n_keys;
+    Buf<uint32_t> side, row_key, row_id, sorted_key, sorted_id, counters;
+    Buf<double> winner;
+    Buf<uint8_t> winner_decoy, row_decoy;
+    Buf<float> pep, q, side_q;
+    Buf<unsigned long long> d_pass;
+    RS_TRY(side.alloc(n_rows));
+    RS_TRY(row_key.alloc(n_rows));
+    RS_TRY(row_id.alloc(n_rows));
+    RS_TRY(sorted_key.alloc(n_rows));
+    RS_TRY(sorted_id.alloc(n_rows));
+    RS_TRY(counters.alloc(2));
+    RS_TRY(winner.alloc(n_keys));
+    RS_TRY(winner_decoy.alloc(n_keys));
+    RS_TRY(row_decoy.alloc(n_rows));
+    RS_TRY(pep.alloc(n_rows));
+    RS_TRY(q.alloc(n_rows));
+    RS_TRY(side_q.alloc(n_rows));
+    RS_TRY(d_pass.alloc(1));
+    RS_TRY(hipMemsetAsync(side.p, 0, (size_t)n_rows * 4, cx.stream));
+    RS_TRY(hipMemsetAsync(counters.p, 0, 8, cx.stream));
+    picked_max_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_key, d_decoy, d_score, n, side.p);
+    picked_rows_kernel<<<grid_for(n_keys, RB), RB, 0, cx.stream>>>(side.p, n_keys, winner.p, winner_decoy.p, row_key.p, row_id.p,
+                                                                    counters.p);
+    uint32_t h_counters[2];
+    RS_TRY(hipMemcpyAsync(h_counters, counters.p, 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    if (h_counters[1]) {
+        cx.code = SAGE_HIP_ERR_INVALID;
+        cx.err = "sage_hip_rescore: competition keys must be dense (" + std::to_string(h_counters[1]) + " of " +
+                 std::to_string(n_keys) + " ids are not used by any feature)";
+        return false;
+    }
+    const uint32_t m = h_counters[0];
+    KdeFit est;
+    if (!kde_build(cx, winner.p, winner_decoy.p, n_keys, true, 1000, 1.0, est)) return false;
+    if (!sort_desc(cx, row_key.p, row_id.p, n_rows, sorted_key.p, sorted_id.p)) return false;  // absent rows (key 0) sort last
+    picked_pep_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(sorted_key.p, sorted_id.p, m, est.dev, pep.p, row_decoy.p);
+    seq_cumsum_kernel<<<1, 64, 0, cx.stream>>>(pep.p, row_decoy.p, m, q.p);
+    suffix_min_kernel<<<1, 1024, 0, cx.stream>>>(q.p, m, row_decoy.p, 0.01f, d_pass.p);
+    // rows that do not exist keep q = 1.0 (never read: a feature's own side always exists)
+    std::vector<float> ones(n_rows, 1.0f);
+    RS_TRY(hipMemcpyAsync(side_q.p, ones.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, cx.stream));
+    picked_scatter_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(sorted_id.p, q.p, m, side_q.p);
+    picked_gather_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_key, d_decoy, n, side_q.p, d_q_out);
+    unsigned long long h_pass = 0;
+    RS_TRY(hipMemcpyAsync(&h_pass, d_pass.p, 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    passing = h_pass;
+    return true;
+}
+
+bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
+    const uint64_t n = in.n;
+    const int tol_kind = in.precursor_tol.kind;
+    Buf<SageFeature> feats;
+    Buf<uint8_t> decoy;
+    Buf<double> dmass, rows, disc, partial, folded;
+    Buf<float> a_rt, d_rt, d_ims, discriminant, posterior, spectrum_q, peptide_q, protein_q, qsorted;
+    Buf<uint32_t> pkey, prkey, keys, idx, keys_sorted, order;
+    Buf<unsigned long long> d_pass;
+    RS_TRY(feats.alloc(n));
+    RS_TRY(decoy.alloc(n));
+    RS_TRY(dmass.alloc(n));
+    RS_TRY(rows.alloc(n * NF));
+    RS_TRY(disc.alloc(n));
+    RS_TRY(discriminant.alloc(n));
+    RS_TRY(posterior.alloc(n));
+    RS_TRY(spectrum_q.alloc(n));
+    RS_TRY(peptide_q.alloc(n));
+    RS_TRY(protein_q.alloc(n));
+    RS_TRY(qsorted.alloc(n));
+    RS_TRY(pkey.alloc(n));
+    RS_TRY(prkey.alloc(n));
+    RS_TRY(keys.alloc(n));
+    RS_TRY(idx.alloc(n));
+    RS_TRY(keys_sorted.alloc(n));
+    RS_TRY(order.alloc(n));
+    RS_TRY(d_pass.alloc(1));
+    RS_TRY(hipMemcpyAsync(feats.p, in.features, n * sizeof(SageFeature), hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemcpyAsync(pkey.p, in.peptide_key, n * 4, hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemcpyAsync(prkey.p, in.protein_key, n * 4, hipMemcpyHostToDevice, cx.stream));
+    const float* opt[3] = {in.aligned_rt, in.delta_rt_model, in.delta_ims_model};
+    Buf<float>* optbuf[3] = {&a_rt, &d_rt, &d_ims};
+    for (int k = 0; k < 3; ++k)
+        if (opt[k]) {
+            RS_TRY(optbuf[k]->alloc(n));
+            RS_TRY(hipMemcpyAsync(optbuf[k]->p, opt[k], n * 4, hipMemcpyHostToDevice, cx.stream));
+        }
+    hipEvent_t ev0, ev1;
+    RS_TRY(hipEventCreate(&ev0));
+    RS_TRY(hipEventCreate(&ev1));
+    RS_TRY(hipEventRecord(ev0, cx.stream));
+    const uint32_t g = grid_for(n, RB);
+    prep_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, tol_kind, decoy.p, dmass.p);
+
+    // ---- score_psms (linear_discriminant.rs:133-231) ----
+    const double bw_adjust = tol_kind == SAGE_TOL_PPM ? 2.0 : 0.1;  // :146-150
+    const float span = in.precursor_tol.hi - in.precursor_tol.lo;
+    const float bin_size = tol_kind == SAGE_TOL_PPM ? std::fmax(span, 100.0f) : std::fmax(span, 1000.0f);
+    const uint32_t mass_bins = (uint32_t)std::fabs(std::ceil(bin_size));
+    KdeFit mass_model;
+    if (!kde_build(cx, dmass.p, decoy.p, n, false, mass_bins, bw_adjust, mass_model)) return false;
+    rows_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, dmass.p, mass_model.dev, a_rt.p, d_rt.p, d_ims.p, rows.p);
+
+    // train (:57-127): class sums -> means -> scatter -> solve
+    const uint32_t nb = blocks_for(n);
+    RS_TRY(partial.alloc((size_t)nb * 2 * NF * NF));
+    RS_TRY(folded.alloc(2 * NF * NF + 2 * NF));
+    class_sum_kernel<<<nb, 64, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
+    fold_partials_kernel<<<1, RB, 0, cx.stream>>>(partial.p, nb, 2 * NF, folded.p);
+    double class_sum[2][NF];
+    RS_TRY(hipMemcpyAsync(class_sum, folded.p, sizeof(class_sum), hipMemcpyDeviceToHost, cx.stream));
+    // class counts: the decoy flags summed by the mass-model fit would do; recount on the host from the labels instead
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    uint64_t class_count[2] = {0, 0};
+    for (uint64_t i = 0; i < n; ++i) class_count[in.features[i].label == -1 ? 0 : 1]++;
+    bool fitted = class_count[0] != 0 && class_count[1] != 0;  // :83-85
+    std::vector<double> coef;
+    if (fitted) {
+        double class_mean[2][NF];
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < NF; ++j) class_mean[c][j] = class_sum[c][j] / (double)class_count[c];
+        double* d_mean = folded.p + 2 * NF * NF;
+        RS_TRY(hipMemcpyAsync(d_mean, class_mean, sizeof(class_mean), hipMemcpyHostToDevice, cx.stream));
+        scatter_kernel<<<nb, SCATTER_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, d_mean, partial.p);
+        fold_partials_kernel<<<grid_for(2 * NF * NF, RB), RB, 0, cx.stream>>>(partial.p, nb, 2 * NF * NF, folded.p);
+        std::vector<double> scatter(2 * NF * NF);
+        RS_TRY(hipMemcpyAsync(scatter.data(), folded.p, scatter.size() * 8, hipMemcpyDeviceToHost, cx.stream));
+        RS_TRY(hipStreamSynchronize(cx.stream));
+        Dense within(NF, NF), mu(NF, 1);
+        for (int c = 0; c < 2; ++c)  // :105-108
+            for (int e = 0; e < NF * NF; ++e) within.a[e] += scatter[c * NF * NF + e] / (double)class_count[c];
+        for (int j = 0; j < NF; ++j) mu.a[j] = class_mean[1][j] - class_mean[0][j];
+        fitted = gauss_solve(within, mu, coef);
+        if (fitted)
+            for (double c : coef)
+                if (!std::isfinite(c)) fitted = false;  // :198-210
+    }
+    out.lda_fitted = fitted ? 1 : 0;
+    std::memset(out.coef, 0, sizeof(out.coef));
+    KdeFit kde;
+    if (fitted) {
+        Coef cf;
+        for (int j = 0; j < NF; ++j) out.coef[j] = cf.w[j] = coef[j];
+        project_kernel<<<g, RB, 0, cx.stream>>>(rows.p, n, cf, disc.p);
+        if (!kde_build(cx, disc.p, decoy.p, n, true, 1000, 1.0, kde)) return false;
+        pep_kernel<<<g, RB, 0, cx.stream>>>(disc.p, n, kde.dev, discriminant.p, posterior.p);
+    } else {
+        heuristic_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, discriminant.p, posterior.p);
+    }
+
+    // ---- runner.rs:290-291: sort by discriminant, spectrum_q_value ----
+    sort_keys_kernel<<<g, RB, 0, cx.stream>>>(discriminant.p, (uint32_t)n, keys.p, idx.p);
+    if (!sort_desc(cx, keys.p, idx.p, (uint32_t)n, keys_sorted.p, order.p)) return false;
+    count_q_kernel<<<1, 1024, 0, cx.stream>>>(order.p, decoy.p, (uint32_t)n, qsorted.p);
+    suffix_min_kernel<<<1, 1024, 0, cx.stream>>>(qsorted.p, (uint32_t)n, nullptr, 0.01f, d_pass.p);
+    scatter_by_order_kernel<<<g, RB, 0, cx.stream>>>(order.p, qsorted.p, (uint32_t)n, spectrum_q.p);
+    unsigned long long h_pass = 0;
+    RS_TRY(hipMemcpyAsync(&h_pass, d_pass.p, 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    out.passing_spectrum = h_pass;
+
+    // ---- fdr.rs:123-187 ----
+    if (!picked(cx, pkey.p, in.n_peptide_keys, decoy.p, discriminant.p, n, peptide_q.p, out.passing_peptide)) return false;
+    if (!picked(cx, prkey.p, in.n_protein_keys, decoy.p, discriminant.p, n, protein_q.p, out.passing_protein)) return false;
+    RS_TRY(hipEventRecord(ev1, cx.stream));
+
+    RS_TRY(hipMemcpyAsync(out.discriminant_score, discriminant.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.posterior_error, posterior.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.spectrum_q, spectrum_q.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.peptide_q, peptide_q.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.protein_q, protein_q.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    if (out.order) RS_TRY(hipMemcpyAsync(out.order, order.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    float ms = 0.0f;
+    RS_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    out.device_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return true;
+}
+
+}  // namespace
+
+// entry point used by capi.hip; returns a SAGE_HIP_* status, message in `err`
+int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err) {
+    Ctx cx;
+    if (hipSetDevice(device) != hipSuccess) {
+        err = "sage_hip_rescore: hipSetDevice failed";
+        return SAGE_HIP_ERR_NO_DEVICE;
+    }
+    if (!cx.check(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        err = cx.err;
+        return cx.code;
+    }
+    const bool ok = rescore_impl(cx, in, out);
+    (void)hipStreamSynchronize(cx.stream);
+    (void)hipStreamDestroy(cx.stream);
+    if (!ok) {
+        err = cx.err;
+        return cx.code ? cx.code : SAGE_HIP_ERR_HIP;
+    }
+    return SAGE_HIP_OK;
+}
+
+}  // namespace sagehip

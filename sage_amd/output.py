@@ -3,10 +3,13 @@
 Column order and number formatting follow the reference byte for byte where the hot path owns the value:
 sage-cli/src/runner.rs:687-780 (serialize_feature), :782-828 (serialize_fragments), :830-935 (headers).  Integers are
 written with `itoa`, floats with `ryu` (shortest digits that round-trip, Rust `ryu::Buffer::format`), reproduced by
-`ryu_f32` / `ryu_f64` below.  Columns the path does not compute (rescoring / FDR outputs) carry the defaults Feature
-gets in build_features (scoring.rs:576-592): discriminant 0.0, posterior_error 1.0, q-values 1.0, predicted_rt 0.0,
-aligned_rt = rt, delta_rt_model / delta_ims_model 0.999.
+`ryu_f32` / `ryu_f64` below.  sage_discriminant_score, posterior_error, spectrum_q, peptide_q and protein_q come from the
+device rescoring (sage_hip_rescore); columns nothing here computes (retention-time / mobility models, protein groups)
+carry the defaults Feature gets in build_features (scoring.rs:576-592): predicted_rt 0.0, aligned_rt = rt,
+delta_rt_model / delta_ims_model 0.999, protein_group_q 1.0.  `results.sage.pin` follows runner.rs:938-1135.
 """
+import ctypes
+import re
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -63,8 +66,13 @@ def ryu_f64(x) -> str:
     return _ryu(x, False)
 
 
-def feature_row(psm_id: int, f, db, filename: str, scannr: str) -> List[str]:
-    """serialize_feature (runner.rs:687-780) for one SageFeature record `f` (numpy void of FEATURE_DTYPE)."""
+DEFAULT_POST = dict(discriminant_score=0.0, posterior_error=1.0, spectrum_q=1.0, peptide_q=1.0, protein_q=1.0)
+
+
+def feature_row(psm_id: int, f, db, filename: str, scannr: str, post: Optional[dict] = None) -> List[str]:
+    """serialize_feature (runner.rs:687-780) for one SageFeature record `f` (numpy void of FEATURE_DTYPE); `post` = the
+    rescoring outputs of this PSM (defaults of scoring.rs:576-592 when the rescoring did not run)."""
+    post = post or DEFAULT_POST
     pep = int(f["peptide_idx"])
     num_proteins, semi = db.peptide_info(pep)
     rt = f["rt"]
@@ -76,7 +84,8 @@ def feature_row(psm_id: int, f, db, filename: str, scannr: str) -> List[str]:
         ryu_f64(f["delta_best"]), ryu_f32(rt), ryu_f32(rt), ryu_f32(0.0), ryu_f32(0.999), ryu_f32(f["ims"]), ryu_f32(0.0),
         ryu_f32(0.999), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
         ryu_f32(f["longest_y_pct"]), ryu_f32(f["matched_intensity_pct"]), str(int(f["scored_candidates"])),
-        ryu_f64(f["poisson"]), ryu_f32(0.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0), ryu_f32(1.0),
+        ryu_f64(f["poisson"]), ryu_f32(post["discriminant_score"]), ryu_f32(post["posterior_error"]),
+        ryu_f32(post["spectrum_q"]), ryu_f32(post["peptide_q"]), ryu_f32(post["protein_q"]), ryu_f32(1.0),
         ryu_f32(f["ms2_intensity"]),
     ]
 
@@ -99,5 +108,59 @@ def fragment_rows(psm_id: int, lo: int, hi: int, arr) -> List[List[str]]:
 def write_fragments(path: str, rows: Sequence[List[str]]) -> None:
     with open(path, "w", newline="") as fh:
         fh.write("\t".join(FRAGMENT_HEADERS) + "\n")
+        for r in rows:
+            fh.write("\t".join(r) + "\n")
+
+
+PIN_HEADERS = ["SpecId", "Label", "ScanNr", "ExpMass", "CalcMass", "FileName", "retentiontime", "ion_mobility", "rank", "z=2",
+               "z=3", "z=4", "z=5", "z=6", "z=other", "peptide_len", "missed_cleavages", "semi_enzymatic", "isotope_error",
+               "ln(precursor_ppm)", "fragment_ppm", "ln(hyperscore)", "ln(delta_next)", "ln(delta_best)", "aligned_rt",
+               "predicted_rt", "sqrt(delta_rt_model)", "predicted_mobility", "sqrt(delta_mobility)", "matched_peaks", "longest_b",
+               "longest_y", "longest_y_pct", "ln(matched_intensity_pct)", "scored_candidates", "ln(-poisson)", "posterior_error",
+               "Peptide", "Proteins"]
+_SCAN_RE = re.compile(r"scan=(\d+)")
+_libm = ctypes.CDLL("libm.so.6")
+_libm.log1pf.restype = ctypes.c_float
+_libm.log1pf.argtypes = [ctypes.c_float]
+_libm.log1p.restype = ctypes.c_double
+_libm.log1p.argtypes = [ctypes.c_double]
+
+
+def _ln1p_f32(x) -> np.float32:  # f32::ln_1p == libm log1pf
+    return np.float32(_libm.log1pf(float(np.float32(x))))
+
+
+def _ln1p_f64(x) -> np.float64:
+    return np.float64(_libm.log1p(float(x)))
+
+
+def pin_row(psm_id: int, f, db, filename: str, spec_id: str, post: Optional[dict] = None) -> List[str]:
+    """serialize_pin (runner.rs:938-1084): percolator input, log / sqrt transformed feature columns."""
+    post = post or DEFAULT_POST
+    pep = int(f["peptide_idx"])
+    _, semi = db.peptide_info(pep)
+    caps = _SCAN_RE.findall(spec_id)
+    scannr = caps[-1] if caps else spec_id
+    z = int(f["charge"])
+    rt = f["rt"]
+    delta_rt = np.float32(0.999)  # delta_rt_model default (no retention-time model); .clamp(0.001, 1.0) leaves it
+    return [
+        str(psm_id), str(int(f["label"])), scannr, ryu_f32(f["expmass"]), ryu_f32(f["calcmass"]), filename, ryu_f32(rt),
+        ryu_f32(f["ims"]), str(int(f["rank"])), str(int(z == 2)), str(int(z == 3)), str(int(z == 4)), str(int(z == 5)),
+        str(int(z == 6)), str(z if (z < 2 or z > 6) else 0), str(int(f["peptide_len"])), str(int(f["missed_cleavages"])),
+        str(semi), ryu_f32(f["isotope_error"]), ryu_f32(_ln1p_f32(np.abs(np.float32(f["delta_mass"])))),
+        ryu_f32(f["average_ppm"]), ryu_f64(_ln1p_f64(f["hyperscore"])), ryu_f64(_ln1p_f64(f["delta_next"])),
+        ryu_f64(_ln1p_f64(f["delta_best"])), ryu_f32(rt), ryu_f32(0.0), ryu_f32(np.sqrt(delta_rt, dtype=np.float32)),
+        ryu_f32(0.0), ryu_f32(0.999), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
+        ryu_f32(f["longest_y_pct"]), ryu_f32(_ln1p_f32(f["matched_intensity_pct"])), str(int(f["scored_candidates"])),
+        ryu_f64(_ln1p_f64(-np.float64(f["poisson"]))), ryu_f32(post["posterior_error"]), db.peptide_string(pep),
+        db.peptide_proteins(pep),
+    ]
+
+
+def write_pin(path: str, rows: Sequence[List[str]]) -> None:
+    """write_pin (runner.rs:1086-1135)."""
+    with open(path, "w", newline="") as fh:
+        fh.write("\t".join(PIN_HEADERS) + "\n")
         for r in rows:
             fh.write("\t".join(r) + "\n")

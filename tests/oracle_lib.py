@@ -31,7 +31,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sage_oracle.cpp", "sage_oracle.hpp", "oracle_capi.cpp", "selftest.cpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sage_oracle.cpp", "sage_oracle.hpp", "oracle_capi.cpp", "rescore_oracle.cpp",
+                                                "selftest.cpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs if os.path.exists(s)):
         build()
     lib = C.CDLL(LIB)
@@ -78,6 +79,16 @@ def load():
     lib.orc_quick_score.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_int, L.c_u8_p]
     lib.orc_tol_bounds.argtypes = [L.SageTolerance, C.c_float, L.c_float_p, L.c_float_p]
     lib.orc_max_threads.restype = C.c_int
+    dp = C.POINTER(C.c_double)
+    lib.orc_lda_train.restype = C.c_int
+    lib.orc_lda_train.argtypes = [dp, C.c_uint64, C.c_uint64, L.c_u8_p, dp]
+    lib.orc_gauss_solve.restype = C.c_int
+    lib.orc_gauss_solve.argtypes = [dp, dp, C.c_uint64, dp]
+    lib.orc_kde.argtypes = [dp, L.c_u8_p, C.c_uint64, C.c_int, C.c_uint64, C.c_double, dp, dp, dp, C.c_uint64, dp]
+    lib.orc_rescore.restype = C.c_int
+    lib.orc_rescore.argtypes = [vp, C.c_uint64, C.c_int, C.c_float, C.c_float, L.c_float_p, L.c_float_p, L.c_float_p,
+                                L.c_u32_p, C.c_uint32, L.c_u32_p, C.c_uint32, L.c_float_p, L.c_float_p, L.c_float_p,
+                                L.c_float_p, L.c_float_p, L.c_u32_p, L.c_u64_p, dp, dp]
     _lib = lib
     return lib
 
@@ -236,3 +247,59 @@ def tol_bounds(tol, center):
     lo, hi = C.c_float(), C.c_float()
     load().orc_tol_bounds(tol.to_c(), center, C.byref(lo), C.byref(hi))
     return np.float32(lo.value), np.float32(hi.value)
+
+
+# ---- post-search rescoring (oracle/rescore_oracle.cpp) ----------------------------------------------------------------
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def lda_train(rows, decoy):
+    """LinearDiscriminantAnalysis::train (linear_discriminant.rs:57-127) -> coefficients or None"""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    decoy = np.ascontiguousarray(decoy, dtype=np.uint8)
+    coef = np.zeros(rows.shape[1])
+    ok = load().orc_lda_train(_dptr(rows), rows.shape[0], rows.shape[1], L.as_ptr(decoy, C.c_uint8), _dptr(coef))
+    return coef if ok else None
+
+
+def gauss_solve(left, right):
+    left = np.ascontiguousarray(left, dtype=np.float64)
+    right = np.ascontiguousarray(right, dtype=np.float64)
+    out = np.zeros(len(right))
+    ok = load().orc_gauss_solve(_dptr(left), _dptr(right), len(right), _dptr(out))
+    return out if ok else None
+
+
+def kde(scores, decoys, monotonic=True, bins=1000, bw_mult=1.0, queries=()):
+    """kde::Builder::build + Estimator::posterior_error -> (bins, min_score, score_step, pep(queries))"""
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    decoys = np.ascontiguousarray(decoys, dtype=np.uint8)
+    q = np.ascontiguousarray(queries, dtype=np.float64)
+    out_bins, ms, pep = np.zeros(bins), np.zeros(2), np.zeros(len(q))
+    load().orc_kde(_dptr(scores), L.as_ptr(decoys, C.c_uint8), len(scores), int(monotonic), bins, bw_mult, _dptr(out_bins),
+                   _dptr(ms), _dptr(q), len(q), _dptr(pep))
+    return out_bins, ms[0], ms[1], pep
+
+
+def rescore(features, precursor_tol, peptide_key, n_peptide_keys, protein_key, n_protein_keys, aligned_rt=None,
+            delta_rt_model=None, delta_ims_model=None, want_rows=False):
+    """spectrum_fdr + picked_peptide + picked_protein (runner.rs:536-541); dict of arrays in input order."""
+    f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
+    n = len(f)
+    pk = np.ascontiguousarray(peptide_key, dtype=np.uint32)
+    prk = np.ascontiguousarray(protein_key, dtype=np.uint32)
+    opt = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (aligned_rt, delta_rt_model, delta_ims_model)]
+    outs = {k: np.empty(n, np.float32) for k in ("discriminant_score", "posterior_error", "spectrum_q", "peptide_q", "protein_q")}
+    order = np.empty(n, np.uint32)
+    passing = np.zeros(3, np.uint64)
+    coef = np.zeros(20)
+    rows = np.zeros((n, 20)) if want_rows else None
+    t = precursor_tol.to_c()
+    fitted = load().orc_rescore(f.ctypes.data, n, t.kind, t.lo, t.hi, *[None if a is None else L.as_ptr(a, C.c_float) for a in opt],
+                                L.as_ptr(pk, C.c_uint32), n_peptide_keys, L.as_ptr(prk, C.c_uint32), n_protein_keys,
+                                *[L.as_ptr(outs[k], C.c_float) for k in ("discriminant_score", "posterior_error", "spectrum_q",
+                                                                           "peptide_q", "protein_q")],
+                                L.as_ptr(order, C.c_uint32), L.as_ptr(passing, C.c_uint64), _dptr(coef),
+                                None if rows is None else _dptr(rows))
+    return dict(outs, order=order, passing=passing, coef=coef, lda_fitted=bool(fitted), rows=rows)

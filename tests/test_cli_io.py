@@ -110,14 +110,17 @@ def test_cli_on_the_reference_config(tmp_path, gpu_required):
     cp = str(tmp_path / "config.json")
     json.dump(cfg, open(cp, "w"))
     out = str(tmp_path / "out")
-    cli.main([cp, "-o", out])
+    cli.main([cp, "-o", out, "--write-pin"])
     hdr, rows = _read_tsv(os.path.join(out, "results.sage.tsv"))
     assert hdr == output.HEADERS and len(rows) == 1
     r = dict(zip(hdr, rows[0]))
     assert r["psm_id"] == "1" and r["peptide"] == "LQSRPAAPPAPGPGQLTLR" and r["proteins"] == "sp|Q99536|VAT1_HUMAN"
     assert r["charge"] == "3" and r["rank"] == "1" and r["label"] == "1"
     assert r["filename"] == "LQSRPAAPPAPGPGQLTLR.mzML" and r["scannr"] == raw.id
-    assert r["spectrum_q"] == "1.0" and r["delta_rt_model"] == "0.999" and r["sage_discriminant_score"] == "0.0"
+    # one target, no decoy: the linear model cannot be fitted (linear_discriminant.rs:83-85) -> heuristic discriminant of
+    # runner.rs:285-288, posterior_error stays 1.0, q = (1 decoy pseudo-count) / (1 target) = 1.0
+    assert r["spectrum_q"] == "1.0" and r["peptide_q"] == "1.0" and r["protein_q"] == "1.0" and r["posterior_error"] == "1.0"
+    assert r["delta_rt_model"] == "0.999" and r["protein_group_q"] == "1.0"
     # the numbers are the oracle's, formatted by ryu
     db = oracle_lib.OracleDb.build(d["fasta"], DatabaseParameters.from_json(d["config_json"]["database"]))
     sp = SpectrumProcessor(150, True, 0.0)
@@ -126,9 +129,19 @@ def test_cli_on_the_reference_config(tmp_path, gpu_required):
     assert oc[0] == 1 and r["matched_peaks"] == str(int(of[0, 0]["matched_peaks"])) == "22"
     assert r["hyperscore"] == output.ryu_f64(of[0, 0]["hyperscore"]) and r["expmass"] == output.ryu_f32(of[0, 0]["expmass"])
     assert r["precursor_ppm"] == output.ryu_f32(of[0, 0]["delta_mass"]) and r["poisson"] == output.ryu_f64(of[0, 0]["poisson"])
+    heur = np.log1p(np.float32(-of[0, 0]["poisson"])) + of[0, 0]["longest_y_pct"] / np.float32(3.0)
+    assert abs(float(r["sage_discriminant_score"]) - float(heur)) <= 1e-5 * abs(float(heur))
     fh, frows = _read_tsv(os.path.join(out, "matched_fragments.sage.tsv"))
     assert fh == output.FRAGMENT_HEADERS and len(frows) == 22 and all(x[0] == "1" for x in frows)
     assert {x[1] for x in frows} <= {"b", "y"}
+    # results.sage.pin (runner.rs:938-1135): log-transformed columns, the scan number picked out of the spectrum id
+    ph, prows = _read_tsv(os.path.join(out, "results.sage.pin"))
+    assert ph == output.PIN_HEADERS and len(prows) == 1
+    p = dict(zip(ph, prows[0]))
+    assert p["SpecId"] == "1" and p["Label"] == "1" and p["Peptide"] == "LQSRPAAPPAPGPGQLTLR" and p["z=3"] == "1" and p["z=2"] == "0"
+    assert p["ScanNr"] == (raw.id.split("scan=")[-1] if "scan=" in raw.id else raw.id)
+    assert p["ln(hyperscore)"] == output.ryu_f64(np.log1p(of[0, 0]["hyperscore"])) and p["posterior_error"] == "1.0"
+    assert p["sqrt(delta_rt_model)"] == output.ryu_f32(np.sqrt(np.float32(0.999)))
 
 
 @pytest.mark.gpu
@@ -150,9 +163,14 @@ def test_cli_synthetic_two_files(tmp_path, gpu_required):
     out = str(tmp_path / "o")
     cli.main([cp, "--output_directory", out])
     hdr, rows = _read_tsv(os.path.join(out, "results.sage.tsv"))
-    assert len(rows) > 60 and [r[0] for r in rows] == [str(i + 1) for i in range(len(rows))]  # psm_id counts from 1
+    assert len(rows) > 60 and sorted(int(r[0]) for r in rows) == list(range(1, len(rows) + 1))  # psm_id counts from 1
     assert {r[hdr.index("filename")] for r in rows} == {"run0.mzML", "run1.mzML"}
-    # same spectra scored by the oracle: identical hyperscore column
+    # rows come out in the order spectrum_fdr leaves them: best discriminant first (runner.rs:290), q-values non-decreasing
+    disc = [float(r[hdr.index("sage_discriminant_score")]) for r in rows]
+    assert disc == sorted(disc, reverse=True)
+    q = [float(r[hdr.index("spectrum_q")]) for r in rows]
+    assert q == sorted(q) and 0 < q[0] <= 1.0
+    # same spectra scored by the oracle: identical hyperscore column (rows matched up by psm_id = creation order)
     sp = SpectrumProcessor(150, True, 0.0)
     orc = oracle_lib.OracleDb.from_product(host)
     want = []
@@ -160,4 +178,5 @@ def test_cli_synthetic_two_files(tmp_path, gpu_required):
         proc = [q for q in (sp.process(r) for r in read_mzml(p, k)) if len(q.masses) >= 15]
         of, oc, _, _ = orc.score(cli.scorer_params(cli.search_parameters(cfg)), SpectrumBatch.from_spectra(proc))
         want += [output.ryu_f64(of[i, r]["hyperscore"]) for i in range(len(proc)) for r in range(int(oc[i]))]
-    assert [r[hdr.index("hyperscore")] for r in rows] == want
+    by_id = sorted(rows, key=lambda r: int(r[0]))
+    assert [r[hdr.index("hyperscore")] for r in by_id] == want

@@ -1,0 +1,202 @@
+"""The rescoring oracle (oracle/rescore_oracle.cpp) against the reference's known-answer test and against independent
+numpy restatements of the pieces the reference does not pin — CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from rescore_utils import synthetic_features
+from sage_amd.api import DatabaseParameters, Tolerance
+
+
+def test_reference_kat_linear_discriminant():
+    """crates/sage/src/ml/linear_discriminant.rs:238-288: 8 rows, 4 features, normalised projections to 1e-8."""
+    feats = np.array([[5, 4, 3, 2], [4, 5, 4, 3], [6, 3, 4, 5], [1, 0, 2, 9], [5, 4, 4, 3], [2, 1, 1, 9.5], [1, 0, 2, 8],
+                      [3, 2, -2, 10]], dtype=np.float64)
+    decoy = np.array([0, 0, 0, 1, 0, 1, 1, 1], dtype=np.uint8)
+    coef = oracle_lib.lda_train(feats, decoy)
+    assert coef is not None
+    scores = np.array([sum(w * x for w, x in zip(coef, row)) for row in feats])
+    scores /= np.sqrt(np.sum(scores ** 2))
+    expected = [0.49706043, 0.48920177, 0.48920177, -0.07209359, 0.51204672, -0.02849527, -0.04924864, -0.06055943]
+    assert np.all(np.abs(scores - expected) <= 1e-8)
+
+
+def test_lda_needs_both_classes():
+    rows = np.random.default_rng(0).normal(size=(10, 3))
+    assert oracle_lib.lda_train(rows, np.zeros(10, np.uint8)) is None
+    assert oracle_lib.lda_train(rows, np.ones(10, np.uint8)) is None
+
+
+def test_gauss_solve_with_epsilon_ladder():
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(6, 6))
+    spd = a @ a.T + 6 * np.eye(6)
+    b = rng.normal(size=6)
+    x = oracle_lib.gauss_solve(spd, b)
+    assert np.allclose(x, np.linalg.solve(spd + 1e-8 * np.eye(6), b), rtol=1e-9, atol=1e-12)  # fill_zero(1e-8), gauss.rs:62
+    # a zero row/column (a constant feature): the regularised system still solves, that coefficient is 0 / eps = 0
+    spd[3, :] = 0
+    spd[:, 3] = 0
+    b[3] = 0
+    x = oracle_lib.gauss_solve(spd, b)
+    assert x is not None and x[3] == 0.0
+
+
+def _numpy_kde(scores, decoys, monotonic, bins, bw_mult):
+    """kde.rs:21-133 restated with numpy (independent of the C++ oracle)."""
+    d, t = scores[decoys == 1], scores[decoys == 0]
+    pi = len(d) / len(scores)
+
+    def pdf(sample, x):
+        sigma = np.sqrt(np.mean((sample - np.mean(sample)) ** 2))
+        h = sigma * (4.0 / 3.0 / len(sample)) ** 0.2 * bw_mult
+        return np.exp(-0.5 * ((x[:, None] - sample[None, :]) / h) ** 2).sum(axis=1) / (np.sqrt(2 * np.pi) * h * len(sample))
+
+    lo, hi = scores.min(), scores.max()
+    step = (hi - lo) / (bins - 1)
+    x = np.arange(bins) * step + lo
+    dd, tt = pdf(d, x) * pi, pdf(t, x) * (1 - pi)
+    pep = dd / (tt + dd)
+    if monotonic:
+        pep = np.maximum.accumulate(pep[::-1])[::-1]
+    return pep, lo, step
+
+
+@pytest.mark.parametrize("monotonic,bins,bw", [(True, 1000, 1.0), (False, 100, 2.0)])
+def test_kde_against_numpy(monotonic, bins, bw):
+    rng = np.random.default_rng(2)
+    decoys = (rng.random(3000) < 0.4).astype(np.uint8)
+    scores = np.where(decoys == 1, rng.normal(-1, 1, 3000), rng.normal(2, 1.5, 3000))
+    q = rng.uniform(scores.min() - 1, scores.max() + 1, 50)
+    ob, lo, step, pep = oracle_lib.kde(scores, decoys, monotonic, bins, bw, q)
+    nb, nlo, nstep = _numpy_kde(scores, decoys, monotonic, bins, bw)
+    assert lo == nlo and step == nstep
+    assert np.allclose(ob, nb, rtol=1e-10, atol=1e-300)
+    # Estimator::posterior_error (kde.rs:146-168): linear interpolation, clamped bin index, extrapolation below/above
+    last = bins - 1
+    for x, p in zip(q, pep):
+        b = int(min(last, max(0, np.floor((x - lo) / step))))
+        h = min(last, b + 1)
+        assert np.isclose(p, ob[b] + (ob[h] - ob[b]) * ((x - (b * step + lo)) / step), rtol=1e-12, atol=1e-300)
+
+
+def _numpy_q(score_sorted_decoy):
+    d = 1 + np.cumsum(score_sorted_decoy)
+    t = np.cumsum(~score_sorted_decoy)
+    with np.errstate(divide="ignore"):
+        q = d.astype(np.float32) / t.astype(np.float32)
+    return np.minimum(np.minimum.accumulate(q[::-1])[::-1], np.float32(1.0))
+
+
+def test_rescore_pipeline_pieces():
+    f, pk, npk, prk, npr = synthetic_features(4000, seed=3)
+    tol = Tolerance("ppm", -10.0, 10.0)
+    r = oracle_lib.rescore(f, tol, pk, npk, prk, npr, want_rows=True)
+    assert r["lda_fitted"]
+    decoy = f["label"] == -1
+    # the design: spot-check columns of compute_features (linear_discriminant.rs:162-195)
+    rows = r["rows"]
+    assert np.allclose(rows[:, 2], np.log1p(f["hyperscore"]))
+    assert np.allclose(rows[:, 8], np.log1p(-f["poisson"]))
+    assert np.all(rows[:, 10] == f["matched_peaks"]) and np.allclose(rows[:, 13], f["longest_y"] / f["peptide_len"])
+    assert np.allclose(rows[:, 18], np.sqrt(0.999)) and np.all(rows[:, 16] == f["rt"].astype(np.float64))
+    # coefficients: LDA direction solves Sw w = mu_t - mu_d (regularised)
+    mu_t, mu_d = rows[~decoy].mean(0), rows[decoy].mean(0)
+    sw = np.cov(rows[~decoy].T, bias=True) + np.cov(rows[decoy].T, bias=True)
+    w = np.linalg.solve(sw + 1e-8 * np.eye(20), mu_t - mu_d)
+    assert np.allclose(r["coef"], w, rtol=1e-5, atol=1e-6)
+    disc = rows @ r["coef"]
+    assert np.allclose(r["discriminant_score"], disc.astype(np.float32), rtol=1e-6)
+    # targets separate from decoys
+    assert np.median(disc[~decoy]) > np.median(disc[decoy])
+    # order: stable, descending total order; q-values from the counts
+    order = r["order"]
+    assert np.all(np.diff(r["discriminant_score"][order]) <= 0)
+    q = _numpy_q(decoy[order])
+    assert np.array_equal(r["spectrum_q"][order], q)
+    assert r["passing"][0] == np.sum(q <= 0.01)
+    assert np.all(r["posterior_error"] <= 0.0 + 1e-6) and np.all(r["posterior_error"] >= -324.0)
+    # picked peptide: per (key, side) maxima, one q per side, features of a side share it; shared proteins keep 1.0
+    for k in np.unique(pk)[:50]:
+        for side in (False, True):
+            m = (pk == k) & (decoy == side)
+            if m.any():
+                assert len(np.unique(r["peptide_q"][m])) == 1
+    assert np.all(r["protein_q"][prk == 0xFFFFFFFF] == 1.0)
+    assert np.all((r["peptide_q"] > 0) & (r["peptide_q"] <= 1.0))
+
+
+def test_picked_competition_worked_example():
+    """fdr.rs:60-120 by hand on 3 keys: rows sorted by score, decoy += pep, target += 1, reverse cumulative minimum."""
+    f, *_ = synthetic_features(6, seed=4)
+    f["label"] = [1, -1, 1, 1, -1, 1]
+    f["poisson"] = [-9.0, -1.0, -7.0, -3.0, -2.0, -8.0]
+    f["longest_y_pct"] = 0.0
+    pk = np.array([0, 0, 1, 2, 2, 0], dtype=np.uint32)
+    prk = np.full(6, 0xFFFFFFFF, dtype=np.uint32)
+    r = oracle_lib.rescore(f[:1].repeat(6) if False else f, Tolerance("ppm", -10.0, 10.0), pk, 3, prk, 0)
+    disc = r["discriminant_score"]
+    decoy = f["label"] == -1
+    # rows (key, side) -> best score
+    rows = {}
+    for i in range(6):
+        key = (int(pk[i]), bool(decoy[i]))
+        rows[key] = max(rows.get(key, -np.inf), float(disc[i]))
+    win_s = np.array([max(rows.get((k, False), np.finfo(np.float32).min), rows.get((k, True), np.finfo(np.float32).min)) for k in range(3)])
+    win_d = np.array([rows.get((k, True), np.finfo(np.float32).min) >= rows.get((k, False), np.finfo(np.float32).min) for k in range(3)])
+    srt = sorted(rows.items(), key=lambda kv: -kv[1])
+    _, _, _, pep = oracle_lib.kde(win_s, win_d.astype(np.uint8), True, 1000, 1.0, [s for _, s in srt])
+    d, t, qs = np.float32(1.0), np.float32(0.0), []
+    for (key, s), p in zip(srt, pep):
+        d = np.float32(d + np.float32(p))
+        if not key[1]:
+            t = np.float32(t + 1)
+        with np.errstate(divide="ignore"):
+            qs.append(np.float32(d) / np.float32(t))
+    qmin, out = np.float32(1.0), {}
+    for (key, _), q in zip(reversed(srt), reversed(qs)):
+        qmin = min(qmin, q) if q == q else qmin
+        out[key] = qmin
+    for i in range(6):
+        exp = out[(int(pk[i]), bool(decoy[i]))]
+        got = r["peptide_q"][i]
+        assert (np.isnan(exp) and np.isnan(got)) or got == exp
+
+
+def test_competition_keys_pair_targets_with_their_decoys():
+    fasta = ">sp|P1|A\nMKAAAGGGLLLKDDDEEEFFFKWWWYYYR\n>sp|P2|B\nMKAAAGGGLLLKCCCHHHIIIK\n"
+    params = DatabaseParameters.from_json({"enzyme": {"missed_cleavages": 0, "min_len": 5}, "static_mods": {}, "decoy_tag": "rev_",
+                                           "generate_decoys": True, "fasta": "x"})
+    host = params.build(fasta, peptides_only=True)
+    n = host.n_peptides
+    pk, npk, prk, npr = host.competition_keys(np.arange(n, dtype=np.uint32))
+    strings = [host.peptide_string(i) for i in range(n)]
+    decoy = host.decoy.astype(bool)
+    assert decoy.any() and (~decoy).any()
+
+    def flip(s):
+        return s if len(s) < 3 else s[0] + s[1:-1][::-1] + s[-1]
+
+    for i in range(n):
+        key_string = flip(strings[i]) if decoy[i] else strings[i]
+        for j in range(n):
+            other = flip(strings[j]) if decoy[j] else strings[j]
+            assert (pk[i] == pk[j]) == (key_string == other)
+    assert npk == len(set(pk)) and set(pk) == set(range(npk))
+    # AAAGGGLLLK occurs in both proteins: shared -> no protein key; unique peptides get their protein's key
+    for i in range(n):
+        nprot, _ = host.peptide_info(i)
+        assert (prk[i] == 0xFFFFFFFF) == (nprot != 1)
+    assert npr == len(set(prk[prk != 0xFFFFFFFF]))
+
+
+def test_heuristic_fallback_when_the_pivot_search_skips_a_column():
+    """A constant ims column gives an exactly-zero scatter row; with this data the signed-maximum pivot search of
+    gauss.rs:97-108 lands on that zero and skips the column, left_solved() fails for every epsilon, and spectrum_fdr falls
+    back to ln_1p(-poisson) + longest_y_pct / 3 (runner.rs:285-288) with posterior_error left at its default."""
+    f, pk, npk, prk, npr = synthetic_features(4000, seed=3, zero_ims=True)
+    r = oracle_lib.rescore(f, Tolerance("ppm", -10.0, 10.0), pk, npk, prk, npr)
+    assert not r["lda_fitted"]
+    exp = np.log1p((-f["poisson"]).astype(np.float32)) + f["longest_y_pct"] / np.float32(3.0)
+    assert np.allclose(r["discriminant_score"], exp, rtol=1e-6)
+    assert np.all(r["posterior_error"] == 1.0)
