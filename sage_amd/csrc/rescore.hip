@@ -28,6 +28,8 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "../../include/sage_hip.h"
 
@@ -234,16 +236,30 @@ __global__ __launch_bounds__(RB) void rows_kernel(const SageFeature* __restrict_
 }
 
 // pass 1 of train (linear_discriminant.rs:70-82): partial[b][cls][j] = sum of column j over the block's rows of class cls.
-// Thread t of a block owns (cls, column) = (t / 20, t % 20) for t < 40; rows are walked in order.
-__global__ __launch_bounds__(64) void class_sum_kernel(const double* __restrict__ rows, const uint8_t* __restrict__ decoy,
-                                                       uint64_t n, double* __restrict__ partial) {
+// 240 threads = 12 row lanes x 20 columns: a step reads 12 whole rows (coalesced), each thread keeps the two class sums of
+// its (row lane, column); the 12 row lanes are then added in lane order.
+constexpr int CSUM_LANES = 12;
+__global__ __launch_bounds__(CSUM_LANES * NF) void class_sum_kernel(const double* __restrict__ rows,
+                                                                    const uint8_t* __restrict__ decoy, uint64_t n,
+                                                                    double* __restrict__ partial) {
+    __shared__ double part[CSUM_LANES][2][NF];
     const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    if (threadIdx.x >= 2 * NF) return;
-    const int cls = threadIdx.x / NF, j = threadIdx.x % NF;
-    double s = 0.0;
-    for (uint64_t i = lo; i < hi; ++i)
-        if ((decoy[i] ? 0 : 1) == cls) s += rows[i * NF + j];
-    partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = s;
+    const int rl = threadIdx.x / NF, j = threadIdx.x % NF;
+    double s[2] = {0.0, 0.0};
+    for (uint64_t i = lo + rl; i < hi; i += CSUM_LANES) {
+        const double v = rows[i * NF + j];
+        if (decoy[i]) s[0] += v;
+        else s[1] += v;
+    }
+    part[rl][0][j] = s[0];
+    part[rl][1][j] = s[1];
+    __syncthreads();
+    if (threadIdx.x < 2 * NF) {
+        const int cls = threadIdx.x / NF;
+        double t = 0.0;
+        for (int r = 0; r < CSUM_LANES; ++r) t += part[r][cls][j];
+        partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = t;
+    }
 }
 
 // pass 2 of train (:92-103): partial[b][cls][j][k] = sum over the block's rows of class cls of (x_j - mu_j)(x_k - mu_k).
@@ -335,74 +351,33 @@ __global__ __launch_bounds__(RB) void sort_keys_kernel(const float* __restrict__
     idx[i] = i;
 }
 
-// qvalue.rs:16-24 on the sorted order: q[j] = (1 + decoys in [0, j]) / (targets in [0, j]).  One block; every thread owns a
-// contiguous chunk, chunk totals are prefixed through LDS.
-__global__ __launch_bounds__(1024) void count_q_kernel(const uint32_t* __restrict__ order, const uint8_t* __restrict__ decoy,
-                                                       uint32_t n, float* __restrict__ q) {
-    __shared__ uint32_t cd[1024], ct[1024];
-    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    uint32_t d = 0, t = 0;
-    for (uint32_t j = lo; j < hi; ++j) {
-        if (decoy[order[j]]) ++d;
-        else ++t;
-    }
-    cd[threadIdx.x] = d;
-    ct[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t sd = 0, st = 0;
-        for (int k = 0; k < 1024; ++k) {
-            const uint32_t a = cd[k], b = ct[k];
-            cd[k] = sd;
-            ct[k] = st;
-            sd += a;
-            st += b;
-        }
-    }
-    __syncthreads();
-    d = cd[threadIdx.x] + 1;  // `let mut decoy = 1`
-    t = ct[threadIdx.x];
-    for (uint32_t j = lo; j < hi; ++j) {
-        if (decoy[order[j]]) ++d;
-        else ++t;
-        q[j] = (float)d / (float)t;
-    }
+// flags[j] = 1 when the j-th best PSM is a decoy (input of the prefix count of qvalue.rs:16-24)
+__global__ __launch_bounds__(RB) void decoy_flags_kernel(const uint32_t* __restrict__ order, const uint8_t* __restrict__ decoy,
+                                                         uint32_t n, uint32_t* __restrict__ flags) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j < n) flags[j] = decoy[order[j]] ? 1u : 0u;
 }
 
-// the reverse cumulative minimum of qvalue.rs:27-35 / fdr.rs:104-112, in place, and the passing count:
-// q_min starts at 1.0; passing counts rows with q_min <= threshold (and, when `row_decoy` is given, not decoy).
-__global__ __launch_bounds__(1024) void suffix_min_kernel(float* __restrict__ q, uint32_t n, const uint8_t* __restrict__ row_decoy,
-                                                          float threshold, unsigned long long* __restrict__ passing) {
-    __shared__ float cm[1024];
-    __shared__ uint32_t cp[1024];
-    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
-    float m = 1.0f;
-    for (uint32_t j = lo; j < hi; ++j) m = fminf(m, q[j]);
-    cm[threadIdx.x] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {  // cm[k] <- minimum over all LATER chunks
-        float carry = 1.0f;
-        for (int k = 1023; k >= 0; --k) {
-            const float own = cm[k];
-            cm[k] = carry;
-            carry = fminf(carry, own);
-        }
-    }
-    __syncthreads();
-    m = cm[threadIdx.x];
-    uint32_t pass = 0;
-    for (uint32_t j = hi; j-- > lo;) {
-        m = fminf(m, q[j]);
-        q[j] = m;
-        if (m <= threshold && !(row_decoy && row_decoy[j])) ++pass;
-    }
-    cp[threadIdx.x] = pass;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (int k = 0; k < 1024; ++k) s += cp[k];
-        *passing = s;
-    }
+// qvalue.rs:16-24 on the sorted order: q[j] = (1 + decoys in [0, j]) / (targets in [0, j]), already folded with the 1.0 the
+// reverse cumulative minimum starts from (min is associative: min(1, min(a, b)) == min(min(1, a), min(1, b)))
+__global__ __launch_bounds__(RB) void q_from_counts_kernel(const uint32_t* __restrict__ decoy_cum, uint32_t n, float* __restrict__ q) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t d = 1u + decoy_cum[j], t = (j + 1u) - decoy_cum[j];  // `let mut decoy = 1; let mut target = 0;`
+    q[j] = fminf(1.0f, (float)d / (float)t);
+}
+
+struct OpFmin {
+    __device__ float operator()(float a, float b) const { return fminf(a, b); }
+};
+
+// rows passing `threshold` after the reverse cumulative minimum (qvalue.rs:31-33; fdr.rs:108-110 also requires a target row)
+__global__ __launch_bounds__(RB) void count_passing_kernel(const float* __restrict__ q, uint32_t n, const uint8_t* __restrict__ row_decoy,
+                                                           float threshold, unsigned long long* __restrict__ passing) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    const bool pass = j < n && q[j] <= threshold && !(row_decoy && row_decoy[j]);
+    const unsigned long long b = __ballot(pass);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(passing, (unsigned long long)__popcll(b));
 }
 
 __global__ __launch_bounds__(RB) void scatter_by_order_kernel(const uint32_t* __restrict__ order, const float* __restrict__ q,
@@ -446,38 +421,89 @@ __global__ __launch_bounds__(RB) void picked_rows_kernel(const uint32_t* __restr
     else atomicAdd(&counters[1], 1u);
 }
 
-// rows in sorted order: their posterior error (fdr.rs:94) and side
+// rows in sorted order: their posterior error (fdr.rs:94), side, and the target flag the prefix count runs over; pep is
+// zero-padded to a whole number of seq_cumsum_kernel tiles
 __global__ __launch_bounds__(RB) void picked_pep_kernel(const uint32_t* __restrict__ sorted_key, const uint32_t* __restrict__ sorted_id,
-                                                        uint32_t m, KdeDev est, float* __restrict__ pep, uint8_t* __restrict__ row_decoy) {
+                                                        uint32_t m, uint32_t m_padded, KdeDev est, float* __restrict__ pep,
+                                                        uint8_t* __restrict__ row_decoy, uint32_t* __restrict__ target_flag) {
     const uint32_t j = blockIdx.x * RB + threadIdx.x;
-    if (j >= m) return;
+    if (j >= m_padded) return;
+    if (j >= m) {
+        pep[j] = 0.0f;
+        return;
+    }
     pep[j] = (float)kde_posterior_error(est, (double)from_total_order_key(sorted_key[j]));
-    row_decoy[j] = sorted_id[j] & 1;
+    const uint32_t dec = sorted_id[j] & 1;
+    row_decoy[j] = (uint8_t)dec;
+    target_flag[j] = dec ^ 1u;
 }
 
-// fdr.rs:91-101: decoy = 1.0; target = 0.0; for row { decoy += pep; if !row.decoy { target += 1.0 }; q = decoy / target }
-// — f32 running sums, strictly in row order.  One wavefront: 64 rows are loaded at once, the two sums are carried through
-// the 64 lanes with readlane (uniform adds), lane k keeps the sums as they stood after row k.
-__global__ __launch_bounds__(64) void seq_cumsum_kernel(const float* __restrict__ pep, const uint8_t* __restrict__ row_decoy,
-                                                        uint32_t m, float* __restrict__ q) {
+// fdr.rs:91-101: decoy = 1.0; target = 0.0; for row { decoy += pep; if !row.decoy { target += 1.0 }; q = decoy / target }.
+// `decoy` is an f32 running sum whose rounding depends on the order, so it is evaluated strictly in row order by ONE
+// wavefront whose lanes all carry the same running sum: one dependent v_add_f32 per row.  The wavefront streams the pep
+// values through LDS in tiles of 1024 rows (the next tile's global loads are in flight while the current one is summed),
+// reads them back with uniform addresses, parks the running sums of 64 rows in LDS and lane k stores the sum as it stood
+// after row k.  Nothing in the loop waits on global memory.  `target` counts whole numbers (exact in f32 below 2^24) and
+// comes from the parallel prefix count; the division is picked_q_kernel's.
+constexpr int CS_TILE = 1024;
+__global__ __launch_bounds__(64) void seq_cumsum_kernel(const float* __restrict__ pep /* zero-padded to m_padded */,
+                                                        uint32_t m_padded /* multiple of CS_TILE, > 0 */,
+                                                        float* __restrict__ dsum) {
+    __shared__ float4 tile[CS_TILE / 4];
+    __shared__ float4 run[16];
     const uint32_t lane = threadIdx.x;
-    float d = 1.0f, t = 0.0f;
-    for (uint32_t base = 0; base < m; base += 64) {
-        const uint32_t j = base + lane;
-        const float p = j < m ? pep[j] : 0.0f;
-        const float one = (j < m && !row_decoy[j]) ? 1.0f : 0.0f;
-        float dk = 0.0f, tk = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            d = d + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), k));
-            t = t + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, one), k));
-            if (lane == (uint32_t)k) {
-                dk = d;
-                tk = t;
-            }
+    const float4* src = reinterpret_cast<const float4*>(pep);
+    float4 n0 = src[lane], n1 = src[64 + lane], n2 = src[128 + lane], n3 = src[192 + lane];
+    float d = 1.0f;
+    for (uint32_t base = 0; base < m_padded; base += CS_TILE) {
+        tile[lane] = n0;
+        tile[64 + lane] = n1;
+        tile[128 + lane] = n2;
+        tile[192 + lane] = n3;
+        __syncthreads();
+        {  // next tile (the last iteration re-reads its own tile: no branch, nothing spilled)
+            const uint32_t nb = (base + CS_TILE < m_padded ? base + CS_TILE : base) / 4;
+            n0 = src[nb + lane];
+            n1 = src[nb + 64 + lane];
+            n2 = src[nb + 128 + lane];
+            n3 = src[nb + 192 + lane];
         }
-        if (j < m) q[j] = dk / tk;
+        float4 cur[16], nxt[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cur[i] = tile[i];  // uniform addresses: every lane reads the same 64 values
+        for (int c = 0; c < CS_TILE / 64; ++c) {
+            const int cn = c + 1 < CS_TILE / 64 ? c + 1 : c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nxt[i] = tile[cn * 16 + i];  // in flight during the 64 dependent adds below
+            float4 r[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                d = d + cur[i].x;
+                r[i].x = d;
+                d = d + cur[i].y;
+                r[i].y = d;
+                d = d + cur[i].z;
+                r[i].z = d;
+                d = d + cur[i].w;
+                r[i].w = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) run[i] = r[i];
+            __syncthreads();
+            dsum[base + c * 64 + lane] = reinterpret_cast<const float*>(run)[lane];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        }
     }
+}
+
+// q = decoy / target, folded with the 1.0 the reverse minimum starts from (a NaN q — no target yet and a NaN posterior
+// error — becomes 1.0, as f32::min makes it in fdr.rs:107)
+__global__ __launch_bounds__(RB) void picked_q_kernel(const float* __restrict__ dsum, const uint32_t* __restrict__ target_cum,
+                                                      uint32_t m, float* __restrict__ q) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j < m) q[j] = fminf(1.0f, dsum[j] / (float)target_cum[j]);
 }
 
 __global__ __launch_bounds__(RB) void picked_scatter_kernel(const uint32_t* __restrict__ sorted_id, const float* __restrict__ q,
@@ -678,6 +704,31 @@ bool sort_desc(Ctx& cx, uint32_t* d_keys_in, uint32_t* d_idx_in, uint32_t n, uin
     return true;
 }
 
+// out[j] = sum of flags[0..j]
+bool prefix_count(Ctx& cx, const uint32_t* d_flags, uint32_t* d_out, uint32_t n) {
+    size_t temp_bytes = 0;
+    RS_TRY(rocprim::inclusive_scan((void*)nullptr, temp_bytes, d_flags, d_out, (size_t)n, rocprim::plus<uint32_t>(), cx.stream));
+    Buf<uint8_t> temp;
+    RS_TRY(temp.alloc(temp_bytes));
+    RS_TRY(rocprim::inclusive_scan((void*)temp.p, temp_bytes, d_flags, d_out, (size_t)n, rocprim::plus<uint32_t>(), cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    return true;
+}
+
+// out[j] = min(q[j], q[j + 1], ..., q[n - 1]): the reverse cumulative minimum of qvalue.rs:27-35 / fdr.rs:104-112
+bool suffix_min(Ctx& cx, const float* d_q, float* d_out, uint32_t n) {
+    if (n == 0) return true;
+    auto in = rocprim::make_reverse_iterator(d_q + n);
+    auto out = rocprim::make_reverse_iterator(d_out + n);
+    size_t temp_bytes = 0;
+    RS_TRY(rocprim::inclusive_scan((void*)nullptr, temp_bytes, in, out, (size_t)n, OpFmin(), cx.stream));
+    Buf<uint8_t> temp;
+    RS_TRY(temp.alloc(temp_bytes));
+    RS_TRY(rocprim::inclusive_scan((void*)temp.p, temp_bytes, in, out, (size_t)n, OpFmin(), cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    return true;
+}
+
 // Competition::assign_q_value over dense keys (fdr.rs:60-120) and the write-back of fdr.rs:146-148 / :179-185
 bool picked(Ctx& cx, const uint32_t* d_key, uint32_t n_keys, const uint8_t* d_decoy, const float* d_score, uint64_t n,
             float* d_q_out, uint64_t& passing) {
@@ -693,7 +744,8 @@ bool picked(Ctx& cx, const uint32_t* d_key, uint32_t n_keys, const uint8_t* d_de
     Buf<uint32_t> side, row_key, row_id, sorted_key, sorted_id, counters;
     Buf<double> winner;
     Buf<uint8_t> winner_decoy, row_decoy;
-    Buf<float> pep, q, side_q;
+    Buf<float> pep, dsum, q, qmin, side_q;
+    Buf<uint32_t> target_flag, target_cum;
     Buf<unsigned long long> d_pass;
     RS_TRY(side.alloc(n_rows));
     RS_TRY(row_key.alloc(n_rows));
@@ -704,8 +756,12 @@ bool picked(Ctx& cx, const uint32_t* d_key, uint32_t n_keys, const uint8_t* d_de
     RS_TRY(winner.alloc(n_keys));
     RS_TRY(winner_decoy.alloc(n_keys));
     RS_TRY(row_decoy.alloc(n_rows));
-    RS_TRY(pep.alloc(n_rows));
+    RS_TRY(pep.alloc((size_t)n_rows + CS_TILE));
+    RS_TRY(dsum.alloc((size_t)n_rows + CS_TILE));
     RS_TRY(q.alloc(n_rows));
+    RS_TRY(qmin.alloc(n_rows));
+    RS_TRY(target_flag.alloc(n_rows));
+    RS_TRY(target_cum.alloc(n_rows));
     RS_TRY(side_q.alloc(n_rows));
     RS_TRY(d_pass.alloc(1));
     RS_TRY(hipMemsetAsync(side.p, 0, (size_t)n_rows * 4, cx.stream));
@@ -726,13 +782,19 @@ bool picked(Ctx& cx, const uint32_t* d_key, uint32_t n_keys, const uint8_t* d_de
     KdeFit est;
     if (!kde_build(cx, winner.p, winner_decoy.p, n_keys, true, 1000, 1.0, est)) return false;
     if (!sort_desc(cx, row_key.p, row_id.p, n_rows, sorted_key.p, sorted_id.p)) return false;  // absent rows (key 0) sort last
-    picked_pep_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(sorted_key.p, sorted_id.p, m, est.dev, pep.p, row_decoy.p);
-    seq_cumsum_kernel<<<1, 64, 0, cx.stream>>>(pep.p, row_decoy.p, m, q.p);
-    suffix_min_kernel<<<1, 1024, 0, cx.stream>>>(q.p, m, row_decoy.p, 0.01f, d_pass.p);
+    const uint32_t m_padded = (m + CS_TILE - 1u) / CS_TILE * CS_TILE;
+    picked_pep_kernel<<<grid_for(m_padded, RB), RB, 0, cx.stream>>>(sorted_key.p, sorted_id.p, m, m_padded, est.dev, pep.p,
+                                                                     row_decoy.p, target_flag.p);
+    if (!prefix_count(cx, target_flag.p, target_cum.p, m)) return false;
+    seq_cumsum_kernel<<<1, 64, 0, cx.stream>>>(pep.p, m_padded, dsum.p);
+    picked_q_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(dsum.p, target_cum.p, m, q.p);
+    if (!suffix_min(cx, q.p, qmin.p, m)) return false;
+    RS_TRY(hipMemsetAsync(d_pass.p, 0, 8, cx.stream));
+    count_passing_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(qmin.p, m, row_decoy.p, 0.01f, d_pass.p);
     // rows that do not exist keep q = 1.0 (never read: a feature's own side always exists)
     std::vector<float> ones(n_rows, 1.0f);
     RS_TRY(hipMemcpyAsync(side_q.p, ones.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, cx.stream));
-    picked_scatter_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(sorted_id.p, q.p, m, side_q.p);
+    picked_scatter_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(sorted_id.p, qmin.p, m, side_q.p);
     picked_gather_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_key, d_decoy, n, side_q.p, d_q_out);
     unsigned long long h_pass = 0;
     RS_TRY(hipMemcpyAsync(&h_pass, d_pass.p, 8, hipMemcpyDeviceToHost, cx.stream));
@@ -748,7 +810,7 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     Buf<SageFeature> feats;
     Buf<uint8_t> decoy;
     Buf<double> dmass, rows, disc, partial, folded;
-    Buf<float> a_rt, d_rt, d_ims, discriminant, posterior, spectrum_q, peptide_q, protein_q, qsorted;
+    Buf<float> a_rt, d_rt, d_ims, discriminant, posterior, spectrum_q, peptide_q, protein_q, qsorted, qmin_sorted;
     Buf<uint32_t> pkey, prkey, keys, idx, keys_sorted, order;
     Buf<unsigned long long> d_pass;
     RS_TRY(feats.alloc(n));
@@ -762,6 +824,7 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     RS_TRY(peptide_q.alloc(n));
     RS_TRY(protein_q.alloc(n));
     RS_TRY(qsorted.alloc(n));
+    RS_TRY(qmin_sorted.alloc(n));
     RS_TRY(pkey.alloc(n));
     RS_TRY(prkey.alloc(n));
     RS_TRY(keys.alloc(n));
@@ -799,7 +862,7 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     const uint32_t nb = blocks_for(n);
     RS_TRY(partial.alloc((size_t)nb * 2 * NF * NF));
     RS_TRY(folded.alloc(2 * NF * NF + 2 * NF));
-    class_sum_kernel<<<nb, 64, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
+    class_sum_kernel<<<nb, CSUM_LANES * NF, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
     fold_partials_kernel<<<1, RB, 0, cx.stream>>>(partial.p, nb, 2 * NF, folded.p);
     double class_sum[2][NF];
     RS_TRY(hipMemcpyAsync(class_sum, folded.p, sizeof(class_sum), hipMemcpyDeviceToHost, cx.stream));
@@ -845,9 +908,13 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     // ---- runner.rs:290-291: sort by discriminant, spectrum_q_value ----
     sort_keys_kernel<<<g, RB, 0, cx.stream>>>(discriminant.p, (uint32_t)n, keys.p, idx.p);
     if (!sort_desc(cx, keys.p, idx.p, (uint32_t)n, keys_sorted.p, order.p)) return false;
-    count_q_kernel<<<1, 1024, 0, cx.stream>>>(order.p, decoy.p, (uint32_t)n, qsorted.p);
-    suffix_min_kernel<<<1, 1024, 0, cx.stream>>>(qsorted.p, (uint32_t)n, nullptr, 0.01f, d_pass.p);
-    scatter_by_order_kernel<<<g, RB, 0, cx.stream>>>(order.p, qsorted.p, (uint32_t)n, spectrum_q.p);
+    decoy_flags_kernel<<<g, RB, 0, cx.stream>>>(order.p, decoy.p, (uint32_t)n, keys.p);  // (keys / idx are free again)
+    if (!prefix_count(cx, keys.p, idx.p, (uint32_t)n)) return false;
+    q_from_counts_kernel<<<g, RB, 0, cx.stream>>>(idx.p, (uint32_t)n, qsorted.p);
+    if (!suffix_min(cx, qsorted.p, qmin_sorted.p, (uint32_t)n)) return false;
+    RS_TRY(hipMemsetAsync(d_pass.p, 0, 8, cx.stream));
+    count_passing_kernel<<<g, RB, 0, cx.stream>>>(qmin_sorted.p, (uint32_t)n, nullptr, 0.01f, d_pass.p);
+    scatter_by_order_kernel<<<g, RB, 0, cx.stream>>>(order.p, qmin_sorted.p, (uint32_t)n, spectrum_q.p);
     unsigned long long h_pass = 0;
     RS_TRY(hipMemcpyAsync(&h_pass, d_pass.p, 8, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipGetLastError());
