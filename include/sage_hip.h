@@ -109,6 +109,20 @@ typedef struct SageHostDb SageHostDb;
 
 /* Parameters::build(Fasta::parse(text)) — database.rs:260-263, fasta.rs:16-56 */
 int sage_hip_hostdb_build(const char* fasta_text, const SageDbParams* params, SageHostDb** out);
+/* ---- the `prefilter` flow of sage-cli (runner.rs:104-127, :143-238) ----------------------------------------------------
+ * database.prefilter: the FASTA is searched in chunks of `prefilter_chunk_size` target proteins with Scorer::quick_score
+ * (sage_hip_quick_score_resident), and the final database holds only the peptides some spectrum picked. */
+/* Fasta::parse(..).targets.len() (fasta.rs:16-56) */
+int sage_hip_fasta_num_targets(const char* fasta_text, const SageDbParams* params, uint64_t* out);
+/* Parameters::auto_calculate_prefilter_chunk_size (database.rs:142-160); `requested` = the configured value, 0 = auto */
+int sage_hip_prefilter_chunk_size(const char* fasta_text, const SageDbParams* params, uint64_t requested, uint64_t* out);
+/* Parameters::build over targets [first_target, first_target + n_targets): one chunk of Fasta::iter_chunks (fasta.rs:81-89) */
+int sage_hip_hostdb_build_chunk(const char* fasta_text, const SageDbParams* params, uint64_t first_target, uint64_t n_targets,
+                                SageHostDb** out);
+/* runner.rs:215-238: the kept peptides of every chunk (keep[c][ix] != 0, consecutive chunks in FASTA order), through
+ * Parameters::reorder_peptides and build_from_peptides (honours params->peptides_only) */
+int sage_hip_hostdb_merge_kept(const SageHostDb* const* chunks, const uint8_t* const* keep, uint32_t n_chunks,
+                               const SageDbParams* params, SageHostDb** out);
 void sage_hip_hostdb_free(SageHostDb* db);
 int sage_hip_hostdb_view(const SageHostDb* db, SageDbView* out);
 /* Display string of peptide i ("[+42]-MEWK...", peptide.rs:391-408) and its ';'-joined proteins;

@@ -147,6 +147,45 @@ void* orc_db_build(const char* fasta_text, const OrcDbParams* p) {
     return new IndexedDatabase(P.build(fasta));
 }
 
+// ---- the `prefilter` flow (sage-cli runner.rs:104-127, :143-238) ----
+// one chunk of Fasta::iter_chunks (fasta.rs:81-89): targets [first, first + count)
+void* orc_db_build_chunk(const char* fasta_text, const OrcDbParams* p, uint64_t first, uint64_t count) {
+    Parameters P = make_params(p);
+    Fasta fasta = Fasta::parse(fasta_text, P.decoy_tag, P.generate_decoys);
+    Fasta chunk;
+    chunk.decoy_tag = fasta.decoy_tag;
+    chunk.generate_decoys = fasta.generate_decoys;
+    for (uint64_t i = first; i < fasta.targets.size() && i < first + count; i++) chunk.targets.push_back(fasta.targets[i]);
+    return new IndexedDatabase(P.build(chunk));
+}
+uint64_t orc_fasta_num_targets(const char* fasta_text, const OrcDbParams* p) {
+    Parameters P = make_params(p);
+    return Fasta::parse(fasta_text, P.decoy_tag, P.generate_decoys).targets.size();
+}
+// Parameters::auto_calculate_prefilter_chunk_size (database.rs:142-160)
+uint64_t orc_prefilter_chunk_size(const char* fasta_text, const OrcDbParams* p, uint64_t requested) {
+    if (requested) return requested;
+    Parameters P = make_params(p);
+    Fasta fasta = Fasta::parse(fasta_text, P.decoy_tag, P.generate_decoys);
+    const uint64_t max_peps_per_chunk = 1ull << 23;
+    const uint64_t total_unmodified_pep_count = fasta.digest(P.enzyme.to_parameters()).size();
+    const uint64_t mod_count_estimate = (P.variable_mods.size() + 1) * (1ull << P.max_variable_mods);
+    const uint64_t chunk_count = mod_count_estimate * total_unmodified_pep_count / max_peps_per_chunk;
+    return chunk_count == 0 ? fasta.targets.size() : fasta.targets.size() / chunk_count;
+}
+// runner.rs:215-238: retain keep[ix] peptides of every chunk database, reorder_peptides, build_from_peptides
+void* orc_db_merge_kept(void* const* chunks, const uint8_t* const* keep, uint32_t n_chunks, const OrcDbParams* p) {
+    Parameters P = make_params(p);
+    std::vector<Peptide> all;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const IndexedDatabase* db = (const IndexedDatabase*)chunks[c];
+        for (size_t i = 0; i < db->peptides.size(); i++)
+            if (keep[c][i]) all.push_back(db->peptides[i]);
+    }
+    Parameters::reorder_peptides(all);
+    return new IndexedDatabase(P.build_from_peptides(std::move(all)));
+}
+
 // Construct an oracle database from a flat (product-shaped) index: used by the cpu_baseline leg
 // so both legs score against byte-identical inputs.
 void* orc_db_from_arrays(const uint32_t* frag_pep, const float* frag_mz, uint64_t nf, const float* min_value,

@@ -238,6 +238,11 @@ def load():
         "sage_hip_host_free": (None, [vp]),
         "sage_hip_rescore": (C.c_int, [C.c_int, C.POINTER(SageRescoreInput), C.POINTER(SageRescoreOutput)]),
         "sage_hip_hostdb_competition_keys": (C.c_int, [vp, c_u32_p, C.c_uint64, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
+        "sage_hip_fasta_num_targets": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), c_u64_p]),
+        "sage_hip_prefilter_chunk_size": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), C.c_uint64, c_u64_p]),
+        "sage_hip_hostdb_build_chunk": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+        "sage_hip_hostdb_merge_kept": (C.c_int, [C.POINTER(vp), C.POINTER(c_u8_p), C.c_uint32, C.POINTER(SageDbParams),
+                                                 C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
@@ -254,7 +259,8 @@ EXPORTED_SYMBOLS = [
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
-    "sage_hip_rescore", "sage_hip_hostdb_competition_keys",
+    "sage_hip_rescore", "sage_hip_hostdb_competition_keys", "sage_hip_fasta_num_targets", "sage_hip_prefilter_chunk_size",
+    "sage_hip_hostdb_build_chunk", "sage_hip_hostdb_merge_kept",
 ]
 
 

@@ -46,6 +46,9 @@ class DatabaseParameters:
     decoy_tag: Optional[str] = None
     generate_decoys: Optional[bool] = None
     fasta: Optional[str] = None
+    prefilter: Optional[bool] = None             # database.rs:88-92: search the FASTA in chunks first (runner.rs:104-127)
+    prefilter_chunk_size: Optional[int] = None   # target proteins per chunk; None / 0 = auto (database.rs:142-160)
+    prefilter_low_memory: Optional[bool] = None  # default true (database.rs:113)
     peptides_only: bool = False  # ours: stop after reorder_peptides; the fragment index is then built on the device
 
     @staticmethod
@@ -121,6 +124,44 @@ class DatabaseParameters:
             p.peptides_only = int(peptides_only)
         h = C.c_void_p()
         L.check(lib.sage_hip_hostdb_build(fasta_text.encode(), C.byref(p), C.byref(h)))
+        return IndexedDatabase(h)
+
+    # ---- the `prefilter` flow of sage-cli (runner.rs:104-127, :143-238) ----
+    def num_targets(self, fasta_text: str) -> int:
+        """Fasta::parse(..).targets.len()"""
+        p, keep = self.to_c()
+        n = C.c_uint64()
+        L.check(L.load().sage_hip_fasta_num_targets(fasta_text.encode(), C.byref(p), C.byref(n)))
+        return int(n.value)
+
+    def auto_prefilter_chunk_size(self, fasta_text: str) -> int:
+        """Parameters::auto_calculate_prefilter_chunk_size (database.rs:142-160)"""
+        p, keep = self.to_c()
+        n = C.c_uint64()
+        L.check(L.load().sage_hip_prefilter_chunk_size(fasta_text.encode(), C.byref(p), int(self.prefilter_chunk_size or 0),
+                                                       C.byref(n)))
+        return int(n.value)
+
+    def build_chunk(self, fasta_text: str, first_target: int, n_targets: int, peptides_only: Optional[bool] = None):
+        """Parameters::build over one chunk of Fasta::iter_chunks (fasta.rs:81-89)"""
+        p, keep = self.to_c()
+        if peptides_only is not None:
+            p.peptides_only = int(peptides_only)
+        h = C.c_void_p()
+        L.check(L.load().sage_hip_hostdb_build_chunk(fasta_text.encode(), C.byref(p), first_target, n_targets, C.byref(h)))
+        return IndexedDatabase(h)
+
+    def merge_kept(self, chunks, keeps, peptides_only: Optional[bool] = None) -> "IndexedDatabase":
+        """runner.rs:215-238: the peptides quick_score kept in every chunk database -> reorder_peptides -> build_from_peptides"""
+        p, keep = self.to_c()
+        if peptides_only is not None:
+            p.peptides_only = int(peptides_only)
+        masks = [np.ascontiguousarray(k, dtype=np.uint8) for k in keeps]
+        assert all(len(m) == c.n_peptides for m, c in zip(masks, chunks))
+        hs = (C.c_void_p * max(len(chunks), 1))(*[c._h for c in chunks])
+        ms = (L.c_u8_p * max(len(chunks), 1))(*[L.as_ptr(m, C.c_uint8) for m in masks])
+        h = C.c_void_p()
+        L.check(L.load().sage_hip_hostdb_merge_kept(hs, ms, len(chunks), C.byref(p), C.byref(h)))
         return IndexedDatabase(h)
 
 

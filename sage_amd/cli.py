@@ -55,6 +55,51 @@ def scorer_params(sp: dict) -> ScorerParams:
                         annotate_matches=sp["annotate_matches"], score_type=sp["score_type"])
 
 
+def _upload(scorer, processor, raw, sp, host_preprocess):
+    """read spectra -> resident ProcessedSpectrum batch (+ spectrum ids); None when nothing is left to search"""
+    if host_preprocess:  # SpectrumProcessor::process on the host (C++), spectra below min_peaks dropped (runner.rs:313)
+        processed = [processor.process(r) for r in raw]
+        processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]
+        if not processed:
+            return None, []
+        return scorer.upload(SpectrumBatch.from_spectra(processed)), [p.id for p in processed]
+    # ... or on the device: raw peaks in, PSMs out; spectra below min_peaks stay in the batch with zero peaks
+    dbatch, _ = scorer.process_upload(RawBatch(raw), sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
+    return dbatch, [r.id for r in raw]
+
+
+def prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, processor, device, host_preprocess, log):
+    """Runner::prefilter_peptides (runner.rs:143-238): search every spectrum against the FASTA one chunk of target proteins
+    at a time with Scorer::quick_score, keep the peptides some spectrum picked, merge the survivors (reorder_peptides) and
+    leave build_from_peptides to the device.  The scorer of this pass reports one PSM more than the final one (runner.rs:190)."""
+    raws = [read_mzml(path, file_id=file_id, ms_level=2) for file_id, path in enumerate(mzml_paths)]
+    pass_params = scorer_params(dict(sp, report_psms=sp["report_psms"] + 1))
+    chunks, keeps = [], []
+    for chunk_id, first in enumerate(range(0, n_targets, chunk)):
+        t0 = time.time()
+        log(f"pre-filtering fasta chunk {chunk_id}")
+        cdb = dbp.build_chunk(fasta_text, first, chunk, peptides_only=True)
+        keep = np.zeros(cdb.n_peptides, dtype=np.uint8)
+        if cdb.n_peptides:
+            scorer = Scorer(DeviceDatabase(cdb, device), pass_params)
+            n = 0
+            for raw in raws:
+                if not raw:
+                    continue
+                dbatch, _ = _upload(scorer, processor, raw, sp, host_preprocess)
+                if dbatch is None:
+                    continue
+                scorer.quick_score(dbatch, True if dbp.prefilter_low_memory is None else bool(dbp.prefilter_low_memory), keep)
+                n += dbatch.n
+                dbatch.close()
+            dt = (time.time() - t0) * 1000.0
+            log(f"- prefilter search:  {int(dt):8d} ms ({int(n * 1000 / (dt + 1))} spectra/s)")  # runner.rs:272-277
+        log(f"found {int(keep.sum())} pre-filtered peptides for fasta chunk {chunk_id}")
+        chunks.append(cdb)
+        keeps.append(keep)
+    return dbp.merge_kept(chunks, keeps, peptides_only=True)
+
+
 def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print, host_preprocess: bool = False,
         write_pin: bool = False) -> dict:
     if device_count() <= 0:
@@ -64,12 +109,21 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     if not dbp.fasta:
         raise SystemExit("`database.fasta` must be set. For more information try '--help'")
     t0 = time.time()
-    host = dbp.build(open(dbp.fasta).read(), peptides_only=True)  # digest / modify / sort / dedup on the host ...
-    dev = DeviceDatabase(host, device)                            # ... build_from_peptides on the device (index_build.hip)
-    log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms")
+    fasta_text = open(dbp.fasta).read()
     params = scorer_params(sp)
-    scorer = Scorer(dev, params)
     processor = SpectrumProcessor(sp["max_peaks"], sp["deisotope"], 0.0)  # (no TMT reporter cut-off: quant is out of scope)
+    host = None
+    if dbp.prefilter:  # runner.rs:104-127
+        chunk = dbp.auto_prefilter_chunk_size(fasta_text)
+        n_targets = dbp.num_targets(fasta_text)
+        if chunk < n_targets:
+            log(f"using {(n_targets + chunk - 1) // chunk} db chunks of size {chunk}")
+            host = prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, processor, device, host_preprocess, log)
+    if host is None:
+        host = dbp.build(fasta_text, peptides_only=True)  # digest / modify / sort / dedup on the host ...
+    dev = DeviceDatabase(host, device)                    # ... build_from_peptides on the device (index_build.hip)
+    log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms")
+    scorer = Scorer(dev, params)
     os.makedirs(output_directory, exist_ok=True)
     feats_all, meta, frags = [], [], []  # per PSM: (filename, spectrum id); matched-fragment rows
     psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
@@ -82,16 +136,9 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         if not raw:
             continue
         t0 = time.time()
-        if host_preprocess:  # SpectrumProcessor::process on the host (C++), spectra below min_peaks dropped (runner.rs:313)
-            processed = [processor.process(r) for r in raw]
-            processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]
-            if not processed:
-                continue
-            ids = [p.id for p in processed]
-            dbatch = scorer.upload(SpectrumBatch.from_spectra(processed))
-        else:  # ... or on the device: raw peaks in, PSMs out; spectra below min_peaks stay in the batch with zero peaks
-            ids = [r.id for r in raw]
-            dbatch, _ = scorer.process_upload(RawBatch(raw), sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
+        dbatch, ids = _upload(scorer, processor, raw, sp, host_preprocess)
+        if dbatch is None:
+            continue
         n_batch = dbatch.n
         feats, counts = scorer.score_resident(dbatch)
         feats, counts = feats.copy(), counts.copy()

@@ -154,6 +154,47 @@ int sage_hip_hostdb_build(const char* fasta_text, const SageDbParams* params, Sa
         return fail(SAGE_HIP_ERR_INVALID, e.what());
     }
 }
+int sage_hip_hostdb_build_chunk(const char* fasta_text, const SageDbParams* params, uint64_t first_target, uint64_t n_targets,
+                                SageHostDb** out) {
+    if (!fasta_text || !params || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    try {
+        auto h = std::make_unique<SageHostDb>();
+        h->db = build_database(fasta_text, config_from_params(*params), first_target, n_targets);
+        *out = h.release();
+        return SAGE_HIP_OK;
+    } catch (const std::exception& e) {
+        return fail(SAGE_HIP_ERR_INVALID, e.what());
+    }
+}
+int sage_hip_fasta_num_targets(const char* fasta_text, const SageDbParams* params, uint64_t* out) {
+    if (!fasta_text || !params || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    *out = fasta_num_targets(fasta_text, config_from_params(*params));
+    return SAGE_HIP_OK;
+}
+int sage_hip_prefilter_chunk_size(const char* fasta_text, const SageDbParams* params, uint64_t requested, uint64_t* out) {
+    if (!fasta_text || !params || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    *out = prefilter_chunk_size(fasta_text, config_from_params(*params), requested);
+    return SAGE_HIP_OK;
+}
+int sage_hip_hostdb_merge_kept(const SageHostDb* const* chunks, const uint8_t* const* keep, uint32_t n_chunks,
+                               const SageDbParams* params, SageHostDb** out) {
+    if ((n_chunks && (!chunks || !keep)) || !params || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    try {
+        std::vector<const HostDb*> dbs;
+        std::vector<const uint8_t*> masks;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            if (!chunks[c] || !keep[c]) return fail(SAGE_HIP_ERR_INVALID, "null chunk");
+            dbs.push_back(&chunks[c]->db);
+            masks.push_back(keep[c]);
+        }
+        auto h = std::make_unique<SageHostDb>();
+        h->db = merge_kept(dbs, masks, config_from_params(*params));
+        *out = h.release();
+        return SAGE_HIP_OK;
+    } catch (const std::exception& e) {
+        return fail(SAGE_HIP_ERR_INVALID, e.what());
+    }
+}
 void sage_hip_hostdb_free(SageHostDb* db) { delete db; }
 int sage_hip_hostdb_view(const SageHostDb* db, SageDbView* out) {
     if (!db || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");

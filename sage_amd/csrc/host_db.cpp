@@ -462,20 +462,20 @@ void ion_series_flat(const uint8_t* seq, const float* mods, size_t len, float nt
     }
 }
 
-HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
-    HostDb db;
+namespace {
+
+void init_database(HostDb& db, const DbBuildConfig& cfg) {
     db.bucket_size = cfg.bucket_size;
     db.ion_kinds = cfg.ion_kinds;
     db.decoy_tag = cfg.decoy_tag;
     db.generate_decoys = cfg.generate_decoys;
     db.min_ion_index = cfg.min_ion_index;
+}
 
-    std::vector<std::string> prot_seqs;
-    parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, db.protein_names, prot_seqs);
+// Fasta::digest (fasta.rs:58-79) for db.protein_names / prot_seqs: one Cut per enzymatic product
+std::vector<Cut> digest_fasta(const HostDb& db, const std::vector<std::string>& prot_seqs, const DbBuildConfig& cfg) {
     const EnzymeSpec enz = make_enzyme(cfg);
     const size_t n_prot = prot_seqs.size();
-
-    // 1. digest every protein (fasta.rs:58-79), proteins in parallel
     std::vector<std::vector<Cut>> per_protein(n_prot);
     parallel_for(n_prot, 16, [&](size_t b, size_t e, unsigned) {
         for (size_t i = b; i < e; i++) {
@@ -486,7 +486,30 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
     });
     std::vector<Cut> cuts;
     for (auto& v : per_protein) cuts.insert(cuts.end(), v.begin(), v.end());
-    per_protein.clear();
+    return cuts;
+}
+
+void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cfg);
+
+}  // namespace
+
+// Parameters::build (database.rs:260-263) over targets [first_target, first_target + n_targets) of the FASTA: the whole
+// file by default, one chunk of Fasta::iter_chunks (fasta.rs:81-89) for the prefilter flow
+HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t first_target, uint64_t n_targets) {
+    HostDb db;
+    init_database(db, cfg);
+
+    std::vector<std::string> prot_seqs;
+    parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, db.protein_names, prot_seqs);
+    if (first_target || n_targets < prot_seqs.size()) {
+        const size_t lo = std::min<size_t>(first_target, prot_seqs.size());
+        const size_t hi = std::min<size_t>(prot_seqs.size(), lo + std::min<uint64_t>(n_targets, prot_seqs.size()));
+        db.protein_names = std::vector<std::string>(db.protein_names.begin() + lo, db.protein_names.begin() + hi);
+        prot_seqs = std::vector<std::string>(prot_seqs.begin() + lo, prot_seqs.begin() + hi);
+    }
+
+    // 1. digest every protein (fasta.rs:58-79), proteins in parallel
+    std::vector<Cut> cuts = digest_fasta(db, prot_seqs, cfg);
     auto cut_seq = [&](const Cut& c) { return std::string_view(prot_seqs[c.protein].data() + c.start, c.len); };
 
     // 2. group_digests (enzyme.rs:33-62): by (position, decoy, sequence)
@@ -570,6 +593,14 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
         }
     }
 
+    finish_database(db, peps, cfg);
+    return db;
+}
+
+namespace {
+
+// reorder_peptides (database.rs:221-258) then Parameters::build_from_peptides (database.rs:265-346) into the flat layout
+void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cfg) {
     // 4. reorder_peptides (database.rs:221-258): sort, dedup, merge proteins.  The comparator is a
     // total order on the dedup key, so the result does not depend on the (thread-dependent) input order
     // except for which duplicate's missed_cleavages/position survives; keep that deterministic by
@@ -606,6 +637,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
     db.decoy.resize(np);
     db.missed.resize(np);
     db.semi.resize(np);
+    db.position.resize(np);
     db.seq_off.resize(np + 1);
     db.pep_protein_off.resize(np + 1);
     uint64_t off = 0, poff = 0;
@@ -629,6 +661,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
         db.decoy[i] = p.decoy;
         db.missed[i] = p.missed;
         db.semi[i] = p.semi;
+        db.position[i] = p.pos;
         std::memcpy(db.seq.data() + db.seq_off[i], p.seq.data(), p.seq.size());
         std::memcpy(db.mods.data() + db.seq_off[i], p.mods.data(), p.mods.size() * 4);
         // proteins.sort_unstable() on names (database.rs:248-250); ids are in FASTA order, so sort by name
@@ -639,7 +672,7 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
       }
     });
     std::vector<Pep>().swap(uniq);
-    if (cfg.peptides_only) return db;  // the device builds the fragment index (index_build.hip)
+    if (cfg.peptides_only) return;  // the device builds the fragment index (index_build.hip)
 
     // 6. theoretical fragments (database.rs:272-297)
     const size_t nk = cfg.ion_kinds.size();
@@ -698,6 +731,64 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg) {
             for (uint64_t i = s; i < e; i++) db.fragments[i] = {tmp[i - s].first, key_to_f32(tmp[i - s].second)};
         }
     });
+}
+
+}  // namespace
+
+// Fasta::parse(..).targets.len() (fasta.rs:16-56)
+uint64_t fasta_num_targets(const std::string& fasta_text, const DbBuildConfig& cfg) {
+    std::vector<std::string> names, seqs;
+    parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, names, seqs);
+    return names.size();
+}
+
+// Parameters::auto_calculate_prefilter_chunk_size (database.rs:142-160)
+uint64_t prefilter_chunk_size(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t requested) {
+    if (requested) return requested;
+    HostDb db;
+    std::vector<std::string> prot_seqs;
+    parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, db.protein_names, prot_seqs);
+    const uint64_t total_unmodified = digest_fasta(db, prot_seqs, cfg).size();
+    std::vector<std::pair<uint8_t, int>> targets;  // variable_mods.len(): distinct ModificationSpecificity keys
+    for (auto& m : cfg.variable_mods) {
+        std::pair<uint8_t, int> key{(uint8_t)m.first.where, m.first.residue};
+        if (std::find(targets.begin(), targets.end(), key) == targets.end()) targets.push_back(key);
+    }
+    const uint64_t mod_count_estimate = (targets.size() + 1) * (1ull << cfg.max_variable_mods);
+    const uint64_t chunk_count = mod_count_estimate * total_unmodified / (1ull << 23);
+    return chunk_count == 0 ? prot_seqs.size() : prot_seqs.size() / chunk_count;
+}
+
+// runner.rs:215-238: the peptides every chunk database kept (keep[c][ix] != 0), concatenated, through reorder_peptides —
+// which merges a peptide found in several chunks, joins its proteins and clears `decoy` when any copy is a target
+// (database.rs:233-247) — and build_from_peptides.  Chunks are consecutive slices of the FASTA targets, so a chunk-local
+// protein id becomes global by adding the number of proteins of the chunks before it.
+HostDb merge_kept(const std::vector<const HostDb*>& chunks, const std::vector<const uint8_t*>& keep, const DbBuildConfig& cfg) {
+    HostDb db;
+    init_database(db, cfg);
+    std::vector<Pep> peps;
+    for (size_t c = 0; c < chunks.size(); c++) {
+        const HostDb& src = *chunks[c];
+        const uint32_t base = (uint32_t)db.protein_names.size();
+        db.protein_names.insert(db.protein_names.end(), src.protein_names.begin(), src.protein_names.end());
+        for (uint64_t i = 0; i < src.n_peptides(); i++) {
+            if (!keep[c][i]) continue;
+            Pep p;
+            p.seq.assign((const char*)src.seq.data() + src.seq_off[i], src.seq_off[i + 1] - src.seq_off[i]);
+            p.mods.assign(src.mods.begin() + src.seq_off[i], src.mods.begin() + src.seq_off[i + 1]);
+            p.nterm = src.nterm[i];
+            p.cterm = src.cterm[i];
+            p.mono = src.pep_mono[i];
+            p.missed = src.missed[i];
+            p.pos = src.position[i];
+            p.decoy = src.decoy[i] != 0;
+            p.semi = src.semi[i] != 0;
+            for (uint64_t j = src.pep_protein_off[i]; j < src.pep_protein_off[i + 1]; j++)
+                p.proteins.push_back(base + src.pep_protein_ids[j]);
+            peps.push_back(std::move(p));
+        }
+    }
+    finish_database(db, peps, cfg);
     return db;
 }
 

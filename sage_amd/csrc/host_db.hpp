@@ -47,7 +47,7 @@ struct HostDb {
     std::vector<uint8_t> seq;
     std::vector<float> mods;
     std::vector<float> nterm, cterm;
-    std::vector<uint8_t> decoy, missed, semi;
+    std::vector<uint8_t> decoy, missed, semi, position;  // position: enzyme.rs:64-71 (Nterm, Cterm, Full, Internal)
     std::vector<uint8_t> ion_kinds;
     // protein bookkeeping (not used by the scoring path; kept so writers can be added later)
     std::vector<std::string> protein_names;
@@ -68,7 +68,12 @@ struct HostDb {
 unsigned host_threads();
 void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t, unsigned)>& f);
 
-HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg);
+HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t first_target = 0,
+                      uint64_t n_targets = ~0ull);
+// the `prefilter` flow of sage-cli (runner.rs:104-127, :143-238)
+uint64_t fasta_num_targets(const std::string& fasta_text, const DbBuildConfig& cfg);
+uint64_t prefilter_chunk_size(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t requested);
+HostDb merge_kept(const std::vector<const HostDb*>& chunks, const std::vector<const uint8_t*>& keep, const DbBuildConfig& cfg);
 
 // f32 residue masses, mass.rs:64-76
 float residue_mass(uint8_t aa);

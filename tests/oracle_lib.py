@@ -79,6 +79,14 @@ def load():
     lib.orc_quick_score.argtypes = [vp, C.POINTER(L.SageScorerParams), C.POINTER(L.SageSpectrumBatch), C.c_int, L.c_u8_p]
     lib.orc_tol_bounds.argtypes = [L.SageTolerance, C.c_float, L.c_float_p, L.c_float_p]
     lib.orc_max_threads.restype = C.c_int
+    lib.orc_db_build_chunk.restype = vp
+    lib.orc_db_build_chunk.argtypes = [C.c_char_p, C.POINTER(L.SageDbParams), C.c_uint64, C.c_uint64]
+    lib.orc_fasta_num_targets.restype = C.c_uint64
+    lib.orc_fasta_num_targets.argtypes = [C.c_char_p, C.POINTER(L.SageDbParams)]
+    lib.orc_prefilter_chunk_size.restype = C.c_uint64
+    lib.orc_prefilter_chunk_size.argtypes = [C.c_char_p, C.POINTER(L.SageDbParams), C.c_uint64]
+    lib.orc_db_merge_kept.restype = vp
+    lib.orc_db_merge_kept.argtypes = [C.POINTER(vp), C.POINTER(L.c_u8_p), C.c_uint32, C.POINTER(L.SageDbParams)]
     dp = C.POINTER(C.c_double)
     lib.orc_lda_train.restype = C.c_int
     lib.orc_lda_train.argtypes = [dp, C.c_uint64, C.c_uint64, L.c_u8_p, dp]
@@ -108,6 +116,19 @@ class OracleDb:
     def build(fasta_text: str, params: DatabaseParameters) -> "OracleDb":
         p, keep = params.to_c()
         return OracleDb(C.c_void_p(load().orc_db_build(fasta_text.encode(), C.byref(p))))
+
+    @staticmethod
+    def build_chunk(fasta_text: str, params: DatabaseParameters, first: int, count: int) -> "OracleDb":
+        p, keep = params.to_c()
+        return OracleDb(C.c_void_p(load().orc_db_build_chunk(fasta_text.encode(), C.byref(p), first, count)))
+
+    @staticmethod
+    def merge_kept(chunks, keeps, params: DatabaseParameters) -> "OracleDb":
+        p, keep = params.to_c()
+        masks = [np.ascontiguousarray(k, dtype=np.uint8) for k in keeps]
+        hs = (C.c_void_p * max(len(chunks), 1))(*[c.h for c in chunks])
+        ms = (L.c_u8_p * max(len(chunks), 1))(*[L.as_ptr(m, C.c_uint8) for m in masks])
+        return OracleDb(C.c_void_p(load().orc_db_merge_kept(hs, ms, len(chunks), C.byref(p))))
 
     @staticmethod
     def from_product(db) -> "OracleDb":
@@ -303,3 +324,13 @@ def rescore(features, precursor_tol, peptide_key, n_peptide_keys, protein_key, n
                                 L.as_ptr(order, C.c_uint32), L.as_ptr(passing, C.c_uint64), _dptr(coef),
                                 None if rows is None else _dptr(rows))
     return dict(outs, order=order, passing=passing, coef=coef, lda_fitted=bool(fitted), rows=rows)
+
+
+def fasta_num_targets(fasta_text, params):
+    p, keep = params.to_c()
+    return int(load().orc_fasta_num_targets(fasta_text.encode(), C.byref(p)))
+
+
+def prefilter_chunk_size(fasta_text, params, requested=0):
+    p, keep = params.to_c()
+    return int(load().orc_prefilter_chunk_size(fasta_text.encode(), C.byref(p), requested))

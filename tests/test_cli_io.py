@@ -180,3 +180,58 @@ def test_cli_synthetic_two_files(tmp_path, gpu_required):
         want += [output.ryu_f64(of[i, r]["hyperscore"]) for i in range(len(proc)) for r in range(int(oc[i]))]
     by_id = sorted(rows, key=lambda r: int(r[0]))
     assert [r[hdr.index("hyperscore")] for r in by_id] == want
+
+
+@pytest.mark.gpu
+def test_cli_prefilter_flow(tmp_path, gpu_required):
+    """database.prefilter (runner.rs:104-127, :143-238): chunked quick_score pass, merged survivors, final search — the CLI on
+    the GPU against the same flow driven through the oracle."""
+    fasta = synthetic_fasta(80, seed=51)
+    fa = str(tmp_path / "db.fasta")
+    open(fa, "w").write(fasta)
+    dbj = {"enzyme": {"missed_cleavages": 1, "cleave_at": "KR", "restrict": "P"}, "static_mods": {"C": 57.0215},
+           "variable_mods": {"M": [15.9949]}, "fasta": fa, "prefilter": True, "prefilter_chunk_size": 25}
+    dbp = DatabaseParameters.from_json(dbj)
+    full = dbp.build(fasta)
+    files = []
+    for k in range(2):
+        p = str(tmp_path / f"run{k}.mzML")
+        write_mzml(p, synthetic_spectra(full, 80, seed=60 + k))
+        files.append(p)
+    cfg = {"database": dbj, "precursor_tol": {"ppm": [-10, 10]}, "fragment_tol": {"ppm": [-10, 10]}, "report_psms": 2,
+           "mzml_paths": files}
+    cp = str(tmp_path / "c.json")
+    json.dump(cfg, open(cp, "w"))
+    out = str(tmp_path / "o")
+    logs = []
+    summary = cli.run(cfg, files, out, log=logs.append)
+    assert any("using 4 db chunks of size 25" in m for m in logs)
+    hdr, rows = _read_tsv(os.path.join(out, "results.sage.tsv"))
+    # the oracle's flow
+    sp = SpectrumProcessor(150, True, 0.0)
+    per_file = []
+    for k, p in enumerate(files):
+        per_file.append(SpectrumBatch.from_spectra([q for q in (sp.process(r) for r in read_mzml(p, k)) if len(q.masses) >= 15]))
+    search = cli.search_parameters(cfg)
+    pass_params = cli.scorer_params(dict(search, report_psms=search["report_psms"] + 1))
+    n_targets = oracle_lib.fasta_num_targets(fasta, dbp)
+    chunks, keeps = [], []
+    for first in range(0, n_targets, 25):
+        oc = oracle_lib.OracleDb.build_chunk(fasta, dbp, first, 25)
+        keep = np.zeros(oc.n_peptides, dtype=np.uint8)
+        for b in per_file:
+            keep |= oc.quick_score(pass_params, b, True)
+        chunks.append(oc)
+        keeps.append(keep)
+    final = oracle_lib.OracleDb.merge_kept(chunks, keeps, dbp)
+    assert 0 < final.n_peptides < full.n_peptides
+    assert any(f"generated {final.n_peptides} peptides" in m for m in logs)
+    strs = final.peptide_strings()
+    want = []
+    for b in per_file:
+        of, oc, _, _ = final.score(cli.scorer_params(search), b)
+        want += [(strs[int(of[i, r]["peptide_idx"])], output.ryu_f64(of[i, r]["hyperscore"]))
+                 for i in range(b.n) for r in range(int(oc[i]))]
+    by_id = sorted(rows, key=lambda r: int(r[0]))
+    assert [(r[hdr.index("peptide")], r[hdr.index("hyperscore")]) for r in by_id] == want
+    assert summary["psms"] == len(want) > 100

@@ -142,3 +142,60 @@ def test_spectrum_processor_matches_oracle():
             np.testing.assert_array_equal(out.masses.view(np.uint32), om.view(np.uint32))
             np.testing.assert_array_equal(out.intensities.view(np.uint32), oi.view(np.uint32))
             assert np.float32(out.total_ion_current) == np.float32(tic)
+
+
+# ---- the `prefilter` flow (sage-cli runner.rs:104-127, :143-238): chunked build, merge of the kept peptides ------------------
+def test_prefilter_chunks_and_merge_match_oracle():
+    # shared tryptic peptides between proteins of different chunks, and a protein whose reversed peptide is a target elsewhere
+    fasta = synthetic_fasta(40, seed=17) + ">sp|DUP1|X\nMKAAAGGGLLLKDDDEEEFFFKWWWYYYR\n>sp|DUP2|Y\nMKAAAGGGLLLKCCCHHHIIIK\n" \
+        + ">sp|PAL1|P\nMRACDEFGHIK\n>sp|PAL2|Q\nMRAIHGFEDCK\n"
+    params = DatabaseParameters(bucket_size=512, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                                static_mods={"C": 57.0215}, variable_mods={"M": [15.9949]})
+    n_targets = params.num_targets(fasta)
+    assert n_targets == oracle_lib.fasta_num_targets(fasta, params) == 44
+    chunk = 9
+    prod_chunks, orc_chunks, keeps = [], [], []
+    rng = np.random.default_rng(5)
+    for first in range(0, n_targets, chunk):
+        pc = params.build_chunk(fasta, first, chunk)
+        oc = oracle_lib.OracleDb.build_chunk(fasta, params, first, chunk)
+        assert_db_equal(pc, oc)
+        prod_chunks.append(pc)
+        orc_chunks.append(oc)
+        keeps.append((rng.random(pc.n_peptides) < 0.4).astype(np.uint8))
+    # the whole FASTA as one chunk is the ordinary build
+    assert_db_equal(params.build_chunk(fasta, 0, n_targets), oracle_lib.OracleDb.build(fasta, params))
+    merged = params.merge_kept(prod_chunks, keeps)
+    omerged = oracle_lib.OracleDb.merge_kept(orc_chunks, keeps, params)
+    assert 0 < merged.n_peptides <= sum(int(k.sum()) for k in keeps)
+    assert_db_equal(merged, omerged, check_missed=False)
+    strs = omerged.peptide_strings()
+    for i in range(merged.n_peptides):
+        assert merged.peptide_string(i) == strs[i]
+        if not merged.decoy[i]:
+            assert merged.peptide_proteins(i) == omerged.peptide_proteins(i)
+    # keeping everything reproduces the peptides of the one-shot build, except decoys that are targets of ANOTHER chunk:
+    # those are only dropped inside a chunk (database.rs:212), the merge keeps them and clears nothing
+    full = params.build(fasta)
+    everything = params.merge_kept(prod_chunks, [np.ones(c.n_peptides, np.uint8) for c in prod_chunks])
+    full_set = {(full.peptide_string(i), bool(full.decoy[i])) for i in range(full.n_peptides)}
+    all_set = {(everything.peptide_string(i), bool(everything.decoy[i])) for i in range(everything.n_peptides)}
+    assert full_set <= all_set
+    # peptides_only merge: same peptide arrays, no fragments
+    po = params.merge_kept(prod_chunks, keeps, peptides_only=True)
+    assert po.n_peptides == merged.n_peptides and not po.has_fragments
+    np.testing.assert_array_equal(po.pep_mono.view(np.uint32), merged.pep_mono.view(np.uint32))
+
+
+def test_auto_prefilter_chunk_size_matches_oracle():
+    fasta = synthetic_fasta(60, seed=19)
+    for kw in (dict(), dict(variable_mods={"M": [15.9949], "S": [79.9663, 541.0611]}, max_variable_mods=3),
+               dict(enzyme=dict(missed_cleavages=2, cleave_at="KR", restrict="P"))):
+        params = DatabaseParameters(**kw)
+        assert params.auto_prefilter_chunk_size(fasta) == oracle_lib.prefilter_chunk_size(fasta, params) == 60
+        fixed = DatabaseParameters(prefilter_chunk_size=7, **kw)
+        assert fixed.auto_prefilter_chunk_size(fasta) == 7
+    # enough estimated modified peptides for more than one chunk: (keys + 1) * 2^max_variable_mods * digests / 2^23
+    big = DatabaseParameters(variable_mods={"M": [15.9949]}, max_variable_mods=13)
+    got = big.auto_prefilter_chunk_size(fasta)
+    assert got == oracle_lib.prefilter_chunk_size(fasta, big) and 0 < got < 60
