@@ -153,11 +153,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libsage_hip has no CPU fallback)")
+    # SAGE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the
+    # barrier / max-over-ranks run over gloo on CPU tensors); the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("SAGE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
 
     from sage_amd.api import DatabaseParameters, DeviceDatabase, Scorer, SpectrumBatch, SpectrumProcessor
     from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
@@ -211,10 +220,10 @@ def main():
     elapsed = time.perf_counter() - t0
     last_t = scorer.last_timing()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nn = torch.tensor([batch.n], dtype=torch.int64, device="cuda")
+        nn = torch.tensor([batch.n], dtype=torch.int64, device=coll_device)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         total_spectra = int(nn.item())
     else:
