@@ -756,7 +756,7 @@ static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore, boo
     const DevBatchView& view = sub ? *sub : b->view;
     DevScorer sc = s->dev;
     sc.exact = exact ? 1u : 0u;
-    const size_t lds_p = prelim_lds_bytes(sc, view), lds_r = rescore_lds_bytes(sc, view, s->db->max_ions);
+    const size_t lds_p = prelim_lds_bytes(sc, view), lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
     const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
     if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");

@@ -146,7 +146,7 @@ struct TileParams {
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
-size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions);
+size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 uint32_t queries_per_spectrum(const DevScorer& sc);

@@ -313,8 +313,10 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     l.listA = (uint64_t*)(smem + off); off += fold ? (size_t)sc.list_cap * 8 : 0;
     l.listB = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
     l.heap = (uint64_t*)(smem + off); off += (size_t)sc.kmax * 8;
-    l.win_lo = (float*)(smem + off); off += (size_t)b.fzcap * b.pcap * 4;
-    l.win_hi = (float*)(smem + off); off += (size_t)b.fzcap * b.pcap * 4;
+    // probe variant: only the peak masses are staged (win_lo[0..pcap)); each lane derives its window bounds on the fly
+    const size_t win = b.probe ? (size_t)b.pcap * 4 : (size_t)b.fzcap * b.pcap * 4;
+    l.win_lo = (float*)(smem + off); off += win;
+    l.win_hi = (float*)(smem + off); off += b.probe ? 0 : win;
     l.cnt = (uint32_t*)(smem + off);
     return l;
 }
@@ -444,8 +446,32 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
 //                    reads + ~10-20 entries).  Cost ~ peaks x fragment charges, independent of the window: best from
 //                    ~100 candidates up.
 // The C ABI picks per batch from the mean window size (capi.hip: sage_hip_batch_upload).
+// Build-time knobs, with the values measured best on MI355X (scripts/variants.sh, scripts/ab_libs.sh; C3: 26.3 -> 29.8 M
+// spectra/s).  Both per-spectrum kernels are bound by dependent memory / LDS round trips, so resident wavefronts matter more
+// than registers per wavefront: capping the VGPR budget at 6 waves per SIMD (80 VGPRs, a handful of spills outside the inner
+// loops) and keeping LDS per wavefront under 160 KB / 24 buys ~10 %; past 6 waves nothing more comes.
+#ifndef SAGE_PROBE_DEPTH
+#define SAGE_PROBE_DEPTH 4  // uint4 loads (two index entries each) a lane of the probe kernel issues per window (~3 entries typical)
+#endif
+#ifndef SAGE_PRELIM_WAVES
+#define SAGE_PRELIM_WAVES 6  // 0: leave the occupancy to the compiler
+#endif
+#ifndef SAGE_RESCORE_WAVES
+#define SAGE_RESCORE_WAVES 6
+#endif
+constexpr uint32_t PROBE_DEPTH = SAGE_PROBE_DEPTH;
+#if SAGE_PRELIM_WAVES
+#define SAGE_PRELIM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SAGE_PRELIM_WAVES, SAGE_PRELIM_WAVES)))
+#else
+#define SAGE_PRELIM_WAVES_ATTR
+#endif
+#if SAGE_RESCORE_WAVES
+#define SAGE_RESCORE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SAGE_RESCORE_WAVES, SAGE_RESCORE_WAVES)))
+#else
+#define SAGE_RESCORE_WAVES_ATTR
+#endif
 template <bool PROBE>
-__global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     const PrelimLds L = carve_prelim(smem, sc, b);
@@ -465,6 +491,10 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
         // experimental mass peak*charge of scoring.rs:360
         for (uint32_t i = lane; i < P; i += WAVE) {
             const float m = masses[i];
+            if (PROBE) {
+                L.win_lo[i] = m;
+                continue;
+            }
             for (uint32_t fz = 1; fz <= nfz_max; fz++) {
                 float lo, hi;
                 tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
@@ -580,8 +610,7 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                             flo = 1.0f; fhi = 0.0f;  // (inactive lane: empty window, empty run)
                             if (pr < nprobe) {
                                 const uint32_t fz = pr / P, i = pr - fz * P;
-                                flo = L.win_lo[(size_t)fz * b.pcap + i];
-                                fhi = L.win_hi[(size_t)fz * b.pcap + i];
+                                tol_bounds(sc.fragment_tol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
                             }
                             // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
                             float cl = floorf(flo * db.lut2_scale), ch = floorf(fhi * db.lut2_scale) + 1.0f;
@@ -598,15 +627,15 @@ __global__ __launch_bounds__(64) void prelim_kernel(DevDbView db, DevScorer sc, 
                             lo = lo_n; hi = hi_n; p0 = p0_n; p1 = p1_n;
                             if (pb + WAVE < nprobe) fetch(pb + WAVE + lane, lo_n, hi_n, p0_n, p1_n);
                             const uint32_t j0 = p0 & ~1u;
-                            uint4 e[8];
+                            uint4 e[PROBE_DEPTH];
 #pragma unroll
-                            for (uint32_t st = 0; st < 8; st++) {  // sixteen entries in flight per lane
+                            for (uint32_t st = 0; st < PROBE_DEPTH; st++) {  // 2 * PROBE_DEPTH entries in flight per lane
                                 e[st] = make_uint4(0u, 0u, 0u, 0u);
                                 if (j0 + 2 * st < p1) e[st] = frag2[(j0 >> 1) + st];
                             }
 #pragma unroll
-                            for (uint32_t st = 0; st < 8; st++) test2(e[st], j0 + 2 * st, p0, p1, lo, hi);
-                            for (uint32_t j = j0 + 16; j < p1; j += 8) {  // long runs: four more loads per trip
+                            for (uint32_t st = 0; st < PROBE_DEPTH; st++) test2(e[st], j0 + 2 * st, p0, p1, lo, hi);
+                            for (uint32_t j = j0 + 2 * PROBE_DEPTH; j < p1; j += 8) {  // long runs: four more loads per trip
                                 uint4 f[4];
 #pragma unroll
                                 for (uint32_t st = 0; st < 4; st++) {
@@ -1621,7 +1650,7 @@ __device__ __forceinline__ bool quick_gt(const QuickKey& a, const QuickKey& b) {
     return a.iso > b.iso;
 }
 
-__global__ __launch_bounds__(64) void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+__global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                      const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                      SageFeature* __restrict__ out,
                                                      uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
@@ -1955,7 +1984,8 @@ __global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc
 
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 + (size_t)b.fzcap * b.pcap * 8;
+    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 +
+               (b.probe ? (size_t)b.pcap * 4 : (size_t)b.fzcap * b.pcap * 8);
     n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }
@@ -1970,9 +2000,9 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
-size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t) {
+size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t, bool quick) {
     size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
-    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + 64 * sizeof(QuickKey);
+    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
     return (n + 15) & ~(size_t)15;
 }
 
@@ -2006,7 +2036,7 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions), (hipStream_t)stream, db,
+    hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, db,
                        sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
