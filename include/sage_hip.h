@@ -344,6 +344,48 @@ typedef struct SageRescoreOutput {
 
 int sage_hip_rescore(int device, const SageRescoreInput* in, SageRescoreOutput* out);
 
+/* ---- the predict_rt block of sage-cli (runner.rs:513-530), the producer of SageRescoreInput's optional arrays ----------
+ *   features.par_sort_unstable_by(poisson) + spectrum_q_value  (runner.rs:517-520, qvalue.rs:8-36): the training filter
+ *   ml::retention_alignment::global_alignment                  (retention_alignment.rs:100-173)  -> aligned_rt
+ *   ml::retention_model::predict                               (retention_model.rs:14-90, regression.rs:58-122)
+ *   ml::mobility_model::predict                                (mobility_model.rs:14-186)
+ * Peptide data the two models embed comes per Feature: sequence bytes and monoisotopic mass of db[features[i].peptide_idx]
+ * (sage_hip_hostdb_feature_peptides gathers them). */
+typedef struct SageRtInput {
+    uint64_t n;
+    const SageFeature* features;   /* host, [n]: rt, ims, charge, label, file_id, poisson, peptide_idx are read */
+    uint32_t n_files;
+    const uint64_t* seq_off;       /* [n + 1] */
+    const uint8_t* seq;            /* residues, 'A'..'Z' */
+    const float* monoisotopic;     /* [n] */
+} SageRtInput;
+
+typedef struct SageAlignment {     /* retention_alignment.rs:92-98 */
+    uint32_t file_id;
+    float max_rt, slope, intercept;
+} SageAlignment;
+
+typedef struct SageRtOutput {
+    /* caller-allocated host arrays [n], input order; Feature defaults (scoring.rs:576-592) where a model is not fitted */
+    float* spectrum_q;             /* q-values of the poisson-sorted pass */
+    float* aligned_rt;
+    float* predicted_rt;
+    float* delta_rt_model;
+    float* predicted_ims;
+    float* delta_ims_model;
+    SageAlignment* alignments;     /* [n_files] */
+    /* filled by the call */
+    int32_t rt_fitted, ims_fitted; /* LinearRegression::fit returned Some */
+    double rt_r2, ims_r2;
+    float device_ms;
+} SageRtOutput;
+
+int sage_hip_predict_rt(int device, const SageRtInput* in, SageRtOutput* out);
+
+/* Peptide.sequence / .monoisotopic of db[peptide_idx[i]] for SageRtInput.  Call with seq == NULL to size: seq_off is filled. */
+int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint64_t* seq_off,
+                                     uint8_t* seq, float* monoisotopic);
+
 /* The competition keys of SageRescoreInput for `n` PSMs given their peptide indices (host work: string keys). */
 int sage_hip_hostdb_competition_keys(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key,
                                  uint32_t* n_peptide_keys, uint32_t* protein_key, uint32_t* n_protein_keys);

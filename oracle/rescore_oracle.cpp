@@ -9,8 +9,14 @@
 //   crates/sage/src/ml/qvalue.rs:8-36                     spectrum_q_value
 //   crates/sage/src/fdr.rs:42-226                         Competition::assign_q_value, picked_peptide, picked_protein
 //   crates/sage-cli/src/runner.rs:281-292                 spectrum_fdr (heuristic fall-back, sort, q-values)
-// Pinned by the only known-answer test the reference holds for this step, linear_discriminant.rs:238-288 (LDA on 8 rows,
-// normalised scores to 1e-8) — tests/test_rescore_oracle.py.  KDE, q-values and the picked competitions have no reference
+//   crates/sage-cli/src/runner.rs:513-530                 the predict_rt block: poisson-sorted q-values, then
+//   crates/sage/src/ml/retention_alignment.rs:26-173      global_alignment
+//   crates/sage/src/ml/regression.rs:21-122               LinearRegression::fit (streaming OLS, r^2)
+//   crates/sage/src/ml/retention_model.rs:14-90           RetentionModel::embed / fit / predict
+//   crates/sage/src/ml/mobility_model.rs:14-186           MobilityModel::embed / fit / predict
+// Pinned by the known-answer tests the reference holds for these steps: linear_discriminant.rs:238-288 (LDA on 8 rows,
+// normalised scores to 1e-8), regression.rs:124-157 (perfect line, noisy line, empty filter), mobility_model.rs:188-267
+// (terminal-residue embedding counts) — tests/test_rescore_oracle.py.  KDE, q-values and the picked competitions have no reference
 // vectors: for those this restatement IS the reference ("parity thinly pinned").
 //
 // Freedoms the reference leaves open, fixed here (and in the product) so that results are reproducible:
@@ -465,6 +471,286 @@ int orc_rescore(const OrcFeature* f, uint64_t n, int tol_kind, float tol_lo, flo
     passing[1] = picked(peptide_key, n_peptide_keys, decoys.data(), discriminant, n, 0.01f, peptide_q);
     passing[2] = picked(protein_key, n_protein_keys, decoys.data(), discriminant, n, 0.01f, protein_q);
     return fitted ? 1 : 0;
+}
+
+}  // extern "C"
+
+// ---- the predict_rt block (runner.rs:513-530) --------------------------------------------------------------------------------
+// LinearRegression::fit over the rows with filter[i] != 0 (regression.rs:58-122).  rows: n x d.  Returns false when no row
+// passes or X^T X is singular.
+static bool linreg_fit(const double* rows, const double* y, const uint8_t* filter, size_t n, size_t d, std::vector<double>& beta,
+                       double& r2) {
+    std::vector<double> cov(d * d, 0.0), b(d, 0.0);
+    double sum_y = 0.0, sum_y2 = 0.0;
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!filter[i]) continue;
+        const double* row = rows + i * d;
+        for (size_t j = 0; j < d; ++j) {  // Acc::add_row, :37-50
+            const double rj = row[j];
+            b[j] += rj * y[i];
+            for (size_t k = 0; k < d; ++k) cov[j * d + k] += rj * row[k];
+        }
+        sum_y += y[i];
+        sum_y2 += y[i] * y[i];
+        cnt++;
+    }
+    if (cnt == 0) return false;
+    const double nf = (double)cnt, y_mean = sum_y / nf, y_var = sum_y2 - nf * y_mean * y_mean;
+    Matrix c(d, d), bm(d, 1), sol;
+    c.data = cov;
+    bm.data = b;
+    if (!Gauss::solve(c, bm, sol)) return false;
+    beta = sol.data;
+    double sse = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!filter[i]) continue;
+        double pred = 0.0;
+        for (size_t j = 0; j < d; ++j) pred += rows[i * d + j] * beta[j];
+        sse += (pred - y[i]) * (pred - y[i]);
+    }
+    r2 = 1.0 - sse / y_var;
+    return true;
+}
+
+static const uint8_t VALID_AA[22] = {'A', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'K', 'L', 'M',
+                                     'N', 'P', 'Q', 'R', 'S', 'T', 'V', 'W', 'Y', 'U', 'O'};  // mass.rs:59-62
+static void aa_map(size_t map[26]) {  // retention_model.rs:65-68
+    for (int i = 0; i < 26; ++i) map[i] = 0;
+    for (size_t i = 0; i < 22; ++i) map[VALID_AA[i] - 'A'] = i;
+}
+constexpr size_t RT_FEATURES = 22 * 3 + 3;  // retention_model.rs:33
+constexpr size_t IM_FEATURES = 22 * 4 + 12;  // mobility_model.rs:78
+
+// RetentionModel::embed (retention_model.rs:44-62)
+static void rt_embed(const uint8_t* seq, size_t len, float mono, const size_t map[26], double* e) {
+    for (size_t j = 0; j < RT_FEATURES; ++j) e[j] = 0.0;
+    const size_t cterm = len >= 3 ? len - 3 : 0;
+    for (size_t a = 0; a < len; ++a) {
+        const size_t idx = map[seq[a] - 'A'];
+        e[idx] += 1.0;
+        if (a == 0 || a == 1) e[22 + idx] += 1.0;
+        else if (a == cterm || a == cterm + 1) e[44 + idx] += 1.0;
+    }
+    e[RT_FEATURES - 3] = (double)len;
+    e[RT_FEATURES - 2] = std::log1p((double)mono);
+    e[RT_FEATURES - 1] = 1.0;
+}
+
+// MobilityModel::embed (mobility_model.rs:103-158).  The residue-class tables hold letter offsets (b'L' - b'A' ...) but are
+// tested against the VALID_AA index of the residue (:121-139) — restated as written.
+static bool in_set(size_t x, const size_t* set, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (set[i] == x) return true;
+    return false;
+}
+static void im_embed(const uint8_t* seq, size_t len, float mono, uint8_t charge, const size_t map[26], double* e) {
+    static const size_t BULKY[6] = {'L' - 'A', 'V' - 'A', 'I' - 'A', 'F' - 'A', 'W' - 'A', 'Y' - 'A'};
+    static const size_t UC_POLAR[4] = {'S' - 'A', 'T' - 'A', 'N' - 'A', 'Q' - 'A'};
+    static const size_t POSITIVE[3] = {'R' - 'A', 'K' - 'A', 'H' - 'A'};
+    static const size_t NEGATIVE[2] = {'D' - 'A', 'E' - 'A'};
+    static const size_t TINY[3] = {'G' - 'A', 'A' - 'A', 'S' - 'A'};
+    static const size_t BRANCHED[3] = {'L' - 'A', 'I' - 'A', 'V' - 'A'};
+    const size_t F = IM_FEATURES;
+    for (size_t j = 0; j < F; ++j) e[j] = 0.0;
+    const size_t cterm = len >= 3 ? len - 3 : 0;
+    for (size_t a = 0; a < len; ++a) {
+        const size_t idx = map[seq[a] - 'A'];
+        e[idx] += 1.0;
+        if (a == 0 || a == 1) e[44 + idx] += 1.0;  // N_TERMINAL = 22 * 2
+        else if (a > cterm) e[66 + idx] += 1.0;     // C_TERMINAL = 22 * 3
+        if (in_set(idx, BULKY, 6)) e[F - 9] += 1.0;
+        if (in_set(idx, UC_POLAR, 4)) e[F - 10] += 1.0;
+        if (in_set(idx, POSITIVE, 3)) e[F - 8] += 1.0;
+        if (in_set(idx, NEGATIVE, 2)) e[F - 7] += 1.0;
+        if (in_set(idx, TINY, 3)) e[F - 11] += 1.0;
+        if (in_set(idx, BRANCHED, 3)) e[F - 12] += 1.0;
+    }
+    for (size_t i = 0; i < 22; ++i) e[22 + i] = e[i] / (double)len;  // PCT_FEATURES_START = 22
+    const double z = (double)charge;
+    e[F - 5] = z;                               // PEPTIDE_CHARGE
+    e[F - 6] = 1.0 / z;                         // INV_PEPTIDE_CHARGE
+    e[F - 3] = (double)len;                     // PEPTIDE_LEN
+    e[F - 2] = (double)mono / 1000.0;           // PEPTIDE_MASS
+    e[F - 4] = ((double)mono / z) / 1000.0;     // PEPTIDE_MZ
+    e[F - 1] = 1.0;                             // INTERCEPT
+}
+
+extern "C" {
+
+// LinearRegression::fit on an explicit design (the reference's unit tests drive it this way). 1 = fitted.
+int orc_linreg_fit(const double* rows, const double* y, const uint8_t* filter, uint64_t n, uint64_t d, double* beta, double* r2) {
+    std::vector<double> bb;
+    double r = 0.0;
+    if (!linreg_fit(rows, y, filter, n, d, bb, r)) return 0;
+    std::memcpy(beta, bb.data(), d * 8);
+    *r2 = r;
+    return 1;
+}
+
+void orc_rt_embed(const uint8_t* seq, uint64_t len, float mono, double* out) {
+    size_t map[26];
+    aa_map(map);
+    rt_embed(seq, len, mono, map, out);
+}
+void orc_im_embed(const uint8_t* seq, uint64_t len, float mono, uint8_t charge, double* out) {
+    size_t map[26];
+    aa_map(map);
+    im_embed(seq, len, mono, charge, map, out);
+}
+
+// runner.rs:513-530 on `n` Features: sort by poisson + spectrum_q_value, global_alignment, retention_model::predict,
+// mobility_model::predict.  seq_off / seq / mono: Peptide.sequence and .monoisotopic of db[f[i].peptide_idx], per Feature.
+// alignments: [n_files][3] = {max_rt, slope, intercept}.  fitted / r2: [0] retention, [1] mobility.
+void orc_predict_rt(const OrcFeature* f, uint64_t n, uint32_t n_files, const uint64_t* seq_off, const uint8_t* seq,
+                    const float* mono, float* spectrum_q, float* aligned_rt, float* predicted_rt, float* delta_rt_model,
+                    float* predicted_ims, float* delta_ims_model, float* alignments, int32_t* fitted, double* r2) {
+    // ---- runner.rs:517-520: features.par_sort_unstable_by(poisson), spectrum_q_value ----
+    auto total_key64 = [](double x) {
+        int64_t b;
+        std::memcpy(&b, &x, 8);
+        return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+    };
+    std::vector<uint32_t> ord(n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return total_key64(f[a].poisson) < total_key64(f[b].poisson); });
+    {
+        uint64_t d = 1, t = 0;
+        for (uint32_t i : ord) {
+            if (f[i].label == -1) d++;
+            else t++;
+            spectrum_q[i] = (float)d / (float)t;
+        }
+        float q_min = 1.0f;
+        for (uint64_t j = n; j-- > 0;) {
+            q_min = std::fmin(q_min, spectrum_q[ord[j]]);
+            spectrum_q[ord[j]] = q_min;
+        }
+    }
+    std::vector<uint8_t> train(n);
+    for (uint64_t i = 0; i < n; ++i) train[i] = f[i].label == 1 && spectrum_q[i] <= 0.01f;
+
+    // ---- global_alignment (retention_alignment.rs:100-173) ----
+    std::vector<double> max_rt(n_files, 0.0);  // max_rt_by_file, :26-41 (ceil as u32)
+    {
+        std::vector<uint32_t> m(n_files, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            const float c = std::ceil(f[i].rt);
+            const uint32_t v = !(c == c) || c <= 0.0f ? 0u : (c >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)c);  // `as u32`
+            m[f[i].file_id] = std::max(m[f[i].file_id], v);
+        }
+        for (uint32_t k = 0; k < n_files; ++k) max_rt[k] = (double)m[k];
+    }
+    // mean_rt_by_file (:45-60): per (peptide, file) the MINIMUM rt of the training PSMs; rows in ascending peptide order
+    std::vector<std::pair<uint32_t, uint64_t>> tr;
+    for (uint64_t i = 0; i < n; ++i)
+        if (train[i]) tr.push_back({f[i].peptide_idx, i});
+    std::stable_sort(tr.begin(), tr.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    std::vector<std::vector<double>> mat;  // rt_matrix (:62-90): rows with a normal mean
+    for (size_t a = 0; a < tr.size();) {
+        size_t b = a;
+        std::vector<double> v(n_files, std::nan(""));
+        while (b < tr.size() && tr[b].first == tr[a].first) {
+            const OrcFeature& x = f[tr[b].second];
+            const double rt = (double)x.rt;
+            v[x.file_id] = v[x.file_id] == v[x.file_id] ? std::fmin(v[x.file_id], rt) : rt;
+            ++b;
+        }
+        double sum = 0.0, len = 0.0;
+        for (uint32_t k = 0; k < n_files; ++k)
+            if (v[k] == v[k]) {
+                v[k] = v[k] / max_rt[k];
+                sum += v[k];
+                len += 1.0;
+            }
+        if (std::isnormal(sum / len)) mat.push_back(v);
+        a = b;
+    }
+    std::vector<double> mean_rts(mat.size());  // :104-115
+    for (size_t r = 0; r < mat.size(); ++r) {
+        size_t len = 0;
+        double sum = 0.0;
+        for (uint32_t k = 0; k < n_files; ++k)
+            if (std::isfinite(mat[r][k])) {
+                len++;
+                sum += mat[r][k];
+            }
+        mean_rts[r] = sum / (double)len;
+    }
+    std::vector<float> slope_f(n_files), icpt_f(n_files);
+    for (uint32_t k = 0; k < n_files; ++k) {  // :118-163
+        size_t len = 0;
+        double dot = 0.0, sum_x = 0.0, sum_y = 0.0;
+        for (size_t r = 0; r < mat.size(); ++r) {
+            const double x = mat[r][k];
+            if (!std::isfinite(x)) continue;
+            len++;
+            dot += x * mean_rts[r];
+            sum_x += x;
+            sum_y += mean_rts[r];
+        }
+        const double x_mean = sum_x / (double)len, y_mean = sum_y / (double)len;
+        const double ssxy = dot - (double)len * x_mean * y_mean;
+        double sx2 = 1e-8;
+        for (size_t r = 0; r < mat.size(); ++r)
+            if (std::isfinite(mat[r][k])) sx2 += (mat[r][k] - x_mean) * (mat[r][k] - x_mean);
+        double slope = ssxy / sx2, intercept = y_mean - slope * x_mean;
+        if (!std::isfinite(slope)) slope = 1.0;
+        if (!std::isfinite(intercept)) intercept = 0.0;
+        alignments[3 * k] = (float)max_rt[k];
+        alignments[3 * k + 1] = slope_f[k] = (float)slope;
+        alignments[3 * k + 2] = icpt_f[k] = (float)intercept;
+    }
+    for (uint64_t i = 0; i < n; ++i) {  // :165-172 (f32 arithmetic)
+        const uint32_t k = f[i].file_id;
+        aligned_rt[i] = (f[i].rt / (float)max_rt[k]) * slope_f[k] + icpt_f[k];
+    }
+
+    // ---- retention_model::predict (retention_model.rs:14-26), mobility_model::predict (mobility_model.rs:14-32) ----
+    size_t map[26];
+    aa_map(map);
+    for (uint64_t i = 0; i < n; ++i) {  // Feature defaults, scoring.rs:576-592
+        predicted_rt[i] = 0.0f;
+        delta_rt_model[i] = 0.999f;
+        predicted_ims[i] = 0.0f;
+        delta_ims_model[i] = 0.999f;
+    }
+    fitted[0] = fitted[1] = 0;
+    r2[0] = r2[1] = 0.0;
+    {
+        std::vector<double> rows(n * RT_FEATURES), y(n), beta;
+        for (uint64_t i = 0; i < n; ++i) {
+            rt_embed(seq + seq_off[i], seq_off[i + 1] - seq_off[i], mono[i], map, &rows[i * RT_FEATURES]);
+            y[i] = (double)aligned_rt[i];
+        }
+        if (linreg_fit(rows.data(), y.data(), train.data(), n, RT_FEATURES, beta, r2[0])) {
+            fitted[0] = 1;
+            for (uint64_t i = 0; i < n; ++i) {
+                double rt = 0.0;
+                for (size_t j = 0; j < RT_FEATURES; ++j) rt = rt + rows[i * RT_FEATURES + j] * beta[j];
+                const float bounded = (float)clamp(rt, 0.0, 1.0);
+                predicted_rt[i] = bounded;
+                delta_rt_model[i] = std::fabs(aligned_rt[i] - bounded);
+            }
+        }
+    }
+    {
+        std::vector<double> rows(n * IM_FEATURES), y(n), beta;
+        for (uint64_t i = 0; i < n; ++i) {
+            im_embed(seq + seq_off[i], seq_off[i + 1] - seq_off[i], mono[i], f[i].charge, map, &rows[i * IM_FEATURES]);
+            y[i] = (double)f[i].ims;
+        }
+        if (linreg_fit(rows.data(), y.data(), train.data(), n, IM_FEATURES, beta, r2[1])) {
+            fitted[1] = 1;
+            for (uint64_t i = 0; i < n; ++i) {
+                double ims = 0.0;
+                for (size_t j = 0; j < IM_FEATURES; ++j) ims = ims + rows[i * IM_FEATURES + j] * beta[j];
+                const float bounded = (float)clamp(ims, 0.0, 2.0);
+                predicted_ims[i] = bounded;
+                delta_ims_model[i] = std::fabs(f[i].ims - bounded);
+            }
+        }
+    }
 }
 
 }  // extern "C"

@@ -185,6 +185,22 @@ class SageRescoreOutput(C.Structure):
                 ("coef", C.c_double * 20), ("device_ms", C.c_float)]
 
 
+class SageAlignment(C.Structure):
+    _fields_ = [("file_id", C.c_uint32), ("max_rt", C.c_float), ("slope", C.c_float), ("intercept", C.c_float)]
+
+
+class SageRtInput(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("features", C.c_void_p), ("n_files", C.c_uint32), ("seq_off", c_u64_p), ("seq", c_u8_p),
+                ("monoisotopic", c_float_p)]
+
+
+class SageRtOutput(C.Structure):
+    _fields_ = [("spectrum_q", c_float_p), ("aligned_rt", c_float_p), ("predicted_rt", c_float_p), ("delta_rt_model", c_float_p),
+                ("predicted_ims", c_float_p), ("delta_ims_model", c_float_p), ("alignments", C.POINTER(SageAlignment)),
+                ("rt_fitted", C.c_int32), ("ims_fitted", C.c_int32), ("rt_r2", C.c_double), ("ims_r2", C.c_double),
+                ("device_ms", C.c_float)]
+
+
 class SageHipError(RuntimeError):
     pass
 
@@ -238,6 +254,8 @@ def load():
         "sage_hip_host_free": (None, [vp]),
         "sage_hip_rescore": (C.c_int, [C.c_int, C.POINTER(SageRescoreInput), C.POINTER(SageRescoreOutput)]),
         "sage_hip_hostdb_competition_keys": (C.c_int, [vp, c_u32_p, C.c_uint64, c_u32_p, c_u32_p, c_u32_p, c_u32_p]),
+        "sage_hip_predict_rt": (C.c_int, [C.c_int, C.POINTER(SageRtInput), C.POINTER(SageRtOutput)]),
+        "sage_hip_hostdb_feature_peptides": (C.c_int, [vp, c_u32_p, C.c_uint64, c_u64_p, c_u8_p, c_float_p]),
         "sage_hip_fasta_num_targets": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), c_u64_p]),
         "sage_hip_prefilter_chunk_size": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), C.c_uint64, c_u64_p]),
         "sage_hip_hostdb_build_chunk": (C.c_int, [C.c_char_p, C.POINTER(SageDbParams), C.c_uint64, C.c_uint64, C.POINTER(vp)]),
@@ -260,7 +278,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
     "sage_hip_rescore", "sage_hip_hostdb_competition_keys", "sage_hip_fasta_num_targets", "sage_hip_prefilter_chunk_size",
-    "sage_hip_hostdb_build_chunk", "sage_hip_hostdb_merge_kept",
+    "sage_hip_hostdb_build_chunk", "sage_hip_hostdb_merge_kept", "sage_hip_predict_rt", "sage_hip_hostdb_feature_peptides",
 ]
 
 

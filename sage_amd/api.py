@@ -235,6 +235,19 @@ class IndexedDatabase:
                                                           C.byref(npk), L.as_ptr(prk, C.c_uint32), C.byref(nprk)))
         return pk, int(npk.value), prk, int(nprk.value)
 
+    def feature_peptides(self, peptide_idx):
+        """(seq_off[n + 1], residues, monoisotopic[n]) of the peptides behind `n` PSMs — the per-Feature peptide data the
+        retention-time / mobility models embed (retention_model.rs:44-62, mobility_model.rs:103-158)."""
+        idx = np.ascontiguousarray(peptide_idx, dtype=np.uint32)
+        off = np.zeros(len(idx) + 1, dtype=np.uint64)
+        lib = L.load()
+        L.check(lib.sage_hip_hostdb_feature_peptides(self._h, L.as_ptr(idx, C.c_uint32), len(idx), L.as_ptr(off, C.c_uint64), None, None))
+        seq = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+        mono = np.zeros(len(idx), dtype=np.float32)
+        L.check(lib.sage_hip_hostdb_feature_peptides(self._h, L.as_ptr(idx, C.c_uint32), len(idx), L.as_ptr(off, C.c_uint64),
+                                                     L.as_ptr(seq, C.c_uint8), L.as_ptr(mono, C.c_float)))
+        return off, seq, mono
+
     def sequence(self, i: int) -> str:
         return bytes(self.seq[int(self.seq_off[i]):int(self.seq_off[i + 1])]).decode()
 
@@ -678,6 +691,45 @@ def rescore(features: np.ndarray, precursor_tol: Tolerance, peptide_key, n_pepti
     L.check(L.load().sage_hip_rescore(device, C.byref(cin), C.byref(cout)))
     return RescoreResult(*outs, order, int(cout.passing_spectrum), int(cout.passing_peptide), int(cout.passing_protein),
                          bool(cout.lda_fitted), np.array(cout.coef[:], dtype=np.float64), float(cout.device_ms))
+
+
+@dataclass
+class RtPrediction:
+    """Outputs of sage_hip_predict_rt, input order (Feature fields aligned_rt, predicted_rt, delta_rt_model, predicted_ims,
+    delta_ims_model; spectrum_q of the poisson-sorted pass) + the per-file alignments."""
+    spectrum_q: np.ndarray
+    aligned_rt: np.ndarray
+    predicted_rt: np.ndarray
+    delta_rt_model: np.ndarray
+    predicted_ims: np.ndarray
+    delta_ims_model: np.ndarray
+    alignments: np.ndarray  # [n_files] of (file_id, max_rt, slope, intercept)
+    rt_fitted: bool
+    ims_fitted: bool
+    rt_r2: float
+    ims_r2: float
+    device_ms: float
+
+
+ALIGNMENT_DTYPE = np.dtype([("file_id", "<u4"), ("max_rt", "<f4"), ("slope", "<f4"), ("intercept", "<f4")])
+
+
+def predict_rt(features: np.ndarray, n_files: int, seq_off, seq, monoisotopic, device: int = 0) -> RtPrediction:
+    """The predict_rt block of sage-cli (runner.rs:513-530) on the device: poisson-sorted q-values, global retention-time
+    alignment, retention-time and ion-mobility linear models."""
+    f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
+    n = len(f)
+    off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    sq = np.ascontiguousarray(seq, dtype=np.uint8)
+    mono = np.ascontiguousarray(monoisotopic, dtype=np.float32)
+    assert len(off) == n + 1 and len(mono) == n
+    outs = [np.empty(n, np.float32) for _ in range(6)]
+    al = np.zeros(n_files, dtype=ALIGNMENT_DTYPE)
+    cin = L.SageRtInput(n, f.ctypes.data, n_files, L.as_ptr(off, C.c_uint64), L.as_ptr(sq, C.c_uint8), L.as_ptr(mono, C.c_float))
+    cout = L.SageRtOutput(*[L.as_ptr(a, C.c_float) for a in outs], C.cast(al.ctypes.data, C.POINTER(L.SageAlignment)))
+    L.check(L.load().sage_hip_predict_rt(device, C.byref(cin), C.byref(cout)))
+    return RtPrediction(*outs, al, bool(cout.rt_fitted), bool(cout.ims_fitted), float(cout.rt_r2), float(cout.ims_r2),
+                        float(cout.device_ms))
 
 
 def device_count() -> int:

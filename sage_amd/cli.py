@@ -22,7 +22,7 @@ import numpy as np
 from . import output
 from ._lib import FEATURE_DTYPE as L_FEATURE_DTYPE
 from .api import (DatabaseParameters, DeviceDatabase, RawBatch, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor,
-                  Tolerance, device_count, rescore)
+                  Tolerance, device_count, predict_rt, rescore)
 from .mzml import read_mzml
 
 
@@ -41,7 +41,8 @@ def search_parameters(cfg: dict) -> dict:
         precursor_charge=(int(pc[0]), int(pc[1])), override_precursor_charge=bool(cfg.get("override_precursor_charge", False)),
         isotope_errors=(int(iso[0]), int(iso[1])), deisotope=True if cfg.get("deisotope") is None else bool(cfg["deisotope"]),
         chimera=bool(cfg.get("chimera", False)), wide_window=bool(cfg.get("wide_window", False)),
-        score_type=cfg.get("score_type") or "SageHyperScore")
+        score_type=cfg.get("score_type") or "SageHyperScore",
+        predict_rt=True if cfg.get("predict_rt") is None else bool(cfg["predict_rt"]))  # input.rs:372
 
 
 def scorer_params(sp: dict) -> ScorerParams:
@@ -162,15 +163,30 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                 psm_id += 1
         dbatch.close()
     # runner.rs:536-541: spectrum_fdr (LDA or heuristic, sort, q-values), picked_peptide, picked_protein — on the device.
-    # (predict_rt / protein grouping are outside this path: their columns keep the defaults, see output.py)
+    # (protein grouping is outside this path: its columns keep the defaults, see output.py)
     flat = np.array(feats_all, dtype=feats_all[0].dtype) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
     post = None
+    rtp = None
     order = range(len(flat))
     rescore_summary = {}
     if len(flat):
         t0 = time.time()
+        model_inputs = {}
+        if sp["predict_rt"]:  # runner.rs:513-530: poisson-sorted q-values, global_alignment, retention / mobility models
+            off, seq, mono = host.feature_peptides(flat["peptide_idx"])
+            rtp = predict_rt(flat, len(mzml_paths), off, seq, mono, device=device)
+            for a in rtp.alignments:
+                log(f"aligning file #{int(a['file_id'])}: y = {float(a['slope']):.4f}x + {float(a['intercept']):.4f}")
+            log(f"aligned retention times across {len(mzml_paths)} files")
+            if rtp.rt_fitted:
+                log(f"- fit retention time model, rsq = {rtp.rt_r2}")
+            if rtp.ims_fitted:
+                log(f"- fit mobility model, rsq = {rtp.ims_r2}")
+            else:
+                log("Mobility model failed to train")
+            model_inputs = dict(aligned_rt=rtp.aligned_rt, delta_rt_model=rtp.delta_rt_model, delta_ims_model=rtp.delta_ims_model)
         pk, npk, prk, npr = host.competition_keys(flat["peptide_idx"])
-        res = rescore(flat, sp["precursor_tol"], pk, npk, prk, npr, device=device)
+        res = rescore(flat, sp["precursor_tol"], pk, npk, prk, npr, device=device, **model_inputs)
         if not res.lda_fitted:
             log("linear model fitting failed, falling back to heuristic discriminant score")  # runner.rs:285
         post = res
@@ -183,9 +199,14 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                            "rescore_device_ms": res.device_ms}
 
     def post_of(i):
-        return None if post is None else dict(discriminant_score=post.discriminant_score[i], posterior_error=post.posterior_error[i],
-                                              spectrum_q=post.spectrum_q[i], peptide_q=post.peptide_q[i],
-                                              protein_q=post.protein_q[i])
+        if post is None:
+            return None
+        d = dict(discriminant_score=post.discriminant_score[i], posterior_error=post.posterior_error[i],
+                 spectrum_q=post.spectrum_q[i], peptide_q=post.peptide_q[i], protein_q=post.protein_q[i])
+        if rtp is not None:
+            d.update(aligned_rt=rtp.aligned_rt[i], predicted_rt=rtp.predicted_rt[i], delta_rt_model=rtp.delta_rt_model[i],
+                     predicted_ims=rtp.predicted_ims[i], delta_ims_model=rtp.delta_ims_model[i])
+        return d
 
     rows = [output.feature_row(meta[i][0], flat[i], host, meta[i][1], meta[i][2], post_of(i)) for i in order]
     results = os.path.join(output_directory, "results.sage.tsv")

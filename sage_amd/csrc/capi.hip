@@ -137,6 +137,26 @@ int sage_hip_rescore(int device, const SageRescoreInput* in, SageRescoreOutput* 
     return rc == SAGE_HIP_OK ? rc : fail(rc, err);
 }
 
+int sage_hip_predict_rt(int device, const SageRtInput* in, SageRtOutput* out) {
+    if (!in || !out) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_predict_rt: null argument");
+    if (sage_hip_device_count() <= 0) return fail(SAGE_HIP_ERR_NO_DEVICE, "sage_hip_predict_rt: no HIP device (there is no CPU fallback)");
+    if (in->n >= (1ull << 31)) return fail(SAGE_HIP_ERR_UNSUPPORTED, "sage_hip_predict_rt: more than 2^31 features");
+    out->rt_fitted = out->ims_fitted = 0;
+    out->rt_r2 = out->ims_r2 = 0.0;
+    out->device_ms = 0.0f;
+    if (in->n_files == 0 && in->n) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_predict_rt: n_files == 0");
+    if (in->n == 0) {
+        for (uint32_t k = 0; out->alignments && k < in->n_files; ++k) out->alignments[k] = SageAlignment{k, 0.0f, 1.0f, 0.0f};
+        return SAGE_HIP_OK;
+    }
+    if (!in->features || !in->seq_off || !in->seq || !in->monoisotopic || !out->spectrum_q || !out->aligned_rt ||
+        !out->predicted_rt || !out->delta_rt_model || !out->predicted_ims || !out->delta_ims_model)
+        return fail(SAGE_HIP_ERR_INVALID, "sage_hip_predict_rt: null array");
+    std::string err;
+    const int rc = predict_rt_on_device(device, *in, *out, err);
+    return rc == SAGE_HIP_OK ? rc : fail(rc, err);
+}
+
 const char* sage_hip_last_error(void) { return g_last_error.c_str(); }
 int sage_hip_abi_version(void) { return SAGE_HIP_ABI_VERSION; }
 
@@ -217,6 +237,22 @@ int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num
     if (!db || i >= db->db.n_peptides()) return fail(SAGE_HIP_ERR_INVALID, "peptide index out of range");
     if (num_proteins) *num_proteins = (uint32_t)(db->db.pep_protein_off[i + 1] - db->db.pep_protein_off[i]);
     if (semi_enzymatic) *semi_enzymatic = db->db.semi[i];
+    return SAGE_HIP_OK;
+}
+int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint64_t* seq_off, uint8_t* seq,
+                                     float* monoisotopic) {
+    if (!db || (n && !peptide_idx) || !seq_off) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_hostdb_feature_peptides: null argument");
+    const HostDb& d = db->db;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (peptide_idx[i] >= d.n_peptides()) return fail(SAGE_HIP_ERR_INVALID, "peptide index out of range");
+        const uint64_t p = peptide_idx[i], len = d.seq_off[p + 1] - d.seq_off[p];
+        seq_off[i] = off;
+        if (seq) std::memcpy(seq + off, d.seq.data() + d.seq_off[p], len);
+        if (monoisotopic) monoisotopic[i] = d.pep_mono[p];
+        off += len;
+    }
+    seq_off[n] = off;
     return SAGE_HIP_OK;
 }
 int sage_hip_hostdb_competition_keys(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key,

@@ -160,6 +160,7 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
                               uint32_t* lut_stride_out, void* stream);
 // rescore.hip
 int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err);
+int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, std::string& err);
 // process.hip
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
 int process_kernel_prepare(size_t max_lds_bytes);

@@ -1521,7 +1521,6 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 //   A. every (candidate, ion, fragment charge) item of the chunk is matched in parallel
 //      (select_most_intense_peak, spectrum.rs:134-159) -> res[item] = peak index or NONE, in LDS;
 //   B. one lane per candidate walks ITS items in order and accumulates (scoring.rs:704-754).
-constexpr uint16_t RES_NONE = 0xFFFFu;
 
 // select_most_intense_peak (spectrum.rs:134-159) with the two partition points found through a direct-index table
 // instead of binary searches: plut[b] = number of peaks with mass < b * W.  W is a power of two, so bin(lo) = floor(lo / W)

@@ -941,6 +941,527 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     return true;
 }
 
+
+// ======================================================================================================================
+// The predict_rt block (sage-cli runner.rs:513-530): poisson-sorted q-values -> global_alignment -> retention / mobility
+// linear models.  Same division of labour as above: everything per-PSM or per-(PSM x feature) is a kernel, the D x D solve
+// and a handful of scalars are host arithmetic.
+// ======================================================================================================================
+
+constexpr int RT_D = 22 * 3 + 3;   // retention_model.rs:33
+constexpr int IM_D = 22 * 4 + 12;  // mobility_model.rs:78
+__constant__ uint8_t kAaMap[26] = {0, 0, 1, 2, 3, 4, 5, 6, 7, 0, 8, 9, 10, 11, 21, 12, 13, 14, 15, 16, 20, 17, 18, 0, 19, 0};
+// ^ retention_model.rs:65-68 over mass.rs:59-62 VALID_AA = ACDEFGHIKLMNPQRSTVWYUO (letters outside it map to 0)
+
+// RetentionModel::embed (retention_model.rs:44-62) into e[RT_D] (any addressable memory)
+struct RtEmbed {
+    static constexpr int D = RT_D;
+    __device__ static void embed(const uint8_t* __restrict__ seq, uint32_t len, float mono, uint8_t, double* e) {
+        for (int j = 0; j < D; ++j) e[j] = 0.0;
+        const uint32_t cterm = len >= 3 ? len - 3 : 0;
+        for (uint32_t a = 0; a < len; ++a) {
+            const uint32_t idx = kAaMap[(uint8_t)(seq[a] - 'A') < 26 ? seq[a] - 'A' : 0];
+            e[idx] += 1.0;
+            if (a == 0 || a == 1) e[22 + idx] += 1.0;
+            else if (a == cterm || a == cterm + 1) e[44 + idx] += 1.0;
+        }
+        e[D - 3] = (double)len;
+        e[D - 2] = log1p((double)mono);
+        e[D - 1] = 1.0;
+    }
+    __device__ static double target(const SageFeature& f, float aligned_rt) { return (double)aligned_rt; }
+};
+
+// MobilityModel::embed (mobility_model.rs:103-158).  The residue-class tables of the reference hold LETTER offsets
+// (b'L' - b'A', ...) but are compared with the residue's VALID_AA index (:121-139); restated as written:
+// bulky {11,21,8,5,22,24}, uncharged polar {18,19,13,16}, positive {17,10,7}, negative {3,4}, tiny {6,0,18}, branched {11,8,21}.
+struct ImEmbed {
+    static constexpr int D = IM_D;
+    __device__ static void embed(const uint8_t* __restrict__ seq, uint32_t len, float mono, uint8_t charge, double* e) {
+        for (int j = 0; j < D; ++j) e[j] = 0.0;
+        const uint32_t cterm = len >= 3 ? len - 3 : 0;
+        for (uint32_t a = 0; a < len; ++a) {
+            const uint32_t x = kAaMap[(uint8_t)(seq[a] - 'A') < 26 ? seq[a] - 'A' : 0];
+            e[x] += 1.0;
+            if (a == 0 || a == 1) e[44 + x] += 1.0;
+            else if (a > cterm) e[66 + x] += 1.0;
+            if (x == 11 || x == 21 || x == 8 || x == 5) e[D - 9] += 1.0;    // NUM_BULKY
+            if (x == 18 || x == 19 || x == 13 || x == 16) e[D - 10] += 1.0;  // NUM_UC_POLAR
+            if (x == 17 || x == 10 || x == 7) e[D - 8] += 1.0;               // NUM_POSITIVE
+            if (x == 3 || x == 4) e[D - 7] += 1.0;                           // NUM_NEGATIVE
+            if (x == 6 || x == 0 || x == 18) e[D - 11] += 1.0;               // NUM_TINY
+            if (x == 11 || x == 8 || x == 21) e[D - 12] += 1.0;              // NUM_BRANCHED
+        }
+        for (int i = 0; i < 22; ++i) e[22 + i] = e[i] / (double)len;
+        const double z = (double)charge;
+        e[D - 5] = z;
+        e[D - 6] = 1.0 / z;
+        e[D - 3] = (double)len;
+        e[D - 2] = (double)mono / 1000.0;
+        e[D - 4] = ((double)mono / z) / 1000.0;
+        e[D - 1] = 1.0;
+    }
+    __device__ static double target(const SageFeature& f, float) { return (double)f.ims; }
+};
+
+__device__ inline uint64_t total_order_key64(double x) {  // ascending u64 order == f64::total_cmp
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return b ^ ((b >> 63) ? 0xFFFFFFFFFFFFFFFFull : 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(RB) void poisson_keys_kernel(const SageFeature* __restrict__ f, uint32_t n, uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ idx, uint8_t* __restrict__ decoy) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = total_order_key64(f[i].poisson);
+    idx[i] = i;
+    decoy[i] = f[i].label == -1;
+}
+
+// the training filter of both models and of the alignment: label == 1 && spectrum_q <= 0.01; max_rt_by_file
+// (retention_alignment.rs:26-41: fetch_max of `rt.ceil() as u32`, a saturating cast)
+__global__ __launch_bounds__(RB) void train_flags_kernel(const SageFeature* __restrict__ f, const float* __restrict__ q, uint32_t n,
+                                                         uint32_t n_files, uint8_t* __restrict__ train,
+                                                         uint32_t* __restrict__ max_rt, uint32_t* __restrict__ bad_file) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    train[i] = f[i].label == 1 && q[i] <= 0.01f;
+    if (f[i].file_id >= n_files) {
+        atomicAdd(bad_file, 1u);
+        return;
+    }
+    const float c = ceilf(f[i].rt);
+    const uint32_t v = (!(c == c) || c <= 0.0f) ? 0u : (c >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)c);
+    atomicMax(&max_rt[f[i].file_id], v);
+}
+
+// sort keys of the training PSMs for the (peptide, file) grouping of mean_rt_by_file (:45-60); others sort last
+__global__ __launch_bounds__(RB) void group_keys_kernel(const SageFeature* __restrict__ f, const uint8_t* __restrict__ train, uint32_t n,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = train[i] ? ((uint64_t)f[i].peptide_idx << 32) | f[i].file_id : 0xFFFFFFFFFFFFFFFFull;
+    idx[i] = i;
+}
+
+// row_start[j] = 1 where a new peptide begins among the first m (training) sorted entries
+__global__ __launch_bounds__(RB) void row_start_kernel(const uint64_t* __restrict__ keys, uint32_t m, uint32_t* __restrict__ row_start) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j < m) row_start[j] = (j == 0 || (keys[j] >> 32) != (keys[j - 1] >> 32)) ? 1u : 0u;
+}
+
+// the head of every (peptide, file) run writes the run's minimum rt, divided by the file's maximum (rt_matrix, :62-90),
+// into mat[row][file]; mat is pre-filled with NaN
+__global__ __launch_bounds__(RB) void run_min_kernel(const SageFeature* __restrict__ f, const uint64_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ idx, const uint32_t* __restrict__ row_cum, uint32_t m,
+                                                     uint32_t n_files, const double* __restrict__ max_rt, double* __restrict__ mat) {
+    const uint32_t j = blockIdx.x * RB + threadIdx.x;
+    if (j >= m || (j > 0 && keys[j] == keys[j - 1])) return;
+    const uint64_t key = keys[j];
+    double mn = (double)f[idx[j]].rt;
+    for (uint32_t k = j + 1; k < m && keys[k] == key; ++k) mn = fmin(mn, (double)f[idx[k]].rt);  // f64::min
+    const uint32_t file = (uint32_t)key;
+    mat[(uint64_t)(row_cum[j] - 1) * n_files + file] = mn / max_rt[file];
+}
+
+// per row: the mean over the files that saw the peptide; rows whose mean is not a normal number are dropped (:79) by
+// turning them into all-NaN rows; mean_rts (:104-115)
+__global__ __launch_bounds__(RB) void row_mean_kernel(double* __restrict__ mat, uint32_t n_rows, uint32_t n_files,
+                                                      double* __restrict__ mean_rts) {
+    const uint32_t r = blockIdx.x * RB + threadIdx.x;
+    if (r >= n_rows) return;
+    double sum = 0.0, len = 0.0;
+    for (uint32_t k = 0; k < n_files; ++k) {
+        const double v = mat[(uint64_t)r * n_files + k];
+        if (v == v) {
+            sum += v;
+            len += 1.0;
+        }
+    }
+    const double mean = sum / len, a = fabs(mean);
+    const bool normal = mean == mean && a >= 2.2250738585072014e-308 && a <= 1.7976931348623157e308;
+    if (!normal)
+        for (uint32_t k = 0; k < n_files; ++k) mat[(uint64_t)r * n_files + k] = __longlong_as_double(0x7FF8000000000000ll);
+    // (a finite entry count recomputed as in :108-113; infinite entries can only come from max_rt == 0)
+    double s2 = 0.0;
+    uint32_t l2 = 0;
+    for (uint32_t k = 0; k < n_files; ++k) {
+        const double v = mat[(uint64_t)r * n_files + k];
+        if (isfinite(v)) {
+            s2 += v;
+            ++l2;
+        }
+    }
+    mean_rts[r] = s2 / (double)l2;
+}
+
+// per file (blockIdx.y): partial {len, dot, sum_x, sum_y} (pass 0) or {sum (x - x_mean)^2} (pass 1) over the finite entries
+// of the file's column (:121-141)
+__global__ __launch_bounds__(RB) void align_sums_kernel(const double* __restrict__ mat, const double* __restrict__ mean_rts,
+                                                        uint32_t n_rows, uint32_t n_files, int pass, const double* __restrict__ x_mean,
+                                                        double* __restrict__ partial) {
+    __shared__ double lds[RB / 64];
+    const uint32_t file = blockIdx.y;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (uint32_t r = blockIdx.x * RB + threadIdx.x; r < n_rows; r += gridDim.x * RB) {
+        const double x = mat[(uint64_t)r * n_files + file];
+        if (!isfinite(x)) continue;
+        if (pass == 0) {
+            const double y = mean_rts[r];
+            a0 += 1.0;
+            a1 += x * y;
+            a2 += x;
+            a3 += y;
+        } else {
+            const double d = x - x_mean[file];
+            a0 += d * d;
+        }
+    }
+    const double r0 = block_reduce(a0, OpSum(), lds), r1 = block_reduce(a1, OpSum(), lds), r2 = block_reduce(a2, OpSum(), lds),
+                 r3 = block_reduce(a3, OpSum(), lds);
+    if (threadIdx.x == 0) {
+        double* o = partial + ((uint64_t)blockIdx.x * n_files + file) * 4;
+        o[0] = r0;
+        o[1] = r1;
+        o[2] = r2;
+        o[3] = r3;
+    }
+}
+
+// feature.aligned_rt = (feature.rt / a.max_rt) * a.slope + a.intercept, in f32 (:165-172)
+__global__ __launch_bounds__(RB) void aligned_rt_kernel(const SageFeature* __restrict__ f, uint32_t n, const SageAlignment* __restrict__ al,
+                                                        float* __restrict__ aligned) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    const SageAlignment a = al[f[i].file_id];
+    aligned[i] = (f[i].rt / a.max_rt) * a.slope + a.intercept;
+}
+
+// LinearRegression::fit pass 1 (regression.rs:68-84): partial[b] = {X^T X (D*D), X^T y (D), sum y, sum y^2, count} over the
+// block's training rows.  Rows are embedded 16 at a time into LDS (one thread per row), then every thread adds its share
+// of the D*D + D + 3 accumulators.
+constexpr int XTX_THREADS = 1024, XTX_STAGE = 16;
+template <class E>
+__global__ __launch_bounds__(XTX_THREADS) void xtx_kernel(const SageFeature* __restrict__ f, const uint8_t* __restrict__ train,
+                                                          const uint64_t* __restrict__ seq_off, const uint8_t* __restrict__ seq,
+                                                          const float* __restrict__ mono, const float* __restrict__ aligned,
+                                                          uint32_t n, double* __restrict__ partial) {
+    constexpr int D = E::D, W = D * D + D + 3, PER = (W + XTX_THREADS - 1) / XTX_THREADS;
+    __shared__ double stage[XTX_STAGE][D];
+    __shared__ double ys[XTX_STAGE];
+    __shared__ uint8_t use[XTX_STAGE];
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double acc[PER];
+#pragma unroll
+    for (int s = 0; s < PER; ++s) acc[s] = 0.0;
+    for (uint32_t base = lo; base < hi; base += XTX_STAGE) {
+        __syncthreads();
+        if (threadIdx.x < XTX_STAGE) {
+            const uint32_t i = base + threadIdx.x;
+            const bool u = i < hi && train[i];
+            use[threadIdx.x] = u;
+            if (u) {
+                E::embed(seq + seq_off[i], (uint32_t)(seq_off[i + 1] - seq_off[i]), mono[i], f[i].charge, stage[threadIdx.x]);
+                ys[threadIdx.x] = E::target(f[i], aligned ? aligned[i] : 0.0f);
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < XTX_STAGE; ++r) {
+            if (!use[r]) continue;
+            const double y = ys[r];
+#pragma unroll
+            for (int s = 0; s < PER; ++s) {
+                const int e = threadIdx.x + s * XTX_THREADS;
+                if (e < D * D) acc[s] += stage[r][e / D] * stage[r][e % D];
+                else if (e < D * D + D) acc[s] += stage[r][e - D * D] * y;
+                else if (e == D * D + D) acc[s] += y;
+                else if (e == D * D + D + 1) acc[s] += y * y;
+                else if (e == D * D + D + 2) acc[s] += 1.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const int e = threadIdx.x + s * XTX_THREADS;
+        if (e < W) partial[(uint64_t)blockIdx.x * W + e] = acc[s];
+    }
+}
+
+template <int D>
+struct Beta {
+    double w[D];
+};
+
+// predictions sum_j x_j * beta_j (left to right from 0.0: regression.rs:108, retention_model.rs:84-88); one thread per PSM,
+// its embedding in LDS.  mode 0: partial[b] = sum over the block's TRAINING rows of (pred - y)^2 (the SSE pass, :104-113).
+// mode 1: write the clamped prediction and |observed - prediction| (retention_model.rs:17-24 / mobility_model.rs:23-30).
+constexpr int PRED_THREADS = 64;
+template <class E>
+__global__ __launch_bounds__(PRED_THREADS) void predict_kernel(const SageFeature* __restrict__ f, const uint8_t* __restrict__ train,
+                                                               const uint64_t* __restrict__ seq_off, const uint8_t* __restrict__ seq,
+                                                               const float* __restrict__ mono, const float* __restrict__ aligned,
+                                                               uint32_t n, Beta<E::D> beta, int mode, double hi_clamp,
+                                                               double* __restrict__ partial, float* __restrict__ predicted,
+                                                               float* __restrict__ delta) {
+    constexpr int D = E::D;
+    __shared__ double rows[PRED_THREADS][D + 1];  // (+1: odd stride, conflict-free row-per-thread access)
+    __shared__ double lds[1];
+    const uint32_t i = blockIdx.x * PRED_THREADS + threadIdx.x;
+    double sq = 0.0;
+    if (i < n && (mode == 1 || train[i])) {
+        double* e = rows[threadIdx.x];
+        E::embed(seq + seq_off[i], (uint32_t)(seq_off[i + 1] - seq_off[i]), mono[i], f[i].charge, e);
+        double pred = 0.0;
+        for (int j = 0; j < D; ++j) pred = pred + e[j] * beta.w[j];
+        const double y = E::target(f[i], aligned ? aligned[i] : 0.0f);
+        if (mode == 0) {
+            sq = (pred - y) * (pred - y);
+        } else {
+            const float bounded = (float)(pred < 0.0 ? 0.0 : (pred > hi_clamp ? hi_clamp : pred));  // f64::clamp: NaN stays NaN
+            predicted[i] = bounded;
+            delta[i] = fabsf((float)y - bounded);  // (y is exactly the f32 the reference subtracts from)
+        }
+    }
+    if (mode == 0) {
+        const double r = block_reduce(sq, OpSum(), lds);
+        if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(RB) void fill_kernel(float* __restrict__ p, uint32_t n, float v) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// LinearRegression::fit + predict for one model; false only on a HIP error (an unfitted model is `fitted = false`)
+template <class E>
+bool fit_and_predict(Ctx& cx, const SageFeature* d_f, const uint8_t* d_train, const uint64_t* d_seq_off, const uint8_t* d_seq,
+                     const float* d_mono, const float* d_aligned, uint32_t n, double hi_clamp, float* d_pred, float* d_delta,
+                     bool& fitted, double& r2) {
+    constexpr int D = E::D, W = D * D + D + 3;
+    fitted = false;
+    r2 = 0.0;
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, (n + 255) / 256));
+    Buf<double> partial, folded;
+    RS_TRY(partial.alloc((size_t)nb * W));
+    RS_TRY(folded.alloc(W));
+    xtx_kernel<E><<<nb, XTX_THREADS, 0, cx.stream>>>(d_f, d_train, d_seq_off, d_seq, d_mono, d_aligned, n, partial.p);
+    fold_partials_kernel<<<grid_for(W, RB), RB, 0, cx.stream>>>(partial.p, nb, W, folded.p);
+    std::vector<double> h(W);
+    RS_TRY(hipMemcpyAsync(h.data(), folded.p, (size_t)W * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    const double cnt = h[D * D + D + 2];
+    if (cnt == 0.0) return true;  // regression.rs:86-88
+    const double sum_y = h[D * D + D], sum_y2 = h[D * D + D + 1];
+    const double y_mean = sum_y / cnt, y_var = sum_y2 - cnt * y_mean * y_mean;
+    Dense cov(D, D), b(D, 1);
+    std::copy(h.begin(), h.begin() + D * D, cov.a.begin());
+    std::copy(h.begin() + D * D, h.begin() + D * D + D, b.a.begin());
+    std::vector<double> beta;
+    if (!gauss_solve(cov, b, beta)) return true;  // :96
+    Beta<D> bw;
+    for (int j = 0; j < D; ++j) bw.w[j] = beta[j];
+    const uint32_t pb = grid_for(n, PRED_THREADS);
+    Buf<double> sse_partial;
+    RS_TRY(sse_partial.alloc(pb));
+    predict_kernel<E><<<pb, PRED_THREADS, 0, cx.stream>>>(d_f, d_train, d_seq_off, d_seq, d_mono, d_aligned, n, bw, 0, hi_clamp,
+                                                           sse_partial.p, nullptr, nullptr);
+    predict_kernel<E><<<pb, PRED_THREADS, 0, cx.stream>>>(d_f, d_train, d_seq_off, d_seq, d_mono, d_aligned, n, bw, 1, hi_clamp,
+                                                           nullptr, d_pred, d_delta);
+    std::vector<double> hs(pb);
+    RS_TRY(hipMemcpyAsync(hs.data(), sse_partial.p, (size_t)pb * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    double sse = 0.0;
+    for (double v : hs) sse += v;
+    r2 = 1.0 - sse / y_var;
+    fitted = true;
+    return true;
+}
+
+bool predict_rt_impl(Ctx& cx, const SageRtInput& in, SageRtOutput& out) {
+    const uint32_t n = (uint32_t)in.n, nf = in.n_files;
+    const uint64_t n_res = in.seq_off[n];
+    Buf<SageFeature> feats;
+    Buf<uint64_t> seq_off, keys, keys_sorted;
+    Buf<uint8_t> seq, decoy, train;
+    Buf<float> mono, q_sorted, qmin_sorted, spectrum_q, aligned, pred_rt, d_rt, pred_ims, d_ims;
+    Buf<uint32_t> idx, order, flags, cum, max_rt_u, counters;
+    Buf<unsigned long long> dummy_pass;
+    RS_TRY(feats.alloc(n));
+    RS_TRY(seq_off.alloc((size_t)n + 1));
+    RS_TRY(seq.alloc(n_res));
+    RS_TRY(mono.alloc(n));
+    RS_TRY(keys.alloc(n));
+    RS_TRY(keys_sorted.alloc(n));
+    RS_TRY(idx.alloc(n));
+    RS_TRY(order.alloc(n));
+    RS_TRY(flags.alloc(n));
+    RS_TRY(cum.alloc(n));
+    RS_TRY(decoy.alloc(n));
+    RS_TRY(train.alloc(n));
+    RS_TRY(q_sorted.alloc(n));
+    RS_TRY(qmin_sorted.alloc(n));
+    RS_TRY(spectrum_q.alloc(n));
+    RS_TRY(aligned.alloc(n));
+    RS_TRY(pred_rt.alloc(n));
+    RS_TRY(d_rt.alloc(n));
+    RS_TRY(pred_ims.alloc(n));
+    RS_TRY(d_ims.alloc(n));
+    RS_TRY(max_rt_u.alloc(nf));
+    RS_TRY(counters.alloc(1));
+    RS_TRY(hipMemcpyAsync(feats.p, in.features, (size_t)n * sizeof(SageFeature), hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemcpyAsync(seq_off.p, in.seq_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemcpyAsync(seq.p, in.seq, n_res, hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemcpyAsync(mono.p, in.monoisotopic, (size_t)n * 4, hipMemcpyHostToDevice, cx.stream));
+    RS_TRY(hipMemsetAsync(max_rt_u.p, 0, (size_t)nf * 4, cx.stream));
+    RS_TRY(hipMemsetAsync(counters.p, 0, 4, cx.stream));
+    hipEvent_t ev0, ev1;
+    RS_TRY(hipEventCreate(&ev0));
+    RS_TRY(hipEventCreate(&ev1));
+    RS_TRY(hipEventRecord(ev0, cx.stream));
+    const uint32_t g = grid_for(n, RB);
+
+    // ---- runner.rs:517-520: sort by poisson (f64 total order, ascending), spectrum_q_value ----
+    poisson_keys_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, keys.p, idx.p, decoy.p);
+    {
+        size_t temp_bytes = 0;
+        RS_TRY(rocprim::radix_sort_pairs((void*)nullptr, temp_bytes, keys.p, keys_sorted.p, idx.p, order.p, n, 0, 64, cx.stream));
+        Buf<uint8_t> temp;
+        RS_TRY(temp.alloc(temp_bytes));
+        RS_TRY(rocprim::radix_sort_pairs((void*)temp.p, temp_bytes, keys.p, keys_sorted.p, idx.p, order.p, n, 0, 64, cx.stream));
+        RS_TRY(hipStreamSynchronize(cx.stream));
+    }
+    decoy_flags_kernel<<<g, RB, 0, cx.stream>>>(order.p, decoy.p, n, flags.p);
+    if (!prefix_count(cx, flags.p, cum.p, n)) return false;
+    q_from_counts_kernel<<<g, RB, 0, cx.stream>>>(cum.p, n, q_sorted.p);
+    if (!suffix_min(cx, q_sorted.p, qmin_sorted.p, n)) return false;
+    scatter_by_order_kernel<<<g, RB, 0, cx.stream>>>(order.p, qmin_sorted.p, n, spectrum_q.p);
+    train_flags_kernel<<<g, RB, 0, cx.stream>>>(feats.p, spectrum_q.p, n, nf, train.p, max_rt_u.p, counters.p);
+
+    // ---- global_alignment (retention_alignment.rs:100-173) ----
+    std::vector<uint32_t> h_max(nf);
+    uint32_t h_bad = 0;
+    RS_TRY(hipMemcpyAsync(h_max.data(), max_rt_u.p, (size_t)nf * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(&h_bad, counters.p, 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    if (h_bad) {
+        cx.code = SAGE_HIP_ERR_INVALID;
+        cx.err = "sage_hip_predict_rt: a feature's file_id is >= n_files";
+        return false;
+    }
+    std::vector<double> h_max_d(nf);
+    for (uint32_t k = 0; k < nf; ++k) h_max_d[k] = (double)h_max[k];
+    Buf<double> d_max;
+    RS_TRY(d_max.alloc(nf));
+    RS_TRY(hipMemcpyAsync(d_max.p, h_max_d.data(), (size_t)nf * 8, hipMemcpyHostToDevice, cx.stream));
+    // group the training PSMs by (peptide, file): 64-bit radix sort, run heads take the minimum
+    group_keys_kernel<<<g, RB, 0, cx.stream>>>(feats.p, train.p, n, keys.p, idx.p);
+    {
+        size_t temp_bytes = 0;
+        RS_TRY(rocprim::radix_sort_pairs((void*)nullptr, temp_bytes, keys.p, keys_sorted.p, idx.p, order.p, n, 0, 64, cx.stream));
+        Buf<uint8_t> temp;
+        RS_TRY(temp.alloc(temp_bytes));
+        RS_TRY(rocprim::radix_sort_pairs((void*)temp.p, temp_bytes, keys.p, keys_sorted.p, idx.p, order.p, n, 0, 64, cx.stream));
+        RS_TRY(hipStreamSynchronize(cx.stream));
+    }
+    // number of training PSMs = position of the first sentinel key; count it with the flags of the q pass
+    std::vector<uint8_t> h_train(n);
+    RS_TRY(hipMemcpyAsync(h_train.data(), train.p, n, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) m += h_train[i];
+    uint32_t n_rows = 0;
+    Buf<double> mat, mean_rts;
+    if (m) {
+        row_start_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(keys_sorted.p, m, flags.p);
+        if (!prefix_count(cx, flags.p, cum.p, m)) return false;
+        RS_TRY(hipMemcpyAsync(&n_rows, cum.p + (m - 1), 4, hipMemcpyDeviceToHost, cx.stream));
+        RS_TRY(hipStreamSynchronize(cx.stream));
+    }
+    RS_TRY(mat.alloc((size_t)std::max<uint32_t>(n_rows, 1) * nf));
+    RS_TRY(mean_rts.alloc(std::max<uint32_t>(n_rows, 1)));
+    std::vector<SageAlignment> al(nf);
+    {
+        std::vector<double> len(nf, 0.0), dot(nf, 0.0), sum_x(nf, 0.0), sum_y(nf, 0.0), sx2(nf, 1e-8), x_mean(nf), y_mean(nf);
+        if (n_rows) {
+            RS_TRY(hipMemsetAsync(mat.p, 0xFF, (size_t)n_rows * nf * 8, cx.stream));  // all-ones bit pattern: a NaN
+            run_min_kernel<<<grid_for(m, RB), RB, 0, cx.stream>>>(feats.p, keys_sorted.p, order.p, cum.p, m, nf, d_max.p, mat.p);
+            row_mean_kernel<<<grid_for(n_rows, RB), RB, 0, cx.stream>>>(mat.p, n_rows, nf, mean_rts.p);
+            const uint32_t nb = (uint32_t)std::min<uint32_t>(64, grid_for(n_rows, RB));
+            Buf<double> partial, d_xmean;
+            RS_TRY(partial.alloc((size_t)nb * nf * 4));
+            RS_TRY(d_xmean.alloc(nf));
+            std::vector<double> hp((size_t)nb * nf * 4);
+            align_sums_kernel<<<dim3(nb, nf), RB, 0, cx.stream>>>(mat.p, mean_rts.p, n_rows, nf, 0, nullptr, partial.p);
+            RS_TRY(hipMemcpyAsync(hp.data(), partial.p, hp.size() * 8, hipMemcpyDeviceToHost, cx.stream));
+            RS_TRY(hipGetLastError());
+            RS_TRY(hipStreamSynchronize(cx.stream));
+            for (uint32_t b = 0; b < nb; ++b)
+                for (uint32_t k = 0; k < nf; ++k) {
+                    const double* o = &hp[((size_t)b * nf + k) * 4];
+                    len[k] += o[0];
+                    dot[k] += o[1];
+                    sum_x[k] += o[2];
+                    sum_y[k] += o[3];
+                }
+            for (uint32_t k = 0; k < nf; ++k) x_mean[k] = sum_x[k] / len[k];
+            RS_TRY(hipMemcpyAsync(d_xmean.p, x_mean.data(), (size_t)nf * 8, hipMemcpyHostToDevice, cx.stream));
+            align_sums_kernel<<<dim3(nb, nf), RB, 0, cx.stream>>>(mat.p, mean_rts.p, n_rows, nf, 1, d_xmean.p, partial.p);
+            RS_TRY(hipMemcpyAsync(hp.data(), partial.p, hp.size() * 8, hipMemcpyDeviceToHost, cx.stream));
+            RS_TRY(hipGetLastError());
+            RS_TRY(hipStreamSynchronize(cx.stream));
+            for (uint32_t b = 0; b < nb; ++b)
+                for (uint32_t k = 0; k < nf; ++k) sx2[k] += hp[((size_t)b * nf + k) * 4];
+        }
+        for (uint32_t k = 0; k < nf; ++k) {  // :129-157 (0 / 0 when a file has no training peptide: slope 1, intercept 0)
+            const double xm = sum_x[k] / len[k], ym = sum_y[k] / len[k];
+            const double ssxy = dot[k] - len[k] * xm * ym;
+            double slope = ssxy / sx2[k], intercept = ym - slope * xm;
+            if (!std::isfinite(slope)) slope = 1.0;
+            if (!std::isfinite(intercept)) intercept = 0.0;
+            al[k] = SageAlignment{k, (float)h_max_d[k], (float)slope, (float)intercept};
+        }
+    }
+    Buf<SageAlignment> d_al;
+    RS_TRY(d_al.alloc(nf));
+    RS_TRY(hipMemcpyAsync(d_al.p, al.data(), (size_t)nf * sizeof(SageAlignment), hipMemcpyHostToDevice, cx.stream));
+    aligned_rt_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, d_al.p, aligned.p);
+
+    // ---- retention_model::predict, mobility_model::predict; Feature defaults where a model is not fitted ----
+    fill_kernel<<<g, RB, 0, cx.stream>>>(pred_rt.p, n, 0.0f);
+    fill_kernel<<<g, RB, 0, cx.stream>>>(d_rt.p, n, 0.999f);
+    fill_kernel<<<g, RB, 0, cx.stream>>>(pred_ims.p, n, 0.0f);
+    fill_kernel<<<g, RB, 0, cx.stream>>>(d_ims.p, n, 0.999f);
+    bool rt_ok = false, ims_ok = false;
+    if (!fit_and_predict<RtEmbed>(cx, feats.p, train.p, seq_off.p, seq.p, mono.p, aligned.p, n, 1.0, pred_rt.p, d_rt.p, rt_ok,
+                                  out.rt_r2))
+        return false;
+    if (!fit_and_predict<ImEmbed>(cx, feats.p, train.p, seq_off.p, seq.p, mono.p, nullptr, n, 2.0, pred_ims.p, d_ims.p, ims_ok,
+                                  out.ims_r2))
+        return false;
+    out.rt_fitted = rt_ok;
+    out.ims_fitted = ims_ok;
+    RS_TRY(hipEventRecord(ev1, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.spectrum_q, spectrum_q.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.aligned_rt, aligned.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.predicted_rt, pred_rt.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.delta_rt_model, d_rt.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.predicted_ims, pred_ims.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(out.delta_ims_model, d_ims.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipGetLastError());
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    if (out.alignments) std::copy(al.begin(), al.end(), out.alignments);
+    float ms = 0.0f;
+    RS_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    out.device_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return true;
+}
+
 }  // namespace
 
 // entry point used by capi.hip; returns a SAGE_HIP_* status, message in `err`
@@ -964,4 +1485,26 @@ int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput&
     return SAGE_HIP_OK;
 }
 
+}  // namespace sagehip
+
+namespace sagehip {
+int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, std::string& err) {
+    Ctx cx;
+    if (hipSetDevice(device) != hipSuccess) {
+        err = "sage_hip_predict_rt: hipSetDevice failed";
+        return SAGE_HIP_ERR_NO_DEVICE;
+    }
+    if (!cx.check(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        err = cx.err;
+        return cx.code;
+    }
+    const bool ok = predict_rt_impl(cx, in, out);
+    (void)hipStreamSynchronize(cx.stream);
+    (void)hipStreamDestroy(cx.stream);
+    if (!ok) {
+        err = cx.err;
+        return cx.code ? cx.code : SAGE_HIP_ERR_HIP;
+    }
+    return SAGE_HIP_OK;
+}
 }  // namespace sagehip

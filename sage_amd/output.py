@@ -4,8 +4,9 @@ Column order and number formatting follow the reference byte for byte where the 
 sage-cli/src/runner.rs:687-780 (serialize_feature), :782-828 (serialize_fragments), :830-935 (headers).  Integers are
 written with `itoa`, floats with `ryu` (shortest digits that round-trip, Rust `ryu::Buffer::format`), reproduced by
 `ryu_f32` / `ryu_f64` below.  sage_discriminant_score, posterior_error, spectrum_q, peptide_q and protein_q come from the
-device rescoring (sage_hip_rescore); columns nothing here computes (retention-time / mobility models, protein groups)
-carry the defaults Feature gets in build_features (scoring.rs:576-592): predicted_rt 0.0, aligned_rt = rt,
+device rescoring (sage_hip_rescore), aligned_rt / predicted_rt / delta_rt_model / predicted_mobility / delta_mobility from
+sage_hip_predict_rt when `predict_rt` is on (the default, input.rs:372); without it, and for the protein-group columns
+nothing here computes, the defaults Feature gets in build_features (scoring.rs:576-592): predicted_rt 0.0, aligned_rt = rt,
 delta_rt_model / delta_ims_model 0.999, protein_group_q 1.0.  `results.sage.pin` follows runner.rs:938-1135.
 """
 import ctypes
@@ -72,17 +73,20 @@ DEFAULT_POST = dict(discriminant_score=0.0, posterior_error=1.0, spectrum_q=1.0,
 def feature_row(psm_id: int, f, db, filename: str, scannr: str, post: Optional[dict] = None) -> List[str]:
     """serialize_feature (runner.rs:687-780) for one SageFeature record `f` (numpy void of FEATURE_DTYPE); `post` = the
     rescoring outputs of this PSM (defaults of scoring.rs:576-592 when the rescoring did not run)."""
-    post = post or DEFAULT_POST
+    post = dict(DEFAULT_POST, **(post or {}))
     pep = int(f["peptide_idx"])
     num_proteins, semi = db.peptide_info(pep)
     rt = f["rt"]
+    aligned_rt = post.get("aligned_rt", rt)  # Feature defaults without the predict_rt block: scoring.rs:576-592
+    predicted_rt, delta_rt = post.get("predicted_rt", 0.0), post.get("delta_rt_model", 0.999)
+    predicted_ims, delta_ims = post.get("predicted_ims", 0.0), post.get("delta_ims_model", 0.999)
     return [
         str(psm_id), db.peptide_string(pep), db.peptide_proteins(pep), "", str(num_proteins), "0", filename, scannr,
         str(int(f["rank"])), str(int(f["label"])), ryu_f32(f["expmass"]), ryu_f32(f["calcmass"]), str(int(f["charge"])),
         str(int(f["peptide_len"])), str(int(f["missed_cleavages"])), str(semi), ryu_f32(f["isotope_error"]),
         ryu_f32(f["delta_mass"]), ryu_f32(f["average_ppm"]), ryu_f64(f["hyperscore"]), ryu_f64(f["delta_next"]),
-        ryu_f64(f["delta_best"]), ryu_f32(rt), ryu_f32(rt), ryu_f32(0.0), ryu_f32(0.999), ryu_f32(f["ims"]), ryu_f32(0.0),
-        ryu_f32(0.999), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
+        ryu_f64(f["delta_best"]), ryu_f32(rt), ryu_f32(aligned_rt), ryu_f32(predicted_rt), ryu_f32(delta_rt), ryu_f32(f["ims"]),
+        ryu_f32(predicted_ims), ryu_f32(delta_ims), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
         ryu_f32(f["longest_y_pct"]), ryu_f32(f["matched_intensity_pct"]), str(int(f["scored_candidates"])),
         ryu_f64(f["poisson"]), ryu_f32(post["discriminant_score"]), ryu_f32(post["posterior_error"]),
         ryu_f32(post["spectrum_q"]), ryu_f32(post["peptide_q"]), ryu_f32(post["protein_q"]), ryu_f32(1.0),
@@ -136,22 +140,26 @@ def _ln1p_f64(x) -> np.float64:
 
 def pin_row(psm_id: int, f, db, filename: str, spec_id: str, post: Optional[dict] = None) -> List[str]:
     """serialize_pin (runner.rs:938-1084): percolator input, log / sqrt transformed feature columns."""
-    post = post or DEFAULT_POST
+    post = dict(DEFAULT_POST, **(post or {}))
     pep = int(f["peptide_idx"])
     _, semi = db.peptide_info(pep)
     caps = _SCAN_RE.findall(spec_id)
     scannr = caps[-1] if caps else spec_id
     z = int(f["charge"])
     rt = f["rt"]
-    delta_rt = np.float32(0.999)  # delta_rt_model default (no retention-time model); .clamp(0.001, 1.0) leaves it
+    aligned_rt = post.get("aligned_rt", rt)
+    predicted_rt, predicted_ims = post.get("predicted_rt", 0.0), post.get("predicted_ims", 0.0)
+    d = np.float32(post.get("delta_rt_model", 0.999))
+    delta_rt = np.float32(0.001) if d < np.float32(0.001) else (np.float32(1.0) if d > np.float32(1.0) else d)  # .clamp(0.001, 1.0)
+    delta_ims = post.get("delta_ims_model", 0.999)
     return [
         str(psm_id), str(int(f["label"])), scannr, ryu_f32(f["expmass"]), ryu_f32(f["calcmass"]), filename, ryu_f32(rt),
         ryu_f32(f["ims"]), str(int(f["rank"])), str(int(z == 2)), str(int(z == 3)), str(int(z == 4)), str(int(z == 5)),
         str(int(z == 6)), str(z if (z < 2 or z > 6) else 0), str(int(f["peptide_len"])), str(int(f["missed_cleavages"])),
         str(semi), ryu_f32(f["isotope_error"]), ryu_f32(_ln1p_f32(np.abs(np.float32(f["delta_mass"])))),
         ryu_f32(f["average_ppm"]), ryu_f64(_ln1p_f64(f["hyperscore"])), ryu_f64(_ln1p_f64(f["delta_next"])),
-        ryu_f64(_ln1p_f64(f["delta_best"])), ryu_f32(rt), ryu_f32(0.0), ryu_f32(np.sqrt(delta_rt, dtype=np.float32)),
-        ryu_f32(0.0), ryu_f32(0.999), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
+        ryu_f64(_ln1p_f64(f["delta_best"])), ryu_f32(aligned_rt), ryu_f32(predicted_rt), ryu_f32(np.sqrt(delta_rt, dtype=np.float32)),
+        ryu_f32(predicted_ims), ryu_f32(delta_ims), str(int(f["matched_peaks"])), str(int(f["longest_b"])), str(int(f["longest_y"])),
         ryu_f32(f["longest_y_pct"]), ryu_f32(_ln1p_f32(f["matched_intensity_pct"])), str(int(f["scored_candidates"])),
         ryu_f64(_ln1p_f64(-np.float64(f["poisson"]))), ryu_f32(post["posterior_error"]), db.peptide_string(pep),
         db.peptide_proteins(pep),

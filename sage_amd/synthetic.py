@@ -177,3 +177,43 @@ def synthetic_features(n: int, seed: int = 7, decoy_frac: float = 0.35, true_fra
     out = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
     out[prk >= 0] = inv.astype(np.uint32)
     return f, pk, n_pk, out, len(used)
+
+
+def synthetic_rt_world(n: int, n_files: int = 3, seed: int = 9, with_ims: bool = True):
+    """(For sage_hip_predict_rt.)  synthetic_features plus what the retention-time / mobility models need: a peptide sequence
+    per PSM (PSMs sharing a peptide key share it), retention times that follow a linear function of the amino-acid
+    composition, distorted per file by a linear map (what global_alignment undoes), ion mobilities that follow composition and
+    charge.  Returns (features, seq_off, seq, monoisotopic)."""
+    f, pk, n_pk, _, _ = synthetic_features(n, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    letters = np.frombuffer(_AA.encode(), dtype=np.uint8)
+    lens = rng.integers(7, 31, n_pk)
+    off_p = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    res = letters[rng.choice(len(_AA), size=int(off_p[-1]), p=_FREQ)]
+    res[(off_p[1:] - 1).astype(np.int64)] = np.where(rng.random(n_pk) < 0.5, ord("K"), ord("R"))  # tryptic C-termini
+    hydro = rng.normal(0, 1, 256)
+    bulk = rng.normal(0, 1, 256)
+    comp_h = np.add.reduceat(hydro[res], off_p[:-1].astype(np.int64))
+    comp_b = np.add.reduceat(bulk[res], off_p[:-1].astype(np.int64))
+    mass_p = (np.add.reduceat(_MASS_LUT[res], off_p[:-1].astype(np.int64)) + H2O).astype(np.float32)
+    rt_p = comp_h - comp_h.min()
+    rt_p = rt_p / rt_p.max()  # the "global" retention of a peptide in [0, 1]
+    true = (f["label"] == 1) & (f["hyperscore"] > 24)
+    file_id = rng.integers(0, n_files, n).astype(np.uint32)
+    slope = rng.uniform(0.8, 1.1, n_files)
+    icpt = rng.uniform(0.0, 0.08, n_files)
+    run_len = rng.uniform(55.0, 120.0, n_files)  # minutes
+    rel = np.where(true, rt_p[pk] + rng.normal(0, 0.01, n), rng.uniform(0, 1, n)).clip(0, 1)
+    f["file_id"] = file_id
+    f["rt"] = (((rel - icpt[file_id]) / slope[file_id]).clip(0, 1) * run_len[file_id]).astype(np.float32)
+    z = f["charge"].astype(np.float64)
+    ims_p = 0.6 + 0.25 * (comp_b - comp_b.min()) / (comp_b.max() - comp_b.min())
+    f["ims"] = (np.where(true, ims_p[pk] + 0.12 * (z - 2) + rng.normal(0, 0.01, n), rng.uniform(0.5, 1.4, n))
+                if with_ims else np.zeros(n)).astype(np.float32)
+    f["peptide_len"] = lens[pk]
+    f["calcmass"] = mass_p[pk]
+    # per-PSM peptide data
+    seq_off = np.concatenate([[0], np.cumsum(lens[pk])]).astype(np.uint64)
+    starts = off_p[:-1][pk].astype(np.int64)
+    idx = np.repeat(starts - seq_off[:-1].astype(np.int64), lens[pk]) + np.arange(int(seq_off[-1]))
+    return f, seq_off, res[idx].copy(), mass_p[pk].copy()

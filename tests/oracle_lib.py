@@ -97,6 +97,12 @@ def load():
     lib.orc_rescore.argtypes = [vp, C.c_uint64, C.c_int, C.c_float, C.c_float, L.c_float_p, L.c_float_p, L.c_float_p,
                                 L.c_u32_p, C.c_uint32, L.c_u32_p, C.c_uint32, L.c_float_p, L.c_float_p, L.c_float_p,
                                 L.c_float_p, L.c_float_p, L.c_u32_p, L.c_u64_p, dp, dp]
+    lib.orc_linreg_fit.restype = C.c_int
+    lib.orc_linreg_fit.argtypes = [dp, dp, L.c_u8_p, C.c_uint64, C.c_uint64, dp, dp]
+    lib.orc_rt_embed.argtypes = [L.c_u8_p, C.c_uint64, C.c_float, dp]
+    lib.orc_im_embed.argtypes = [L.c_u8_p, C.c_uint64, C.c_float, C.c_uint8, dp]
+    lib.orc_predict_rt.argtypes = [vp, C.c_uint64, C.c_uint32, L.c_u64_p, L.c_u8_p, L.c_float_p] + [L.c_float_p] * 7 + \
+        [C.POINTER(C.c_int32), dp]
     _lib = lib
     return lib
 
@@ -334,3 +340,46 @@ def fasta_num_targets(fasta_text, params):
 def prefilter_chunk_size(fasta_text, params, requested=0):
     p, keep = params.to_c()
     return int(load().orc_prefilter_chunk_size(fasta_text.encode(), C.byref(p), requested))
+
+
+# ---- the predict_rt block (runner.rs:513-530) ------------------------------------------------------------------------------
+def linreg_fit(rows, y, keep=None):
+    """LinearRegression::fit (regression.rs:58-122) -> (beta, r2) or None"""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    keep = np.ones(len(y), np.uint8) if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    beta, r2 = np.zeros(rows.shape[1]), np.zeros(1)
+    ok = load().orc_linreg_fit(_dptr(rows), _dptr(y), L.as_ptr(keep, C.c_uint8), len(y), rows.shape[1], _dptr(beta), _dptr(r2))
+    return (beta, float(r2[0])) if ok else None
+
+
+def rt_embed(sequence: str, mono: float):
+    seq = np.frombuffer(sequence.encode(), dtype=np.uint8).copy()
+    out = np.zeros(69)
+    load().orc_rt_embed(L.as_ptr(seq, C.c_uint8), len(seq), mono, _dptr(out))
+    return out
+
+
+def im_embed(sequence: str, mono: float, charge: int):
+    seq = np.frombuffer(sequence.encode(), dtype=np.uint8).copy()
+    out = np.zeros(100)
+    load().orc_im_embed(L.as_ptr(seq, C.c_uint8), len(seq), mono, charge, _dptr(out))
+    return out
+
+
+def predict_rt(features, n_files, seq_off, seq, mono):
+    """runner.rs:513-530: poisson-sorted q-values, global_alignment, retention / mobility models; dict of arrays, input order"""
+    f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
+    n = len(f)
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    mono = np.ascontiguousarray(mono, dtype=np.float32)
+    names = ("spectrum_q", "aligned_rt", "predicted_rt", "delta_rt_model", "predicted_ims", "delta_ims_model")
+    outs = {k: np.empty(n, np.float32) for k in names}
+    align = np.zeros((n_files, 3), np.float32)
+    fitted = np.zeros(2, np.int32)
+    r2 = np.zeros(2)
+    load().orc_predict_rt(f.ctypes.data, n, n_files, L.as_ptr(seq_off, C.c_uint64), L.as_ptr(seq, C.c_uint8),
+                          L.as_ptr(mono, C.c_float), *[L.as_ptr(outs[k], C.c_float) for k in names], L.as_ptr(align, C.c_float),
+                          fitted.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(r2))
+    return dict(outs, alignments=align, fitted=fitted.astype(bool), r2=r2)

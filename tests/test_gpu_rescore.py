@@ -114,3 +114,82 @@ def test_search_then_rescore_end_to_end(gpu_required):
     # (whether the linear model is fitted here is up to the reference's pivot search: ims is constant, see
     # tests/test_rescore_oracle.py — either way true matches are found at 1 %)
     assert g.passing_spectrum > 100
+
+
+# ---- the predict_rt block (runner.rs:513-530) on the device --------------------------------------------------------------
+def compare_rt(f, n_files, off, seq, mono, context):
+    from sage_amd.api import predict_rt
+    g = predict_rt(f, n_files, off, seq, mono)
+    o = oracle_lib.predict_rt(f, n_files, off, seq, mono)
+    assert np.array_equal(g.spectrum_q, o["spectrum_q"]), context  # integer counts, min: exact
+    assert np.array_equal(g.alignments["max_rt"], o["alignments"][:, 0]), context
+    assert np.allclose(g.alignments["slope"], o["alignments"][:, 1], rtol=1e-5, atol=1e-6), context
+    assert np.allclose(g.alignments["intercept"], o["alignments"][:, 2], rtol=1e-5, atol=1e-6), context
+    assert np.allclose(g.aligned_rt, o["aligned_rt"], rtol=1e-5, atol=1e-6), context
+    assert (g.rt_fitted, g.ims_fitted) == tuple(o["fitted"]), context
+    # the normal equations are rank deficient (counts sum to the length, ...) and solved through a 1e-8 regulariser:
+    # coefficients are noisy, predictions much less so (a few 1e-5 on values of order 0.1 - 1 with a few thousand rows)
+    for name, got, exp in (("predicted_rt", g.predicted_rt, o["predicted_rt"]), ("delta_rt_model", g.delta_rt_model, o["delta_rt_model"]),
+                           ("predicted_ims", g.predicted_ims, o["predicted_ims"]), ("delta_ims_model", g.delta_ims_model, o["delta_ims_model"])):
+        assert np.allclose(got, exp, rtol=1e-3, atol=3e-4), (context, name, np.abs(got - exp).max())
+    for fitted, got, exp in ((g.rt_fitted, g.rt_r2, o["r2"][0]), (g.ims_fitted, g.ims_r2, o["r2"][1])):
+        if fitted:  # (all-zero ion mobilities: y_var == 0, r^2 = 1 - 0 / 0 on both sides)
+            assert (np.isnan(got) and np.isnan(exp)) or abs(got - exp) < 1e-5, (context, got, exp)
+    return g, o
+
+
+@pytest.mark.parametrize("n,n_files,seed", [(20000, 3, 9), (500, 1, 10), (60000, 8, 11)])
+def test_predict_rt_synthetic(gpu_required, n, n_files, seed):
+    from sage_amd.synthetic import synthetic_rt_world
+    f, off, seq, mono = synthetic_rt_world(n, n_files, seed=seed)
+    g, _ = compare_rt(f, n_files, off, seq, mono, f"rt n={n} files={n_files}")
+    assert g.rt_fitted
+
+
+def test_predict_rt_degenerate_inputs(gpu_required):
+    from sage_amd._lib import SageHipError
+    from sage_amd.api import predict_rt
+    from sage_amd.synthetic import synthetic_rt_world
+    f, off, seq, mono = synthetic_rt_world(4000, 2, seed=12, with_ims=False)  # no ion mobility: the IM model fits zeros
+    compare_rt(f, 2, off, seq, mono, "no ims")
+    f0 = f.copy()
+    f0["label"] = -1  # nothing to train on
+    g, _ = compare_rt(f0, 2, off, seq, mono, "no targets")
+    assert not g.rt_fitted and np.all(g.delta_rt_model == np.float32(0.999))
+    with pytest.raises(SageHipError):
+        predict_rt(f, 1, off, seq, mono)  # file_id 1 with n_files 1
+
+
+def test_search_predict_rescore_chain(gpu_required):
+    """search -> predict_rt -> rescore with the model outputs as LDA features, against the oracle's chain"""
+    from sage_amd.api import predict_rt
+    fasta = synthetic_fasta(400, seed=41)
+    params = DatabaseParameters(bucket_size=2048, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                                static_mods={"C": 57.0215})
+    host = params.build(fasta)
+    dev = DeviceDatabase(host, 0)
+    sp = SpectrumProcessor(150, True, 0.0)
+    tol = Tolerance("ppm", -20.0, 20.0)
+    scorer = Scorer(dev, ScorerParams(precursor_tol=tol, fragment_tol=Tolerance("ppm", -10.0, 10.0), report_psms=2))
+    flat = []
+    for file_id in range(2):
+        raw = synthetic_spectra(host, 2000, 42 + file_id)
+        batch = SpectrumBatch.from_spectra([sp.process(r) for r in raw])
+        feats, counts = scorer.score(batch)
+        part = np.concatenate([feats[i, :counts[i]] for i in range(len(counts))])
+        part["file_id"] = file_id
+        # synthetic spectra carry no retention time: give every peptide a reproducible one, stretched per file
+        rng = np.random.default_rng(7)
+        rt_of_pep = rng.uniform(5, 50, host.n_peptides).astype(np.float32)
+        part["rt"] = rt_of_pep[part["peptide_idx"]] * np.float32(1.0 + 0.1 * file_id) + np.float32(2.0 * file_id)
+        # ... and an ion mobility, so that no LDA column is constant: with constant columns the reference's elimination pivots
+        # on rounding noise (DESIGN.md section 7) and neither side's coefficients mean anything
+        ims_of_pep = rng.uniform(0.7, 1.2, host.n_peptides).astype(np.float32)
+        part["ims"] = ims_of_pep[part["peptide_idx"]] + np.float32(0.1) * part["charge"] + rng.normal(0, 0.01, len(part)).astype(np.float32)
+        flat.append(part)
+    flat = np.concatenate(flat)
+    off, seq, mono = host.feature_peptides(flat["peptide_idx"])
+    g, o = compare_rt(flat, 2, off, seq, mono, "chain")
+    pk, npk, prk, npr = host.competition_keys(flat["peptide_idx"])
+    opt = dict(aligned_rt=o["aligned_rt"], delta_rt_model=o["delta_rt_model"], delta_ims_model=o["delta_ims_model"])
+    compare(flat, tol, pk, npk, prk, npr, "chain rescore", **opt)

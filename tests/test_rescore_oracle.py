@@ -200,3 +200,82 @@ def test_heuristic_fallback_when_the_pivot_search_skips_a_column():
     exp = np.log1p((-f["poisson"]).astype(np.float32)) + f["longest_y_pct"] / np.float32(3.0)
     assert np.allclose(r["discriminant_score"], exp, rtol=1e-6)
     assert np.all(r["posterior_error"] == 1.0)
+
+
+# ---- the predict_rt block (runner.rs:513-530) ------------------------------------------------------------------------------
+def test_reference_kat_linear_regression():
+    """crates/sage/src/ml/regression.rs:124-157"""
+    x = np.arange(50, dtype=np.float64)
+    beta, r2 = oracle_lib.linreg_fit(np.stack([x, np.ones(50)], 1), 2.0 * x + 1.0)
+    assert abs(beta[0] - 2.0) < 1e-9 and abs(beta[1] - 1.0) < 1e-9 and abs(r2 - 1.0) < 1e-9  # fit_perfect_line
+    i = np.arange(200, dtype=np.float64)
+    x = i / 10.0
+    beta, r2 = oracle_lib.linreg_fit(np.stack([x, np.ones(200)], 1), 3.0 * x + 2.0 + np.sin(i * 0.7) * 0.1)
+    assert abs(beta[0] - 3.0) < 0.05 and abs(beta[1] - 2.0) < 0.1 and r2 > 0.99  # fit_with_noise
+    assert oracle_lib.linreg_fit(np.ones((3, 1)), [1.0, 2.0, 3.0], keep=[0, 0, 0]) is None  # empty_filter_returns_none
+
+
+def test_reference_kat_mobility_embedding():
+    """crates/sage/src/ml/mobility_model.rs:188-267: N- / C-terminal residue counts of four peptides at charge 2"""
+    valid = "ACDEFGHIKLMNPQRSTVWYUO"
+    idx = {c: i for i, c in enumerate(valid)}
+    n_term, c_term = 44, 66
+    emb = [oracle_lib.im_embed(s, 1000.0, 2) for s in ("LEKSLIEK", "LERSLIEWK", "LWESLIEK", "CHADWICK")]
+    assert [e[n_term + idx["L"]] for e in emb] == [1.0, 1.0, 1.0, 0.0]
+    assert [e[n_term + idx["K"]] for e in emb] == [0.0, 0.0, 0.0, 0.0]
+    assert [e[n_term + idx["W"]] for e in emb] == [0.0, 0.0, 1.0, 0.0]
+    assert [e[c_term + idx["K"]] for e in emb] == [1.0, 1.0, 1.0, 1.0]
+    assert [e[c_term + idx["W"]] for e in emb] == [0.0, 1.0, 0.0, 0.0]
+    assert [e[c_term + idx["I"]] for e in emb] == [0.0, 0.0, 0.0, 0.0]
+    e = emb[0]
+    assert e[100 - 5] == 2.0 and e[100 - 6] == 0.5 and e[100 - 3] == 8.0 and e[100 - 1] == 1.0 and e[100 - 2] == 1.0
+    assert np.isclose(e[22 + idx["L"]], 2 / 8) and e[idx["E"]] == 2.0
+    # retention embedding (retention_model.rs:44-62): counts, first two residues, residues len-3 and len-2, len, ln1p(mass), 1
+    r = oracle_lib.rt_embed("LEKSLIEK", 944.5)
+    assert r[idx["L"]] == 2 and r[22 + idx["L"]] == 1 and r[22 + idx["E"]] == 1 and r[44 + idx["I"]] == 1 and r[44 + idx["E"]] == 1
+    assert r[44 + idx["K"]] == 0 and r[66] == 8.0 and np.isclose(r[67], np.log1p(np.float32(944.5))) and r[68] == 1.0
+
+
+def test_predict_rt_block_properties():
+    """runner.rs:513-530 restated: poisson-sorted q-values, alignment, the two linear models — structural checks"""
+    from sage_amd.synthetic import synthetic_rt_world
+    f, off, seq, mono = synthetic_rt_world(12000, n_files=3, seed=21)
+    r = oracle_lib.predict_rt(f, 3, off, seq, mono)
+    decoy = f["label"] == -1
+    # q-values of the poisson-sorted pass (ascending poisson = best first)
+    order = np.argsort(f["poisson"], kind="stable")
+    assert np.array_equal(r["spectrum_q"][order], _numpy_q(decoy[order]))
+    train = (~decoy) & (r["spectrum_q"] <= 0.01)
+    assert train.sum() > 1000
+    # alignment: max_rt = ceil of the largest rt of the file; aligned_rt is the f32 formula of retention_alignment.rs:171
+    al = r["alignments"]
+    for k in range(3):
+        assert al[k, 0] == np.ceil(f["rt"][f["file_id"] == k].max())
+    a = al[f["file_id"]]
+    assert np.array_equal(r["aligned_rt"], (f["rt"] / a[:, 0]) * a[:, 1] + a[:, 2])
+    # the per-file regression maps each file onto the across-file mean: the same peptide seen in two files lands close
+    assert np.all((al[:, 1] > 0.5) & (al[:, 1] < 1.5)) and np.all(np.abs(al[:, 2]) < 0.2)
+    # models: fitted, predictions clamped, deltas as defined; independent least squares on the oracle's own embedding
+    assert r["fitted"].all() and 0.2 < r["r2"][0] <= 1.0
+    assert np.all((r["predicted_rt"] >= 0) & (r["predicted_rt"] <= 1)) and np.all((r["predicted_ims"] >= 0) & (r["predicted_ims"] <= 2))
+    assert np.array_equal(r["delta_rt_model"], np.abs(r["aligned_rt"] - r["predicted_rt"]))
+    assert np.array_equal(r["delta_ims_model"], np.abs(f["ims"] - r["predicted_ims"]))
+    strs = [bytes(seq[int(off[i]):int(off[i + 1])]).decode() for i in range(len(f))]
+    rows = np.stack([oracle_lib.rt_embed(strs[i], float(mono[i])) for i in np.flatnonzero(train)])
+    y = r["aligned_rt"][train].astype(np.float64)
+    beta = np.linalg.lstsq(rows, y, rcond=None)[0]
+    pred = np.clip(rows @ beta, 0, 1)
+    assert np.max(np.abs(pred - r["predicted_rt"][train])) < 5e-4  # (the reference solves the 1e-8-regularised normal equations)
+    # true identifications are predicted better than random ones
+    assert np.median(r["delta_rt_model"][train]) < 0.3 * np.median(r["delta_rt_model"][decoy])
+    # one file, nothing to align against: slope ~ 1, intercept ~ 0
+    f1 = f.copy()
+    f1["file_id"] = 0
+    r1 = oracle_lib.predict_rt(f1, 1, off, seq, mono)
+    assert abs(r1["alignments"][0, 1] - 1.0) < 1e-5 and abs(r1["alignments"][0, 2]) < 1e-5
+    # no training PSM at all: alignment falls back to slope 1 / intercept 0, models stay unfitted, defaults remain
+    f0 = f.copy()
+    f0["label"] = -1
+    r0 = oracle_lib.predict_rt(f0, 3, off, seq, mono)
+    assert not r0["fitted"].any() and np.all(r0["alignments"][:, 1] == 1.0) and np.all(r0["alignments"][:, 2] == 0.0)
+    assert np.all(r0["delta_rt_model"] == np.float32(0.999)) and np.all(r0["predicted_rt"] == 0.0)
