@@ -17,7 +17,7 @@
 // Pinned by the known-answer tests the reference holds for these steps: linear_discriminant.rs:238-288 (LDA on 8 rows,
 // normalised scores to 1e-8), regression.rs:124-157 (perfect line, noisy line, empty filter), mobility_model.rs:188-267
 // (terminal-residue embedding counts) — tests/test_rescore_oracle.py.  KDE, q-values and the picked competitions have no reference
-// vectors: for those this restatement IS the reference ("parity thinly pinned", DESIGN.md §9).
+// vectors: for those this restatement IS the reference ("parity thinly pinned", DESIGN.md §2).
 //
 // Freedoms the reference leaves open, fixed here (and in the product) so that results are reproducible:
 //   * rayon fold/sum order inside Kde::pdf (kde.rs:38-46) — here: sample order;

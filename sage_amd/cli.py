@@ -235,9 +235,21 @@ def main(argv=None):
     ap.add_argument("-o", "--output_directory", help="where to place output files. Overrides the directory specified in the configuration file.")
     ap.add_argument("--annotate-matches", action="store_true", help="write matched fragments output file")
     ap.add_argument("--write-pin", action="store_true", help="write percolator-compatible `.pin` output files")
+    # accepted for command-line compatibility with sage (sage-cli/src/main.rs:55-97)
+    ap.add_argument("--batch-size", type=int, help="number of files sage loads and searches in parallel; files are searched one "
+                                                   "after the other here (every file is one resident GPU batch)")
+    ap.add_argument("--parquet", action="store_true", help="not supported by this path (tsv only)")
+    ap.add_argument("--write-report", action="store_true", help="not supported by this path")
+    ap.add_argument("--disable-telemetry-i-dont-want-to-improve-sage", action="store_true", dest="disable_telemetry",
+                    help="accepted; this implementation never sends telemetry")
+    ap.add_argument("--stack-size", type=int, help="accepted; no effect")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--host-preprocess", action="store_true", help="run SpectrumProcessor::process on the host instead of the device")
     args = ap.parse_args(argv)
+    if args.parquet or args.write_report:
+        raise SystemExit("sage_amd.cli: --parquet / --write-report are outside the search-and-score path (tsv / pin output only)")
+    if args.batch_size is not None and args.batch_size < 1:
+        raise SystemExit("error: invalid value for '--batch-size': must be >= 1")
     cfg = json.load(open(args.parameters))
     if args.fasta:
         cfg.setdefault("database", {})["fasta"] = args.fasta
