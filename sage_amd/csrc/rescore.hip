@@ -537,6 +537,17 @@ struct Buf {
     }
 };
 
+struct EventPair {  // start / stop events of one call, destroyed on every exit path
+    hipEvent_t start = nullptr, stop = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() {
+        if (start) (void)hipEventDestroy(start);
+        if (stop) (void)hipEventDestroy(stop);
+    }
+};
+
 struct Ctx {
     hipStream_t stream = nullptr;
     std::string err;
@@ -842,10 +853,10 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
             RS_TRY(optbuf[k]->alloc(n));
             RS_TRY(hipMemcpyAsync(optbuf[k]->p, opt[k], n * 4, hipMemcpyHostToDevice, cx.stream));
         }
-    hipEvent_t ev0, ev1;
-    RS_TRY(hipEventCreate(&ev0));
-    RS_TRY(hipEventCreate(&ev1));
-    RS_TRY(hipEventRecord(ev0, cx.stream));
+    EventPair ev;
+    RS_TRY(hipEventCreate(&ev.start));
+    RS_TRY(hipEventCreate(&ev.stop));
+    RS_TRY(hipEventRecord(ev.start, cx.stream));
     const uint32_t g = grid_for(n, RB);
     prep_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, tol_kind, decoy.p, dmass.p);
 
@@ -924,7 +935,7 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     // ---- fdr.rs:123-187 ----
     if (!picked(cx, pkey.p, in.n_peptide_keys, decoy.p, discriminant.p, n, peptide_q.p, out.passing_peptide)) return false;
     if (!picked(cx, prkey.p, in.n_protein_keys, decoy.p, discriminant.p, n, protein_q.p, out.passing_protein)) return false;
-    RS_TRY(hipEventRecord(ev1, cx.stream));
+    RS_TRY(hipEventRecord(ev.stop, cx.stream));
 
     RS_TRY(hipMemcpyAsync(out.discriminant_score, discriminant.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipMemcpyAsync(out.posterior_error, posterior.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
@@ -934,10 +945,8 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     if (out.order) RS_TRY(hipMemcpyAsync(out.order, order.p, n * 4, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipStreamSynchronize(cx.stream));
     float ms = 0.0f;
-    RS_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    RS_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
     out.device_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return true;
 }
 
@@ -1317,10 +1326,10 @@ bool predict_rt_impl(Ctx& cx, const SageRtInput& in, SageRtOutput& out) {
     RS_TRY(hipMemcpyAsync(mono.p, in.monoisotopic, (size_t)n * 4, hipMemcpyHostToDevice, cx.stream));
     RS_TRY(hipMemsetAsync(max_rt_u.p, 0, (size_t)nf * 4, cx.stream));
     RS_TRY(hipMemsetAsync(counters.p, 0, 4, cx.stream));
-    hipEvent_t ev0, ev1;
-    RS_TRY(hipEventCreate(&ev0));
-    RS_TRY(hipEventCreate(&ev1));
-    RS_TRY(hipEventRecord(ev0, cx.stream));
+    EventPair ev;
+    RS_TRY(hipEventCreate(&ev.start));
+    RS_TRY(hipEventCreate(&ev.stop));
+    RS_TRY(hipEventRecord(ev.start, cx.stream));
     const uint32_t g = grid_for(n, RB);
 
     // ---- runner.rs:517-520: sort by poisson (f64 total order, ascending), spectrum_q_value ----
@@ -1444,7 +1453,7 @@ bool predict_rt_impl(Ctx& cx, const SageRtInput& in, SageRtOutput& out) {
         return false;
     out.rt_fitted = rt_ok;
     out.ims_fitted = ims_ok;
-    RS_TRY(hipEventRecord(ev1, cx.stream));
+    RS_TRY(hipEventRecord(ev.stop, cx.stream));
     RS_TRY(hipMemcpyAsync(out.spectrum_q, spectrum_q.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipMemcpyAsync(out.aligned_rt, aligned.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipMemcpyAsync(out.predicted_rt, pred_rt.p, (size_t)n * 4, hipMemcpyDeviceToHost, cx.stream));
@@ -1455,10 +1464,8 @@ bool predict_rt_impl(Ctx& cx, const SageRtInput& in, SageRtOutput& out) {
     RS_TRY(hipStreamSynchronize(cx.stream));
     if (out.alignments) std::copy(al.begin(), al.end(), out.alignments);
     float ms = 0.0f;
-    RS_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    RS_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
     out.device_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return true;
 }
 
