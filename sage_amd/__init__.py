@@ -4,7 +4,8 @@ The package holds only what that path needs: csrc/ (HIP kernels, the C ABI of in
 index builder) and a thin host-side mirror of the reference's Scorer / IndexedDatabase interface (api.py).
 """
 from .api import (DatabaseParameters, DeviceBatch, DeviceDatabase, IndexedDatabase, ProcessedSpectrum, RawSpectrum,
-                  Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor, Tolerance, device_count)
+                  Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor, Tolerance, device_count, predict_rt, rescore)
 
 __all__ = ["DatabaseParameters", "DeviceBatch", "DeviceDatabase", "IndexedDatabase", "ProcessedSpectrum",
-           "RawSpectrum", "Scorer", "ScorerParams", "SpectrumBatch", "SpectrumProcessor", "Tolerance", "device_count"]
+           "RawSpectrum", "Scorer", "ScorerParams", "SpectrumBatch", "SpectrumProcessor", "Tolerance", "device_count",
+           "predict_rt", "rescore"]
