@@ -386,6 +386,29 @@ int sage_hip_predict_rt(int device, const SageRtInput* in, SageRtOutput* out);
 int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint64_t* seq_off,
                                      uint8_t* seq, float* monoisotopic);
 
+/* ---- writers (host): results.sage.tsv / results.sage.pin, byte for byte as sage-cli/src/runner.rs:687-780, :830-905,
+ * :938-1135 format them (itoa integers, ryu floats).  Arrays of SagePostColumns may be NULL: the Feature defaults of
+ * scoring.rs:576-592 are written (aligned_rt = rt, predicted_* 0.0, delta_*_model 0.999, discriminant 0.0, posterior_error
+ * and q-values 1.0).  protein-group columns are always the defaults. */
+typedef struct SagePostColumns {
+    const float* discriminant_score;
+    const float* posterior_error;
+    const float* spectrum_q;
+    const float* peptide_q;
+    const float* protein_q;
+    const float* aligned_rt;
+    const float* predicted_rt;
+    const float* delta_rt_model;
+    const float* predicted_ims;
+    const float* delta_ims_model;
+} SagePostColumns;
+enum { SAGE_FORMAT_TSV = 0, SAGE_FORMAT_PIN = 1 };
+/* order: [n] row order (indices into features) or NULL; psm_id, spec_ids (spectrum ids, NUL-terminated): [n], indexed like
+ * features; filenames: [n_files], indexed by SageFeature.file_id. */
+int sage_hip_write_results(const char* path, int format, const SageHostDb* db, const SageFeature* features, uint64_t n,
+                           const uint64_t* order, const uint64_t* psm_id, const char* const* filenames, uint32_t n_files,
+                           const char* const* spec_ids, const SagePostColumns* post);
+
 /* The competition keys of SageRescoreInput for `n` PSMs given their peptide indices (host work: string keys). */
 int sage_hip_hostdb_competition_keys(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key,
                                  uint32_t* n_peptide_keys, uint32_t* protein_key, uint32_t* n_protein_keys);

@@ -198,19 +198,12 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                            "q_protein": res.passing_protein, "rescore_ms": (time.time() - t0) * 1000.0,
                            "rescore_device_ms": res.device_ms}
 
-    def post_of(i):
-        if post is None:
-            return None
-        d = dict(discriminant_score=post.discriminant_score[i], posterior_error=post.posterior_error[i],
-                 spectrum_q=post.spectrum_q[i], peptide_q=post.peptide_q[i], protein_q=post.protein_q[i])
-        if rtp is not None:
-            d.update(aligned_rt=rtp.aligned_rt[i], predicted_rt=rtp.predicted_rt[i], delta_rt_model=rtp.delta_rt_model[i],
-                     predicted_ims=rtp.predicted_ims[i], delta_ims_model=rtp.delta_ims_model[i])
-        return d
-
-    rows = [output.feature_row(meta[i][0], flat[i], host, meta[i][1], meta[i][2], post_of(i)) for i in order]
+    # writers: C++ (sage_hip_write_results) — byte-identical to output.feature_row / pin_row, which tests/test_cli_io.py checks
+    filenames = [os.path.basename(p) for p in mzml_paths]
+    psm_ids = [m[0] for m in meta]
+    spec_ids = [m[2] for m in meta]
     results = os.path.join(output_directory, "results.sage.tsv")
-    output.write_features(results, rows)
+    output.write_results_native(results, "tsv", host, flat, list(order), psm_ids, filenames, spec_ids, [rtp, post])
     paths = [results]
     if sp["annotate_matches"]:
         fp = os.path.join(output_directory, "matched_fragments.sage.tsv")
@@ -218,9 +211,9 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         paths.append(fp)
     if write_pin:  # runner.rs:655-660
         pp = os.path.join(output_directory, "results.sage.pin")
-        output.write_pin(pp, [output.pin_row(meta[i][0], flat[i], host, meta[i][1], meta[i][2], post_of(i)) for i in order])
+        output.write_results_native(pp, "pin", host, flat, list(order), psm_ids, filenames, spec_ids, [rtp, post])
         paths.append(pp)
-    summary = {"version": "sage-hip 0.1 (search-and-score path of sage 0.15.0-beta.2)", "psms": len(rows),
+    summary = {"version": "sage-hip 0.1 (search-and-score path of sage 0.15.0-beta.2)", "psms": len(flat),
                "spectra_searched": n_searched, "search_ms": search_ms, "output_paths": paths, **rescore_summary}
     with open(os.path.join(output_directory, "results.json"), "w") as fh:
         json.dump(dict(cfg, output_paths=paths, summary=summary), fh, indent=2, default=str)

@@ -239,6 +239,19 @@ int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num
     if (semi_enzymatic) *semi_enzymatic = db->db.semi[i];
     return SAGE_HIP_OK;
 }
+int sage_hip_write_results(const char* path, int format, const SageHostDb* db, const SageFeature* features, uint64_t n,
+                           const uint64_t* order, const uint64_t* psm_id, const char* const* filenames, uint32_t n_files,
+                           const char* const* spec_ids, const SagePostColumns* post) {
+    if (!path || !db || (n && (!features || !psm_id || !filenames || !spec_ids)))
+        return fail(SAGE_HIP_ERR_INVALID, "sage_hip_write_results: null argument");
+    if (format != SAGE_FORMAT_TSV && format != SAGE_FORMAT_PIN) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_write_results: unknown format");
+    for (uint64_t r = 0; order && r < n; ++r)
+        if (order[r] >= n) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_write_results: order entry out of range");
+    std::string err;
+    if (!write_results(path, format, db->db, features, n, order, psm_id, filenames, n_files, spec_ids, post, err))
+        return fail(SAGE_HIP_ERR_INVALID, err);
+    return SAGE_HIP_OK;
+}
 int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint64_t* seq_off, uint8_t* seq,
                                      float* monoisotopic) {
     if (!db || (n && !peptide_idx) || !seq_off) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_hostdb_feature_peptides: null argument");

@@ -75,6 +75,11 @@ uint64_t fasta_num_targets(const std::string& fasta_text, const DbBuildConfig& c
 uint64_t prefilter_chunk_size(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t requested);
 HostDb merge_kept(const std::vector<const HostDb*>& chunks, const std::vector<const uint8_t*>& keep, const DbBuildConfig& cfg);
 
+// writers.cpp
+bool write_results(const char* path, int format, const HostDb& db, const SageFeature* f, uint64_t n, const uint64_t* order,
+                   const uint64_t* psm_id, const char* const* filenames, uint32_t n_files, const char* const* spec_ids,
+                   const SagePostColumns* post, std::string& err);
+
 // f32 residue masses, mass.rs:64-76
 float residue_mass(uint8_t aa);
 // IonSeries (ion_series.rs:36-85) for a flat peptide record; writes L-1 masses to out

@@ -172,3 +172,33 @@ def write_pin(path: str, rows: Sequence[List[str]]) -> None:
         fh.write("\t".join(PIN_HEADERS) + "\n")
         for r in rows:
             fh.write("\t".join(r) + "\n")
+
+
+def write_results_native(path: str, fmt: str, db, features, order, psm_ids, filenames, spec_ids, post=None) -> None:
+    """results.sage.tsv (fmt "tsv") / results.sage.pin (fmt "pin") through the C++ writer (sage_hip_write_results): the same
+    bytes as feature_row / pin_row + write_features / write_pin, without a Python loop per PSM.  `post`: RescoreResult-like
+    and / or RtPrediction-like objects (attributes named like SagePostColumns), or None."""
+    import ctypes as C
+
+    from . import _lib as L
+
+    f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
+    n = len(f)
+    order_a = None if order is None else np.ascontiguousarray(order, dtype=np.uint64)
+    ids = np.ascontiguousarray(psm_ids, dtype=np.uint64)
+    assert len(ids) == n and len(spec_ids) == n and (order_a is None or len(order_a) == n)
+    names = (C.c_char_p * max(len(filenames), 1))(*[s.encode() for s in filenames])
+    specs = (C.c_char_p * max(n, 1))(*[s.encode() for s in spec_ids])
+    cols = L.SagePostColumns()
+    keep = []
+    for source in (post if isinstance(post, (list, tuple)) else [post]):
+        for k, _ in L.SagePostColumns._fields_:
+            a = getattr(source, k, None) if source is not None else None
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                assert len(a) == n
+                keep.append(a)
+                setattr(cols, k, L.as_ptr(a, C.c_float))
+    L.check(L.load().sage_hip_write_results(path.encode(), {"tsv": 0, "pin": 1}[fmt], db._h, f.ctypes.data, n,
+                                            None if order_a is None else L.as_ptr(order_a, C.c_uint64), L.as_ptr(ids, C.c_uint64),
+                                            names, len(filenames), specs, C.byref(cols)))

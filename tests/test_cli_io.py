@@ -235,3 +235,51 @@ def test_cli_prefilter_flow(tmp_path, gpu_required):
     by_id = sorted(rows, key=lambda r: int(r[0]))
     assert [(r[hdr.index("peptide")], r[hdr.index("hyperscore")]) for r in by_id] == want
     assert summary["psms"] == len(want) > 100
+
+
+def test_native_writers_match_the_python_rows(tmp_path):
+    """sage_hip_write_results (C++: std::to_chars digits in ryu's layout) against output.feature_row / pin_row byte for byte —
+    random PSM records incl. awkward floats, with and without the rescoring / model columns.  CPU only."""
+    from types import SimpleNamespace
+
+    from sage_amd import _lib as L
+    from sage_amd.synthetic import synthetic_features
+    host = DatabaseParameters(enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"), static_mods={"C": 57.0215},
+                              variable_mods={"M": [15.9949]}).build(synthetic_fasta(30, seed=71), peptides_only=True)
+    n = 400
+    f, *_ = synthetic_features(n, seed=72)
+    rng = np.random.default_rng(73)
+    f["peptide_idx"] = rng.integers(0, host.n_peptides, n)
+    f["file_id"] = rng.integers(0, 2, n)
+    f["charge"] = rng.integers(1, 8, n)
+    specials = np.array([0.0, -0.0, 1e-7, 123456.789, 1e13, 9.999999e12, 1e-5, 1e-6, 0.3, 16777216.0, np.inf, -np.inf, np.nan,
+                         1.17549435e-38, 3.4028235e38, 0.001, 100.0], dtype=np.float32)
+    f["average_ppm"][:len(specials)] = specials
+    f["hyperscore"][:len(specials)] = specials.astype(np.float64) * 1.000000001
+    f["poisson"][:8] = [-1e-300, -5e-324, -1e16, -1.5e17, -0.1, -1e-5, -9.99999e-6, -123456789012345680.0]
+    f["delta_mass"][:4] = [-3.5, 0.0, 1e-8, 250.25]
+    spec_ids = [f"controllerType=0 controllerNumber=1 scan={1000 + i}" if i % 3 else f"index={i}" for i in range(n)]
+    psm_ids = np.arange(1, n + 1)
+    order = rng.permutation(n)
+    filenames = ["a.mzML", "b.mzML"]
+    post = SimpleNamespace(discriminant_score=rng.normal(0, 3, n).astype(np.float32), posterior_error=-rng.gamma(2, 2, n).astype(np.float32),
+                           spectrum_q=rng.uniform(0, 1, n).astype(np.float32), peptide_q=rng.uniform(0, 1, n).astype(np.float32),
+                           protein_q=rng.uniform(0, 1, n).astype(np.float32))
+    rtp = SimpleNamespace(aligned_rt=rng.uniform(0, 1, n).astype(np.float32), predicted_rt=rng.uniform(0, 1, n).astype(np.float32),
+                          delta_rt_model=np.abs(rng.normal(0, 0.3, n)).astype(np.float32), predicted_ims=rng.uniform(0, 2, n).astype(np.float32),
+                          delta_ims_model=np.abs(rng.normal(0, 0.1, n)).astype(np.float32), spectrum_q=np.zeros(n, np.float32))
+    rtp.delta_rt_model[:3] = [0.0, 2.5, 0.0005]  # the pin column clamps to [0.001, 1.0] before the square root
+    for with_post in (True, False):
+        def post_of(i):
+            if not with_post:
+                return None
+            d = {k: getattr(post, k)[i] for k in ("discriminant_score", "posterior_error", "spectrum_q", "peptide_q", "protein_q")}
+            d.update({k: getattr(rtp, k)[i] for k in ("aligned_rt", "predicted_rt", "delta_rt_model", "predicted_ims", "delta_ims_model")})
+            return d
+        for fmt, row_fn, header in (("tsv", output.feature_row, output.HEADERS), ("pin", output.pin_row, output.PIN_HEADERS)):
+            p = str(tmp_path / f"native_{fmt}_{with_post}.txt")
+            output.write_results_native(p, fmt, host, f, order, psm_ids, filenames, spec_ids, [rtp, post] if with_post else None)
+            want = ["\t".join(header)] + ["\t".join(row_fn(int(psm_ids[i]), f[i], host, filenames[int(f["file_id"][i])], spec_ids[i], post_of(i)))
+                                          for i in order]
+            got = open(p).read().split("\n")
+            assert got[-1] == "" and got[:-1] == want, next((a, b) for a, b in zip(got, want) if a != b)
