@@ -386,6 +386,15 @@ int sage_hip_predict_rt(int device, const SageRtInput* in, SageRtOutput* out);
 int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* peptide_idx, uint64_t n, uint64_t* seq_off,
                                      uint8_t* seq, float* monoisotopic);
 
+/* ---- mzML input (host; sage-cloudpath/src/mzml.rs:109-403 MzMLReader::with_file_id_and_level_filter(..).parse): the MSn
+ * spectra of one file as a SageRawBatch whose arrays the handle owns, ready for sage_hip_batch_process_upload.  ms_level < 0
+ * keeps every level.  spectrum ids: sage_hip_mzml_spectrum_id. */
+typedef struct SageMzml SageMzml;
+int sage_hip_mzml_read(const char* path, uint32_t file_id, int ms_level, SageMzml** out);
+int sage_hip_mzml_view(const SageMzml* run, SageRawBatch* out);
+const char* sage_hip_mzml_spectrum_id(const SageMzml* run, uint64_t i);
+void sage_hip_mzml_free(SageMzml* run);
+
 /* ---- writers (host): results.sage.tsv / results.sage.pin, byte for byte as sage-cli/src/runner.rs:687-780, :830-905,
  * :938-1135 format them (itoa integers, ryu floats).  Arrays of SagePostColumns may be NULL: the Feature defaults of
  * scoring.rs:576-592 are written (aligned_rt = rt, predicted_* 0.0, delta_*_model 0.999, discriminant 0.0, posterior_error

@@ -473,6 +473,32 @@ class RawBatch:
         self.inverse_ion_mobility = f32([nan if s.inverse_ion_mobility is None else s.inverse_ion_mobility for s in spectra])
         self.file_id = np.ascontiguousarray([s.file_id for s in spectra], dtype=np.uint32)
 
+    @classmethod
+    def from_arrays(cls, ids, peak_off, mz, intensities, precursor_mz, precursor_charge, isolation_lo, isolation_hi,
+                    scan_start_time, inverse_ion_mobility, file_id) -> "RawBatch":
+        """Adopt SoA arrays (NaN == None for the optional floats, 0 == unknown charge): what the C++ mzML reader returns."""
+        b = cls.__new__(cls)
+        b.n = len(precursor_mz)
+        b.ids = list(ids)
+        b.peak_off = np.ascontiguousarray(peak_off, dtype=np.uint64)
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        b.mz, b.intensities = f32(mz), f32(intensities)
+        b.precursor_mz = f32(precursor_mz)
+        b.precursor_charge = np.ascontiguousarray(precursor_charge, dtype=np.uint8)
+        b.isolation_lo, b.isolation_hi = f32(isolation_lo), f32(isolation_hi)
+        b.scan_start_time, b.inverse_ion_mobility = f32(scan_start_time), f32(inverse_ion_mobility)
+        b.file_id = np.ascontiguousarray(file_id, dtype=np.uint32)
+        assert len(b.peak_off) == b.n + 1 and len(b.mz) == len(b.intensities) == int(b.peak_off[-1])
+        return b
+
+    def spectrum(self, i: int) -> RawSpectrum:
+        lo, hi = int(self.peak_off[i]), int(self.peak_off[i + 1])
+        iso = None if np.isnan(self.isolation_lo[i]) else (float(self.isolation_lo[i]), float(self.isolation_hi[i]))
+        ims = None if np.isnan(self.inverse_ion_mobility[i]) else float(self.inverse_ion_mobility[i])
+        return RawSpectrum(self.mz[lo:hi], self.intensities[lo:hi], float(self.precursor_mz[i]),
+                           int(self.precursor_charge[i]) or None, iso, float(self.scan_start_time[i]), ims, int(self.file_id[i]),
+                           self.ids[i])
+
     def to_c(self):
         b = L.SageRawBatch()
         b.n_spectra = self.n

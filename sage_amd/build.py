@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("SAGE_HIP_LIB") or os.path.join(HERE, "libsage_hip.so")  # (override: kernel experiments)
-SOURCES = ["kernels.hip", "process.hip", "index_build.hip", "rescore.hip", "capi.hip", "host_db.cpp", "writers.cpp"]
+SOURCES = ["kernels.hip", "process.hip", "index_build.hip", "rescore.hip", "capi.hip", "host_db.cpp", "writers.cpp", "mzml_reader.cpp"]
 HEADERS = ["core.h", "device_types.h", "host_db.hpp", os.path.join("..", "..", "include", "sage_hip.h")]
 ARCH = "gfx950"
 
@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread"]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

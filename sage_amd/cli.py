@@ -23,7 +23,7 @@ from . import output
 from ._lib import FEATURE_DTYPE as L_FEATURE_DTYPE
 from .api import (DatabaseParameters, DeviceDatabase, RawBatch, Scorer, ScorerParams, SpectrumBatch, SpectrumProcessor,
                   Tolerance, device_count, predict_rt, rescore)
-from .mzml import read_mzml
+from .mzml import read_mzml_native
 
 
 def search_parameters(cfg: dict) -> dict:
@@ -57,23 +57,23 @@ def scorer_params(sp: dict) -> ScorerParams:
 
 
 def _upload(scorer, processor, raw, sp, host_preprocess):
-    """read spectra -> resident ProcessedSpectrum batch (+ spectrum ids); None when nothing is left to search"""
+    """spectra of one file (RawBatch) -> resident ProcessedSpectrum batch (+ spectrum ids); None when nothing is left to search"""
     if host_preprocess:  # SpectrumProcessor::process on the host (C++), spectra below min_peaks dropped (runner.rs:313)
-        processed = [processor.process(r) for r in raw]
+        processed = [processor.process(raw.spectrum(i)) for i in range(raw.n)]
         processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]
         if not processed:
             return None, []
         return scorer.upload(SpectrumBatch.from_spectra(processed)), [p.id for p in processed]
     # ... or on the device: raw peaks in, PSMs out; spectra below min_peaks stay in the batch with zero peaks
-    dbatch, _ = scorer.process_upload(RawBatch(raw), sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
-    return dbatch, [r.id for r in raw]
+    dbatch, _ = scorer.process_upload(raw, sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
+    return dbatch, list(raw.ids)
 
 
 def prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, processor, device, host_preprocess, log):
     """Runner::prefilter_peptides (runner.rs:143-238): search every spectrum against the FASTA one chunk of target proteins
     at a time with Scorer::quick_score, keep the peptides some spectrum picked, merge the survivors (reorder_peptides) and
     leave build_from_peptides to the device.  The scorer of this pass reports one PSM more than the final one (runner.rs:190)."""
-    raws = [read_mzml(path, file_id=file_id, ms_level=2) for file_id, path in enumerate(mzml_paths)]
+    raws = [read_mzml_native(path, file_id=file_id, ms_level=2) for file_id, path in enumerate(mzml_paths)]
     pass_params = scorer_params(dict(sp, report_psms=sp["report_psms"] + 1))
     chunks, keeps = [], []
     for chunk_id, first in enumerate(range(0, n_targets, chunk)):
@@ -85,7 +85,7 @@ def prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, proces
             scorer = Scorer(DeviceDatabase(cdb, device), pass_params)
             n = 0
             for raw in raws:
-                if not raw:
+                if raw.n == 0:
                     continue
                 dbatch, _ = _upload(scorer, processor, raw, sp, host_preprocess)
                 if dbatch is None:
@@ -132,9 +132,9 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     search_ms = 0.0
     for file_id, path in enumerate(mzml_paths):
         t0 = time.time()
-        raw = read_mzml(path, file_id=file_id, ms_level=2)
+        raw = read_mzml_native(path, file_id=file_id, ms_level=2)  # csrc/mzml_reader.cpp
         log(f"- file IO: {int((time.time() - t0) * 1000):8d} ms")
-        if not raw:
+        if raw.n == 0:
             continue
         t0 = time.time()
         dbatch, ids = _upload(scorer, processor, raw, sp, host_preprocess)

@@ -239,6 +239,42 @@ int sage_hip_hostdb_peptide_info(const SageHostDb* db, uint64_t i, uint32_t* num
     if (semi_enzymatic) *semi_enzymatic = db->db.semi[i];
     return SAGE_HIP_OK;
 }
+struct SageMzml {
+    MzmlRun run;
+};
+int sage_hip_mzml_read(const char* path, uint32_t file_id, int ms_level, SageMzml** out) {
+    if (!path || !out) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_mzml_read: null argument");
+    auto h = std::make_unique<SageMzml>();
+    std::string err;
+    try {
+        if (!read_mzml(path, file_id, ms_level, h->run, err)) return fail(SAGE_HIP_ERR_INVALID, err);
+    } catch (const std::exception& e) {
+        return fail(SAGE_HIP_ERR_INVALID, e.what());
+    }
+    *out = h.release();
+    return SAGE_HIP_OK;
+}
+int sage_hip_mzml_view(const SageMzml* run, SageRawBatch* out) {
+    if (!run || !out) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_mzml_view: null argument");
+    const MzmlRun& r = run->run;
+    out->n_spectra = (uint32_t)r.n();
+    out->peak_off = r.peak_off.data();
+    out->mz = r.mz.data();
+    out->intensities = r.intensities.data();
+    out->precursor_mz = r.precursor_mz.data();
+    out->precursor_charge = r.precursor_charge.data();
+    out->isolation_lo = r.isolation_lo.data();
+    out->isolation_hi = r.isolation_hi.data();
+    out->scan_start_time = r.scan_start_time.data();
+    out->inverse_ion_mobility = r.inverse_ion_mobility.data();
+    out->file_id = r.file_id.data();
+    return SAGE_HIP_OK;
+}
+const char* sage_hip_mzml_spectrum_id(const SageMzml* run, uint64_t i) {
+    if (!run || i >= run->run.n()) return nullptr;
+    return run->run.ids.data() + run->run.id_off[i];
+}
+void sage_hip_mzml_free(SageMzml* run) { delete run; }
 int sage_hip_write_results(const char* path, int format, const SageHostDb* db, const SageFeature* features, uint64_t n,
                            const uint64_t* order, const uint64_t* psm_id, const char* const* filenames, uint32_t n_files,
                            const char* const* spec_ids, const SagePostColumns* post) {

@@ -75,6 +75,19 @@ uint64_t fasta_num_targets(const std::string& fasta_text, const DbBuildConfig& c
 uint64_t prefilter_chunk_size(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t requested);
 HostDb merge_kept(const std::vector<const HostDb*>& chunks, const std::vector<const uint8_t*>& keep, const DbBuildConfig& cfg);
 
+// mzml_reader.cpp: the MSn spectra of one mzML file as flat arrays (the layout of SageRawBatch) + their ids
+struct MzmlRun {
+    std::vector<uint64_t> peak_off;  // [n + 1]
+    std::vector<float> mz, intensities;
+    std::vector<float> precursor_mz, isolation_lo, isolation_hi, scan_start_time, inverse_ion_mobility;  // NaN == None
+    std::vector<uint8_t> precursor_charge;                                                                 // 0 == None
+    std::vector<uint32_t> file_id;
+    std::string ids;                 // NUL-separated spectrum ids
+    std::vector<uint64_t> id_off;    // [n + 1] into ids
+    uint64_t n() const { return precursor_mz.size(); }
+};
+bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, std::string& err);
+
 // writers.cpp
 bool write_results(const char* path, int format, const HostDb& db, const SageFeature* f, uint64_t n, const uint64_t* order,
                    const uint64_t* psm_id, const char* const* filenames, uint32_t n_files, const char* const* spec_ids,

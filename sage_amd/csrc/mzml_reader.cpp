@@ -1,0 +1,383 @@
+// mzml_reader.cpp — mzML input on the host, in C++.
+//
+// Follows the reference's streaming reader, crates/sage-cloudpath/src/mzml.rs:109-403, for the fields the path uses — the
+// same state machine over tag names (spectrum / scan / precursor / selectedIon / binaryDataArray / binary, :153-158, :349-364)
+// and the same rules sage_amd/mzml.py implements in Python (kept as the cross-check, tests/test_cli_io.py):
+//   * binary arrays: base64, optional zlib (MS:1000574), 32- or 64-bit floats (MS:1000521 / MS:1000523), 64-bit values narrowed
+//     to f32 element-wise (:318-326);
+//   * numeric cvParam values parsed straight to f32 (`str::parse::<f32>()` and strtof are both correctly rounded);
+//   * selected ion m/z (MS:1000744, ignored when 0), charge (MS:1000041); isolation window target as the fallback precursor m/z
+//     (MS:1000827, :221-229); isolation_window = Da(-lower, +upper) when both offsets are present (:354-357); a precursor is
+//     kept only if its m/z != 0 (:353); the path reads precursors.first();
+//   * scan start time in minutes (seconds / 60 in f32, :262-272); inverse reduced ion mobility (MS:1002815);
+//   * a spectrum whose total ion current cvParam is 0 is dropped (:205-213); the ms-level filter drops other levels.
+// No XML library: mzML's spectrum blocks are flat enough for a tag scanner (attributes in single or double quotes, the five
+// predefined entities in attribute values, namespace prefixes stripped).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "host_db.hpp"
+
+namespace sagehip {
+
+namespace {
+
+struct Tag {
+    std::string_view name;     // local name
+    std::string_view attrs;    // raw attribute text
+    bool closing = false, self_closing = false;
+    const char* end = nullptr; // one past '>'
+};
+
+// next tag at or after p (comments, processing instructions and CDATA skipped); false at end of input
+bool next_tag(const char*& p, const char* e, Tag& t) {
+    for (;;) {
+        const char* lt = (const char*)std::memchr(p, '<', (size_t)(e - p));
+        if (!lt) return false;
+        if (e - lt >= 4 && !std::memcmp(lt, "<!--", 4)) {
+            const char* c = (const char*)memmem(lt, (size_t)(e - lt), "-->", 3);
+            if (!c) return false;
+            p = c + 3;
+            continue;
+        }
+        if (e - lt >= 2 && (lt[1] == '?' || lt[1] == '!')) {
+            const char* c = (const char*)std::memchr(lt, '>', (size_t)(e - lt));
+            if (!c) return false;
+            p = c + 1;
+            continue;
+        }
+        const char* q = lt + 1;
+        t.closing = q < e && *q == '/';
+        if (t.closing) ++q;
+        const char* n0 = q;
+        while (q < e && *q != '>' && *q != '/' && !isspace((unsigned char)*q)) ++q;
+        std::string_view name(n0, (size_t)(q - n0));
+        const size_t colon = name.rfind(':');
+        t.name = colon == std::string_view::npos ? name : name.substr(colon + 1);
+        const char* a0 = q;
+        char quote = 0;
+        while (q < e && (quote || *q != '>')) {  // '>' inside a quoted attribute value does not end the tag
+            if (quote) {
+                if (*q == quote) quote = 0;
+            } else if (*q == '"' || *q == '\'') {
+                quote = *q;
+            }
+            ++q;
+        }
+        if (q >= e) return false;
+        t.self_closing = q > a0 && q[-1] == '/';
+        t.attrs = std::string_view(a0, (size_t)(q - a0 - (t.self_closing ? 1 : 0)));
+        t.end = q + 1;
+        p = t.end;
+        return true;
+    }
+}
+
+// value of attribute `key` (exact name match), raw; false when absent
+bool attr(std::string_view attrs, std::string_view key, std::string_view& out) {
+    size_t i = 0;
+    const size_t n = attrs.size();
+    while (i < n) {
+        while (i < n && isspace((unsigned char)attrs[i])) ++i;
+        const size_t k0 = i;
+        while (i < n && attrs[i] != '=' && !isspace((unsigned char)attrs[i])) ++i;
+        const std::string_view k = attrs.substr(k0, i - k0);
+        while (i < n && isspace((unsigned char)attrs[i])) ++i;
+        if (i >= n || attrs[i] != '=') return false;
+        ++i;
+        while (i < n && isspace((unsigned char)attrs[i])) ++i;
+        if (i >= n || (attrs[i] != '"' && attrs[i] != '\'')) return false;
+        const char quote = attrs[i++];
+        const size_t v0 = i;
+        while (i < n && attrs[i] != quote) ++i;
+        if (i >= n) return false;
+        if (k == key) {
+            out = attrs.substr(v0, i - v0);
+            return true;
+        }
+        ++i;
+    }
+    return false;
+}
+
+std::string unescape(std::string_view s) {
+    std::string o;
+    o.reserve(s.size());
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (s[i] == '&') {
+            static const struct { const char* ent; char ch; } kEnt[] = {{"&amp;", '&'}, {"&lt;", '<'}, {"&gt;", '>'}, {"&quot;", '"'}, {"&apos;", '\''}};
+            bool hit = false;
+            for (auto& en : kEnt) {
+                const size_t l = std::strlen(en.ent);
+                if (s.compare(i, l, en.ent) == 0) {
+                    o += en.ch;
+                    i += l - 1;
+                    hit = true;
+                    break;
+                }
+            }
+            if (hit) continue;
+        }
+        o += s[i];
+    }
+    return o;
+}
+
+float parse_f32(std::string_view v) {  // str::parse::<f32>(): one correct rounding; "" -> 0 (mzml.py: _f32)
+    if (v.empty()) return 0.0f;
+    std::string s(v);
+    return std::strtof(s.c_str(), nullptr);
+}
+
+void base64_decode(std::string_view in, std::vector<uint8_t>& out) {
+    static int8_t lut[256];
+    static bool init = false;
+    if (!init) {
+        std::memset(lut, -1, sizeof lut);
+        const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; ++i) lut[(unsigned char)al[i]] = (int8_t)i;
+        init = true;
+    }
+    out.clear();
+    out.reserve(in.size() * 3 / 4);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (unsigned char c : in) {
+        if (c == '=') break;
+        const int v = lut[c];
+        if (v < 0) continue;  // whitespace / foreign characters are skipped, like a lenient decoder
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((uint8_t)(acc >> bits));
+        }
+    }
+}
+
+bool inflate_all(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+    z_stream zs{};
+    if (inflateInit(&zs) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(in.data());
+    zs.avail_in = (uInt)in.size();
+    out.resize(std::max<size_t>(in.size() * 4, 1024));
+    size_t have = 0;
+    int rc;
+    do {
+        if (have == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + have;
+        zs.avail_out = (uInt)(out.size() - have);
+        rc = inflate(&zs, Z_NO_FLUSH);
+        have = out.size() - zs.avail_out;
+    } while (rc == Z_OK);
+    inflateEnd(&zs);
+    out.resize(have);
+    return rc == Z_STREAM_END;
+}
+
+}  // namespace
+
+// MzMLReader::with_file_id_and_level_filter(file_id, ms_level).parse(..): ms_level < 0 keeps every level
+bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, std::string& err) {
+    FILE* fh = std::fopen(path, "rb");
+    if (!fh) {
+        err = std::string("cannot open ") + path;
+        return false;
+    }
+    std::fseek(fh, 0, SEEK_END);
+    const long size = std::ftell(fh);
+    std::fseek(fh, 0, SEEK_SET);
+    std::string text((size_t)std::max<long>(size, 0), '\0');
+    const size_t got = size > 0 ? std::fread(&text[0], 1, (size_t)size, fh) : 0;
+    std::fclose(fh);
+    if ((long)got != size) {
+        err = std::string("short read of ") + path;
+        return false;
+    }
+    run = MzmlRun{};
+    run.peak_off.push_back(0);
+    run.id_off.push_back(0);
+    const char *p = text.data(), *e = text.data() + text.size();
+    Tag t;
+    std::vector<uint8_t> raw, plain;
+    while (next_tag(p, e, t)) {
+        if (t.closing || t.name != "spectrum") continue;
+        // ---- one <spectrum> ... </spectrum> block ----
+        std::string_view idv;
+        std::string id = attr(t.attrs, "id", idv) ? unescape(idv) : std::string();
+        bool have_level = false, tic_zero = false, have_precursor = false, in_precursor = false, in_scan = false, in_bda = false;
+        int level = 0, depth = 1;
+        std::vector<float> mz, inten;
+        float scan_start = 0.0f, prec_mz = 0.0f, prec_ims = NAN, iso_lo = NAN, iso_hi = NAN;
+        uint8_t prec_charge = 0;
+        float p_mz = 0.0f, p_lo = NAN, p_hi = NAN;  // the precursor being read
+        bool p_has_lo = false, p_has_hi = false, have_lo = false, have_hi = false;
+        uint8_t p_z = 0;
+        int precursor_depth = 0, scan_depth = 0, bda_depth = 0;
+        bool bda_f32 = false, bda_zlib = false;
+        int bda_kind = 0;  // 1 m/z, 2 intensity
+        std::string_view bda_text;
+        bool closed = t.self_closing;
+        while (!closed && next_tag(p, e, t)) {
+            if (t.closing) {
+                if (t.name == "spectrum") {
+                    closed = true;
+                    break;
+                }
+                if (in_precursor && t.name == "precursor" && depth == precursor_depth) {
+                    in_precursor = false;
+                    if (p_mz != 0.0f) {  // :353
+                        have_precursor = true;
+                        prec_mz = p_mz;
+                        prec_charge = p_z;
+                        iso_lo = p_lo;
+                        iso_hi = p_hi;
+                        have_lo = p_has_lo;
+                        have_hi = p_has_hi;
+                    }
+                } else if (in_scan && t.name == "scan" && depth == scan_depth) {
+                    in_scan = false;
+                } else if (in_bda && t.name == "binaryDataArray" && depth == bda_depth) {
+                    in_bda = false;
+                    if (!bda_text.empty() && bda_kind) {
+                        base64_decode(bda_text, raw);
+                        const std::vector<uint8_t>* bytes = &raw;
+                        if (bda_zlib) {
+                            if (!inflate_all(raw, plain)) {
+                                err = "malformed mzML: zlib stream of spectrum " + id;
+                                return false;
+                            }
+                            bytes = &plain;
+                        }
+                        std::vector<float>& dst = bda_kind == 1 ? mz : inten;
+                        if (bda_f32) {
+                            dst.resize(bytes->size() / 4);
+                            std::memcpy(dst.data(), bytes->data(), dst.size() * 4);
+                        } else {
+                            dst.resize(bytes->size() / 8);
+                            for (size_t i = 0; i < dst.size(); ++i) {
+                                double d;
+                                std::memcpy(&d, bytes->data() + 8 * i, 8);
+                                dst[i] = (float)d;
+                            }
+                        }
+                    }
+                }
+                --depth;
+                continue;
+            }
+            // opening (or empty) tag at `depth` + 1
+            const int child_depth = depth + 1;
+            if (t.name == "cvParam") {
+                std::string_view acc, val, unit;
+                if (attr(t.attrs, "accession", acc)) {
+                    const bool has_val = attr(t.attrs, "value", val);
+                    if (!has_val) val = std::string_view();
+                    if (in_precursor) {  // every cvParam below <precursor>
+                        if (acc == "MS:1000827") {
+                            if (p_mz == 0.0f) p_mz = parse_f32(val);
+                        } else if (acc == "MS:1000828") {
+                            p_lo = parse_f32(val);
+                            p_has_lo = true;
+                        } else if (acc == "MS:1000829") {
+                            p_hi = parse_f32(val);
+                            p_has_hi = true;
+                        } else if (acc == "MS:1000041") {
+                            p_z = (uint8_t)std::atoi(std::string(val).c_str());
+                        } else if (acc == "MS:1000744") {
+                            const float v = parse_f32(val);
+                            if (v != 0.0f) p_mz = v;
+                        } else if (acc == "MS:1002815") {
+                            prec_ims = parse_f32(val);
+                        }
+                    } else if (in_scan && child_depth == scan_depth + 1) {
+                        if (acc == "MS:1000016") {
+                            float v = parse_f32(val);
+                            if (attr(t.attrs, "unitAccession", unit) && unit == "UO:0000010") v = v / 60.0f;
+                            else if (!(unit == "UO:0000031")) {
+                                err = "malformed mzML: scan start time unit of spectrum " + id;
+                                return false;
+                            }
+                            scan_start = v;
+                        } else if (acc == "MS:1002815") {
+                            prec_ims = parse_f32(val);
+                        }
+                    } else if (in_bda && child_depth == bda_depth + 1) {
+                        if (acc == "MS:1000514") bda_kind = 1;
+                        else if (acc == "MS:1000515" && bda_kind != 1) bda_kind = 2;
+                        else if (acc == "MS:1000574") bda_zlib = true;
+                        else if (acc == "MS:1000521") bda_f32 = true;
+                    } else if (child_depth == 2) {  // direct children of <spectrum>
+                        if (acc == "MS:1000511") {
+                            level = std::atoi(std::string(val).c_str());
+                            have_level = true;
+                        } else if (acc == "MS:1000285") {
+                            tic_zero = parse_f32(val) == 0.0f;
+                        }
+                    }
+                }
+            } else if (t.name == "scan" && !in_scan && !in_precursor) {
+                if (!t.self_closing) {
+                    in_scan = true;
+                    scan_depth = child_depth;
+                }
+            } else if (t.name == "precursor" && !in_precursor && !have_precursor) {
+                if (!t.self_closing) {
+                    in_precursor = true;
+                    precursor_depth = child_depth;
+                    p_mz = 0.0f;
+                    p_z = 0;
+                    p_lo = p_hi = NAN;
+                    p_has_lo = p_has_hi = false;
+                }
+            } else if (t.name == "binaryDataArray" && !in_bda) {
+                if (!t.self_closing) {
+                    in_bda = true;
+                    bda_depth = child_depth;
+                    bda_f32 = bda_zlib = false;
+                    bda_kind = 0;
+                    bda_text = std::string_view();
+                }
+            } else if (t.name == "binary" && in_bda && child_depth == bda_depth + 1 && !t.self_closing) {
+                const char* lt = (const char*)std::memchr(t.end, '<', (size_t)(e - t.end));
+                if (!lt) {
+                    err = "malformed mzML: unterminated <binary>";
+                    return false;
+                }
+                bda_text = std::string_view(t.end, (size_t)(lt - t.end));
+            }
+            if (!t.self_closing) ++depth;
+        }
+        if (!closed) {
+            err = "malformed mzML: unterminated <spectrum>";
+            return false;
+        }
+        if (tic_zero || (ms_level >= 0 && (!have_level || level != ms_level))) continue;
+        run.mz.insert(run.mz.end(), mz.begin(), mz.end());
+        // (a spectrum with arrays of different lengths is malformed; keep the peak table rectangular)
+        inten.resize(mz.size(), 0.0f);
+        run.intensities.insert(run.intensities.end(), inten.begin(), inten.end());
+        run.peak_off.push_back(run.mz.size());
+        run.precursor_mz.push_back(prec_mz);
+        run.precursor_charge.push_back(prec_charge);
+        const bool iso = have_precursor && have_lo && have_hi;
+        run.isolation_lo.push_back(iso ? -iso_lo : NAN);
+        run.isolation_hi.push_back(iso ? iso_hi : NAN);
+        run.scan_start_time.push_back(scan_start);
+        run.inverse_ion_mobility.push_back(prec_ims);
+        run.file_id.push_back(file_id);
+        run.ids += id;
+        run.ids += '\0';
+        run.id_off.push_back(run.ids.size());
+    }
+    return true;
+}
+
+}  // namespace sagehip

@@ -142,6 +142,38 @@ def read_mzml(path: str, file_id: int = 0, ms_level: Optional[int] = 2) -> List[
     return out
 
 
+def read_mzml_native(path: str, file_id: int = 0, ms_level: Optional[int] = 2):
+    """The same reader in C++ (csrc/mzml_reader.cpp, sage_hip_mzml_read): one call per file, arrays straight into a RawBatch
+    for Scorer.process_upload — no Python object per spectrum."""
+    import ctypes as C
+
+    from . import _lib as L
+    from .api import RawBatch
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.sage_hip_mzml_read(path.encode(), file_id, -1 if ms_level is None else int(ms_level), C.byref(h)))
+    try:
+        v = L.SageRawBatch()
+        L.check(lib.sage_hip_mzml_view(h, C.byref(v)))
+        n = int(v.n_spectra)
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+        peak_off = arr(v.peak_off, n + 1, np.uint64)
+        npk = int(peak_off[-1])
+        ids = [lib.sage_hip_mzml_spectrum_id(h, i).decode() for i in range(n)]
+        return RawBatch.from_arrays(ids, peak_off, arr(v.mz, npk, np.float32), arr(v.intensities, npk, np.float32),
+                                    arr(v.precursor_mz, n, np.float32), arr(v.precursor_charge, n, np.uint8),
+                                    arr(v.isolation_lo, n, np.float32), arr(v.isolation_hi, n, np.float32),
+                                    arr(v.scan_start_time, n, np.float32), arr(v.inverse_ion_mobility, n, np.float32),
+                                    arr(v.file_id, n, np.uint32))
+    finally:
+        lib.sage_hip_mzml_free(h)
+
+
 def _b64(arr: np.ndarray) -> str:
     return base64.b64encode(zlib.compress(np.ascontiguousarray(arr, dtype="<f4").tobytes())).decode()
 

@@ -283,3 +283,103 @@ def test_native_writers_match_the_python_rows(tmp_path):
                                           for i in order]
             got = open(p).read().split("\n")
             assert got[-1] == "" and got[:-1] == want, next((a, b) for a, b in zip(got, want) if a != b)
+
+
+def _assert_same_run(batch, spectra, context):
+    """RawBatch from the C++ reader vs the list of RawSpectrum from the Python reader"""
+    assert batch.n == len(spectra), context
+    for i, s in enumerate(spectra):
+        g = batch.spectrum(i)
+        assert g.id == s.id, (context, i)
+        assert np.array_equal(np.asarray(g.mz, np.float32).view(np.uint32), np.asarray(s.mz, np.float32).view(np.uint32)), (context, i)
+        assert np.array_equal(np.asarray(g.intensity, np.float32).view(np.uint32), np.asarray(s.intensity, np.float32).view(np.uint32))
+        assert np.float32(g.precursor_mz) == np.float32(s.precursor_mz) and (g.precursor_charge or None) == (s.precursor_charge or None)
+        assert np.float32(g.scan_start_time) == np.float32(s.scan_start_time), (context, i, g.scan_start_time, s.scan_start_time)
+        assert (g.isolation_window is None) == (s.isolation_window is None), (context, i)
+        if s.isolation_window is not None:
+            assert tuple(np.float32(x) for x in g.isolation_window) == tuple(np.float32(x) for x in s.isolation_window)
+        assert (g.inverse_ion_mobility is None) == (s.inverse_ion_mobility is None)
+        if s.inverse_ion_mobility is not None:
+            assert np.float32(g.inverse_ion_mobility) == np.float32(s.inverse_ion_mobility)
+        assert g.file_id == s.file_id
+
+
+def test_native_mzml_reader_matches_the_python_reader(tmp_path):
+    """csrc/mzml_reader.cpp against sage_amd/mzml.py (itself checked against the reference's fixture): synthetic files, a
+    hand-written file with the awkward cases, and the reference's own mzML when the checkout is present.  CPU only."""
+    import base64
+    import zlib
+    from sage_amd.mzml import read_mzml_native
+    d, raw = c1_raw()
+    host = DatabaseParameters(static_mods={"C": 57.0215}).build(synthetic_fasta(40, seed=81))
+    spectra = synthetic_spectra(host, 50, seed=82, )
+    spectra[3] = RawSpectrum(spectra[3].mz, spectra[3].intensity, spectra[3].precursor_mz, None, (1.5, 2.25), 12.5, None, 0, "scan=4")
+    p = str(tmp_path / "syn.mzML")
+    write_mzml(p, spectra + [raw])
+    _assert_same_run(read_mzml_native(p, 3), read_mzml(p, 3), "synthetic")
+
+    def arr64(a):
+        return base64.b64encode(np.asarray(a, dtype="<f8").tobytes()).decode()
+
+    def arr32z(a):
+        s = base64.b64encode(zlib.compress(np.asarray(a, dtype="<f4").tobytes())).decode()
+        return s[:20] + "\n   " + s[20:]  # line break inside the base64 text
+
+    def spectrum(idx, sid, level, body, mzs, ints, tic=None):
+        tic_cv = f'<cvParam cvRef="MS" accession="MS:1000285" name="total ion current" value="{tic}"/>' if tic is not None else ""
+        return (f"<spectrum index='{idx}' id=\"{sid}\" defaultArrayLength='{len(mzs)}'>"
+                f'<cvParam cvRef="MS" accession="MS:1000511" name="ms level" value="{level}"/>{tic_cv}{body}'
+                '<binaryDataArrayList count="2"><binaryDataArray encodedLength="0">'
+                '<cvParam cvRef="MS" accession="MS:1000523" name="64-bit float"/><cvParam cvRef="MS" accession="MS:1000576" name="no compression"/>'
+                f'<cvParam cvRef="MS" accession="MS:1000514" name="m/z array"/><binary>{arr64(mzs)}</binary></binaryDataArray>'
+                '<binaryDataArray><cvParam cvRef="MS" accession="MS:1000521" name="32-bit float"/>'
+                '<cvParam cvRef="MS" accession="MS:1000574" name="zlib compression"/>'
+                f'<cvParam cvRef="MS" accession="MS:1000515" name="intensity array"/><binary>{arr32z(ints)}</binary></binaryDataArray>'
+                "</binaryDataArrayList></spectrum>")
+
+    scan_s = ('<scanList count="1"><scan><cvParam cvRef="MS" accession="MS:1000016" name="scan start time" value="754.321" '
+              'unitCvRef="UO" unitAccession="UO:0000010" unitName="second"/>'
+              '<cvParam cvRef="MS" accession="MS:1002815" name="inverse reduced ion mobility" value="0.987654321"/></scan></scanList>')
+    scan_m = ('<scanList count="1"><scan><cvParam cvRef="MS" accession="MS:1000016" name="scan start time" value="12.0000001" '
+              'unitCvRef="UO" unitAccession="UO:0000031" unitName="minute"/></scan></scanList>')
+    two_prec = ('<precursorList count="2"><precursor spectrumRef="x"><isolationWindow>'
+                '<cvParam cvRef="MS" accession="MS:1000827" name="isolation window target m/z" value="0"/>'
+                '</isolationWindow><selectedIonList count="1"><selectedIon>'
+                '<cvParam cvRef="MS" accession="MS:1000744" name="selected ion m/z" value="0.0"/></selectedIon></selectedIonList></precursor>'
+                '<precursor><isolationWindow>'
+                '<cvParam cvRef="MS" accession="MS:1000827" name="isolation window target m/z" value="500.123456789"/>'
+                '<cvParam cvRef="MS" accession="MS:1000828" name="isolation window lower offset" value="0.8"/>'
+                '<cvParam cvRef="MS" accession="MS:1000829" name="isolation window upper offset" value="1.2"/>'
+                '</isolationWindow><selectedIonList count="1"><selectedIon>'
+                '<cvParam cvRef="MS" accession="MS:1000744" name="selected ion m/z" value="500.2500001"/>'
+                '<cvParam cvRef="MS" accession="MS:1000041" name="charge state" value="3"/>'
+                '<cvParam cvRef="MS" accession="MS:1000042" name="peak intensity" value="1e6"/></selectedIon></selectedIonList></precursor>'
+                '</precursorList>')
+    target_only = ('<precursorList count="1"><precursor><isolationWindow>'
+                   '<cvParam cvRef="MS" accession="MS:1000827" name="isolation window target m/z" value="733.3333333"/>'
+                   '</isolationWindow></precursor></precursorList>')
+    mzs = [100.000001234, 250.5, 999.99999]
+    body = "".join([
+        spectrum(0, "ms1 scan=1", 1, scan_m, mzs, [1, 2, 3]),
+        spectrum(1, "controllerType=0 scan=2 &amp; more", 2, scan_s + two_prec, mzs, [10.5, 0.0, 3e7]),
+        spectrum(2, "scan=3", 2, scan_m + target_only, mzs[:2], [5, 6], tic="0"),       # dropped: TIC 0
+        spectrum(3, "scan=4", 2, scan_m + target_only, mzs[:2], [5, 6], tic="123.4"),
+        spectrum(4, "scan=5", 2, scan_m, [], []),                                         # no precursor, no peaks
+    ])
+    p2 = str(tmp_path / "hand.mzML")
+    open(p2, "w").write('<?xml version="1.0" encoding="utf-8"?>\n<!-- a comment with a <spectrum> inside -->\n'
+                        '<indexedmzML><mzML xmlns="http://psi.hupo.org/ms/mzml"><run id="r"><spectrumList count="5">'
+                        + body + "</spectrumList></run></mzML></indexedmzML>\n")
+    for level in (2, 1, None):
+        want = read_mzml(p2, 0, level)
+        _assert_same_run(read_mzml_native(p2, 0, level), want, f"hand level={level}")
+    ms2 = read_mzml_native(p2, 7, 2)
+    assert ms2.ids == ["controllerType=0 scan=2 & more", "scan=4", "scan=5"] and list(ms2.file_id) == [7, 7, 7]
+    assert ms2.precursor_charge[0] == 3 and np.float32(ms2.precursor_mz[0]) == np.float32(500.2500001)
+    assert np.float32(ms2.isolation_lo[0]) == np.float32(-0.8) and np.float32(ms2.scan_start_time[0]) == np.float32(754.321) / np.float32(60)
+    assert np.float32(ms2.precursor_mz[1]) == np.float32(733.3333333) and np.isnan(ms2.isolation_lo[1])
+    ref = "/root/reference/tests/LQSRPAAPPAPGPGQLTLR.mzML"
+    if os.path.exists(ref):
+        _assert_same_run(read_mzml_native(ref, 0, 2), read_mzml(ref, 0, 2), "reference fixture")
+    with pytest.raises(Exception):
+        read_mzml_native(str(tmp_path / "missing.mzML"))
