@@ -36,10 +36,10 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    objs = []
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
     common += os.environ.get("SAGE_HIP_EXTRA_FLAGS", "").split()
-    for src in SOURCES:
+
+    def compile_one(src):
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + os.environ.get("SAGE_HIP_OBJ_SUFFIX", "") + ".o")
         cmd = [hipcc(), f"--offload-arch={ARCH}", *common, "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
@@ -48,7 +48,11 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:  # translation units are independent
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)

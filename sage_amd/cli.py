@@ -151,20 +151,22 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         if sp["annotate_matches"]:
             off, arr = scorer.annotate(dbatch, feats, counts)
         name = os.path.basename(path)
-        for i in range(n_batch):
-            for r in range(int(counts[i])):
-                f = feats[i, r].copy()
-                f["file_id"] = file_id
-                feats_all.append(f)
-                meta.append((psm_id, name, ids[i]))
-                if arr is not None:
-                    s = i * params.report_psms + r
-                    frags.append(output.fragment_rows(psm_id, int(off[s]), int(off[s + 1]), arr))
-                psm_id += 1
+        # the PSMs of the file in (spectrum, rank) order — the order Scorer::score results are collected in (runner.rs:325)
+        spec_of = np.repeat(np.arange(n_batch), counts.astype(np.int64))
+        rank_of = np.arange(len(spec_of)) - np.repeat(np.cumsum(counts.astype(np.int64)) - counts, counts.astype(np.int64))
+        part = feats[spec_of, rank_of].copy()
+        part["file_id"] = file_id
+        feats_all.append(part)
+        meta += [(psm_id + j, name, ids[i]) for j, i in enumerate(spec_of.tolist())]
+        if arr is not None:
+            for j, (i, r) in enumerate(zip(spec_of.tolist(), rank_of.tolist())):
+                slot = i * params.report_psms + r
+                frags.append(output.fragment_rows(psm_id + j, int(off[slot]), int(off[slot + 1]), arr))
+        psm_id += len(part)
         dbatch.close()
     # runner.rs:536-541: spectrum_fdr (LDA or heuristic, sort, q-values), picked_peptide, picked_protein — on the device.
     # (protein grouping is outside this path: its columns keep the defaults, see output.py)
-    flat = np.array(feats_all, dtype=feats_all[0].dtype) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
+    flat = np.concatenate(feats_all) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
     post = None
     rtp = None
     order = range(len(flat))
