@@ -21,11 +21,6 @@ def _has_gpu():
         return False
 
 
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly rather than silently pass
-    pass
-
-
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
