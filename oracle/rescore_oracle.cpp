@@ -31,7 +31,30 @@
 #include <numeric>
 #include <vector>
 
+// The arithmetic contract the PRODUCT fixes for this step (deterministic ln_1p / exp, blocked summation order).  Including it
+// here does not make the checker depend on the product's results: the header is pure arithmetic, pinned against the platform
+// libm in oracle/selftest.cpp, and the reference-order mode below does not use it.
+#include "../sage_amd/csrc/detmath.h"
+
 namespace {
+
+// Two evaluation modes of the same restatement:
+//   det == 0  the reference's own order: every sum strictly left to right (`iter().sum()`), ln_1p / exp from the platform
+//             libm (what Rust's f64::ln_1p / exp call).  Kde::pdf, whose order the reference leaves to rayon, in sample order.
+//   det == 1  the order and elementary functions the device evaluates (detmath.h): sums in blocks of DET_BLOCK (identical to
+//             det == 0 for n <= DET_BLOCK), ln_1p / exp from IEEE basic operations.  The device is held to this bit for bit.
+thread_local int g_det = 0;
+
+double ln1p(double x) { return g_det ? sagedet::det_log1p(x) : std::log1p(x); }
+float ln1pf(float x) { return g_det ? sagedet::det_log1pf(x) : std::log1p(x); }
+double expd(double x) { return g_det ? sagedet::det_exp(x) : std::exp(x); }
+template <class Term>
+double sum_terms(size_t n, Term term) {
+    if (g_det) return sagedet::blocked_sum((uint64_t)n, term);
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += term(i);
+    return s;
+}
 
 struct Matrix {  // ml/matrix.rs: row-major f64
     std::vector<double> data;
@@ -136,13 +159,12 @@ struct Gauss {  // gauss.rs:11-165
 };
 
 double mean_of(const std::vector<double>& s) {  // ml/mod.rs:22-24
-    double sum = 0.0;
-    for (double x : s) sum += x;
+    double sum = sum_terms(s.size(), [&](size_t i) { return s[i]; });
     return sum / (double)s.size();
 }
 double std_of(const std::vector<double>& s) {  // ml/mod.rs:26-30
-    double m = mean_of(s), x = 0.0;
-    for (double v : s) x += (v - m) * (v - m);
+    double m = mean_of(s);
+    double x = sum_terms(s.size(), [&](size_t i) { return (s[i] - m) * (s[i] - m); });
     return std::sqrt(x / (double)s.size());
 }
 
@@ -161,11 +183,11 @@ struct Kde {  // kde.rs:14-51
         constant = std::sqrt(2.0 * M_PI) * bandwidth * (double)s.size();
     }
     double pdf(double x) const {
-        double sum = 0.0;
-        for (double xi : *sample) {
-            double u = (x - xi) / bandwidth;
-            sum += std::exp(-0.5 * (u * u));
-        }
+        const std::vector<double>& sm = *sample;
+        double sum = sum_terms(sm.size(), [&](size_t i) {
+            double u = (x - sm[i]) / bandwidth;
+            return expd(-0.5 * (u * u));
+        });
         return sum / constant;
     }
 };
@@ -216,13 +238,23 @@ Estimator kde_build(const std::vector<double>& scores, const std::vector<uint8_t
 }
 
 // LinearDiscriminantAnalysis::train, linear_discriminant.rs:57-127.  rows: n x d row-major.
+// det mode: rows are cut into consecutive blocks of DET_BLOCK (both classes together); a block's contribution to a class
+// accumulator is summed left to right over the block's rows of that class, and the block contributions are added in block
+// order (a block without rows of a class contributes +0.0) — the order of the device's class_sum / scatter kernels.
 bool lda_train(const double* rows, size_t n, size_t d, const uint8_t* decoy, std::vector<double>& coef) {
+    const size_t block = g_det ? (size_t)sagedet::DET_BLOCK : (n ? n : 1);
     std::vector<double> class_sum[2] = {std::vector<double>(d, 0.0), std::vector<double>(d, 0.0)};
     size_t class_count[2] = {0, 0};
-    for (size_t i = 0; i < n; ++i) {
-        int cls = decoy[i] ? 0 : 1;
-        for (size_t j = 0; j < d; ++j) class_sum[cls][j] += rows[i * d + j];
-        class_count[cls]++;
+    for (size_t b0 = 0; b0 < n; b0 += block) {
+        const size_t b1 = std::min(n, b0 + block);
+        std::vector<double> part[2] = {std::vector<double>(d, 0.0), std::vector<double>(d, 0.0)};
+        for (size_t i = b0; i < b1; ++i) {
+            int cls = decoy[i] ? 0 : 1;
+            for (size_t j = 0; j < d; ++j) part[cls][j] += rows[i * d + j];
+            class_count[cls]++;
+        }
+        for (int c = 0; c < 2; ++c)
+            for (size_t j = 0; j < d; ++j) class_sum[c][j] += part[c][j];  // (one block: 0.0 + part == part, the reference's sum)
     }
     if (class_count[0] == 0 || class_count[1] == 0) return false;
     std::vector<double> class_mean[2] = {std::vector<double>(d), std::vector<double>(d)};
@@ -230,11 +262,17 @@ bool lda_train(const double* rows, size_t n, size_t d, const uint8_t* decoy, std
         for (size_t j = 0; j < d; ++j) class_mean[c][j] = class_sum[c][j] / (double)class_count[c];
     Matrix scatter[2] = {Matrix(d, d), Matrix(d, d)};
     std::vector<double> centered(d);
-    for (size_t i = 0; i < n; ++i) {
-        int cls = decoy[i] ? 0 : 1;
-        for (size_t j = 0; j < d; ++j) centered[j] = rows[i * d + j] - class_mean[cls][j];
-        for (size_t j = 0; j < d; ++j)
-            for (size_t k = 0; k < d; ++k) scatter[cls].at(j, k) += centered[j] * centered[k];
+    for (size_t b0 = 0; b0 < n; b0 += block) {
+        const size_t b1 = std::min(n, b0 + block);
+        Matrix part[2] = {Matrix(d, d), Matrix(d, d)};
+        for (size_t i = b0; i < b1; ++i) {
+            int cls = decoy[i] ? 0 : 1;
+            for (size_t j = 0; j < d; ++j) centered[j] = rows[i * d + j] - class_mean[cls][j];
+            for (size_t j = 0; j < d; ++j)
+                for (size_t k = 0; k < d; ++k) part[cls].at(j, k) += centered[j] * centered[k];
+        }
+        for (int c = 0; c < 2; ++c)
+            for (size_t e = 0; e < d * d; ++e) scatter[c].data[e] += part[c].data[e];
     }
     Matrix within(d, d);
     for (int c = 0; c < 2; ++c)
@@ -333,6 +371,9 @@ size_t picked(const uint32_t* key, uint32_t n_keys, const uint8_t* decoy, const 
 extern "C" {
 
 // LDA on an explicit n x d design (the reference's known-answer test drives train() this way). 1 = fitted.
+// 0: the reference's order + platform libm (default); 1: the device's arithmetic contract (detmath.h).  Per calling thread.
+void orc_rescore_mode(int det) { g_det = det ? 1 : 0; }
+
 int orc_lda_train(const double* rows, uint64_t n, uint64_t d, const uint8_t* decoy, double* coef) {
     std::vector<double> c;
     if (!lda_train(rows, n, d, decoy, c)) return 0;
@@ -389,24 +430,24 @@ int orc_rescore(const OrcFeature* f, uint64_t n, int tol_kind, float tol_lo, flo
         Estimator mass_model = kde_build(delta_mass, decoys, false, (size_t)std::fabs(std::ceil(bin_size)), bw_adjust);
         for (uint64_t i = 0; i < n; ++i) {  // compute_features, :162-195
             const OrcFeature& p = f[i];
-            double poisson = std::log1p(-p.poisson);
+            double poisson = ln1p(-p.poisson);
             if (!std::isfinite(poisson)) poisson = 3.5;
             double* r = &rows[i * FEATURES];
             r[0] = (double)p.rank;
             r[1] = (double)p.charge;
-            r[2] = std::log1p(p.hyperscore);
-            r[3] = std::log1p(p.delta_next);
-            r[4] = std::log1p(p.delta_best);
+            r[2] = ln1p(p.hyperscore);
+            r[3] = ln1p(p.delta_next);
+            r[4] = ln1p(p.delta_best);
             r[5] = mass_model.posterior_error(mass_error(p));
             r[6] = (double)p.isotope_error;
             r[7] = (double)p.average_ppm;
             r[8] = poisson;
-            r[9] = std::log1p((double)p.matched_intensity_pct);
+            r[9] = ln1p((double)p.matched_intensity_pct);
             r[10] = (double)p.matched_peaks;
-            r[11] = std::log1p((double)p.longest_b);
-            r[12] = std::log1p((double)p.longest_y);
+            r[11] = ln1p((double)p.longest_b);
+            r[12] = ln1p((double)p.longest_y);
             r[13] = (double)p.longest_y / (double)p.peptide_len;
-            r[14] = std::log1p((double)p.peptide_len);
+            r[14] = ln1p((double)p.peptide_len);
             r[15] = (double)p.missed_cleavages;
             r[16] = (double)(aligned_rt ? aligned_rt[i] : p.rt);
             r[17] = (double)p.ims;
@@ -437,7 +478,7 @@ int orc_rescore(const OrcFeature* f, uint64_t n, int tol_kind, float tol_lo, flo
         if (coef_out) std::memcpy(coef_out, coef.data(), FEATURES * 8);
     } else {
         for (uint64_t i = 0; i < n; ++i)  // runner.rs:285-288
-            discriminant[i] = std::log1p((float)(-f[i].poisson)) + f[i].longest_y_pct / 3.0f;
+            discriminant[i] = ln1pf((float)(-f[i].poisson)) + f[i].longest_y_pct / 3.0f;
     }
     // runner.rs:290 sort by discriminant descending (total_cmp), then qvalue.rs:8-36
     auto total_key = [](float x) {

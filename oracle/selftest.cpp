@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "sage_oracle.hpp"
+#include "../sage_amd/csrc/detmath.h"
+#include <cstring>
 
 using namespace sage_oracle;
 
@@ -372,7 +374,50 @@ static void test_database() {
     }
 }
 
+// The elementary functions of the rescoring contract (sage_amd/csrc/detmath.h) against the platform libm — what Rust's
+// f64::ln_1p / exp / f32::ln_1p call: never more than 1 ulp apart over the ranges the rescoring uses; special values equal.
+static long ulps(double a, double b) {
+    if (a == b || (a != a && b != b)) return 0;
+    int64_t x, y;
+    std::memcpy(&x, &a, 8);
+    std::memcpy(&y, &b, 8);
+    if ((x < 0) != (y < 0)) return 1L << 40;
+    return std::labs((long)(x - y));
+}
+static void test_detmath() {
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> e(-60.0, 12.0), u(-745.0, 709.0);
+    long worst_l = 0, worst_e = 0, worst_f = 0;
+    for (int i = 0; i < 2000000; i++) {
+        double x = std::exp2(e(rng));
+        if (i & 1) x = -x;
+        if (x <= -1.0) x = -0.999999 * std::generate_canonical<double, 53>(rng);
+        worst_l = std::max(worst_l, ulps(sagedet::det_log1p(x), std::log1p(x)));
+        const double y = (i % 3 == 0) ? u(rng) : -std::exp2(e(rng));
+        worst_e = std::max(worst_e, ulps(sagedet::det_exp(y), std::exp(y)));
+        const float xf = (float)std::fabs(x);
+        const float a = sagedet::det_log1pf(xf), b = std::log1p(xf);
+        worst_f = std::max(worst_f, a == b ? 0L : (std::nextafterf(a, b) == b ? 1L : 2L));
+    }
+    std::printf("detmath vs libm: log1p <= %ld ulp, exp <= %ld ulp, log1pf <= %ld ulp(f32)\n", worst_l, worst_e, worst_f);
+    CHECK(worst_l <= 1);
+    CHECK(worst_e <= 1);
+    CHECK(worst_f <= 1);
+    const double inf = std::numeric_limits<double>::infinity();
+    CHECK(sagedet::det_log1p(0.0) == 0.0 && sagedet::det_log1p(-1.0) == -inf && sagedet::det_log1p(inf) == inf);
+    CHECK(sagedet::det_log1p(-2.0) != sagedet::det_log1p(-2.0));  // NaN
+    CHECK(sagedet::det_exp(0.0) == 1.0 && sagedet::det_exp(-inf) == 0.0 && sagedet::det_exp(inf) == inf && sagedet::det_exp(-800.0) == 0.0);
+    CHECK(sagedet::det_exp(1.0) == std::nextafter(std::exp(1.0), 3.0) || sagedet::det_exp(1.0) == std::exp(1.0));
+    // the blocked order is the sequential order up to DET_BLOCK elements
+    std::vector<double> v(sagedet::DET_BLOCK);
+    for (auto& x : v) x = std::generate_canonical<double, 53>(rng) * 1e3;
+    double seq = 0.0;
+    for (double x : v) seq += x;
+    CHECK(sagedet::blocked_sum(v.size(), [&](uint64_t i) { return v[i]; }) == seq);
+}
+
 int main() {
+    test_detmath();
     test_mass();
     test_binary_search();
     test_scoring_units();

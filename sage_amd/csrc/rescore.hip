@@ -13,11 +13,14 @@
 // decoy/target prefix counts and the suffix minimum of the q-values, the per-key maxima of the picked competitions.  The
 // host does the scalar glue between kernels: final addition of per-block partials, bandwidths, the Gauss-Jordan solve.
 //
-// Reductions are deterministic (fixed block count, fixed tree, partials added in block order) but are not the reference's
-// left-to-right sums; results agree with the CPU restatement to f64 rounding, not bit for bit (the reference itself sums
-// Kde::pdf in rayon's arbitrary order).  The one sum the reference keeps in f32 — `decoy += pep` of fdr.rs:93-101 — is
-// evaluated strictly in order (seq_cumsum_kernel), because f32 rounding of a long running sum is order dependent at the
-// 1e-4 level.
+// Every long f64 reduction (class sums, within-class scatter, KDE means / deviations / Gaussian sums) is evaluated in the
+// BLOCKED ORDER of detmath.h — consecutive blocks of DET_BLOCK elements, left to right inside a block (one sequential chain
+// per (block, accumulator) on the device), block sums added left to right — and ln_1p / exp come from detmath.h's IEEE-only
+// implementations.  That fixes every bit that reaches the Gauss-Jordan pivot search, so the fit-or-heuristic decision
+// (gauss.rs:69-124 compares with `>=` / `== 0.0`; constant columns such as ims == 0 make some pivots candidates pure
+// rounding noise) and everything downstream equal the CPU restatement of the same contract bit for bit; for n <= DET_BLOCK
+// the order is the reference's own sequential one.  The one sum the reference keeps in f32 — `decoy += pep` of
+// fdr.rs:93-101 — is evaluated strictly in order (seq_cumsum_kernel).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,6 +35,7 @@
 #include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "../../include/sage_hip.h"
+#include "detmath.h"
 
 namespace sagehip {
 
@@ -39,9 +43,8 @@ namespace {
 
 constexpr int NF = 20;           // FEATURES, linear_discriminant.rs:19
 constexpr int RB = 256;          // threads of a row-parallel block
-constexpr int MAX_BLOCKS = 512;  // partials per reduction
-constexpr int KDE_BINS_PER_BLOCK = 8;
-constexpr int KDE_SLICES = 32;
+constexpr int MAX_BLOCKS = 512;  // partials per (order-free) reduction
+constexpr uint32_t DB = sagedet::DET_BLOCK;  // elements per block of the blocked summation order
 constexpr int SCATTER_THREADS = 448;  // >= 400 matrix entries, whole waves
 constexpr int SCATTER_STAGE = 64;     // rows staged in LDS at a time
 
@@ -103,90 +106,85 @@ __global__ __launch_bounds__(RB) void prep_kernel(const SageFeature* __restrict_
     dmass[i] = tol_kind == SAGE_TOL_PPM ? (double)f[i].delta_mass : (double)(f[i].expmass - f[i].calcmass);
 }
 
-// partial[b] = {count_d, count_t, sum_d, sum_t, min, max}  (ml/mod.rs:22-24, kde.rs:105-111)
-__global__ __launch_bounds__(RB) void stats1_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
-                                                    double* __restrict__ partial) {
+// partial[b] = {min, max} over the block's slice (kde.rs:105-111; f64::min / max ignore a NaN operand, like fmin / fmax)
+__global__ __launch_bounds__(RB) void minmax_kernel(const double* __restrict__ x, uint64_t n, double* __restrict__ partial) {
     __shared__ double lds[RB / 64];
-    double c[2] = {0, 0}, s[2] = {0, 0};
     double mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
     for (uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RB) {
         const double v = x[i];
-        const int cls = decoy[i] ? 0 : 1;
-        c[cls] += 1.0;
-        s[cls] += v;
         mn = fmin(mn, v);
         mx = fmax(mx, v);
     }
-    double r[6] = {block_reduce(c[0], OpSum(), lds), block_reduce(c[1], OpSum(), lds), block_reduce(s[0], OpSum(), lds),
-                   block_reduce(s[1], OpSum(), lds), block_reduce(mn, OpMin(), lds),   block_reduce(mx, OpMax(), lds)};
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 6; ++k) partial[blockIdx.x * 6 + k] = r[k];
-}
-
-// partial[b] = {sum (x - mean_d)^2 over decoys, sum (x - mean_t)^2 over targets}  (ml/mod.rs:26-30)
-__global__ __launch_bounds__(RB) void stats2_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
-                                                    double mean_d, double mean_t, double* __restrict__ partial) {
-    __shared__ double lds[RB / 64];
-    double s[2] = {0, 0};
-    for (uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RB) {
-        const int cls = decoy[i] ? 0 : 1;
-        const double d = x[i] - (cls ? mean_t : mean_d);
-        s[cls] += d * d;
-    }
-    const double r0 = block_reduce(s[0], OpSum(), lds), r1 = block_reduce(s[1], OpSum(), lds);
+    const double r0 = block_reduce(mn, OpMin(), lds), r1 = block_reduce(mx, OpMax(), lds);
     if (threadIdx.x == 0) {
         partial[blockIdx.x * 2] = r0;
         partial[blockIdx.x * 2 + 1] = r1;
     }
 }
 
-// Kde::pdf numerators (kde.rs:34-50) for a tile of bins over one slice of the sample:
-// partial[(slice * nbins + bin) * 2 + cls] = sum_i exp(-0.5 ((score_bin - x_i) / h_cls)^2).
-// Each sample is loaded once per tile and serves KDE_BINS_PER_BLOCK bins from registers.
-__global__ __launch_bounds__(RB) void kde_pdf_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy, uint64_t n,
-                                                     double min_score, double score_step, uint32_t nbins, double h_d,
-                                                     double h_t, double* __restrict__ partial) {
-    __shared__ double lds[RB / 64];
-    const uint32_t bin0 = blockIdx.x * KDE_BINS_PER_BLOCK, slice = blockIdx.y;
-    double centre[KDE_BINS_PER_BLOCK], acc[KDE_BINS_PER_BLOCK][2];
-#pragma unroll
-    for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
-        centre[b] = ((double)(bin0 + b) * score_step) + min_score;
-        acc[b][0] = acc[b][1] = 0.0;
-    }
-    const uint64_t per = (n + gridDim.y - 1) / gridDim.y, lo = slice * per, hi = lo + per < n ? lo + per : n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += RB) {
-        const double xi = x[i];
-        const bool dec = decoy[i] != 0;
-        const double h = dec ? h_d : h_t;
-#pragma unroll
-        for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
-            const double u = (centre[b] - xi) / h;
-            const double k = exp(-0.5 * (u * u));
-            acc[b][0] += dec ? k : 0.0;
-            acc[b][1] += dec ? 0.0 : k;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < KDE_BINS_PER_BLOCK; ++b) {
-        const double r0 = block_reduce(acc[b][0], OpSum(), lds), r1 = block_reduce(acc[b][1], OpSum(), lds);
-        if (threadIdx.x == 0 && bin0 + b < nbins) {
-            partial[((uint64_t)slice * nbins + bin0 + b) * 2] = r0;
-            partial[((uint64_t)slice * nbins + bin0 + b) * 2 + 1] = r1;
-        }
-    }
+// Builder::build's `d` / `t` vectors (kde.rs:86-98): the scores split by class, each class in input order.
+// dpos[i] = number of decoys before i (exclusive scan of the flags); xs[0, nd) = decoys, xs[nd, n) = targets.
+__global__ __launch_bounds__(RB) void class_flags_kernel(const uint8_t* __restrict__ decoy, uint64_t n, uint32_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i < n) flags[i] = decoy[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(RB) void class_split_kernel(const double* __restrict__ x, const uint8_t* __restrict__ decoy,
+                                                         const uint32_t* __restrict__ dpos, uint64_t n, uint64_t nd,
+                                                         double* __restrict__ xs) {
+    const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t d = dpos[i];
+    xs[decoy[i] ? d : nd + (i - d)] = x[i];
 }
 
-// bins[b] = decoy_pdf * pi / (target_pdf * (1 - pi) + decoy_pdf * pi), then the monotone fold (kde.rs:113-126). One block.
-__global__ __launch_bounds__(1024) void kde_finish_kernel(const double* __restrict__ partial, uint32_t n_slices, uint32_t nbins,
+// part[b] = left-to-right sum over block b of x[i] (mode 0: ml/mod.rs:22-24) or (x[i] - mean)^2 (mode 1: ml/mod.rs:26-30).
+// One thread = one block = one sequential chain (the blocked order of detmath.h).
+__global__ __launch_bounds__(64) void blocked_sum_kernel(const double* __restrict__ x, uint64_t n, int mode, double mean,
+                                                         double* __restrict__ part) {
+    const uint64_t b = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint64_t lo = b * DB, hi = lo + DB < n ? lo + DB : n;
+    if (lo >= n) return;
+    double s = 0.0;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const double v = x[i];
+        s += mode ? (v - mean) * (v - mean) : v;
+    }
+    part[b] = s;
+}
+
+// Kde::pdf numerators (kde.rs:34-50) of ONE class: partial[blk * nbins + bin] = sum over sample block blk, left to right, of
+// exp(-0.5 ((score_bin - x_i) / h)^2).  One thread = one (bin, block) chain; the block's samples are staged in LDS once and
+// read with wave-uniform addresses.
+constexpr int KDE_THREADS = 256;
+__global__ __launch_bounds__(KDE_THREADS) void kde_pdf_kernel(const double* __restrict__ xs, uint64_t n_c, double min_score,
+                                                              double score_step, uint32_t nbins, double h,
+                                                              double* __restrict__ partial) {
+    __shared__ double tile[DB];
+    const uint64_t lo = (uint64_t)blockIdx.y * DB;
+    const uint32_t cnt = (uint32_t)(n_c - lo < DB ? n_c - lo : DB);
+    for (uint32_t i = threadIdx.x; i < cnt; i += KDE_THREADS) tile[i] = xs[lo + i];
+    __syncthreads();
+    const uint32_t bin = blockIdx.x * KDE_THREADS + threadIdx.x;
+    if (bin >= nbins) return;
+    const double centre = ((double)bin * score_step) + min_score;
+    double acc = 0.0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const double u = (centre - tile[i]) / h;
+        acc += sagedet::det_exp(-0.5 * (u * u));
+    }
+    partial[(uint64_t)blockIdx.y * nbins + bin] = acc;
+}
+
+// bins[b] = decoy_pdf * pi / (target_pdf * (1 - pi) + decoy_pdf * pi), then the monotone fold (kde.rs:113-126).  The block
+// partials of a bin are added left to right from 0.0 (second level of the blocked order).  One workgroup.
+__global__ __launch_bounds__(1024) void kde_finish_kernel(const double* __restrict__ part_d, uint32_t nblk_d,
+                                                          const double* __restrict__ part_t, uint32_t nblk_t, uint32_t nbins,
                                                           double const_d, double const_t, double pi, int monotonic,
                                                           double* __restrict__ bins) {
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) {
         double sd = 0.0, st = 0.0;
-        for (uint32_t s = 0; s < n_slices; ++s) {
-            sd += partial[((uint64_t)s * nbins + b) * 2];
-            st += partial[((uint64_t)s * nbins + b) * 2 + 1];
-        }
+        for (uint32_t s = 0; s < nblk_d; ++s) sd += part_d[(uint64_t)s * nbins + b];
+        for (uint32_t s = 0; s < nblk_t; ++s) st += part_t[(uint64_t)s * nbins + b];
         const double d = (sd / const_d) * pi;
         const double t = (st / const_t) * (1.0 - pi);
         bins[b] = d / (t + d);
@@ -209,24 +207,24 @@ __global__ __launch_bounds__(RB) void rows_kernel(const SageFeature* __restrict_
     const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
     if (i >= n) return;
     const SageFeature p = f[i];
-    double poisson = log1p(-p.poisson);
+    double poisson = sagedet::det_log1p(-p.poisson);
     if (!isfinite(poisson)) poisson = 3.5;
     double* r = rows + i * NF;
     r[0] = (double)p.rank;
     r[1] = (double)p.charge;
-    r[2] = log1p(p.hyperscore);
-    r[3] = log1p(p.delta_next);
-    r[4] = log1p(p.delta_best);
+    r[2] = sagedet::det_log1p(p.hyperscore);
+    r[3] = sagedet::det_log1p(p.delta_next);
+    r[4] = sagedet::det_log1p(p.delta_best);
     r[5] = kde_posterior_error(mass_model, dmass[i]);
     r[6] = (double)p.isotope_error;
     r[7] = (double)p.average_ppm;
     r[8] = poisson;
-    r[9] = log1p((double)p.matched_intensity_pct);
+    r[9] = sagedet::det_log1p((double)p.matched_intensity_pct);
     r[10] = (double)p.matched_peaks;
-    r[11] = log1p((double)p.longest_b);
-    r[12] = log1p((double)p.longest_y);
+    r[11] = sagedet::det_log1p((double)p.longest_b);
+    r[12] = sagedet::det_log1p((double)p.longest_y);
     r[13] = (double)p.longest_y / (double)p.peptide_len;
-    r[14] = log1p((double)p.peptide_len);
+    r[14] = sagedet::det_log1p((double)p.peptide_len);
     r[15] = (double)p.missed_cleavages;
     r[16] = (double)(aligned_rt ? aligned_rt[i] : p.rt);
     r[17] = (double)p.ims;
@@ -235,35 +233,36 @@ __global__ __launch_bounds__(RB) void rows_kernel(const SageFeature* __restrict_
     r[19] = sqrt(dims < 0.001 ? 0.001 : (dims > 0.999 ? 0.999 : dims));
 }
 
-// pass 1 of train (linear_discriminant.rs:70-82): partial[b][cls][j] = sum of column j over the block's rows of class cls.
-// 240 threads = 12 row lanes x 20 columns: a step reads 12 whole rows (coalesced), each thread keeps the two class sums of
-// its (row lane, column); the 12 row lanes are then added in lane order.
-constexpr int CSUM_LANES = 12;
-__global__ __launch_bounds__(CSUM_LANES * NF) void class_sum_kernel(const double* __restrict__ rows,
-                                                                    const uint8_t* __restrict__ decoy, uint64_t n,
-                                                                    double* __restrict__ partial) {
-    __shared__ double part[CSUM_LANES][2][NF];
-    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    const int rl = threadIdx.x / NF, j = threadIdx.x % NF;
-    double s[2] = {0.0, 0.0};
-    for (uint64_t i = lo + rl; i < hi; i += CSUM_LANES) {
-        const double v = rows[i * NF + j];
-        if (decoy[i]) s[0] += v;
-        else s[1] += v;
+// pass 1 of train (linear_discriminant.rs:70-82): partial[b][cls][j] = sum, left to right, of column j over the rows of
+// class cls in row block b (DET_BLOCK consecutive rows).  Thread (cls, j) owns one chain; rows are staged through LDS.
+constexpr int CSUM_THREADS = 64;
+__global__ __launch_bounds__(CSUM_THREADS) void class_sum_kernel(const double* __restrict__ rows,
+                                                                 const uint8_t* __restrict__ decoy, uint64_t n,
+                                                                 double* __restrict__ partial) {
+    __shared__ double stage[SCATTER_STAGE][NF];
+    __shared__ uint8_t stage_cls[SCATTER_STAGE];
+    const uint64_t lo = (uint64_t)blockIdx.x * DB, hi = lo + DB < n ? lo + DB : n;
+    const int cls = threadIdx.x / NF, j = threadIdx.x % NF;  // threads >= 2 * NF only help staging
+    double acc = 0.0;
+    for (uint64_t base = lo; base < hi; base += SCATTER_STAGE) {
+        const uint32_t cnt = (uint32_t)(hi - base < SCATTER_STAGE ? hi - base : SCATTER_STAGE);
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < cnt * NF; e += CSUM_THREADS) {
+            const uint32_t r = e / NF, c = e % NF;
+            stage[r][c] = rows[(base + r) * NF + c];
+            if (c == 0) stage_cls[r] = decoy[base + r] ? 0 : 1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * NF)
+            for (uint32_t r = 0; r < cnt; ++r)
+                if (stage_cls[r] == cls) acc += stage[r][j];
     }
-    part[rl][0][j] = s[0];
-    part[rl][1][j] = s[1];
-    __syncthreads();
-    if (threadIdx.x < 2 * NF) {
-        const int cls = threadIdx.x / NF;
-        double t = 0.0;
-        for (int r = 0; r < CSUM_LANES; ++r) t += part[r][cls][j];
-        partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = t;
-    }
+    if (threadIdx.x < 2 * NF) partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = acc;
 }
 
-// pass 2 of train (:92-103): partial[b][cls][j][k] = sum over the block's rows of class cls of (x_j - mu_j)(x_k - mu_k).
-// Thread (j, k) owns one matrix entry of both classes; centred rows are staged through LDS 64 at a time.
+// pass 2 of train (:92-103): partial[b][cls][j][k] = sum, left to right over the rows of class cls in row block b, of
+// (x_j - mu_j)(x_k - mu_k).  Thread (j, k) owns the chain of one matrix entry for both classes; centred rows are staged
+// through LDS 64 at a time.
 __global__ __launch_bounds__(SCATTER_THREADS) void scatter_kernel(const double* __restrict__ rows,
                                                                   const uint8_t* __restrict__ decoy, uint64_t n,
                                                                   const double* __restrict__ class_mean /* [2][20] */,
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void scatter_kernel(const double* 
     __shared__ uint8_t stage_cls[SCATTER_STAGE];
     __shared__ double mu[2][NF];
     if (threadIdx.x < 2 * NF) mu[threadIdx.x / NF][threadIdx.x % NF] = class_mean[threadIdx.x];
-    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const uint64_t lo = (uint64_t)blockIdx.x * DB, hi = lo + DB < n ? lo + DB : n;
     const int j = threadIdx.x / NF, k = threadIdx.x % NF;
     double acc[2] = {0.0, 0.0};
     for (uint64_t base = lo; base < hi; base += SCATTER_STAGE) {
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(RB) void heuristic_kernel(const SageFeature* __rest
                                                        float* __restrict__ discriminant, float* __restrict__ posterior_error) {
     const uint64_t i = (uint64_t)blockIdx.x * RB + threadIdx.x;
     if (i >= n) return;
-    discriminant[i] = log1pf((float)(-f[i].poisson)) + f[i].longest_y_pct / 3.0f;
+    discriminant[i] = sagedet::det_log1pf((float)(-f[i].poisson)) + f[i].longest_y_pct / 3.0f;
     posterior_error[i] = 1.0f;
 }
 
@@ -521,19 +520,64 @@ __global__ __launch_bounds__(RB) void picked_gather_kernel(const uint32_t* __res
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 
+// Device scratch of one call.  Allocations are stream-ordered (hipMallocAsync / hipFreeAsync on the call's stream) out of
+// the device's default memory pool, whose release threshold is raised once so that freed blocks stay cached between
+// calls: after the first call a rescoring allocates nothing from the driver (the ~30 hipMalloc / hipFree pairs used to be a
+// third of the wall time of a 1 M-PSM call).  SAGE_HIP_NO_POOL=1 falls back to plain hipMalloc / hipFree.
+thread_local hipStream_t tl_stream = nullptr;
+thread_local bool tl_pooled = false;
+
+void scratch_begin(int device, hipStream_t stream) {
+    tl_stream = stream;
+    tl_pooled = false;
+    if (const char* e = getenv("SAGE_HIP_NO_POOL"))
+        if (atoi(e) != 0) return;
+    static bool configured[64] = {};
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || !pool) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (device >= 0 && device < 64 && !configured[device]) {
+        uint64_t keep = ~0ull;
+        if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        configured[device] = true;
+    }
+    tl_pooled = true;
+}
+
 template <class T>
 struct Buf {
     T* p = nullptr;
+    bool pooled = false;
+    hipStream_t stream = nullptr;
     Buf() = default;
     Buf(const Buf&) = delete;
     Buf& operator=(const Buf&) = delete;
-    ~Buf() {
-        if (p) (void)hipFree(p);
+    ~Buf() { release(); }
+    void release() {
+        if (!p) return;
+        if (pooled) (void)hipFreeAsync(p, stream);  // ordered after every kernel of this call that uses it
+        else (void)hipFree(p);
+        p = nullptr;
     }
     hipError_t alloc(size_t count) {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        release();
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        if (tl_pooled) {
+            if (hipMallocAsync((void**)&p, bytes, tl_stream) == hipSuccess) {
+                pooled = true;
+                stream = tl_stream;
+                return hipSuccess;
+            }
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+        pooled = false;
+        return hipMalloc((void**)&p, bytes);
     }
 };
 
@@ -572,54 +616,84 @@ struct KdeFit {
     KdeDev dev{};
 };
 
+bool exclusive_count(Ctx& cx, const uint32_t* d_flags, uint32_t* d_out, uint64_t n);
+
+// left-to-right fold of block partials from +0.0 (second level of the blocked order)
+double fold_partials(const std::vector<double>& part) {
+    double s = 0.0;
+    for (double v : part) s += v;
+    return s;
+}
+
+// blocked-order sum of x[0, n) (mode 0) or of (x - mean)^2 (mode 1): chains on the device, block partials folded on the host
+bool blocked_sum(Ctx& cx, const double* d_x, uint64_t n, int mode, double mean, double& out) {
+    out = 0.0;
+    if (n == 0) return true;
+    const uint64_t nblk = (n + DB - 1) / DB;
+    Buf<double> part;
+    RS_TRY(part.alloc(nblk));
+    blocked_sum_kernel<<<grid_for(nblk, 64), 64, 0, cx.stream>>>(d_x, n, mode, mean, part.p);
+    std::vector<double> h(nblk);
+    RS_TRY(hipMemcpyAsync(h.data(), part.p, nblk * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipStreamSynchronize(cx.stream));
+    out = fold_partials(h);
+    return true;
+}
+
 // kde::Builder{monotonic, bins, bw_adjust = x * bw_mult}.build(scores, decoys)  (kde.rs:85-133)
 bool kde_build(Ctx& cx, const double* d_scores, const uint8_t* d_decoy, uint64_t n, bool monotonic, uint32_t nbins,
                double bw_mult, KdeFit& fit) {
+    // the class vectors `d` and `t` (kde.rs:86-98), each in input order
+    Buf<uint32_t> flags, dpos;
+    Buf<double> xs, mm;
+    RS_TRY(flags.alloc(n));
+    RS_TRY(dpos.alloc(n));
+    RS_TRY(xs.alloc(n));
+    class_flags_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_decoy, n, flags.p);
+    if (!exclusive_count(cx, flags.p, dpos.p, n)) return false;
+    uint32_t last_pos = 0, last_flag = 0;
+    RS_TRY(hipMemcpyAsync(&last_pos, dpos.p + (n - 1), 4, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(hipMemcpyAsync(&last_flag, flags.p + (n - 1), 4, hipMemcpyDeviceToHost, cx.stream));
     const uint32_t nb = blocks_for(n);
-    Buf<double> partial;
-    RS_TRY(partial.alloc((size_t)nb * 6));
-    std::vector<double> h((size_t)nb * 6);
-    stats1_kernel<<<nb, RB, 0, cx.stream>>>(d_scores, d_decoy, n, partial.p);
-    RS_TRY(hipMemcpyAsync(h.data(), partial.p, h.size() * 8, hipMemcpyDeviceToHost, cx.stream));
+    RS_TRY(mm.alloc((size_t)nb * 2));
+    minmax_kernel<<<nb, RB, 0, cx.stream>>>(d_scores, n, mm.p);
+    std::vector<double> hmm((size_t)nb * 2);
+    RS_TRY(hipMemcpyAsync(hmm.data(), mm.p, hmm.size() * 8, hipMemcpyDeviceToHost, cx.stream));
     RS_TRY(hipStreamSynchronize(cx.stream));
-    double cnt[2] = {0, 0}, sum[2] = {0, 0};
+    const uint64_t cnt_u[2] = {(uint64_t)last_pos + last_flag, n - ((uint64_t)last_pos + last_flag)};
+    class_split_kernel<<<grid_for(n, RB), RB, 0, cx.stream>>>(d_scores, d_decoy, dpos.p, n, cnt_u[0], xs.p);
     double mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
     for (uint32_t b = 0; b < nb; ++b) {
-        cnt[0] += h[b * 6 + 0];
-        cnt[1] += h[b * 6 + 1];
-        sum[0] += h[b * 6 + 2];
-        sum[1] += h[b * 6 + 3];
-        mn = std::fmin(mn, h[b * 6 + 4]);
-        mx = std::fmax(mx, h[b * 6 + 5]);
+        mn = std::fmin(mn, hmm[b * 2]);
+        mx = std::fmax(mx, hmm[b * 2 + 1]);
     }
-    const double mean_d = sum[0] / cnt[0], mean_t = sum[1] / cnt[1];
-    stats2_kernel<<<nb, RB, 0, cx.stream>>>(d_scores, d_decoy, n, mean_d, mean_t, partial.p);
-    RS_TRY(hipMemcpyAsync(h.data(), partial.p, (size_t)nb * 2 * 8, hipMemcpyDeviceToHost, cx.stream));
-    RS_TRY(hipStreamSynchronize(cx.stream));
-    double ss[2] = {0, 0};
-    for (uint32_t b = 0; b < nb; ++b) {
-        ss[0] += h[b * 2];
-        ss[1] += h[b * 2 + 1];
-    }
-    // Kde::new (kde.rs:21-32)
+    const double* cls_x[2] = {xs.p, xs.p + cnt_u[0]};
+    // Kde::new (kde.rs:21-32) over mean / std of ml/mod.rs:22-30
     double bw[2], constant[2];
     for (int c = 0; c < 2; ++c) {
-        const double sigma = std::sqrt(ss[c] / cnt[c]);
-        bw[c] = (sigma * std::pow((4.0 / 3.0) / cnt[c], 1.0 / 5.0)) * bw_mult;
-        constant[c] = std::sqrt(2.0 * M_PI) * bw[c] * cnt[c];
+        const double cnt = (double)cnt_u[c];
+        double sum = 0.0, ss = 0.0;
+        if (!blocked_sum(cx, cls_x[c], cnt_u[c], 0, 0.0, sum)) return false;
+        const double mean = sum / cnt;
+        if (!blocked_sum(cx, cls_x[c], cnt_u[c], 1, mean, ss)) return false;
+        const double sigma = std::sqrt(ss / cnt);
+        bw[c] = (sigma * std::pow((4.0 / 3.0) / cnt, 1.0 / 5.0)) * bw_mult;
+        constant[c] = std::sqrt(2.0 * M_PI) * bw[c] * cnt;
     }
-    const double pi = cnt[0] / (double)n;
+    const double pi = (double)cnt_u[0] / (double)n;
     const double step = (mx - mn) / (double)(nbins - 1);
-    const uint32_t tiles = (nbins + KDE_BINS_PER_BLOCK - 1) / KDE_BINS_PER_BLOCK;
-    const uint32_t slices = (uint32_t)std::min<uint64_t>(KDE_SLICES, std::max<uint64_t>(1, n / (4 * RB)));
-    Buf<double> pdf_partial;
-    RS_TRY(pdf_partial.alloc((size_t)slices * nbins * 2));
+    const uint32_t nblk[2] = {(uint32_t)((cnt_u[0] + DB - 1) / DB), (uint32_t)((cnt_u[1] + DB - 1) / DB)};
+    Buf<double> pdf_partial[2];
     RS_TRY(fit.bins.alloc(nbins));
-    kde_pdf_kernel<<<dim3(tiles, slices), RB, 0, cx.stream>>>(d_scores, d_decoy, n, mn, step, nbins, bw[0], bw[1], pdf_partial.p);
-    kde_finish_kernel<<<1, 1024, 0, cx.stream>>>(pdf_partial.p, slices, nbins, constant[0], constant[1], pi, monotonic ? 1 : 0,
-                                                fit.bins.p);
+    for (int c = 0; c < 2; ++c) {
+        RS_TRY(pdf_partial[c].alloc((size_t)nblk[c] * nbins));
+        if (nblk[c])
+            kde_pdf_kernel<<<dim3(grid_for(nbins, KDE_THREADS), nblk[c]), KDE_THREADS, 0, cx.stream>>>(cls_x[c], cnt_u[c], mn, step,
+                                                                                                   nbins, bw[c], pdf_partial[c].p);
+    }
+    kde_finish_kernel<<<1, 1024, 0, cx.stream>>>(pdf_partial[0].p, nblk[0], pdf_partial[1].p, nblk[1], nbins, constant[0],
+                                                constant[1], pi, monotonic ? 1 : 0, fit.bins.p);
     RS_TRY(hipGetLastError());
-    RS_TRY(hipStreamSynchronize(cx.stream));  // pdf_partial is freed on return
     fit.dev = KdeDev{fit.bins.p, mn, step, nbins};
     return true;
 }
@@ -723,6 +797,16 @@ bool prefix_count(Ctx& cx, const uint32_t* d_flags, uint32_t* d_out, uint32_t n)
     RS_TRY(temp.alloc(temp_bytes));
     RS_TRY(rocprim::inclusive_scan((void*)temp.p, temp_bytes, d_flags, d_out, (size_t)n, rocprim::plus<uint32_t>(), cx.stream));
     RS_TRY(hipStreamSynchronize(cx.stream));
+    return true;
+}
+
+// out[j] = sum of flags[0..j)
+bool exclusive_count(Ctx& cx, const uint32_t* d_flags, uint32_t* d_out, uint64_t n) {
+    size_t temp_bytes = 0;
+    RS_TRY(rocprim::exclusive_scan((void*)nullptr, temp_bytes, d_flags, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), cx.stream));
+    Buf<uint8_t> temp;
+    RS_TRY(temp.alloc(temp_bytes));
+    RS_TRY(rocprim::exclusive_scan((void*)temp.p, temp_bytes, d_flags, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), cx.stream));
     return true;
 }
 
@@ -870,10 +954,10 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     rows_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, dmass.p, mass_model.dev, a_rt.p, d_rt.p, d_ims.p, rows.p);
 
     // train (:57-127): class sums -> means -> scatter -> solve
-    const uint32_t nb = blocks_for(n);
+    const uint32_t nb = (uint32_t)((n + DB - 1) / DB);  // row blocks of the blocked order
     RS_TRY(partial.alloc((size_t)nb * 2 * NF * NF));
     RS_TRY(folded.alloc(2 * NF * NF + 2 * NF));
-    class_sum_kernel<<<nb, CSUM_LANES * NF, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
+    class_sum_kernel<<<nb, CSUM_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
     fold_partials_kernel<<<1, RB, 0, cx.stream>>>(partial.p, nb, 2 * NF, folded.p);
     double class_sum[2][NF];
     RS_TRY(hipMemcpyAsync(class_sum, folded.p, sizeof(class_sum), hipMemcpyDeviceToHost, cx.stream));
@@ -1482,6 +1566,7 @@ int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput&
         err = cx.err;
         return cx.code;
     }
+    scratch_begin(device, cx.stream);
     const bool ok = rescore_impl(cx, in, out);
     (void)hipStreamSynchronize(cx.stream);
     (void)hipStreamDestroy(cx.stream);
@@ -1505,6 +1590,7 @@ int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, s
         err = cx.err;
         return cx.code;
     }
+    scratch_begin(device, cx.stream);
     const bool ok = predict_rt_impl(cx, in, out);
     (void)hipStreamSynchronize(cx.stream);
     (void)hipStreamDestroy(cx.stream);

@@ -88,6 +88,7 @@ def load():
     lib.orc_db_merge_kept.restype = vp
     lib.orc_db_merge_kept.argtypes = [C.POINTER(vp), C.POINTER(L.c_u8_p), C.c_uint32, C.POINTER(L.SageDbParams)]
     dp = C.POINTER(C.c_double)
+    lib.orc_rescore_mode.argtypes = [C.c_int]
     lib.orc_lda_train.restype = C.c_int
     lib.orc_lda_train.argtypes = [dp, C.c_uint64, C.c_uint64, L.c_u8_p, dp]
     lib.orc_gauss_solve.restype = C.c_int
@@ -281,12 +282,27 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def lda_train(rows, decoy):
+class _mode:
+    """det=False: the reference's own summation order and the platform libm (the restatement proper).  det=True: the order and
+    the elementary functions the device evaluates (sage_amd/csrc/detmath.h) — what the GPU is held to bit for bit."""
+
+    def __init__(self, det):
+        self.det = det
+
+    def __enter__(self):
+        load().orc_rescore_mode(1 if self.det else 0)
+
+    def __exit__(self, *a):
+        load().orc_rescore_mode(0)
+
+
+def lda_train(rows, decoy, det=False):
     """LinearDiscriminantAnalysis::train (linear_discriminant.rs:57-127) -> coefficients or None"""
     rows = np.ascontiguousarray(rows, dtype=np.float64)
     decoy = np.ascontiguousarray(decoy, dtype=np.uint8)
     coef = np.zeros(rows.shape[1])
-    ok = load().orc_lda_train(_dptr(rows), rows.shape[0], rows.shape[1], L.as_ptr(decoy, C.c_uint8), _dptr(coef))
+    with _mode(det):
+        ok = load().orc_lda_train(_dptr(rows), rows.shape[0], rows.shape[1], L.as_ptr(decoy, C.c_uint8), _dptr(coef))
     return coef if ok else None
 
 
@@ -298,20 +314,22 @@ def gauss_solve(left, right):
     return out if ok else None
 
 
-def kde(scores, decoys, monotonic=True, bins=1000, bw_mult=1.0, queries=()):
+def kde(scores, decoys, monotonic=True, bins=1000, bw_mult=1.0, queries=(), det=False):
     """kde::Builder::build + Estimator::posterior_error -> (bins, min_score, score_step, pep(queries))"""
     scores = np.ascontiguousarray(scores, dtype=np.float64)
     decoys = np.ascontiguousarray(decoys, dtype=np.uint8)
     q = np.ascontiguousarray(queries, dtype=np.float64)
     out_bins, ms, pep = np.zeros(bins), np.zeros(2), np.zeros(len(q))
-    load().orc_kde(_dptr(scores), L.as_ptr(decoys, C.c_uint8), len(scores), int(monotonic), bins, bw_mult, _dptr(out_bins),
-                   _dptr(ms), _dptr(q), len(q), _dptr(pep))
+    with _mode(det):
+        load().orc_kde(_dptr(scores), L.as_ptr(decoys, C.c_uint8), len(scores), int(monotonic), bins, bw_mult, _dptr(out_bins),
+                       _dptr(ms), _dptr(q), len(q), _dptr(pep))
     return out_bins, ms[0], ms[1], pep
 
 
 def rescore(features, precursor_tol, peptide_key, n_peptide_keys, protein_key, n_protein_keys, aligned_rt=None,
-            delta_rt_model=None, delta_ims_model=None, want_rows=False):
-    """spectrum_fdr + picked_peptide + picked_protein (runner.rs:536-541); dict of arrays in input order."""
+            delta_rt_model=None, delta_ims_model=None, want_rows=False, det=True):
+    """spectrum_fdr + picked_peptide + picked_protein (runner.rs:536-541); dict of arrays in input order.
+    det=True (default): the arithmetic contract the device evaluates; det=False: the reference's own order + platform libm."""
     f = np.ascontiguousarray(features, dtype=L.FEATURE_DTYPE).reshape(-1)
     n = len(f)
     pk = np.ascontiguousarray(peptide_key, dtype=np.uint32)
@@ -323,12 +341,13 @@ def rescore(features, precursor_tol, peptide_key, n_peptide_keys, protein_key, n
     coef = np.zeros(20)
     rows = np.zeros((n, 20)) if want_rows else None
     t = precursor_tol.to_c()
-    fitted = load().orc_rescore(f.ctypes.data, n, t.kind, t.lo, t.hi, *[None if a is None else L.as_ptr(a, C.c_float) for a in opt],
-                                L.as_ptr(pk, C.c_uint32), n_peptide_keys, L.as_ptr(prk, C.c_uint32), n_protein_keys,
-                                *[L.as_ptr(outs[k], C.c_float) for k in ("discriminant_score", "posterior_error", "spectrum_q",
-                                                                           "peptide_q", "protein_q")],
-                                L.as_ptr(order, C.c_uint32), L.as_ptr(passing, C.c_uint64), _dptr(coef),
-                                None if rows is None else _dptr(rows))
+    with _mode(det):
+        fitted = load().orc_rescore(f.ctypes.data, n, t.kind, t.lo, t.hi, *[None if a is None else L.as_ptr(a, C.c_float) for a in opt],
+                                    L.as_ptr(pk, C.c_uint32), n_peptide_keys, L.as_ptr(prk, C.c_uint32), n_protein_keys,
+                                    *[L.as_ptr(outs[k], C.c_float) for k in ("discriminant_score", "posterior_error", "spectrum_q",
+                                                                               "peptide_q", "protein_q")],
+                                    L.as_ptr(order, C.c_uint32), L.as_ptr(passing, C.c_uint64), _dptr(coef),
+                                    None if rows is None else _dptr(rows))
     return dict(outs, order=order, passing=passing, coef=coef, lda_fitted=bool(fitted), rows=rows)
 
 

@@ -1,0 +1,104 @@
+"""Config-scale GPU parity: the FULL BASELINE.json databases (C2-C5: up to 7.8 M peptides / 284 M fragments), index
+built on the device, >= 4096 spectra of each configuration's own synthetic run compared with the CPU oracle through the
+C ABI — Features (ints / f32 bit-exact, f64 within 1e-12) and the preliminary candidate lists including heap order.
+
+The small-database tests (test_gpu_parity.py) reach windows above 2^21 slots, counts >= 63 and arena-chunk boundaries only
+through debug knobs; here they occur (or not) the way they do in the benchmark workloads, with no knob set.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from parity_utils import assert_features_equal, assert_initial_hits_equal
+from sage_amd.api import DeviceDatabase, Scorer
+from sage_amd.workloads import CONFIGS, build_host_db, scorer_params, workload_batch
+
+pytestmark = pytest.mark.gpu
+
+N_SPECTRA = 4096
+_worlds = {}
+
+
+class ConfigWorld:
+    """Host database WITH fragments (the oracle needs the reference-shaped index), device index generated from the peptide
+    list (index_build.hip), oracle database, and the first N_SPECTRA spectra of the configuration's run."""
+
+    def __init__(self, name):
+        cfg = CONFIGS[name]
+        self.cfg = cfg
+        self.host = build_host_db(cfg)
+        self.dev = DeviceDatabase(self.host, 0, build_on_device=True)
+        self.orc = oracle_lib.OracleDb.from_product(self.host)
+        self.params = scorer_params(cfg)
+
+
+def world_for(name):
+    """C3 and C5 share one database (same FASTA seed and digest parameters)."""
+    key = "C3" if name == "C5" else name
+    if key not in _worlds:
+        _worlds.clear()  # one full-size database (host + oracle copies, several GB) at a time
+        _worlds[key] = ConfigWorld(key)
+    return _worlds[key]
+
+
+def _check(name, every, monkeypatch=None, n=N_SPECTRA, env=None, begin=0):
+    w = world_for(name)
+    cfg = CONFIGS[name]
+    params = scorer_params(cfg)
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    batch, _ = workload_batch(cfg, w.host, begin, begin + n)
+    scorer = Scorer(w.dev, params)
+    dbatch = scorer.upload(batch)
+    gf, gc = scorer.score_resident(dbatch)
+    gf, gc = gf.copy(), gc.copy()
+    t = scorer.last_timing()
+    of, oc, _, _ = w.orc.score(params, batch, threads=0)
+    n_psm = assert_features_equal(gf, gc, of, oc, f"{name} config-scale")
+    if every:
+        assert_initial_hits_equal(scorer, dbatch, w.orc, params, batch, f"{name} config-scale", every)
+    # the upload + score + download entry point on the same spectra
+    gf2, gc2 = scorer.score(batch)
+    assert_features_equal(gf2, gc2, of, oc, f"{name} config-scale (score_batch)")
+    return batch, n_psm, t
+
+
+def test_c2_yeast_narrow(gpu_required):
+    batch, n_psm, t = _check("C2", every=16)
+    assert batch.n >= 4000 and n_psm > 0.8 * batch.n * 0.85 and t["n_wide"] == 0
+
+
+def test_c3_human_narrow(gpu_required):
+    batch, n_psm, t = _check("C3", every=16)
+    assert batch.n >= 4000 and n_psm > 0.8 * batch.n * 0.85 and t["n_wide"] == 0
+
+
+def test_c3_human_narrow_exact_mode(gpu_required, monkeypatch):
+    """SAGE_HIP_EXACT=1: every trim replays bounded_min_heapify (no order-free trims, no retry pass)."""
+    batch, n_psm, t = _check("C3", every=0, monkeypatch=monkeypatch, env={"SAGE_HIP_EXACT": "1"}, begin=N_SPECTRA)
+    assert t["n_retry"] == 0 and n_psm > 0
+
+
+def test_c5_chimeric_wide_window(gpu_required):
+    """wide_window + chimera + report_psms 5, three precursor charges per spectrum: every spectrum takes the tiled pipeline."""
+    batch, n_psm, t = _check("C5", every=64)
+    assert batch.n >= 4000 and t["n_wide"] == batch.n and n_psm > batch.n
+
+
+def test_c5_few_workgroups_cross_arena_chunks(gpu_required, monkeypatch):
+    """The same spectra with 48 persistent workgroups instead of ~512: each walks ~85 spectra, so its candidate segments
+    run through several 64 Ki-entry arena chunks (kernels.hip: ARENA_CHUNK) — chunk boundaries inside a query's chain."""
+    batch, n_psm, t = _check("C5", every=0, monkeypatch=monkeypatch, env={"SAGE_HIP_TILE_BLOCKS": "48"})
+    assert t["arena_entries"] > 2 * 48 * 65536, t  # more than the first two chunks of every workgroup
+
+
+def test_c4_open_search(gpu_required):
+    """da[-500, 100] on 7.8 M peptides: windows of ~10^6 candidate slots, ~50 tiles each."""
+    batch, n_psm, t = _check("C4", every=128)
+    assert batch.n >= 4000 and t["n_wide"] == batch.n and n_psm > 0.5 * batch.n
+
+
+def test_c4_open_search_exact_mode(gpu_required, monkeypatch):
+    batch, n_psm, t = _check("C4", every=0, monkeypatch=monkeypatch, env={"SAGE_HIP_EXACT": "1"}, n=1024, begin=N_SPECTRA)
+    assert t["n_retry"] == 0 and n_psm > 0
+    _worlds.clear()

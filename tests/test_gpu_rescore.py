@@ -1,9 +1,11 @@
 """GPU parity of the post-search rescoring (rescore.hip, through sage_hip_rescore) against the CPU oracle.
 
-Reductions on the device are tree sums, the oracle's are left-to-right (the reference's own KDE sums run in rayon's
-arbitrary order), so f64 intermediates agree to rounding, not bit for bit:
-  coefficients 1e-6 relative (the regularised 20x20 system has condition number ~1e9), discriminant 1e-5, log10 posterior
-  error 2e-3 absolute, q-values equal except where two PSMs are closer than that noise (at most 0.1 % of rows may differ).
+The device evaluates the arithmetic contract of sage_amd/csrc/detmath.h (blocked summation order, IEEE-only ln_1p / exp) and
+the oracle is run in the same mode (`det=True`): every bit that reaches the Gauss-Jordan pivot search is then the same on both
+sides, so the fit-or-heuristic decision, the coefficients, the discriminants, every q-value and the output order are held
+EQUAL — also on data with constant columns (ims == 0 is the normal case without ion mobility), where the elimination pivots
+on rounding noise.  The one exception is log10 of the posterior error (device libm vs glibc): 2 f32 ulps.
+How far the contract is from the reference's own order + platform libm is measured on the CPU in test_rescore_oracle.py.
 """
 import numpy as np
 import pytest
@@ -17,35 +19,26 @@ from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
 pytestmark = pytest.mark.gpu
 
 
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.array_equal(a, b) or bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
 def compare(f, tol, pk, npk, prk, npr, context, **opt):
     g = rescore(f, tol, pk, npk, prk, npr, **opt)
-    o = oracle_lib.rescore(f, tol, pk, npk, prk, npr, want_rows=True, **opt)
+    o = oracle_lib.rescore(f, tol, pk, npk, prk, npr, det=True, **opt)
     n = len(f)
     assert g.lda_fitted == o["lda_fitted"], context
     if g.lda_fitted:
-        # constant columns (ims without ion mobility, the two model deltas at their 0.999 default) have a scatter row of
-        # rounding noise over the 1e-8 regulariser: their coefficients are noise / 1e-8 on both sides, and multiply a constant
-        live = np.array([np.ptp(o["rows"][:, j]) > 0 for j in range(20)]) if o.get("rows") is not None else np.ones(20, bool)
-        scale = np.abs(o["coef"][live]).max()
-        assert np.allclose(g.coef[live], o["coef"][live], rtol=1e-6, atol=1e-7 * scale), (context, g.coef, o["coef"])
-        assert np.all(np.abs(g.coef[~live]) < 1e-2 * scale), (context, g.coef)
-    # (the noise coefficients of constant columns shift every discriminant by the same constant: no effect on order, PEP, q)
-    offset = float(np.median(g.discriminant_score.astype(np.float64) - o["discriminant_score"]))
-    assert abs(offset) < 1e-3, (context, offset)
-    assert np.allclose(g.discriminant_score - offset, o["discriminant_score"], rtol=1e-5, atol=1e-5), context
-    bad = np.abs(g.posterior_error - o["posterior_error"]) > 2e-3
-    assert bad.mean() <= 1e-3, (context, int(bad.sum()), g.posterior_error[bad][:5], o["posterior_error"][bad][:5])
+        assert _same(g.coef, o["coef"]), (context, g.coef, o["coef"])  # f64, bit for bit
+    assert _same(g.discriminant_score, o["discriminant_score"]), (context, np.flatnonzero(g.discriminant_score != o["discriminant_score"])[:5])
+    pe_g, pe_o = g.posterior_error.astype(np.float64), o["posterior_error"].astype(np.float64)
+    assert np.all(np.abs(pe_g - pe_o) <= 2.5e-7 * np.maximum(np.abs(pe_o), 1e-30)), (context, np.abs(pe_g - pe_o).max())
     for name, got, exp in (("spectrum_q", g.spectrum_q, o["spectrum_q"]), ("peptide_q", g.peptide_q, o["peptide_q"]),
                            ("protein_q", g.protein_q, o["protein_q"])):
-        both_nan = np.isnan(got) & np.isnan(exp)
-        close = both_nan | np.isclose(got, exp, rtol=1e-4, atol=1e-7)
-        assert (~close).mean() <= 1e-3, (context, name, int((~close).sum()), got[~close][:5], exp[~close][:5])
-    # the output order: a permutation, descending, and the same as the oracle's wherever scores are not near-tied
-    assert sorted(g.order.tolist()) == list(range(n)), context
-    assert np.all(np.diff(g.discriminant_score[g.order]) <= 0), context
-    assert (g.order != o["order"]).mean() <= 1e-2, context
-    for got, exp in zip((g.passing_spectrum, g.passing_peptide, g.passing_protein), o["passing"]):
-        assert abs(int(got) - int(exp)) <= max(2, int(exp) // 500), (context, got, exp)
+        assert _same(got, exp), (context, name, np.flatnonzero(got != exp)[:5])
+    assert np.array_equal(g.order, o["order"]), context
+    assert (int(g.passing_spectrum), int(g.passing_peptide), int(g.passing_protein)) == tuple(int(x) for x in o["passing"]), context
     return g, o
 
 
@@ -73,14 +66,15 @@ def test_rescore_fallback_paths(gpu_required):
     f, pk, npk, prk, npr = synthetic_features(5000, seed=11, decoy_frac=0.0)
     g, o = compare(f, Tolerance("ppm", -10.0, 10.0), pk, npk, prk, npr, "no decoys")
     assert not g.lda_fitted and np.all(g.posterior_error == 1.0)
-    # constant ims column: whether the reference's solve succeeds depends on rounding noise in the last pivots (see
-    # tests/test_rescore_oracle.py); parity is required only when both sides take the same branch
-    f, pk, npk, prk, npr = synthetic_features(4000, seed=3, zero_ims=True)
+    # constant ims column (the normal case without ion mobility): the elimination meets exact zeros and rounding noise among
+    # its pivot candidates; the device must take the oracle's branch whatever it is, on every one of these data sets
     tol = Tolerance("ppm", -10.0, 10.0)
-    g = rescore(f, tol, pk, npk, prk, npr)
-    o = oracle_lib.rescore(f, tol, pk, npk, prk, npr)
-    if g.lda_fitted == o["lda_fitted"]:
-        compare(f, tol, pk, npk, prk, npr, "zero ims")
+    branches = set()
+    for n, seed in ((4000, 3), (900, 14), (12000, 15), (50000, 16), (2500, 17)):
+        f, pk, npk, prk, npr = synthetic_features(n, seed=seed, zero_ims=True)
+        g, _ = compare(f, tol, pk, npk, prk, npr, f"zero ims n={n} seed={seed}")
+        branches.add(bool(g.lda_fitted))
+    assert branches  # (which branches occur is data; both are legitimate)
 
 
 def test_rescore_rejects_sparse_keys_and_pct(gpu_required):
@@ -110,9 +104,7 @@ def test_search_then_rescore_end_to_end(gpu_required):
     flat = np.concatenate([feats[i, :counts[i]] for i in range(len(counts))])
     assert len(flat) > 1000 and (flat["label"] == -1).any()
     pk, npk, prk, npr = host.competition_keys(flat["peptide_idx"])
-    g, o = compare(flat, tol, pk, npk, prk, npr, "end to end")
-    # (whether the linear model is fitted here is up to the reference's pivot search: ims is constant, see
-    # tests/test_rescore_oracle.py — either way true matches are found at 1 %)
+    g, o = compare(flat, tol, pk, npk, prk, npr, "end to end")  # (asserts lda_fitted equal: ims is constant here)
     assert g.passing_spectrum > 100
 
 
