@@ -11,8 +11,10 @@
  *   - every function returns a status code (SAGE_HIP_OK == 0) instead of panicking
  *     (the reference panics at scoring.rs:261-267, 301-304, 466-468); sage_hip_last_error() gives
  *     the message of the last failure on the calling thread;
- *   - one SageScorer handle may be used from one host thread at a time; use one handle per device
- *     for multi-GPU (spectra sharded, index replicated, no collective on the data path).
+ *   - a SageScorer handle may be shared by any number of host threads, like `&Scorer` (scoring.rs:300 is called from every
+ *     rayon worker): calls on ONE handle run one after the other; sage_hip_scorer_clone() gives a thread its own handle
+ *     (own streams and working set, same device database) when batches should be scored concurrently.  Use one device
+ *     database + scorer per device for multi-GPU (spectra sharded, index replicated, no collective on the data path).
  *   - there is NO CPU fallback: scoring entry points fail with SAGE_HIP_ERR_NO_DEVICE when no
  *     gfx950 device is usable.
  */
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAGE_HIP_ABI_VERSION 3
+#define SAGE_HIP_ABI_VERSION 4
 
 enum {
     SAGE_HIP_OK = 0,
@@ -172,6 +174,9 @@ typedef struct SageScorerParams {
 } SageScorerParams;
 
 int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* params, SageScorer** out);
+/* A second handle with the same parameters on the same device database (`&Scorer` is Sync: runner.rs:311-325 calls score from
+ * every worker thread).  Handles are independent: own streams, own device working set. */
+int sage_hip_scorer_clone(SageScorer* scorer, SageScorer** out);
 void sage_hip_scorer_destroy(SageScorer* scorer);
 
 /* A batch of ProcessedSpectrum (spectrum.rs:57-79) + precursors[0] (spectrum.rs:46-55), SoA.
@@ -208,7 +213,13 @@ typedef struct SageFeature {
 } SageFeature;
 
 /* Scorer::score for every spectrum of the batch (scoring.rs:300-309), results in input order:
- * out[i*report_psms + r] for r < out_count[i].  Uploads, scores, downloads. */
+ * out[i*report_psms + r] for r < out_count[i], Feature.spec_index == i.
+ * Host memory in, host memory out, as a three-stage pipeline over chunks of the batch (SAGE_HIP_CHUNK spectra, default 65536):
+ * chunk c + 1 is staged and uploaded on a copy stream while chunk c is scored and the PSM records of chunk c - 1 come back —
+ * the reader / processor / search overlap of runner.rs:365-375, 450-461 at the PCIe boundary.  Arrays allocated with
+ * sage_hip_host_alloc (page-locked) move by DMA at full PCIe rate; pageable arrays are accepted and staged through
+ * page-locked blocks by a few host threads.  A chunk whose large-window candidates exhaust the device arena is scored again
+ * in halves (never an error unless a single spectrum does not fit). */
 int sage_hip_score_batch(SageScorer* scorer, const SageSpectrumBatch* batch, SageFeature* out,
                          uint32_t* out_count);
 

@@ -512,7 +512,14 @@ std::string Peptide::to_string() const {  // peptide.rs:391-408
 // ---------------------------------------------------------------------------
 // ion_series.rs:36-85
 // ---------------------------------------------------------------------------
+void ion_series_into(const Peptide& p, Kind kind, std::vector<float>& out);
 std::vector<float> ion_series(const Peptide& p, Kind kind) {
+    std::vector<float> out;
+    ion_series_into(p, kind, out);
+    return out;
+}
+void ion_series_into(const Peptide& p, Kind kind, std::vector<float>& out) {
+    out.clear();
     const float C = 12.0f, O = 15.994914f, H = 1.007825f, PRO = 1.0072764f, N = 14.003074f;
     const float NH3 = N + H * 2.0f + PRO;
     float nterm = p.nterm.value_or(0.0f);
@@ -525,15 +532,13 @@ std::vector<float> ion_series(const Peptide& p, Kind kind) {
         case Kind::Y: cum = p.monoisotopic - nterm; break;
         default: cum = p.monoisotopic - nterm - NH3; break;  // Z
     }
-    std::vector<float> out;
-    if (p.sequence.empty()) return out;
+    if (p.sequence.empty()) return;
     for (size_t idx = 0; idx + 1 < p.sequence.size(); idx++) {
         float r = monoisotopic((uint8_t)p.sequence[idx]);
         float m = p.modifications[idx];
         if (is_nterm_kind(kind)) cum += r + m; else cum += -(r + m);
         out.push_back(cum);
     }
-    return out;
 }
 
 // ---------------------------------------------------------------------------
@@ -685,8 +690,15 @@ static uint64_t ceil_log2(uint64_t x) {  // ceil(log2(x)) for x >= 1
     return n;
 }
 
-void IndexedQuery::page_search(float mass, const std::function<void(const Theoretical&)>& f,
-                               WorkCounters* wc) const {  // database.rs:480-536
+// database.rs:480-536, with the consumer of the yielded fragments as a template parameter: the scoring loop passes its
+// closure directly (inlined, like the reference's iterator chain); IndexedQuery::page_search wraps it for other callers
+template <class F>
+static inline void page_search_impl(const IndexedQuery& q, float mass, F&& f, WorkCounters* wc) {
+    const IndexedDatabase* db = q.db;
+    const Tolerance& fragment_tol = q.fragment_tol;
+    const Tolerance& precursor_tol = q.precursor_tol;
+    const float precursor_mass = q.precursor_mass;
+    const size_t pre_idx_lo = q.pre_idx_lo, pre_idx_hi = q.pre_idx_hi;
     auto fb = fragment_tol.bounds(mass);
     auto pb = precursor_tol.bounds(precursor_mass);
     float fragment_lo = fb.first, fragment_hi = fb.second;
@@ -731,6 +743,11 @@ void IndexedQuery::page_search(float mass, const std::function<void(const Theore
             }
         }
     }
+}
+
+void IndexedQuery::page_search(float mass, const std::function<void(const Theoretical&)>& f,
+                               WorkCounters* wc) const {
+    page_search_impl(*this, mass, f, wc);
 }
 
 // ---------------------------------------------------------------------------
@@ -931,8 +948,8 @@ InitialHits Scorer::matched_peaks_with_isotope(const ProcessedSpectrum& query, f
     for (float peak_mass : query.masses) {
         for (unsigned charge = 1; charge < mfc; charge++) {
             float mass = peak_mass * (float)charge;
-            candidates.page_search(
-                mass,
+            page_search_impl(
+                candidates, mass,
                 [&](const Theoretical& frag) {
                     size_t idx = (size_t)frag.peptide_index - candidates.pre_idx_lo;
                     PreScore& sc = hits.preliminary[idx];
@@ -1005,8 +1022,9 @@ std::pair<Score, std::optional<Fragments>> Scorer::score_candidate(const Process
     }
     Run b_run, y_run;
     Fragments details;
+    static thread_local std::vector<float> ions;  // (the reference's IonSeries is an iterator: no allocation per candidate)
     for (Kind kind : db->ion_kinds) {
-        std::vector<float> ions = ion_series(peptide, kind);
+        ion_series_into(peptide, kind, ions);
         for (size_t idx = 0; idx < ions.size(); idx++) {
             for (unsigned charge = 1; charge < mfc; charge++) {
                 float mz = ions[idx] / (float)charge;

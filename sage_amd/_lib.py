@@ -243,6 +243,7 @@ def load():
         "sage_hip_db_device_bytes": (C.c_uint64, [vp]),
         "sage_hip_scorer_create": (C.c_int, [vp, C.POINTER(SageScorerParams), C.POINTER(vp)]),
         "sage_hip_scorer_destroy": (None, [vp]),
+        "sage_hip_scorer_clone": (C.c_int, [vp, C.POINTER(vp)]),
         "sage_hip_score_batch": (C.c_int, [vp, C.POINTER(SageSpectrumBatch), vp, c_u32_p]),
         "sage_hip_batch_upload": (C.c_int, [vp, C.POINTER(SageSpectrumBatch), C.POINTER(vp)]),
         "sage_hip_batch_free": (None, [vp]),
@@ -285,7 +286,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_last_error", "sage_hip_abi_version", "sage_hip_hostdb_build", "sage_hip_hostdb_free",
     "sage_hip_hostdb_view", "sage_hip_hostdb_peptide_string", "sage_hip_hostdb_peptide_proteins",
     "sage_hip_hostdb_peptide_info", "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
-    "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_score_batch",
+    "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_scorer_clone", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
     "sage_hip_rescore", "sage_hip_hostdb_competition_keys", "sage_hip_fasta_num_targets", "sage_hip_prefilter_chunk_size",

@@ -382,6 +382,42 @@ class SpectrumBatch:
             [nan if s.inverse_ion_mobility is None else s.inverse_ion_mobility for s in spectra],
             [s.file_id for s in spectra])
 
+    def page_locked(self) -> "SpectrumBatch":
+        """The same batch with every array in page-locked host memory (sage_hip_host_alloc): Scorer.score then moves the
+        peaks by DMA straight out of these arrays instead of staging them.  What a caller that owns its spectrum arena
+        (the mzML reader, a Rust Vec allocated through the C ABI) would hand over."""
+        lib = L.load()
+        keep = []
+
+        def lock(a):
+            if a is None:
+                return None
+            p = C.c_void_p()
+            L.check(lib.sage_hip_host_alloc(max(a.nbytes, 1), C.byref(p)))
+            out = np.frombuffer((C.c_char * max(a.nbytes, 1)).from_address(p.value), dtype=a.dtype, count=a.size).reshape(a.shape)
+            out[...] = a
+            keep.append(p)
+            return out
+
+        b = SpectrumBatch.__new__(SpectrumBatch)
+        for k in ("peak_off", "masses", "intensities", "precursor_mz", "precursor_charge", "total_ion_current", "isolation_lo",
+                  "isolation_hi", "scan_start_time", "inverse_ion_mobility", "file_id"):
+            setattr(b, k, lock(getattr(self, k)))
+        b.n = self.n
+        b._locked = keep
+        return b
+
+    def __del__(self):
+        locked = getattr(self, "_locked", None)
+        if locked:
+            try:
+                lib = L.load()
+                for p in locked:
+                    lib.sage_hip_host_free(p)
+            except Exception:
+                pass
+            self._locked = None
+
     def subset(self, idx) -> "SpectrumBatch":
         idx = np.asarray(idx)
         lens = (self.peak_off[1:] - self.peak_off[:-1])[idx].astype(np.int64)
@@ -561,6 +597,14 @@ class Scorer:
         cp = params.to_c()
         L.check(lib.sage_hip_scorer_create(db._h, C.byref(cp), C.byref(self._h)))
 
+    def clone(self) -> "Scorer":
+        """A second handle on the same device database (own streams and working set): `&Scorer` is shared by every rayon
+        worker in the reference (scoring.rs:300); calls on one handle serialise, clones run concurrently."""
+        other = Scorer.__new__(Scorer)
+        other.db, other.params, other._h = self.db, self.params, C.c_void_p()
+        L.check(L.load().sage_hip_scorer_clone(self._h, C.byref(other._h)))
+        return other
+
     def upload(self, batch: SpectrumBatch) -> DeviceBatch:
         return DeviceBatch(self, batch)
 
@@ -611,10 +655,15 @@ class Scorer:
                                             L.as_ptr(counts, C.c_uint32)))
         return feats.reshape(dbatch.n, self.params.report_psms), counts
 
-    def score(self, batch: SpectrumBatch):
-        """Vec<Feature> per spectrum: returns (features[n, report_psms], counts[n])."""
+    def score(self, batch: SpectrumBatch, pinned_out: bool = True):
+        """Vec<Feature> per spectrum: returns (features[n, report_psms], counts[n]).  Host arrays in, host arrays out, through
+        the upload / score / download pipeline of sage_hip_score_batch.  pinned_out=False: plain (pageable) result arrays."""
         lib = L.load()
-        feats, counts = self._alloc_out(batch.n)
+        if pinned_out:
+            feats, counts = self._alloc_out(batch.n)
+        else:
+            feats = np.zeros(batch.n * self.params.report_psms, dtype=L.FEATURE_DTYPE)
+            counts = np.zeros(batch.n, dtype=np.uint32)
         cb = batch.to_c()
         L.check(lib.sage_hip_score_batch(self._h, C.byref(cb), feats.ctypes.data_as(C.c_void_p),
                                          L.as_ptr(counts, C.c_uint32)))

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,7 +53,52 @@ struct DevBuf {
         if (e != hipSuccess) return e;
         return count ? hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
     }
+    // grow-only: keep the allocation when it is large enough (no driver call on the steady-state path)
+    hipError_t reserve(size_t count) {
+        if (p && count <= n) return hipSuccess;
+        return alloc(std::max(count, n + n / 2));
+    }
     size_t bytes() const { return n * sizeof(T); }
+};
+
+// page-locked host block, grow-only (staging of the streaming pipeline: DMA at full PCIe rate)
+struct Pinned {
+    unsigned char* p = nullptr;
+    size_t cap = 0;
+    Pinned() = default;
+    Pinned(const Pinned&) = delete;
+    Pinned& operator=(const Pinned&) = delete;
+    ~Pinned() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t reserve(size_t bytes) {
+        if (p && bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
+template <class T>
+T* carve(unsigned char*& cur, size_t count) {  // next 64-byte aligned array of a staging block
+    T* p = (T*)cur;
+    cur += ((count * sizeof(T) + 63) / 64) * 64;
+    return p;
+}
+
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() = default;
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
+    ~Event() {
+        if (e) (void)hipEventDestroy(e);
+    }
+    hipError_t create(bool timing) { return e ? hipSuccess : hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming); }
 };
 
 }  // namespace
@@ -79,30 +125,36 @@ struct SageDeviceDb {
     uint64_t bytes = 0;
 };
 
-struct SageScorer {
-    SageDeviceDb* db = nullptr;
-    SageScorerParams params{};
-    DevScorer dev{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {};
-    DevBuf<double> lnfact;
-    DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
-    uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel
-    SageTiming timing{};
-    // per-batch work buffers, grown on demand
+// Device-side working set of ONE scoring pass pair (device_types.h: DevWork).  Kernels of successive batches run in order on
+// one compute stream, so a scorer needs a single set whatever the number of batches in flight.
+struct WorkSet {
     DevBuf<uint64_t> cand;
-    DevBuf<uint32_t> cand_len, totals, status, n_deferred, out_count, queue, retry;
-    bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
-    // large-window pipeline scratch (device_types.h: DevWork)
+    DevBuf<uint32_t> cand_len, totals, status, queue, retry;
     DevBuf<QueryRec> qrec;
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
     DevBuf<uint32_t> arena;
-    DevBuf<TileParams> tile_params;
-    uint32_t qmax = 1;
+    uint32_t cap_n = 0;
+};
+
+// What a batch leaves behind: PSM records, counters, timing events.  Double-buffered by the streaming pipeline (batch c + 1 is
+// scored while the records of batch c cross PCIe).
+struct OutSet {
     DevBuf<SageFeature> features;
-    uint32_t work_n = 0;
-    uint32_t* h_counters = nullptr;  // pinned [2]: deferred, overflow
+    DevBuf<uint32_t> out_count;
+    DevBuf<uint32_t> counters;       // [2 * CTR_COUNT]: first pass, exact retry pass
+    DevBuf<TileParams> tile_params;  // [2]
+    uint32_t* h_counters = nullptr;  // pinned [2 * CTR_COUNT]
+    TileParams* h_tile_params = nullptr;  // pinned [2]
+    Pinned h_out;                    // landing block for the records when the caller's arrays are pageable
+    Event ev[5];                     // start, prelim 1, rescore 1, prelim 2, rescore 2
+    Event comp_done, down_done;
+    bool in_flight = false, two_pass = false, with_rescore = false;
+    uint32_t n = 0;
+    ~OutSet() {
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (h_tile_params) (void)hipHostFree(h_tile_params);
+    }
 };
 
 struct SageDeviceBatch {
@@ -111,8 +163,37 @@ struct SageDeviceBatch {
     DevBuf<uint64_t> peak_off;
     DevBuf<float> masses, intensities, precursor_mz, iso_lo, iso_hi, tic, rt, ims;
     DevBuf<uint8_t> charge;
-    DevBuf<uint32_t> file_id, order;
+    DevBuf<uint32_t> file_id, order, sort_a, sort_b, sort_idx;
+    DevBuf<uint8_t> sort_tmp;
+    Pinned stage;      // host staging of the arrays above (everything but the peaks when those are already page-locked)
+    Event up_done;     // uploads of this batch finished (its staging block may be refilled)
     DevBatchView view{};
+};
+
+struct SageScorer {
+    SageDeviceDb* db = nullptr;
+    SageScorerParams params{};
+    DevScorer dev{};
+    std::mutex mu;                   // entry points taking this handle serialise on it (clone the scorer for concurrency)
+    hipStream_t stream = nullptr;    // compute (and, for resident batches, the result download)
+    hipStream_t up_stream = nullptr, down_stream = nullptr;  // streaming pipeline: H2D of batch c + 1, D2H of batch c - 1
+    DevBuf<double> lnfact;
+    DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
+    uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel
+    SageTiming timing{};
+    bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
+    uint32_t qmax = 1;
+    WorkSet ws;
+    OutSet outs[2];
+    SageDeviceBatch slots[2];   // input double buffer of the streaming pipeline
+    uint32_t chunk = 65536;     // spectra per pipeline stage (SAGE_HIP_CHUNK)
+    // scratch of sage_hip_annotate_resident / sage_hip_quick_score_resident, grow-only
+    DevBuf<SageFeature> an_feats;
+    DevBuf<uint32_t> an_counts;
+    DevBuf<uint64_t> an_off;
+    DevBuf<uint8_t> an_kinds, keep;
+    DevBuf<int32_t> an_charges, an_ord;
+    DevBuf<float> an_int, an_calc, an_exp;
 };
 
 extern "C" {
@@ -528,16 +609,8 @@ void sage_hip_db_destroy(SageDeviceDb* db) {
 }
 uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db) { return db ? db->bytes : 0; }
 
-int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
-    if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
-    if (p->report_psms > 32) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32 (k-select wider than one wavefront)");
-    if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
-    if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
-        return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
-    if (p->score_type != 0 && p->score_type != 1) return fail(SAGE_HIP_ERR_INVALID, "unknown score_type");
-    HIP_TRY(hipSetDevice(db->device));
-    auto s = std::make_unique<SageScorer>();
+static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams* p) {
+    SageScorer* s = sp;
     s->db = db;
     s->params = *p;
     DevScorer& d = s->dev;
@@ -564,8 +637,23 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
     d.exact = 0;
     if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
+    if (const char* e = getenv("SAGE_HIP_CHUNK")) s->chunk = (uint32_t)std::min(1 << 22, std::max(64, atoi(e)));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
+    for (OutSet& o : s->outs) {
+        for (auto& e : o.ev) HIP_TRY(e.create(true));
+        HIP_TRY(o.comp_done.create(false));
+        HIP_TRY(o.down_done.create(false));
+        HIP_TRY(o.counters.alloc(2 * CTR_COUNT));
+        HIP_TRY(o.tile_params.alloc(2));
+        HIP_TRY(hipHostMalloc((void**)&o.h_counters, 2 * CTR_COUNT * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&o.h_tile_params, 2 * sizeof(TileParams), hipHostMallocDefault));
+    }
+    for (SageDeviceBatch& b : s->slots) {
+        b.device = db->device;
+        HIP_TRY(b.up_done.create(false));
+    }
     // lnfact (scoring.rs:170-177) tabulated with the host libm so the factorial terms are bit-identical
     // to a CPU evaluation
     std::vector<double> tbl(4096);
@@ -586,138 +674,259 @@ int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScor
         HIP_TRY((hipError_t)tile_kernel_prepare(160 * 1024));
     }
     s->qmax = queries_per_spectrum(d);
-    HIP_TRY(s->n_deferred.alloc(CTR_COUNT));
-    HIP_TRY(s->tile_params.alloc(1));
-    HIP_TRY(hipHostMalloc((void**)&s->h_counters, CTR_COUNT * 4, hipHostMallocDefault));
     if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
         if (atoi(e) > 0) {
             HIP_TRY(s->dbg.alloc(4096 * 32));
             HIP_TRY(hipMemset(s->dbg.p, 0, 4096 * 32 * 8));
         }
     }
-    *out = s.release();
     return SAGE_HIP_OK;
+}
+
+static void scorer_release(SageScorer* s) {
+    (void)hipSetDevice(s->db->device);
+    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    delete s;
+}
+
+int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
+    if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
+    if (p->report_psms > 32) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32 (k-select wider than one wavefront)");
+    if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
+    if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
+        return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
+    if (p->score_type != 0 && p->score_type != 1) return fail(SAGE_HIP_ERR_INVALID, "unknown score_type");
+    HIP_TRY(hipSetDevice(db->device));
+    SageScorer* s = new SageScorer();
+    const int rc = scorer_init(s, db, p);
+    if (rc != SAGE_HIP_OK) {
+        s->db = db;
+        scorer_release(s);
+        return rc;
+    }
+    *out = s;
+    return SAGE_HIP_OK;
+}
+
+// Scorer::score takes &self and is called from every rayon worker at once (scoring.rs:300, runner.rs:311-325).  One handle
+// may be shared between host threads — its calls then run one after the other — and a clone is a second handle on the same
+// device database with its own streams and working set, for callers that want their batches scored concurrently.
+int sage_hip_scorer_clone(SageScorer* scorer, SageScorer** out) {
+    if (!scorer || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    return sage_hip_scorer_create(scorer->db, &scorer->params, out);
 }
 
 void sage_hip_scorer_destroy(SageScorer* s) {
     if (!s) return;
-    (void)hipSetDevice(s->db->device);
-    for (auto& e : s->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->h_counters) (void)hipHostFree(s->h_counters);
-    delete s;
+    scorer_release(s);
 }
 
-// precursor-side arrays, launch schedule, kernel variant and the view of a batch whose peak arrays are already on the device
-static int finish_batch(SageScorer* s, SageDeviceBatch* d, uint32_t n, const float* precursor_mz, const uint8_t* precursor_charge,
-                        const float* isolation_lo, const float* isolation_hi, const float* scan_start_time,
-                        const float* inverse_ion_mobility, const uint32_t* file_id, uint32_t pcap) {
-    uint32_t zmax = 0;
-    bool any_unknown = false;
-    for (uint32_t i = 0; i < n; i++) {
-        zmax = std::max<uint32_t>(zmax, precursor_charge[i]);
-        any_unknown = any_unknown || precursor_charge[i] == 0;
+// ---- batches ---------------------------------------------------------------------------------------------------------------
+static bool is_page_locked(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain pageable memory: "invalid value", not an error for us
+        return false;
     }
-    // largest fragment charge any spectrum of this batch can ask for (scoring.rs:239-247)
-    uint32_t fzcap = 1;
+    return at.type == hipMemoryTypeHost;
+}
+
+// narrow-kernel variant for a batch: mean candidate-window size of (a sample of) its spectra, first query each
+static uint32_t choose_probe(const SageScorer* s, uint32_t n, const float* precursor_mz, const uint8_t* precursor_charge,
+                             const float* isolation_lo, const float* isolation_hi) {
     const SageScorerParams& p = s->params;
+    const std::vector<float>& pm = s->db->h_pep_mono;
+    const uint32_t step = std::max<uint32_t>(1, n / 2048);
+    double sum = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < n; i += step, cnt++) {
+        const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
+        const float center = (precursor_mz[i] - sagecore::PROTON) * (float)z;
+        sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
+        if (p.wide_window) {
+            float lo = -2.4f, hi = 2.4f;
+            if (isolation_lo && isolation_hi && isolation_lo[i] == isolation_lo[i] && isolation_hi[i] == isolation_hi[i]) {
+                lo = isolation_lo[i];
+                hi = isolation_hi[i];
+            }
+            tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
+        }
+        float lo, hi;
+        sagecore::tol_bounds(tol, center, lo, hi);
+        sum += (double)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
+    }
+    const double mean_window = cnt ? sum / cnt : 0.0;
+    uint32_t probe = mean_window > 96.0 ? 1u : 0u;
+    if (const char* e = getenv("SAGE_HIP_NARROW")) probe = std::string(e) == "probe" ? 1u : std::string(e) == "stream" ? 0u : probe;
+    return probe;
+}
+
+// largest fragment charge any spectrum of a batch can ask for (scoring.rs:239-247)
+static uint32_t batch_fzcap(const SageScorerParams& p, uint32_t zmax, bool any_unknown) {
+    uint32_t fzcap = 1;
     const bool ranged = p.wide_window || p.override_precursor_charge || any_unknown;
     for (uint32_t z = 1; z <= 255; z++) {
         const bool used = (ranged && z >= p.min_precursor_charge && z <= p.max_precursor_charge) ||
                           (!p.wide_window && !p.override_precursor_charge && z <= zmax);
         if (used) fzcap = std::max(fzcap, sagecore::max_fragment_charge(p.max_fragment_charge, z) - 1);
     }
-    // schedule spectra by ascending neutral precursor mass: wavefronts resident together then read
-    // overlapping ranges of the index and of the ion table (outputs keep input order)
-    std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; i++) order[i] = i;
-    {
-        std::vector<float> key(n);
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
-            key[i] = (precursor_mz[i] - sagecore::PROTON) * (float)z;
+    return fzcap;
+}
+
+// Spectra [c0, c1) of a host batch -> the device arrays of `d`, asynchronously on `up`:
+//   * the per-spectrum arrays (40 bytes per spectrum) are staged through d's page-locked block (peak offsets rebased to the
+//     range, the launch limits pcap / fzcap found on the way);
+//   * the peak arrays go by DMA straight from the caller's memory when it is page-locked (sage_hip_host_alloc), else through
+//     the staging block (copied by a few host threads).
+// The caller must have waited for d->up_done before (the staging block is being rewritten).  `probe`: narrow-kernel variant.
+static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectrumBatch* b, uint32_t c0, uint32_t c1, bool peaks_locked,
+                            uint32_t probe, hipStream_t up) {
+    const uint32_t n = c1 - c0;
+    const uint64_t base = n ? b->peak_off[c0] : 0, total = n ? b->peak_off[c1] - base : 0;
+    if (n && b->peak_off[c1] < base) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
+    const bool has_iso = b->isolation_lo && b->isolation_hi, has_rt = b->scan_start_time != nullptr,
+               has_ims = b->inverse_ion_mobility != nullptr, has_fid = b->file_id != nullptr;
+    d->n = n;
+    HIP_TRY(d->peak_off.reserve((size_t)n + 1));
+    HIP_TRY(d->masses.reserve(total));
+    HIP_TRY(d->intensities.reserve(total));
+    HIP_TRY(d->precursor_mz.reserve(n));
+    HIP_TRY(d->charge.reserve(n));
+    HIP_TRY(d->tic.reserve(n));
+    if (has_iso) {
+        HIP_TRY(d->iso_lo.reserve(n));
+        HIP_TRY(d->iso_hi.reserve(n));
+    }
+    if (has_rt) HIP_TRY(d->rt.reserve(n));
+    if (has_ims) HIP_TRY(d->ims.reserve(n));
+    if (has_fid) HIP_TRY(d->file_id.reserve(n));
+    HIP_TRY(d->order.reserve(n));
+    HIP_TRY(d->sort_a.reserve(n));
+    HIP_TRY(d->sort_b.reserve(n));
+    HIP_TRY(d->sort_idx.reserve(n));
+    const size_t sort_bytes = schedule_temp_bytes(n);
+    HIP_TRY(d->sort_tmp.reserve(sort_bytes));
+    const size_t small = ((size_t)n + 1) * 8 + (size_t)n * (4 * 7 + 1) + 64 * 12;
+    HIP_TRY(d->stage.reserve(small + (peaks_locked ? 0 : total * 8 + 128)));
+    unsigned char* cur = d->stage.p;
+    uint64_t* h_off = carve<uint64_t>(cur, (size_t)n + 1);
+    float* h_mz = carve<float>(cur, n);
+    uint8_t* h_z = carve<uint8_t>(cur, n);
+    float* h_tic = carve<float>(cur, n);
+    float* h_lo = has_iso ? carve<float>(cur, n) : nullptr;
+    float* h_hi = has_iso ? carve<float>(cur, n) : nullptr;
+    float* h_rt = has_rt ? carve<float>(cur, n) : nullptr;
+    float* h_ims = has_ims ? carve<float>(cur, n) : nullptr;
+    uint32_t* h_fid = has_fid ? carve<uint32_t>(cur, n) : nullptr;
+    uint32_t pcap = 1, zmax = 0;
+    bool any_unknown = false;
+    h_off[0] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t a = b->peak_off[c0 + i], e = b->peak_off[c0 + i + 1];
+        if (e < a) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
+        h_off[i + 1] = e - base;
+        pcap = std::max<uint32_t>(pcap, (uint32_t)std::min<uint64_t>(e - a, 0xFFFFFFFFull));
+        const uint8_t z = b->precursor_charge[c0 + i];
+        zmax = std::max<uint32_t>(zmax, z);
+        any_unknown = any_unknown || z == 0;
+    }
+    if (n) {
+        std::memcpy(h_mz, b->precursor_mz + c0, (size_t)n * 4);
+        std::memcpy(h_z, b->precursor_charge + c0, n);
+        std::memcpy(h_tic, b->total_ion_current + c0, (size_t)n * 4);
+        if (has_iso) {
+            std::memcpy(h_lo, b->isolation_lo + c0, (size_t)n * 4);
+            std::memcpy(h_hi, b->isolation_hi + c0, (size_t)n * 4);
         }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return key[a] < key[c]; });
+        if (has_rt) std::memcpy(h_rt, b->scan_start_time + c0, (size_t)n * 4);
+        if (has_ims) std::memcpy(h_ims, b->inverse_ion_mobility + c0, (size_t)n * 4);
+        if (has_fid) std::memcpy(h_fid, b->file_id + c0, (size_t)n * 4);
     }
-    // narrow-kernel variant for this batch: mean candidate-window size of (a sample of) its spectra, first query each
-    {
-        const std::vector<float>& pm = s->db->h_pep_mono;
-        const uint32_t step = std::max<uint32_t>(1, n / 2048);
-        double sum = 0.0;
-        uint32_t cnt = 0;
-        for (uint32_t i = 0; i < n; i += step, cnt++) {
-            const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
-            const float center = (precursor_mz[i] - sagecore::PROTON) * (float)z;
-            sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
-            if (p.wide_window) {
-                float lo = -2.4f, hi = 2.4f;
-                if (isolation_lo && isolation_hi && isolation_lo[i] == isolation_lo[i] && isolation_hi[i] == isolation_hi[i]) {
-                    lo = isolation_lo[i];
-                    hi = isolation_hi[i];
-                }
-                tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
-            }
-            float lo, hi;
-            sagecore::tol_bounds(tol, center, lo, hi);
-            sum += (double)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
+    const float* src_m = b->masses ? b->masses + base : nullptr;
+    const float* src_i = b->intensities ? b->intensities + base : nullptr;
+    if (!peaks_locked && total) {
+        float* h_m = carve<float>(cur, total);
+        float* h_i = carve<float>(cur, total);
+        const float *pm_ = src_m, *pi_ = src_i;
+        parallel_for(total, 1u << 20, [&](size_t ib, size_t ie, unsigned) {
+            std::memcpy(h_m + ib, pm_ + ib, (ie - ib) * 4);
+            std::memcpy(h_i + ib, pi_ + ib, (ie - ib) * 4);
+        });
+        src_m = h_m;
+        src_i = h_i;
+    }
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d->peak_off.p, h_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d->precursor_mz.p, h_mz, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d->charge.p, h_z, n, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(d->tic.p, h_tic, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        if (has_iso) {
+            HIP_TRY(hipMemcpyAsync(d->iso_lo.p, h_lo, (size_t)n * 4, hipMemcpyHostToDevice, up));
+            HIP_TRY(hipMemcpyAsync(d->iso_hi.p, h_hi, (size_t)n * 4, hipMemcpyHostToDevice, up));
         }
-        const double mean_window = cnt ? sum / cnt : 0.0;
-        d->view.probe = mean_window > 96.0 ? 1u : 0u;
-        if (const char* e = getenv("SAGE_HIP_NARROW")) d->view.probe = std::string(e) == "probe" ? 1u : std::string(e) == "stream" ? 0u : d->view.probe;
+        if (has_rt) HIP_TRY(hipMemcpyAsync(d->rt.p, h_rt, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        if (has_ims) HIP_TRY(hipMemcpyAsync(d->ims.p, h_ims, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        if (has_fid) HIP_TRY(hipMemcpyAsync(d->file_id.p, h_fid, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        if (total) {
+            HIP_TRY(hipMemcpyAsync(d->masses.p, src_m, total * 4, hipMemcpyHostToDevice, up));
+            HIP_TRY(hipMemcpyAsync(d->intensities.p, src_i, total * 4, hipMemcpyHostToDevice, up));
+        }
+        // the launch schedule (ascending neutral precursor mass), sorted on the device right behind the uploads
+        HIP_TRY((hipError_t)schedule_on_device(n, d->precursor_mz.p, d->charge.p, s->params.min_precursor_charge, d->sort_a.p, d->sort_b.p,
+                                               d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, up));
     }
-    HIP_TRY(d->order.upload(order.data(), n));
-    HIP_TRY(d->precursor_mz.upload(precursor_mz, n));
-    HIP_TRY(d->charge.upload(precursor_charge, n));
-    if (isolation_lo && isolation_hi) {
-        HIP_TRY(d->iso_lo.upload(isolation_lo, n));
-        HIP_TRY(d->iso_hi.upload(isolation_hi, n));
-    }
-    if (scan_start_time) HIP_TRY(d->rt.upload(scan_start_time, n));
-    if (inverse_ion_mobility) HIP_TRY(d->ims.upload(inverse_ion_mobility, n));
-    if (file_id) HIP_TRY(d->file_id.upload(file_id, n));
+    HIP_TRY(hipEventRecord(d->up_done.e, up));
     DevBatchView& v = d->view;
+    v = DevBatchView{};
     v.n = n;
+    v.n_dev = nullptr;
+    v.spec_base = c0;
     v.peak_off = d->peak_off.p;
     v.masses = d->masses.p;
     v.intensities = d->intensities.p;
     v.precursor_mz = d->precursor_mz.p;
     v.precursor_charge = d->charge.p;
-    v.isolation_lo = d->iso_lo.p;
-    v.isolation_hi = d->iso_hi.p;
+    v.isolation_lo = has_iso ? d->iso_lo.p : nullptr;
+    v.isolation_hi = has_iso ? d->iso_hi.p : nullptr;
     v.tic = d->tic.p;
-    v.rt = d->rt.p;
-    v.ims = d->ims.p;
-    v.file_id = d->file_id.p;
+    v.rt = has_rt ? d->rt.p : nullptr;
+    v.ims = has_ims ? d->ims.p : nullptr;
+    v.file_id = has_fid ? d->file_id.p : nullptr;
     v.order = d->order.p;
+    v.probe = probe;
     v.pcap = pcap;
-    v.fzcap = fzcap;
+    v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
+    return SAGE_HIP_OK;
+}
+
+static int check_batch_args(const SageSpectrumBatch* b) {
+    if (b->n_spectra && (!b->peak_off || !b->precursor_mz || !b->precursor_charge || !b->total_ion_current))
+        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
+    const uint64_t total = b->n_spectra ? b->peak_off[b->n_spectra] - b->peak_off[0] : 0;
+    if (total && (!b->masses || !b->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
     return SAGE_HIP_OK;
 }
 
 int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceBatch** out) {
     if (!s || !b || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    if (b->n_spectra && (!b->peak_off || !b->precursor_mz || !b->precursor_charge || !b->total_ion_current))
-        return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
+    int rc = check_batch_args(b);
+    if (rc != SAGE_HIP_OK) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
     HIP_TRY(hipSetDevice(s->db->device));
     auto d = std::make_unique<SageDeviceBatch>();
     d->device = s->db->device;
+    HIP_TRY(d->up_done.create(false));
     const uint32_t n = b->n_spectra;
-    d->n = n;
-    const uint64_t total = n ? b->peak_off[n] : 0;
-    uint32_t pcap = 1;
-    for (uint32_t i = 0; i < n; i++) {
-        if (b->peak_off[i + 1] < b->peak_off[i]) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
-        pcap = std::max<uint32_t>(pcap, (uint32_t)(b->peak_off[i + 1] - b->peak_off[i]));
-    }
-    if (total && (!b->masses || !b->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
-    HIP_TRY(d->peak_off.upload(b->peak_off, n ? (size_t)n + 1 : 0));
-    HIP_TRY(d->masses.upload(b->masses, total));
-    HIP_TRY(d->intensities.upload(b->intensities, total));
-    HIP_TRY(d->tic.upload(b->total_ion_current, n));
-    int rc = finish_batch(s, d.get(), n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi,
-                          b->scan_start_time, b->inverse_ion_mobility, b->file_id, pcap);
+    const uint32_t probe = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    rc = stage_and_upload(s, d.get(), b, 0, n, is_page_locked(b->masses) && is_page_locked(b->intensities), probe, s->up_stream);
     if (rc != SAGE_HIP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->up_stream));
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -729,10 +938,11 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     if (n && (!raw->peak_off || !raw->precursor_mz || !raw->precursor_charge))
         return fail(SAGE_HIP_ERR_INVALID, "missing required spectrum arrays");
     if (take_top_n == 0 || take_top_n > 0xFFFFu) return fail(SAGE_HIP_ERR_INVALID, "take_top_n must be in [1, 65535]");
+    std::lock_guard<std::mutex> lock(s->mu);
     HIP_TRY(hipSetDevice(s->db->device));
     auto d = std::make_unique<SageDeviceBatch>();
     d->device = s->db->device;
-    d->n = n;
+    HIP_TRY(d->up_done.create(false));
     const uint64_t total = n ? raw->peak_off[n] : 0;
     uint32_t rcap = 1;
     for (uint32_t i = 0; i < n; i++) {
@@ -768,21 +978,59 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (out_npeaks) std::copy(counts.begin(), counts.end(), out_npeaks);
     std::vector<uint64_t> off((size_t)n + 1, 0);
-    uint32_t pcap = 1;
+    uint32_t pcap = 1, zmax = 0;
+    bool any_unknown = false;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t c = counts[i] >= min_peaks ? counts[i] : 0;  // runner.rs:313: too few peaks -> not searched
         off[i + 1] = off[i] + c;
         pcap = std::max(pcap, c);
+        zmax = std::max<uint32_t>(zmax, raw->precursor_charge[i]);
+        any_unknown = any_unknown || raw->precursor_charge[i] == 0;
     }
     HIP_TRY(d->peak_off.upload(off.data(), n ? (size_t)n + 1 : 0));
     HIP_TRY(d->masses.alloc(off[n]));
     HIP_TRY(d->intensities.alloc(off[n]));
     launch_compact(n, d->peak_off.p, stride, sm.p, si.p, d->masses.p, d->intensities.p, s->stream);
     HIP_TRY(hipGetLastError());
+    // precursor-side arrays and the launch schedule
+    d->n = n;
+    HIP_TRY(d->precursor_mz.upload(raw->precursor_mz, n));
+    HIP_TRY(d->charge.upload(raw->precursor_charge, n));
+    const bool has_iso = raw->isolation_lo && raw->isolation_hi;
+    if (has_iso) {
+        HIP_TRY(d->iso_lo.upload(raw->isolation_lo, n));
+        HIP_TRY(d->iso_hi.upload(raw->isolation_hi, n));
+    }
+    if (raw->scan_start_time) HIP_TRY(d->rt.upload(raw->scan_start_time, n));
+    if (raw->inverse_ion_mobility) HIP_TRY(d->ims.upload(raw->inverse_ion_mobility, n));
+    if (raw->file_id) HIP_TRY(d->file_id.upload(raw->file_id, n));
+    HIP_TRY(d->order.alloc(n));
+    HIP_TRY(d->sort_a.alloc(n));
+    HIP_TRY(d->sort_b.alloc(n));
+    HIP_TRY(d->sort_idx.alloc(n));
+    const size_t sort_bytes = schedule_temp_bytes(n);
+    HIP_TRY(d->sort_tmp.alloc(sort_bytes));
+    HIP_TRY((hipError_t)schedule_on_device(n, d->precursor_mz.p, d->charge.p, s->params.min_precursor_charge, d->sort_a.p, d->sort_b.p,
+                                           d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    int rc = finish_batch(s, d.get(), n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi,
-                          raw->scan_start_time, raw->inverse_ion_mobility, raw->file_id, pcap);
-    if (rc != SAGE_HIP_OK) return rc;
+    DevBatchView& v = d->view;
+    v = DevBatchView{};
+    v.n = n;
+    v.peak_off = d->peak_off.p;
+    v.masses = d->masses.p;
+    v.intensities = d->intensities.p;
+    v.precursor_mz = d->precursor_mz.p;
+    v.precursor_charge = d->charge.p;
+    v.isolation_lo = has_iso ? d->iso_lo.p : nullptr;
+    v.isolation_hi = has_iso ? d->iso_hi.p : nullptr;
+    v.tic = d->tic.p;
+    v.rt = raw->scan_start_time ? d->rt.p : nullptr;
+    v.ims = raw->inverse_ion_mobility ? d->ims.p : nullptr;
+    v.file_id = raw->file_id ? d->file_id.p : nullptr;
+    v.order = d->order.p;
+    v.probe = choose_probe(s, n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi);
+    v.pcap = pcap;
+    v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -805,165 +1053,283 @@ void sage_hip_batch_free(SageDeviceBatch* b) {
     delete b;
 }
 
+// ---- scoring ---------------------------------------------------------------------------------------------------------------
+static uint64_t arena_entries_for(const SageScorer* s, uint32_t n) {
+    // 16 Ki entries = 64 KiB per spectrum on average + two 64 Ki-entry chunks per resident workgroup (each takes its arena space
+    // a chunk at a time); an exhausted arena is detected, and the batch is then scored in smaller pieces
+    uint64_t e = std::max<uint64_t>((uint64_t)n * 16384, 16ull << 20) + (uint64_t)std::min(n, s->tile_blocks) * (2u << 16);
+    e = std::min<uint64_t>(e, 0xFFFFFFF0ull);
+    if (const char* v = getenv("SAGE_HIP_ARENA_MB")) e = std::min<uint64_t>((uint64_t)std::max(1, atoi(v)) << 18, 0xFFFFFFF0ull);
+    return e;
+}
+
 static int ensure_work(SageScorer* s, uint32_t n) {
-    if (n <= s->work_n) return SAGE_HIP_OK;
-    HIP_TRY(s->cand.alloc((size_t)n * s->dev.kmax));
-    HIP_TRY(s->cand_len.alloc(n));
-    HIP_TRY(s->totals.alloc((size_t)n * 2));
-    HIP_TRY(s->status.alloc(n));
-    HIP_TRY(s->queue.alloc(n));
-    HIP_TRY(s->retry.alloc(n));
-    HIP_TRY(s->out_count.alloc(n));
+    WorkSet& w = s->ws;
+    for (OutSet& o : s->outs) {
+        HIP_TRY(o.features.reserve((size_t)n * s->params.report_psms));
+        HIP_TRY(o.out_count.reserve(n));
+    }
+    if (n <= w.cap_n) return SAGE_HIP_OK;
+    HIP_TRY(w.cand.reserve((size_t)n * s->dev.kmax));
+    HIP_TRY(w.cand_len.reserve(n));
+    HIP_TRY(w.totals.reserve((size_t)n * 2));
+    HIP_TRY(w.status.reserve(n));
+    HIP_TRY(w.queue.reserve(n));
+    HIP_TRY(w.retry.reserve(n));
     // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
-    // (16 Ki entries = 64 KiB per spectrum on average; an exhausted arena is reported, never silently truncated)
-    HIP_TRY(s->qrec.alloc((size_t)n * s->qmax));
-    HIP_TRY(s->seeds.alloc((size_t)n * s->qmax * 64));
-    HIP_TRY(s->qres.alloc((size_t)n * s->qmax * 64));
-    // + two 64 Ki-entry chunks per resident workgroup (each takes its arena space a chunk at a time)
-    uint64_t arena_entries = std::max<uint64_t>((uint64_t)n * 16384, 16ull << 20) + (uint64_t)std::min(n, s->tile_blocks) * (2u << 16);
-    arena_entries = std::min<uint64_t>(arena_entries, 0xFFFFFFF0ull);
-    if (const char* e = getenv("SAGE_HIP_ARENA_MB")) arena_entries = std::min<uint64_t>((uint64_t)std::max(1, atoi(e)) << 18, 0xFFFFFFF0ull);
-    if (arena_entries > s->arena.n) HIP_TRY(s->arena.alloc(arena_entries));
-    HIP_TRY(s->features.alloc((size_t)n * s->params.report_psms));
-    s->work_n = n;
+    HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
+    HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * 64));
+    HIP_TRY(w.qres.reserve((size_t)n * s->qmax * 64));
+    const uint64_t arena_entries = arena_entries_for(s, n);
+    if (arena_entries > w.arena.n) HIP_TRY(w.arena.alloc(arena_entries));
+    w.cap_n = n;
     return SAGE_HIP_OK;
 }
 
-static DevWork make_work(SageScorer* s);
+static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
+    DevWork w{};
+    WorkSet& ws = s->ws;
+    w.cand = ws.cand.p;
+    w.cand_len = ws.cand_len.p;
+    w.totals = ws.totals.p;
+    w.status = ws.status.p;
+    w.n_deferred = o.counters.p + (size_t)pass * CTR_COUNT;
+    w.queue = ws.queue.p;
+    w.retry = ws.retry.p;
+    w.tile_blocks = s->tile_blocks;
+    w.qrec = ws.qrec.p;
+    w.seeds = ws.seeds.p;
+    w.qres = ws.qres.p;
+    w.arena = ws.arena.p;
+    w.arena_cap = (uint32_t)ws.arena.n;
+    w.qmax = s->qmax;
+    w.dbg = s->dbg.p;
+    w.tile_params = o.tile_params.p + pass;
+    return w;
+}
 
-// One pass of the kernels over `view` (the whole resident batch, or — `exact` retry pass — the spectra listed in view.order).
-// exact: every trim replays bounded_min_heapify (reference heap layouts); otherwise the order-free trims.
-static int run_kernels(SageScorer* s, SageDeviceBatch* b, bool with_rescore, bool exact, const DevBatchView* sub = nullptr) {
-    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
-    HIP_TRY(hipSetDevice(s->db->device));
-    int rc = ensure_work(s, b->n);
+enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the spectra whose reported ranks tie
+       MODE_EXACT = 1,  // every trim replays bounded_min_heapify: one pass
+       MODE_FAST = 2 }; // order-free trims only (quick_score: which peptides survive does not depend on heap layouts)
+
+// Enqueue the kernels of one batch on `st` — nothing here waits for the device.  The retry pass is launched unconditionally:
+// its spectrum list and its COUNT live on the device (the first pass's CTR_RETRY counter), so no host round trip separates
+// the two passes; with no tied spectrum its blocks exit at once.
+static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st) {
+    int rc = ensure_work(s, view.n);
     if (rc != SAGE_HIP_OK) return rc;
-    const DevBatchView& view = sub ? *sub : b->view;
     DevScorer sc = s->dev;
-    sc.exact = exact ? 1u : 0u;
     const size_t lds_p = prelim_lds_bytes(sc, view), lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
     const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
     if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
-    DevWork w = make_work(s);
-    {
-        TileParams tp{s->db->view, sc, view, w};
-        HIP_TRY(hipMemcpyAsync(s->tile_params.p, &tp, sizeof tp, hipMemcpyHostToDevice, s->stream));  // (small: staged at call time)
-    }
-    HIP_TRY(hipMemsetAsync(s->n_deferred.p, 0, CTR_COUNT * 4, s->stream));
-    HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-    launch_prelim(s->db->view, sc, view, w, s->stream);
+    const bool two_pass = mode == MODE_SCORE && with_rescore;
+    o.two_pass = two_pass;
+    o.with_rescore = with_rescore;
+    o.n = view.n;
+    DevBatchView v2 = view;
+    v2.order = s->ws.retry.p;  // filled by the rescoring kernel of the first pass, in no particular order
+    v2.n_dev = o.counters.p + CTR_RETRY;
+    DevWork w1 = make_work(s, o, 0), w2 = make_work(s, o, 1);
+    DevScorer sc1 = sc, sc2 = sc;
+    sc1.exact = mode == MODE_EXACT ? 1u : 0u;
+    sc2.exact = 1u;
+    o.h_tile_params[0] = TileParams{s->db->view, sc1, view, w1};
+    o.h_tile_params[1] = TileParams{s->db->view, sc2, v2, w2};
+    HIP_TRY(hipMemcpyAsync(o.tile_params.p, o.h_tile_params, 2 * sizeof(TileParams), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
+    HIP_TRY(hipEventRecord(o.ev[0].e, st));
+    launch_prelim(s->db->view, sc1, view, w1, st);
     HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
-    launch_prelim_tile(s->db->view, sc, view, w, s->stream);
+    launch_prelim_tile(s->db->view, sc1, view, w1, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    HIP_TRY(hipEventRecord(o.ev[1].e, st));
     if (with_rescore)
-        launch_rescore(s->db->view, sc, view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions,
-                       s->features.p, s->out_count.p, nullptr, s->stream);
-    HIP_TRY(hipEventRecord(s->ev[2], s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_counters, s->n_deferred.p, CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
+        launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p, o.out_count.p,
+                       nullptr, st);
+    HIP_TRY(hipEventRecord(o.ev[2].e, st));
+    if (two_pass) {
+        launch_prelim(s->db->view, sc2, v2, w2, st);
+        HIP_TRY(hipGetLastError());
+        launch_prelim_tile(s->db->view, sc2, v2, w2, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(o.ev[3].e, st));
+        launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p, o.out_count.p,
+                       nullptr, st);
+        HIP_TRY(hipEventRecord(o.ev[4].e, st));
+    }
     HIP_TRY(hipGetLastError());
+    o.in_flight = true;
     return SAGE_HIP_OK;
 }
 
-static int finish_timing(SageScorer* s, bool with_rescore) {
-    HIP_TRY(hipEventSynchronize(s->ev[2]));
-    float a = 0, c = 0;
-    HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&c, s->ev[1], s->ev[2]));
-    s->timing.prelim_ms = a;
-    s->timing.rescore_ms = with_rescore ? c : 0.f;
-    s->timing.total_ms = a + c;
-    s->timing.n_launches = with_rescore ? 6 : 5;
-    s->timing.n_wide = s->h_counters[CTR_QUEUED];  // copied on the stream before the caller's synchronize
-    s->timing.arena_entries = s->h_counters[CTR_ARENA_PTR];
-    s->timing.n_retry = 0;
-    if (s->h_counters[CTR_ARENA_OVERFLOW])
-        return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->arena.n >> 18) +
+// counters + timing of a finished batch (its comp_done / down_done event has completed); accumulates into s->timing
+static int collect(SageScorer* s, OutSet& o, bool* arena_overflow) {
+    o.in_flight = false;
+    const uint32_t* c1 = o.h_counters;
+    const uint32_t* c2 = o.h_counters + CTR_COUNT;
+    float a = 0, r = 0, a2 = 0, r2 = 0;
+    HIP_TRY(hipEventElapsedTime(&a, o.ev[0].e, o.ev[1].e));
+    HIP_TRY(hipEventElapsedTime(&r, o.ev[1].e, o.ev[2].e));
+    if (o.two_pass) {
+        HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[3].e));
+        HIP_TRY(hipEventElapsedTime(&r2, o.ev[3].e, o.ev[4].e));
+    }
+    SageTiming& t = s->timing;
+    t.prelim_ms += a + a2;
+    t.rescore_ms += o.with_rescore ? r + r2 : 0.f;
+    t.total_ms += a + a2 + (o.with_rescore ? r + r2 : 0.f);
+    t.n_launches += (o.with_rescore ? 6 : 5) * (o.two_pass ? 2 : 1);
+    t.n_wide += c1[CTR_QUEUED];
+    t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
+    t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
+    if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
+        if (arena_overflow) {
+            *arena_overflow = true;
+            return SAGE_HIP_OK;
+        }
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->ws.arena.n >> 18) +
                                                   " MiB): score this batch in smaller pieces or raise SAGE_HIP_ARENA_MB");
+    }
+    if (c1[CTR_LIST_OVERFLOW] || c2[CTR_LIST_OVERFLOW])
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "preliminary candidate list capacity exceeded (" +
+                                                  std::to_string(c1[CTR_LIST_OVERFLOW] + c2[CTR_LIST_OVERFLOW]) + " spectra)");
     return SAGE_HIP_OK;
 }
 
-static DevWork make_work(SageScorer* s) {
-    DevWork w{};
-    w.cand = s->cand.p;
-    w.cand_len = s->cand_len.p;
-    w.totals = s->totals.p;
-    w.status = s->status.p;
-    w.n_deferred = s->n_deferred.p;
-    w.queue = s->queue.p;
-    w.retry = s->retry.p;
-    w.tile_blocks = s->tile_blocks;
-    w.qrec = s->qrec.p;
-    w.seeds = s->seeds.p;
-    w.qres = s->qres.p;
-    w.arena = s->arena.p;
-    w.arena_cap = (uint32_t)s->arena.n;
-    w.qmax = s->qmax;
-    w.dbg = s->dbg.p;
-    w.tile_params = s->tile_params.p;
-    return w;
+static void reset_timing(SageScorer* s) { s->timing = SageTiming{}; }
+
+// score a resident batch on the compute stream: kernels, record download, ONE host synchronisation
+static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
+    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    HIP_TRY(hipSetDevice(s->db->device));
+    reset_timing(s);
+    OutSet& o = s->outs[0];
+    int rc = enqueue_compute(s, b->view, o, true, s->exact_always ? MODE_EXACT : MODE_SCORE, s->stream);
+    if (rc != SAGE_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
+    if (b->n) {
+        HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(out, o.features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature), hipMemcpyDeviceToHost,
+                               s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return collect(s, o, nullptr);
 }
 
 int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
     if (!s || !b || !out || !out_count) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    const bool exact = s->exact_always;
-    int rc = run_kernels(s, b, true, exact);
-    if (rc != SAGE_HIP_OK) return rc;
-    // the counters (copied on the stream by run_kernels) decide whether a second pass is needed before anything is downloaded
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    rc = finish_timing(s, true);
-    if (rc != SAGE_HIP_OK) return rc;
-    const uint32_t n_retry = exact ? 0 : s->h_counters[CTR_RETRY];
-    if (n_retry && !s->h_counters[CTR_LIST_OVERFLOW]) {
-        // Some spectra have equal hyperscores at a reported rank: there the heap layout of the preliminary list decides
-        // the order (the stable sort of scoring.rs:495), so exactly those spectra go through the kernels again with every
-        // trim replaying bounded_min_heapify.
-        const SageTiming first = s->timing;
-        DevBatchView sub = b->view;
-        sub.order = s->retry.p;  // filled by the rescoring kernel, in no particular order
-        sub.n = n_retry;
-        rc = run_kernels(s, b, true, true, &sub);
-        if (rc != SAGE_HIP_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        rc = finish_timing(s, true);
-        if (rc != SAGE_HIP_OK) return rc;
-        s->timing.prelim_ms += first.prelim_ms;
-        s->timing.rescore_ms += first.rescore_ms;
-        s->timing.total_ms += first.total_ms;
-        s->timing.n_launches += first.n_launches;
-        s->timing.n_wide = first.n_wide;
-        s->timing.arena_entries = std::max(s->timing.arena_entries, first.arena_entries);
-        s->timing.n_retry = n_retry;
-    }
-    HIP_TRY(hipMemcpyAsync(out_count, s->out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(out, s->features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature),
-                           hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->h_counters[CTR_LIST_OVERFLOW]) {  // rare: find the offending spectrum for the message
-        std::vector<uint32_t> st(b->n);
-        HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < b->n; i++)
-            if (st[i] != ST_OK)
-                return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": preliminary pass status " +
-                                                          std::to_string(st[i]) + " (candidate list capacity)");
-    }
-    return SAGE_HIP_OK;
+    std::lock_guard<std::mutex> lock(s->mu);
+    return score_resident_locked(s, b, out, out_count);
 }
 
-int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* batch, SageFeature* out, uint32_t* out_count) {
-    SageDeviceBatch* d = nullptr;
-    int rc = sage_hip_batch_upload(s, batch, &d);
+// Spectra [r0, r1) of a host batch through the three-stage pipeline: while chunk c is scored on the compute stream, chunk
+// c + 1 is staged and uploaded on the copy stream and the PSM records of chunk c - 1 return on the download stream.  Mirrors the
+// reference's reader -> processor -> search overlap (runner.rs:365-375, 450-461) at the PCIe boundary.
+static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, uint32_t r1, SageFeature* out, uint32_t* out_count,
+                       uint32_t chunk, bool peaks_locked, uint32_t probe, std::vector<std::pair<uint32_t, uint32_t>>& overflowed) {
+    const uint32_t rp = s->params.report_psms;
+    // page-locked result arrays (sage_hip_host_alloc) receive the records by DMA; pageable ones through a page-locked landing
+    // block per slot (an asynchronous copy into pageable memory would stall the pipeline)
+    const bool out_locked = is_page_locked(out) && is_page_locked(out_count);
+    const int mode = s->exact_always ? MODE_EXACT : MODE_SCORE;
+    struct Pending {
+        uint32_t c0, c1;
+        int slot;
+    };
+    Pending pend[2];
+    bool has[2] = {false, false};
+    auto finish = [&](int slot) -> int {
+        if (!has[slot]) return SAGE_HIP_OK;
+        has[slot] = false;
+        OutSet& o = s->outs[slot];
+        HIP_TRY(hipEventSynchronize(o.down_done.e));
+        if (!out_locked) {
+            const uint32_t c0 = pend[slot].c0, cn = pend[slot].c1 - pend[slot].c0;
+            std::memcpy(out + (size_t)c0 * rp, o.h_out.p, (size_t)cn * rp * sizeof(SageFeature));
+            std::memcpy(out_count + c0, o.h_out.p + (((size_t)cn * rp * sizeof(SageFeature) + 63) / 64) * 64, (size_t)cn * 4);
+        }
+        bool ovf = false;
+        const int rc = collect(s, o, &ovf);
+        if (ovf) overflowed.push_back({pend[slot].c0, pend[slot].c1});
+        return rc;
+    };
+    int k = 0;
+    for (uint32_t c0 = r0; c0 < r1; c0 += chunk, k++) {
+        const uint32_t c1 = (uint32_t)std::min<uint64_t>((uint64_t)c0 + chunk, r1);
+        const int slot = k & 1;
+        int rc = finish(slot);  // chunk k - 2 used this slot: its records are home, its buffers are free
+        if (rc != SAGE_HIP_OK) return rc;
+        SageDeviceBatch& in = s->slots[slot];
+        OutSet& o = s->outs[slot];
+        // (the uploads of chunk k - 2 finished long ago — its kernels ran — so the staging block may be rewritten)
+        rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, probe, s->up_stream);
+        if (rc != SAGE_HIP_OK) return rc;
+        HIP_TRY(hipStreamWaitEvent(s->stream, in.up_done.e, 0));
+        rc = enqueue_compute(s, in.view, o, true, mode, s->stream);
+        if (rc != SAGE_HIP_OK) return rc;
+        HIP_TRY(hipEventRecord(o.comp_done.e, s->stream));
+        // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
+        // download, which itself follows its kernels: no device-side guard is needed for the input buffers
+        HIP_TRY(hipStreamWaitEvent(s->down_stream, o.comp_done.e, 0));
+        HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->down_stream));
+        SageFeature* dst_f = out + (size_t)c0 * rp;
+        uint32_t* dst_c = out_count + c0;
+        if (!out_locked) {
+            const size_t fb = (((size_t)(c1 - c0) * rp * sizeof(SageFeature) + 63) / 64) * 64;
+            HIP_TRY(o.h_out.reserve(fb + (size_t)(c1 - c0) * 4));
+            dst_f = (SageFeature*)o.h_out.p;
+            dst_c = (uint32_t*)(o.h_out.p + fb);
+        }
+        HIP_TRY(hipMemcpyAsync(dst_c, o.out_count.p, (size_t)(c1 - c0) * 4, hipMemcpyDeviceToHost, s->down_stream));
+        HIP_TRY(hipMemcpyAsync(dst_f, o.features.p, (size_t)(c1 - c0) * rp * sizeof(SageFeature), hipMemcpyDeviceToHost, s->down_stream));
+        HIP_TRY(hipEventRecord(o.down_done.e, s->down_stream));
+        pend[slot] = Pending{c0, c1, slot};
+        has[slot] = true;
+    }
+    // the working set (candidate lists, arena) is shared by both slots: kernels run in order on one stream, and a chunk's
+    // records leave through its own OutSet, so the next chunk's kernels may start while they are being downloaded
+    int rc = finish(k & 1);
     if (rc != SAGE_HIP_OK) return rc;
-    rc = sage_hip_score_resident(s, d, out, out_count);
-    sage_hip_batch_free(d);
-    return rc;
+    return finish((k + 1) & 1);
+}
+
+int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature* out, uint32_t* out_count) {
+    if (!s || !b || (b->n_spectra && (!out || !out_count))) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    int rc = check_batch_args(b);
+    if (rc != SAGE_HIP_OK) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->db->device));
+    reset_timing(s);
+    const uint32_t n = b->n_spectra;
+    if (n == 0) return SAGE_HIP_OK;
+    const bool peaks_locked = is_page_locked(b->masses) && is_page_locked(b->intensities);
+    const uint32_t probe = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    std::vector<std::pair<uint32_t, uint32_t>> todo, next;
+    rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, probe, todo);
+    if (rc != SAGE_HIP_OK) return rc;
+    // chunks whose large-window candidates did not fit the arena: again in halves (the arena is sized for the chunk, so a
+    // piece with the same arena and half the spectra has twice the room per spectrum)
+    while (!todo.empty()) {
+        next.clear();
+        for (auto& r : todo) {
+            const uint32_t len = r.second - r.first;
+            if (len <= 1)
+                return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted by a single spectrum (" +
+                                                          std::to_string(s->ws.arena.n >> 18) + " MiB): raise SAGE_HIP_ARENA_MB");
+            rc = score_range(s, b, r.first, r.second, out, out_count, (len + 1) / 2, peaks_locked, probe, next);
+            if (rc != SAGE_HIP_OK) return rc;
+        }
+        todo.swap(next);
+    }
+    return SAGE_HIP_OK;
 }
 
 int sage_hip_annotate_resident(SageScorer* s, SageDeviceBatch* b, const SageFeature* features, const uint32_t* counts,
                                SageFragments* out) {
     if (!s || !b || !features || !counts || !out || !out->psm_off) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    std::lock_guard<std::mutex> lock(s->mu);
     HIP_TRY(hipSetDevice(s->db->device));
     const uint32_t n = b->n, rp = s->params.report_psms;
     const size_t slots = (size_t)n * rp;
@@ -982,55 +1348,57 @@ int sage_hip_annotate_resident(SageScorer* s, SageDeviceBatch* b, const SageFeat
     if (total && (!out->kinds || !out->charges || !out->fragment_ordinals || !out->intensities || !out->mz_calculated || !out->mz_experimental))
         return fail(SAGE_HIP_ERR_INVALID, "missing SageFragments arrays");
     if (n == 0 || total == 0) return SAGE_HIP_OK;
-    DevBuf<SageFeature> d_feats;
-    DevBuf<uint32_t> d_counts;
-    DevBuf<uint64_t> d_off;
-    DevBuf<uint8_t> d_kinds;
-    DevBuf<int32_t> d_charges, d_ord;
-    DevBuf<float> d_int, d_calc, d_exp;
-    HIP_TRY(d_feats.upload(features, slots));
-    HIP_TRY(d_counts.upload(counts, n));
-    HIP_TRY(d_off.upload(out->psm_off, slots + 1));
-    HIP_TRY(d_kinds.alloc(total));
-    HIP_TRY(d_charges.alloc(total));
-    HIP_TRY(d_ord.alloc(total));
-    HIP_TRY(d_int.alloc(total));
-    HIP_TRY(d_calc.alloc(total));
-    HIP_TRY(d_exp.alloc(total));
-    DevFragments df{total, d_kinds.p, d_charges.p, d_ord.p, d_int.p, d_calc.p, d_exp.p};
-    launch_annotate(s->db->view, s->dev, b->view, d_feats.p, d_counts.p, d_off.p, df, s->stream);
+    HIP_TRY(s->an_feats.reserve(slots));
+    HIP_TRY(s->an_counts.reserve(n));
+    HIP_TRY(s->an_off.reserve(slots + 1));
+    HIP_TRY(s->an_kinds.reserve(total));
+    HIP_TRY(s->an_charges.reserve(total));
+    HIP_TRY(s->an_ord.reserve(total));
+    HIP_TRY(s->an_int.reserve(total));
+    HIP_TRY(s->an_calc.reserve(total));
+    HIP_TRY(s->an_exp.reserve(total));
+    hipStream_t st = s->stream;
+    HIP_TRY(hipMemcpyAsync(s->an_feats.p, features, slots * sizeof(SageFeature), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->an_counts.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->an_off.p, out->psm_off, (slots + 1) * 8, hipMemcpyHostToDevice, st));
+    DevFragments df{total, s->an_kinds.p, s->an_charges.p, s->an_ord.p, s->an_int.p, s->an_calc.p, s->an_exp.p};
+    launch_annotate(s->db->view, s->dev, b->view, s->an_feats.p, s->an_counts.p, s->an_off.p, df, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(out->kinds, d_kinds.p, total, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->charges, d_charges.p, total * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->fragment_ordinals, d_ord.p, total * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->intensities, d_int.p, total * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->mz_calculated, d_calc.p, total * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out->mz_experimental, d_exp.p, total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out->kinds, s->an_kinds.p, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->charges, s->an_charges.p, total * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->fragment_ordinals, s->an_ord.p, total * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->intensities, s->an_int.p, total * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->mz_calculated, s->an_calc.p, total * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->mz_experimental, s->an_exp.p, total * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return SAGE_HIP_OK;
 }
 
 int sage_hip_quick_score_resident(SageScorer* s, SageDeviceBatch* b, int prefilter_low_memory, uint8_t* keep) {
     if (!s || !b || !keep) return fail(SAGE_HIP_ERR_INVALID, "null argument");
-    int rc = run_kernels(s, b, false, false);  // Scorer::initial_hits; which peptides survive each trim does not depend on heap layouts
+    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->db->device));
+    reset_timing(s);
+    OutSet& o = s->outs[0];
+    int rc = enqueue_compute(s, b->view, o, false, MODE_FAST, s->stream);  // Scorer::initial_hits
     if (rc != SAGE_HIP_OK) return rc;
     const uint64_t np = s->db->view.np;
-    DevBuf<uint8_t> d_keep;
-    HIP_TRY(d_keep.alloc(np));
-    HIP_TRY(hipMemsetAsync(d_keep.p, 0, std::max<uint64_t>(np, 1), s->stream));
-    const DevWork w = make_work(s);
+    HIP_TRY(s->keep.reserve(np));
+    HIP_TRY(hipMemsetAsync(s->keep.p, 0, std::max<uint64_t>(np, 1), s->stream));
+    const DevWork w = make_work(s, o, 0);
     if (prefilter_low_memory)
-        launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, s->features.p,
-                       s->out_count.p, d_keep.p, s->stream);
+        launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p,
+                       o.out_count.p, s->keep.p, s->stream);
     else
-        launch_quick_mark(s->dev, b->view, w, d_keep.p, s->stream);
+        launch_quick_mark(s->dev, b->view, w, s->keep.p, s->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    rc = finish_timing(s, false);
-    if (rc != SAGE_HIP_OK) return rc;
-    if (s->h_counters[CTR_LIST_OVERFLOW]) return fail(SAGE_HIP_ERR_UNSUPPORTED, "preliminary candidate list capacity exceeded");
+    HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
     std::vector<uint8_t> h(np);
-    HIP_TRY(hipMemcpy(h.data(), d_keep.p, np, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(h.data(), s->keep.p, np, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = collect(s, o, nullptr);
+    if (rc != SAGE_HIP_OK) return rc;
     for (uint64_t i = 0; i < np; i++) keep[i] |= h[i];
     return SAGE_HIP_OK;
 }
@@ -1039,18 +1407,24 @@ int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, u
                           uint64_t* matched_peaks, uint64_t* scored_candidates) {
     if (!s || !b || !packed || !len) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (cap < s->dev.kmax) return fail(SAGE_HIP_ERR_INVALID, "cap must be >= max(50, 2*report_psms)");
-    int rc = run_kernels(s, b, false, true);  // the reference's heap layouts
+    if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipSetDevice(s->db->device));
+    reset_timing(s);
+    OutSet& o = s->outs[0];
+    int rc = enqueue_compute(s, b->view, o, false, MODE_EXACT, s->stream);  // the reference's heap layouts
     if (rc != SAGE_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    rc = finish_timing(s, false);
+    rc = collect(s, o, nullptr);
     if (rc != SAGE_HIP_OK) return rc;
     const uint32_t n = b->n, kmax = s->dev.kmax;
     std::vector<uint64_t> c((size_t)n * kmax);
     std::vector<uint32_t> tot((size_t)n * 2), st(n);
-    HIP_TRY(hipMemcpy(c.data(), s->cand.p, c.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(len, s->cand_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tot.data(), s->totals.p, tot.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(st.data(), s->status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c.data(), s->ws.cand.p, c.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(len, s->ws.cand_len.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tot.data(), s->ws.totals.p, tot.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), s->ws.status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) {
         if (st[i] != ST_OK) return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": status " + std::to_string(st[i]));
         for (uint32_t j = 0; j < len[i]; j++) packed[(size_t)i * cap + j] = c[(size_t)i * kmax + j];

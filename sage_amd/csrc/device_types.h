@@ -68,7 +68,10 @@ struct DevScorer {
 };
 
 struct DevBatchView {
-    uint32_t n;
+    uint32_t n;                 // spectra of this batch == upper bound of the launch grids
+    const uint32_t* n_dev;      // when not null: the number of entries of `order` to score lives on the device (the exact
+                                //     retry pass is launched without a host round trip: its count is a counter of pass 1)
+    uint32_t spec_base;         // added to Feature.spec_index: position of this batch's first spectrum in the caller's batch
     const uint64_t* peak_off;
     const float* masses;
     const float* intensities;
@@ -162,6 +165,10 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
 int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err);
 int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, std::string& err);
 // process.hip
+// launch schedule of a batch (index_build.hip): order[k] = spectrum scored by block k, ascending neutral precursor mass
+size_t schedule_temp_bytes(uint32_t n);
+int schedule_on_device(uint32_t n, const float* d_precursor_mz, const uint8_t* d_charge, uint32_t min_charge, uint32_t* d_keys_a,
+                       uint32_t* d_keys_b, uint32_t* d_idx, uint32_t* d_order, void* d_temp, size_t temp_bytes, void* stream);
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
 int process_kernel_prepare(size_t max_lds_bytes);
 void launch_process(uint32_t n, const uint64_t* raw_off, const float* raw_mz, const float* raw_int, const uint8_t* charge,

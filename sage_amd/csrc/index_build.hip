@@ -209,4 +209,40 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
     return (int)hipSuccess;
 }
 
+
+// ---- launch schedule of a spectrum batch -------------------------------------------------------------------------------
+// Spectra are scored in ascending order of their neutral precursor mass, so that wavefronts resident together read
+// overlapping ranges of the index and of the ion table (outputs keep input order).  One stable 32-bit radix sort on the
+// device instead of a host sort: the schedule of a batch is ready a few microseconds after its upload.
+namespace {
+__global__ __launch_bounds__(256) void schedule_keys_kernel(uint32_t n, const float* __restrict__ precursor_mz,
+                                                            const uint8_t* __restrict__ charge, uint32_t min_charge,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t z = charge[i] ? charge[i] : min_charge;
+    const float m = (precursor_mz[i] - sagecore::PROTON) * (float)z;  // scoring.rs:420 (first charge when unknown)
+    const uint32_t b = __float_as_uint(m);
+    keys[i] = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // ascending u32 == ascending f32 (total order)
+    idx[i] = i;
+}
+}  // namespace
+
+size_t schedule_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    uint32_t* p = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, n ? n : 1, 0, 32, (hipStream_t) nullptr);
+    return bytes ? bytes : 16;
+}
+
+int schedule_on_device(uint32_t n, const float* d_precursor_mz, const uint8_t* d_charge, uint32_t min_charge, uint32_t* d_keys_a,
+                       uint32_t* d_keys_b, uint32_t* d_idx, uint32_t* d_order, void* d_temp, size_t temp_bytes, void* stream_) {
+    if (n == 0) return (int)hipSuccess;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(schedule_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, d_precursor_mz, d_charge, min_charge,
+                       d_keys_a, d_idx);
+    size_t bytes = temp_bytes;
+    return (int)rocprim::radix_sort_pairs(d_temp, bytes, d_keys_a, d_keys_b, d_idx, d_order, n, 0, 32, stream);
+}
+
 }  // namespace sagehip

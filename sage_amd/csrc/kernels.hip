@@ -21,6 +21,10 @@ namespace sagehip {
 namespace {
 
 constexpr uint32_t WAVE = 64;
+#ifndef SAGE_PROBE_PER_LANE
+#define SAGE_PROBE_PER_LANE 4   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch)
+#endif
+constexpr uint32_t PROBE_BATCH_WORDS = SAGE_PROBE_PER_LANE * 64;
 
 // optional per-phase cycle accounting (DevWork::dbg != null): every work item of a launch adds its clock deltas to slot
 // [item mod DBG_BLOCKS][kernel*8 + phase] (debug builds of the numbers only; atomics, so slightly perturbing);
@@ -303,6 +307,7 @@ struct PrelimLds {
     uint64_t* listA;
     uint64_t* listB;
     uint64_t* heap;
+    uint32_t* ptab;  // probe variant: run table of one batch of windows, 3 x PROBE_BATCH words
     uint32_t* cnt;
 };
 
@@ -317,6 +322,8 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     const size_t win = b.probe ? (size_t)b.pcap * 4 : (size_t)b.fzcap * b.pcap * 4;
     l.win_lo = (float*)(smem + off); off += win;
     l.win_hi = (float*)(smem + off); off += b.probe ? 0 : win;
+    off = (off + 3) & ~(size_t)3;
+    l.ptab = (uint32_t*)(smem + off); off += b.probe ? (size_t)3 * PROBE_BATCH_WORDS * 4 : 0;
     l.cnt = (uint32_t*)(smem + off);
     return l;
 }
@@ -460,6 +467,17 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
 #define SAGE_RESCORE_WAVES 6
 #endif
 constexpr uint32_t PROBE_DEPTH = SAGE_PROBE_DEPTH;
+#ifndef SAGE_PROBE_PER_LANE
+#define SAGE_PROBE_PER_LANE 4   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch)
+#endif
+#ifndef SAGE_PROBE_CELLS
+#define SAGE_PROBE_CELLS 4      // 16-byte index cells a lane keeps in flight per pass over the flattened runs
+#endif
+constexpr uint32_t PROBE_PER_LANE = SAGE_PROBE_PER_LANE;
+constexpr uint32_t PROBE_BATCH = PROBE_PER_LANE * 64;  // (a power of two: the owner search halves it)
+constexpr uint32_t PROBE_CELLS = SAGE_PROBE_CELLS;
+constexpr uint32_t NO_WINDOW = 0xFFFFFFFFu;
+static_assert((PROBE_BATCH & (PROBE_BATCH - 1)) == 0, "PROBE_BATCH must be a power of two");
 #if SAGE_PRELIM_WAVES
 #define SAGE_PRELIM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SAGE_PRELIM_WAVES, SAGE_PRELIM_WAVES)))
 #else
@@ -478,7 +496,12 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
     Counters cnt;
     cnt.p = L.cnt;
 
-    for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
+    uint32_t n_batch = b.n;
+    if (b.n_dev) {  // retry pass: the count is a device-side counter of the first pass
+        const uint32_t nd = uni(*b.n_dev);
+        n_batch = nd < n_batch ? nd : n_batch;
+    }
+    for (uint32_t blk = blockIdx.x; blk < n_batch; blk += gridDim.x) {
         const uint32_t spec = b.order ? uni(b.order[blk]) : blk;
         __syncthreads();
         PhaseClock pc;
@@ -588,63 +611,98 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                     }
                 }
                 if (PROBE && q.first < q.end) {
-                    // One lane per (peak, fragment charge) window: two reads of the (small) tile's position table give the run
-                    // of index entries inside the fragment tolerance, the few entries of the run are tested against the
-                    // precursor window (database.rs:526-533) and hits bump the LDS counters.  ~3 entries per window
-                    // instead of a binary search per fragment of every candidate peptide.
+                    // Per (peak, fragment charge) window, two reads of the (small) tile's position table give the RUN of index
+                    // entries inside the window's table cells; the entries of the run are tested against the fragment and
+                    // precursor windows (database.rs:526-533) and hits bump the LDS counters.  Run lengths are very skewed
+                    // (fragment masses sit in narrow mass-defect bands: most windows of a spectrum find nothing, a few find
+                    // dozens of entries), so the runs of a batch of windows are FLATTENED into a list of 16-byte cells (two
+                    // entries each) shared evenly by the 64 lanes, each lane's cells in flight together: one round trip for
+                    // the table, one for the entries, no lane waiting on another lane's long run.
                     const uint4* __restrict__ frag2 = (const uint4*)db.tm2_frag;
                     const float cell_max = (float)(db.lut2_stride - 1);
                     const uint32_t t0 = q.first >> db.tile2_shift, t1 = (q.end - 1) >> db.tile2_shift;
-                    auto test2 = [&](const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo, float hi) {
-                        const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
-                        if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= q.first && e.x < q.end) { cnt.add(e.x - left, 1); acc++; }
-                        if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= q.first && e.z < q.end) { cnt.add(e.z - left, 1); acc++; }
-                    };
                     const uint32_t nprobe = P * nfz;
+                    uint32_t* const tp0 = L.ptab;                      // [PROBE_BATCH] first entry of the run
+                    uint32_t* const tp1 = L.ptab + PROBE_BATCH;        // [PROBE_BATCH] end entry
+                    uint32_t* const tcs = L.ptab + 2 * PROBE_BATCH;    // [PROBE_BATCH] first cell in the flattened list
+                    auto window_of = [&](uint32_t pr, float& flo, float& fhi) {
+                        flo = 1.0f; fhi = 0.0f;  // (no such window: empty)
+                        if (pr < nprobe) {
+                            const uint32_t fz = pr / P, i = pr - fz * P;
+                            tol_bounds(sc.fragment_tol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
+                        }
+                    };
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
                         const uint32_t* __restrict__ lut = db.tm2_lut + (size_t)t * db.lut2_stride;
-                        // the table reads of the next 64 windows are issued before this trip's entries are tested
-                        float lo = 1.0f, hi = 0.0f, lo_n = 1.0f, hi_n = 0.0f;
-                        uint32_t p0 = 0, p1 = 0, p0_n = 0, p1_n = 0;
-                        auto fetch = [&](uint32_t pr, float& flo, float& fhi, uint32_t& fp0, uint32_t& fp1) {
-                            flo = 1.0f; fhi = 0.0f;  // (inactive lane: empty window, empty run)
-                            if (pr < nprobe) {
-                                const uint32_t fz = pr / P, i = pr - fz * P;
-                                tol_bounds(sc.fragment_tol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
+                        for (uint32_t pbase = 0; pbase < nprobe; pbase += PROBE_BATCH) {
+                            // table reads of up to PROBE_BATCH windows, PROBE_PER_LANE per lane, all in flight together;
+                            // window q of the flattened order (lane-major) is window pbase + (q % PPL) * 64 + q / PPL
+                            uint32_t rp0[PROBE_PER_LANE], rp1[PROBE_PER_LANE];
+#pragma unroll
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
+                                float flo, fhi;
+                                window_of(pbase + i * WAVE + lane, flo, fhi);
+                                // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
+                                float cl = floorf(flo * db.lut2_scale), ch = floorf(fhi * db.lut2_scale) + 1.0f;
+                                cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
+                                ch = ch > 0.0f ? ch : 0.0f;
+                                uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut2_stride - 1;
+                                uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut2_stride - 1;
+                                if (!(flo <= fhi)) icl = ich = 0;
+                                rp0[i] = lut[icl];
+                                rp1[i] = lut[ich];
                             }
-                            // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
-                            float cl = floorf(flo * db.lut2_scale), ch = floorf(fhi * db.lut2_scale) + 1.0f;
-                            cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
-                            ch = ch > 0.0f ? ch : 0.0f;
-                            uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut2_stride - 1;
-                            uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut2_stride - 1;
-                            if (!(flo <= fhi)) icl = ich = 0;
-                            fp0 = lut[icl];
-                            fp1 = lut[ich];
-                        };
-                        fetch(lane, lo_n, hi_n, p0_n, p1_n);
-                        for (uint32_t pb = 0; pb < nprobe; pb += WAVE) {
-                            lo = lo_n; hi = hi_n; p0 = p0_n; p1 = p1_n;
-                            if (pb + WAVE < nprobe) fetch(pb + WAVE + lane, lo_n, hi_n, p0_n, p1_n);
-                            const uint32_t j0 = p0 & ~1u;
-                            uint4 e[PROBE_DEPTH];
+                            uint32_t tot = 0;
 #pragma unroll
-                            for (uint32_t st = 0; st < PROBE_DEPTH; st++) {  // 2 * PROBE_DEPTH entries in flight per lane
-                                e[st] = make_uint4(0u, 0u, 0u, 0u);
-                                if (j0 + 2 * st < p1) e[st] = frag2[(j0 >> 1) + st];
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) tot += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
+                            uint32_t incl = tot;  // inclusive prefix of the lanes' cell counts
+#pragma unroll
+                            for (int off = 1; off < 64; off <<= 1) {
+                                const uint32_t o = __shfl_up(incl, off, 64);
+                                if ((int)lane >= off) incl += o;
                             }
+                            uint32_t run = incl - tot;
 #pragma unroll
-                            for (uint32_t st = 0; st < PROBE_DEPTH; st++) test2(e[st], j0 + 2 * st, p0, p1, lo, hi);
-                            for (uint32_t j = j0 + 2 * PROBE_DEPTH; j < p1; j += 8) {  // long runs: four more loads per trip
-                                uint4 f[4];
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
+                                tp0[lane * PROBE_PER_LANE + i] = rp0[i];
+                                tp1[lane * PROBE_PER_LANE + i] = rp1[i];
+                                tcs[lane * PROBE_PER_LANE + i] = run;
+                                run += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
+                            }
+                            const uint32_t n_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            wave_sync();
+                            for (uint32_t cb = 0; cb < n_cells; cb += WAVE * PROBE_CELLS) {
+                                uint4 e[PROBE_CELLS];
+                                uint32_t eq[PROBE_CELLS], ej[PROBE_CELLS];
 #pragma unroll
-                                for (uint32_t st = 0; st < 4; st++) {
-                                    f[st] = make_uint4(0u, 0u, 0u, 0u);
-                                    if (j + 2 * st < p1) f[st] = frag2[(j >> 1) + st];
+                                for (uint32_t c = 0; c < PROBE_CELLS; c++) {
+                                    const uint32_t k = cb + c * WAVE + lane;
+                                    e[c] = make_uint4(0u, 0u, 0u, 0u);
+                                    eq[c] = NO_WINDOW;
+                                    ej[c] = 0;
+                                    if (k < n_cells) {
+                                        uint32_t a = 0;  // the owner of cell k: the largest q with tcs[q] <= k (tcs ascends; windows
+                                                         // with an empty run share their successor's start)
+#pragma unroll
+                                        for (uint32_t step = PROBE_BATCH / 2; step; step >>= 1) a += (tcs[a + step] <= k) ? step : 0;
+                                        eq[c] = a;
+                                        ej[c] = ((tp0[a] >> 1) + (k - tcs[a])) << 1;
+                                        e[c] = frag2[ej[c] >> 1];  // (tm2_frag is padded by 2 entries)
+                                    }
                                 }
 #pragma unroll
-                                for (uint32_t st = 0; st < 4; st++) test2(f[st], j + 2 * st, p0, p1, lo, hi);
+                                for (uint32_t c = 0; c < PROBE_CELLS; c++) {
+                                    if (eq[c] == NO_WINDOW) continue;
+                                    const uint32_t a = eq[c];
+                                    float lo, hi;
+                                    window_of(pbase + (a % PROBE_PER_LANE) * WAVE + a / PROBE_PER_LANE, lo, hi);
+                                    const uint32_t p0 = tp0[a], p1 = tp1[a], j = ej[c];
+                                    const float mz0 = __uint_as_float(e[c].y), mz1 = __uint_as_float(e[c].w);
+                                    if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e[c].x >= q.first && e[c].x < q.end) { cnt.add(e[c].x - left, 1); acc++; }
+                                    if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e[c].z >= q.first && e[c].z < q.end) { cnt.add(e[c].z - left, 1); acc++; }
+                                }
                             }
+                            wave_sync();  // (the next batch rewrites the run table)
                         }
                     }
                 }
@@ -752,8 +810,6 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
 // Same predicate as database.rs:526-533, so counts — and everything downstream — are identical.
 constexpr uint32_t TILE_THREADS = 512;
 constexpr uint32_t TILE_WAVES = TILE_THREADS / WAVE;
-constexpr uint32_t GROUP = 8;                         // lanes per (peak, fragment charge) window
-constexpr uint32_t NGROUP = TILE_THREADS / GROUP;     // windows in flight per pass
 constexpr uint32_t HIST_BINS = 64;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
@@ -765,6 +821,12 @@ struct TileLds {
     uint32_t* hist;     // [HIST_BINS] non-empty slots of the query so far, by matched count
     uint32_t* wsum;     // [TILE_WAVES]
     uint32_t* sh;       // [16] workgroup-shared scalars
+    // the runs of the unit being streamed (one probe per thread): first entry, end entry, first 16-byte cell of the run in the
+    // wavefront's flattened cell list; psum[w] = cells of wavefront w's probes
+    uint32_t* pp0;      // [TILE_THREADS]
+    uint32_t* pp1;      // [TILE_THREADS]
+    uint32_t* pcs;      // [TILE_THREADS]
+    uint32_t* psum;     // [TILE_WAVES]
 };
 __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem) {
     size_t off = 0;
@@ -782,6 +844,14 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     off += TILE_WAVES * 4;
     if (l) l->sh = (uint32_t*)(smem + off);
     off += 16 * 4;
+    if (l) l->pp0 = (uint32_t*)(smem + off);
+    off += TILE_THREADS * 4;
+    if (l) l->pp1 = (uint32_t*)(smem + off);
+    off += TILE_THREADS * 4;
+    if (l) l->pcs = (uint32_t*)(smem + off);
+    off += TILE_THREADS * 4;
+    if (l) l->psum = (uint32_t*)(smem + off);
+    off += TILE_WAVES * 4;
     return (off + 15) & ~(size_t)15;
 }
 
@@ -795,19 +865,19 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
     return (z - si.z0) * n_iso + (uint32_t)(iso - (fold ? sc.min_isotope_err : 0));
 }
 
-constexpr uint32_t PROBE_CACHE = 8;  // (peak, fragment charge) windows per 8-lane group whose table reads are in flight together
+constexpr uint32_t CELLS_PER_THREAD = 4;  // 16-byte index cells a thread of the count kernel keeps in flight (x 512 threads per unit)
 
-__device__ __forceinline__ void tile_hit(const TileLds& L, uint32_t x, uint32_t& acc) {
+__device__ __forceinline__ void tile_hit(uint32_t* cnt, uint32_t* bm, uint32_t x, uint32_t& acc) {
     // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
-    atomicAdd(&L.cnt[x >> 1], 1u << ((x & 1) * 16));
-    atomicOr(&L.bm[x >> 6], 1u << ((x >> 1) & 31u));
+    atomicAdd(&cnt[x >> 1], 1u << ((x & 1) * 16));
+    atomicOr(&bm[x >> 6], 1u << ((x >> 1) & 31u));
     acc++;
 }
-__device__ __forceinline__ void tile_test2(const TileLds& L, const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo,
+__device__ __forceinline__ void tile_test2(uint32_t* cnt, uint32_t* bm, const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo,
                                            float hi, uint32_t first, uint32_t end, uint32_t tb, uint32_t& acc) {
     const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
-    if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= first && e.x < end) tile_hit(L, e.x - tb, acc);
-    if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= first && e.z < end) tile_hit(L, e.z - tb, acc);
+    if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= first && e.x < end) tile_hit(cnt, bm, e.x - tb, acc);
+    if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= first && e.z < end) tile_hit(cnt, bm, e.z - tb, acc);
 }
 
 // (parameters through memory: ~300 bytes of by-value arguments would all be live in SGPRs and spill)
@@ -821,33 +891,44 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     const bool w0 = wave == 0;
     const uint32_t n_queued = uni(w.n_deferred[CTR_QUEUED]);
     if (n_queued == 0) return;
-    TileLds L;
-    tile_lds_layout(db.tile_shift, b, &L, smem);
+    // (the LDS arrays as plain locals: a struct of pointers captured by the lambdas below would live in scratch memory)
+    TileLds lds_;
+    tile_lds_layout(db.tile_shift, b, &lds_, smem);
+    uint32_t* const l_cnt = lds_.cnt;
+    uint32_t* const l_bm = lds_.bm;
+    float* const l_win_lo = lds_.win_lo;
+    float* const l_win_hi = lds_.win_hi;
+    uint32_t* const l_hist = lds_.hist;
+    uint32_t* const l_wsum = lds_.wsum;
+    uint32_t* const l_sh = lds_.sh;
+    uint32_t* const l_pp0 = lds_.pp0;
+    uint32_t* const l_pp1 = lds_.pp1;
+    uint32_t* const l_pcs = lds_.pcs;
+    uint32_t* const l_psum = lds_.psum;
     const uint32_t TSH = db.tile_shift, TS = 1u << TSH;
     const uint32_t n_bm = TS / 64;                                 // bitmap words of a tile
     const uint32_t bw_per = n_bm > TILE_THREADS ? n_bm / TILE_THREADS : 1;  // ... owned by one thread, contiguous: slot order == thread order
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
-    const uint32_t grp = tid / GROUP, sub = tid % GROUP;
     const float cell_max = (float)(db.lut_stride - 1);
     const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
 
-    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) L.cnt[i] = 0;  // all-zero between tiles: the scan clears what it reads
-    for (uint32_t i = tid; i < n_bm; i += TILE_THREADS) L.bm[i] = 0;
+    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: the scan clears what it reads
+    for (uint32_t i = tid; i < n_bm; i += TILE_THREADS) l_bm[i] = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     if (tid == 0) {  // first arena chunk of this workgroup
         const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
         const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
         const bool fits = (uint64_t)got + chunk <= w.arena_cap;
-        L.sh[SH_CHUNK_CUR] = fits ? got : NONE32;
-        L.sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
+        l_sh[SH_CHUNK_CUR] = fits ? got : NONE32;
+        l_sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
     }
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) L.sh[SH_ITEM] = atomicAdd(w.n_deferred + CTR_QUEUE_HEAD, 1u);
+        if (tid == 0) l_sh[SH_ITEM] = atomicAdd(w.n_deferred + CTR_QUEUE_HEAD, 1u);
         __syncthreads();
-        const uint32_t item = uni(L.sh[SH_ITEM]);
+        const uint32_t item = uni(l_sh[SH_ITEM]);
         if (item >= n_queued) break;
         const uint32_t spec = uni(w.queue[item]);
         PhaseClock pc;
@@ -860,8 +941,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             for (uint32_t fz = 1; fz <= si.nfz_max; fz++) {
                 float lo, hi;
                 tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
-                L.win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
-                L.win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
+                l_win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
+                l_win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
             }
         }
         if (tid < w.qmax) w.qrec[(size_t)item * w.qmax + tid].potential = 0;  // queries this spectrum does not run
@@ -877,14 +958,14 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 if (w0) {
                     const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
                     if (lane == 0) {
-                        L.sh[SH_LEFT] = q.left; L.sh[SH_RIGHT] = q.right; L.sh[SH_FIRST] = q.first; L.sh[SH_END] = q.end;
-                        L.sh[SH_MATCHED] = 0; L.sh[SH_SCORED] = 0; L.sh[SH_HMIN] = 0; L.sh[SH_HEAD] = NONE32; L.sh[SH_PREV] = NONE32;
+                        l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
+                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_HMIN] = 0; l_sh[SH_HEAD] = NONE32; l_sh[SH_PREV] = NONE32;
                     }
-                    L.hist[lane] = 0;
+                    l_hist[lane] = 0;
                     w.seeds[qid * 64 + lane] = 0;  // (pass 2 of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
-                const uint32_t left = uni(L.sh[SH_LEFT]), right = uni(L.sh[SH_RIGHT]), first = uni(L.sh[SH_FIRST]), end = uni(L.sh[SH_END]);
+                const uint32_t left = uni(l_sh[SH_LEFT]), right = uni(l_sh[SH_RIGHT]), first = uni(l_sh[SH_FIRST]), end = uni(l_sh[SH_END]);
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
                 const uint32_t k = trim_k(potential, sc.report_psms);
                 const bool select = potential > k;
@@ -896,8 +977,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     lo = 1.0f; hi = 0.0f;  // inactive: empty window
                     if (pr < nprobe && first < end) {
                         const uint32_t fz = pr / P, i = pr - fz * P;
-                        lo = L.win_lo[(size_t)fz * b.pcap + i];
-                        hi = L.win_hi[(size_t)fz * b.pcap + i];
+                        lo = l_win_lo[(size_t)fz * b.pcap + i];
+                        hi = l_win_hi[(size_t)fz * b.pcap + i];
                     }
                 };
                 auto probe_cells = [&](float lo, float hi, uint32_t& icl, uint32_t& ich) {
@@ -912,54 +993,124 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 pc.mark(0);
                 const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it
                 const uint32_t t0 = left >> TSH, t1 = db.np ? (last_pep >> TSH) : 0;
-                for (uint32_t t = t0; t <= t1; t++) {
-                    const uint32_t tb = t << TSH;
-                    // ---- stream: scoring.rs:358-375 over database.rs:480-536 ----
-                    {
+                // ---- stream: scoring.rs:358-375 over database.rs:480-536 --------------------------------------------------
+                // The work of a tile is its RUNS — for every (peak, fragment charge) window the index entries of the tile whose
+                // m/z falls into the window's table cells — and run lengths are extremely skewed: fragment masses sit in narrow
+                // mass-defect bands, so most windows of a spectrum find nothing while the ones on a band find 100+ entries.
+                // One thread per window reads its two table cells; the runs are then flattened into a list of 16-byte cells
+                // (two entries each) that ALL threads share evenly, every thread's cells in flight together.  Software
+                // pipeline over units (a unit = up to 512 windows of one tile): while tile t's counters are scanned, the
+                // entry cells of tile t + 1 and the table reads of tile t + 2 are in flight.
+                const uint32_t nb = nprobe ? (nprobe + TILE_THREADS - 1) / TILE_THREADS : 1;  // units per tile (1 up to 512 windows)
+                const uint32_t n_units = (t1 - t0 + 1) * nb;
+                uint32_t np0 = 0, np1 = 0;  // table values of this thread's window in the NEXT unit (in flight)
+                auto issue_lut = [&](uint32_t u) {
+                    np0 = np1 = 0;
+                    if (u >= n_units) return;
+                    const uint32_t t = t0 + u / nb, pr = (u % nb) * TILE_THREADS + tid;
+                    float lo, hi;
+                    uint32_t icl, ich;
+                    probe_bounds(pr, lo, hi);
+                    probe_cells(lo, hi, icl, ich);
+                    if (pr < nprobe && first < end && lo <= hi) {
                         const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
-                        for (uint32_t prb = grp; prb < nprobe; prb += PROBE_CACHE * NGROUP) {
-                            uint32_t p0[PROBE_CACHE], p1[PROBE_CACHE];
+                        np0 = lut[icl];
+                        np1 = lut[ich];
+                    }
+                };
+                // cells of the CURRENT unit in flight — named scalars, not arrays (arrays captured by the lambdas below end up in
+                // scratch memory): ceN the two entries, cprN the window (thread index of the unit; NONE32: none), cjjN the
+                // index of the cell's first entry
+#define SAGE_FOR_CELLS(X) X(0) X(1) X(2) X(3)
+                static_assert(CELLS_PER_THREAD == 4, "SAGE_FOR_CELLS lists the cells");
+#define SAGE_DECL_CELL(I) uint4 ce##I = make_uint4(0u, 0u, 0u, 0u); uint32_t cpr##I = NONE32, cjj##I = 0;
+                SAGE_FOR_CELLS(SAGE_DECL_CELL)
+#undef SAGE_DECL_CELL
+                uint32_t unit_cells = 0;         // cells of the current unit (uniform)
+                // locate flattened cell k of the published unit: wavefront by the wave totals, window by a 6-step search
+                auto locate = [&](uint32_t k, uint32_t& pr, uint32_t& j) {
+                    uint32_t wv = 0, base = 0;
 #pragma unroll
-                            for (uint32_t u = 0; u < PROBE_CACHE; u++) {  // all table reads in flight together
-                                float lo, hi;
-                                uint32_t icl, ich;
-                                probe_bounds(prb + u * NGROUP, lo, hi);
-                                probe_cells(lo, hi, icl, ich);
-                                p0[u] = lut[icl];
-                                p1[u] = lut[ich];
-                            }
+                    for (uint32_t i = 0; i + 1 < TILE_WAVES; i++) {
+                        const uint32_t v = l_psum[i];
+                        const bool past = k >= base + v && wv == i;
+                        base += past ? v : 0;
+                        wv += past ? 1 : 0;
+                    }
+                    const uint32_t kk = k - base;
+                    uint32_t a = 0;  // largest lane with pcs[wv * 64 + lane] <= kk: the owner of cell kk (pcs ascends inside a
+                                     // wavefront and lanes with empty runs share their successor's start)
 #pragma unroll
-                            for (uint32_t h = 0; h < PROBE_CACHE; h += 4) {
-                                uint4 e[4][2];
-                                uint32_t j0[4];
+                    for (uint32_t step = 32; step; step >>= 1) a += (l_pcs[wv * 64 + a + step] <= kk) ? step : 0;
+                    pr = wv * 64 + a;
+                    j = ((l_pp0[pr] >> 1) + (kk - l_pcs[pr])) << 1;
+                };
+#define SAGE_LOAD_CELL(I)                                                        \
+    {                                                                            \
+        const uint32_t k_ = kbase_ + I * TILE_THREADS + tid;                     \
+        cpr##I = NONE32;                                                         \
+        ce##I = make_uint4(0u, 0u, 0u, 0u);                                      \
+        if (k_ < unit_cells) {                                                   \
+            locate(k_, cpr##I, cjj##I);                                          \
+            ce##I = frag2[cjj##I >> 1]; /* (tm_frag is padded by 2 entries) */   \
+        }                                                                        \
+    }
+#define SAGE_APPLY_CELL(I)                                                                                         \
+    if (cpr##I != NONE32) {                                                                                        \
+        float lo_, hi_;                                                                                            \
+        probe_bounds(pb_ + cpr##I, lo_, hi_);                                                                      \
+        tile_test2(l_cnt, l_bm, ce##I, cjj##I, l_pp0[cpr##I], l_pp1[cpr##I], lo_, hi_, first, end, tb_, acc);                \
+    }
+                // publish unit u (its table values have arrived in np0 / np1), put its first cells and the table reads of unit
+                // u + 1 in flight.  One barrier inside; the caller has made sure nobody still reads the previous unit's table.
+                auto publish = [&](uint32_t u) {
+                    const uint32_t p0 = np0, p1 = np1;
+                    const uint32_t ncell = p1 > p0 ? ((p1 - 1) >> 1) - (p0 >> 1) + 1 : 0;
+                    uint32_t incl = ncell;  // inclusive prefix over the lanes
 #pragma unroll
-                                for (uint32_t u = 0; u < 4; u++) {  // the first two 16-entry steps of four windows in flight together
-                                    j0[u] = (p0[h + u] & ~1u) + 2 * sub;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t o = __shfl_up(incl, off, 64);
+                        if ((int)lane >= off) incl += o;
+                    }
+                    l_pp0[tid] = p0;
+                    l_pp1[tid] = p1;
+                    l_pcs[tid] = incl - ncell;
+                    if (lane == 63) l_psum[wave] = incl;
+                    issue_lut(u + 1);
+                    lds_barrier();
+                    uint32_t total = 0;
 #pragma unroll
-                                    for (uint32_t st = 0; st < 2; st++) {
-                                        const uint32_t j = j0[u] + st * 2 * GROUP;
-                                        e[u][st] = make_uint4(0u, 0u, 0u, 0u);
-                                        if (j < p1[h + u]) e[u][st] = frag2[j >> 1];  // (tm_frag is padded by 2 entries)
-                                    }
-                                }
-#pragma unroll
-                                for (uint32_t u = 0; u < 4; u++) {
-                                    float lo, hi;
-                                    probe_bounds(prb + (h + u) * NGROUP, lo, hi);
-#pragma unroll
-                                    for (uint32_t st = 0; st < 2; st++)
-                                        tile_test2(L, e[u][st], j0[u] + st * 2 * GROUP, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
-                                    for (uint32_t j = j0[u] + 4 * GROUP; j < p1[h + u]; j += 2 * GROUP)
-                                        tile_test2(L, frag2[j >> 1], j, p0[h + u], p1[h + u], lo, hi, first, end, tb, acc);
-                                }
-                            }
+                    for (uint32_t i = 0; i < TILE_WAVES; i++) total += l_psum[i];
+                    unit_cells = uni(total);
+                };
+                issue_lut(0);
+                publish(0);
+                {
+                    const uint32_t kbase_ = 0;
+                    SAGE_FOR_CELLS(SAGE_LOAD_CELL)
+                }
+                for (uint32_t u = 0; u < n_units; u++) {
+                    const uint32_t t = t0 + u / nb;
+                    const uint32_t tb = t << TSH;
+                    {
+                        const uint32_t tb_ = tb, pb_ = (u % nb) * TILE_THREADS;
+                        SAGE_FOR_CELLS(SAGE_APPLY_CELL)
+                        for (uint32_t kbase_ = CELLS_PER_THREAD * TILE_THREADS; kbase_ < unit_cells; kbase_ += CELLS_PER_THREAD * TILE_THREADS) {
+                            SAGE_FOR_CELLS(SAGE_LOAD_CELL)  // (a unit with more cells than fit in flight: the rest synchronously)
+                            SAGE_FOR_CELLS(SAGE_APPLY_CELL)
                         }
                     }
                     pc.mark(1);
-                    lds_barrier();
+                    lds_barrier();  // every hit of the unit is counted; its run table is free
+                    if (u + 1 < n_units) {
+                        publish(u + 1);
+                        const uint32_t kbase_ = 0;
+                        SAGE_FOR_CELLS(SAGE_LOAD_CELL)
+                    }
+                    if ((u % nb) != nb - 1) continue;  // (more windows of this tile to come)
                     pc.mark(2);
                     // ---- scan pass 1: each thread walks the touched counter words of its share of the tile, in slot order ----
-                    const uint32_t hmin = uni(L.sh[SH_HMIN]);  // lower bound of the heap minimum's count for this tile
+                    const uint32_t hmin = uni(l_sh[SH_HMIN]);  // lower bound of the heap minimum's count for this tile
                     const uint32_t bw0 = tid * bw_per;
                     uint32_t nne = 0, ncand = 0, h12 = 0, h34 = 0;
                     auto slot_stats = [&](uint32_t c, uint32_t x) {
@@ -967,12 +1118,12 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         nne++;
                         if (c <= 2) h12 += c == 1 ? 1u : 0x10000u;
                         else if (c <= 4) h34 += c == 3 ? 1u : 0x10000u;
-                        else atomicAdd(&L.hist[c < HIST_BINS ? c : HIST_BINS - 1], 1u);
+                        else atomicAdd(&l_hist[c < HIST_BINS ? c : HIST_BINS - 1], 1u);
                         if (select && c >= hmin && (uint64_t)tb + x >= (uint64_t)left + nseed) ncand++;
                     };
                     if (bw0 < n_bm) {
                         for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
-                            uint32_t m = L.bm[bwi];
+                            uint32_t m = l_bm[bwi];
                             while (m) {  // four touched words per trip: their LDS reads overlap
                                 constexpr int SB = 4;
                                 uint32_t wd[SB], v[SB];
@@ -982,7 +1133,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                                     m &= m - 1;  // (0 stays 0)
                                 }
 #pragma unroll
-                                for (int i = 0; i < SB; i++) v[i] = wd[i] != NONE32 ? L.cnt[wd[i]] : 0;
+                                for (int i = 0; i < SB; i++) v[i] = wd[i] != NONE32 ? l_cnt[wd[i]] : 0;
 #pragma unroll
                                 for (int i = 0; i < SB; i++) {
                                     if (v[i] == 0) continue;
@@ -997,11 +1148,11 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     h12 = wave_sum_dpp(h12);
                     h34 = wave_sum_dpp(h34);
                     if (lane == 0 && nne) {
-                        atomicAdd(&L.sh[SH_SCORED], nne);
-                        if (h12 & 0xFFFFu) atomicAdd(&L.hist[1], h12 & 0xFFFFu);
-                        if (h12 >> 16) atomicAdd(&L.hist[2], h12 >> 16);
-                        if (h34 & 0xFFFFu) atomicAdd(&L.hist[3], h34 & 0xFFFFu);
-                        if (h34 >> 16) atomicAdd(&L.hist[4], h34 >> 16);
+                        atomicAdd(&l_sh[SH_SCORED], nne);
+                        if (h12 & 0xFFFFu) atomicAdd(&l_hist[1], h12 & 0xFFFFu);
+                        if (h12 >> 16) atomicAdd(&l_hist[2], h12 >> 16);
+                        if (h34 & 0xFFFFu) atomicAdd(&l_hist[3], h34 & 0xFFFFu);
+                        if (h34 >> 16) atomicAdd(&l_hist[4], h34 >> 16);
                     }
                     // exclusive prefix of ncand over the lanes, bit-sliced through ballots (no cross-lane data movement)
                     uint32_t lane_off = 0, wave_total = 0;
@@ -1010,23 +1161,23 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         lane_off += (uint32_t)__popcll(m & lt_mask) << bit;
                         wave_total += (uint32_t)__popcll(m) << bit;
                     }
-                    if (lane == 0) L.wsum[wave] = wave_total;
+                    if (lane == 0) l_wsum[wave] = wave_total;
                     pc.mark(3);
                     lds_barrier();
                     uint32_t woff = 0, total = 0;
 #pragma unroll
                     for (uint32_t i = 0; i < TILE_WAVES; i++) {
-                        const uint32_t v = L.wsum[i];
+                        const uint32_t v = l_wsum[i];
                         woff += i < wave ? v : 0;
                         total += v;
                     }
                     // one candidate segment per tile, carved from this workgroup's arena chunk (room for a whole tile is
                     // reserved ahead of time, see below): {next, n, tile_base, 0} + entries, 16-byte aligned
                     total = uni(total);
-                    const uint32_t seg = total ? uni(L.sh[SH_CHUNK_CUR]) : NONE32;  // (NONE32 when the arena is exhausted)
+                    const uint32_t seg = total ? uni(l_sh[SH_CHUNK_CUR]) : NONE32;  // (NONE32 when the arena is exhausted)
                     if (w0) {
                         // the k-th largest count seen so far bounds the heap minimum for every LATER slot
-                        uint32_t suffix = L.hist[lane];
+                        uint32_t suffix = l_hist[lane];
 #pragma unroll
                         for (int off = 1; off < 64; off <<= 1) {
                             const uint32_t o = __shfl_down(suffix, off, 64);
@@ -1034,13 +1185,13 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         }
                         const uint64_t ok = __ballot(lane >= 1 && suffix >= k);
                         if (lane == 0) {
-                            L.sh[SH_HMIN_NEXT] = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
+                            l_sh[SH_HMIN_NEXT] = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
                             if (seg != NONE32) {
                                 *(uint4*)(w.arena + seg) = make_uint4(NONE32, total, tb, 0u);
-                                const uint32_t prev = L.sh[SH_PREV];
-                                if (prev == NONE32) L.sh[SH_HEAD] = seg;
+                                const uint32_t prev = l_sh[SH_PREV];
+                                if (prev == NONE32) l_sh[SH_HEAD] = seg;
                                 else w.arena[prev] = seg;
-                                L.sh[SH_PREV] = seg;
+                                l_sh[SH_PREV] = seg;
                             }
                         }
                     }
@@ -1055,8 +1206,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             else if (select && c >= hmin && seg != NONE32) w.arena[pos++] = (c << 16) | x;
                         };
                         for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
-                            uint32_t m = L.bm[bwi];
-                            if (m) L.bm[bwi] = 0;
+                            uint32_t m = l_bm[bwi];
+                            if (m) l_bm[bwi] = 0;
                             while (m) {
                                 constexpr int SB = 4;
                                 uint32_t wd[SB], v[SB];
@@ -1069,8 +1220,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                                 for (int i = 0; i < SB; i++) {
                                     v[i] = 0;
                                     if (wd[i] != NONE32) {
-                                        v[i] = L.cnt[wd[i]];
-                                        L.cnt[wd[i]] = 0;
+                                        v[i] = l_cnt[wd[i]];
+                                        l_cnt[wd[i]] = 0;
                                     }
                                 }
 #pragma unroll
@@ -1086,33 +1237,33 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     lds_barrier();  // (the candidate / verbatim-slot stores of pass 2 stay in flight)
                     pc.mark(6);
                     if (tid == 0) {  // (read again only after the next tile's first barrier)
-                        L.sh[SH_HMIN] = L.sh[SH_HMIN_NEXT];
-                        uint32_t cur = L.sh[SH_CHUNK_CUR];
+                        l_sh[SH_HMIN] = l_sh[SH_HMIN_NEXT];
+                        uint32_t cur = l_sh[SH_CHUNK_CUR];
                         if (seg != NONE32) cur += ((total + 3u) & ~3u) + 4u;
                         else if (total && cur == NONE32) atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);  // candidates were dropped
                         // keep room for a whole tile's worth of candidates, so that every thread can take the segment base
                         // from LDS without waiting for a global allocation
-                        if (cur == NONE32 || L.sh[SH_CHUNK_LIM] - cur < TS + 8u) {
+                        if (cur == NONE32 || l_sh[SH_CHUNK_LIM] - cur < TS + 8u) {
                             const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
                             const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
                             if ((uint64_t)got + chunk > w.arena_cap) {
                                 cur = NONE32;
                             } else {
                                 cur = got;
-                                L.sh[SH_CHUNK_LIM] = got + chunk;
+                                l_sh[SH_CHUNK_LIM] = got + chunk;
                             }
                         }
-                        L.sh[SH_CHUNK_CUR] = cur;
+                        l_sh[SH_CHUNK_CUR] = cur;
                     }
                 }
                 // ---- totals of this query ----
                 acc = wave_sum_dpp(acc);
-                if (lane == 0 && acc) atomicAdd(&L.sh[SH_MATCHED], acc);
+                if (lane == 0 && acc) atomicAdd(&l_sh[SH_MATCHED], acc);
                 __syncthreads();
                 if (w0) {
                     // the k-th largest count T of the whole window and how many of the slots equal to T (the first ones) do
                     // NOT make the cut: all an order-free trim_hits needs (tile_select_kernel)
-                    const uint32_t hmine = L.hist[lane];
+                    const uint32_t hmine = l_hist[lane];
                     uint32_t suffix = hmine;
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
@@ -1128,9 +1279,9 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         QueryRec r;
                         r.left = left;
                         r.potential = potential;
-                        r.matched = L.sh[SH_MATCHED];
-                        r.scored = L.sh[SH_SCORED];
-                        r.head = L.sh[SH_HEAD];
+                        r.matched = l_sh[SH_MATCHED];
+                        r.scored = l_sh[SH_SCORED];
+                        r.head = l_sh[SH_HEAD];
                         r.z_iso = z | ((uint32_t)(iso + 128) << 8);
                         r.pad[0] = big | (T << 8);                        // bit 0: the heap replay must keep 64-bit keys / no fast select
                         r.pad[1] = T ? n_eq - (k - n_gt) : 0;             // slots equal to T to skip
@@ -1657,6 +1808,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     if (blockIdx.x >= b.n) return;
+    if (b.n_dev && blockIdx.x >= *b.n_dev) return;  // retry pass: device-side count
     const uint32_t spec = b.order ? b.order[blockIdx.x] : blockIdx.x;
     // LDS carve
     double* s_sorted = (double*)smem;                         // [64] hyperscores by rank
@@ -1856,7 +2008,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
                 (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
             const uint32_t plen = info & 0xFFFF;
             SageFeature f;
-            f.spec_index = spec;
+            f.spec_index = b.spec_base + spec;
             f.peptide_idx = pep;
             f.rank = sc.chimera ? round + 1 : rank + 1;  // scoring.rs:541, 664
             f.label = ((info >> 16) & 0xFF) ? -1 : 1;
@@ -1984,7 +2136,7 @@ __global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
     size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 +
-               (b.probe ? (size_t)b.pcap * 4 : (size_t)b.fzcap * b.pcap * 8);
+               (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)3 * PROBE_BATCH_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
     n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }

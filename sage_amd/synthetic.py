@@ -51,11 +51,15 @@ def synthetic_spectra(db: IndexedDatabase, n_spectra: int, seed: int, noise_peak
     plain = modded = None
     if varmod_frac is not None:
         # a source peptide "carries a variable mod" when it has a terminal mod or a modified `varmod_residues` residue
-        flag = np.zeros(len(db.seq) + 1, dtype=np.int64)
-        flag[:-1] = np.isin(db.seq, np.frombuffer(varmod_residues.encode(), np.uint8)) & (db.mods != 0)
-        per_pep = np.add.reduceat(flag, db.seq_off[:-1].astype(np.int64)) if db.n_peptides else np.zeros(0, np.int64)
-        is_mod = (per_pep > 0) | (np.nan_to_num(db.nterm) != 0) | (np.nan_to_num(db.cterm) != 0)
-        plain, modded = targets[~is_mod[targets]], targets[is_mod[targets]]
+        # (computed once per database: it walks every residue)
+        cache = db.__dict__.setdefault("_synthetic_pools", {})
+        if varmod_residues not in cache:
+            flag = np.zeros(len(db.seq) + 1, dtype=np.int64)
+            flag[:-1] = np.isin(db.seq, np.frombuffer(varmod_residues.encode(), np.uint8)) & (db.mods != 0)
+            per_pep = np.add.reduceat(flag, db.seq_off[:-1].astype(np.int64)) if db.n_peptides else np.zeros(0, np.int64)
+            is_mod = (per_pep > 0) | (np.nan_to_num(db.nterm) != 0) | (np.nan_to_num(db.cterm) != 0)
+            cache[varmod_residues] = (targets[~is_mod[targets]], targets[is_mod[targets]])
+        plain, modded = cache[varmod_residues]
         if len(plain) == 0 or len(modded) == 0:
             plain = modded = None
     zs = np.array([c for c, _ in charges])

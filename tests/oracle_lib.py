@@ -12,6 +12,8 @@ from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+# the same sources built for speed (oracle/Makefile: FASTFLAGS); bit-identical outputs; bench.py's cpu_baseline times this one
+LIB_FAST = os.path.join(ORACLE_DIR, "_build", "liboracle_fast.so")
 SELFTEST = os.path.join(ORACLE_DIR, "_build", "oracle_selftest")
 
 
@@ -24,13 +26,30 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-_lib = None
+_libs = {}
+_kind = "check"
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
+class use:
+    """with oracle_lib.use("fast"): objects created inside bind to the performance build of the oracle."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        global _kind
+        self.prev, _kind = _kind, self.kind
+
+    def __exit__(self, *a):
+        global _kind
+        _kind = self.prev
+
+
+def load(kind=None):
+    kind = kind or _kind
+    if kind in _libs:
+        return _libs[kind]
+    LIB = LIB_FAST if kind == "fast" else globals()["LIB"]
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("sage_oracle.cpp", "sage_oracle.hpp", "oracle_capi.cpp", "rescore_oracle.cpp",
                                                 "selftest.cpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs if os.path.exists(s)):
@@ -104,7 +123,7 @@ def load():
     lib.orc_im_embed.argtypes = [L.c_u8_p, C.c_uint64, C.c_float, C.c_uint8, dp]
     lib.orc_predict_rt.argtypes = [vp, C.c_uint64, C.c_uint32, L.c_u64_p, L.c_u8_p, L.c_float_p] + [L.c_float_p] * 7 + \
         [C.POINTER(C.c_int32), dp]
-    _lib = lib
+    _libs[kind] = lib
     return lib
 
 
@@ -113,7 +132,7 @@ class OracleDb:
 
     def __init__(self, handle):
         self.h = handle
-        lib = load()
+        lib = self.lib = load()
         self.n_peptides = int(lib.orc_db_num_peptides(self.h))
         self.n_fragments = int(lib.orc_db_num_fragments(self.h))
         self.n_buckets = int(lib.orc_db_num_buckets(self.h))
@@ -153,7 +172,7 @@ class OracleDb:
         return OracleDb(C.c_void_p(h))
 
     def arrays(self):
-        lib = load()
+        lib = self.lib
         nf, np_, nb = self.n_fragments, self.n_peptides, self.n_buckets
         tot = int(lib.orc_db_total_residues(self.h))
         out = dict(frag_pep=np.zeros(nf, np.uint32), frag_mz=np.zeros(nf, np.float32), min_value=np.zeros(nb, np.float32),
@@ -169,7 +188,7 @@ class OracleDb:
         return out
 
     def peptide_strings(self):
-        lib = load()
+        lib = self.lib
         n = lib.orc_db_peptide_strings(self.h, None, 0)
         buf = C.create_string_buffer(int(n))
         lib.orc_db_peptide_strings(self.h, buf, n)
@@ -177,14 +196,14 @@ class OracleDb:
         return s.split("\n")[:-1] if s else []
 
     def peptide_proteins(self, i):
-        lib = load()
+        lib = self.lib
         n = lib.orc_db_peptide_proteins(self.h, i, None, 0)
         buf = C.create_string_buffer(int(n))
         lib.orc_db_peptide_proteins(self.h, i, buf, n)
         return buf.value.decode()
 
     def page_search(self, precursor_mass, ptol, ftol, mass, cap=1 << 20):
-        lib = load()
+        lib = self.lib
         idx = np.zeros(cap, np.uint64)
         lo, hi = C.c_uint64(), C.c_uint64()
         n = lib.orc_db_page_search(self.h, precursor_mass, ptol.to_c(), ftol.to_c(), mass, L.as_ptr(idx, C.c_uint64),
@@ -193,7 +212,7 @@ class OracleDb:
 
     def score(self, params: ScorerParams, batch: SpectrumBatch, threads: int = 0, work: bool = False):
         """Scorer::score for each spectrum.  Returns (features[n, report], counts[n], elapsed_ms, work|None)."""
-        lib = load()
+        lib = self.lib
         cp = params.to_c()
         cb = batch.to_c()
         feats = np.zeros(batch.n * params.report_psms, dtype=L.FEATURE_DTYPE)
@@ -206,7 +225,7 @@ class OracleDb:
 
     def annotate(self, params: ScorerParams, batch: SpectrumBatch, cap: int = 1 << 22):
         """Fragments (scoring.rs:152-161) of every reported PSM: (psm_off[n*report+1], dict of flat arrays)."""
-        lib = load()
+        lib = self.lib
         cp = params.to_c(); cb = batch.to_c()
         off = np.zeros(batch.n * params.report_psms + 1, np.uint64)
         out = dict(kinds=np.zeros(cap, np.uint8), charges=np.zeros(cap, np.int32), fragment_ordinals=np.zeros(cap, np.int32),
@@ -221,14 +240,14 @@ class OracleDb:
         return off, {k: v[:n].copy() for k, v in out.items()}
 
     def quick_score(self, params: ScorerParams, batch: SpectrumBatch, prefilter_low_memory: bool):
-        lib = load()
+        lib = self.lib
         cp = params.to_c(); cb = batch.to_c()
         keep = np.zeros(self.n_peptides, np.uint8)
         lib.orc_quick_score(self.h, C.byref(cp), C.byref(cb), int(prefilter_low_memory), L.as_ptr(keep, C.c_uint8))
         return keep
 
     def initial_hits(self, params: ScorerParams, batch: SpectrumBatch, i: int):
-        lib = load()
+        lib = self.lib
         cap = 4096
         m = np.zeros(cap, np.uint16); p = np.zeros(cap, np.uint32); z = np.zeros(cap, np.uint8); iso = np.zeros(cap, np.int8)
         mp, sc = C.c_uint64(), C.c_uint64()
@@ -241,7 +260,7 @@ class OracleDb:
         return packed, int(mp.value), int(sc.value)
 
     def brute_force(self, params: ScorerParams, batch: SpectrumBatch, i: int, charge: int, iso: int, cap=1 << 16):
-        lib = load()
+        lib = self.lib
         p = np.zeros(cap, np.uint32); m = np.zeros(cap, np.uint32); h = np.zeros(cap, np.float64)
         cp = params.to_c(); cb = batch.to_c()
         n = int(lib.orc_brute_force(self.h, C.byref(cp), C.byref(cb), i, charge, iso, L.as_ptr(p, C.c_uint32),
@@ -250,7 +269,7 @@ class OracleDb:
 
     def close(self):
         if self.h:
-            load().orc_db_free(self.h)
+            self.lib.orc_db_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -29,34 +29,55 @@ def _last_json(stdout):
 @pytest.mark.gpu
 def test_bench_single_rank_line(gpu_required):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--spectra", "3000", "--proteins", "400",
-                        "--cpu-sample", "512"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--cpu-sample", "512", "--traffic-timeout", "150"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     for k in REQUIRED:
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "spectra/s" and j["value"] > 0
-    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
+    assert j["scaling"] == "strong" and j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "traffic" in rf and rf["traffic_source"]  # measured now (rocprofv3 --pmc passes) or says why not
+    if rf["traffic"] is not None:
+        assert abs(rf["frac_traffic"] - rf["achieved_traffic"] / rf["peak"]) < 1e-9
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "identical" in cb["parity"]
-    assert "workload" in j["config"]
+    assert cb["threads_table"] and str(cb["cores"]) in cb["threads_table"]
+    assert "workload" in j["config"] and j["config"]["spectra_this_rank"] == j["config"]["spectra_total"]
+    assert j["sustained"]["seconds"] >= 1.0 and j["sustained"]["value"] > 0
+    h2h = j["host_to_host_value"]
+    assert h2h["page_locked"] > 0 and h2h["pageable"] > 0 and j["pcie_inclusive_value"] == h2h["page_locked"]
+
+
+def _torchrun(n, extra, timeout=900):
+    env = dict(os.environ, SAGE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--proteins", "300",
+           "--no-extras"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _last_json(r.stdout)
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_through_torchrun(gpu_required):
+def test_bench_two_ranks_strong_scaling_through_torchrun(gpu_required):
     """The driver's N > 1 launch line with two ranks.  A 1-GPU box cannot give each rank its own device or run RCCL between
-    them, so the rehearsal backend (gloo; ranks share the device) stands in: everything else — env parsing, per-rank
-    workloads, barrier, max-over-ranks, whole-job aggregate, rank-0-only output — is the code the real run executes."""
-    env = dict(os.environ, SAGE_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--spectra", "2000",
-           "--proteins", "300"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    j = _last_json(r.stdout)
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["cpu_baseline"] is None
-    # weak scaling: both ranks scored their own batch, the aggregate counts both
-    per_rank = j["config"]["spectra_per_gpu"]
-    assert 1500 < per_rank <= 2000
-    assert abs(j["value"] - 2 * per_rank * 3 / (j["ms_per_step"] * 3 / 1000.0)) / j["value"] < 0.05
+    them, so the rehearsal backend (gloo; ranks share the device) stands in: everything else — env parsing, the one workload cut
+    with plan_shards, per-rank scoring, barrier, max-over-ranks, whole-job aggregate, the ordered gather and its check against
+    rank 0's single-GPU pass, rank-0-only output — is the code the real run executes."""
+    j = _torchrun(2, ["--spectra", "3000"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
+    sh = j["sharding"]
+    assert sh["identical_to_single_gpu"] is True and len(sh["shards"]) == 2 and sh["shards"][0][1] == sh["shards"][1][0]
+    total = j["config"]["spectra_total"]
+    assert 2500 < total <= 3000 and sh["shards"][1][1] == total and 0 < j["config"]["spectra_this_rank"] < total
+    assert abs(j["value"] - total * 3 / (j["ms_per_step"] * 3 / 1000.0)) / j["value"] < 0.05
+
+
+@pytest.mark.gpu
+def test_bench_weak_scaling_mode(gpu_required):
+    j = _torchrun(2, ["--spectra", "2000", "--scaling", "weak"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["sharding"] is None
+    per_rank = j["config"]["spectra_this_rank"]
+    assert 1500 < per_rank <= 2000 and abs(j["config"]["spectra_total"] - 2 * per_rank) < 100

@@ -341,3 +341,73 @@ def test_error_paths(small_world):
         Scorer(small_world.dev, ScorerParams(report_psms=0))
     with pytest.raises(L.SageHipError):
         Scorer(small_world.dev, ScorerParams(min_isotope_err=2, max_isotope_err=1))
+
+
+def test_streaming_pipeline_chunks(small_world, monkeypatch):
+    """sage_hip_score_batch as a pipeline over chunks (here 64 spectra instead of 65536, so ten chunks rotate through the two
+    slots): pageable and page-locked inputs, page-locked and pageable outputs, spec_index in the caller's numbering; narrow,
+    isotope-folded / unknown-charge, mixed narrow / tiled, chimera."""
+    monkeypatch.setenv("SAGE_HIP_CHUNK", "64")
+    b = small_world.batch
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current,
+                            b.isolation_lo, b.isolation_hi, b.scan_start_time, b.inverse_ion_mobility, b.file_id)
+    for params, batch, ctx in ((ScorerParams(), b, "narrow"),
+                               (ScorerParams(min_isotope_err=-1, max_isotope_err=2, report_psms=3), unknown, "iso x charges"),
+                               (ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0), report_psms=2), b, "mixed routing"),
+                               (ScorerParams(chimera=True, report_psms=3), b, "chimera")):
+        scorer = Scorer(small_world.dev, params)
+        of, oc, _, _ = small_world.orc.score(params, batch)
+        locked = batch.page_locked()
+        for inp, pinned_out, how in ((batch, True, "pageable in"), (locked, True, "page-locked in"), (batch, False, "pageable out")):
+            gf, gc = scorer.score(inp, pinned_out=pinned_out)
+            n = assert_features_equal(gf, gc, of, oc, f"pipeline {ctx}, {how}")
+            valid = np.arange(gf.shape[1])[None, :] < gc[:, None]
+            assert np.array_equal(gf["spec_index"][valid], np.broadcast_to(np.arange(batch.n)[:, None], gf.shape)[valid])
+        t = scorer.last_timing()
+        assert n > 100 and t["n_launches"] >= 10 * 12  # ten chunks, two passes each
+    # a chunk boundary that leaves a last chunk of one spectrum, and a batch smaller than a chunk
+    scorer = Scorer(small_world.dev, ScorerParams())
+    for m in (65, 64, 3, 1):
+        sub = b.subset(np.arange(m))
+        of, oc, _, _ = small_world.orc.score(ScorerParams(), sub)
+        assert_features_equal(*scorer.score(sub), of, oc, f"pipeline, {m} spectra")
+
+
+def test_scorer_shared_between_threads_and_cloned(small_world):
+    """`&Scorer` is shared by every rayon worker (scoring.rs:300, runner.rs:311-325): one handle called from several host
+    threads at once (calls serialise), and clones of it scoring concurrently — all results equal the oracle's."""
+    import threading
+    params = ScorerParams(report_psms=2)
+    scorer = Scorer(small_world.dev, params)
+    of, oc, _, _ = small_world.orc.score(params, small_world.batch)
+    parts = [small_world.batch.subset(np.arange(k, small_world.batch.n, 4)) for k in range(4)]
+    refs = [small_world.orc.score(params, p)[:2] for p in parts]
+    errors = []
+
+    def work(sc, k, reps):
+        try:
+            for _ in range(reps):
+                gf, gc = sc.score(parts[k], pinned_out=False)
+                assert_features_equal(gf, gc, refs[k][0], refs[k][1], f"thread {k}")
+        except Exception as e:  # noqa: BLE001 (reported below)
+            errors.append(repr(e))
+
+    for scorers in ([scorer] * 4, [scorer.clone() for _ in range(4)]):
+        ts = [threading.Thread(target=work, args=(scorers[k], k, 5)) for k in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors
+    assert_features_equal(*scorer.score(small_world.batch), of, oc, "after the threads")
+
+
+def test_arena_exhaustion_splits_the_batch(small_world, monkeypatch):
+    """A large-window candidate arena too small for the chunk (1 MiB instead of ~1 GiB): the chunk is scored again in halves
+    until its pieces fit — same PSMs, no error."""
+    monkeypatch.setenv("SAGE_HIP_ARENA_MB", "1")
+    params = ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0))
+    sub = small_world.batch.subset(np.arange(0, small_world.batch.n, 5))
+    scorer = Scorer(small_world.dev, params)
+    of, oc, _, _ = small_world.orc.score(params, sub)
+    gf, gc = scorer.score(sub)
+    assert_features_equal(gf, gc, of, oc, "arena split")
+    assert scorer.last_timing()["n_launches"] > 12  # more than one piece

@@ -94,3 +94,25 @@ def test_oracle_index_vs_brute_force():
     assert best is not None
     assert best[0] == feats[0, 0]["peptide_idx"] and best[1] == feats[0, 0]["matched_peaks"]
     assert best[2] == feats[0, 0]["hyperscore"]
+
+
+def test_performance_build_of_the_oracle_is_bit_identical():
+    """oracle/_build/liboracle_fast.so (the same sources at -O3 for x86-64-v3, the build bench.py times as cpu_baseline) against
+    the -O2 checker: narrow, isotope-folded, open and chimeric searches, every Feature field bit for bit."""
+    import oracle_lib
+    from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch, SpectrumProcessor, Tolerance
+    from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
+    fasta = synthetic_fasta(200, seed=51)
+    host = DatabaseParameters(bucket_size=2048, enzyme=dict(missed_cleavages=1, cleave_at="KR", restrict="P"),
+                              static_mods={"C": 57.0215}, variable_mods={"M": [15.9949]}).build(fasta)
+    sp = SpectrumProcessor(150, True, 0.0)
+    batch = SpectrumBatch.from_spectra([sp.process(r) for r in synthetic_spectra(host, 300, seed=52)])
+    check = oracle_lib.OracleDb.from_product(host)
+    with oracle_lib.use("fast"):
+        fast = oracle_lib.OracleDb.from_product(host)
+    assert fast.lib is not check.lib
+    for params in (ScorerParams(), ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=3),
+                   ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0)), ScorerParams(chimera=True, wide_window=True, report_psms=3)):
+        a, ac, _, _ = check.score(params, batch)
+        b, bc, _, _ = fast.score(params, batch)
+        assert np.array_equal(ac, bc) and a.tobytes() == b.tobytes()

@@ -44,12 +44,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather_preserves_input_order():
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_and_gather_preserves_input_order(world):
+    """world_size 2 and 8 (the node the path is sharded over): every rank scores its plan_shards range, the gathered records
+    equal a single pass over the whole batch byte for byte."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=300)
