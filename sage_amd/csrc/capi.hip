@@ -1103,6 +1103,7 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
     w.arena = ws.arena.p;
     w.arena_cap = (uint32_t)ws.arena.n;
     w.qmax = s->qmax;
+    w.tile_shift = s->db->view.tile_shift;
     w.dbg = s->dbg.p;
     w.tile_params = o.tile_params.p + pass;
     return w;

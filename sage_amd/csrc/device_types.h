@@ -109,6 +109,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
     uint32_t arena_cap;    // entries
     uint32_t qmax;
+    uint32_t tile_shift;   // log2 of the peptides per tile (the readers of the candidate directories need it)
     unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)
 };
 
@@ -122,9 +123,11 @@ struct QueryRec {
     uint32_t potential;   // number of candidate slots (scoring.rs:351); 0 == query not evaluated
     uint32_t matched;     // InitialHits.matched_peaks of this query
     uint32_t scored;      // InitialHits.scored_candidates of this query
-    uint32_t head;        // first candidate segment in the arena (0xFFFFFFFF: none)
+    uint32_t head;        // the query's candidate directory in the arena (0xFFFFFFFF: none): n_dir entries {position, count}
     uint32_t z_iso;       // precursor charge | (isotope error + 128) << 8
-    uint32_t pad[2];
+    uint32_t pad[2];      // [0] bit 0: some count >= 63 (clipped histogram), bits 8..: k-th largest count T; [1] slots == T to skip
+    uint32_t n_dir;       // directory entries: tiles of the window x wavefronts of the count kernel, in slot order
+    uint32_t t0;          // first tile of the window
 };
 
 // device-side SageFragments (sage_hip.h)

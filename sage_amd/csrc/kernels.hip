@@ -64,6 +64,18 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// wave64 inclusive prefix sum through DPP row operations (no LDS crossbar round trips): Hillis-Steele inside the rows of 16,
+// then the last lane of a row / of the lower half is broadcast into the rows above
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -815,14 +827,13 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
 struct TileLds {
     uint32_t* cnt;      // [tile_size / 2] u16 pairs
-    uint32_t* bm;       // [tile_size / 64] one bit per counter word: touched since the last scan
+    uint32_t* bm;       // [tile_size / 32] one bit per slot: its count reached this tile's pruning threshold (a candidate)
     float* win_lo;      // [fzcap * pcap]
     float* win_hi;
     uint32_t* hist;     // [HIST_BINS] non-empty slots of the query so far, by matched count
-    uint32_t* wsum;     // [TILE_WAVES]
     uint32_t* sh;       // [16] workgroup-shared scalars
-    // the runs of the unit being streamed (one probe per thread): first entry, end entry, first 16-byte cell of the run in the
-    // wavefront's flattened cell list; psum[w] = cells of wavefront w's probes
+    // the runs of the unit being streamed (one window per thread): first entry, end entry, first 16-byte cell of the run in the
+    // wavefront's flattened cell list; psum[w] = cells of wavefront w's windows
     uint32_t* pp0;      // [TILE_THREADS]
     uint32_t* pp1;      // [TILE_THREADS]
     uint32_t* pcs;      // [TILE_THREADS]
@@ -833,15 +844,14 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     if (l) l->cnt = (uint32_t*)(smem + off);
     off += ((size_t)1 << tile_shift) * 2;
     if (l) l->bm = (uint32_t*)(smem + off);
-    off += ((size_t)1 << tile_shift) / 64 * 4;
+    off += (((size_t)1 << tile_shift) / 32 + 3) / 4 * 16;
     if (l) l->win_lo = (float*)(smem + off);
     off += (size_t)b.fzcap * b.pcap * 4;
     if (l) l->win_hi = (float*)(smem + off);
     off += (size_t)b.fzcap * b.pcap * 4;
+    off = (off + 15) & ~(size_t)15;  // (what follows is read in 16-byte pieces)
     if (l) l->hist = (uint32_t*)(smem + off);
     off += HIST_BINS * 4;
-    if (l) l->wsum = (uint32_t*)(smem + off);
-    off += TILE_WAVES * 4;
     if (l) l->sh = (uint32_t*)(smem + off);
     off += 16 * 4;
     if (l) l->pp0 = (uint32_t*)(smem + off);
@@ -855,8 +865,7 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     return (off + 15) & ~(size_t)15;
 }
 
-enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_HMIN, SH_HMIN_NEXT, SH_HEAD, SH_PREV,
-       SH_CHUNK_CUR, SH_CHUNK_LIM };
+enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_DIR, SH_ARENA_OK, SH_CHUNK_CUR, SH_CHUNK_LIM, SH_THR };
 constexpr uint32_t ARENA_CHUNK = 1u << 16;  // entries a workgroup takes from the global arena at a time
 
 __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecInfo& si, uint32_t z, int iso) {
@@ -867,26 +876,39 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
 
 constexpr uint32_t CELLS_PER_THREAD = 4;  // 16-byte index cells a thread of the count kernel keeps in flight (x 512 threads per unit)
 
-__device__ __forceinline__ void tile_hit(uint32_t* cnt, uint32_t* bm, uint32_t x, uint32_t& acc) {
-    // two fire-and-forget LDS atomics (no returned value to wait for): the counter and its word's "touched" bit
-    atomicAdd(&cnt[x >> 1], 1u << ((x & 1) * 16));
-    atomicOr(&bm[x >> 6], 1u << ((x >> 1) & 31u));
-    acc++;
-}
-__device__ __forceinline__ void tile_test2(uint32_t* cnt, uint32_t* bm, const uint4 e, uint32_t j, uint32_t p0, uint32_t p1, float lo,
-                                           float hi, uint32_t first, uint32_t end, uint32_t tb, uint32_t& acc) {
-    const float mz0 = __uint_as_float(e.y), mz1 = __uint_as_float(e.w);
-    if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e.x >= first && e.x < end) tile_hit(cnt, bm, e.x - tb, acc);
-    if (j + 1 < p1 && mz1 >= lo && mz1 <= hi && e.z >= first && e.z < end) tile_hit(cnt, bm, e.z - tb, acc);
+// j-th (0-based) set bit of a 64-bit mask that has more than j bits set
+__device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t j) {
+    uint32_t pos = 0;
+    uint32_t lo = (uint32_t)m;
+    const uint32_t c32 = (uint32_t)__popc(lo);
+    if (j >= c32) { j -= c32; pos = 32; lo = (uint32_t)(m >> 32); }
+#pragma unroll
+    for (uint32_t width = 16; width; width >>= 1) {
+        const uint32_t c = (uint32_t)__popc(lo & ((1u << width) - 1u));
+        const bool up = j >= c;
+        j -= up ? c : 0;
+        pos += up ? width : 0;
+        lo = up ? lo >> width : lo;
+    }
+    return pos;
 }
 
-// (parameters through memory: ~300 bytes of by-value arguments would all be live in SGPRs and spill)
-__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams* __restrict__ kp) {
+// The candidate stream of a query is a DIRECTORY in the arena: for every (tile of the window, wavefront of the count kernel)
+// one entry {position, count} of a run of candidate words `matched count << 16 | slot in tile`, in slot order inside the run;
+// directory order == slot order (tile-major, then the 8 slot ranges of a tile the 8 wavefronts own).  A word with count 0 is
+// a hole (a slot that belongs to the verbatim head of the window): readers skip it.
+constexpr uint32_t DIR_WORDS = 2;
+
+// Parameters BY VALUE: pointer members of a by-value kernel argument are known to be global, so the compiler emits global_*
+// instructions.  (Read through a TileParams pointer they were generic pointers -> FLAT loads / stores / atomics, which count
+// on lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of an LDS access then also waited for all outstanding HBM
+// loads.)
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams kp) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const DevDbView& db = kp->db;
-    const DevScorer& sc = kp->sc;
-    const DevBatchView& b = kp->b;
-    const DevWork& w = kp->w;
+    const DevDbView& db = kp.db;
+    const DevScorer& sc = kp.sc;
+    const DevBatchView& b = kp.b;
+    const DevWork& w = kp.w;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool w0 = wave == 0;
     const uint32_t n_queued = uni(w.n_deferred[CTR_QUEUED]);
@@ -899,29 +921,39 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     float* const l_win_lo = lds_.win_lo;
     float* const l_win_hi = lds_.win_hi;
     uint32_t* const l_hist = lds_.hist;
-    uint32_t* const l_wsum = lds_.wsum;
     uint32_t* const l_sh = lds_.sh;
     uint32_t* const l_pp0 = lds_.pp0;
     uint32_t* const l_pp1 = lds_.pp1;
     uint32_t* const l_pcs = lds_.pcs;
     uint32_t* const l_psum = lds_.psum;
     const uint32_t TSH = db.tile_shift, TS = 1u << TSH;
-    const uint32_t n_bm = TS / 64;                                 // bitmap words of a tile
-    const uint32_t bw_per = n_bm > TILE_THREADS ? n_bm / TILE_THREADS : 1;  // ... owned by one thread, contiguous: slot order == thread order
+    // counter words (two slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [2 * tid * wpt, ...), so thread
+    // order == slot order.  tile_shift 15: 32 words = eight 16-byte quads per thread.
+    const uint32_t wpt = (TS / 2 + TILE_THREADS - 1) / TILE_THREADS;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
     const float cell_max = (float)(db.lut_stride - 1);
     const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
 
-    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: the scan clears what it reads
-    for (uint32_t i = tid; i < n_bm; i += TILE_THREADS) l_bm[i] = 0;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    if (tid == 0) {  // first arena chunk of this workgroup
-        const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
+    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: every scan clears them
+    for (uint32_t i = tid; i < TS / 32; i += TILE_THREADS) l_bm[i] = 0;
+    // this workgroup's share of the arena: a bump allocator in LDS over chunks taken from the global arena.  Invariant kept by
+    // thread 0 between tiles: the chunk has room for a whole tile's candidates, so the wavefronts' allocations during a scan
+    // are plain LDS atomics that cannot fail.
+    auto refill = [&](uint32_t need) {  // thread 0 only
+        const uint32_t cur = l_sh[SH_CHUNK_CUR], lim = l_sh[SH_CHUNK_LIM];
+        if (l_sh[SH_ARENA_OK] && lim - cur >= need) return;
+        const uint32_t chunk = need > ARENA_CHUNK ? need : ARENA_CHUNK;
         const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
         const bool fits = (uint64_t)got + chunk <= w.arena_cap;
-        l_sh[SH_CHUNK_CUR] = fits ? got : NONE32;
+        l_sh[SH_CHUNK_CUR] = fits ? got : 0;
         l_sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
+        l_sh[SH_ARENA_OK] = fits ? 1u : 0u;
+    };
+    if (tid == 0) {
+        l_sh[SH_ARENA_OK] = 0;
+        l_sh[SH_CHUNK_CUR] = l_sh[SH_CHUNK_LIM] = 0;
+        refill(TS + 8u);
     }
 
     for (;;) {
@@ -941,8 +973,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             for (uint32_t fz = 1; fz <= si.nfz_max; fz++) {
                 float lo, hi;
                 tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
-                l_win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
-                l_win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
+                l_win_lo[(size_t)(fz - 1) * P + i] = lo;  // stride P: the array index IS the window number fz * P + i
+                l_win_hi[(size_t)(fz - 1) * P + i] = hi;
             }
         }
         if (tid < w.qmax) w.qrec[(size_t)item * w.qmax + tid].potential = 0;  // queries this spectrum does not run
@@ -954,18 +986,31 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
             for (int iso = isoA; iso <= isoB; iso++) {
                 const size_t qid = (size_t)item * w.qmax + query_index(sc, si, z, iso);
-                // ---- IndexedDatabase::query by wavefront 0, shared through LDS ----
+                // ---- IndexedDatabase::query by wavefront 0, shared through LDS; the query's candidate directory ----
                 if (w0) {
                     const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
-                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_HMIN] = 0; l_sh[SH_HEAD] = NONE32; l_sh[SH_PREV] = NONE32;
+                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1;
+                        const uint32_t lp = q.right < db.np ? q.right : db.np - 1;
+                        const uint32_t nt = db.np ? (lp >> TSH) - (q.left >> TSH) + 1 : 1;
+                        const uint32_t words = (nt * TILE_WAVES * DIR_WORDS + 3u) & ~3u;
+                        refill(words + TS + 8u);
+                        uint32_t dir = NONE32;
+                        if (l_sh[SH_ARENA_OK]) {
+                            dir = l_sh[SH_CHUNK_CUR];
+                            l_sh[SH_CHUNK_CUR] = dir + words;
+                        } else {
+                            atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
+                        }
+                        l_sh[SH_DIR] = dir;
                     }
                     l_hist[lane] = 0;
-                    w.seeds[qid * 64 + lane] = 0;  // (pass 2 of any wavefront may overwrite these: the __syncthreads below drains them first)
+                    w.seeds[qid * 64 + lane] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
                 const uint32_t left = uni(l_sh[SH_LEFT]), right = uni(l_sh[SH_RIGHT]), first = uni(l_sh[SH_FIRST]), end = uni(l_sh[SH_END]);
+                const uint32_t dir = uni(l_sh[SH_DIR]);
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
                 const uint32_t k = trim_k(potential, sc.report_psms);
                 const bool select = potential > k;
@@ -976,9 +1021,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                 auto probe_bounds = [&](uint32_t pr, float& lo, float& hi) {
                     lo = 1.0f; hi = 0.0f;  // inactive: empty window
                     if (pr < nprobe && first < end) {
-                        const uint32_t fz = pr / P, i = pr - fz * P;
-                        lo = l_win_lo[(size_t)fz * b.pcap + i];
-                        hi = l_win_hi[(size_t)fz * b.pcap + i];
+                        lo = l_win_lo[pr];
+                        hi = l_win_hi[pr];
                     }
                 };
                 auto probe_cells = [&](float lo, float hi, uint32_t& icl, uint32_t& ich) {
@@ -1026,13 +1070,15 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 #define SAGE_DECL_CELL(I) uint4 ce##I = make_uint4(0u, 0u, 0u, 0u); uint32_t cpr##I = NONE32, cjj##I = 0;
                 SAGE_FOR_CELLS(SAGE_DECL_CELL)
 #undef SAGE_DECL_CELL
-                uint32_t unit_cells = 0;         // cells of the current unit (uniform)
+                uint32_t unit_cells = 0;  // cells of the current unit (uniform)
                 // locate flattened cell k of the published unit: wavefront by the wave totals, window by a 6-step search
+                uint4 psA = make_uint4(0u, 0u, 0u, 0u), psB = psA;  // the eight wave totals of the published unit (two LDS reads)
                 auto locate = [&](uint32_t k, uint32_t& pr, uint32_t& j) {
                     uint32_t wv = 0, base = 0;
+                    const uint32_t pv[TILE_WAVES - 1] = {psA.x, psA.y, psA.z, psA.w, psB.x, psB.y, psB.z};
 #pragma unroll
                     for (uint32_t i = 0; i + 1 < TILE_WAVES; i++) {
-                        const uint32_t v = l_psum[i];
+                        const uint32_t v = pv[i];
                         const bool past = k >= base + v && wv == i;
                         base += past ? v : 0;
                         wv += past ? 1 : 0;
@@ -1055,33 +1101,56 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             ce##I = frag2[cjj##I >> 1]; /* (tm_frag is padded by 2 entries) */   \
         }                                                                        \
     }
-#define SAGE_APPLY_CELL(I)                                                                                         \
-    if (cpr##I != NONE32) {                                                                                        \
-        float lo_, hi_;                                                                                            \
-        probe_bounds(pb_ + cpr##I, lo_, hi_);                                                                      \
-        tile_test2(l_cnt, l_bm, ce##I, cjj##I, l_pp0[cpr##I], l_pp1[cpr##I], lo_, hi_, first, end, tb_, acc);                \
+// One entry of a cell: inside its run, its window and the precursor window (database.rs:526-533)?  Then its slot's counter goes
+// up by one — a RETURNING LDS atomic, branch-free (a lane without a hit adds 0 to a counter word of its own: were the idle
+// lanes all sent to one address they would serialise in the LDS), all of a thread's atomics in flight together — so that the statistics the k-select needs are
+// kept at hit time: the old count tells which histogram bin the slot leaves and enters, whether it is a new non-empty slot,
+// and whether it just reached the tile's pruning threshold (then its bit in the candidate bitmap is set — a count crosses
+// the threshold once).  The scan after the tile only has to visit the set bits.
+#define SAGE_HIT(I, H, PEP, MZ, JJ)                                                                                  \
+    const bool hit##I##H = cpr##I != NONE32 && (JJ) >= p0_##I && (JJ) < p1_##I && (MZ) >= lo_##I && (MZ) <= hi_##I && \
+                           (PEP) >= first && (PEP) < end;                                                            \
+    const uint32_t x##I##H = hit##I##H ? (PEP) - tb_ : 0u;                                                           \
+    /* no hit: add 0 to a counter word of this thread's own (distinct addresses, no branch, nothing changes) */       \
+    const uint32_t old##I##H = atomicAdd(&l_cnt[hit##I##H ? x##I##H >> 1 : tid], hit##I##H ? 1u << ((x##I##H & 1) * 16) : 0u);
+#define SAGE_APPLY_CELL(I)                                                      \
+    float lo_##I = 1.0f, hi_##I = 0.0f;                                         \
+    uint32_t p0_##I = 0, p1_##I = 0;                                            \
+    if (cpr##I != NONE32) {                                                     \
+        probe_bounds(pb_ + cpr##I, lo_##I, hi_##I);                             \
+        p0_##I = l_pp0[cpr##I];                                                 \
+        p1_##I = l_pp1[cpr##I];                                                 \
+    }                                                                           \
+    SAGE_HIT(I, a, ce##I.x, __uint_as_float(ce##I.y), cjj##I)                   \
+    SAGE_HIT(I, b, ce##I.z, __uint_as_float(ce##I.w), cjj##I + 1)
+#define SAGE_ACCOUNT(I, H)                                                                             \
+    {                                                                                                  \
+        const uint32_t c_ = (old##I##H >> ((x##I##H & 1) * 16)) & 0xFFFFu; /* count before this hit */ \
+        acc += hit##I##H ? 1u : 0u;                                                                    \
+        trans += (hit##I##H && c_ < 3) ? 1u << (c_ * 8) : 0u; /* bytes: 0 -> 1, 1 -> 2, 2 -> 3 */        \
+        if (hit##I##H && c_ >= 3 && c_ < HIST_BINS - 1) { /* rare in a search: straight to the histogram (bin 63 = "63 or more") */ \
+            atomicSub(&l_hist[c_], 1u);                                                                \
+            atomicAdd(&l_hist[c_ + 1], 1u);                                                            \
+        }                                                                                              \
+        if (hit##I##H && c_ + 1 == thr) atomicOr(&l_bm[x##I##H >> 5], 1u << (x##I##H & 31u));          \
     }
-                // publish unit u (its table values have arrived in np0 / np1), put its first cells and the table reads of unit
-                // u + 1 in flight.  One barrier inside; the caller has made sure nobody still reads the previous unit's table.
+#define SAGE_ACCOUNT_CELL(I) SAGE_ACCOUNT(I, a) SAGE_ACCOUNT(I, b)
+                // publish unit u (its table values have arrived in np0 / np1) and put the table reads of unit u + 1 in flight.
+                // One barrier inside; the caller has made sure nobody still reads the previous unit's run table.
                 auto publish = [&](uint32_t u) {
                     const uint32_t p0 = np0, p1 = np1;
                     const uint32_t ncell = p1 > p0 ? ((p1 - 1) >> 1) - (p0 >> 1) + 1 : 0;
-                    uint32_t incl = ncell;  // inclusive prefix over the lanes
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t o = __shfl_up(incl, off, 64);
-                        if ((int)lane >= off) incl += o;
-                    }
+                    const uint32_t incl = wave_incl_scan_dpp(ncell);  // inclusive prefix over the lanes
                     l_pp0[tid] = p0;
                     l_pp1[tid] = p1;
                     l_pcs[tid] = incl - ncell;
                     if (lane == 63) l_psum[wave] = incl;
                     issue_lut(u + 1);
                     lds_barrier();
-                    uint32_t total = 0;
-#pragma unroll
-                    for (uint32_t i = 0; i < TILE_WAVES; i++) total += l_psum[i];
-                    unit_cells = uni(total);
+                    static_assert(TILE_WAVES == 8, "psA / psB hold the eight wave totals");
+                    psA = *(const uint4*)l_psum;
+                    psB = *(const uint4*)(l_psum + 4);
+                    unit_cells = uni(psA.x + psA.y + psA.z + psA.w + psB.x + psB.y + psB.z + psB.w);
                 };
                 issue_lut(0);
                 publish(0);
@@ -1089,94 +1158,58 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     const uint32_t kbase_ = 0;
                     SAGE_FOR_CELLS(SAGE_LOAD_CELL)
                 }
+                uint32_t trans = 0, t01 = 0, t12 = 0, t23 = 0;  // slots this thread moved from count 0 -> 1, 1 -> 2, 2 -> 3 (histogram transitions)
                 for (uint32_t u = 0; u < n_units; u++) {
                     const uint32_t t = t0 + u / nb;
                     const uint32_t tb = t << TSH;
+                    // the tile's pruning threshold (wavefront 0 derived it from the histogram of all EARLIER tiles, see below):
+                    // a slot whose final count is below it cannot enter the k-select (heap.rs:22 rejects it on arrival)
+                    const uint32_t thr = uni(l_sh[SH_THR]);
+                    if (pc.slot) {  // (profiling builds of the numbers only: separate the wait for the cells in flight from the apply)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        pc.mark(7);
+                    }
                     {
                         const uint32_t tb_ = tb, pb_ = (u % nb) * TILE_THREADS;
-                        SAGE_FOR_CELLS(SAGE_APPLY_CELL)
+                        {
+                            SAGE_FOR_CELLS(SAGE_APPLY_CELL)      // eight returning LDS atomics in flight ...
+                            SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)    // ... then the bookkeeping of the hits
+                            t01 += trans & 0xFFu; t12 += (trans >> 8) & 0xFFu; t23 += (trans >> 16) & 0xFFu; trans = 0;
+                        }
                         for (uint32_t kbase_ = CELLS_PER_THREAD * TILE_THREADS; kbase_ < unit_cells; kbase_ += CELLS_PER_THREAD * TILE_THREADS) {
                             SAGE_FOR_CELLS(SAGE_LOAD_CELL)  // (a unit with more cells than fit in flight: the rest synchronously)
                             SAGE_FOR_CELLS(SAGE_APPLY_CELL)
+                            SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)
+                            t01 += trans & 0xFFu; t12 += (trans >> 8) & 0xFFu; t23 += (trans >> 16) & 0xFFu; trans = 0;
                         }
+                    }
+                    const bool last_unit = (u % nb) == nb - 1;
+                    if (last_unit) {
+                        // histogram transitions of this wavefront, one LDS atomic per bin: a slot going c -> c + 1 leaves bin c
+                        // (c >= 1) and enters bin c + 1; new non-empty slots count towards scored_candidates
+                        const uint32_t s01 = wave_sum_dpp(t01), s12 = wave_sum_dpp(t12), s23 = wave_sum_dpp(t23);
+                        if (lane == 0) {
+                            if (s01) atomicAdd(&l_sh[SH_SCORED], s01);
+                            if (s01 != s12) atomicAdd(&l_hist[1], s01 - s12);
+                            if (s12 != s23) atomicAdd(&l_hist[2], s12 - s23);
+                            if (s23) atomicAdd(&l_hist[3], s23);
+                        }
+                        t01 = t12 = t23 = 0;
                     }
                     pc.mark(1);
                     lds_barrier();  // every hit of the unit is counted; its run table is free
+                    pc.mark(2);
                     if (u + 1 < n_units) {
                         publish(u + 1);
                         const uint32_t kbase_ = 0;
                         SAGE_FOR_CELLS(SAGE_LOAD_CELL)
                     }
-                    if ((u % nb) != nb - 1) continue;  // (more windows of this tile to come)
-                    pc.mark(2);
-                    // ---- scan pass 1: each thread walks the touched counter words of its share of the tile, in slot order ----
-                    const uint32_t hmin = uni(l_sh[SH_HMIN]);  // lower bound of the heap minimum's count for this tile
-                    const uint32_t bw0 = tid * bw_per;
-                    uint32_t nne = 0, ncand = 0, h12 = 0, h34 = 0;
-                    auto slot_stats = [&](uint32_t c, uint32_t x) {
-                        if (c == 0) return;
-                        nne++;
-                        if (c <= 2) h12 += c == 1 ? 1u : 0x10000u;
-                        else if (c <= 4) h34 += c == 3 ? 1u : 0x10000u;
-                        else atomicAdd(&l_hist[c < HIST_BINS ? c : HIST_BINS - 1], 1u);
-                        if (select && c >= hmin && (uint64_t)tb + x >= (uint64_t)left + nseed) ncand++;
-                    };
-                    if (bw0 < n_bm) {
-                        for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
-                            uint32_t m = l_bm[bwi];
-                            while (m) {  // four touched words per trip: their LDS reads overlap
-                                constexpr int SB = 4;
-                                uint32_t wd[SB], v[SB];
-#pragma unroll
-                                for (int i = 0; i < SB; i++) {
-                                    wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
-                                    m &= m - 1;  // (0 stays 0)
-                                }
-#pragma unroll
-                                for (int i = 0; i < SB; i++) v[i] = wd[i] != NONE32 ? l_cnt[wd[i]] : 0;
-#pragma unroll
-                                for (int i = 0; i < SB; i++) {
-                                    if (v[i] == 0) continue;
-                                    slot_stats(v[i] & 0xFFFFu, 2 * wd[i]);
-                                    slot_stats(v[i] >> 16, 2 * wd[i] + 1);
-                                }
-                            }
-                        }
-                    }
-                    // wavefront totals of the non-empty slot count and of histogram bins 1..4 (16-bit fields: <= 64 * 64)
-                    nne = wave_sum_dpp(nne);
-                    h12 = wave_sum_dpp(h12);
-                    h34 = wave_sum_dpp(h34);
-                    if (lane == 0 && nne) {
-                        atomicAdd(&l_sh[SH_SCORED], nne);
-                        if (h12 & 0xFFFFu) atomicAdd(&l_hist[1], h12 & 0xFFFFu);
-                        if (h12 >> 16) atomicAdd(&l_hist[2], h12 >> 16);
-                        if (h34 & 0xFFFFu) atomicAdd(&l_hist[3], h34 & 0xFFFFu);
-                        if (h34 >> 16) atomicAdd(&l_hist[4], h34 >> 16);
-                    }
-                    // exclusive prefix of ncand over the lanes, bit-sliced through ballots (no cross-lane data movement)
-                    uint32_t lane_off = 0, wave_total = 0;
-                    for (uint32_t bit = 0; __ballot((ncand >> bit) != 0) != 0ull; bit++) {
-                        const uint64_t m = __ballot(((ncand >> bit) & 1u) != 0);
-                        lane_off += (uint32_t)__popcll(m & lt_mask) << bit;
-                        wave_total += (uint32_t)__popcll(m) << bit;
-                    }
-                    if (lane == 0) l_wsum[wave] = wave_total;
+                    if (!last_unit) continue;  // (more windows of this tile to come)
                     pc.mark(3);
-                    lds_barrier();
-                    uint32_t woff = 0, total = 0;
-#pragma unroll
-                    for (uint32_t i = 0; i < TILE_WAVES; i++) {
-                        const uint32_t v = l_wsum[i];
-                        woff += i < wave ? v : 0;
-                        total += v;
-                    }
-                    // one candidate segment per tile, carved from this workgroup's arena chunk (room for a whole tile is
-                    // reserved ahead of time, see below): {next, n, tile_base, 0} + entries, 16-byte aligned
-                    total = uni(total);
-                    const uint32_t seg = total ? uni(l_sh[SH_CHUNK_CUR]) : NONE32;  // (NONE32 when the arena is exhausted)
+                    // ---- the NEXT tile's threshold, by wavefront 0: the histogram now holds every slot up to this tile and
+                    //      stays put until the next tile's hits (two barriers away).  The k-th largest count so far is a lower
+                    //      bound of the heap minimum for every later slot.
                     if (w0) {
-                        // the k-th largest count seen so far bounds the heap minimum for every LATER slot
                         uint32_t suffix = l_hist[lane];
 #pragma unroll
                         for (int off = 1; off < 64; off <<= 1) {
@@ -1184,78 +1217,126 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             if ((int)lane + off < 64) suffix += o;
                         }
                         const uint64_t ok = __ballot(lane >= 1 && suffix >= k);
+                        const uint32_t hmin = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
+                        if (lane == 0) l_sh[SH_THR] = hmin > 1 ? hmin : 1;
+                    }
+                    // ---- scan: only the candidate bits.  Thread tid owns slots [tid * spt, (tid + 1) * spt): lane order == slot
+                    //      order, a wavefront owns one contiguous slot range, so the candidates of a wavefront, ranked through a
+                    //      prefix sum of popcounts, ARE in slot order.
+                    const uint32_t spt = 2 * wpt;                 // slots per thread (64 at tile_shift 15)
+                    const uint32_t bwt = (spt + 31) / 32;         // bitmap words per thread (2), or a part of one (spt < 32)
+                    uint64_t mask = 0;
+                    if (tid * spt < TS) {
+                        if (spt >= 64) {
+                            const uint2 mw = *(const uint2*)(l_bm + tid * 2);
+                            mask = ((uint64_t)mw.y << 32) | mw.x;
+                        } else if (spt == 32) {
+                            mask = l_bm[tid];
+                        } else {
+                            mask = (l_bm[(tid * spt) >> 5] >> ((tid * spt) & 31u)) & ((1u << spt) - 1u);
+                        }
+                    }
+                    (void)bwt;
+                    const uint32_t mine = (uint32_t)__popcll(mask);
+                    const uint32_t incl = wave_incl_scan_dpp(mine);
+                    const uint32_t excl = incl - mine;
+                    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    // this wavefront's run of candidates: one LDS atomic on the workgroup's bump pointer (room for a whole tile
+                    // is guaranteed, see refill), one directory entry per (tile, wavefront) — also when the run is empty
+                    uint32_t run_at = NONE32;
+                    if (dir != NONE32) {
+                        uint32_t at = 0;
                         if (lane == 0) {
-                            l_sh[SH_HMIN_NEXT] = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
-                            if (seg != NONE32) {
-                                *(uint4*)(w.arena + seg) = make_uint4(NONE32, total, tb, 0u);
-                                const uint32_t prev = l_sh[SH_PREV];
-                                if (prev == NONE32) l_sh[SH_HEAD] = seg;
-                                else w.arena[prev] = seg;
-                                l_sh[SH_PREV] = seg;
+                            uint32_t n_out = wave_total;
+                            if (wave_total) {
+                                if (l_sh[SH_ARENA_OK]) {
+                                    at = atomicAdd(&l_sh[SH_CHUNK_CUR], (wave_total + 3u) & ~3u);
+                                } else {  // the global arena ran out between two tiles: candidates are dropped, the host is told
+                                    atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
+                                    at = NONE32;
+                                    n_out = 0;
+                                }
+                            }
+                            const uint32_t d = dir + ((t - t0) * TILE_WAVES + wave) * DIR_WORDS;
+                            w.arena[d] = at;
+                            w.arena[d + 1] = n_out;
+                        }
+                        run_at = uni(at);
+                    }
+                    // every lane writes ITS candidates (the set bits of its mask, in slot order) at run position excl + j: lane
+                    // order == slot order, so the run is in slot order.  The counters of the first four are read together.
+                    if (mine && run_at != NONE32) {
+                        const uint32_t x_base = tid * spt;
+                        uint64_t m = mask;
+                        uint32_t pos = run_at + excl;
+                        uint32_t xs[4], cs[4];
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            xs[i] = NONE32;
+                            cs[i] = 0;
+                            if (m) {
+                                xs[i] = x_base + (uint32_t)__ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                cs[i] = l_cnt[xs[i] >> 1];
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            if (xs[i] == NONE32) continue;
+                            const uint32_t c = (cs[i] >> ((xs[i] & 1) * 16)) & 0xFFFFu;
+                            const uint64_t g = (uint64_t)tb + xs[i] - left;  // candidate slot
+                            // (the verbatim head of the window is written below from the counters; here it leaves a hole)
+                            w.arena[pos++] = g < nseed ? 0u : (c << 16) | xs[i];
+                        }
+                        while (m) {
+                            const uint32_t x = x_base + (uint32_t)__ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const uint32_t c = (l_cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+                            const uint64_t g = (uint64_t)tb + x - left;
+                            w.arena[pos++] = g < nseed ? 0u : (c << 16) | x;
+                        }
+                    }
+                    // the first min(k, potential) slots of the window go to the k-select verbatim, whatever their count
+                    if ((uint64_t)tb < (uint64_t)left + nseed && (uint64_t)tb + TS > left) {
+                        const uint32_t x_lo = tid * spt;
+                        for (uint32_t i = 0; i < spt; i++) {
+                            const uint64_t gx = (uint64_t)tb + x_lo + i;
+                            if (gx >= left && gx - left < nseed && x_lo + i < TS) {
+                                const uint32_t x = x_lo + i;
+                                const uint32_t c = (l_cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+                                if (c) w.seeds[qid * 64 + (gx - left)] = (uint16_t)c;
                             }
                         }
                     }
                     pc.mark(4);
-                    // ---- scan pass 2: write candidates and the verbatim slots, clear counters and bitmap ----
-                    if (bw0 < n_bm) {
-                        uint32_t pos = seg + 4 + woff + lane_off;
-                        auto slot_emit = [&](uint32_t c, uint32_t x) {
-                            if (c == 0) return;
-                            const uint64_t g = (uint64_t)tb + x - left;  // candidate slot
-                            if (g < nseed) w.seeds[qid * 64 + g] = (uint16_t)c;
-                            else if (select && c >= hmin && seg != NONE32) w.arena[pos++] = (c << 16) | x;
-                        };
-                        for (uint32_t bwi = bw0; bwi < bw0 + bw_per; bwi++) {
-                            uint32_t m = l_bm[bwi];
-                            if (m) l_bm[bwi] = 0;
-                            while (m) {
-                                constexpr int SB = 4;
-                                uint32_t wd[SB], v[SB];
-#pragma unroll
-                                for (int i = 0; i < SB; i++) {
-                                    wd[i] = m ? (bwi << 5) + (uint32_t)__ffs((int)m) - 1 : NONE32;
-                                    m &= m - 1;
-                                }
-#pragma unroll
-                                for (int i = 0; i < SB; i++) {
-                                    v[i] = 0;
-                                    if (wd[i] != NONE32) {
-                                        v[i] = l_cnt[wd[i]];
-                                        l_cnt[wd[i]] = 0;
-                                    }
-                                }
-#pragma unroll
-                                for (int i = 0; i < SB; i++) {
-                                    if (v[i] == 0) continue;
-                                    slot_emit(v[i] & 0xFFFFu, 2 * wd[i]);
-                                    slot_emit(v[i] >> 16, 2 * wd[i] + 1);
-                                }
+                    // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them)
+                    {
+                        const uint32_t w_lo = tid * wpt;
+                        if (w_lo < TS / 2) {
+                            if (wpt >= 4) {
+                                for (uint32_t i = 0; i < wpt; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(0u, 0u, 0u, 0u);
+                            } else {
+                                for (uint32_t i = 0; i < wpt; i++) l_cnt[w_lo + i] = 0;
                             }
+                        }
+                        // (a bitmap word shared by several threads — fewer than 32 slots per thread — belongs to lanes of one
+                        // wavefront, which all read their masks above before any of them gets here)
+                        if (tid * spt < TS) {
+                            if (spt >= 64) *(uint2*)(l_bm + tid * 2) = make_uint2(0u, 0u);
+                            else if (((tid * spt) & 31u) == 0) l_bm[(tid * spt) >> 5] = 0;
                         }
                     }
                     pc.mark(5);
-                    lds_barrier();  // (the candidate / verbatim-slot stores of pass 2 stay in flight)
+                    lds_barrier();  // counters and bits clear again (the candidate stores stay in flight)
                     pc.mark(6);
-                    if (tid == 0) {  // (read again only after the next tile's first barrier)
-                        l_sh[SH_HMIN] = l_sh[SH_HMIN_NEXT];
-                        uint32_t cur = l_sh[SH_CHUNK_CUR];
-                        if (seg != NONE32) cur += ((total + 3u) & ~3u) + 4u;
-                        else if (total && cur == NONE32) atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);  // candidates were dropped
-                        // keep room for a whole tile's worth of candidates, so that every thread can take the segment base
-                        // from LDS without waiting for a global allocation
-                        if (cur == NONE32 || l_sh[SH_CHUNK_LIM] - cur < TS + 8u) {
-                            const uint32_t chunk = TS + 8u > ARENA_CHUNK ? TS + 8u : ARENA_CHUNK;
-                            const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
-                            if ((uint64_t)got + chunk > w.arena_cap) {
-                                cur = NONE32;
-                            } else {
-                                cur = got;
-                                l_sh[SH_CHUNK_LIM] = got + chunk;
-                            }
-                        }
-                        l_sh[SH_CHUNK_CUR] = cur;
-                    }
+                    if (tid == 0) refill(TS + 8u);  // room for the next tile's candidates (read again only after two more barriers)
                 }
+#undef SAGE_LOAD_CELL
+#undef SAGE_APPLY_CELL
+#undef SAGE_ACCOUNT_CELL
+#undef SAGE_ACCOUNT
+#undef SAGE_HIT
+#undef SAGE_FOR_CELLS
                 // ---- totals of this query ----
                 acc = wave_sum_dpp(acc);
                 if (lane == 0 && acc) atomicAdd(&l_sh[SH_MATCHED], acc);
@@ -1281,10 +1362,12 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         r.potential = potential;
                         r.matched = l_sh[SH_MATCHED];
                         r.scored = l_sh[SH_SCORED];
-                        r.head = l_sh[SH_HEAD];
+                        r.head = dir;
                         r.z_iso = z | ((uint32_t)(iso + 128) << 8);
                         r.pad[0] = big | (T << 8);                        // bit 0: the heap replay must keep 64-bit keys / no fast select
                         r.pad[1] = T ? n_eq - (k - n_gt) : 0;             // slots equal to T to skip
+                        r.n_dir = dir != NONE32 ? (t1 - t0 + 1) * TILE_WAVES : 0;
+                        r.t0 = t0;
                         w.qrec[qid] = r;
                     }
                 }
@@ -1293,15 +1376,20 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     }
 }
 
-// Candidate chains are walked defensively: a link outside the arena or an absurd number of hops (a count kernel that did
-// not run, a stale record) ends the walk instead of hanging the GPU.
-constexpr uint32_t MAX_SEGMENTS = 1u << 18;
-__device__ __forceinline__ bool seg_ok(const DevWork& w, uint32_t seg, uint32_t hops) {
-    return seg != NONE32 && (uint64_t)seg + 4 <= w.arena_cap && hops < MAX_SEGMENTS;
-}
-__device__ __forceinline__ uint32_t seg_len(const DevWork& w, uint32_t seg, uint32_t n) {
-    const uint64_t room = (uint64_t)w.arena_cap - seg - 4;
-    return (uint64_t)n <= room ? n : (uint32_t)room;
+// A query's candidates are read back through its directory (QueryRec::head / n_dir), defensively: a position outside the
+// arena (a count kernel that did not run, a stale record) yields an empty run instead of a wild read.
+struct DirRun {
+    uint32_t at, n, tile_base;
+};
+__device__ __forceinline__ DirRun dir_run(const DevWork& w, const QueryRec& rec, uint32_t d) {
+    DirRun r{0u, 0u, 0u};
+    const uint64_t e = (uint64_t)rec.head + (uint64_t)d * DIR_WORDS;
+    if (rec.head == NONE32 || e + DIR_WORDS > w.arena_cap) return r;
+    const uint2 v = *(const uint2*)(w.arena + e);
+    r.at = v.x;
+    r.n = ((uint64_t)v.x + v.y <= w.arena_cap) ? v.y : 0u;
+    r.tile_base = (rec.t0 + d / TILE_WAVES) << w.tile_shift;
+    return r;
 }
 
 // strided sift_down (heap.rs:40-60): element i of this lane's heap lives at hp[i * 64]
@@ -1392,9 +1480,9 @@ template <> struct ReplayKey<uint32_t> {
     static __device__ __forceinline__ uint32_t matched(uint32_t v) { return v >> K32_SLOT_BITS; }
 };
 
-// one lane = one query; every round each lane looks at ONE candidate entry (entries are fetched four at a time, one
-// load ahead) and the lanes whose entry can enter — heap.rs:22: later slots have larger peptide indices, so
-// `slice[i] > slice[0]` <=> count >= the root's count — replace their root and sift down together
+// one lane = one query; every round each lane looks at ONE candidate entry (fetched four at a time) and the lanes whose entry
+// can enter — heap.rs:22: later slots have larger peptide indices, so `slice[i] > slice[0]` <=> count >= the root's count —
+// replace their root and sift down together
 template <typename K>
 __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const QueryRec& rec, uint64_t qid, uint32_t k, bool live,
                                                uint32_t z, int iso, PhaseClock& pc) {
@@ -1408,51 +1496,31 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
             if (hp[(2 * p + 2) * 64] < hp[(2 * p + 1) * 64]) rightmin |= 1u << p;
         hmin = RK::matched(hp[0]);
     }
-    // The candidate stream of a query is a chain of segments {header cell, entry cells...} (one 16-byte cell = a header or
-    // four entries).  A workgroup of the count kernel carves consecutive segments of a query from one chunk, so the chain is
-    // almost always contiguous: cells are consumed linearly with the next cell always in flight, and only a chunk boundary
-    // costs a dependent load.
-    uint32_t nextseg = live ? rec.head : NONE32;  // header position of the next segment
-    uint32_t pos = 0;                               // position of the cell in flight (pf)
-    uint32_t rem = 0, q = 4, tb = 0, hops = 0;      // entries left in the segment, next entry of the current cell
-    bool done = nextseg == NONE32;
-    uint4 cell = make_uint4(0u, 0u, 0u, 0u), pf = make_uint4(0u, 0u, 0u, 0u);
-    if (!done) {
-        pos = nextseg;
-        pf = *(const uint4*)(w.arena + pos);
-    }
-    auto take_cell = [&]() {
-        cell = pf;
-        pos += 4;
-        if (pos + 4 <= w.arena_cap) pf = *(const uint4*)(w.arena + pos);
-    };
+    // the lane's position in its query's candidate stream: directory entry d, entry j of run (at, n); runs start 16-byte
+    // aligned, so entries are fetched as cells of four
+    uint32_t d = 0, j = 0, n = 0, at = 0, tb = 0;
+    const uint32_t n_dir = live ? rec.n_dir : 0;
+    bool done = n_dir == 0;
+    uint4 cell = make_uint4(0u, 0u, 0u, 0u);
     pc.mark(0);
     while (__ballot(!done) != 0ull) {
         bool have = false;
         uint32_t e = 0;
         if (!done) {
-            if (rem == 0) {  // the next cell is a header (or the chain ends)
-                if (!seg_ok(w, nextseg, hops++)) {
+            if (j == n) {  // next non-empty run (one directory entry per round: lanes stay in step)
+                if (d == n_dir) {
                     done = true;
                 } else {
-                    if (nextseg != pos) {  // chunk boundary: not the cell in flight
-                        pos = nextseg;
-                        pf = *(const uint4*)(w.arena + pos);
-                    }
-                    const uint32_t at = pos;
-                    take_cell();
-                    nextseg = cell.x; rem = seg_len(w, at, cell.y); tb = cell.z;
-                    q = 4;
+                    const DirRun r = dir_run(w, rec, d++);
+                    at = r.at; n = r.n; tb = r.tile_base;
+                    j = 0;
                 }
             } else {
-                if (q == 4) {
-                    take_cell();
-                    q = 0;
-                }
+                if ((j & 3u) == 0) cell = *(const uint4*)(w.arena + at + j);
+                const uint32_t q = j & 3u;
                 e = q == 0 ? cell.x : q == 1 ? cell.y : q == 2 ? cell.z : cell.w;
-                q++;
-                rem--;
-                have = (e >> 16) >= hmin;
+                j++;
+                have = (e >> 16) != 0 && (e >> 16) >= hmin;  // (count 0: a hole)
             }
         }
         if (__ballot(have) == 0ull) continue;
@@ -1515,14 +1583,14 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
         eq_seen += (uint32_t)__popcll(eqm);
     };
     offer(lane < k ? w.seeds[qid * 64 + lane] : 0u, rec.left + lane);  // the first k slots
-    for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
-        const uint4 hdr = *(const uint4*)(w.arena + seg);
-        const uint32_t n = seg_len(w, seg, hdr.y);
-        for (uint32_t j = 0; j < n; j += WAVE) {
-            const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
-            offer(e >> 16, hdr.z + (e & 0xFFFFu));
+    for (uint32_t d = 0; d < rec.n_dir; d++) {
+        const DirRun r = dir_run(w, rec, d);
+        for (uint32_t j = 0; j < r.n; j += WAVE) {
+            const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
+            // (a candidate below T can never be taken: skip the wavefront's bookkeeping when the whole row is below)
+            if (__ballot((e >> 16) >= T && e != 0u) == 0ull) continue;
+            offer(e >> 16, r.tile_base + (e & 0xFFFFu));
         }
-        seg = hdr.x;
     }
     for (uint32_t i = (nsel < k ? nsel : k) + lane; i < k; i += WAVE) out[i] = PRESCORE_EMPTY;  // fewer than k non-empty slots
 }
@@ -1546,13 +1614,12 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
     if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
         uint32_t h = seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u;
         wh32_build(h, k);
-        for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
-            const uint4 hdr = *(const uint4*)(w.arena + seg);
-            const uint32_t n = seg_len(w, seg, hdr.y);
-            for (uint32_t j = 0; j < n; j += WAVE) {
-                const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
+        for (uint32_t d = 0; d < rec.n_dir; d++) {
+            const DirRun r = dir_run(w, rec, d);
+            for (uint32_t j = 0; j < r.n; j += WAVE) {
+                const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
                 const uint32_t c = e >> 16;
-                const uint32_t v = (c << K32_SLOT_BITS) | (hdr.z + (e & 0xFFFFu) - rec.left);
+                const uint32_t v = (c << K32_SLOT_BITS) | (r.tile_base + (e & 0xFFFFu) - rec.left);
                 // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
                 uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> K32_SLOT_BITS));
                 while (mask) {
@@ -1561,7 +1628,6 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
                     wh32_offer(h, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
                 }
             }
-            seg = hdr.x;
         }
         if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(h, rec.left, z, iso);
     } else {
@@ -1570,13 +1636,12 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
         h.lo = (uint32_t)sv;
         h.hi = (uint32_t)(sv >> 32);
         wh_build(h, k);
-        for (uint32_t seg = rec.head, guard = 0; seg_ok(w, seg, guard); guard++) {
-            const uint4 hdr = *(const uint4*)(w.arena + seg);
-            const uint32_t n = seg_len(w, seg, hdr.y);
-            for (uint32_t j = 0; j < n; j += WAVE) {
-                const uint32_t e = j + lane < n ? w.arena[seg + 4 + j + lane] : 0u;
+        for (uint32_t d = 0; d < rec.n_dir; d++) {
+            const DirRun r = dir_run(w, rec, d);
+            for (uint32_t j = 0; j < r.n; j += WAVE) {
+                const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
                 const uint32_t c = e >> 16;
-                const uint64_t v = pack_prescore(c, hdr.z + (e & 0xFFFFu), z, iso);
+                const uint64_t v = pack_prescore(c, r.tile_base + (e & 0xFFFFu), z, iso);
                 uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
                 while (mask) {
                     const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
@@ -1584,7 +1649,6 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
                     wh_offer(h, k, lane_value(v, bit));
                 }
             }
-            seg = hdr.x;
         }
         if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
     }
@@ -2168,7 +2232,7 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
     hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
-                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, w.tile_params);
+                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, TileParams{db, sc, b, w});
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
@@ -2176,7 +2240,8 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query
     uint32_t wave_max = 32768;
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint32_t)atoi(e);
-    if ((!sc.exact && wave_max) || nq <= wave_max)
+    // (the exact retry pass — b.n_dev set — holds a few percent of the batch: its queries are few whatever the grid's upper bound)
+    if ((!sc.exact && wave_max) || nq <= wave_max || (b.n_dev != nullptr && wave_max))
         hipLaunchKernelGGL(tile_replay_wave_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
     else
         hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);

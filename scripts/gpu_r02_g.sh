@@ -1,0 +1,11 @@
+#!/bin/bash
+OUT=gpurun_out/r02g; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_config_scale.py -q -x > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+tail -15 $OUT/pytest.log
+for C in C4 C5; do
+  timeout 300 python bench.py --config $C --no-traffic --no-cpu-baseline --no-extras > $OUT/bench_$C.json 2> $OUT/bench_$C.err; echo "bench $C rc=$?"
+  python -c "
+import json,sys
+d=json.loads(open('$OUT/bench_$C.json').read()); print('$C', round(d['value']), d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['psms_per_step_rank0'], d['roofline']['routing'])" 2>&1 | tail -1
+done
+timeout 400 python scripts/phase_probe.py C4 8192 2>&1 | grep -v amdgpu.ids | tail -3
