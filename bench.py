@@ -153,6 +153,35 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None):
     return batch, np.concatenate([p[2] for p in parts])
 
 
+def gpu_algorithm_bytes(dev, params, batch, n_sample=8192):
+    """Bytes the GPU ALGORITHM asks memory for, per spectrum, counted by the kernels themselves in a profiling pass over a
+    prefix of the workload (SAGE_HIP_PHASE_CLOCKS build of the counters, kernels.hip: DBG_*): position-table words (8 B per
+    window and tile), 16-byte index cells of the flattened runs, candidate words, and for rescoring the peaks + every
+    candidate's ion table.  Not lines: a 4-byte table read moves a 128-byte line (roofline.traffic has the lines)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from sage_amd import _lib as L
+    from sage_amd.api import Scorer
+    os.environ["SAGE_HIP_PHASE_CLOCKS"] = "1"
+    try:
+        sc = Scorer(dev, params)
+    finally:
+        del os.environ["SAGE_HIP_PHASE_CLOCKS"]
+    sub = batch if batch.n <= n_sample else batch.subset(np.arange(n_sample))
+    sc.score_resident(sc.upload(sub))
+    out = np.zeros(32, np.uint64)
+    L.check(L.load().sage_hip_debug_phase_cycles(sc._h, L.as_ptr(out, C.c_uint64)))
+    sc.close()
+    o = out.astype(np.float64) / sub.n
+    return {"prelim": float(o[26] + o[27] + o[29] + o[30] + o[31]), "rescore": float(o[28]),
+            "detail": {"narrow_table_words": float(o[26]), "narrow_index_cells_and_peaks": float(o[27]),
+                       "large_window_table_words": float(o[29]), "large_window_index_cells": float(o[30]),
+                       "large_window_candidate_words": float(o[31]), "rescore_peaks_candidates_ions": float(o[28])},
+            "sample": sub.n}
+
+
 def measure_traffic(args, kernels=("prelim", "rescore")):
     """HBM bytes per spectrum of the search kernels from rocprofv3's memory-side counters, taken NOW on this GPU in separate
     --pmc passes over a short run of this script (no kernel trace in the same pass: MI355X_MICROARCH.md §HBM, and gpurun refuses
@@ -162,7 +191,7 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
     import sqlite3
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not found"
-    n_spec = min(args.traffic_spectra, CONFIGS[args.config]["spectra"])
+    n_spec = min(args.traffic_spectra, args.spectra or CONFIGS[args.config]["spectra"])
     tmp = tempfile.mkdtemp(prefix="sage_pmc_", dir="/tmp")
     res = {}
     try:
@@ -447,12 +476,21 @@ def main():
                 else:
                     source = f"unavailable ({why})" if why else "unavailable"
             traffic = traffic_ps[dom] * batch.n if traffic_ps and dom in traffic_ps else None
+            gab = None
+            if not args.no_extras:
+                try:
+                    gab = gpu_algorithm_bytes(dev, params, batch)
+                except Exception as e:  # noqa: BLE001 — a profiling extra must not take the line down
+                    gab = {"error": repr(e)}
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                     # the second fraction: bytes that actually crossed the HBM interface (PMC) over the same kernel time
                     "achieved_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
                     "frac_traffic": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic_bytes_per_spectrum": traffic_ps,
+                    # the third figure: what the GPU algorithm itself requests (table words, index cells, candidates, ions)
+                    "gpu_algorithm_bytes_per_spectrum": gab,
+                    "frac_gpu_algorithm": None if not gab or "error" in gab else gab[dom] * batch.n / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernel_ms": {"prelim": pm, "rescore": rm},
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,

@@ -402,6 +402,10 @@ int sage_hip_hostdb_feature_peptides(const SageHostDb* db, const uint32_t* pepti
  * keeps every level.  spectrum ids: sage_hip_mzml_spectrum_id. */
 typedef struct SageMzml SageMzml;
 int sage_hip_mzml_read(const char* path, uint32_t file_id, int ms_level, SageMzml** out);
+/* The inputs the reference refuses to search — it panics while PROCESSING them, the reader accepts them: an MS2 spectrum in
+ * profile mode (spectrum.rs:280-286; Representation defaults to Profile, so the centroid term MS:1000127 must be present) or
+ * without a precursor (scoring.rs:466-468).  SAGE_HIP_ERR_INVALID with the reference's message; call before searching a run. */
+int sage_hip_mzml_check_searchable(const SageMzml* run);
 int sage_hip_mzml_view(const SageMzml* run, SageRawBatch* out);
 const char* sage_hip_mzml_spectrum_id(const SageMzml* run, uint64_t i);
 void sage_hip_mzml_free(SageMzml* run);

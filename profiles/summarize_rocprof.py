@@ -1,70 +1,54 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3's rocpd sqlite output (gpurun_out/prof/*/…_results.db) into the small text summaries that
-are committed under profiles/.
-Usage: python profiles/summarize_rocprof.py <tag> <config> <trace.db> [<pmc.db> ...]
-Also updates profiles/traffic.json[<config>] (PMC-derived HBM bytes per launch, read back by bench.py)."""
+"""Turn rocprofv3's rocpd sqlite output of a `--kernel-trace --stats` run of bench.py into the small text summary that is
+committed under profiles/, next to the figures of the bench line of the same configuration (HIP-event kernel times, live PMC
+traffic), so that the two can be held against each other.
+Usage: python profiles/summarize_rocprof.py <tag> <config> <trace.db> [<bench.json>]"""
 import json
 import sqlite3
 import sys
 
 
+def short(name):
+    return name.replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:70]
+
+
 def main():
-    tag = sys.argv[1]
-    config = sys.argv[2]
-    trace = sys.argv[3]
-    pmcs = sys.argv[4:]
-    out = []
+    tag, config, trace = sys.argv[1], sys.argv[2], sys.argv[3]
+    bench = sys.argv[4] if len(sys.argv) > 4 else None
+    out = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --steps 5 --warmup 2 --no-extras   ({tag})\n",
+           "# 7 calls of score_resident (2 warm-up + 5 timed); the search kernels show twice per call (first pass + exact retry pass)\n"]
     con = sqlite3.connect(trace)
-    out.append(f"# rocprofv3 --kernel-trace --stats  ({tag})\n")
-    out.append(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'pct':>6}\n")
-    kernels = {}
+    out.append(f"{'kernel':<70} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'pct':>6}\n")
+    per_step = {}
     for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        short = name.replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        kernels[short] = avg
-        out.append(f"{short:<70} {calls:>6} {total:>12.1f} {avg:>10.2f} {pct:>6.2f}\n")
-    out.append("\n# per-dispatch resources\n")
-    q = ("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, sgpr_count, count(*) "
-         "from kernels group by name, grid_x, workgroup_x, lds_size")
+        s = short(name)
+        out.append(f"{s:<70} {calls:>6} {total / 1e3:>10.2f} {avg:>10.1f} {pct:>6.2f}\n")   # the view is in microseconds
+        if s.startswith(("prelim_", "tile_", "rescore", "schedule")):
+            per_step[s] = total / 1e3 / 7.0
+    out.append("\n# search kernels, ms per step (total / 7 calls):\n")
+    for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
+        out.append(f"  {k:<40} {v:8.3f}\n")
     try:
+        out.append("\n# per-dispatch resources\n")
+        q = ("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, sgpr_count, count(*) "
+             "from kernels group by name, grid_x, workgroup_x, lds_size")
         for r in con.execute(q):
-            short = r[0].replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-            out.append(f"{short:<40} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]} n={r[7]}\n")
+            if short(r[0]).startswith(("prelim_", "tile_", "rescore")):
+                out.append(f"  {short(r[0]):<40} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]} n={r[7]}\n")
     except sqlite3.Error as e:
         out.append(f"(resource query failed: {e})\n")
-    traffic = {}
-    for p in pmcs:
-        c = sqlite3.connect(p)
-        out.append(f"\n# rocprofv3 --pmc  ({p.split('/')[-2]})  values are per dispatch; FETCH_SIZE/WRITE_SIZE in KiB\n")
-        for name, ctr, n, avg, mn, mx in c.execute(
-                "select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
-                "group by kernel_name, counter_name"):
-            short = name.replace("sagehip::(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-            out.append(f"{short:<40} {ctr:<12} n={n:<4} avg={avg:>14.2f} min={mn:>14.2f} max={mx:>14.2f}\n")
-            # a step dispatches each search kernel twice — the full pass and the (small) exact retry pass over the tied
-            # spectra — so the per-launch figure that goes with bench.py's `achieved` is the full-pass dispatch: the maximum
-            traffic.setdefault(short, {})[ctr] = mx
-    # HBM bytes per (full-pass) launch, corrected as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE under-reports
-    # coalesced reads by 2x on gfx950 (x2), WRITE_SIZE taken as is; both counters are KiB.
-    tj = {}
-    for k, v in traffic.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            b = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-            # bench.py's prelim_ms spans all preliminary kernels (narrow + the tiled count / replay / assemble pipeline)
-            key = "prelim" if (k.startswith("prelim_") or k.startswith("tile_")) else ("rescore" if k.startswith("rescore") else None)
-            if key:
-                tj[key + "_bytes_per_launch"] = tj.get(key + "_bytes_per_launch", 0.0) + b
-                tj.setdefault(key + "_raw", {})[k] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}
-            out.append(f"HBM traffic {k:<40} (2*FETCH+WRITE)*1024 = {b/1e6:.1f} MB per launch\n")
-    open(f"profiles/{tag}_rocprof_summary.txt", "w").write("".join(out))
-    if tj:
-        tj["source"] = f"profiles/{tag}_rocprof_summary.txt"
+    if bench:
         try:
-            allt = json.load(open("profiles/traffic.json"))
-        except (OSError, ValueError):
-            allt = {}
-        allt = {k: v for k, v in allt.items() if isinstance(v, dict) and k.startswith("C")}
-        allt[config] = tj
-        json.dump(allt, open("profiles/traffic.json", "w"), indent=1)
+            j = json.loads([ln for ln in open(bench) if ln.startswith("{")][-1])
+            rf = j["roofline"]
+            out.append("\n# the bench line of the same build (profiles/%s_%s_bench.json): HIP events on the scorer's stream\n" % (tag, config))
+            out.append(f"  value {j['value']:.4g} {j['unit']}, ms_per_step {j['ms_per_step']:.3f}, kernel_ms {rf['kernel_ms']}\n")
+            out.append(f"  algorithmic bytes/spectrum {rf['algorithmic_bytes_per_spectrum']}\n")
+            out.append(f"  traffic bytes/spectrum (PMC) {rf.get('traffic_bytes_per_spectrum')}  [{rf.get('traffic_source')}]\n")
+            out.append(f"  GPU-algorithm bytes/spectrum {rf.get('gpu_algorithm_bytes_per_spectrum')}\n")
+            out.append(f"  frac (algorithmic) {rf['frac']:.3f}  frac_traffic {rf.get('frac_traffic')}  frac_gpu_algorithm {rf.get('frac_gpu_algorithm')}\n")
+        except (OSError, ValueError, KeyError, IndexError) as e:
+            out.append(f"(bench line not read: {e!r})\n")
     print("".join(out))
 
 

@@ -264,6 +264,7 @@ def load():
         "sage_hip_hostdb_feature_peptides": (C.c_int, [vp, c_u32_p, C.c_uint64, c_u64_p, c_u8_p, c_float_p]),
         "sage_hip_mzml_read": (C.c_int, [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(vp)]),
         "sage_hip_mzml_view": (C.c_int, [vp, C.POINTER(SageRawBatch)]),
+        "sage_hip_mzml_check_searchable": (C.c_int, [vp]),
         "sage_hip_mzml_spectrum_id": (C.c_char_p, [vp, C.c_uint64]),
         "sage_hip_mzml_free": (None, [vp]),
         "sage_hip_write_results": (C.c_int, [C.c_char_p, C.c_int, vp, vp, C.c_uint64, c_u64_p, c_u64_p, C.POINTER(C.c_char_p),
@@ -291,7 +292,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
     "sage_hip_rescore", "sage_hip_hostdb_competition_keys", "sage_hip_fasta_num_targets", "sage_hip_prefilter_chunk_size",
     "sage_hip_hostdb_build_chunk", "sage_hip_hostdb_merge_kept", "sage_hip_predict_rt", "sage_hip_hostdb_feature_peptides",
-    "sage_hip_write_results", "sage_hip_mzml_read", "sage_hip_mzml_view", "sage_hip_mzml_spectrum_id", "sage_hip_mzml_free",
+    "sage_hip_write_results", "sage_hip_mzml_read", "sage_hip_mzml_view", "sage_hip_mzml_check_searchable", "sage_hip_mzml_spectrum_id", "sage_hip_mzml_free",
 ]
 
 

@@ -527,6 +527,14 @@ class RawBatch:
         assert len(b.peak_off) == b.n + 1 and len(b.mz) == len(b.intensities) == int(b.peak_off[-1])
         return b
 
+    def slice(self, begin: int, end: int) -> "RawBatch":
+        """Spectra [begin, end) as a batch of their own (contiguous shard of a file)."""
+        a, b = int(self.peak_off[begin]), int(self.peak_off[end])
+        return RawBatch.from_arrays(self.ids[begin:end], self.peak_off[begin:end + 1] - np.uint64(a), self.mz[a:b], self.intensities[a:b],
+                                    self.precursor_mz[begin:end], self.precursor_charge[begin:end], self.isolation_lo[begin:end],
+                                    self.isolation_hi[begin:end], self.scan_start_time[begin:end],
+                                    self.inverse_ion_mobility[begin:end], self.file_id[begin:end])
+
     def spectrum(self, i: int) -> RawSpectrum:
         lo, hi = int(self.peak_off[i]), int(self.peak_off[i + 1])
         iso = None if np.isnan(self.isolation_lo[i]) else (float(self.isolation_lo[i]), float(self.isolation_hi[i]))

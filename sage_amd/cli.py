@@ -101,16 +101,111 @@ def prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, proces
     return dbp.merge_kept(chunks, keeps, peptides_only=True)
 
 
+def read_text(path: str) -> str:
+    """FASTA text; gzip-compressed files (sage-cloudpath lib.rs:44-90 gunzips `*.gz` / `*.gzip`; here: by the 1f 8b magic)."""
+    raw = open(path, "rb").read()
+    if raw[:2] == b"\x1f\x8b":
+        import gzip
+        raw = gzip.decompress(raw)
+    return raw.decode()
+
+
+def parse_devices(spec, n_visible: int):
+    """--devices all | 0-7 | 0,2,3 (a device may be named twice: two workers share it)"""
+    if spec is None:
+        return None
+    if spec == "all":
+        return list(range(n_visible))
+    out = []
+    for part in str(spec).split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    bad = [d for d in out if d < 0 or d >= n_visible]
+    if bad or not out:
+        raise SystemExit(f"sage_amd.cli: --devices {spec}: {n_visible} HIP device(s) visible")
+    return out
+
+
+def search_file(workers, processor, raw, sp, host_preprocess, annotate):
+    """Scorer::score over every MS2 spectrum of one file (runner.rs:311-325), on all the workers' devices at once: the file's
+    spectra are cut into contiguous work-balanced shards (sharding.plan_shards: index replicated, no exchange between
+    devices), one host thread per device preprocesses, scores and — if asked — annotates its shard, and the shards' results
+    are concatenated in input order, as `collect()` does.  Returns (features[n, report], counts[n], ids, annotation | None)."""
+    import threading
+
+    from .sharding import plan_shards
+    shards = plan_shards(raw.peak_off, len(workers)) if len(workers) > 1 else [(0, raw.n)]
+    results = [None] * len(workers)
+    errors = []
+
+    def work(k):
+        try:
+            b, e = shards[k]
+            scorer = workers[k][1]
+            part = raw if (b, e) == (0, raw.n) else raw.slice(b, e)
+            if part.n == 0:
+                return
+            dbatch, ids = _upload(scorer, processor, part, sp, host_preprocess)
+            if dbatch is None:
+                return
+            feats, counts = scorer.score_resident(dbatch)
+            feats, counts = feats.copy(), counts.copy()
+            ann = scorer.annotate(dbatch, feats, counts) if annotate else None
+            dbatch.close()
+            valid = np.arange(feats.shape[1])[None, :] < counts[:, None]
+            feats["spec_index"][valid] += np.uint32(b)  # position in the file, not in the shard
+            results[k] = (feats, counts, ids, ann)
+        except BaseException as exc:  # noqa: BLE001 — re-raised on the calling thread
+            errors.append(exc)
+
+    if len(workers) == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(len(workers))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    if errors:
+        raise errors[0]
+    parts = [r for r in results if r is not None]
+    if not parts:
+        return None
+    feats = np.concatenate([p[0] for p in parts], axis=0)
+    counts = np.concatenate([p[1] for p in parts])
+    ids = [i for p in parts for i in p[2]]
+    ann = None
+    if annotate:  # Fragments offsets are per shard: rebase them onto the concatenated arrays
+        offs, arrs, base = [], {k: [] for k in parts[0][3][1]}, 0
+        for p in parts:
+            off, arr = p[3]
+            offs.append(off[:-1] + np.uint64(base))
+            base += int(off[-1])
+            for k in arrs:
+                arrs[k].append(arr[k])
+        ann = (np.concatenate(offs + [np.array([base], dtype=np.uint64)]), {k: np.concatenate(v) for k, v in arrs.items()})
+    return feats, counts, ids, ann
+
+
 def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print, host_preprocess: bool = False,
-        write_pin: bool = False) -> dict:
+        write_pin: bool = False, devices=None) -> dict:
     if device_count() <= 0:
         raise SystemExit("sage_amd.cli: no HIP device visible — libsage_hip has no CPU fallback")
     sp = search_parameters(cfg)
     dbp = DatabaseParameters.from_json(cfg["database"])
     if not dbp.fasta:
         raise SystemExit("`database.fasta` must be set. For more information try '--help'")
+    # the wave-wide k-select holds max(50, 2 * report_psms) <= 64 candidates (the prefilter pass scores with report_psms + 1)
+    need = sp["report_psms"] + (1 if dbp.prefilter else 0)
+    if need > 32:
+        raise SystemExit(f"sage_amd.cli: report_psms = {sp['report_psms']}" + (" with database.prefilter" if dbp.prefilter else "") +
+                         " needs a k-select of more than 64 candidates per spectrum; this build supports report_psms <= " +
+                         ("31 with the prefilter" if dbp.prefilter else "32"))
+    devices = list(devices) if devices else [device]
+    device = devices[0]
     t0 = time.time()
-    fasta_text = open(dbp.fasta).read()
+    fasta_text = read_text(dbp.fasta)
     params = scorer_params(sp)
     processor = SpectrumProcessor(sp["max_peaks"], sp["deisotope"], 0.0)  # (no TMT reporter cut-off: quant is out of scope)
     host = None
@@ -122,9 +217,13 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
             host = prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, processor, device, host_preprocess, log)
     if host is None:
         host = dbp.build(fasta_text, peptides_only=True)  # digest / modify / sort / dedup on the host ...
-    dev = DeviceDatabase(host, device)                    # ... build_from_peptides on the device (index_build.hip)
-    log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms")
-    scorer = Scorer(dev, params)
+    # ... build_from_peptides on the device (index_build.hip): the index is replicated on every device that searches
+    workers = []
+    for d in devices:
+        dev_db = DeviceDatabase(host, d)
+        workers.append((dev_db, Scorer(dev_db, params)))
+    log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms" +
+        (f" on {len(devices)} devices" if len(devices) > 1 else ""))
     os.makedirs(output_directory, exist_ok=True)
     feats_all, meta, frags = [], [], []  # per PSM: (filename, spectrum id); matched-fragment rows
     psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
@@ -132,24 +231,21 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     search_ms = 0.0
     for file_id, path in enumerate(mzml_paths):
         t0 = time.time()
-        raw = read_mzml_native(path, file_id=file_id, ms_level=2)  # csrc/mzml_reader.cpp
+        raw = read_mzml_native(path, file_id=file_id, ms_level=2, check_searchable=True)  # csrc/mzml_reader.cpp
         log(f"- file IO: {int((time.time() - t0) * 1000):8d} ms")
         if raw.n == 0:
             continue
         t0 = time.time()
-        dbatch, ids = _upload(scorer, processor, raw, sp, host_preprocess)
-        if dbatch is None:
+        found = search_file(workers, processor, raw, sp, host_preprocess, sp["annotate_matches"])
+        if found is None:
             continue
-        n_batch = dbatch.n
-        feats, counts = scorer.score_resident(dbatch)
-        feats, counts = feats.copy(), counts.copy()
+        feats, counts, ids, ann = found
+        n_batch = len(counts)
         dt = (time.time() - t0) * 1000.0
         search_ms += dt
         n_searched += n_batch
         log(f"- search:  {int(dt):8d} ms ({int(n_batch * 1000 / (dt + 1))} spectra/s)")  # runner.rs:327-330
-        off = arr = None
-        if sp["annotate_matches"]:
-            off, arr = scorer.annotate(dbatch, feats, counts)
+        off, arr = ann if ann is not None else (None, None)
         name = os.path.basename(path)
         # the PSMs of the file in (spectrum, rank) order — the order Scorer::score results are collected in (runner.rs:325)
         spec_of = np.repeat(np.arange(n_batch), counts.astype(np.int64))
@@ -163,7 +259,6 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                 slot = i * params.report_psms + r
                 frags.append(output.fragment_rows(psm_id + j, int(off[slot]), int(off[slot + 1]), arr))
         psm_id += len(part)
-        dbatch.close()
     # runner.rs:536-541: spectrum_fdr (LDA or heuristic, sort, q-values), picked_peptide, picked_protein — on the device.
     # (protein grouping is outside this path: its columns keep the defaults, see output.py)
     flat = np.concatenate(feats_all) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
@@ -238,7 +333,9 @@ def main(argv=None):
     ap.add_argument("--disable-telemetry-i-dont-want-to-improve-sage", action="store_true", dest="disable_telemetry",
                     help="accepted; this implementation never sends telemetry")
     ap.add_argument("--stack-size", type=int, help="accepted; no effect")
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=0, help="the HIP device that searches (default 0)")
+    ap.add_argument("--devices", help="search on several devices at once: all | 0-7 | 0,2,3 — every file's spectra are sharded "
+                                      "over them, the index is replicated (sage uses every core of the machine; this is the same)")
     ap.add_argument("--host-preprocess", action="store_true", help="run SpectrumProcessor::process on the host instead of the device")
     args = ap.parse_args(argv)
     if args.parquet or args.write_report:
@@ -255,7 +352,8 @@ def main(argv=None):
         raise SystemExit("'mzml_paths' must be provided!")
     out = args.output_directory or cfg.get("output_directory") or os.getcwd()
     summary = run(cfg, mzml, out, args.device, host_preprocess=args.host_preprocess,
-                  write_pin=args.write_pin or bool(cfg.get("write_pin", False)))
+                  write_pin=args.write_pin or bool(cfg.get("write_pin", False)),
+                  devices=parse_devices(args.devices, device_count()))
     print(json.dumps(summary))
 
 

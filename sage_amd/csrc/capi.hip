@@ -335,6 +335,20 @@ int sage_hip_mzml_read(const char* path, uint32_t file_id, int ms_level, SageMzm
     *out = h.release();
     return SAGE_HIP_OK;
 }
+// Inputs the reference refuses to SEARCH (it panics while processing them; the reader itself accepts them): profile-mode MS2
+// spectra (spectrum.rs:280-286 — Representation defaults to Profile, so a spectrum without the centroid term counts) and MS2
+// spectra without a precursor (scoring.rs:466-468).  Call before preprocessing / scoring a run.
+int sage_hip_mzml_check_searchable(const SageMzml* run) {
+    if (!run) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_mzml_check_searchable: null argument");
+    const MzmlRun& r = run->run;
+    for (uint64_t i = 0; i < r.n(); ++i) {
+        if (r.ms_level[i] < 2) continue;
+        const char* id = r.ids.data() + r.id_off[i];
+        if (!r.centroid[i]) return fail(SAGE_HIP_ERR_INVALID, std::string("Scan ") + id + " contains profile data! Please convert to centroid");
+        if (!r.has_precursor[i]) return fail(SAGE_HIP_ERR_INVALID, std::string("missing MS1 precursor for ") + id);
+    }
+    return SAGE_HIP_OK;
+}
 int sage_hip_mzml_view(const SageMzml* run, SageRawBatch* out) {
     if (!run || !out) return fail(SAGE_HIP_ERR_INVALID, "sage_hip_mzml_view: null argument");
     const MzmlRun& r = run->run;

@@ -842,7 +842,10 @@ std::string HostDb::peptide_string(uint64_t i) const {
 void HostDb::competition_keys(const uint32_t* peptide_idx, uint64_t n, uint32_t* peptide_key, uint32_t& n_peptide_keys,
                               uint32_t* protein_key, uint32_t& n_protein_keys) const {
     std::unordered_map<std::string, uint32_t> pep_ids;
-    std::unordered_map<uint32_t, uint32_t> prot_ids;
+    // protein competitions are keyed by the `proteins` vector's CONTENT (fdr.rs:158-161), i.e. the accession string: two FASTA
+    // entries with one accession are one competition
+    std::unordered_map<std::string, uint32_t> prot_ids;
+    std::unordered_map<uint32_t, uint32_t> prot_seen;  // protein id -> key
     std::unordered_map<uint32_t, uint32_t> seen;  // peptide index -> key (PSMs of one peptide are common)
     for (uint64_t f = 0; f < n; f++) {
         const uint64_t i = peptide_idx[f];
@@ -866,7 +869,12 @@ void HostDb::competition_keys(const uint32_t* peptide_idx, uint64_t n, uint32_t*
         }
         if (pep_protein_off[i + 1] - pep_protein_off[i] == 1) {
             const uint32_t prot = pep_protein_ids[pep_protein_off[i]];
-            protein_key[f] = prot_ids.emplace(prot, (uint32_t)prot_ids.size()).first->second;
+            auto ph = prot_seen.find(prot);
+            if (ph == prot_seen.end()) {
+                const uint32_t id = prot_ids.emplace(protein_names[prot], (uint32_t)prot_ids.size()).first->second;
+                ph = prot_seen.emplace(prot, id).first;
+            }
+            protein_key[f] = ph->second;
         } else {
             protein_key[f] = 0xFFFFFFFFu;
         }

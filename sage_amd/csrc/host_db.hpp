@@ -81,6 +81,7 @@ struct MzmlRun {
     std::vector<float> mz, intensities;
     std::vector<float> precursor_mz, isolation_lo, isolation_hi, scan_start_time, inverse_ion_mobility;  // NaN == None
     std::vector<uint8_t> precursor_charge;                                                                 // 0 == None
+    std::vector<uint8_t> centroid, has_precursor, ms_level;  // Representation::Centroid seen; a <precursor> with a selected ion; level
     std::vector<uint32_t> file_id;
     std::string ids;                 // NUL-separated spectrum ids
     std::vector<uint64_t> id_off;    // [n + 1] into ids

@@ -30,11 +30,20 @@ constexpr uint32_t PROBE_BATCH_WORDS = SAGE_PROBE_PER_LANE * 64;
 // [item mod DBG_BLOCKS][kernel*8 + phase] (debug builds of the numbers only; atomics, so slightly perturbing);
 // kernel 0 = narrow preliminary, 1 = rescoring, 2 = large-window count, 3 = large-window replay
 constexpr uint32_t DBG_BLOCKS = 4096;
+// Slots 26..31 of a row count the BYTES the kernels ask memory for (profiling runs only; bench.py reports them next to the
+// reference algorithm's bytes): 26 narrow kernel table words, 27 narrow kernel index cells, 28 rescoring ion masses + peaks,
+// 29 large-window table words, 30 large-window index cells, 31 candidate words written to the arena.
+enum { DBG_NARROW_LUT = 26, DBG_NARROW_CELLS = 27, DBG_RESCORE = 28, DBG_TILE_LUT = 29, DBG_TILE_CELLS = 30, DBG_TILE_CAND = 31 };
 struct PhaseClock {
     unsigned long long* slot;
     long long t;
+    __device__ __forceinline__ void bytes(int which, unsigned long long n) {  // call from ONE lane
+        if (slot) atomicAdd(&slot[which - row_base], n);
+    }
+    int row_base;
     __device__ __forceinline__ void start(unsigned long long* dbg, uint32_t blk, uint32_t kernel) {
         slot = dbg ? dbg + (size_t)(blk % DBG_BLOCKS) * 32 + kernel * 8 : nullptr;
+        row_base = (int)kernel * 8;
         if (slot) t = clock64();
     }
     __device__ __forceinline__ void mark(int phase) {
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
             }
         }
         __syncthreads();
+        if (pc.slot && lane == 0) pc.bytes(DBG_NARROW_CELLS, 4ull * P);  // (the peak masses)
         bool sorted_ok = true;  // (stream) the sorted-count shortcut needs ascending bounds and lo <= hi
         uint32_t ptop = 0;
         if (!PROBE) {
@@ -682,6 +692,11 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                                 run += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
                             }
                             const uint32_t n_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            if (pc.slot && lane == 0) {
+                                const uint32_t nw = nprobe - pbase < PROBE_BATCH ? nprobe - pbase : PROBE_BATCH;
+                                pc.bytes(DBG_NARROW_LUT, 8ull * nw);
+                                pc.bytes(DBG_NARROW_CELLS, 16ull * n_cells);
+                            }
                             wave_sync();
                             for (uint32_t cb = 0; cb < n_cells; cb += WAVE * PROBE_CELLS) {
                                 uint4 e[PROBE_CELLS];
@@ -1151,6 +1166,11 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     psA = *(const uint4*)l_psum;
                     psB = *(const uint4*)(l_psum + 4);
                     unit_cells = uni(psA.x + psA.y + psA.z + psA.w + psB.x + psB.y + psB.z + psB.w);
+                    if (pc.slot && tid == 0) {
+                        const uint32_t pb = (u % nb) * TILE_THREADS;
+                        pc.bytes(DBG_TILE_LUT, 8ull * (nprobe - pb < TILE_THREADS ? nprobe - pb : TILE_THREADS));
+                        pc.bytes(DBG_TILE_CELLS, 16ull * unit_cells);
+                    }
                 };
                 issue_lut(0);
                 publish(0);
@@ -1260,6 +1280,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             const uint32_t d = dir + ((t - t0) * TILE_WAVES + wave) * DIR_WORDS;
                             w.arena[d] = at;
                             w.arena[d + 1] = n_out;
+                            if (w.dbg) atomicAdd(w.dbg + (size_t)(item % DBG_BLOCKS) * 32 + DBG_TILE_CAND, 4ull * n_out + 8ull);
                         }
                         run_at = uni(at);
                     }
@@ -1925,6 +1946,10 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
     __syncthreads();
     pc.mark(0);
+    if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
+        const uint32_t ion_bytes = wave_sum(valid ? 4u * db.n_kinds * lm1 + 24u : 0u);
+        if (lane == 0) pc.bytes(DBG_RESCORE, 8ull * P + 8ull * ncand + ion_bytes);
+    }
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
     const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;

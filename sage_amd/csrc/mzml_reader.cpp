@@ -201,6 +201,48 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
         err = std::string("short read of ") + path;
         return false;
     }
+    // gzip-compressed input (sage-cloudpath lib.rs:44-90 gunzips paths ending in gz / gzip; here: by the 1f 8b magic)
+    if (text.size() >= 2 && (unsigned char)text[0] == 0x1f && (unsigned char)text[1] == 0x8b) {
+        z_stream zs{};
+        if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) {
+            err = std::string("zlib initialisation failed for ") + path;
+            return false;
+        }
+        std::string plain_text;
+        plain_text.resize(std::max<size_t>(text.size() * 6, 1 << 16));
+        zs.next_in = (Bytef*)text.data();
+        zs.avail_in = (uInt)std::min<size_t>(text.size(), 0xFFFFFFFFu);
+        size_t consumed_in = zs.avail_in, have = 0;
+        int rc = Z_OK;
+        for (;;) {
+            if (have == plain_text.size()) plain_text.resize(plain_text.size() * 2);
+            zs.next_out = (Bytef*)&plain_text[have];
+            const size_t room = std::min<size_t>(plain_text.size() - have, 0x40000000u);
+            zs.avail_out = (uInt)room;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            have += room - zs.avail_out;
+            if (rc == Z_STREAM_END) {
+                if (zs.avail_in == 0 && consumed_in == text.size()) break;
+                if (inflateReset(&zs) != Z_OK) break;  // (concatenated gzip members)
+                if (zs.avail_in == 0) break;
+                continue;
+            }
+            if (rc != Z_OK) break;
+            if (zs.avail_in == 0 && consumed_in < text.size()) {  // (inputs above 4 GiB: feed the next piece)
+                const size_t more = std::min<size_t>(text.size() - consumed_in, 0xFFFFFFFFu);
+                zs.next_in = (Bytef*)text.data() + consumed_in;
+                zs.avail_in = (uInt)more;
+                consumed_in += more;
+            }
+        }
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) {
+            err = std::string("corrupt gzip stream in ") + path;
+            return false;
+        }
+        plain_text.resize(have);
+        text.swap(plain_text);
+    }
     run = MzmlRun{};
     run.peak_off.push_back(0);
     run.id_off.push_back(0);
@@ -213,6 +255,7 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
         std::string_view idv;
         std::string id = attr(t.attrs, "id", idv) ? unescape(idv) : std::string();
         bool have_level = false, tic_zero = false, have_precursor = false, in_precursor = false, in_scan = false, in_bda = false;
+        bool centroid = false;  // Representation::default() is Profile (spectrum.rs:119-124); MS:1000127 / MS:1000128 set it
         int level = 0, depth = 1;
         std::vector<float> mz, inten;
         float scan_start = 0.0f, prec_mz = 0.0f, prec_ims = NAN, iso_lo = NAN, iso_hi = NAN;
@@ -320,6 +363,10 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
                             have_level = true;
                         } else if (acc == "MS:1000285") {
                             tic_zero = parse_f32(val) == 0.0f;
+                        } else if (acc == "MS:1000127") {
+                            centroid = true;
+                        } else if (acc == "MS:1000128") {
+                            centroid = false;
                         }
                     }
                 }
@@ -373,6 +420,9 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
         run.scan_start_time.push_back(scan_start);
         run.inverse_ion_mobility.push_back(prec_ims);
         run.file_id.push_back(file_id);
+        run.centroid.push_back(centroid ? 1 : 0);
+        run.has_precursor.push_back(have_precursor ? 1 : 0);
+        run.ms_level.push_back((uint8_t)std::min(std::max(level, 0), 255));
         run.ids += id;
         run.ids += '\0';
         run.id_off.push_back(run.ids.size());

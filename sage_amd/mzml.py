@@ -142,9 +142,10 @@ def read_mzml(path: str, file_id: int = 0, ms_level: Optional[int] = 2) -> List[
     return out
 
 
-def read_mzml_native(path: str, file_id: int = 0, ms_level: Optional[int] = 2):
+def read_mzml_native(path: str, file_id: int = 0, ms_level: Optional[int] = 2, check_searchable: bool = False):
     """The same reader in C++ (csrc/mzml_reader.cpp, sage_hip_mzml_read): one call per file, arrays straight into a RawBatch
-    for Scorer.process_upload — no Python object per spectrum."""
+    for Scorer.process_upload — no Python object per spectrum.  gzip-compressed files are inflated on the way in.
+    check_searchable: refuse what the reference refuses to search (profile-mode MS2 spectra, MS2 spectra without precursor)."""
     import ctypes as C
 
     from . import _lib as L
@@ -153,6 +154,8 @@ def read_mzml_native(path: str, file_id: int = 0, ms_level: Optional[int] = 2):
     h = C.c_void_p()
     L.check(lib.sage_hip_mzml_read(path.encode(), file_id, -1 if ms_level is None else int(ms_level), C.byref(h)))
     try:
+        if check_searchable:
+            L.check(lib.sage_hip_mzml_check_searchable(h))
         v = L.SageRawBatch()
         L.check(lib.sage_hip_mzml_view(h, C.byref(v)))
         n = int(v.n_spectra)

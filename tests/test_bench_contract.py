@@ -29,7 +29,7 @@ def _last_json(stdout):
 @pytest.mark.gpu
 def test_bench_single_rank_line(gpu_required):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--spectra", "3000", "--proteins", "400",
-                        "--cpu-sample", "512", "--traffic-timeout", "150"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--cpu-sample", "512", "--traffic-timeout", "90"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     for k in REQUIRED:

@@ -383,3 +383,120 @@ def test_native_mzml_reader_matches_the_python_reader(tmp_path):
         _assert_same_run(read_mzml_native(ref, 0, 2), read_mzml(ref, 0, 2), "reference fixture")
     with pytest.raises(Exception):
         read_mzml_native(str(tmp_path / "missing.mzML"))
+
+
+# ---- inputs at the edge of the boundary: gzip, unsearchable spectra, device lists --------------------------------------------
+def test_gzip_inputs_and_device_lists(tmp_path):
+    import gzip
+    from sage_amd.mzml import read_mzml_native
+    fasta = synthetic_fasta(20, seed=61)
+    host = DatabaseParameters(static_mods={"C": 57.0215}).build(fasta)
+    p = str(tmp_path / "run.mzML")
+    write_mzml(p, synthetic_spectra(host, 25, seed=62))
+    open(p + ".gz", "wb").write(gzip.compress(open(p, "rb").read()))
+    a, b = read_mzml_native(p, 0), read_mzml_native(p + ".gz", 0)  # sage-cloudpath lib.rs:44-90: gz inputs are inflated
+    assert a.n == b.n == 25 and a.ids == b.ids and np.array_equal(a.mz, b.mz) and np.array_equal(a.precursor_mz, b.precursor_mz)
+    fa = str(tmp_path / "db.fasta.gz")
+    open(fa, "wb").write(gzip.compress(fasta.encode()))
+    assert cli.read_text(fa) == fasta
+    assert cli.parse_devices("all", 4) == [0, 1, 2, 3] and cli.parse_devices("0-2,1", 4) == [0, 1, 2, 1] and cli.parse_devices(None, 4) is None
+    with pytest.raises(SystemExit):
+        cli.parse_devices("0-8", 4)
+
+
+def test_unsearchable_spectra_are_refused(tmp_path):
+    """The reference panics on profile-mode MS2 spectra (spectrum.rs:280-286; no centroid term == profile) and on MS2 spectra
+    without a precursor (scoring.rs:466-468) when it PROCESSES them; the reader accepts them.  Same here: the read succeeds,
+    sage_hip_mzml_check_searchable refuses with the reference's message."""
+    from sage_amd._lib import SageHipError
+    from sage_amd.mzml import read_mzml_native
+    fasta = synthetic_fasta(20, seed=63)
+    host = DatabaseParameters(static_mods={"C": 57.0215}).build(fasta)
+    p = str(tmp_path / "ok.mzML")
+    write_mzml(p, synthetic_spectra(host, 5, seed=64))
+    text = open(p).read()
+    assert read_mzml_native(p, 0, check_searchable=True).n == 5
+    prof = str(tmp_path / "profile.mzML")
+    open(prof, "w").write(text.replace('accession="MS:1000127" name="centroid spectrum"', 'accession="MS:1000128" name="profile spectrum"', 1))
+    assert read_mzml_native(prof, 0).n == 5
+    with pytest.raises(SageHipError, match="contains profile data"):
+        read_mzml_native(prof, 0, check_searchable=True)
+    nop = str(tmp_path / "noprecursor.mzML")
+    a, b = text.index("<precursorList"), text.index("</precursorList>") + len("</precursorList>")
+    open(nop, "w").write(text[:a] + text[b:])
+    with pytest.raises(SageHipError, match="missing MS1 precursor"):
+        read_mzml_native(nop, 0, check_searchable=True)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_c_driver(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "drive_search")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "ctest", "drive_search.c"), "-o", exe, "-L" + os.path.join(ROOT, "sage_amd"),
+                           "-lsage_hip", "-Wl,-rpath," + os.path.join(ROOT, "sage_amd")])
+    return exe
+
+
+def test_c_driver_compiles_and_links_against_the_header(tmp_path):
+    """include/sage_hip.h is a C header: a C11 translation unit that drives mzML -> results.sage.tsv through it compiles with
+    gcc -Wall -Werror and links against libsage_hip.so (no C++ or HIP types leak through the boundary)."""
+    from sage_amd import _lib
+    _lib.load()  # (builds the library if it is missing)
+    assert os.path.exists(_build_c_driver(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_driver_matches_the_cli(tmp_path, gpu_required):
+    """tests/ctest/drive_search.c (plain C, -lsage_hip: FASTA + mzML in, results.sage.tsv out, no Python in the data path)
+    against the Python CLI on the same inputs and parameters: the two files are byte-identical."""
+    import subprocess
+    fasta = synthetic_fasta(120, seed=71)
+    fa = str(tmp_path / "db.fasta")
+    open(fa, "w").write(fasta)
+    dbj = {"enzyme": {"missed_cleavages": 1, "cleave_at": "KR", "restrict": "P"}, "static_mods": {"C": 57.0215}, "fasta": fa}
+    host = DatabaseParameters.from_json(dbj).build(fasta)
+    mz = str(tmp_path / "run.mzML")
+    write_mzml(mz, synthetic_spectra(host, 400, seed=72))
+    cfg = {"database": dbj, "precursor_tol": {"ppm": [-20, 20]}, "fragment_tol": {"ppm": [-10, 10]}, "predict_rt": False,
+           "mzml_paths": [mz]}
+    cp = str(tmp_path / "c.json")
+    json.dump(cfg, open(cp, "w"))
+    out = str(tmp_path / "o")
+    cli.main([cp, "--output_directory", out])
+    exe = _build_c_driver(tmp_path)
+    c_out = str(tmp_path / "c_results.tsv")
+    r = subprocess.run([exe, fa, mz, c_out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(c_out, "rb").read() == open(os.path.join(out, "results.sage.tsv"), "rb").read()
+    assert "PSMs" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_on_several_devices(tmp_path, gpu_required):
+    """--devices: every file's spectra sharded over the workers (one host thread, device database and scorer each), results
+    concatenated in input order.  A 1-GPU box names its device twice — two workers, two replicas of the index — and the
+    output must equal the single-device run byte for byte, matched fragments included."""
+    fasta = synthetic_fasta(80, seed=81)
+    fa = str(tmp_path / "db.fasta")
+    open(fa, "w").write(fasta)
+    dbj = {"enzyme": {"missed_cleavages": 1, "cleave_at": "KR", "restrict": "P"}, "static_mods": {"C": 57.0215}, "fasta": fa}
+    host = DatabaseParameters.from_json(dbj).build(fasta)
+    files = []
+    for k in range(2):
+        p = str(tmp_path / f"run{k}.mzML")
+        write_mzml(p, synthetic_spectra(host, 90, seed=82 + k))
+        files.append(p)
+    cfg = {"database": dbj, "precursor_tol": {"ppm": [-10, 10]}, "fragment_tol": {"ppm": [-10, 10]}, "report_psms": 2,
+           "annotate_matches": True, "mzml_paths": files}
+    cp = str(tmp_path / "c.json")
+    json.dump(cfg, open(cp, "w"))
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    cli.main([cp, "--output_directory", one])
+    cli.main([cp, "--output_directory", two, "--devices", "0,0,0"])
+    for name in ("results.sage.tsv", "matched_fragments.sage.tsv"):
+        assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
+    with pytest.raises(SystemExit, match="report_psms"):
+        cli.run(dict(cfg, report_psms=40), files, str(tmp_path / "x"))
