@@ -131,8 +131,14 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None):
     parts = None
     if workers > 1 and n_chunks > 1:
         try:
-            with mp.get_context("fork").Pool(workers) as pool:
+            # close + join, not the context manager: its terminate() sends SIGTERM to the workers, which a profiler's signal
+            # handler inherited through the fork (rocprofv3 --pmc) turns into a hang
+            pool = mp.get_context("fork").Pool(workers)
+            try:
                 parts = pool.map(_gen_chunk, range(n_chunks), chunksize=1)
+            finally:
+                pool.close()
+                pool.join()
         except Exception as e:  # noqa: BLE001 — fall back to the serial path, say so
             print(f"bench.py: parallel workload generation failed ({e!r}); generating serially", file=sys.stderr)
             parts = None

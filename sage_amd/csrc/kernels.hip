@@ -1734,6 +1734,17 @@ __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatc
 }
 
 // ---- rescoring -------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_max_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double from_order_key64(long long k) {  // inverse of order_key64 (the mapping is an involution)
+    return __longlong_as_double(k ^ (long long)(((unsigned long long)(k >> 63)) >> 1));
+}
 __device__ __forceinline__ double lnfact_dev(uint32_t n, const double* __restrict__ table, uint32_t table_n) {
     if (n < table_n) return table[n];
     const double x = (double)n;  // scoring.rs:170-177
@@ -1789,6 +1800,51 @@ __device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, flo
     } else {
         tol_bounds(t, center, lo, hi);
     }
+}
+
+// A peak-presence bitmap over PBM_BITS mass bins (width: a power of two, so bin() is exact) filters score_candidate's lookups:
+// every peak sets the bins that overlap [mass - D, mass + D], where D bounds |peak - mz| over every (mz, matching peak) pair
+// the fragment tolerance admits below the bitmap's span.  An ion whose own bin is clear cannot match any peak, so only the
+// few ions with a set bin (true matches + ~2 % neighbours) go through Tolerance::bounds and select_most_intense_peak — with
+// exactly the reference's arithmetic.  The filter is conservative by construction (never drops a match); when that cannot
+// be guaranteed (non-finite masses, tolerances of a quarter of the mass range and more) every bin is set.
+constexpr uint32_t PBM_BITS = 8192, PBM_WORDS = PBM_BITS / 32;
+__device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
+    const uint32_t lane = lane_id();
+    const float top = P ? pm[P - 1] : 0.0f;
+    const float tmax = __builtin_fmaxf(__builtin_fabsf(t.lo), __builtin_fabsf(t.hi));
+    // Tolerance::bounds (mass.rs:21-35): a window relative to the centre (ppm, pct) or absolute (Da)
+    const bool relative = t.kind != 2;
+    const float rel = t.kind == 0 ? tmax * 1.0e-6f : t.kind == 1 ? tmax * 1.0e-2f : 0.0f;
+    bool ok = top == top && top < 1.0e30f && tmax == tmax && (relative ? rel < 0.25f : tmax < 1.0e30f) && (P == 0 || pm[0] == pm[0]);
+    // span = PBM_BITS * wb must exceed every mz that can still reach a peak: top * (1 + 2 tol) + 1, resp. top + 2 tol + 1
+    const float reach = relative ? top * (1.0f + 2.0f * rel) + 1.0f : top + 2.0f * tmax + 1.0f;
+    float wb = 1.0f / 64.0f;
+    while (ok && (float)PBM_BITS * wb <= reach && wb < 1.0e30f) wb *= 2.0f;
+    const float span = (float)PBM_BITS * wb;
+    // D: the widest half window below `span`, a relative 1e-4 for the roundings inside Tolerance::bounds, and 8 ulp(span)
+    // for the rounding of mz / charge through a reciprocal and of mass -+ D
+    const float D = (relative ? span * rel : tmax) * 1.0001f + span * (1.0f / 1048576.0f);
+    if (D > 32.0f * wb) ok = false;  // (a peak would set more than 64 bins: no filter)
+    inv_wb = ok ? 1.0f / wb : 0.0f;
+    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = ok ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    if (!ok) return;
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        const float m = pm[i];
+        if (!(m == m)) continue;  // (a NaN mass never satisfies `mass >= lo && mass <= hi`)
+        float f0 = (m - D) * inv_wb, f1 = (m + D) * inv_wb;
+        f0 = f0 > 0.0f ? f0 : 0.0f;
+        f1 = f1 > 0.0f ? f1 : 0.0f;
+        const uint32_t b0 = f0 < (float)(PBM_BITS - 1) ? (uint32_t)f0 : PBM_BITS - 1;
+        const uint32_t b1 = f1 < (float)(PBM_BITS - 1) ? (uint32_t)f1 : PBM_BITS - 1;
+        for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[bin >> 5], 1u << (bin & 31u));
+    }
+}
+__device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
+    // clamp to [0, PBM_BITS - 1] in one v_med3_f32 (a NaN comes out as one of the bounds), then truncate
+    const uint32_t bin = (uint32_t)__builtin_amdgcn_fmed3f(mz * inv_wb, 0.0f, (float)(PBM_BITS - 1));
+    return (bm[bin >> 5] >> (bin & 31u)) & 1u;
 }
 
 __device__ __forceinline__ int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w,
@@ -1903,7 +1959,8 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     uint8_t* rm = (uint8_t*)(pi + b.pcap);                    // [pcap] chimera: peak selected by the winner
     uint8_t* rm2 = rm + b.pcap;
     uint32_t* plut = (uint32_t*)(smem + (((size_t)(rm2 + b.pcap - smem) + 7) & ~(size_t)7));  // [PLUT_BINS] peak position table
-    QuickKey* qkeys = (QuickKey*)(plut + PLUT_BINS);          // [64] quick_score only
+    uint32_t* pbm = plut + PLUT_BINS;                         // [PBM_WORDS] peak presence bitmap
+    QuickKey* qkeys = (QuickKey*)(pbm + PBM_WORDS);           // [64] quick_score only
 
     if (w.status[spec] != ST_OK) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -1949,6 +2006,12 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
         const uint32_t ion_bytes = wave_sum(valid ? 4u * db.n_kinds * lm1 + 24u : 0u);
         if (lane == 0) pc.bytes(DBG_RESCORE, 8ull * P + 8ull * ncand + ion_bytes);
+        // shape of the work: (ion, charge) items of all candidates, of the longest candidate, candidates, peaks
+        const uint32_t items = wave_sum(n_items);
+        uint32_t longest = n_items;
+        for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)longest, o, 64); longest = v > longest ? v : longest; }
+        const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
+        if (lane == 0) { atomicAdd(&pc.slot[5], items); atomicAdd(&pc.slot[6], longest); atomicAdd(&pc.slot[7], nvalid); }
     }
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
@@ -1957,9 +2020,12 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
+    float inv_wb = 0.0f;
     for (uint32_t round = 0; round < rounds; round++) {
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
+        // (built once: after remove_matched_peaks the bitmap is a superset of the remaining peaks' bins — still conservative)
+        if (round == 0) build_peak_bitmap(pbm, inv_wb, pm, P, sc.fragment_tol);
         __syncthreads();
         Score s;
         s.peptide = pep;
@@ -1971,36 +2037,62 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
         s.longest_b = s.longest_y = 0;
         {
             // ---- score_candidate (scoring.rs:699-759), one lane per candidate, in the reference's (kind, index, charge)
-            //      order; the candidate's ion masses are fetched four ahead of their use, peaks are matched through the
-            //      direct-index table.  (SAGE_HIP_DEBUG_FLAGS=8 selects the item-parallel two-phase variant below.)
-            if (valid && lm1) {
+            //      order, in chunks of <= 64 (ion, charge) items: first every item of the chunk is tested against the
+            //      peak-presence bitmap (one LDS word per item, no division), then only the items whose bin is set go through
+            //      Tolerance::bounds + select_most_intense_peak (direct-index table) and are accumulated — in item order,
+            //      so the f32 sums are the reference's.  ~90 % of the items of a candidate match nothing.
+            //      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles with 6 wavefronts —
+            //      so what counts is instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
+            if (valid && lm1 && nfz) {
                 Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
                 const float* __restrict__ my = db.ions + ion_base;
                 const uint32_t nions = db.n_kinds * lm1;
-                float nxt[4];
+                const uint32_t ipc = 64u / (nfz < 64u ? nfz : 64u);  // ions per chunk
+                for (uint32_t j0 = 0; j0 < nions; j0 += ipc) {
+                    const uint32_t j1 = j0 + ipc < nions ? j0 + ipc : nions;
+                    uint64_t hits = 0;
+                    uint32_t pos = 0;
+                    float nxt[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) nxt[u] = u < nions ? my[u] : 0.0f;
-                uint32_t kind_i = 0, idx = 0;  // ion j = kind_i * lm1 + idx
-                for (uint32_t j0 = 0; j0 < nions; j0 += 4) {
-                    float cur[4];
+                    for (uint32_t u = 0; u < 4; u++) nxt[u] = j0 + u < j1 ? my[j0 + u] : 0.0f;
+                    for (uint32_t j = j0; j < j1; j += 4) {
+                        float cur[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        cur[u] = nxt[u];
-                        nxt[u] = j0 + 4 + u < nions ? my[j0 + 4 + u] : 0.0f;
+                        for (uint32_t u = 0; u < 4; u++) {
+                            cur[u] = nxt[u];
+                            nxt[u] = j + 4 + u < j1 ? my[j + 4 + u] : 0.0f;
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            if (j + u >= j1) break;
+                            for (uint32_t c = 1; c < mfc; c++) {
+                                // (an approximate mz / c is enough to pick the bin: D carries the slack)
+                                const float mzf = c == 1 ? cur[u] : c == 2 ? cur[u] * 0.5f : c == 3 ? cur[u] * (1.0f / 3.0f) : cur[u] / (float)c;
+                                hits |= (uint64_t)peak_bitmap_test(pbm, inv_wb, mzf) << pos;
+                                pos++;
+                            }
+                        }
                     }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        if (j0 + u >= nions) break;
-                        const bool nterm_kind = (nterm_mask >> kind_i) & 1u;
-                        for (uint32_t c = 1; c < mfc; c++) {
-                            const float mz = c == 1 ? cur[u] : cur[u] / (float)c;  // (x / 1.0 == x)
-                            float flo, fhi;
-                            tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
-                            const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
-                            if (pk < 0) continue;
+                    if (!hits) continue;
+                    uint32_t bit = (uint32_t)__ffsll((long long)hits) - 1;
+                    uint32_t jj = j0 + (nfz == 1 ? bit : nfz == 2 ? bit >> 1 : bit / nfz);
+                    float ionv = my[jj];
+                    while (hits) {
+                        hits &= hits - 1;
+                        const uint32_t nbit = hits ? (uint32_t)__ffsll((long long)hits) - 1 : bit;
+                        const uint32_t njj = j0 + (nfz == 1 ? nbit : nfz == 2 ? nbit >> 1 : nbit / nfz);
+                        const float nion = my[njj];  // (the next item's ion is in flight while this one is matched)
+                        const uint32_t c = bit - (jj - j0) * nfz + 1;
+                        uint32_t kind_i = 0, idx = jj;
+                        while (idx >= lm1) { idx -= lm1; kind_i++; }
+                        const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
+                        float flo, fhi;
+                        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
+                        if (pk >= 0) {
                             const float peak_mass = pm[pk], peak_intensity = pi[pk];
                             s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
-                            if (nterm_kind) {
+                            if ((nterm_mask >> kind_i) & 1u) {
                                 s.matched_b += 1;
                                 s.summed_b += peak_intensity;
                                 run_matched(b_run, idx);
@@ -2010,7 +2102,9 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
                                 run_matched(y_run, idx);
                             }
                         }
-                        if (++idx == lm1) { idx = 0; kind_i++; }
+                        bit = nbit;
+                        jj = njj;
+                        ionv = nion;
                     }
                 }
                 s.longest_b = b_run.longest;
@@ -2054,28 +2148,47 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
         }
         // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation
         const long long key = order_key64(h);
-        s_key[lane] = key;
         const uint64_t pmask = __ballot(pass);
         const uint32_t npass = (uint32_t)__popcll(pmask);
-        __syncthreads();
         uint32_t rank = 0;
-        if (pass) {
-            uint64_t m = pmask;
-            while (m) {
-                const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
-                m &= m - 1;
-                const long long kj = s_key[j];
-                rank += (kj > key) || (kj == key && j < lane);
+        double next_h = 0.0, best_h = 0.0;  // hyperscore of the next rank (0 if none) and of rank 0
+        bool tie = false;                   // equal hyperscores meet at a reported rank
+        if (per_round == 1) {
+            // one reported PSM: the sort reduces to the largest key (first lane on ties — the sort is stable) and the
+            // largest key among the others
+            const long long lowest = (long long)0x8000000000000000ull;
+            const long long best_key = wave_max_i64(pass ? key : lowest);
+            const uint64_t wins = __ballot(pass && key == best_key);
+            const uint32_t wl = (uint32_t)__ffsll((long long)wins) - 1;
+            const long long second_key = wave_max_i64(pass && lane != wl ? key : lowest);
+            rank = pass && lane == wl ? 0u : 1u;
+            best_h = from_order_key64(best_key);
+            next_h = npass > 1 ? from_order_key64(second_key) : 0.0;
+            tie = pass && rank == 0 && npass > 1 && second_key == best_key;
+        } else {
+            s_key[lane] = key;
+            __syncthreads();
+            if (pass) {
+                uint64_t m = pmask;
+                while (m) {
+                    const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const long long kj = s_key[j];
+                    rank += (kj > key) || (kj == key && j < lane);
+                }
+                s_sorted[rank] = h;
             }
-            s_sorted[rank] = h;
+            __syncthreads();
+            if (pass && rank < per_round) {
+                next_h = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
+                best_h = s_sorted[0];
+                tie = rank + 1 < npass && __double_as_longlong(s_sorted[rank]) == __double_as_longlong(s_sorted[rank + 1]);
+            }
         }
-        __syncthreads();
         pc.mark(3);
         if (!sc.exact) {
             // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two
             // equal hyperscores meet at a reported rank (i, i+1 with i < per_round).  Otherwise: back through the exact path.
-            const bool tie = pass && rank < per_round && rank + 1 < npass &&
-                             __double_as_longlong(s_sorted[rank]) == __double_as_longlong(s_sorted[rank + 1]);
             if (__ballot(tie) != 0ull) {
                 if (lane == 0) {
                     w.status[spec] = ST_RETRY;
@@ -2086,8 +2199,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
             }
         }
         if (pass && rank < per_round) {  // scoring.rs:504-594
-            const double next = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
-            const double best = s_sorted[0];
+            const double next = next_h, best = best_h;
             const float precursor_mass = mzp * (float)z;
             const uint32_t k = s.matched_b + s.matched_y;
             const double log10_poisson =
@@ -2242,7 +2354,7 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
 }
 size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t, bool quick) {
     size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
-    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
+    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + PBM_WORDS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
     return (n + 15) & ~(size_t)15;
 }
 

@@ -24,3 +24,5 @@ nq = max(1, 2 * (t["n_wide"] + t["n_retry"]))  # items of both calls (pass 1 + r
 print("count kernel, wave 0, cycles per queued spectrum: " + " ".join("%s=%d" % (k, v / nq) for k, v in
       zip(("query", "apply", "barrierA", "publish+load", "scan", "clear", "barrierC", "wait for cells"), ph)), " total=%d" % (ph.sum() / nq))
 print("narrow prelim phases:", (out[0:8] / max(1, 2 * batch.n)).astype(int), " rescore phases:", (out[8:16] / max(1, 2 * batch.n)).astype(int))
+r = out[8:16].astype(np.float64) / max(1, batch.n + t["n_retry"])
+print("rescore per spectrum: load=%d score=%d sort=%d feature=%d cycles; items=%.1f longest=%.1f candidates=%.1f" % (r[0], r[1], r[3], r[4], r[5], r[6], r[7]))

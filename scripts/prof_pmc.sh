@@ -2,7 +2,7 @@
 # usage: scripts/prof_pmc.sh <tag> "<counters>" <command...> : rocprofv3 --pmc pass, per-kernel average of each counter
 TAG=$1; CTRS=$2; shift; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS -d $OUT/pmc -o p -- "$@" > $OUT/cmd.log 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-150} rocprofv3 --pmc $CTRS -d $OUT/pmc -o p -- "$@" > $OUT/cmd.log 2>&1 || { echo "pmc pass failed or timed out"; tail -n 3 $OUT/cmd.log; exit 1; }
 python - <<PY
 import sqlite3, glob
 db = glob.glob("$OUT/pmc/**/*.db", recursive=True)[0]
