@@ -1553,14 +1553,11 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
         for (uint32_t i = 0; i < k; i++) w.qres[qid * 64 + i] = RK::unpack(hp[i * 64], rec.left, z, iso);
 }
 
-__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w) {
-    __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
+__device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const DevWork& w, uint64_t* heap, uint64_t n_q, uint32_t blk) {
     const uint32_t lane = lane_id();
-    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    if ((uint64_t)blockIdx.x * 64 >= n_q) return;
-    const uint64_t qid = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t qid = (uint64_t)blk * 64 + lane;
     PhaseClock pc;
-    pc.start(w.dbg, blockIdx.x, 3);
+    pc.start(w.dbg, blk, 3);
     QueryRec rec{};
     if (qid < n_q) rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
@@ -1575,15 +1572,22 @@ __global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w
     if (small_keys) replay_queries<uint32_t>((uint32_t*)heap + lane, w, rec, qid, k, live, z, iso, pc);
     else replay_queries<uint64_t>(heap + lane, w, rec, qid, k, live, z, iso, pc);
 }
+// The grids of the four kernels below are capped (TILE_GRID_CAP) and stride over the device-side count of queued spectra:
+// a narrow search queues none, and half a million blocks that only read the counter and leave would cost ~0.3 ms per kernel.
+__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w) {
+    __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    for (uint64_t blk = blockIdx.x; blk * 64 < n_q; blk += gridDim.x) {
+        tile_replay_block(sc, w, heap, n_q, (uint32_t)blk);
+        __syncthreads();
+    }
+}
 
 // trim_hits of a large-window query WITHOUT replaying the heap (DevScorer::exact == 0): one wavefront walks the verbatim
 // slots and the candidate stream in slot order and keeps every slot above the k-th largest count T, plus the last
 // (k - #above) slots equal to T — the same k candidates bounded_min_heapify keeps — in slot order.
-__global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w) {
+__device__ __forceinline__ void tile_select_query(const DevScorer& sc, const DevWork& w, const uint64_t qid) {
     const uint32_t lane = lane_id();
-    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    const uint64_t qid = blockIdx.x;
-    if (qid >= n_q) return;
     const QueryRec rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
     if (rec.potential <= k || rec.matched == 0 || (rec.pad[0] & 1u)) return;
@@ -1615,15 +1619,16 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
     }
     for (uint32_t i = (nsel < k ? nsel : k) + lane; i < k; i += WAVE) out[i] = PRESCORE_EMPTY;  // fewer than k non-empty slots
 }
+__global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w) {
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_select_query(sc, w, qid);
+}
 
 // The same replay with ONE WAVEFRONT per query (heap one element per lane, wh32_* / wh_* above): ~10x more work per
 // query than the lane-per-query kernel, but every query proceeds in parallel — the better choice while the batch has
 // fewer queries than the GPU has wavefront slots (an open search of ~10^4 spectra, or an exact retry pass).
-__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w) {
+__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid) {
     const uint32_t lane = lane_id();
-    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    const uint64_t qid = blockIdx.x;
-    if (qid >= n_q) return;
     const QueryRec rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
     if (rec.potential <= k || rec.matched == 0) return;        // no k-select: the assembler takes the slots verbatim
@@ -1674,12 +1679,14 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
         if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
     }
 }
+__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w) {
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid);
+}
 
-__global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const DevBatchView& b, const DevWork& w, unsigned char* smem,
+                                                   const uint32_t item) {
     const uint32_t lane = lane_id();
-    const uint32_t item = blockIdx.x;
-    if (item >= w.n_deferred[CTR_QUEUED]) return;
     const uint32_t spec = w.queue[item];
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
@@ -1731,6 +1738,14 @@ __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatc
         w.totals[2 * spec + 1] = tot_scored;
     }
     for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
+}
+__global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t n_items = w.n_deferred[CTR_QUEUED];
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        tile_assemble_item(sc, b, w, smem, item);
+        __syncthreads();
+    }
 }
 
 // ---- rescoring -------------------------------------------------------------------------------
@@ -1809,6 +1824,7 @@ __device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, flo
 // exactly the reference's arithmetic.  The filter is conservative by construction (never drops a match); when that cannot
 // be guaranteed (non-finite masses, tolerances of a quarter of the mass range and more) every bin is set.
 constexpr uint32_t PBM_BITS = 8192, PBM_WORDS = PBM_BITS / 32;
+constexpr uint32_t TILE_GRID_CAP = 32768;  // blocks of the per-query / per-item kernels of the large-window path
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
     const uint32_t lane = lane_id();
     const float top = P ? pm[P - 1] : 0.0f;
@@ -2372,17 +2388,18 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
                        tile_lds_bytes(db, sc, b), (hipStream_t)stream, TileParams{db, sc, b, w});
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
-    if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
+    auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
+    if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
     // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query
     uint32_t wave_max = 32768;
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint32_t)atoi(e);
     // (the exact retry pass — b.n_dev set — holds a few percent of the batch: its queries are few whatever the grid's upper bound)
     if ((!sc.exact && wave_max) || nq <= wave_max || (b.n_dev != nullptr && wave_max))
-        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, sc, w);
+        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     else
-        hipLaunchKernelGGL(tile_replay_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
-    hipLaunchKernelGGL(tile_assemble_kernel, dim3(b.n), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
+        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
+    hipLaunchKernelGGL(tile_assemble_kernel, dim3(capped(b.n)), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
                        (hipStream_t)stream, sc, b, w);
 }
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
