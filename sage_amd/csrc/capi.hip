@@ -179,7 +179,9 @@ struct SageScorer {
     hipStream_t up_stream = nullptr, down_stream = nullptr;  // streaming pipeline: H2D of batch c + 1, D2H of batch c - 1
     DevBuf<double> lnfact;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
-    uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel
+    uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
+    uint32_t tile_blocks8 = 0;       // ... of its u8 instance (smaller LDS footprint: more of them per CU)
+    bool cnt8 = true;                // first pass of a search counts in u8 (SAGE_HIP_NO_U8=1 turns it off)
     SageTiming timing{};
     bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
     uint32_t qmax = 1;
@@ -684,7 +686,10 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         const size_t tile_lds = ((size_t)1 << db->view.tile_shift) * 2 + 12 * 1024;  // counters + bitmap + windows (typical)
         const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / tile_lds));
         s->tile_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
-        if (const char* e = getenv("SAGE_HIP_TILE_BLOCKS")) s->tile_blocks = (uint32_t)std::max(1, atoi(e));
+        const size_t tile_lds8 = ((size_t)1 << db->view.tile_shift) + 14 * 1024;
+        s->tile_blocks8 = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / tile_lds8));
+        if (const char* e = getenv("SAGE_HIP_TILE_BLOCKS")) s->tile_blocks = s->tile_blocks8 = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("SAGE_HIP_NO_U8")) s->cnt8 = atoi(e) == 0;
         HIP_TRY((hipError_t)tile_kernel_prepare(160 * 1024));
     }
     s->qmax = queries_per_spectrum(d);
@@ -1071,7 +1076,7 @@ void sage_hip_batch_free(SageDeviceBatch* b) {
 static uint64_t arena_entries_for(const SageScorer* s, uint32_t n) {
     // 16 Ki entries = 64 KiB per spectrum on average + two 64 Ki-entry chunks per resident workgroup (each takes its arena space
     // a chunk at a time); an exhausted arena is detected, and the batch is then scored in smaller pieces
-    uint64_t e = std::max<uint64_t>((uint64_t)n * 16384, 16ull << 20) + (uint64_t)std::min(n, s->tile_blocks) * (2u << 16);
+    uint64_t e = std::max<uint64_t>((uint64_t)n * 16384, 16ull << 20) + (uint64_t)std::min(n, std::max(s->tile_blocks, s->tile_blocks8)) * (2u << 16);
     e = std::min<uint64_t>(e, 0xFFFFFFF0ull);
     if (const char* v = getenv("SAGE_HIP_ARENA_MB")) e = std::min<uint64_t>((uint64_t)std::max(1, atoi(v)) << 18, 0xFFFFFFF0ull);
     return e;
@@ -1146,6 +1151,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     v2.order = s->ws.retry.p;  // filled by the rescoring kernel of the first pass, in no particular order
     v2.n_dev = o.counters.p + CTR_RETRY;
     DevWork w1 = make_work(s, o, 0), w2 = make_work(s, o, 1);
+    if (two_pass && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
+        w1.cnt8 = 1;
+        w1.tile_blocks = s->tile_blocks8;
+    }
     DevScorer sc1 = sc, sc2 = sc;
     sc1.exact = mode == MODE_EXACT ? 1u : 0u;
     sc2.exact = 1u;

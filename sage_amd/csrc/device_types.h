@@ -101,6 +101,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* queue;       // [n] spectra queued for the large-window kernels
     uint32_t* retry;       // [n] spectra whose reported ranks tie in hyperscore: re-run with exact heap layouts
     uint32_t tile_blocks;  // persistent workgroups of the large-window counting kernel
+    uint32_t cnt8;         // count in u8 (first pass of a two-pass search only: overflowing spectra go to the u16 retry pass)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
     uint16_t* seeds;       // [n * qmax * 64] matched counts of the first min(k, potential) candidate slots
@@ -150,7 +151,7 @@ struct TileParams {
 
 // launch wrappers (kernels.hip)
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
-size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b);
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);

@@ -22,7 +22,7 @@ namespace {
 
 constexpr uint32_t WAVE = 64;
 #ifndef SAGE_PROBE_PER_LANE
-#define SAGE_PROBE_PER_LANE 4   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch)
+#define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
 #endif
 constexpr uint32_t PROBE_BATCH_WORDS = SAGE_PROBE_PER_LANE * 64;
 
@@ -482,14 +482,14 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
 #define SAGE_PROBE_DEPTH 4  // uint4 loads (two index entries each) a lane of the probe kernel issues per window (~3 entries typical)
 #endif
 #ifndef SAGE_PRELIM_WAVES
-#define SAGE_PRELIM_WAVES 6  // 0: leave the occupancy to the compiler
+#define SAGE_PRELIM_WAVES 5  // 0: leave the occupancy to the compiler (A/B on C3: 5 > 6 > 7 > 8)
 #endif
 #ifndef SAGE_RESCORE_WAVES
 #define SAGE_RESCORE_WAVES 6
 #endif
 constexpr uint32_t PROBE_DEPTH = SAGE_PROBE_DEPTH;
 #ifndef SAGE_PROBE_PER_LANE
-#define SAGE_PROBE_PER_LANE 4   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch)
+#define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
 #endif
 #ifndef SAGE_PROBE_CELLS
 #define SAGE_PROBE_CELLS 4      // 16-byte index cells a lane keeps in flight per pass over the flattened runs
@@ -841,7 +841,7 @@ constexpr uint32_t HIST_BINS = 64;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
 struct TileLds {
-    uint32_t* cnt;      // [tile_size / 2] u16 pairs
+    uint32_t* cnt;      // [tile_size / 2] u16 pairs, or [tile_size / 4] u8 quads (cnt8)
     uint32_t* bm;       // [tile_size / 32] one bit per slot: its count reached this tile's pruning threshold (a candidate)
     float* win_lo;      // [fzcap * pcap]
     float* win_hi;
@@ -854,10 +854,10 @@ struct TileLds {
     uint32_t* pcs;      // [TILE_THREADS]
     uint32_t* psum;     // [TILE_WAVES]
 };
-__host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem) {
+__host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem, bool cnt8) {
     size_t off = 0;
     if (l) l->cnt = (uint32_t*)(smem + off);
-    off += ((size_t)1 << tile_shift) * 2;
+    off += ((size_t)1 << tile_shift) * (cnt8 ? 1 : 2);
     if (l) l->bm = (uint32_t*)(smem + off);
     off += (((size_t)1 << tile_shift) / 32 + 3) / 4 * 16;
     if (l) l->win_lo = (float*)(smem + off);
@@ -880,7 +880,7 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     return (off + 15) & ~(size_t)15;
 }
 
-enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_DIR, SH_ARENA_OK, SH_CHUNK_CUR, SH_CHUNK_LIM, SH_THR };
+enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_DIR, SH_ARENA_OK, SH_CHUNK_CUR, SH_CHUNK_LIM, SH_THR, SH_OVF };
 constexpr uint32_t ARENA_CHUNK = 1u << 16;  // entries a workgroup takes from the global arena at a time
 
 __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecInfo& si, uint32_t z, int iso) {
@@ -918,8 +918,22 @@ constexpr uint32_t DIR_WORDS = 2;
 // instructions.  (Read through a TileParams pointer they were generic pointers -> FLAT loads / stores / atomics, which count
 // on lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of an LDS access then also waited for all outstanding HBM
 // loads.)
-__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams kp) {
-    extern __shared__ __align__(16) unsigned char smem[];
+//
+// Two instances.  C8 = false: u16 counters, two per LDS word — 78 KB per workgroup, 2 workgroups per CU.  C8 = true: u8
+// counters, four per word — 46 KB, 3 workgroups per CU (6 wavefronts per SIMD for a kernel that is bound by latency).  A u8
+// counter that reaches 255 flags its query (SH_OVF): the spectrum is not trusted and goes to the retry pass, which always counts
+// in u16 — so the first pass of a search may use u8 and nothing else does (DevWork::cnt8).
+template <bool C8>
+__device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned char* smem) {
+    constexpr uint32_t SPW = C8 ? 4 : 2;            // slots per counter word
+    constexpr uint32_t CSH = C8 ? 2 : 1;            // slot -> word
+    constexpr uint32_t CBITS = C8 ? 8 : 16;         // bits per counter
+    constexpr uint32_t CMAX = C8 ? 0xFFu : 0xFFFFu;
+#ifndef SAGE_TILE8_CELLS
+#define SAGE_TILE8_CELLS 3
+#endif
+    // cells a thread keeps in flight: the u8 instance runs 6 wavefronts per SIMD in 80 VGPRs, the u16 one 4 in 128
+    constexpr uint32_t CPT = C8 ? SAGE_TILE8_CELLS : CELLS_PER_THREAD;
     const DevDbView& db = kp.db;
     const DevScorer& sc = kp.sc;
     const DevBatchView& b = kp.b;
@@ -930,7 +944,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     if (n_queued == 0) return;
     // (the LDS arrays as plain locals: a struct of pointers captured by the lambdas below would live in scratch memory)
     TileLds lds_;
-    tile_lds_layout(db.tile_shift, b, &lds_, smem);
+    tile_lds_layout(db.tile_shift, b, &lds_, smem, C8);
     uint32_t* const l_cnt = lds_.cnt;
     uint32_t* const l_bm = lds_.bm;
     float* const l_win_lo = lds_.win_lo;
@@ -942,15 +956,17 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     uint32_t* const l_pcs = lds_.pcs;
     uint32_t* const l_psum = lds_.psum;
     const uint32_t TSH = db.tile_shift, TS = 1u << TSH;
-    // counter words (two slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [2 * tid * wpt, ...), so thread
-    // order == slot order.  tile_shift 15: 32 words = eight 16-byte quads per thread.
-    const uint32_t wpt = (TS / 2 + TILE_THREADS - 1) / TILE_THREADS;
+    // counter words (SPW slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [SPW * tid * wpt, ...), so thread
+    // order == slot order.  tile_shift 15, u16: 32 words = eight 16-byte quads per thread.
+    const uint32_t wpt = (TS / SPW + TILE_THREADS - 1) / TILE_THREADS;
+    const uint32_t ovf_at = (sc.dbg_flags & 16u) ? 2u : 254u;  // (SAGE_HIP_DEBUG_FLAGS=16: tests send every slot with 3+ matches through the overflow path)
+    const uint32_t idle_mask = (TS / SPW < TILE_THREADS ? TS / SPW : TILE_THREADS) - 1u;  // (word a thread without a hit adds 0 to)
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
     const float cell_max = (float)(db.lut_stride - 1);
     const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
 
-    for (uint32_t i = tid; i < TS / 2; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: every scan clears them
+    for (uint32_t i = tid; i < TS / SPW; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: every scan clears them
     for (uint32_t i = tid; i < TS / 32; i += TILE_THREADS) l_bm[i] = 0;
     // this workgroup's share of the arena: a bump allocator in LDS over chunks taken from the global arena.  Invariant kept by
     // thread 0 between tiles: the chunk has room for a whole tile's candidates, so the wavefronts' allocations during a scan
@@ -1006,7 +1022,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
-                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1;
+                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0;
                         const uint32_t lp = q.right < db.np ? q.right : db.np - 1;
                         const uint32_t nt = db.np ? (lp >> TSH) - (q.left >> TSH) + 1 : 1;
                         const uint32_t words = (nt * TILE_WAVES * DIR_WORDS + 3u) & ~3u;
@@ -1111,7 +1127,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const uint32_t k_ = kbase_ + I * TILE_THREADS + tid;                     \
         cpr##I = NONE32;                                                         \
         ce##I = make_uint4(0u, 0u, 0u, 0u);                                      \
-        if (k_ < unit_cells) {                                                   \
+        if (I < CPT && k_ < unit_cells) {                                        \
             locate(k_, cpr##I, cjj##I);                                          \
             ce##I = frag2[cjj##I >> 1]; /* (tm_frag is padded by 2 entries) */   \
         }                                                                        \
@@ -1127,7 +1143,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                            (PEP) >= first && (PEP) < end;                                                            \
     const uint32_t x##I##H = hit##I##H ? (PEP) - tb_ : 0u;                                                           \
     /* no hit: add 0 to a counter word of this thread's own (distinct addresses, no branch, nothing changes) */       \
-    const uint32_t old##I##H = atomicAdd(&l_cnt[hit##I##H ? x##I##H >> 1 : tid], hit##I##H ? 1u << ((x##I##H & 1) * 16) : 0u);
+    const uint32_t old##I##H = atomicAdd(&l_cnt[hit##I##H ? x##I##H >> CSH : tid & idle_mask], hit##I##H ? 1u << ((x##I##H & (SPW - 1u)) * CBITS) : 0u);
 #define SAGE_APPLY_CELL(I)                                                      \
     float lo_##I = 1.0f, hi_##I = 0.0f;                                         \
     uint32_t p0_##I = 0, p1_##I = 0;                                            \
@@ -1140,7 +1156,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     SAGE_HIT(I, b, ce##I.z, __uint_as_float(ce##I.w), cjj##I + 1)
 #define SAGE_ACCOUNT(I, H)                                                                             \
     {                                                                                                  \
-        const uint32_t c_ = (old##I##H >> ((x##I##H & 1) * 16)) & 0xFFFFu; /* count before this hit */ \
+        const uint32_t c_ = (old##I##H >> ((x##I##H & (SPW - 1u)) * CBITS)) & CMAX; /* count before this hit */ \
+        if (C8 && hit##I##H && c_ >= ovf_at) l_sh[SH_OVF] = 1u; /* (254: the next hit of this slot would carry into its neighbour) */ \
         acc += hit##I##H ? 1u : 0u;                                                                    \
         trans += (hit##I##H && c_ < 3) ? 1u << (c_ * 8) : 0u; /* bytes: 0 -> 1, 1 -> 2, 2 -> 3 */        \
         if (hit##I##H && c_ >= 3 && c_ < HIST_BINS - 1) { /* rare in a search: straight to the histogram (bin 63 = "63 or more") */ \
@@ -1196,7 +1213,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)    // ... then the bookkeeping of the hits
                             t01 += trans & 0xFFu; t12 += (trans >> 8) & 0xFFu; t23 += (trans >> 16) & 0xFFu; trans = 0;
                         }
-                        for (uint32_t kbase_ = CELLS_PER_THREAD * TILE_THREADS; kbase_ < unit_cells; kbase_ += CELLS_PER_THREAD * TILE_THREADS) {
+                        for (uint32_t kbase_ = CPT * TILE_THREADS; kbase_ < unit_cells; kbase_ += CPT * TILE_THREADS) {
                             SAGE_FOR_CELLS(SAGE_LOAD_CELL)  // (a unit with more cells than fit in flight: the rest synchronously)
                             SAGE_FOR_CELLS(SAGE_APPLY_CELL)
                             SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)
@@ -1243,7 +1260,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     // ---- scan: only the candidate bits.  Thread tid owns slots [tid * spt, (tid + 1) * spt): lane order == slot
                     //      order, a wavefront owns one contiguous slot range, so the candidates of a wavefront, ranked through a
                     //      prefix sum of popcounts, ARE in slot order.
-                    const uint32_t spt = 2 * wpt;                 // slots per thread (64 at tile_shift 15)
+                    const uint32_t spt = SPW * wpt;               // slots per thread (64 at tile_shift 15)
                     const uint32_t bwt = (spt + 31) / 32;         // bitmap words per thread (2), or a part of one (spt < 32)
                     uint64_t mask = 0;
                     if (tid * spt < TS) {
@@ -1298,13 +1315,13 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             if (m) {
                                 xs[i] = x_base + (uint32_t)__ffsll((long long)m) - 1;
                                 m &= m - 1;
-                                cs[i] = l_cnt[xs[i] >> 1];
+                                cs[i] = l_cnt[xs[i] >> CSH];
                             }
                         }
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) {
                             if (xs[i] == NONE32) continue;
-                            const uint32_t c = (cs[i] >> ((xs[i] & 1) * 16)) & 0xFFFFu;
+                            const uint32_t c = (cs[i] >> ((xs[i] & (SPW - 1u)) * CBITS)) & CMAX;
                             const uint64_t g = (uint64_t)tb + xs[i] - left;  // candidate slot
                             // (the verbatim head of the window is written below from the counters; here it leaves a hole)
                             w.arena[pos++] = g < nseed ? 0u : (c << 16) | xs[i];
@@ -1312,7 +1329,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         while (m) {
                             const uint32_t x = x_base + (uint32_t)__ffsll((long long)m) - 1;
                             m &= m - 1;
-                            const uint32_t c = (l_cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+                            const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
                             const uint64_t g = (uint64_t)tb + x - left;
                             w.arena[pos++] = g < nseed ? 0u : (c << 16) | x;
                         }
@@ -1324,7 +1341,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                             const uint64_t gx = (uint64_t)tb + x_lo + i;
                             if (gx >= left && gx - left < nseed && x_lo + i < TS) {
                                 const uint32_t x = x_lo + i;
-                                const uint32_t c = (l_cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+                                const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
                                 if (c) w.seeds[qid * 64 + (gx - left)] = (uint16_t)c;
                             }
                         }
@@ -1333,7 +1350,7 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                     // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them)
                     {
                         const uint32_t w_lo = tid * wpt;
-                        if (w_lo < TS / 2) {
+                        if (w_lo < TS / SPW) {
                             if (wpt >= 4) {
                                 for (uint32_t i = 0; i < wpt; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(0u, 0u, 0u, 0u);
                             } else {
@@ -1385,7 +1402,8 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                         r.scored = l_sh[SH_SCORED];
                         r.head = dir;
                         r.z_iso = z | ((uint32_t)(iso + 128) << 8);
-                        r.pad[0] = big | (T << 8);                        // bit 0: the heap replay must keep 64-bit keys / no fast select
+                        // bit 0: the heap replay must keep 64-bit keys / no fast select; bit 1: a u8 counter may have overflowed
+                        r.pad[0] = big | (l_sh[SH_OVF] ? 2u : 0u) | (T << 8);
                         r.pad[1] = T ? n_eq - (k - n_gt) : 0;             // slots equal to T to skip
                         r.n_dir = dir != NONE32 ? (t1 - t0 + 1) * TILE_WAVES : 0;
                         r.t0 = t0;
@@ -1395,6 +1413,15 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             }
         }
     }
+}
+
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams kp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    tile_count_body<false>(kp, smem);
+}
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void tile_count8_kernel(const TileParams kp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    tile_count_body<true>(kp, smem);
 }
 
 // A query's candidates are read back through its directory (QueryRec::head / n_dir), defensively: a position outside the
@@ -1697,6 +1724,7 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     A.items = listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
     B.items = listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
     uint32_t tot_matched = 0, tot_scored = 0;
+    bool cnt_overflow = false;
     for (uint32_t z = si.z0; z <= si.z1; z++) {
         if (fold) { A.stored = 0; A.len = 0; }
         for (int iso = isoA; iso <= isoB; iso++) {
@@ -1704,6 +1732,7 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
             const QueryRec rec = w.qrec[qid];
             const uint32_t k = trim_k(rec.potential, sc.report_psms);
             tot_matched += rec.matched;
+            cnt_overflow |= (rec.pad[0] & 2u) != 0;
             UList& target = fold ? A : B;
             if (rec.matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
                 ulist_append_empties(target, rec.potential, sc.kmax);
@@ -1730,6 +1759,13 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     }
     ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
     wave_sync();
+    if (cnt_overflow) {  // a u8 counter of the count kernel may have wrapped: the spectrum goes through the retry pass (u16 counters)
+        if (lane == 0) {
+            w.status[spec] = ST_RETRY;
+            w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+        }
+        return;
+    }
     if (lane == 0) {
         if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
         w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
@@ -2357,12 +2393,13 @@ size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
     n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }
-size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b) {
-    return tile_lds_layout(db.tile_shift, b, nullptr, nullptr);
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8) {
+    return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8);
 }
 int tile_kernel_prepare(size_t max_lds_bytes) {
-    return (int)hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)max_lds_bytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void*)tile_count8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
 }
 uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
@@ -2384,8 +2421,12 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
-                       tile_lds_bytes(db, sc, b), (hipStream_t)stream, TileParams{db, sc, b, w});
+    if (w.cnt8)
+        hipLaunchKernelGGL(tile_count8_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
+                           tile_lds_bytes(db, sc, b, true), (hipStream_t)stream, TileParams{db, sc, b, w});
+    else
+        hipLaunchKernelGGL(tile_count_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
+                           tile_lds_bytes(db, sc, b, false), (hipStream_t)stream, TileParams{db, sc, b, w});
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };

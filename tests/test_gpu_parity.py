@@ -156,6 +156,17 @@ def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", "2")
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, 64-bit replay keys",
                       batch=sub, dev=dev)
+    # the first pass counts in u8 and hands spectra whose counters might wrap to the u16 retry pass: force that hand-over for
+    # every slot with three matches, and switch the u8 instance off altogether
+    monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", "16")
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, u8 counter overflow path",
+                             batch=sub, dev=dev)
+    assert t["n_retry"] > sub.n // 2
+    monkeypatch.delenv("SAGE_HIP_DEBUG_FLAGS")
+    monkeypatch.setenv("SAGE_HIP_NO_U8", "1")
+    n, t2 = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, u16 counters only",
+                              batch=sub, dev=dev)
+    assert t2["n_retry"] < t["n_retry"]
     dev.close()
 
 
