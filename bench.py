@@ -498,6 +498,18 @@ def main():
                     "gpu_algorithm_bytes_per_spectrum": gab,
                     "frac_gpu_algorithm": None if not gab or "error" in gab else gab[dom] * batch.n / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "kernel_ms": {"prelim": pm, "rescore": rm},
+                    # both phases, each against the HBM roofline with the same three byte counts (the top-level fields repeat
+                    # the entry of the phase that takes longer)
+                    "by_kernel": {k: {"ms": ms_k,
+                                      "frac": bytes_per_spec[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "frac_traffic": None if not traffic_ps or k not in traffic_ps else
+                                      traffic_ps[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "frac_gpu_algorithm": None if not gab or "error" in gab else
+                                      gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
+                    "limiters": "prelim (fragment matching + k-select) is the phase that moves the bytes; rescoring reads ~20 KB "
+                                "per spectrum and is bound by VALU issue, not by HBM (rocprofv3 SQ counters, profiles/README.md), "
+                                "so its byte fractions are small by construction",
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],

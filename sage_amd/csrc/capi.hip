@@ -143,9 +143,7 @@ struct OutSet {
     DevBuf<SageFeature> features;
     DevBuf<uint32_t> out_count;
     DevBuf<uint32_t> counters;       // [2 * CTR_COUNT]: first pass, exact retry pass
-    DevBuf<TileParams> tile_params;  // [2]
     uint32_t* h_counters = nullptr;  // pinned [2 * CTR_COUNT]
-    TileParams* h_tile_params = nullptr;  // pinned [2]
     Pinned h_out;                    // landing block for the records when the caller's arrays are pageable
     Event ev[5];                     // start, prelim 1, rescore 1, prelim 2, rescore 2
     Event comp_done, down_done;
@@ -153,7 +151,6 @@ struct OutSet {
     uint32_t n = 0;
     ~OutSet() {
         if (h_counters) (void)hipHostFree(h_counters);
-        if (h_tile_params) (void)hipHostFree(h_tile_params);
     }
 };
 
@@ -486,7 +483,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         HIP_TRY(d->pep_mono.upload(v->pep_mono, np));
         HIP_TRY(d->ion_off.upload(ion_off.data(), np + 1));
         HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
-        HIP_TRY(d->ions.alloc(ion_off[np]));
+        HIP_TRY(d->ions.alloc(ion_off[np] + 8));  // (padded: the rescoring kernel reads ions four at a time)
         HIP_TRY(d->pm_frag.alloc(nf));
         HIP_TRY(d->tm_frag.alloc(nf + 2));
         hipError_t be = (hipError_t)generate_fragments_on_device(np, nk, d_kinds.p, d_seq_off.p, d_seq.p, d_mods.p, d_nterm.p, d->pep_mono.p,
@@ -517,7 +514,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         HIP_TRY(d->pm_frag.upload(tm.data(), nf));  // (before the tiles are re-sorted by m/z below)
         HIP_TRY(d->pm_off.upload(pm_off.data(), np + 1));
         d->h_pep_mono.assign(v->pep_mono, v->pep_mono + np);
-        std::vector<float> ions(ion_off[np]);
+        std::vector<float> ions(ion_off[np] + 8);  // (padded: the rescoring kernel reads ions four at a time)
         parallel_for(np, 4096, [&](size_t ib, size_t ie, unsigned) {
             for (size_t i = ib; i < ie; i++) {
                 const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
@@ -662,9 +659,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         HIP_TRY(o.comp_done.create(false));
         HIP_TRY(o.down_done.create(false));
         HIP_TRY(o.counters.alloc(2 * CTR_COUNT));
-        HIP_TRY(o.tile_params.alloc(2));
         HIP_TRY(hipHostMalloc((void**)&o.h_counters, 2 * CTR_COUNT * 4, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void**)&o.h_tile_params, 2 * sizeof(TileParams), hipHostMallocDefault));
     }
     for (SageDeviceBatch& b : s->slots) {
         b.device = db->device;
@@ -1124,7 +1119,6 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
     w.qmax = s->qmax;
     w.tile_shift = s->db->view.tile_shift;
     w.dbg = s->dbg.p;
-    w.tile_params = o.tile_params.p + pass;
     return w;
 }
 
@@ -1158,9 +1152,6 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     DevScorer sc1 = sc, sc2 = sc;
     sc1.exact = mode == MODE_EXACT ? 1u : 0u;
     sc2.exact = 1u;
-    o.h_tile_params[0] = TileParams{s->db->view, sc1, view, w1};
-    o.h_tile_params[1] = TileParams{s->db->view, sc2, v2, w2};
-    HIP_TRY(hipMemcpyAsync(o.tile_params.p, o.h_tile_params, 2 * sizeof(TileParams), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
     HIP_TRY(hipEventRecord(o.ev[0].e, st));
     launch_prelim(s->db->view, sc1, view, w1, st);

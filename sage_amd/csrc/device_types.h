@@ -106,7 +106,6 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     struct QueryRec* qrec; // [n * qmax]
     uint16_t* seeds;       // [n * qmax * 64] matched counts of the first min(k, potential) candidate slots
     uint64_t* qres;        // [n * qmax * 64] heap of each k-selected query, in the reference's layout order
-    const struct TileParams* tile_params;  // device copy of {db, scorer, batch, work} for the count kernel
     uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
     uint32_t arena_cap;    // entries
     uint32_t qmax;

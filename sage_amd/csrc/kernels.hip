@@ -164,6 +164,10 @@ __device__ __forceinline__ uint64_t lane_value(uint64_t v, uint32_t src_lane) { 
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src_lane);
 }
+__device__ __forceinline__ float lane_valuef(float v, uint32_t src_lane) {
+    src_lane = __builtin_amdgcn_readfirstlane(src_lane);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)src_lane));
+}
 // sift_down (heap.rs:40-60) of value `moving` placed at `index`.  sift_down always descends to the smaller child
 // (the left one on a tie), a path that does not depend on the value being sifted: every lane compares ITS two
 // children once (two cross-lane reads), a ballot turns that into one bit per node, the path is then walked with
@@ -478,16 +482,12 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
 // spectra/s).  Both per-spectrum kernels are bound by dependent memory / LDS round trips, so resident wavefronts matter more
 // than registers per wavefront: capping the VGPR budget at 6 waves per SIMD (80 VGPRs, a handful of spills outside the inner
 // loops) and keeping LDS per wavefront under 160 KB / 24 buys ~10 %; past 6 waves nothing more comes.
-#ifndef SAGE_PROBE_DEPTH
-#define SAGE_PROBE_DEPTH 4  // uint4 loads (two index entries each) a lane of the probe kernel issues per window (~3 entries typical)
-#endif
 #ifndef SAGE_PRELIM_WAVES
 #define SAGE_PRELIM_WAVES 5  // 0: leave the occupancy to the compiler (A/B on C3: 5 > 6 > 7 > 8)
 #endif
 #ifndef SAGE_RESCORE_WAVES
-#define SAGE_RESCORE_WAVES 6
+#define SAGE_RESCORE_WAVES 5  // (A/B on C3 with the cooperative matching: 5 > 6)
 #endif
-constexpr uint32_t PROBE_DEPTH = SAGE_PROBE_DEPTH;
 #ifndef SAGE_PROBE_PER_LANE
 #define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
 #endif
@@ -890,23 +890,6 @@ __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecI
 }
 
 constexpr uint32_t CELLS_PER_THREAD = 4;  // 16-byte index cells a thread of the count kernel keeps in flight (x 512 threads per unit)
-
-// j-th (0-based) set bit of a 64-bit mask that has more than j bits set
-__device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t j) {
-    uint32_t pos = 0;
-    uint32_t lo = (uint32_t)m;
-    const uint32_t c32 = (uint32_t)__popc(lo);
-    if (j >= c32) { j -= c32; pos = 32; lo = (uint32_t)(m >> 32); }
-#pragma unroll
-    for (uint32_t width = 16; width; width >>= 1) {
-        const uint32_t c = (uint32_t)__popc(lo & ((1u << width) - 1u));
-        const bool up = j >= c;
-        j -= up ? c : 0;
-        pos += up ? width : 0;
-        lo = up ? lo >> width : lo;
-    }
-    return pos;
-}
 
 // The candidate stream of a query is a DIRECTORY in the arena: for every (tile of the window, wavefront of the count kernel)
 // one entry {position, count} of a run of candidate words `matched count << 16 | slot in tile`, in slot order inside the run;
@@ -1601,9 +1584,12 @@ __device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const Dev
 }
 // The grids of the four kernels below are capped (TILE_GRID_CAP) and stride over the device-side count of queued spectra:
 // a narrow search queues none, and half a million blocks that only read the counter and leave would cost ~0.3 ms per kernel.
-__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w) {
+// (lo, hi]: the kernel only runs when the device-side query count lies in that range — the retry pass launches both replay
+// flavours and the count, which the host never sees, picks one)
+__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w, uint64_t lo, uint64_t hi) {
     __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    if (n_q <= lo || n_q > hi) return;
     for (uint64_t blk = blockIdx.x; blk * 64 < n_q; blk += gridDim.x) {
         tile_replay_block(sc, w, heap, n_q, (uint32_t)blk);
         __syncthreads();
@@ -1706,8 +1692,9 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
         if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
     }
 }
-__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w) {
+__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w, uint64_t lo, uint64_t hi) {
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    if (n_q <= lo || n_q > hi) return;
     for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid);
 }
 
@@ -1860,6 +1847,16 @@ __device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, flo
 // exactly the reference's arithmetic.  The filter is conservative by construction (never drops a match); when that cannot
 // be guaranteed (non-finite masses, tolerances of a quarter of the mass range and more) every bin is set.
 constexpr uint32_t PBM_BITS = 8192, PBM_WORDS = PBM_BITS / 32;
+#ifndef SAGE_COOP_MIN_HITS
+#define SAGE_COOP_MIN_HITS 16
+#endif
+#ifndef SAGE_COOP_MAX_LANES
+#define SAGE_COOP_MAX_LANES 2
+#endif
+// rescore_kernel: hits in a 64-ion chunk above which the wavefront matches the candidate together — when at most
+// COOP_MAX_LANES candidates of the spectrum are that heavy (with many heavy candidates — an open search keeps the 50 best of a
+// million — every lane is busy anyway and the lanes work on their own)
+constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COOP_MAX_LANES;
 constexpr uint32_t TILE_GRID_CAP = 32768;  // blocks of the per-query / per-item kernels of the large-window path
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
     const uint32_t lane = lane_id();
@@ -1896,7 +1893,7 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, c
 __device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
     // clamp to [0, PBM_BITS - 1] in one v_med3_f32 (a NaN comes out as one of the bounds), then truncate
     const uint32_t bin = (uint32_t)__builtin_amdgcn_fmed3f(mz * inv_wb, 0.0f, (float)(PBM_BITS - 1));
-    return (bm[bin >> 5] >> (bin & 31u)) & 1u;
+    return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
 }
 
 __device__ __forceinline__ int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w,
@@ -2004,15 +2001,16 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     if (b.n_dev && blockIdx.x >= *b.n_dev) return;  // retry pass: device-side count
     const uint32_t spec = b.order ? b.order[blockIdx.x] : blockIdx.x;
     // LDS carve
-    double* s_sorted = (double*)smem;                         // [64] hyperscores by rank
-    long long* s_key = (long long*)(smem + 64 * 8);           // [64] sort keys by lane
-    float* pm = (float*)(smem + 128 * 8);                     // [pcap] peak masses
+    uint32_t* pbm = (uint32_t*)smem;                          // [PBM_WORDS] peak presence bitmap (at offset 0: its reads, one per
+                                                              // (ion, charge) item, then address LDS with an immediate base)
+    uint32_t* plut = pbm + PBM_WORDS;                         // [PLUT_BINS] peak position table
+    double* s_sorted = (double*)(plut + PLUT_BINS);           // [64] hyperscores by rank
+    long long* s_key = (long long*)(s_sorted + 64);           // [64] sort keys by lane
+    float* pm = (float*)(s_key + 64);                         // [pcap] peak masses
     float* pi = pm + b.pcap;                                  // [pcap] peak intensities
     uint8_t* rm = (uint8_t*)(pi + b.pcap);                    // [pcap] chimera: peak selected by the winner
     uint8_t* rm2 = rm + b.pcap;
-    uint32_t* plut = (uint32_t*)(smem + (((size_t)(rm2 + b.pcap - smem) + 7) & ~(size_t)7));  // [PLUT_BINS] peak position table
-    uint32_t* pbm = plut + PLUT_BINS;                         // [PBM_WORDS] peak presence bitmap
-    QuickKey* qkeys = (QuickKey*)(pbm + PBM_WORDS);           // [64] quick_score only
+    QuickKey* qkeys = (QuickKey*)(smem + (((size_t)(rm2 + b.pcap - smem) + 7) & ~(size_t)7));  // [64] quick_score only
 
     if (w.status[spec] != ST_OK) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -2073,6 +2071,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
     float inv_wb = 0.0f;
+    const bool any_fz2 = __ballot(valid && nfz >= 2) != 0ull, any_fz3 = __ballot(valid && nfz >= 3) != 0ull;
     for (uint32_t round = 0; round < rounds; round++) {
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
@@ -2089,59 +2088,148 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
         s.longest_b = s.longest_y = 0;
         {
             // ---- score_candidate (scoring.rs:699-759), one lane per candidate, in the reference's (kind, index, charge)
-            //      order, in chunks of <= 64 (ion, charge) items: first every item of the chunk is tested against the
-            //      peak-presence bitmap (one LDS word per item, no division), then only the items whose bin is set go through
-            //      Tolerance::bounds + select_most_intense_peak (direct-index table) and are accumulated — in item order,
-            //      so the f32 sums are the reference's.  ~90 % of the items of a candidate match nothing.
-            //      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles with 6 wavefronts —
-            //      so what counts is instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
-            if (valid && lm1 && nfz) {
+            //      order, in chunks of 64 ions: first every (ion, charge) item of the chunk is tested against the
+            //      peak-presence bitmap — one hit mask per fragment charge 1..3, four ions per trip so that their LDS reads are
+            //      in flight together, no division — then only the items whose bin is set go through Tolerance::bounds +
+            //      select_most_intense_peak (direct-index table) and are accumulated, in item order, so the f32 sums are
+            //      the reference's.  ~90 % of the items of a candidate match nothing.  (Fragment charges above 3 — precursor
+            //      charge 5+ — are not filtered.)
+            //      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles — so what counts is
+            //      instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
+            //      A candidate with many hits in a chunk (the true peptide: ~35 of its ~47 ions) would keep its lane busy
+            //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
+            //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
+            //      adds per match) and handed back to the candidate's lane.
+            {
                 Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
+                const bool scored = valid && lm1 && nfz;
                 const float* __restrict__ my = db.ions + ion_base;
-                const uint32_t nions = db.n_kinds * lm1;
-                const uint32_t ipc = 64u / (nfz < 64u ? nfz : 64u);  // ions per chunk
-                for (uint32_t j0 = 0; j0 < nions; j0 += ipc) {
-                    const uint32_t j1 = j0 + ipc < nions ? j0 + ipc : nions;
-                    uint64_t hits = 0;
-                    uint32_t pos = 0;
-                    float nxt[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) nxt[u] = j0 + u < j1 ? my[j0 + u] : 0.0f;
-                    for (uint32_t j = j0; j < j1; j += 4) {
-                        float cur[4];
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            cur[u] = nxt[u];
-                            nxt[u] = j + 4 + u < j1 ? my[j + 4 + u] : 0.0f;
-                        }
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            if (j + u >= j1) break;
-                            for (uint32_t c = 1; c < mfc; c++) {
-                                // (an approximate mz / c is enough to pick the bin: D carries the slack)
-                                const float mzf = c == 1 ? cur[u] : c == 2 ? cur[u] * 0.5f : c == 3 ? cur[u] * (1.0f / 3.0f) : cur[u] / (float)c;
-                                hits |= (uint64_t)peak_bitmap_test(pbm, inv_wb, mzf) << pos;
-                                pos++;
+                const uint32_t nions = scored ? db.n_kinds * lm1 : 0u;
+                for (uint32_t j0 = 0; __ballot(j0 < nions) != 0ull; j0 += 64u) {  // (wave-uniform trip count)
+                    const bool act = j0 < nions;
+                    const uint32_t n_here = !act ? 0u : nions - j0 < 64u ? nions - j0 : 64u;
+                    uint64_t m1 = 0, m2 = 0, m3 = 0;
+                    if (act) {
+                        // (the ion table is padded by 8: reading past the candidate's last ion is harmless, those bits are masked below)
+                        const float* __restrict__ q = my + j0;
+                        float n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+                        for (uint32_t r = 0; r < n_here; r += 4) {
+                            const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
+                            n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
+                            const uint32_t t1 = peak_bitmap_test(pbm, inv_wb, i0) | (peak_bitmap_test(pbm, inv_wb, i1) << 1) |
+                                                (peak_bitmap_test(pbm, inv_wb, i2) << 2) | (peak_bitmap_test(pbm, inv_wb, i3) << 3);
+                            m1 |= (uint64_t)t1 << r;
+                            if (any_fz2) {  // (wave-uniform: some candidate of this spectrum has fragment charge 2)
+                                // an approximate ion / charge is enough to pick the bin: D carries the slack
+                                const uint32_t t2 = peak_bitmap_test(pbm, inv_wb, i0 * 0.5f) | (peak_bitmap_test(pbm, inv_wb, i1 * 0.5f) << 1) |
+                                                    (peak_bitmap_test(pbm, inv_wb, i2 * 0.5f) << 2) | (peak_bitmap_test(pbm, inv_wb, i3 * 0.5f) << 3);
+                                m2 |= (uint64_t)t2 << r;
+                            }
+                            if (any_fz3) {
+                                const float third = 1.0f / 3.0f;
+                                const uint32_t t3 = peak_bitmap_test(pbm, inv_wb, i0 * third) | (peak_bitmap_test(pbm, inv_wb, i1 * third) << 1) |
+                                                    (peak_bitmap_test(pbm, inv_wb, i2 * third) << 2) | (peak_bitmap_test(pbm, inv_wb, i3 * third) << 3);
+                                m3 |= (uint64_t)t3 << r;
                             }
                         }
+                        const uint64_t in_chunk = n_here >= 64u ? ~0ull : (1ull << n_here) - 1ull;
+                        m1 &= in_chunk;
+                        m2 = nfz >= 2 ? m2 & in_chunk : 0ull;
+                        m3 = nfz >= 3 ? m3 & in_chunk : 0ull;
+                        if (nfz > 3) m1 = m2 = m3 = in_chunk;  // (charges above 3 are not filtered: every ion goes through)
                     }
-                    if (!hits) continue;
-                    uint32_t bit = (uint32_t)__ffsll((long long)hits) - 1;
-                    uint32_t jj = j0 + (nfz == 1 ? bit : nfz == 2 ? bit >> 1 : bit / nfz);
-                    float ionv = my[jj];
-                    while (hits) {
-                        hits &= hits - 1;
-                        const uint32_t nbit = hits ? (uint32_t)__ffsll((long long)hits) - 1 : bit;
-                        const uint32_t njj = j0 + (nfz == 1 ? nbit : nfz == 2 ? nbit >> 1 : nbit / nfz);
-                        const float nion = my[njj];  // (the next item's ion is in flight while this one is matched)
-                        const uint32_t c = bit - (jj - j0) * nfz + 1;
+                    // ---- chunks with many hits: the whole wavefront on one candidate at a time
+                    const uint32_t hc = act && nfz <= 3 ? (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3)) : 0u;
+                    uint64_t bigs = (sc.dbg_flags & 32u) ? 0ull : __ballot(hc > COOP_MIN_HITS);  // (SAGE_HIP_DEBUG_FLAGS=32: tests switch it off)
+                    if ((uint32_t)__popcll(bigs) > COOP_MAX_LANES && !(sc.dbg_flags & 64u)) bigs = 0ull;  // (64: tests take every heavy lane)
+                    while (bigs) {
+                        const uint32_t L = (uint32_t)__ffsll((long long)bigs) - 1;
+                        bigs &= bigs - 1;
+                        const uint64_t M1 = lane_value(m1, L), M2 = lane_value(m2, L), M3 = lane_value(m3, L);
+                        const uint64_t base_L = lane_value((uint64_t)ion_base, L);
+                        const uint32_t lm1_L = (uint32_t)__builtin_amdgcn_readlane((int)lm1, (int)L);
+                        const bool on1 = (M1 >> lane) & 1ull, on2 = (M2 >> lane) & 1ull, on3 = (M3 >> lane) & 1ull;
+                        float it1 = 0.f, it2 = 0.f, it3 = 0.f, tm1 = 0.f, tm2 = 0.f, tm3 = 0.f;
+                        bool ok1 = false, ok2 = false, ok3 = false;
+                        if (on1 || on2 || on3) {
+                            const float ionv = db.ions[base_L + j0 + lane];
+#define SAGE_COOP_LOOKUP(C, ON, OK, IT, TM)                                                              \
+    if (ON) {                                                                                            \
+        const float mz = (C) == 1 ? ionv : ionv / (float)(C);                                            \
+        float flo, fhi;                                                                                  \
+        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);                                          \
+        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);                                \
+        if (pk >= 0) {                                                                                   \
+            const float peak_mass = pm[pk], peak_intensity = pi[pk];                                     \
+            OK = true;                                                                                   \
+            IT = peak_intensity;                                                                         \
+            TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);             \
+        }                                                                                                \
+    }
+                            SAGE_COOP_LOOKUP(1, on1, ok1, it1, tm1)
+                            SAGE_COOP_LOOKUP(2, on2, ok2, it2, tm2)
+                            SAGE_COOP_LOOKUP(3, on3, ok3, it3, tm3)
+#undef SAGE_COOP_LOOKUP
+                        }
+                        const uint64_t K1 = __ballot(ok1), K2 = __ballot(ok2), K3 = __ballot(ok3);
+                        // the candidate's accumulators, wave-uniform while its matches are added in (ion, charge) order
+                        float u_sb = lane_valuef(s.summed_b, L), u_sy = lane_valuef(s.summed_y, L), u_pp = lane_valuef(s.ppm_difference, L);
+                        uint32_t u_mb = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_b, (int)L);
+                        uint32_t u_my = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_y, (int)L);
+                        Run u_b, u_y;
+                        u_b.start = (uint32_t)__builtin_amdgcn_readlane((int)b_run.start, (int)L);
+                        u_b.length = (uint32_t)__builtin_amdgcn_readlane((int)b_run.length, (int)L);
+                        u_b.last = (uint32_t)__builtin_amdgcn_readlane((int)b_run.last, (int)L);
+                        u_b.longest = (uint32_t)__builtin_amdgcn_readlane((int)b_run.longest, (int)L);
+                        u_y.start = (uint32_t)__builtin_amdgcn_readlane((int)y_run.start, (int)L);
+                        u_y.length = (uint32_t)__builtin_amdgcn_readlane((int)y_run.length, (int)L);
+                        u_y.last = (uint32_t)__builtin_amdgcn_readlane((int)y_run.last, (int)L);
+                        u_y.longest = (uint32_t)__builtin_amdgcn_readlane((int)y_run.longest, (int)L);
+                        uint64_t anyK = K1 | K2 | K3;
+                        while (anyK) {
+                            const uint32_t bit = (uint32_t)__ffsll((long long)anyK) - 1;
+                            anyK &= anyK - 1;
+                            uint32_t kind_i = 0, idx = j0 + bit;
+                            while (idx >= lm1_L) { idx -= lm1_L; kind_i++; }
+                            const bool nterm = (nterm_mask >> kind_i) & 1u;
+#define SAGE_COOP_ADD(K, IT, TM)                                                   \
+    if ((K >> bit) & 1ull) {                                                       \
+        const float it = lane_valuef(IT, bit), tm = lane_valuef(TM, bit);          \
+        u_pp += tm;                                                                \
+        if (nterm) { u_mb += 1; u_sb += it; run_matched(u_b, idx); }               \
+        else       { u_my += 1; u_sy += it; run_matched(u_y, idx); }               \
+    }
+                            SAGE_COOP_ADD(K1, it1, tm1)
+                            SAGE_COOP_ADD(K2, it2, tm2)
+                            SAGE_COOP_ADD(K3, it3, tm3)
+#undef SAGE_COOP_ADD
+                        }
+                        if (lane == L) {
+                            s.summed_b = u_sb; s.summed_y = u_sy; s.ppm_difference = u_pp;
+                            s.matched_b = u_mb; s.matched_y = u_my;
+                            b_run = u_b; y_run = u_y;
+                            m1 = m2 = m3 = 0ull;  // done
+                        }
+                    }
+                    // ---- everybody else: the lane walks its own hits
+                    uint64_t any = m1 | m2 | m3;
+                    if (!any) continue;
+                    uint32_t bit = (uint32_t)__ffsll((long long)any) - 1;
+                    float ionv = my[j0 + bit];
+                    while (any) {
+                        any &= any - 1;
+                        const uint32_t nbit = any ? (uint32_t)__ffsll((long long)any) - 1 : bit;
+                        const float nion = my[j0 + nbit];  // (the next item's ion is in flight while this one is matched)
+                        const uint32_t jj = j0 + bit;
                         uint32_t kind_i = 0, idx = jj;
                         while (idx >= lm1) { idx -= lm1; kind_i++; }
-                        const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
-                        float flo, fhi;
-                        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
-                        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
-                        if (pk >= 0) {
+                        for (uint32_t c = 1; c <= nfz; c++) {
+                            if (c <= 3 && !(((c == 1 ? m1 : c == 2 ? m2 : m3) >> bit) & 1ull)) continue;
+                            const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
+                            float flo, fhi;
+                            tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                            const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
+                            if (pk < 0) continue;
                             const float peak_mass = pm[pk], peak_intensity = pi[pk];
                             s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
                             if ((nterm_mask >> kind_i) & 1u) {
@@ -2155,7 +2243,6 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
                             }
                         }
                         bit = nbit;
-                        jj = njj;
                         ionv = nion;
                     }
                 }
@@ -2406,8 +2493,8 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
 size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t, bool quick) {
-    size_t n = 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
-    n = ((n + 7) & ~(size_t)7) + PLUT_BINS * 4 + PBM_WORDS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
+    size_t n = PBM_WORDS * 4 + PLUT_BINS * 4 + 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
+    n = ((n + 7) & ~(size_t)7) + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
     return (n + 15) & ~(size_t)15;
 }
 
@@ -2432,14 +2519,20 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
-    // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query
-    uint32_t wave_max = 32768;
-    if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint32_t)atoi(e);
-    // (the exact retry pass — b.n_dev set — holds a few percent of the batch: its queries are few whatever the grid's upper bound)
-    if ((!sc.exact && wave_max) || nq <= wave_max || (b.n_dev != nullptr && wave_max))
-        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
-    else
-        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w);
+    // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query (far fewer
+    // instructions per offer, but a wavefront lasts as long as its longest query)
+    uint64_t wave_max = 32768;
+    if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint64_t)atoll(e);
+    const uint64_t all = ~0ull;
+    if (b.n_dev != nullptr) {
+        // the exact retry pass: how many spectra it holds is only known on the device
+        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, wave_max);
+        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w, wave_max, all);
+    } else if ((!sc.exact && wave_max) || nq <= wave_max) {
+        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, all);
+    } else {
+        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, all);
+    }
     hipLaunchKernelGGL(tile_assemble_kernel, dim3(capped(b.n)), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
                        (hipStream_t)stream, sc, b, w);
 }

@@ -90,6 +90,22 @@ def test_narrow_kernel_variants(small_world, monkeypatch, variant):
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -0.5, 0.5)), f"{variant}: charge None", batch=unknown)
 
 
+def test_rescoring_with_and_without_cooperative_matching(small_world, monkeypatch):
+    """score_candidate takes a candidate with many filter hits with the whole wavefront (lookups in parallel, sums in item
+    order) when few candidates are that heavy; SAGE_HIP_DEBUG_FLAGS=32 leaves every candidate to its own lane, 64 takes every
+    heavy candidate together.  Same Features either way, also with fragment
+    charges above 3 (unfiltered items) and a wide fragment tolerance (every bin of the peak bitmap set)."""
+    for flags in (None, "32", "64"):
+        if flags:
+            monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", flags)
+        small_world.check(ScorerParams(report_psms=3), f"coop flags={flags}: narrow")
+        small_world.check(ScorerParams(max_fragment_charge=5, override_precursor_charge=True, min_precursor_charge=5,
+                                       max_precursor_charge=6, precursor_tol=Tolerance("da", -3.0, 3.0)),
+                          f"coop flags={flags}: fragment charges 1..5")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("da", -0.6, 0.6), chimera=True, report_psms=2),
+                          f"coop flags={flags}: ±0.6 Da fragments, chimera")
+
+
 def test_report_psms_and_score_types(small_world):
     small_world.check(ScorerParams(report_psms=5, precursor_tol=Tolerance("ppm", -50.0, 50.0)), "report_psms=5")
     small_world.check(ScorerParams(score_type="OpenMSHyperScore", min_matched_peaks=2), "OpenMS score")
