@@ -46,6 +46,9 @@ def test_bench_single_rank_line(gpu_required):
     assert cb["threads_table"] and str(cb["cores"]) in cb["threads_table"]
     assert "workload" in j["config"] and j["config"]["spectra_this_rank"] == j["config"]["spectra_total"]
     assert j["sustained"]["seconds"] >= 1.0 and j["sustained"]["value"] > 0
+    assert j["concurrent"]["host_threads"] == 2 and j["concurrent"]["value"] > 0  # two scorer handles on the same GPU
+    assert set(j["roofline"]["by_kernel"]) == {"prelim", "rescore"}
+    assert j["roofline"]["kernel"] in ("prelim", "rescore")
     h2h = j["host_to_host_value"]
     assert h2h["page_locked"] > 0 and h2h["pageable"] > 0 and j["pcie_inclusive_value"] == h2h["page_locked"]
 
