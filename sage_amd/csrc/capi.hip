@@ -129,7 +129,7 @@ struct SageDeviceDb {
 // one compute stream, so a scorer needs a single set whatever the number of batches in flight.
 struct WorkSet {
     DevBuf<uint64_t> cand;
-    DevBuf<uint32_t> cand_len, totals, status, queue, retry;
+    DevBuf<uint32_t> cand_len, totals, status, queue, retry, item_of;
     DevBuf<QueryRec> qrec;
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
@@ -179,6 +179,7 @@ struct SageScorer {
     uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
     uint32_t tile_blocks8 = 0;       // ... of its u8 instance (smaller LDS footprint: more of them per CU)
     bool cnt8 = true;                // first pass of a search counts in u8 (SAGE_HIP_NO_U8=1 turns it off)
+    bool reuse_counts = true;        // the retry pass reuses the first pass's large-window counts (SAGE_HIP_NO_REUSE=1 turns it off)
     SageTiming timing{};
     bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
     uint32_t qmax = 1;
@@ -685,6 +686,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         s->tile_blocks8 = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / tile_lds8));
         if (const char* e = getenv("SAGE_HIP_TILE_BLOCKS")) s->tile_blocks = s->tile_blocks8 = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("SAGE_HIP_NO_U8")) s->cnt8 = atoi(e) == 0;
+        if (const char* e = getenv("SAGE_HIP_NO_REUSE")) s->reuse_counts = atoi(e) == 0;
         HIP_TRY((hipError_t)tile_kernel_prepare(160 * 1024));
     }
     s->qmax = queries_per_spectrum(d);
@@ -1090,6 +1092,7 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     HIP_TRY(w.status.reserve(n));
     HIP_TRY(w.queue.reserve(n));
     HIP_TRY(w.retry.reserve(n));
+    HIP_TRY(w.item_of.reserve(n));
     // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
     HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
     HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * 64));
@@ -1110,6 +1113,9 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
     w.n_deferred = o.counters.p + (size_t)pass * CTR_COUNT;
     w.queue = ws.queue.p;
     w.retry = ws.retry.p;
+    w.item_of = ws.item_of.p;
+    w.reuse = 0;
+    w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.tile_blocks = s->tile_blocks;
     w.qrec = ws.qrec.p;
     w.seeds = ws.seeds.p;
@@ -1148,6 +1154,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     if (two_pass && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
+    }
+    if (two_pass && s->reuse_counts) {  // the retry pass replays from the first pass's counts, appending to the same arena
+        w2.reuse = 1;
+        w2.arena_ptr = w1.arena_ptr;
     }
     DevScorer sc1 = sc, sc2 = sc;
     sc1.exact = mode == MODE_EXACT ? 1u : 0u;

@@ -102,6 +102,9 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* retry;       // [n] spectra whose reported ranks tie in hyperscore: re-run with exact heap layouts
     uint32_t tile_blocks;  // persistent workgroups of the large-window counting kernel
     uint32_t cnt8;         // count in u8 (first pass of a two-pass search only: overflowing spectra go to the u16 retry pass)
+    uint32_t reuse;        // retry pass: the large-window counts of the first pass are reused through item_of (kernels.hip: query_slot)
+    uint32_t* item_of;     // [n] spectrum -> its item in the first pass's queue; bit 31: count again (a u8 counter may have wrapped)
+    uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
     uint16_t* seeds;       // [n * qmax * 64] matched counts of the first min(k, potential) candidate slots

@@ -800,7 +800,9 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         if (deferred) {  // some precursor window of this spectrum is too large for the LDS counters
             if (lane == 0) {
                 w.status[spec] = ST_DEFERRED;
-                w.queue[atomicAdd(w.n_deferred + CTR_QUEUED, 1u)] = spec;
+                const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
+                w.queue[it] = spec;
+                if (!w.reuse) w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
             }
             continue;
         }
@@ -958,16 +960,15 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         const uint32_t cur = l_sh[SH_CHUNK_CUR], lim = l_sh[SH_CHUNK_LIM];
         if (l_sh[SH_ARENA_OK] && lim - cur >= need) return;
         const uint32_t chunk = need > ARENA_CHUNK ? need : ARENA_CHUNK;
-        const uint32_t got = atomicAdd(w.n_deferred + CTR_ARENA_PTR, chunk);
+        const uint32_t got = atomicAdd(w.arena_ptr, chunk);
         const bool fits = (uint64_t)got + chunk <= w.arena_cap;
         l_sh[SH_CHUNK_CUR] = fits ? got : 0;
         l_sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
         l_sh[SH_ARENA_OK] = fits ? 1u : 0u;
     };
-    if (tid == 0) {
+    if (tid == 0) {  // (the first chunk is taken by the first query that needs one: a retry pass usually has nothing to count)
         l_sh[SH_ARENA_OK] = 0;
         l_sh[SH_CHUNK_CUR] = l_sh[SH_CHUNK_LIM] = 0;
-        refill(TS + 8u);
     }
 
     for (;;) {
@@ -977,6 +978,16 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         const uint32_t item = uni(l_sh[SH_ITEM]);
         if (item >= n_queued) break;
         const uint32_t spec = uni(w.queue[item]);
+        // Retry pass of a two-pass search (DevWork::reuse): the first pass counted this spectrum already and its records —
+        // QueryRec, verbatim head, candidate directory in the arena, all of them independent of the trim mode — are still
+        // there, in the slot item_of[spec] names.  Only a spectrum whose u8 counters might have wrapped (bit 31) is counted
+        // again, in u16, into the same slot.
+        uint32_t slot = item;
+        if (w.reuse) {
+            const uint32_t v = uni(w.item_of[spec]);
+            if (!(v >> 31)) continue;
+            slot = v & 0x7FFFFFFFu;
+        }
         PhaseClock pc;
         pc.start(w0 ? w.dbg : nullptr, item, 2);
         const SpecInfo si = load_spec(sc, b, spec);
@@ -991,7 +1002,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 l_win_hi[(size_t)(fz - 1) * P + i] = hi;
             }
         }
-        if (tid < w.qmax) w.qrec[(size_t)item * w.qmax + tid].potential = 0;  // queries this spectrum does not run
+        if (tid < w.qmax) w.qrec[(size_t)slot * w.qmax + tid].potential = 0;  // queries this spectrum does not run
 
         for (uint32_t z = si.z0; z <= si.z1; z++) {
             const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
@@ -999,7 +1010,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
             const float precursor_mass = si.mzp * (float)z;
             const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
             for (int iso = isoA; iso <= isoB; iso++) {
-                const size_t qid = (size_t)item * w.qmax + query_index(sc, si, z, iso);
+                const size_t qid = (size_t)slot * w.qmax + query_index(sc, si, z, iso);
                 // ---- IndexedDatabase::query by wavefront 0, shared through LDS; the query's candidate directory ----
                 if (w0) {
                     const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
@@ -1563,13 +1574,21 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
         for (uint32_t i = 0; i < k; i++) w.qres[qid * 64 + i] = RK::unpack(hp[i * 64], rec.left, z, iso);
 }
 
+// query `qid` of the queue (item * qmax + query) -> where its records live: the same place, or — retry pass reusing the first
+// pass's counts — the slot the first pass gave the spectrum
+__device__ __forceinline__ uint64_t query_slot(const DevWork& w, uint64_t qid) {
+    if (!w.reuse) return qid;
+    const uint32_t item = (uint32_t)(qid / w.qmax), q = (uint32_t)(qid % w.qmax);
+    return (uint64_t)(w.item_of[w.queue[item]] & 0x7FFFFFFFu) * w.qmax + q;
+}
 __device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const DevWork& w, uint64_t* heap, uint64_t n_q, uint32_t blk) {
     const uint32_t lane = lane_id();
-    const uint64_t qid = (uint64_t)blk * 64 + lane;
+    const uint64_t qid_in = (uint64_t)blk * 64 + lane;
+    const uint64_t qid = qid_in < n_q ? query_slot(w, qid_in) : qid_in;
     PhaseClock pc;
     pc.start(w.dbg, blk, 3);
     QueryRec rec{};
-    if (qid < n_q) rec = w.qrec[qid];
+    if (qid_in < n_q) rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
     bool live = rec.potential > k && rec.matched != 0;  // else no k-select: the assembler takes the slots verbatim
     const uint32_t z = rec.z_iso & 0xFFu;
@@ -1640,8 +1659,9 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
 // The same replay with ONE WAVEFRONT per query (heap one element per lane, wh32_* / wh_* above): ~10x more work per
 // query than the lane-per-query kernel, but every query proceeds in parallel — the better choice while the batch has
 // fewer queries than the GPU has wavefront slots (an open search of ~10^4 spectra, or an exact retry pass).
-__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid) {
+__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in) {
     const uint32_t lane = lane_id();
+    const uint64_t qid = query_slot(w, qid_in);
     const QueryRec rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
     if (rec.potential <= k || rec.matched == 0) return;        // no k-select: the assembler takes the slots verbatim
@@ -1702,6 +1722,7 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
                                                    const uint32_t item) {
     const uint32_t lane = lane_id();
     const uint32_t spec = w.queue[item];
+    const uint32_t slot = w.reuse ? w.item_of[spec] & 0x7FFFFFFFu : item;  // (see query_slot)
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
     uint64_t* listA = (uint64_t*)smem;
@@ -1715,7 +1736,7 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     for (uint32_t z = si.z0; z <= si.z1; z++) {
         if (fold) { A.stored = 0; A.len = 0; }
         for (int iso = isoA; iso <= isoB; iso++) {
-            const size_t qid = (size_t)item * w.qmax + query_index(sc, si, z, iso);
+            const size_t qid = (size_t)slot * w.qmax + query_index(sc, si, z, iso);
             const QueryRec rec = w.qrec[qid];
             const uint32_t k = trim_k(rec.potential, sc.report_psms);
             tot_matched += rec.matched;
@@ -1748,6 +1769,7 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     wave_sync();
     if (cnt_overflow) {  // a u8 counter of the count kernel may have wrapped: the spectrum goes through the retry pass (u16 counters)
         if (lane == 0) {
+            w.item_of[spec] |= 0x80000000u;  // ... which must count it again
             w.status[spec] = ST_RETRY;
             w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
         }

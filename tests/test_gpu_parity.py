@@ -178,7 +178,15 @@ def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, u8 counter overflow path",
                              batch=sub, dev=dev)
     assert t["n_retry"] > sub.n // 2
+    # (the retry pass above counted the flagged spectra again, into the first pass's slots; now without any reuse of the first
+    # pass's counts: the retry pass counts everything itself)
+    monkeypatch.setenv("SAGE_HIP_NO_REUSE", "1")
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, overflow path, no reuse",
+                      batch=sub, dev=dev)
     monkeypatch.delenv("SAGE_HIP_DEBUG_FLAGS")
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -40.0, 40.0), min_isotope_err=-1, max_isotope_err=2, report_psms=4),
+                      "open ±40 Da x iso -1..2, no reuse", batch=sub, dev=dev)
+    monkeypatch.delenv("SAGE_HIP_NO_REUSE")
     monkeypatch.setenv("SAGE_HIP_NO_U8", "1")
     n, t2 = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, u16 counters only",
                               batch=sub, dev=dev)
