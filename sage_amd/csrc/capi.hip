@@ -1279,20 +1279,28 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         if (ovf) overflowed.push_back({pend[slot].c0, pend[slot].c1});
         return rc;
     };
+    // an error with chunks still in flight: nothing may keep writing into the caller's arrays after the call has returned
+    auto bail = [&](int rc) -> int {
+        (void)hipStreamSynchronize(s->up_stream);
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamSynchronize(s->down_stream);
+        s->outs[0].in_flight = s->outs[1].in_flight = false;
+        return rc;
+    };
     int k = 0;
     for (uint32_t c0 = r0; c0 < r1; c0 += chunk, k++) {
         const uint32_t c1 = (uint32_t)std::min<uint64_t>((uint64_t)c0 + chunk, r1);
         const int slot = k & 1;
         int rc = finish(slot);  // chunk k - 2 used this slot: its records are home, its buffers are free
-        if (rc != SAGE_HIP_OK) return rc;
+        if (rc != SAGE_HIP_OK) return bail(rc);
         SageDeviceBatch& in = s->slots[slot];
         OutSet& o = s->outs[slot];
         // (the uploads of chunk k - 2 finished long ago — its kernels ran — so the staging block may be rewritten)
         rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, probe, s->up_stream);
-        if (rc != SAGE_HIP_OK) return rc;
+        if (rc != SAGE_HIP_OK) return bail(rc);
         HIP_TRY(hipStreamWaitEvent(s->stream, in.up_done.e, 0));
         rc = enqueue_compute(s, in.view, o, true, mode, s->stream);
-        if (rc != SAGE_HIP_OK) return rc;
+        if (rc != SAGE_HIP_OK) return bail(rc);
         HIP_TRY(hipEventRecord(o.comp_done.e, s->stream));
         // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
         // download, which itself follows its kernels: no device-side guard is needed for the input buffers
@@ -1315,7 +1323,7 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
     // the working set (candidate lists, arena) is shared by both slots: kernels run in order on one stream, and a chunk's
     // records leave through its own OutSet, so the next chunk's kernels may start while they are being downloaded
     int rc = finish(k & 1);
-    if (rc != SAGE_HIP_OK) return rc;
+    if (rc != SAGE_HIP_OK) return bail(rc);
     return finish((k + 1) & 1);
 }
 

@@ -6,10 +6,15 @@
 //   rescore_kernel : Scorer::build_features / score_candidate / score_chimera_fast
 //                    (scoring.rs:478-595, 675-767, 648-672, 598-644).
 //
-// One 64-lane wavefront owns one spectrum.  Spectrum peaks and their fragment-tolerance windows live
-// in LDS, candidate counters live in LDS (u16 pairs), the window's fragments are one contiguous
-// range of the peptide-major index and are streamed with coalesced 8-byte loads.  This is sparse
-// gather/compare/accumulate work: no MFMA.  Compile with -ffp-contract=off.
+//   tile_*_kernel  : the same for precursor windows too large for one wavefront's LDS counters
+//                    (open search, wide-window / DIA): count -> select / replay -> assemble.
+//
+// One 64-lane wavefront owns one spectrum in the narrow kernels (peaks, fragment-tolerance windows and
+// u16 candidate counters in LDS; the window's fragments come either as one contiguous range of the
+// peptide-major index or as short runs of a small-tile copy found through a position table); a
+// 512-thread workgroup owns one spectrum at a time in the count kernel.  This is sparse
+// gather/compare/accumulate work: no MFMA.  Compile with -ffp-contract=off.  DESIGN.md §4 has the rationale
+// and the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -823,17 +828,18 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
 // ---- large windows (open search, wide-window / DIA, mid-size tolerances) ---------------------------
 // A window of 10^3..10^6 candidates is walked in TILES of 2^tile_shift consecutive peptides.  The index has a
 // tile-major copy (device_types.h): inside a tile the fragments are m/z-sorted and a position table turns a
-// fragment-tolerance window into a short contiguous run.  Three kernels:
-//   count    : one workgroup per spectrum.  Every (peak, fragment charge) window is looked up by an 8-lane
-//              group — 2 table reads, then the run is read 16 entries per step — and each entry inside both
-//              the m/z window and the precursor window bumps a u16 counter of the tile IN LDS (no counter
-//              traffic to HBM).  After each tile all wavefronts scan the counters in slot order and append
-//              the slots that can still enter the k-select to a candidate segment in HBM.  "Can still enter":
-//              count >= the k-th largest count of all EARLIER tiles (a histogram), which is a lower bound of
-//              the heap minimum at that point of heap.rs:21-27 — pruning with it never changes the replay.
-//   replay   : trim_hits' bounded_min_heapify (heap.rs:7-28) is inherently sequential per query, so ONE LANE
-//              replays one query (heap in LDS, first k slots verbatim, build, offers in slot order): 64
-//              queries per wavefront instead of one.
+// fragment-tolerance window into a short contiguous run.  The kernels:
+//   count    : persistent workgroups pull queued spectra.  Per tile, every (peak, fragment charge) window reads its two
+//              table words, the runs are cut into 16-byte cells (two entries) that all 512 threads share evenly, and each
+//              entry inside both the m/z window and the precursor window bumps a counter of the tile IN LDS (u8 in the
+//              first pass of a search, u16 otherwise; no counter traffic to HBM) with one returning atomic whose old value
+//              also maintains the histogram of counts and marks the slot in a bitmap once it reaches the tile's pruning
+//              threshold.  After each tile the wavefronts append the marked slots, in slot order, to the query's candidate
+//              directory in HBM.  "Pruning threshold": the k-th largest count of all EARLIER tiles, a lower bound of the
+//              heap minimum at that point of heap.rs:21-27 — pruning with it never changes the replay.
+//   select   : order-free trim_hits: the k candidates bounded_min_heapify would keep, without the heap.
+//   replay   : trim_hits' bounded_min_heapify (heap.rs:7-28) itself, sequential per query: one wavefront per query (heap one
+//              element per lane) or one lane per query (heap in LDS, 64 queries per wavefront).
 //   assemble : one wavefront per spectrum concatenates / folds the per-query lists exactly as
 //              scoring.rs:384-462 does and writes the final preliminary list.
 // Same predicate as database.rs:526-533, so counts — and everything downstream — are identical.
