@@ -354,4 +354,56 @@ SAGE_HD void score_candidate(Score& s, const float* ions, uint32_t lm1, const ui
     s.ppm_difference /= s.summed_b + s.summed_y;
 }
 
+// ---- peak-presence bitmap (rescore_kernel's filter in front of select_most_intense_peak) --------------------------------
+// PBM_BITS mass bins of width wb (a power of two, so bin() is exact).  Every peak sets the bins that overlap [mass - D,
+// mass + D], where D bounds |peak - mz| over every (mz, matching peak) pair the fragment tolerance admits below the bitmap's
+// span; an ion whose own bin is clear cannot match any peak.  Conservative by construction (never drops a match —
+// tests/test_core_emulation.py checks it against Tolerance::bounds on adversarial inputs); when that cannot be guaranteed
+// (non-finite masses, a tolerance of a quarter of the mass range and more, more than 64 bins per peak) `ok` is false and
+// every bin counts as set.
+constexpr uint32_t PBM_BITS = 8192, PBM_WORDS = PBM_BITS / 32;
+struct PeakBitmap {
+    float inv_wb;  // 1 / bin width; 0 when !ok (every mz then lands in bin 0 of an all-ones bitmap)
+    float D;
+    bool ok;
+};
+// top / first: the largest and the smallest peak mass (the peaks are mass-sorted); n_peaks == 0: top = first = 0
+SAGE_HD PeakBitmap peak_bitmap_params(float top, float first, const Tol& t) {
+    const float tmax = __builtin_fmaxf(__builtin_fabsf(t.lo), __builtin_fabsf(t.hi));
+    // Tolerance::bounds (mass.rs:21-35): a window relative to the centre (ppm, pct) or absolute (Da)
+    const bool relative = t.kind != 2;
+    const float rel = t.kind == 0 ? tmax * 1.0e-6f : t.kind == 1 ? tmax * 1.0e-2f : 0.0f;
+    bool ok = top == top && top < 1.0e30f && tmax == tmax && (relative ? rel < 0.25f : tmax < 1.0e30f) && first == first;
+    // span = PBM_BITS * wb must exceed every mz that can still reach a peak: top * (1 + 2 tol) + 1, resp. top + 2 tol + 1
+    const float reach = relative ? top * (1.0f + 2.0f * rel) + 1.0f : top + 2.0f * tmax + 1.0f;
+    float wb = 1.0f / 64.0f;
+    while (ok && (float)PBM_BITS * wb <= reach && wb < 1.0e30f) wb *= 2.0f;
+    const float span = (float)PBM_BITS * wb;
+    // D: the widest half window below `span`, a relative 1e-4 for the roundings inside Tolerance::bounds, and 8 ulp(span)
+    // for the rounding of mz / charge through a reciprocal and of mass -+ D
+    PeakBitmap r;
+    r.D = (relative ? span * rel : tmax) * 1.0001f + span * (1.0f / 1048576.0f);
+    if (r.D > 32.0f * wb) ok = false;  // (a peak would set more than 64 bins: no filter)
+    r.ok = ok;
+    r.inv_wb = ok ? 1.0f / wb : 0.0f;
+    return r;
+}
+// bins [b0, b1] a peak of mass m sets (m is not NaN)
+SAGE_HD void peak_bitmap_span(const PeakBitmap& pb, float m, uint32_t& b0, uint32_t& b1) {
+    float f0 = (m - pb.D) * pb.inv_wb, f1 = (m + pb.D) * pb.inv_wb;
+    f0 = f0 > 0.0f ? f0 : 0.0f;
+    f1 = f1 > 0.0f ? f1 : 0.0f;
+    b0 = f0 < (float)(PBM_BITS - 1) ? (uint32_t)f0 : PBM_BITS - 1;
+    b1 = f1 < (float)(PBM_BITS - 1) ? (uint32_t)f1 : PBM_BITS - 1;
+}
+// bin of an ion's m/z (an approximate ion / charge is enough: D carries the slack): clamp to [0, PBM_BITS - 1], truncate
+SAGE_HD uint32_t peak_bitmap_bin(float inv_wb, float mz) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_fmed3f(mz * inv_wb, 0.0f, (float)(PBM_BITS - 1));  // one v_med3_f32; a NaN comes out as a bound
+#else
+    const float f = mz * inv_wb;
+    return (uint32_t)(f > 0.0f ? (f < (float)(PBM_BITS - 1) ? f : (float)(PBM_BITS - 1)) : 0.0f);  // (also maps NaN to 0)
+#endif
+}
+
 }  // namespace sagecore

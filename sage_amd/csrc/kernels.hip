@@ -1868,13 +1868,8 @@ __device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, flo
     }
 }
 
-// A peak-presence bitmap over PBM_BITS mass bins (width: a power of two, so bin() is exact) filters score_candidate's lookups:
-// every peak sets the bins that overlap [mass - D, mass + D], where D bounds |peak - mz| over every (mz, matching peak) pair
-// the fragment tolerance admits below the bitmap's span.  An ion whose own bin is clear cannot match any peak, so only the
-// few ions with a set bin (true matches + ~2 % neighbours) go through Tolerance::bounds and select_most_intense_peak — with
-// exactly the reference's arithmetic.  The filter is conservative by construction (never drops a match); when that cannot
-// be guaranteed (non-finite masses, tolerances of a quarter of the mass range and more) every bin is set.
-constexpr uint32_t PBM_BITS = 8192, PBM_WORDS = PBM_BITS / 32;
+// The peak-presence bitmap that filters score_candidate's lookups (core.h: peak_bitmap_params / _span / _bin, shared with the
+// host so that the CPU suite can test that the filter never drops a match).
 #ifndef SAGE_COOP_MIN_HITS
 #define SAGE_COOP_MIN_HITS 16
 #endif
@@ -1888,39 +1883,21 @@ constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COO
 constexpr uint32_t TILE_GRID_CAP = 32768;  // blocks of the per-query / per-item kernels of the large-window path
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
     const uint32_t lane = lane_id();
-    const float top = P ? pm[P - 1] : 0.0f;
-    const float tmax = __builtin_fmaxf(__builtin_fabsf(t.lo), __builtin_fabsf(t.hi));
-    // Tolerance::bounds (mass.rs:21-35): a window relative to the centre (ppm, pct) or absolute (Da)
-    const bool relative = t.kind != 2;
-    const float rel = t.kind == 0 ? tmax * 1.0e-6f : t.kind == 1 ? tmax * 1.0e-2f : 0.0f;
-    bool ok = top == top && top < 1.0e30f && tmax == tmax && (relative ? rel < 0.25f : tmax < 1.0e30f) && (P == 0 || pm[0] == pm[0]);
-    // span = PBM_BITS * wb must exceed every mz that can still reach a peak: top * (1 + 2 tol) + 1, resp. top + 2 tol + 1
-    const float reach = relative ? top * (1.0f + 2.0f * rel) + 1.0f : top + 2.0f * tmax + 1.0f;
-    float wb = 1.0f / 64.0f;
-    while (ok && (float)PBM_BITS * wb <= reach && wb < 1.0e30f) wb *= 2.0f;
-    const float span = (float)PBM_BITS * wb;
-    // D: the widest half window below `span`, a relative 1e-4 for the roundings inside Tolerance::bounds, and 8 ulp(span)
-    // for the rounding of mz / charge through a reciprocal and of mass -+ D
-    const float D = (relative ? span * rel : tmax) * 1.0001f + span * (1.0f / 1048576.0f);
-    if (D > 32.0f * wb) ok = false;  // (a peak would set more than 64 bins: no filter)
-    inv_wb = ok ? 1.0f / wb : 0.0f;
-    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = ok ? 0u : 0xFFFFFFFFu;
+    const PeakBitmap pb = peak_bitmap_params(P ? pm[P - 1] : 0.0f, P ? pm[0] : 0.0f, t);
+    inv_wb = pb.inv_wb;
+    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = pb.ok ? 0u : 0xFFFFFFFFu;
     __syncthreads();
-    if (!ok) return;
+    if (!pb.ok) return;
     for (uint32_t i = lane; i < P; i += WAVE) {
         const float m = pm[i];
         if (!(m == m)) continue;  // (a NaN mass never satisfies `mass >= lo && mass <= hi`)
-        float f0 = (m - D) * inv_wb, f1 = (m + D) * inv_wb;
-        f0 = f0 > 0.0f ? f0 : 0.0f;
-        f1 = f1 > 0.0f ? f1 : 0.0f;
-        const uint32_t b0 = f0 < (float)(PBM_BITS - 1) ? (uint32_t)f0 : PBM_BITS - 1;
-        const uint32_t b1 = f1 < (float)(PBM_BITS - 1) ? (uint32_t)f1 : PBM_BITS - 1;
+        uint32_t b0, b1;
+        peak_bitmap_span(pb, m, b0, b1);
         for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[bin >> 5], 1u << (bin & 31u));
     }
 }
 __device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
-    // clamp to [0, PBM_BITS - 1] in one v_med3_f32 (a NaN comes out as one of the bounds), then truncate
-    const uint32_t bin = (uint32_t)__builtin_amdgcn_fmed3f(mz * inv_wb, 0.0f, (float)(PBM_BITS - 1));
+    const uint32_t bin = peak_bitmap_bin(inv_wb, mz);
     return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
 }
 

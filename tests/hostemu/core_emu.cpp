@@ -50,4 +50,40 @@ void emu_score_candidate(const float* ions, uint32_t lm1, const uint8_t* kinds, 
     out_f32[0] = s.summed_b; out_f32[1] = s.summed_y; out_f32[2] = s.ppm_difference;
 }
 
+// rescore_kernel's peak-presence filter (core.h: peak_bitmap_*) against the thing it must never contradict: for every ion and
+// fragment charge 1..3, "some peak lies inside Tolerance::bounds(ion / charge)" implies "the bit of the ion's bin is set".
+// The bin is taken from the same approximate ion / charge the kernel uses (x * 0.5f, x * (1 / 3.0f)); the window from the
+// exact quotient.  Returns the number of violations; counts matches and set bits among the items for the statistics.
+uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, float tlo, float thi, const float* ions, uint32_t m,
+                                    uint32_t* n_match, uint32_t* n_set, int* filter_active) {
+    Tol t{kind, tlo, thi};
+    const PeakBitmap pb = peak_bitmap_params(n ? masses[n - 1] : 0.0f, n ? masses[0] : 0.0f, t);
+    std::vector<uint32_t> bm(PBM_WORDS, pb.ok ? 0u : 0xFFFFFFFFu);
+    if (pb.ok)
+        for (uint32_t i = 0; i < n; i++) {
+            if (!(masses[i] == masses[i])) continue;
+            uint32_t b0, b1;
+            peak_bitmap_span(pb, masses[i], b0, b1);
+            for (uint32_t b = b0; b <= b1; b++) bm[b >> 5] |= 1u << (b & 31u);
+        }
+    *filter_active = pb.ok ? 1 : 0;
+    uint32_t bad = 0;
+    *n_match = *n_set = 0;
+    for (uint32_t j = 0; j < m; j++)
+        for (uint32_t c = 1; c <= 3; c++) {
+            const float exact = c == 1 ? ions[j] : ions[j] / (float)c;
+            const float approx = c == 1 ? ions[j] : c == 2 ? ions[j] * 0.5f : ions[j] * (1.0f / 3.0f);
+            float lo, hi;
+            tol_bounds(t, exact, lo, hi);
+            bool match = false;
+            for (uint32_t i = 0; i < n && !match; i++) match = masses[i] >= lo && masses[i] <= hi;  // spectrum.rs:147-157
+            const uint32_t bin = peak_bitmap_bin(pb.inv_wb, approx);
+            const bool set = (bm[bin >> 5] >> (bin & 31u)) & 1u;
+            *n_match += match;
+            *n_set += set;
+            bad += match && !set;
+        }
+    return bad;
+}
+
 }  // extern "C"

@@ -34,6 +34,9 @@ def emu():
     lib.emu_count_windows.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int]
     lib.emu_select_peak.restype = C.c_int
     lib.emu_select_peak.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    lib.emu_peak_bitmap_violations.restype = C.c_uint32
+    lib.emu_peak_bitmap_violations.argtypes = [f32p, C.c_uint32, C.c_int, C.c_float, C.c_float, f32p, C.c_uint32,
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     return lib
 
 
@@ -147,3 +150,55 @@ def test_select_most_intense_peak_variants(emu):
                     best, want = it[i], i
             for lock in (0, 1):
                 assert emu.emu_select_peak(fp(m), fp(it), n, np.float32(center), 0, -20.0, 20.0, lock) == want
+
+
+def test_peak_bitmap_filter_never_drops_a_match(emu):
+    """The rescoring kernel tests the bin of every (ion, fragment charge) in a peak-presence bitmap before it runs
+    Tolerance::bounds + select_most_intense_peak (core.h: peak_bitmap_*).  Conservative by construction — and here by
+    test: ions placed exactly on, one ulp inside and one ulp outside the window edges of real peaks, for ppm / pct / Da
+    tolerances from tight to absurd, symmetric or not, spectra from a handful of peaks to dense ones, ions far beyond the
+    last peak, NaNs in the masses.  A match must always find its bit; the bitmap must also still filter (few set bits
+    among non-matching ions) for the tolerances searches use."""
+    rng = np.random.default_rng(7)
+    kinds = {"ppm": 0, "pct": 1, "da": 2}
+    cases = [("ppm", -10.0, 10.0), ("ppm", -20.0, 20.0), ("ppm", -3.0, 15.0), ("ppm", -500.0, 500.0), ("ppm", 0.0, 0.0),
+             ("pct", -0.001, 0.001), ("pct", -0.05, 0.02), ("pct", -30.0, 30.0),
+             ("da", -0.02, 0.02), ("da", -0.5, 0.25), ("da", -1.5, 1.5), ("da", -40.0, 40.0), ("ppm", 10.0, -10.0)]
+    total_match = 0
+    for kind, tlo, thi in cases:
+        for n_peaks, top in ((5, 800.0), (150, 2000.0), (400, 5500.0), (150, 60.0)):
+            masses = np.sort(rng.uniform(50.0 if top > 60 else 1.0, top, n_peaks)).astype(np.float32)
+            ions = [rng.uniform(20.0, 3.2 * top, 300).astype(np.float32)]
+            # ions whose window edge sits on a peak: invert the bounds numerically, then walk a few ulps around
+            for c in (1, 2, 3):
+                for sign, tol in ((1, thi), (-1, tlo)):
+                    if kind == "da":
+                        centre = masses - np.float32(tol)
+                    else:
+                        centre = masses / np.float32(1.0 + tol * (1e-6 if kind == "ppm" else 1e-2))
+                    x = (centre.astype(np.float64) * c).astype(np.float32)
+                    for k in range(-3, 4):
+                        y = x.copy()
+                        for _ in range(abs(k)):
+                            y = np.nextafter(y, np.float32(np.inf if k > 0 else -np.inf))
+                        ions.append(y)
+            ions = np.concatenate(ions).astype(np.float32)
+            n_match, n_set, active = C.c_uint32(), C.c_uint32(), C.c_int()
+            bad = emu.emu_peak_bitmap_violations(fp(masses), len(masses), kinds[kind], tlo, thi, fp(ions), len(ions),
+                                                 C.byref(n_match), C.byref(n_set), C.byref(active))
+            assert bad == 0, (kind, tlo, thi, n_peaks, top, bad)
+            total_match += n_match.value
+            if (kind, tlo, thi) in (("ppm", -10.0, 10.0), ("ppm", -20.0, 20.0), ("da", -0.02, 0.02)) and n_peaks == 150 and top == 2000.0:
+                assert active.value == 1
+                rnd = ions[:300]  # the uniformly drawn ones: almost none of them match, few may pass the filter
+                m2, s2, a2 = C.c_uint32(), C.c_uint32(), C.c_int()
+                emu.emu_peak_bitmap_violations(fp(masses), len(masses), kinds[kind], tlo, thi, fp(rnd), len(rnd),
+                                               C.byref(m2), C.byref(s2), C.byref(a2))
+                assert s2.value < 0.12 * 3 * len(rnd), (kind, s2.value)
+    assert total_match > 5000  # the edge constructions do produce matches
+    # NaN masses / NaN tolerance: the filter switches itself off (every bit set), it never claims "no match"
+    masses = np.array([100.0, 200.0, np.nan], dtype=np.float32)
+    ions = np.array([100.0, 200.0, 300.0, 400.0], dtype=np.float32)
+    n_match, n_set, active = C.c_uint32(), C.c_uint32(), C.c_int()
+    assert emu.emu_peak_bitmap_violations(fp(masses), 3, 0, -10.0, 10.0, fp(ions), 4, C.byref(n_match), C.byref(n_set), C.byref(active)) == 0
+    assert active.value == 0 and n_set.value == 12
