@@ -354,6 +354,50 @@ SAGE_HD void score_candidate(Score& s, const float* ions, uint32_t lm1, const ui
     s.ppm_difference /= s.summed_b + s.summed_y;
 }
 
+// ---- select_most_intense_peak through a direct-index table (rescore_kernel) ------------------------------------------------
+// plut[b] = number of peaks with mass < b * W (total order).  W is a power of two, so bin(lo) = floor(lo / W) and b * W are
+// exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same peaks considered and
+// the same filtered scan as select_most_intense_peak above.
+constexpr uint32_t PLUT_BINS = 256;
+SAGE_HD float peak_lut_width(float top) {  // smallest power of two with PLUT_BINS * w > the largest mass
+    float w = 1.0f;
+    while (top == top && (float)PLUT_BINS * w <= top && w < 1.0e30f) w *= 2.0f;
+    return w;
+}
+SAGE_HD uint32_t peak_lut_entry(const float* pm, uint32_t P, uint32_t b, float w) {
+    const int32_t edge = order_key((float)b * w);
+    uint32_t lo = 0, hi = P;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (order_key(pm[mid]) < edge) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+SAGE_HD int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w, float lo, float hi) {
+    float fb = __builtin_floorf(lo * inv_w);
+    fb = fb > 0.0f ? fb : 0.0f;  // also maps NaN to 0
+    const uint32_t bin = fb < (float)(PLUT_BINS - 1) ? (uint32_t)fb : PLUT_BINS - 1;
+    // Every peak with lo <= mass <= hi lies at or after plut[bin] (all earlier masses are < bin * W <= lo), and the
+    // reference's scan over [left, right) keeps exactly those peaks (spectrum.rs:147-157: `mass >= lo && mass <= hi`,
+    // most intense wins, the last one on ties).  Walk forward two peaks at a time — their LDS reads are independent —
+    // until a mass exceeds hi (masses ascend); intensities are only read for peaks inside the window.
+    int best = -1;
+    float max_int = 0.0f;
+    for (uint32_t a = plut[bin]; a < P; a += 2) {
+        const float m0 = pm[a], m1 = pm[a + 1 < P ? a + 1 : a];
+        if (m0 >= lo && m0 <= hi) {
+            const float it = pi[a];
+            if (it >= max_int) { max_int = it; best = (int)a; }
+        }
+        if (a + 1 < P && m1 >= lo && m1 <= hi) {
+            const float it = pi[a + 1];
+            if (it >= max_int) { max_int = it; best = (int)(a + 1); }
+        }
+        if (m0 > hi || m1 > hi || !(hi == hi)) break;
+    }
+    return best;
+}
+
 // ---- peak-presence bitmap (rescore_kernel's filter in front of select_most_intense_peak) --------------------------------
 // PBM_BITS mass bins of width wb (a power of two, so bin() is exact).  Every peak sets the bins that overlap [mass - D,
 // mass + D], where D bounds |peak - mz| over every (mz, matching peak) pair the fragment tolerance admits below the bitmap's

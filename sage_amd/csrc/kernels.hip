@@ -1835,26 +1835,13 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 //      (select_most_intense_peak, spectrum.rs:134-159) -> res[item] = peak index or NONE, in LDS;
 //   B. one lane per candidate walks ITS items in order and accumulates (scoring.rs:704-754).
 
-// select_most_intense_peak (spectrum.rs:134-159) with the two partition points found through a direct-index table
-// instead of binary searches: plut[b] = number of peaks with mass < b * W.  W is a power of two, so bin(lo) = floor(lo / W)
-// and b * W are exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same
-// [left, right) and the same filtered scan as core.h's select_most_intense_peak.
-constexpr uint32_t PLUT_BINS = 256;
+// select_most_intense_peak through a direct-index table over the peak masses (core.h: peak_lut_width / peak_lut_entry /
+// select_peak_lut, shared with the host: tests/test_core_emulation.py holds it to select_most_intense_peak)
 __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, const float* pm, uint32_t P) {
     const uint32_t lane = lane_id();
-    const float top = P ? pm[P - 1] : 0.0f;
-    float w = 1.0f;  // bin width: smallest power of two with PLUT_BINS * w > largest mass
-    while (top == top && (float)PLUT_BINS * w <= top && w < 1.0e30f) w *= 2.0f;
+    const float w = peak_lut_width(P ? pm[P - 1] : 0.0f);
     inv_w = 1.0f / w;
-    for (uint32_t b = lane; b < PLUT_BINS; b += WAVE) {
-        const int32_t edge = order_key((float)b * w);
-        uint32_t lo = 0, hi = P;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (order_key(pm[mid]) < edge) lo = mid + 1; else hi = mid;
-        }
-        plut[b] = lo;
-    }
+    for (uint32_t b = lane; b < PLUT_BINS; b += WAVE) plut[b] = peak_lut_entry(pm, P, b, w);
 }
 // Tolerance::bounds (mass.rs:21-35) with one division instead of two when the tolerance is symmetric (lo == -hi):
 // center * -h == -(center * h) and x / 1e6 is sign-symmetric, so the lower delta is exactly the negated upper one.
@@ -1899,32 +1886,6 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, c
 __device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
     const uint32_t bin = peak_bitmap_bin(inv_wb, mz);
     return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
-}
-
-__device__ __forceinline__ int select_peak_lut(const float* pm, const float* pi, uint32_t P, const uint32_t* plut, float inv_w,
-                                               float lo, float hi) {
-    float fb = floorf(lo * inv_w);
-    fb = fb > 0.0f ? fb : 0.0f;  // also maps NaN to 0
-    const uint32_t bin = fb < (float)(PLUT_BINS - 1) ? (uint32_t)fb : PLUT_BINS - 1;
-    // Every peak with lo <= mass <= hi lies at or after plut[bin] (all earlier masses are < bin * W <= lo), and the
-    // reference's scan over [left, right) keeps exactly those peaks (spectrum.rs:147-157: `mass >= lo && mass <= hi`,
-    // most intense wins, the last one on ties).  Walk forward two peaks at a time — their LDS reads are independent —
-    // until a mass exceeds hi (masses ascend); intensities are only read for peaks inside the window.
-    int best = -1;
-    float max_int = 0.0f;
-    for (uint32_t a = plut[bin]; a < P; a += 2) {
-        const float m0 = pm[a], m1 = pm[a + 1 < P ? a + 1 : a];
-        if (m0 >= lo && m0 <= hi) {
-            const float it = pi[a];
-            if (it >= max_int) { max_int = it; best = (int)a; }
-        }
-        if (a + 1 < P && m1 >= lo && m1 <= hi) {
-            const float it = pi[a + 1];
-            if (it >= max_int) { max_int = it; best = (int)(a + 1); }
-        }
-        if (m0 > hi || m1 > hi || !(hi == hi)) break;
-    }
-    return best;
 }
 
 // remove_matched_peaks (scoring.rs:598-644) on the LDS copy of the spectrum: drop every peak whose (mass, intensity)

@@ -50,6 +50,17 @@ void emu_score_candidate(const float* ions, uint32_t lm1, const uint8_t* kinds, 
     out_f32[0] = s.summed_b; out_f32[1] = s.summed_y; out_f32[2] = s.ppm_difference;
 }
 
+// select_peak_lut (the rescoring kernel's table-driven lookup) next to select_most_intense_peak on the same window
+int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, float center, int kind, float tlo, float thi) {
+    Tol t{kind, tlo, thi};
+    const float w = peak_lut_width(n ? masses[n - 1] : 0.0f);
+    std::vector<uint32_t> plut(PLUT_BINS);
+    for (uint32_t b = 0; b < PLUT_BINS; b++) plut[b] = peak_lut_entry(masses, n, b, w);
+    float lo, hi;
+    tol_bounds(t, center, lo, hi);
+    return select_peak_lut(masses, intens, n, plut.data(), 1.0f / w, lo, hi);
+}
+
 // rescore_kernel's peak-presence filter (core.h: peak_bitmap_*) against the thing it must never contradict: for every ion and
 // fragment charge 1..3, "some peak lies inside Tolerance::bounds(ion / charge)" implies "the bit of the ion's bin is set".
 // The bin is taken from the same approximate ion / charge the kernel uses (x * 0.5f, x * (1 / 3.0f)); the window from the

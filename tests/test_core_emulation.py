@@ -34,6 +34,8 @@ def emu():
     lib.emu_count_windows.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int]
     lib.emu_select_peak.restype = C.c_int
     lib.emu_select_peak.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    lib.emu_select_peak_lut.restype = C.c_int
+    lib.emu_select_peak_lut.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.emu_peak_bitmap_violations.restype = C.c_uint32
     lib.emu_peak_bitmap_violations.argtypes = [f32p, C.c_uint32, C.c_int, C.c_float, C.c_float, f32p, C.c_uint32,
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
@@ -150,6 +152,31 @@ def test_select_most_intense_peak_variants(emu):
                     best, want = it[i], i
             for lock in (0, 1):
                 assert emu.emu_select_peak(fp(m), fp(it), n, np.float32(center), 0, -20.0, 20.0, lock) == want
+            # the rescoring kernel's table-driven lookup (core.h: select_peak_lut)
+            assert emu.emu_select_peak_lut(fp(m), fp(it), n, np.float32(center), 0, -20.0, 20.0) == want
+
+
+def test_select_peak_lut_equals_the_reference_scan(emu):
+    """select_peak_lut against select_most_intense_peak itself on harder inputs: wide and absolute tolerances (windows with
+    many peaks, duplicated masses, tied / zero / negative intensities), tiny and dense spectra, centres outside the mass range,
+    masses above the table's last bin edge."""
+    rng = np.random.default_rng(11)
+    kinds = {"ppm": 0, "pct": 1, "da": 2}
+    for trial in range(400):
+        n = int(rng.choice([0, 1, 2, 3, 7, 64, 150, 400]))
+        top = float(rng.choice([30.0, 255.9, 256.0, 1500.0, 6000.0]))
+        m = np.sort(rng.uniform(0.0, top, n)).astype(np.float32)
+        if n > 6:
+            m[3] = m[2]
+            m[5] = m[4]
+        it = rng.choice([-1.0, 0.0, 1.0, 2.0, 5.0, 5.0, 9.0], n).astype(np.float32)
+        kind, tlo, thi = [("ppm", -10.0, 10.0), ("ppm", -5000.0, 800.0), ("pct", -1.0, 2.0), ("da", -0.5, 0.5), ("da", -30.0, 4.0),
+                          ("da", 0.2, -0.2)][trial % 6]
+        centres = list(rng.uniform(-5.0, 1.3 * top + 5.0, 12).astype(np.float32)) + list(m[:8]) + list(m[-3:])
+        for c in centres:
+            want = emu.emu_select_peak(fp(m), fp(it), n, np.float32(c), kinds[kind], tlo, thi, 0)
+            got = emu.emu_select_peak_lut(fp(m), fp(it), n, np.float32(c), kinds[kind], tlo, thi)
+            assert got == want, (trial, n, top, kind, tlo, thi, float(c), got, want)
 
 
 def test_peak_bitmap_filter_never_drops_a_match(emu):
