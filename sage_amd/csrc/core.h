@@ -44,6 +44,19 @@ SAGE_HD void tol_bounds(const Tol& t, float center, float& out_lo, float& out_hi
     }
 }
 
+// Tolerance::bounds with one division instead of two when a ppm tolerance is symmetric (lo == -hi): center * -h == -(center * h)
+// and x / 1e6 is sign-symmetric under round-to-nearest, so the lower delta is exactly the negated upper one (the rescoring
+// kernel's per-match call; tests/test_core_emulation.py compares the bits with tol_bounds)
+SAGE_HD void tol_bounds_sym(const Tol& t, bool symmetric, float center, float& lo, float& hi) {
+    if (symmetric && t.kind == 0) {
+        const float d = center * t.hi / 1000000.0f;
+        lo = center + -d;
+        hi = center + d;
+    } else {
+        tol_bounds(t, center, lo, hi);
+    }
+}
+
 SAGE_HD Tol tol_scaled(const Tol& t, float rhs) {  // impl Mul<f32>, mass.rs:47-57
     Tol r;
     r.kind = t.kind;

@@ -1843,18 +1843,6 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
     inv_w = 1.0f / w;
     for (uint32_t b = lane; b < PLUT_BINS; b += WAVE) plut[b] = peak_lut_entry(pm, P, b, w);
 }
-// Tolerance::bounds (mass.rs:21-35) with one division instead of two when the tolerance is symmetric (lo == -hi):
-// center * -h == -(center * h) and x / 1e6 is sign-symmetric, so the lower delta is exactly the negated upper one.
-__device__ __forceinline__ void tol_bounds_sym(const Tol& t, bool symmetric, float center, float& lo, float& hi) {
-    if (symmetric && t.kind == 0) {
-        const float d = center * t.hi / 1000000.0f;
-        lo = center + -d;
-        hi = center + d;
-    } else {
-        tol_bounds(t, center, lo, hi);
-    }
-}
-
 // The peak-presence bitmap that filters score_candidate's lookups (core.h: peak_bitmap_params / _span / _bin, shared with the
 // host so that the CPU suite can test that the filter never drops a match).
 #ifndef SAGE_COOP_MIN_HITS

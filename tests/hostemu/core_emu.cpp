@@ -13,6 +13,10 @@ void emu_tol_bounds(int kind, float tlo, float thi, float center, float* lo, flo
     Tol t{kind, tlo, thi};
     tol_bounds(t, center, *lo, *hi);
 }
+void emu_tol_bounds_sym(float thi, float center, float* lo, float* hi) {  // the kernel's shortcut for ppm(-h, h)
+    Tol t{0, -thi, thi};
+    tol_bounds_sym(t, t.lo == -t.hi, center, *lo, *hi);
+}
 uint32_t emu_trim_k(uint64_t len, uint32_t report_psms) { return trim_k(len, report_psms); }
 uint32_t emu_max_fragment_charge(int user, uint32_t z) { return max_fragment_charge(user, z); }
 int32_t emu_order_key(float f) { return order_key(f); }

@@ -24,6 +24,7 @@ def emu():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", SRC, "-o", LIB])
     lib = C.CDLL(LIB)
     lib.emu_tol_bounds.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]
+    lib.emu_tol_bounds_sym.argtypes = [C.c_float, C.c_float, f32p, f32p]
     lib.emu_trim_k.restype = C.c_uint32
     lib.emu_trim_k.argtypes = [C.c_uint64, C.c_uint32]
     lib.emu_max_fragment_charge.restype = C.c_uint32
@@ -229,3 +230,19 @@ def test_peak_bitmap_filter_never_drops_a_match(emu):
     n_match, n_set, active = C.c_uint32(), C.c_uint32(), C.c_int()
     assert emu.emu_peak_bitmap_violations(fp(masses), 3, 0, -10.0, 10.0, fp(ions), 4, C.byref(n_match), C.byref(n_set), C.byref(active)) == 0
     assert active.value == 0 and n_set.value == 12
+
+
+def test_symmetric_ppm_shortcut_is_bit_identical_to_tolerance_bounds(emu):
+    """The rescoring kernel computes a symmetric ppm window with one division (core.h: tol_bounds_sym); its bits must be the
+    bits of Tolerance::bounds (mass.rs:21-35) for every centre: random ones, powers of two, values whose product with the
+    tolerance rounds, denormal products, zero, negative, infinite and NaN."""
+    rng = np.random.default_rng(3)
+    centres = np.concatenate([rng.uniform(0.0, 6000.0, 20000), 2.0 ** rng.integers(-120, 120, 500), -rng.uniform(0, 100, 200),
+                              rng.uniform(0, 1e-38, 200), [0.0, -0.0, np.inf, -np.inf, np.nan, 3.4e38, 1e-45]]).astype(np.float32)
+    lo1, hi1, lo2, hi2 = (np.zeros(1, np.float32) for _ in range(4))
+    for thi in (10.0, 20.0, 7.5, 0.0, 1e-3, 333.333, 1e6, 3e38):
+        for c in centres[:: 7 if thi not in (10.0, 20.0) else 1]:
+            emu.emu_tol_bounds(0, -thi, thi, float(c), fp(lo1), fp(hi1))
+            emu.emu_tol_bounds_sym(thi, float(c), fp(lo2), fp(hi2))
+            for a, b in ((lo1, lo2), (hi1, hi2)):
+                assert a.view(np.uint32)[0] == b.view(np.uint32)[0] or (np.isnan(a[0]) and np.isnan(b[0])), (thi, float(c))
