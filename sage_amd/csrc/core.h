@@ -367,6 +367,36 @@ SAGE_HD void score_candidate(Score& s, const float* ions, uint32_t lm1, const ui
     s.ppm_difference /= s.summed_b + s.summed_y;
 }
 
+// ---- position tables of the tile-major index copies ------------------------------------------------------------------------
+// lut[t][c] = first position of tile t whose m/z is >= c / scale; scale is a power of two, so lo * scale, hi * scale and
+// c / scale are exact and a window [lo, hi] needs NO safety margin: its entries start at cell floor(lo * scale) and end
+// before cell floor(hi * scale) + 1.  Row entry 0 is the tile's start and the last one (stride - 1) its end, whatever the
+// m/z there (NaN and m/z beyond the table stay in the last cell's run).  tests/test_core_emulation.py checks the pair
+// (lut_entry, lut_cells) against a plain scan.
+SAGE_HD void lut_cells(float lo, float hi, float scale, uint32_t stride, uint32_t& icl, uint32_t& ich) {
+    float cl = __builtin_floorf(lo * scale);
+    float ch = __builtin_floorf(hi * scale) + 1.0f;
+    cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
+    ch = ch > 0.0f ? ch : 0.0f;
+    // a window beyond the table starts at the last real cell (stride - 2), whose run also holds every entry beyond the table
+    // (a table capped below the largest m/z); it ends with the tile
+    icl = cl < (float)(stride - 2) ? (uint32_t)cl : stride - 2;
+    ich = ch < (float)(stride - 1) ? (uint32_t)ch : stride - 1;
+    if (!(lo <= hi)) icl = ich = 0;  // empty run
+}
+// entry c of the row of a tile that spans positions [begin, end) of `mz` (read with a stride of `step` floats)
+SAGE_HD uint32_t lut_entry(const float* mz, uint32_t step, uint64_t begin, uint64_t end, uint32_t c, uint32_t stride, float scale) {
+    if (c == 0) return (uint32_t)begin;
+    if (c == stride - 1) return (uint32_t)end;
+    const double edge = (double)c / (double)scale;
+    uint64_t lo = begin, hi = end;
+    while (lo < hi) {  // partition_point(m/z < edge); NaN compares false and stays at the end
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((double)mz[mid * step] < edge) lo = mid + 1; else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
 // ---- select_most_intense_peak through a direct-index table (rescore_kernel) ------------------------------------------------
 // plut[b] = number of peaks with mass < b * W (total order).  W is a power of two, so bin(lo) = floor(lo / W) and b * W are
 // exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same peaks considered and

@@ -108,15 +108,8 @@ __global__ __launch_bounds__(256) void lut_kernel(uint32_t n_tiles, uint32_t lut
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (uint64_t)n_tiles * lut_stride) return;
     const uint32_t t = (uint32_t)(gid / lut_stride), c = (uint32_t)(gid - (uint64_t)t * lut_stride);
-    uint64_t lo = tile_off[t], hi = tile_off[t + 1];
-    if (c == 0) { lut[gid] = (uint32_t)lo; return; }
-    if (c == lut_stride - 1) { lut[gid] = (uint32_t)hi; return; }
-    const double edge = (double)c / (double)lut_scale;
-    while (lo < hi) {  // partition_point(m/z < edge); NaN compares false and stays at the end
-        const uint64_t mid = (lo + hi) >> 1;
-        if ((double)tm[mid].fragment_mz < edge) lo = mid + 1; else hi = mid;
-    }
-    lut[gid] = (uint32_t)lo;
+    static_assert(sizeof(SageTheoretical) == 8, "m/z is every second float of the entry array");
+    lut[gid] = sagecore::lut_entry(&tm[0].fragment_mz, 2, tile_off[t], tile_off[t + 1], c, lut_stride, lut_scale);
 }
 
 __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheoretical* __restrict__ pm, uint32_t* __restrict__ out) {

@@ -646,7 +646,6 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                     // entries each) shared evenly by the 64 lanes, each lane's cells in flight together: one round trip for
                     // the table, one for the entries, no lane waiting on another lane's long run.
                     const uint4* __restrict__ frag2 = (const uint4*)db.tm2_frag;
-                    const float cell_max = (float)(db.lut2_stride - 1);
                     const uint32_t t0 = q.first >> db.tile2_shift, t1 = (q.end - 1) >> db.tile2_shift;
                     const uint32_t nprobe = P * nfz;
                     uint32_t* const tp0 = L.ptab;                      // [PROBE_BATCH] first entry of the run
@@ -669,13 +668,8 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
                                 float flo, fhi;
                                 window_of(pbase + i * WAVE + lane, flo, fhi);
-                                // lut_scale is a power of two: lo*scale and hi*scale are exact, no safety margin needed
-                                float cl = floorf(flo * db.lut2_scale), ch = floorf(fhi * db.lut2_scale) + 1.0f;
-                                cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
-                                ch = ch > 0.0f ? ch : 0.0f;
-                                uint32_t icl = cl < cell_max ? (uint32_t)cl : db.lut2_stride - 1;
-                                uint32_t ich = ch < cell_max ? (uint32_t)ch : db.lut2_stride - 1;
-                                if (!(flo <= fhi)) icl = ich = 0;
+                                uint32_t icl, ich;  // (core.h: the scale is a power of two, no safety margin needed)
+                                lut_cells(flo, fhi, db.lut2_scale, db.lut2_stride, icl, ich);
                                 rp0[i] = lut[icl];
                                 rp1[i] = lut[ich];
                             }
@@ -954,7 +948,6 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     const uint32_t idle_mask = (TS / SPW < TILE_THREADS ? TS / SPW : TILE_THREADS) - 1u;  // (word a thread without a hit adds 0 to)
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
     const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
-    const float cell_max = (float)(db.lut_stride - 1);
     const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
 
     for (uint32_t i = tid; i < TS / SPW; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: every scan clears them
@@ -1057,13 +1050,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                 };
                 auto probe_cells = [&](float lo, float hi, uint32_t& icl, uint32_t& ich) {
-                    float cl = floorf(lo * db.lut_scale);
-                    float ch = floorf(hi * db.lut_scale) + 1.0f;
-                    cl = cl > 0.0f ? cl : 0.0f;  // also maps NaN to 0
-                    ch = ch > 0.0f ? ch : 0.0f;
-                    icl = cl < cell_max ? (uint32_t)cl : db.lut_stride - 1;
-                    ich = ch < cell_max ? (uint32_t)ch : db.lut_stride - 1;
-                    if (!(lo <= hi)) icl = ich = 0;  // empty run
+                    lut_cells(lo, hi, db.lut_scale, db.lut_stride, icl, ich);
                 };
                 pc.mark(0);
                 const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it

@@ -54,6 +54,26 @@ void emu_score_candidate(const float* ions, uint32_t lm1, const uint8_t* kinds, 
     out_f32[0] = s.summed_b; out_f32[1] = s.summed_y; out_f32[2] = s.ppm_difference;
 }
 
+// position table of one tile (core.h: lut_entry) and the runs m windows [lo, hi] read through it (lut_cells): returns the number
+// of entries with lo <= m/z <= hi that their run [row[icl], row[ich]) MISSES (must be 0), and the runs' total length
+uint64_t emu_lut_windows(const float* mz, uint32_t n, float scale, uint32_t stride, const float* lo, const float* hi, uint32_t m,
+                         uint64_t* run_len) {
+    std::vector<uint32_t> row(stride);
+    for (uint32_t c = 0; c < stride; c++) row[c] = lut_entry(mz, 1, 0, n, c, stride, scale);
+    uint64_t missed = 0;
+    *run_len = 0;
+    for (uint32_t w = 0; w < m; w++) {
+        uint32_t icl, ich;
+        lut_cells(lo[w], hi[w], scale, stride, icl, ich);
+        const uint32_t p0 = row[icl], p1 = row[ich];
+        *run_len += p1 > p0 ? p1 - p0 : 0;
+        // entries inside the window: mz is sorted up to its NaN-free prefix, so a scan between two binary-search bounds suffices
+        for (uint32_t i = 0; i < n; i++)
+            if (mz[i] >= lo[w] && mz[i] <= hi[w] && !(i >= p0 && i < p1)) missed++;
+    }
+    return missed;
+}
+
 // select_peak_lut (the rescoring kernel's table-driven lookup) next to select_most_intense_peak on the same window
 int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, float center, int kind, float tlo, float thi) {
     Tol t{kind, tlo, thi};

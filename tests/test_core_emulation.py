@@ -35,6 +35,8 @@ def emu():
     lib.emu_count_windows.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int]
     lib.emu_select_peak.restype = C.c_int
     lib.emu_select_peak.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    lib.emu_lut_windows.restype = C.c_uint64
+    lib.emu_lut_windows.argtypes = [f32p, C.c_uint32, C.c_float, C.c_uint32, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.emu_select_peak_lut.restype = C.c_int
     lib.emu_select_peak_lut.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.emu_peak_bitmap_violations.restype = C.c_uint32
@@ -246,3 +248,42 @@ def test_symmetric_ppm_shortcut_is_bit_identical_to_tolerance_bounds(emu):
             emu.emu_tol_bounds_sym(thi, float(c), fp(lo2), fp(hi2))
             for a, b in ((lo1, lo2), (hi1, hi2)):
                 assert a.view(np.uint32)[0] == b.view(np.uint32)[0] or (np.isnan(a[0]) and np.isnan(b[0])), (thi, float(c))
+
+
+def test_position_table_windows_need_no_safety_margin(emu):
+    """The tile-major index copies are read through position tables with a power-of-two number of cells per Da
+    (core.h: lut_entry builds a row, lut_cells maps a fragment-tolerance window to two cells) and the kernels add NO margin:
+    every entry with lo <= m/z <= hi must lie inside [row[cell(lo)], row[cell(hi) + 1]).  Windows with edges exactly on cell
+    boundaries and on entries, one ulp either side, below the table, beyond its last cell, empty and NaN windows; m/z values
+    exactly on cell edges, duplicates, entries beyond the table (they stay in the last cell's run)."""
+    rng = np.random.default_rng(5)
+    for scale, top in ((256.0, 40.0), (32.0, 300.0), (256.0, 7.99), (32.0, 2000.0)):
+        stride = int(np.ceil(top * scale)) + 3  # capi.hip / index_build.hip: ceil(max m/z * scale) + 3 cells
+        n = 3000
+        mz = rng.uniform(0.0, top, n).astype(np.float32)
+        mz[:200] = (rng.integers(0, int(top * scale), 200) / scale).astype(np.float32)  # exactly on cell edges
+        mz[200:260] = mz[260:320]                                                       # duplicates
+        mz[-3:] = [top * 1.5, top * 40.0, np.float32(3.0e38)]                           # beyond the table
+        mz = np.sort(mz)
+        run = C.c_uint64()
+        los = np.concatenate([rng.uniform(-1.0, top * 1.2, 150), mz[rng.integers(0, n, 100)],
+                              rng.integers(0, int(top * scale), 100) / scale]).astype(np.float32)
+        wl, wh = [], []
+        for width in (0.0, 1e-4, 0.01, 0.3, 5.0):
+            for dl in (-1, 0, 1):
+                for dh in (-1, 0, 1):
+                    a = los.copy()
+                    b = (los + np.float32(width)).astype(np.float32)
+                    if dl:
+                        a = np.nextafter(a, np.float32(np.inf * dl))
+                    if dh:
+                        b = np.nextafter(b, np.float32(np.inf * dh))
+                    wl.append(a)
+                    wh.append(b)
+        wl, wh = np.concatenate(wl).astype(np.float32), np.concatenate(wh).astype(np.float32)
+        assert emu.emu_lut_windows(fp(mz), n, scale, stride, fp(wl), fp(wh), len(wl), C.byref(run)) == 0, (scale, top)
+        assert run.value > 0
+        # degenerate windows read nothing or stay in range
+        dl = np.array([5.0, np.nan, 1.0, -10.0, top * 100.0, top * 1.4], dtype=np.float32)
+        dh = np.array([4.0, 1.0, np.nan, -5.0, top * 200.0, np.inf], dtype=np.float32)
+        assert emu.emu_lut_windows(fp(mz), n, scale, stride, fp(dl), fp(dh), len(dl), C.byref(run)) == 0
