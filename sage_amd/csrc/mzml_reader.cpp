@@ -137,14 +137,16 @@ float parse_f32(std::string_view v) {  // str::parse::<f32>(): one correct round
 }
 
 void base64_decode(std::string_view in, std::vector<uint8_t>& out) {
-    static int8_t lut[256];
-    static bool init = false;
-    if (!init) {
-        std::memset(lut, -1, sizeof lut);
-        const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-        for (int i = 0; i < 64; ++i) lut[(unsigned char)al[i]] = (int8_t)i;
-        init = true;
-    }
+    struct Table {
+        int8_t v[256];
+        Table() {
+            std::memset(v, -1, sizeof v);
+            const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+            for (int i = 0; i < 64; ++i) v[(unsigned char)al[i]] = (int8_t)i;
+        }
+    };
+    static const Table table;  // (initialised once, thread-safely: the spectra of a file are decoded in parallel)
+    const int8_t* lut = table.v;
     out.clear();
     out.reserve(in.size() * 3 / 4);
     uint32_t acc = 0;
@@ -180,6 +182,193 @@ bool inflate_all(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
     inflateEnd(&zs);
     out.resize(have);
     return rc == Z_STREAM_END;
+}
+
+// One <spectrum> ... </spectrum> block.  `t` is its opening tag, p the position behind it; on return p is behind the closing
+// tag.  false: malformed (err says why; `unterminated`: the input ended inside the block).
+struct SpectrumOut {
+    std::string id;
+    std::vector<float> mz, inten;
+    float scan_start = 0.0f, prec_mz = 0.0f, prec_ims = NAN, iso_lo = NAN, iso_hi = NAN;
+    uint8_t prec_charge = 0;
+    bool have_precursor = false, have_lo = false, have_hi = false, centroid = false, keep = false;
+    int level = 0;
+};
+bool parse_spectrum(Tag t, const char*& p, const char* e, int ms_level, SpectrumOut& o, std::string& err, bool& unterminated) {
+    std::vector<uint8_t> raw, plain;
+    unterminated = false;
+    std::string_view idv;
+    std::string id = attr(t.attrs, "id", idv) ? unescape(idv) : std::string();
+    bool have_level = false, tic_zero = false, have_precursor = false, in_precursor = false, in_scan = false, in_bda = false;
+    bool centroid = false;  // Representation::default() is Profile (spectrum.rs:119-124); MS:1000127 / MS:1000128 set it
+    int level = 0, depth = 1;
+    std::vector<float> mz, inten;
+    float scan_start = 0.0f, prec_mz = 0.0f, prec_ims = NAN, iso_lo = NAN, iso_hi = NAN;
+    uint8_t prec_charge = 0;
+    float p_mz = 0.0f, p_lo = NAN, p_hi = NAN;  // the precursor being read
+    bool p_has_lo = false, p_has_hi = false, have_lo = false, have_hi = false;
+    uint8_t p_z = 0;
+    int precursor_depth = 0, scan_depth = 0, bda_depth = 0;
+    bool bda_f32 = false, bda_zlib = false;
+    int bda_kind = 0;  // 1 m/z, 2 intensity
+    std::string_view bda_text;
+    bool closed = t.self_closing;
+    while (!closed && next_tag(p, e, t)) {
+        if (t.closing) {
+            if (t.name == "spectrum") {
+                closed = true;
+                break;
+            }
+            if (in_precursor && t.name == "precursor" && depth == precursor_depth) {
+                in_precursor = false;
+                if (p_mz != 0.0f) {  // :353
+                    have_precursor = true;
+                    prec_mz = p_mz;
+                    prec_charge = p_z;
+                    iso_lo = p_lo;
+                    iso_hi = p_hi;
+                    have_lo = p_has_lo;
+                    have_hi = p_has_hi;
+                }
+            } else if (in_scan && t.name == "scan" && depth == scan_depth) {
+                in_scan = false;
+            } else if (in_bda && t.name == "binaryDataArray" && depth == bda_depth) {
+                in_bda = false;
+                if (!bda_text.empty() && bda_kind) {
+                    base64_decode(bda_text, raw);
+                    const std::vector<uint8_t>* bytes = &raw;
+                    if (bda_zlib) {
+                        if (!inflate_all(raw, plain)) {
+                            err = "malformed mzML: zlib stream of spectrum " + id;
+                            return false;
+                        }
+                        bytes = &plain;
+                    }
+                    std::vector<float>& dst = bda_kind == 1 ? mz : inten;
+                    if (bda_f32) {
+                        dst.resize(bytes->size() / 4);
+                        std::memcpy(dst.data(), bytes->data(), dst.size() * 4);
+                    } else {
+                        dst.resize(bytes->size() / 8);
+                        for (size_t i = 0; i < dst.size(); ++i) {
+                            double d;
+                            std::memcpy(&d, bytes->data() + 8 * i, 8);
+                            dst[i] = (float)d;
+                        }
+                    }
+                }
+            }
+            --depth;
+            continue;
+        }
+        // opening (or empty) tag at `depth` + 1
+        const int child_depth = depth + 1;
+        if (t.name == "cvParam") {
+            std::string_view acc, val, unit;
+            if (attr(t.attrs, "accession", acc)) {
+                const bool has_val = attr(t.attrs, "value", val);
+                if (!has_val) val = std::string_view();
+                if (in_precursor) {  // every cvParam below <precursor>
+                    if (acc == "MS:1000827") {
+                        if (p_mz == 0.0f) p_mz = parse_f32(val);
+                    } else if (acc == "MS:1000828") {
+                        p_lo = parse_f32(val);
+                        p_has_lo = true;
+                    } else if (acc == "MS:1000829") {
+                        p_hi = parse_f32(val);
+                        p_has_hi = true;
+                    } else if (acc == "MS:1000041") {
+                        p_z = (uint8_t)std::atoi(std::string(val).c_str());
+                    } else if (acc == "MS:1000744") {
+                        const float v = parse_f32(val);
+                        if (v != 0.0f) p_mz = v;
+                    } else if (acc == "MS:1002815") {
+                        prec_ims = parse_f32(val);
+                    }
+                } else if (in_scan && child_depth == scan_depth + 1) {
+                    if (acc == "MS:1000016") {
+                        float v = parse_f32(val);
+                        if (attr(t.attrs, "unitAccession", unit) && unit == "UO:0000010") v = v / 60.0f;
+                        else if (!(unit == "UO:0000031")) {
+                            err = "malformed mzML: scan start time unit of spectrum " + id;
+                            return false;
+                        }
+                        scan_start = v;
+                    } else if (acc == "MS:1002815") {
+                        prec_ims = parse_f32(val);
+                    }
+                } else if (in_bda && child_depth == bda_depth + 1) {
+                    if (acc == "MS:1000514") bda_kind = 1;
+                    else if (acc == "MS:1000515" && bda_kind != 1) bda_kind = 2;
+                    else if (acc == "MS:1000574") bda_zlib = true;
+                    else if (acc == "MS:1000521") bda_f32 = true;
+                } else if (child_depth == 2) {  // direct children of <spectrum>
+                    if (acc == "MS:1000511") {
+                        level = std::atoi(std::string(val).c_str());
+                        have_level = true;
+                    } else if (acc == "MS:1000285") {
+                        tic_zero = parse_f32(val) == 0.0f;
+                    } else if (acc == "MS:1000127") {
+                        centroid = true;
+                    } else if (acc == "MS:1000128") {
+                        centroid = false;
+                    }
+                }
+            }
+        } else if (t.name == "scan" && !in_scan && !in_precursor) {
+            if (!t.self_closing) {
+                in_scan = true;
+                scan_depth = child_depth;
+            }
+        } else if (t.name == "precursor" && !in_precursor && !have_precursor) {
+            if (!t.self_closing) {
+                in_precursor = true;
+                precursor_depth = child_depth;
+                p_mz = 0.0f;
+                p_z = 0;
+                p_lo = p_hi = NAN;
+                p_has_lo = p_has_hi = false;
+            }
+        } else if (t.name == "binaryDataArray" && !in_bda) {
+            if (!t.self_closing) {
+                in_bda = true;
+                bda_depth = child_depth;
+                bda_f32 = bda_zlib = false;
+                bda_kind = 0;
+                bda_text = std::string_view();
+            }
+        } else if (t.name == "binary" && in_bda && child_depth == bda_depth + 1 && !t.self_closing) {
+            const char* lt = (const char*)std::memchr(t.end, '<', (size_t)(e - t.end));
+            if (!lt) {
+                err = "malformed mzML: unterminated <binary>";
+                return false;
+            }
+            bda_text = std::string_view(t.end, (size_t)(lt - t.end));
+        }
+        if (!t.self_closing) ++depth;
+    }
+    if (!closed) {
+        err = "malformed mzML: unterminated <spectrum>";
+        unterminated = true;
+        return false;
+    }
+    o.keep = !(tic_zero || (ms_level >= 0 && (!have_level || level != ms_level)));
+    o.id.swap(id);
+    inten.resize(mz.size(), 0.0f);  // (a spectrum with arrays of different lengths is malformed; keep the peak table rectangular)
+    o.mz.swap(mz);
+    o.inten.swap(inten);
+    o.scan_start = scan_start;
+    o.prec_mz = prec_mz;
+    o.prec_ims = prec_ims;
+    o.iso_lo = iso_lo;
+    o.iso_hi = iso_hi;
+    o.prec_charge = prec_charge;
+    o.have_precursor = have_precursor;
+    o.have_lo = have_lo;
+    o.have_hi = have_hi;
+    o.centroid = centroid;
+    o.level = level;
+    return true;
 }
 
 }  // namespace
@@ -246,186 +435,84 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
     run = MzmlRun{};
     run.peak_off.push_back(0);
     run.id_off.push_back(0);
+    // Pass 1, sequential and cheap (a tag scan; base64 text is skipped by memchr): where the top-level <spectrum> blocks are.
+    // Pass 2, parallel: every block is decoded on its own (base64, zlib, number parsing — the expensive part) by the same state
+    // machine.  Pass 3: the spectra that pass the level / TIC filters are appended in file order.  Errors are reported in file
+    // order too: the first malformed block wins, as in a sequential read.
     const char *p = text.data(), *e = text.data() + text.size();
-    Tag t;
-    std::vector<uint8_t> raw, plain;
-    while (next_tag(p, e, t)) {
-        if (t.closing || t.name != "spectrum") continue;
-        // ---- one <spectrum> ... </spectrum> block ----
-        std::string_view idv;
-        std::string id = attr(t.attrs, "id", idv) ? unescape(idv) : std::string();
-        bool have_level = false, tic_zero = false, have_precursor = false, in_precursor = false, in_scan = false, in_bda = false;
-        bool centroid = false;  // Representation::default() is Profile (spectrum.rs:119-124); MS:1000127 / MS:1000128 set it
-        int level = 0, depth = 1;
-        std::vector<float> mz, inten;
-        float scan_start = 0.0f, prec_mz = 0.0f, prec_ims = NAN, iso_lo = NAN, iso_hi = NAN;
-        uint8_t prec_charge = 0;
-        float p_mz = 0.0f, p_lo = NAN, p_hi = NAN;  // the precursor being read
-        bool p_has_lo = false, p_has_hi = false, have_lo = false, have_hi = false;
-        uint8_t p_z = 0;
-        int precursor_depth = 0, scan_depth = 0, bda_depth = 0;
-        bool bda_f32 = false, bda_zlib = false;
-        int bda_kind = 0;  // 1 m/z, 2 intensity
-        std::string_view bda_text;
-        bool closed = t.self_closing;
-        while (!closed && next_tag(p, e, t)) {
-            if (t.closing) {
-                if (t.name == "spectrum") {
-                    closed = true;
-                    break;
-                }
-                if (in_precursor && t.name == "precursor" && depth == precursor_depth) {
-                    in_precursor = false;
-                    if (p_mz != 0.0f) {  // :353
-                        have_precursor = true;
-                        prec_mz = p_mz;
-                        prec_charge = p_z;
-                        iso_lo = p_lo;
-                        iso_hi = p_hi;
-                        have_lo = p_has_lo;
-                        have_hi = p_has_hi;
-                    }
-                } else if (in_scan && t.name == "scan" && depth == scan_depth) {
-                    in_scan = false;
-                } else if (in_bda && t.name == "binaryDataArray" && depth == bda_depth) {
-                    in_bda = false;
-                    if (!bda_text.empty() && bda_kind) {
-                        base64_decode(bda_text, raw);
-                        const std::vector<uint8_t>* bytes = &raw;
-                        if (bda_zlib) {
-                            if (!inflate_all(raw, plain)) {
-                                err = "malformed mzML: zlib stream of spectrum " + id;
-                                return false;
-                            }
-                            bytes = &plain;
-                        }
-                        std::vector<float>& dst = bda_kind == 1 ? mz : inten;
-                        if (bda_f32) {
-                            dst.resize(bytes->size() / 4);
-                            std::memcpy(dst.data(), bytes->data(), dst.size() * 4);
-                        } else {
-                            dst.resize(bytes->size() / 8);
-                            for (size_t i = 0; i < dst.size(); ++i) {
-                                double d;
-                                std::memcpy(&d, bytes->data() + 8 * i, 8);
-                                dst[i] = (float)d;
-                            }
-                        }
-                    }
-                }
-                --depth;
-                continue;
+    struct Span {
+        const char* begin;  // at or before the '<' of the opening tag
+        const char* end;    // behind the closing tag (or the end of the input)
+    };
+    std::vector<Span> spans;
+    bool input_ends_in_block = false;
+    {
+        Tag t;
+        for (;;) {
+            const char* before = p;
+            if (!next_tag(p, e, t)) break;
+            if (t.closing || t.name != "spectrum") continue;
+            bool closed = t.self_closing;
+            while (!closed && next_tag(p, e, t)) closed = t.closing && t.name == "spectrum";
+            spans.push_back(Span{before, closed ? p : e});
+            if (!closed) {
+                input_ends_in_block = true;
+                break;
             }
-            // opening (or empty) tag at `depth` + 1
-            const int child_depth = depth + 1;
-            if (t.name == "cvParam") {
-                std::string_view acc, val, unit;
-                if (attr(t.attrs, "accession", acc)) {
-                    const bool has_val = attr(t.attrs, "value", val);
-                    if (!has_val) val = std::string_view();
-                    if (in_precursor) {  // every cvParam below <precursor>
-                        if (acc == "MS:1000827") {
-                            if (p_mz == 0.0f) p_mz = parse_f32(val);
-                        } else if (acc == "MS:1000828") {
-                            p_lo = parse_f32(val);
-                            p_has_lo = true;
-                        } else if (acc == "MS:1000829") {
-                            p_hi = parse_f32(val);
-                            p_has_hi = true;
-                        } else if (acc == "MS:1000041") {
-                            p_z = (uint8_t)std::atoi(std::string(val).c_str());
-                        } else if (acc == "MS:1000744") {
-                            const float v = parse_f32(val);
-                            if (v != 0.0f) p_mz = v;
-                        } else if (acc == "MS:1002815") {
-                            prec_ims = parse_f32(val);
-                        }
-                    } else if (in_scan && child_depth == scan_depth + 1) {
-                        if (acc == "MS:1000016") {
-                            float v = parse_f32(val);
-                            if (attr(t.attrs, "unitAccession", unit) && unit == "UO:0000010") v = v / 60.0f;
-                            else if (!(unit == "UO:0000031")) {
-                                err = "malformed mzML: scan start time unit of spectrum " + id;
-                                return false;
-                            }
-                            scan_start = v;
-                        } else if (acc == "MS:1002815") {
-                            prec_ims = parse_f32(val);
-                        }
-                    } else if (in_bda && child_depth == bda_depth + 1) {
-                        if (acc == "MS:1000514") bda_kind = 1;
-                        else if (acc == "MS:1000515" && bda_kind != 1) bda_kind = 2;
-                        else if (acc == "MS:1000574") bda_zlib = true;
-                        else if (acc == "MS:1000521") bda_f32 = true;
-                    } else if (child_depth == 2) {  // direct children of <spectrum>
-                        if (acc == "MS:1000511") {
-                            level = std::atoi(std::string(val).c_str());
-                            have_level = true;
-                        } else if (acc == "MS:1000285") {
-                            tic_zero = parse_f32(val) == 0.0f;
-                        } else if (acc == "MS:1000127") {
-                            centroid = true;
-                        } else if (acc == "MS:1000128") {
-                            centroid = false;
-                        }
-                    }
-                }
-            } else if (t.name == "scan" && !in_scan && !in_precursor) {
-                if (!t.self_closing) {
-                    in_scan = true;
-                    scan_depth = child_depth;
-                }
-            } else if (t.name == "precursor" && !in_precursor && !have_precursor) {
-                if (!t.self_closing) {
-                    in_precursor = true;
-                    precursor_depth = child_depth;
-                    p_mz = 0.0f;
-                    p_z = 0;
-                    p_lo = p_hi = NAN;
-                    p_has_lo = p_has_hi = false;
-                }
-            } else if (t.name == "binaryDataArray" && !in_bda) {
-                if (!t.self_closing) {
-                    in_bda = true;
-                    bda_depth = child_depth;
-                    bda_f32 = bda_zlib = false;
-                    bda_kind = 0;
-                    bda_text = std::string_view();
-                }
-            } else if (t.name == "binary" && in_bda && child_depth == bda_depth + 1 && !t.self_closing) {
-                const char* lt = (const char*)std::memchr(t.end, '<', (size_t)(e - t.end));
-                if (!lt) {
-                    err = "malformed mzML: unterminated <binary>";
-                    return false;
-                }
-                bda_text = std::string_view(t.end, (size_t)(lt - t.end));
-            }
-            if (!t.self_closing) ++depth;
         }
-        if (!closed) {
-            err = "malformed mzML: unterminated <spectrum>";
+    }
+    std::vector<SpectrumOut> outs(spans.size());
+    std::vector<std::string> errs(spans.size());
+    std::vector<uint8_t> failed(spans.size(), 0);
+    parallel_for(spans.size(), 64, [&](size_t b, size_t e2, unsigned) {
+        for (size_t i = b; i < e2; i++) {
+            const char* q = spans[i].begin;
+            Tag t;
+            bool unterminated = false;
+            if (!next_tag(q, spans[i].end, t) || !parse_spectrum(t, q, spans[i].end, ms_level, outs[i], errs[i], unterminated)) {
+                failed[i] = 1;
+                if (errs[i].empty()) errs[i] = "malformed mzML: unterminated <spectrum>";
+            }
+        }
+    });
+    for (size_t i = 0; i < spans.size(); i++)
+        if (failed[i]) {
+            err = errs[i];
             return false;
         }
-        if (tic_zero || (ms_level >= 0 && (!have_level || level != ms_level))) continue;
-        run.mz.insert(run.mz.end(), mz.begin(), mz.end());
-        // (a spectrum with arrays of different lengths is malformed; keep the peak table rectangular)
-        inten.resize(mz.size(), 0.0f);
-        run.intensities.insert(run.intensities.end(), inten.begin(), inten.end());
+    (void)input_ends_in_block;  // (its block failed above with "unterminated <spectrum>")
+    size_t n_peaks = 0, n_keep = 0, id_bytes = 0;
+    for (const SpectrumOut& o : outs)
+        if (o.keep) {
+            n_peaks += o.mz.size();
+            n_keep++;
+            id_bytes += o.id.size() + 1;
+        }
+    run.mz.reserve(n_peaks);
+    run.intensities.reserve(n_peaks);
+    run.peak_off.reserve(n_keep + 1);
+    run.ids.reserve(id_bytes);
+    for (SpectrumOut& o : outs) {
+        if (!o.keep) continue;
+        run.mz.insert(run.mz.end(), o.mz.begin(), o.mz.end());
+        run.intensities.insert(run.intensities.end(), o.inten.begin(), o.inten.end());
         run.peak_off.push_back(run.mz.size());
-        run.precursor_mz.push_back(prec_mz);
-        run.precursor_charge.push_back(prec_charge);
-        const bool iso = have_precursor && have_lo && have_hi;
-        run.isolation_lo.push_back(iso ? -iso_lo : NAN);
-        run.isolation_hi.push_back(iso ? iso_hi : NAN);
-        run.scan_start_time.push_back(scan_start);
-        run.inverse_ion_mobility.push_back(prec_ims);
+        run.precursor_mz.push_back(o.prec_mz);
+        run.precursor_charge.push_back(o.prec_charge);
+        const bool iso = o.have_precursor && o.have_lo && o.have_hi;
+        run.isolation_lo.push_back(iso ? -o.iso_lo : NAN);
+        run.isolation_hi.push_back(iso ? o.iso_hi : NAN);
+        run.scan_start_time.push_back(o.scan_start);
+        run.inverse_ion_mobility.push_back(o.prec_ims);
         run.file_id.push_back(file_id);
-        run.centroid.push_back(centroid ? 1 : 0);
-        run.has_precursor.push_back(have_precursor ? 1 : 0);
-        run.ms_level.push_back((uint8_t)std::min(std::max(level, 0), 255));
-        run.ids += id;
+        run.centroid.push_back(o.centroid ? 1 : 0);
+        run.has_precursor.push_back(o.have_precursor ? 1 : 0);
+        run.ms_level.push_back((uint8_t)std::min(std::max(o.level, 0), 255));
+        run.ids += o.id;
         run.ids += '\0';
         run.id_off.push_back(run.ids.size());
+        std::vector<float>().swap(o.mz);  // (give the memory back as we go)
+        std::vector<float>().swap(o.inten);
     }
     return true;
 }

@@ -385,6 +385,57 @@ def test_native_mzml_reader_matches_the_python_reader(tmp_path):
         read_mzml_native(str(tmp_path / "missing.mzML"))
 
 
+def test_native_mzml_reader_decodes_in_parallel_with_sequential_semantics(tmp_path, monkeypatch):
+    """The reader finds the <spectrum> blocks in one cheap sequential pass and decodes them on all host threads
+    (mzml_reader.cpp).  The result must not depend on the thread count, spectra stay in file order, and a malformed file
+    reports what a sequential read would have reported: the FIRST bad block, even when a later one is broken too."""
+    import base64
+    import zlib
+    from sage_amd.mzml import read_mzml_native
+    host = DatabaseParameters(static_mods={"C": 57.0215}).build(synthetic_fasta(40, seed=83))
+    spectra = synthetic_spectra(host, 700, seed=84)
+    p = str(tmp_path / "many.mzML")
+    write_mzml(p, spectra)
+    runs = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("SAGE_HIP_THREADS", threads)
+        runs.append(read_mzml_native(p, 0, 2))
+    _assert_same_run(runs[0], read_mzml(p, 0, 2), "700 spectra, one thread")
+    for r in runs[1:]:
+        assert r.ids == runs[0].ids
+        for name in ("peak_off", "mz", "intensities", "precursor_mz", "precursor_charge", "scan_start_time"):
+            assert np.array_equal(getattr(r, name), getattr(runs[0], name), equal_nan=True), name
+    # corrupt the zlib stream of block 300's second array and cut the file inside the last block
+    text = open(p).read()
+    blocks = text.split("<spectrum ")
+    assert len(blocks) > 600
+    victim = blocks[300]
+    b0 = victim.index("<binary>", victim.index("<binary>") + 1) + len("<binary>")
+    b1 = victim.index("</binary>", b0)
+    payload = base64.b64decode(victim[b0:b1])
+    if "MS:1000574" in victim:  # zlib-compressed arrays: flip bytes in the middle of the stream
+        bad = bytearray(payload)
+        for k in range(len(bad) // 3, len(bad) // 3 + 6):
+            bad[k] ^= 0xFF
+        blocks[300] = victim[:b0] + base64.b64encode(bytes(bad)).decode() + victim[b1:]
+        broken = "<spectrum ".join(blocks)
+        broken = broken[:broken.rindex("</spectrum>") - 40]
+        pb = str(tmp_path / "broken.mzML")
+        open(pb, "w").write(broken)
+        sid = victim[victim.index('id="') + 4:victim.index('"', victim.index('id="') + 4)]
+        for threads in ("1", "8"):
+            monkeypatch.setenv("SAGE_HIP_THREADS", threads)
+            with pytest.raises(Exception) as ei:
+                read_mzml_native(pb, 0, 2)
+            assert "zlib" in str(ei.value) and sid in str(ei.value), str(ei.value)
+    cut = text[:text.rindex("</spectrum>") - 40]
+    pc = str(tmp_path / "cut.mzML")
+    open(pc, "w").write(cut)
+    with pytest.raises(Exception) as ei:
+        read_mzml_native(pc, 0, 2)
+    assert "unterminated" in str(ei.value)
+
+
 # ---- inputs at the edge of the boundary: gzip, unsearchable spectra, device lists --------------------------------------------
 def test_gzip_inputs_and_device_lists(tmp_path):
     import gzip
