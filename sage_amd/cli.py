@@ -229,10 +229,27 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
     n_searched = 0
     search_ms = 0.0
-    for file_id, path in enumerate(mzml_paths):
+    # The reader works one file ahead of the search (the reference reads and preprocesses its files in parallel batches,
+    # runner.rs:450-461): file k + 1 is parsed on the host threads (csrc/mzml_reader.cpp decodes the spectra of a file in
+    # parallel, outside the GIL) while the devices score file k.
+    from concurrent.futures import ThreadPoolExecutor
+
+    def read_file(file_id, path):
         t0 = time.time()
-        raw = read_mzml_native(path, file_id=file_id, ms_level=2, check_searchable=True)  # csrc/mzml_reader.cpp
-        log(f"- file IO: {int((time.time() - t0) * 1000):8d} ms")
+        raw = read_mzml_native(path, file_id=file_id, ms_level=2, check_searchable=True)
+        return raw, (time.time() - t0) * 1000.0
+
+    mzml_paths = list(mzml_paths)
+    reader = ThreadPoolExecutor(max_workers=1)
+    ahead = reader.submit(read_file, 0, mzml_paths[0]) if mzml_paths else None
+    for file_id, path in enumerate(mzml_paths):
+        try:
+            raw, io_ms = ahead.result()
+        except BaseException:
+            reader.shutdown(wait=True)
+            raise
+        ahead = reader.submit(read_file, file_id + 1, mzml_paths[file_id + 1]) if file_id + 1 < len(mzml_paths) else None
+        log(f"- file IO: {int(io_ms):8d} ms")
         if raw.n == 0:
             continue
         t0 = time.time()
@@ -259,6 +276,7 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                 slot = i * params.report_psms + r
                 frags.append(output.fragment_rows(psm_id + j, int(off[slot]), int(off[slot + 1]), arr))
         psm_id += len(part)
+    reader.shutdown(wait=True)
     # runner.rs:536-541: spectrum_fdr (LDA or heuristic, sort, q-values), picked_peptide, picked_protein — on the device.
     # (protein grouping is outside this path: its columns keep the defaults, see output.py)
     flat = np.concatenate(feats_all) if feats_all else np.zeros(0, dtype=L_FEATURE_DTYPE)
