@@ -33,6 +33,7 @@ struct Tag {
     std::string_view name;     // local name
     std::string_view attrs;    // raw attribute text
     bool closing = false, self_closing = false;
+    const char* lt = nullptr;  // the tag's '<'
     const char* end = nullptr; // one past '>'
 };
 
@@ -54,6 +55,7 @@ bool next_tag(const char*& p, const char* e, Tag& t) {
             continue;
         }
         const char* q = lt + 1;
+        t.lt = lt;
         t.closing = q < e && *q == '/';
         if (t.closing) ++q;
         const char* n0 = q;
@@ -444,22 +446,55 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
         const char* begin;  // at or before the '<' of the opening tag
         const char* end;    // behind the closing tag (or the end of the input)
     };
-    std::vector<Span> spans;
-    bool input_ends_in_block = false;
-    {
+    // top-level <spectrum> blocks from `from` on, until the input ends or — `limit` set — a top-level tag at or behind `limit`
+    // shows up; returns that tag's '<' (nullptr: the input ended)
+    auto scan_blocks = [&](const char* from, const char* limit, std::vector<Span>& out) -> const char* {
+        const char* q = from;
         Tag t;
         for (;;) {
-            const char* before = p;
-            if (!next_tag(p, e, t)) break;
+            const char* before = q;
+            if (!next_tag(q, e, t)) return nullptr;
+            if (limit && t.lt >= limit) return t.lt;
             if (t.closing || t.name != "spectrum") continue;
             bool closed = t.self_closing;
-            while (!closed && next_tag(p, e, t)) closed = t.closing && t.name == "spectrum";
-            spans.push_back(Span{before, closed ? p : e});
-            if (!closed) {
-                input_ends_in_block = true;
-                break;
-            }
+            while (!closed && next_tag(q, e, t)) closed = t.closing && t.name == "spectrum";
+            out.push_back(Span{before, closed ? q : e});
+            if (!closed) return nullptr;
         }
+    };
+    std::vector<Span> spans;
+    // Large inputs: the scan itself in parallel.  The text is cut at occurrences of the literal `<spectrum ` near equal
+    // distances; a piece is scanned from its cut to the next one.  That is the sequential scan exactly if every cut is a
+    // top-level position — checked, not assumed: the scanner of piece k must arrive at cut k + 1 as its next top-level tag
+    // (it would have run past it inside a block, a comment or a CDATA section otherwise), else the sequential scan runs.
+    bool scanned = false;
+    const size_t piece = (size_t)4 << 20;
+    if (text.size() >= 4 * piece && host_threads() > 1) {
+        std::vector<const char*> cuts{p};
+        for (size_t at = piece; at < text.size(); at += piece) {
+            const char* c = (const char*)memmem(text.data() + at, text.size() - at, "<spectrum ", 10);
+            if (!c) break;
+            if (c > cuts.back()) cuts.push_back(c);
+            at = std::max(at, (size_t)(c - text.data()));
+        }
+        std::vector<std::vector<Span>> found(cuts.size());
+        std::vector<uint8_t> consistent(cuts.size(), 1);
+        parallel_for(cuts.size(), 1, [&](size_t b, size_t e2, unsigned) {
+            for (size_t k = b; k < e2; k++) {
+                const char* limit = k + 1 < cuts.size() ? cuts[k + 1] : nullptr;
+                const char* stop = scan_blocks(cuts[k], limit, found[k]);
+                // (a piece that runs into the end of the input before its successor's cut swallowed that cut)
+                if (limit && stop != limit) consistent[k] = 0;
+            }
+        });
+        scanned = true;
+        for (uint8_t c : consistent) scanned = scanned && c;
+        if (scanned)
+            for (auto& f : found) spans.insert(spans.end(), f.begin(), f.end());
+    }
+    if (!scanned) {
+        spans.clear();
+        (void)scan_blocks(p, nullptr, spans);
     }
     std::vector<SpectrumOut> outs(spans.size());
     std::vector<std::string> errs(spans.size());
@@ -480,39 +515,57 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
             err = errs[i];
             return false;
         }
-    (void)input_ends_in_block;  // (its block failed above with "unterminated <spectrum>")
-    size_t n_peaks = 0, n_keep = 0, id_bytes = 0;
-    for (const SpectrumOut& o : outs)
-        if (o.keep) {
-            n_peaks += o.mz.size();
-            n_keep++;
-            id_bytes += o.id.size() + 1;
+    // pass 3: offsets of the kept spectra (sequential, cheap), then the peak arrays are copied into place in parallel
+    std::vector<size_t> kept;
+    kept.reserve(outs.size());
+    size_t n_peaks = 0, id_bytes = 0;
+    for (size_t i = 0; i < outs.size(); i++)
+        if (outs[i].keep) {
+            kept.push_back(i);
+            run.peak_off.push_back(n_peaks += outs[i].mz.size());
+            id_bytes += outs[i].id.size() + 1;
         }
-    run.mz.reserve(n_peaks);
-    run.intensities.reserve(n_peaks);
-    run.peak_off.reserve(n_keep + 1);
+    const size_t n_keep = kept.size();
+    run.mz.resize(n_peaks);
+    run.intensities.resize(n_peaks);
+    run.precursor_mz.resize(n_keep);
+    run.precursor_charge.resize(n_keep);
+    run.isolation_lo.resize(n_keep);
+    run.isolation_hi.resize(n_keep);
+    run.scan_start_time.resize(n_keep);
+    run.inverse_ion_mobility.resize(n_keep);
+    run.file_id.assign(n_keep, file_id);
+    run.centroid.resize(n_keep);
+    run.has_precursor.resize(n_keep);
+    run.ms_level.resize(n_keep);
+    parallel_for(n_keep, 256, [&](size_t b, size_t e2, unsigned) {
+        for (size_t j = b; j < e2; j++) {
+            SpectrumOut& o = outs[kept[j]];
+            const size_t at = run.peak_off[j];
+            if (!o.mz.empty()) {
+                std::memcpy(run.mz.data() + at, o.mz.data(), o.mz.size() * sizeof(float));
+                std::memcpy(run.intensities.data() + at, o.inten.data(), o.inten.size() * sizeof(float));
+            }
+            run.precursor_mz[j] = o.prec_mz;
+            run.precursor_charge[j] = o.prec_charge;
+            const bool iso = o.have_precursor && o.have_lo && o.have_hi;
+            run.isolation_lo[j] = iso ? -o.iso_lo : NAN;
+            run.isolation_hi[j] = iso ? o.iso_hi : NAN;
+            run.scan_start_time[j] = o.scan_start;
+            run.inverse_ion_mobility[j] = o.prec_ims;
+            run.centroid[j] = o.centroid ? 1 : 0;
+            run.has_precursor[j] = o.have_precursor ? 1 : 0;
+            run.ms_level[j] = (uint8_t)std::min(std::max(o.level, 0), 255);
+            std::vector<float>().swap(o.mz);
+            std::vector<float>().swap(o.inten);
+        }
+    });
     run.ids.reserve(id_bytes);
-    for (SpectrumOut& o : outs) {
-        if (!o.keep) continue;
-        run.mz.insert(run.mz.end(), o.mz.begin(), o.mz.end());
-        run.intensities.insert(run.intensities.end(), o.inten.begin(), o.inten.end());
-        run.peak_off.push_back(run.mz.size());
-        run.precursor_mz.push_back(o.prec_mz);
-        run.precursor_charge.push_back(o.prec_charge);
-        const bool iso = o.have_precursor && o.have_lo && o.have_hi;
-        run.isolation_lo.push_back(iso ? -o.iso_lo : NAN);
-        run.isolation_hi.push_back(iso ? o.iso_hi : NAN);
-        run.scan_start_time.push_back(o.scan_start);
-        run.inverse_ion_mobility.push_back(o.prec_ims);
-        run.file_id.push_back(file_id);
-        run.centroid.push_back(o.centroid ? 1 : 0);
-        run.has_precursor.push_back(o.have_precursor ? 1 : 0);
-        run.ms_level.push_back((uint8_t)std::min(std::max(o.level, 0), 255));
-        run.ids += o.id;
+    run.id_off.reserve(n_keep + 1);
+    for (size_t j = 0; j < n_keep; j++) {
+        run.ids += outs[kept[j]].id;
         run.ids += '\0';
         run.id_off.push_back(run.ids.size());
-        std::vector<float>().swap(o.mz);  // (give the memory back as we go)
-        std::vector<float>().swap(o.inten);
     }
     return true;
 }
