@@ -468,7 +468,8 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
     // top-level position — checked, not assumed: the scanner of piece k must arrive at cut k + 1 as its next top-level tag
     // (it would have run past it inside a block, a comment or a CDATA section otherwise), else the sequential scan runs.
     bool scanned = false;
-    const size_t piece = (size_t)4 << 20;
+    size_t piece = (size_t)4 << 20;
+    if (const char* v = std::getenv("SAGE_HIP_MZML_PIECE_KB")) piece = (size_t)std::max(1, std::atoi(v)) << 10;  // (tests)
     if (text.size() >= 4 * piece && host_threads() > 1) {
         std::vector<const char*> cuts{p};
         for (size_t at = piece; at < text.size(); at += piece) {

@@ -405,6 +405,21 @@ def test_native_mzml_reader_decodes_in_parallel_with_sequential_semantics(tmp_pa
         assert r.ids == runs[0].ids
         for name in ("peak_off", "mz", "intensities", "precursor_mz", "precursor_charge", "scan_start_time"):
             assert np.array_equal(getattr(r, name), getattr(runs[0], name), equal_nan=True), name
+    # the block scan itself runs in parallel on large files: force it with small pieces, and make it fall back — a comment that
+    # holds the text `<spectrum ` right where a cut would land must send the reader down the sequential scan
+    monkeypatch.setenv("SAGE_HIP_THREADS", "4")
+    monkeypatch.setenv("SAGE_HIP_MZML_PIECE_KB", "64")
+    r = read_mzml_native(p, 0, 2)
+    assert r.ids == runs[0].ids and np.array_equal(r.mz, runs[0].mz) and np.array_equal(r.peak_off, runs[0].peak_off)
+    text0 = open(p).read()
+    marks = [m for m in range(len(text0)) if text0.startswith("<spectrum ", m)]
+    at = marks[len(marks) // 2]
+    tricky = text0[:at] + "<!-- " + "x" * 70000 + " <spectrum id='not one'> " + "y" * 70000 + " -->" + text0[at:]
+    pt = str(tmp_path / "tricky.mzML")
+    open(pt, "w").write(tricky)
+    r = read_mzml_native(pt, 0, 2)
+    assert r.ids == runs[0].ids and np.array_equal(r.mz, runs[0].mz) and np.array_equal(r.intensities, runs[0].intensities)
+    monkeypatch.delenv("SAGE_HIP_MZML_PIECE_KB")
     # corrupt the zlib stream of block 300's second array and cut the file inside the last block
     text = open(p).read()
     blocks = text.split("<spectrum ")
