@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,18 @@ unsigned host_threads() {
     return n ? n : 1;
 }
 
+// SAGE_HIP_TIMING=1: wall time of the stages of the host-side database build on stderr
+struct StageTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const bool on = std::getenv("SAGE_HIP_TIMING") != nullptr;
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[host_db] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // dynamic-chunk parallel loop over [0, n): f(begin, end, thread_index)
 void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t, unsigned)>& f) {
     const unsigned nt = (unsigned)std::min<size_t>(host_threads(), (n + grain - 1) / std::max<size_t>(grain, 1));
@@ -48,6 +61,52 @@ void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_
 }
 
 namespace {
+
+// Stable sort on the host threads: equal pieces are sorted independently, then merged pairwise, level by level (the merges of
+// a level run in parallel).  Same result as std::stable_sort — pieces and merges both keep the order of equal elements.
+template <typename T, typename Less>
+void parallel_stable_sort(std::vector<T>& v, Less less) {
+    const size_t n = v.size();
+    unsigned pieces = 1;
+    while (pieces < host_threads() && n / (pieces * 2) >= 65536) pieces *= 2;
+    if (pieces == 1) {
+        std::stable_sort(v.begin(), v.end(), less);
+        return;
+    }
+    std::vector<size_t> cut(pieces + 1);
+    for (unsigned i = 0; i <= pieces; i++) cut[i] = n * i / pieces;
+    parallel_for(pieces, 1, [&](size_t b, size_t e, unsigned) {
+        for (size_t i = b; i < e; i++) std::stable_sort(v.begin() + cut[i], v.begin() + cut[i + 1], less);
+    });
+    std::vector<T> tmp(n);
+    std::vector<T>* src = &v;
+    std::vector<T>* dst = &tmp;
+    for (unsigned width = 1; width < pieces; width *= 2) {
+        const unsigned pairs = pieces / (2 * width);
+        parallel_for(pairs, 1, [&](size_t b, size_t e, unsigned) {
+            for (size_t k = b; k < e; k++) {
+                const size_t lo = cut[2 * width * k], mid = cut[2 * width * k + width], hi = cut[2 * width * (k + 1)];
+                std::merge(std::make_move_iterator(src->begin() + lo), std::make_move_iterator(src->begin() + mid),
+                           std::make_move_iterator(src->begin() + mid), std::make_move_iterator(src->begin() + hi),
+                           dst->begin() + lo, less);  // (std::merge takes from the first range on ties: stable)
+            }
+        });
+        std::swap(src, dst);
+    }
+    if (src != &v) v.swap(tmp);
+}
+
+// destroys the elements of a vector of heap-owning objects on the host threads (millions of small frees)
+template <typename T>
+void parallel_clear(std::vector<T>& v) {
+    parallel_for(v.size(), 16384, [&](size_t b, size_t e, unsigned) {
+        for (size_t i = b; i < e; i++) {
+            T gone = std::move(v[i]);
+            (void)gone;
+        }
+    });
+    std::vector<T>().swap(v);
+}
 
 constexpr float kH2O = 18.010565f;     // mass.rs:5
 constexpr float kProton = 1.0072764f;  // mass.rs:6
@@ -497,10 +556,12 @@ void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cf
 // file by default, one chunk of Fasta::iter_chunks (fasta.rs:81-89) for the prefilter flow
 HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, uint64_t first_target, uint64_t n_targets) {
     HostDb db;
+    StageTimer timer;
     init_database(db, cfg);
 
     std::vector<std::string> prot_seqs;
     parse_fasta(fasta_text, cfg.decoy_tag, cfg.generate_decoys, db.protein_names, prot_seqs);
+    timer.lap("parse_fasta");
     if (first_target || n_targets < prot_seqs.size()) {
         const size_t lo = std::min<size_t>(first_target, prot_seqs.size());
         const size_t hi = std::min<size_t>(prot_seqs.size(), lo + std::min<uint64_t>(n_targets, prot_seqs.size()));
@@ -510,10 +571,11 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, u
 
     // 1. digest every protein (fasta.rs:58-79), proteins in parallel
     std::vector<Cut> cuts = digest_fasta(db, prot_seqs, cfg);
+    timer.lap("digest");
     auto cut_seq = [&](const Cut& c) { return std::string_view(prot_seqs[c.protein].data() + c.start, c.len); };
 
     // 2. group_digests (enzyme.rs:33-62): by (position, decoy, sequence)
-    std::stable_sort(cuts.begin(), cuts.end(), [&](const Cut& a, const Cut& b) {
+    parallel_stable_sort(cuts, [&](const Cut& a, const Cut& b) {
         if (a.pos != b.pos) return a.pos < b.pos;
         if (a.decoy != b.decoy) return a.decoy < b.decoy;
         return cut_seq(a) < cut_seq(b);
@@ -526,12 +588,15 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, u
     }
     group_start.push_back(cuts.size());
     const size_t n_groups = group_start.size() - 1;
+    timer.lap("group_digests (sort)");
 
     // target sequences, for dropping decoys that collide with a target (database.rs:184-190, 212)
     std::unordered_set<std::string_view> target_seqs;
+    target_seqs.reserve(n_groups);
     for (size_t g = 0; g < n_groups; g++)
         if (!cuts[group_start[g]].decoy) target_seqs.insert(cut_seq(cuts[group_start[g]]));
 
+    timer.lap("target sequence set");
     // 3. modify + decoys (database.rs:193-214), groups in parallel
     const unsigned nthreads = host_threads();
     std::vector<std::vector<Pep>> per_thread(nthreads);
@@ -593,7 +658,9 @@ HostDb build_database(const std::string& fasta_text, const DbBuildConfig& cfg, u
         }
     }
 
+    timer.lap("modify + decoys");
     finish_database(db, peps, cfg);
+    timer.lap("finish_database");
     return db;
 }
 
@@ -601,17 +668,19 @@ namespace {
 
 // reorder_peptides (database.rs:221-258) then Parameters::build_from_peptides (database.rs:265-346) into the flat layout
 void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cfg) {
+    StageTimer timer;
     // 4. reorder_peptides (database.rs:221-258): sort, dedup, merge proteins.  The comparator is a
     // total order on the dedup key, so the result does not depend on the (thread-dependent) input order
     // except for which duplicate's missed_cleavages/position survives; keep that deterministic by
     // preferring the smallest (missed, position, first protein) among duplicates.
-    std::stable_sort(peps.begin(), peps.end(), [](const Pep& a, const Pep& b) {
+    parallel_stable_sort(peps, [](const Pep& a, const Pep& b) {
         if (pep_before(a, b)) return true;
         if (pep_before(b, a)) return false;
         if (a.missed != b.missed) return a.missed < b.missed;
         if (a.pos != b.pos) return a.pos < b.pos;
         return a.proteins < b.proteins;
     });
+    timer.lap("  reorder: sort");
     std::vector<Pep> uniq;
     uniq.reserve(peps.size());
     for (Pep& p : peps) {
@@ -626,7 +695,8 @@ void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cf
         }
         uniq.push_back(std::move(p));
     }
-    std::vector<Pep>().swap(peps);
+    parallel_clear(peps);
+    timer.lap("  reorder: dedup");
     const size_t np = uniq.size();
     if (np >= 0xFFFFFFFFull) throw std::runtime_error("too many peptides for a u32 PeptideIx");
 
@@ -671,7 +741,9 @@ void finish_database(HostDb& db, std::vector<Pep>& peps, const DbBuildConfig& cf
         std::copy(p.proteins.begin(), p.proteins.end(), db.pep_protein_ids.begin() + db.pep_protein_off[i]);
       }
     });
-    std::vector<Pep>().swap(uniq);
+    timer.lap("  flatten");
+    parallel_clear(uniq);
+    timer.lap("  free");
     if (cfg.peptides_only) return;  // the device builds the fragment index (index_build.hip)
 
     // 6. theoretical fragments (database.rs:272-297)
