@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAGE_HIP_ABI_VERSION 4
+#define SAGE_HIP_ABI_VERSION 5
 
 enum {
     SAGE_HIP_OK = 0,
@@ -36,7 +36,8 @@ enum {
     SAGE_HIP_ERR_NO_DEVICE = 2,   /* no usable HIP device */
     SAGE_HIP_ERR_HIP = 3,         /* a HIP runtime call failed */
     SAGE_HIP_ERR_UNSUPPORTED = 4, /* valid in the reference, outside this build's device limits */
-    SAGE_HIP_ERR_OOM = 5
+    SAGE_HIP_ERR_OOM = 5,
+    SAGE_HIP_ERR_INTERNAL = 6     /* an invariant of the library itself did not hold (a bug: report it) */
 };
 
 /* mass.rs:10-16  enum Tolerance { Ppm(f32,f32), Pct(f32,f32), Da(f32,f32) } */
@@ -295,7 +296,9 @@ typedef struct SageTiming {
     uint32_t n_launches;
     uint32_t n_wide;   /* spectra routed to the tiled large-window kernels */
     uint32_t arena_entries; /* 4-byte entries of the large-window candidate arena this call used */
-    uint32_t n_retry;  /* spectra with equal hyperscores at a reported rank, re-run with exact heap layouts */
+    uint32_t n_retry;  /* spectra with equal hyperscores at a reported rank, re-run with exact heap layouts (the retry pass) */
+    float retry_ms;    /* of total_ms: that retry pass */
+    uint32_t n_tied;   /* SAGE_HIP_FUSED=1 only: narrow spectra with such a tie, settled inside the fused first-pass kernel */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 

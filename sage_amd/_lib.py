@@ -146,6 +146,8 @@ class SageTiming(C.Structure):
         ("n_wide", C.c_uint32),
         ("arena_entries", C.c_uint32),
         ("n_retry", C.c_uint32),
+        ("retry_ms", C.c_float),
+        ("n_tied", C.c_uint32),
     ]
 
 

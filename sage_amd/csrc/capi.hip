@@ -129,7 +129,8 @@ struct SageDeviceDb {
 // one compute stream, so a scorer needs a single set whatever the number of batches in flight.
 struct WorkSet {
     DevBuf<uint64_t> cand;
-    DevBuf<uint32_t> cand_len, totals, status, queue, retry, item_of;
+    DevBuf<uint32_t> cand_len, totals, status, queue, retry, item_of, ready;
+    uint32_t epoch = 0;  // of the last search_kernel launch (DevWork::epoch)
     DevBuf<QueryRec> qrec;
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
@@ -148,6 +149,8 @@ struct OutSet {
     Event ev[5];                     // start, prelim 1, rescore 1, prelim 2, rescore 2
     Event comp_done, down_done;
     bool in_flight = false, two_pass = false, with_rescore = false;
+    bool fused = false;          // the narrow spectra were scored by the fused kernel (ev[0] -> ev[1])
+    bool wide_launched = true;   // the large-window kernels ran behind it (else: the batch was expected to hold narrow windows only)
     uint32_t n = 0;
     ~OutSet() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -162,6 +165,9 @@ struct SageDeviceBatch {
     DevBuf<uint8_t> charge;
     DevBuf<uint32_t> file_id, order, sort_a, sort_b, sort_idx;
     DevBuf<uint8_t> sort_tmp;
+    bool maybe_wide = true;  // some precursor window may exceed the narrow kernel's LDS counters (estimated at upload; a wrong
+                             // "no" is noticed after the step — the queue counter — and the step is repeated with the
+                             // large-window kernels)
     Pinned stage;      // host staging of the arrays above (everything but the peaks when those are already page-locked)
     Event up_done;     // uploads of this batch finished (its staging block may be refilled)
     DevBatchView view{};
@@ -182,6 +188,12 @@ struct SageScorer {
     bool reuse_counts = true;        // the retry pass reuses the first pass's large-window counts (SAGE_HIP_NO_REUSE=1 turns it off)
     SageTiming timing{};
     bool exact_always = false;  // SAGE_HIP_EXACT=1: never use the order-free trims
+    bool one_launch = false;    // SAGE_HIP_ONE_LAUNCH=1: the first pass of narrow windows as one launch of two kinds of workgroups
+                                // (kernels.hip: search_kernel) instead of prelim_kernel, then rescore_kernel — measured slower, like
+                                // the fused kernel: the larger kernel body costs scalar-register spills
+    bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
+                                // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
+    bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
     uint32_t qmax = 1;
     WorkSet ws;
     OutSet outs[2];
@@ -649,7 +661,13 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     d.dbg_flags = 0;
     if (const char* e = getenv("SAGE_HIP_DEBUG_FLAGS")) d.dbg_flags = (uint32_t)atoi(e);
     d.exact = 0;
+    d.xcd_chunk = 1024;
+    if (const char* e = getenv("SAGE_HIP_XCD_CHUNK")) d.xcd_chunk = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("SAGE_HIP_SCHED_DESC")) d.xcd_chunk |= atoi(e) ? 0x80000000u : 0u;
     if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
+    if (const char* e = getenv("SAGE_HIP_FUSED")) s->fused = atoi(e) != 0;
+    if (const char* e = getenv("SAGE_HIP_ONE_LAUNCH")) s->one_launch = atoi(e) != 0;
+    if (const char* e = getenv("SAGE_HIP_NO_ZEROCOPY")) s->zero_copy = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
     if (const char* e = getenv("SAGE_HIP_CHUNK")) s->chunk = (uint32_t)std::min(1 << 22, std::max(64, atoi(e)));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -743,6 +761,16 @@ void sage_hip_scorer_destroy(SageScorer* s) {
 }
 
 // ---- batches ---------------------------------------------------------------------------------------------------------------
+// the device-side address of page-locked, mapped host memory (sage_hip_host_alloc / hipHostMalloc); null for anything else
+static void* device_view(const void* p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
 static bool is_page_locked(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t at;
@@ -753,34 +781,49 @@ static bool is_page_locked(const void* p) {
     return at.type == hipMemoryTypeHost;
 }
 
-// narrow-kernel variant for a batch: mean candidate-window size of (a sample of) its spectra, first query each
-static uint32_t choose_probe(const SageScorer* s, uint32_t n, const float* precursor_mz, const uint8_t* precursor_charge,
-                             const float* isolation_lo, const float* isolation_hi) {
+// What a batch looks like to the narrow kernel, from (a sample of) its spectra: the mean candidate-window size picks the
+// matching variant, the largest one says whether the large-window kernels have to be launched at all.
+struct WindowEstimate {
+    uint32_t probe;       // narrow kernel variant (DevBatchView::probe)
+    bool maybe_wide;      // some window may exceed DevScorer::wcap (a sample cannot rule it out: callers re-run on a wrong "no")
+};
+static WindowEstimate choose_probe(const SageScorer* s, uint32_t n, const float* precursor_mz, const uint8_t* precursor_charge,
+                                   const float* isolation_lo, const float* isolation_hi) {
     const SageScorerParams& p = s->params;
     const std::vector<float>& pm = s->db->h_pep_mono;
-    const uint32_t step = std::max<uint32_t>(1, n / 2048);
+    const uint32_t step = std::max<uint32_t>(1, n / 4096);
     double sum = 0.0;
+    uint64_t widest = 0;
     uint32_t cnt = 0;
     for (uint32_t i = 0; i < n; i += step, cnt++) {
-        const uint32_t z = precursor_charge[i] ? precursor_charge[i] : p.min_precursor_charge;
-        const float center = (precursor_mz[i] - sagecore::PROTON) * (float)z;
-        sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
-        if (p.wide_window) {
-            float lo = -2.4f, hi = 2.4f;
-            if (isolation_lo && isolation_hi && isolation_lo[i] == isolation_lo[i] && isolation_hi[i] == isolation_hi[i]) {
-                lo = isolation_lo[i];
-                hi = isolation_hi[i];
+        const bool ranged = p.wide_window || precursor_charge[i] == 0 || p.override_precursor_charge;  // scoring.rs:423, 437, 442
+        const uint32_t z0 = ranged ? p.min_precursor_charge : precursor_charge[i], z1 = ranged ? p.max_precursor_charge : precursor_charge[i];
+        for (uint32_t z = z0; z <= z1; z++) {
+            const float center = (precursor_mz[i] - sagecore::PROTON) * (float)z;
+            sagecore::Tol tol{p.precursor_tol.kind, p.precursor_tol.lo, p.precursor_tol.hi};
+            if (p.wide_window) {
+                float lo = -2.4f, hi = 2.4f;
+                if (isolation_lo && isolation_hi && isolation_lo[i] == isolation_lo[i] && isolation_hi[i] == isolation_hi[i]) {
+                    lo = isolation_lo[i];
+                    hi = isolation_hi[i];
+                }
+                tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
             }
-            tol = sagecore::Tol{2, lo * (float)z, hi * (float)z};
+            float lo, hi;
+            sagecore::tol_bounds(tol, center, lo, hi);
+            const uint64_t wdw = (uint64_t)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
+            if (z == z0) sum += (double)wdw;
+            widest = std::max(widest, wdw);
         }
-        float lo, hi;
-        sagecore::tol_bounds(tol, center, lo, hi);
-        sum += (double)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
     }
     const double mean_window = cnt ? sum / cnt : 0.0;
-    uint32_t probe = mean_window > 96.0 ? 1u : 0u;
-    if (const char* e = getenv("SAGE_HIP_NARROW")) probe = std::string(e) == "probe" ? 1u : std::string(e) == "stream" ? 0u : probe;
-    return probe;
+    WindowEstimate e;
+    e.probe = mean_window > 96.0 ? 1u : 0u;
+    if (const char* v = getenv("SAGE_HIP_NARROW")) e.probe = std::string(v) == "probe" ? 1u : std::string(v) == "stream" ? 0u : e.probe;
+    // (a quarter of headroom between the widest sampled window and the capacity: isotope errors shift the centre, the sample is thin)
+    e.maybe_wide = widest + widest / 4 + 2 > s->dev.wcap;
+    if (const char* v = getenv("SAGE_HIP_ASSUME_NARROW")) e.maybe_wide = atoi(v) == 0;  // (tests: force the wrong guess and its repair)
+    return e;
 }
 
 // largest fragment charge any spectrum of a batch can ask for (scoring.rs:239-247)
@@ -802,7 +845,9 @@ static uint32_t batch_fzcap(const SageScorerParams& p, uint32_t zmax, bool any_u
 //     the staging block (copied by a few host threads).
 // The caller must have waited for d->up_done before (the staging block is being rewritten).  `probe`: narrow-kernel variant.
 static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectrumBatch* b, uint32_t c0, uint32_t c1, bool peaks_locked,
-                            uint32_t probe, hipStream_t up) {
+                            const WindowEstimate& est, hipStream_t up) {
+    const uint32_t probe = est.probe;
+    d->maybe_wide = est.maybe_wide;
     const uint32_t n = c1 - c0;
     const uint64_t base = n ? b->peak_off[c0] : 0, total = n ? b->peak_off[c1] - base : 0;
     if (n && b->peak_off[c1] < base) return fail(SAGE_HIP_ERR_INVALID, "peak_off is not monotone");
@@ -939,8 +984,8 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
     d->device = s->db->device;
     HIP_TRY(d->up_done.create(false));
     const uint32_t n = b->n_spectra;
-    const uint32_t probe = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
-    rc = stage_and_upload(s, d.get(), b, 0, n, is_page_locked(b->masses) && is_page_locked(b->intensities), probe, s->up_stream);
+    const WindowEstimate est = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    rc = stage_and_upload(s, d.get(), b, 0, n, is_page_locked(b->masses) && is_page_locked(b->intensities), est, s->up_stream);
     if (rc != SAGE_HIP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s->up_stream));
     *out = d.release();
@@ -1044,7 +1089,9 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     v.ims = raw->inverse_ion_mobility ? d->ims.p : nullptr;
     v.file_id = raw->file_id ? d->file_id.p : nullptr;
     v.order = d->order.p;
-    v.probe = choose_probe(s, n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi);
+    const WindowEstimate est = choose_probe(s, n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi);
+    v.probe = est.probe;
+    d->maybe_wide = est.maybe_wide;
     v.pcap = pcap;
     v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
     *out = d.release();
@@ -1093,6 +1140,9 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     HIP_TRY(w.queue.reserve(n));
     HIP_TRY(w.retry.reserve(n));
     HIP_TRY(w.item_of.reserve(n));
+    HIP_TRY(w.ready.reserve(n));
+    HIP_TRY(hipMemset(w.ready.p, 0, (size_t)w.ready.n * 4));  // (no launch has the epoch 0)
+    w.epoch = 0;
     // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
     HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
     HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * 64));
@@ -1114,6 +1164,10 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
     w.queue = ws.queue.p;
     w.retry = ws.retry.p;
     w.item_of = ws.item_of.p;
+    w.ready = ws.ready.p;
+    w.epoch = ws.epoch;
+    w.search_lag = 0;
+    if (const char* e = getenv("SAGE_HIP_SEARCH_LAG")) w.search_lag = (uint32_t)std::max(0, atoi(e));
     w.reuse = 0;
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.tile_blocks = s->tile_blocks;
@@ -1132,30 +1186,47 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
        MODE_EXACT = 1,  // every trim replays bounded_min_heapify: one pass
        MODE_FAST = 2 }; // order-free trims only (quick_score: which peptides survive does not depend on heap layouts)
 
-// Enqueue the kernels of one batch on `st` — nothing here waits for the device.  The retry pass is launched unconditionally:
-// its spectrum list and its COUNT live on the device (the first pass's CTR_RETRY counter), so no host round trip separates
-// the two passes; with no tied spectrum its blocks exit at once.
-static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st) {
+// Enqueue the kernels of one batch on `st` — nothing here waits for the device.
+//   MODE_SCORE with rescoring, the production path.  First pass, order-free trims: prelim_kernel scores the narrow windows and
+//   queues the others; when `wide`, the large-window kernels take the queue; rescore_kernel reports every spectrum except those
+//   whose reported ranks tie in hyperscore, which it lists.  Exact retry pass over that list, launched unconditionally — the
+//   list and its COUNT live on the device (the first pass's CTR_RETRY counter), so no host round trip separates the passes, and
+//   with no tied spectrum its blocks exit at once: narrow_kernel (matching with bounded_min_heapify replayed + rescoring, one
+//   launch) reports the narrow ones and queues the others; when `wide`, the large-window kernels and rescore_kernel follow.
+//   `wide` == false skips the ten launches of the large-window path: the caller checks the queue counter afterwards and
+//   repeats the batch with wide == true if the guess was wrong.  SAGE_HIP_FUSED=1: narrow_kernel as the first pass, too.
+//   Other modes: preliminary kernel, large-window kernels, rescoring kernel.
+// `rec`: where the PSM records go — device memory (null: the OutSet's buffer) or the device-side view of page-locked host memory.
+static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st,
+                           SageFeature* rec = nullptr, bool wide = true) {
     int rc = ensure_work(s, view.n);
     if (rc != SAGE_HIP_OK) return rc;
+    if (!rec) rec = o.features.p;
     DevScorer sc = s->dev;
-    const size_t lds_p = prelim_lds_bytes(sc, view), lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
+    const bool production = mode == MODE_SCORE && with_rescore;
+    const bool fused = s->fused && production;
+    if (!production) wide = true;
+    const bool one_launch = production && !fused && s->one_launch;
+    const size_t lds_p = std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
+                 lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
     const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
     if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
-    const bool two_pass = mode == MODE_SCORE && with_rescore;
-    o.two_pass = two_pass;
+    o.two_pass = production && !(fused && !wide);  // (the fused first pass settles the ties of narrow spectra itself)
     o.with_rescore = with_rescore;
+    o.fused = fused || one_launch;
+    o.wide_launched = wide;
     o.n = view.n;
     DevBatchView v2 = view;
     v2.order = s->ws.retry.p;  // filled by the rescoring kernel of the first pass, in no particular order
     v2.n_dev = o.counters.p + CTR_RETRY;
+    if (one_launch && ++s->ws.epoch == 0) s->ws.epoch = 1;
     DevWork w1 = make_work(s, o, 0), w2 = make_work(s, o, 1);
-    if (two_pass && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
+    if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
     }
-    if (two_pass && s->reuse_counts) {  // the retry pass replays from the first pass's counts, appending to the same arena
+    if (production && s->reuse_counts) {  // the retry pass replays from the first pass's counts, appending to the same arena
         w2.reuse = 1;
         w2.arena_ptr = w1.arena_ptr;
     }
@@ -1164,23 +1235,31 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     sc2.exact = 1u;
     HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
     HIP_TRY(hipEventRecord(o.ev[0].e, st));
-    launch_prelim(s->db->view, sc1, view, w1, st);
+    if (fused)
+        launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
+    else if (one_launch)
+        launch_search(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
+    else
+        launch_prelim(s->db->view, sc1, view, w1, st);
     HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
-    launch_prelim_tile(s->db->view, sc1, view, w1, st);
-    HIP_TRY(hipGetLastError());
+    if (wide) {
+        launch_prelim_tile(s->db->view, sc1, view, w1, st);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(o.ev[1].e, st));
-    if (with_rescore)
-        launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p, o.out_count.p,
-                       nullptr, st);
+    if (with_rescore && (wide || !(fused || one_launch)))  // (behind search_kernel / the fused kernel: only the spectra the large-window kernels assembled)
+        launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, o.out_count.p, nullptr, st);
     HIP_TRY(hipEventRecord(o.ev[2].e, st));
-    if (two_pass) {
-        launch_prelim(s->db->view, sc2, v2, w2, st);
+    if (o.two_pass) {
+        launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
         HIP_TRY(hipGetLastError());
-        launch_prelim_tile(s->db->view, sc2, v2, w2, st);
-        HIP_TRY(hipGetLastError());
+        if (wide) {
+            launch_prelim_tile(s->db->view, sc2, v2, w2, st);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(o.ev[3].e, st));
-        launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p, o.out_count.p,
-                       nullptr, st);
+        if (wide)
+            launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, o.out_count.p, nullptr, st);
         HIP_TRY(hipEventRecord(o.ev[4].e, st));
     }
     HIP_TRY(hipGetLastError());
@@ -1188,11 +1267,19 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     return SAGE_HIP_OK;
 }
 
-// counters + timing of a finished batch (its comp_done / down_done event has completed); accumulates into s->timing
-static int collect(SageScorer* s, OutSet& o, bool* arena_overflow) {
+// counters + timing of a finished batch (its comp_done / down_done event has completed); accumulates into s->timing.
+// *redo_wide: the batch was launched without the large-window kernels and turned out to need them — nothing is accumulated.
+static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wide = nullptr) {
     o.in_flight = false;
     const uint32_t* c1 = o.h_counters;
     const uint32_t* c2 = o.h_counters + CTR_COUNT;
+    if (!o.wide_launched && c1[CTR_QUEUED]) {
+        if (redo_wide) {
+            *redo_wide = true;
+            return SAGE_HIP_OK;
+        }
+        return fail(SAGE_HIP_ERR_INTERNAL, "spectra queued for the large-window kernels, which were not launched");
+    }
     float a = 0, r = 0, a2 = 0, r2 = 0;
     HIP_TRY(hipEventElapsedTime(&a, o.ev[0].e, o.ev[1].e));
     HIP_TRY(hipEventElapsedTime(&r, o.ev[1].e, o.ev[2].e));
@@ -1204,10 +1291,13 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow) {
     t.prelim_ms += a + a2;
     t.rescore_ms += o.with_rescore ? r + r2 : 0.f;
     t.total_ms += a + a2 + (o.with_rescore ? r + r2 : 0.f);
-    t.n_launches += (o.with_rescore ? 6 : 5) * (o.two_pass ? 2 : 1);
+    t.retry_ms += a2 + r2;
+    t.n_launches += 1 + (o.wide_launched ? 4 : 0) + (o.with_rescore && (o.wide_launched || !o.fused) ? 1 : 0) +
+                    (o.two_pass ? 1 + (o.wide_launched ? 5 : 0) : 0);
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
+    t.n_tied += c1[CTR_TIED];
     if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
         if (arena_overflow) {
             *arena_overflow = true;
@@ -1224,22 +1314,32 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow) {
 
 static void reset_timing(SageScorer* s) { s->timing = SageTiming{}; }
 
-// score a resident batch on the compute stream: kernels, record download, ONE host synchronisation
+// score a resident batch on the compute stream: kernels, record download, ONE host synchronisation.  Page-locked result
+// arrays receive the records straight from the kernels (the stores cross PCIe while the other wavefronts compute: no download
+// phase); pageable ones through the device buffer and a copy.
 static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
     if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
     HIP_TRY(hipSetDevice(s->db->device));
     reset_timing(s);
     OutSet& o = s->outs[0];
-    int rc = enqueue_compute(s, b->view, o, true, s->exact_always ? MODE_EXACT : MODE_SCORE, s->stream);
-    if (rc != SAGE_HIP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
-    if (b->n) {
-        HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipMemcpyAsync(out, o.features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature), hipMemcpyDeviceToHost,
-                               s->stream));
+    SageFeature* direct = s->zero_copy && b->n ? (SageFeature*)device_view(out) : nullptr;
+    for (int attempt = 0;; attempt++) {
+        int rc = enqueue_compute(s, b->view, o, true, s->exact_always ? MODE_EXACT : MODE_SCORE, s->stream, direct, b->maybe_wide);
+        if (rc != SAGE_HIP_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
+        if (b->n) {
+            HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
+            if (!direct)
+                HIP_TRY(hipMemcpyAsync(out, o.features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature), hipMemcpyDeviceToHost,
+                                       s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        bool redo = false;
+        rc = collect(s, o, nullptr, &redo);
+        if (rc != SAGE_HIP_OK || !redo) return rc;
+        if (attempt) return fail(SAGE_HIP_ERR_INTERNAL, "large-window queue not drained");
+        b->maybe_wide = true;  // (and stays so: the batch holds large windows after all)
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    return collect(s, o, nullptr);
 }
 
 int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out, uint32_t* out_count) {
@@ -1252,11 +1352,12 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
 // c + 1 is staged and uploaded on the copy stream and the PSM records of chunk c - 1 return on the download stream.  Mirrors the
 // reference's reader -> processor -> search overlap (runner.rs:365-375, 450-461) at the PCIe boundary.
 static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, uint32_t r1, SageFeature* out, uint32_t* out_count,
-                       uint32_t chunk, bool peaks_locked, uint32_t probe, std::vector<std::pair<uint32_t, uint32_t>>& overflowed) {
+                       uint32_t chunk, bool peaks_locked, WindowEstimate est, std::vector<std::pair<uint32_t, uint32_t>>& overflowed) {
     const uint32_t rp = s->params.report_psms;
-    // page-locked result arrays (sage_hip_host_alloc) receive the records by DMA; pageable ones through a page-locked landing
-    // block per slot (an asynchronous copy into pageable memory would stall the pipeline)
+    // page-locked result arrays (sage_hip_host_alloc) receive the records from the kernels' own stores; pageable ones through a
+    // page-locked landing block per slot (an asynchronous copy into pageable memory would stall the pipeline)
     const bool out_locked = is_page_locked(out) && is_page_locked(out_count);
+    SageFeature* const direct = s->zero_copy && out_locked ? (SageFeature*)device_view(out) : nullptr;
     const int mode = s->exact_always ? MODE_EXACT : MODE_SCORE;
     struct Pending {
         uint32_t c0, c1;
@@ -1264,21 +1365,6 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
     };
     Pending pend[2];
     bool has[2] = {false, false};
-    auto finish = [&](int slot) -> int {
-        if (!has[slot]) return SAGE_HIP_OK;
-        has[slot] = false;
-        OutSet& o = s->outs[slot];
-        HIP_TRY(hipEventSynchronize(o.down_done.e));
-        if (!out_locked) {
-            const uint32_t c0 = pend[slot].c0, cn = pend[slot].c1 - pend[slot].c0;
-            std::memcpy(out + (size_t)c0 * rp, o.h_out.p, (size_t)cn * rp * sizeof(SageFeature));
-            std::memcpy(out_count + c0, o.h_out.p + (((size_t)cn * rp * sizeof(SageFeature) + 63) / 64) * 64, (size_t)cn * 4);
-        }
-        bool ovf = false;
-        const int rc = collect(s, o, &ovf);
-        if (ovf) overflowed.push_back({pend[slot].c0, pend[slot].c1});
-        return rc;
-    };
     // an error with chunks still in flight: nothing may keep writing into the caller's arrays after the call has returned
     auto bail = [&](int rc) -> int {
         (void)hipStreamSynchronize(s->up_stream);
@@ -1287,43 +1373,84 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         s->outs[0].in_flight = s->outs[1].in_flight = false;
         return rc;
     };
+#define HIP_TRY_BAIL(expr)                                                                  \
+    do {                                                                                    \
+        const hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) return bail(fail(SAGE_HIP_ERR_HIP, hipGetErrorString(e_)));   \
+    } while (0)
+    // kernels + the way home of the records of one chunk (its input is resident in s->slots[slot])
+    auto launch = [&](int slot, uint32_t c0, uint32_t c1, bool wide) -> int {
+        SageDeviceBatch& in = s->slots[slot];
+        OutSet& o = s->outs[slot];
+        int rc = enqueue_compute(s, in.view, o, true, mode, s->stream, direct ? direct + (size_t)c0 * rp : nullptr, wide);
+        if (rc != SAGE_HIP_OK) return bail(rc);
+        HIP_TRY_BAIL(hipEventRecord(o.comp_done.e, s->stream));
+        // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
+        // download, which itself follows its kernels: no device-side guard is needed for the input buffers
+        HIP_TRY_BAIL(hipStreamWaitEvent(s->down_stream, o.comp_done.e, 0));
+        HIP_TRY_BAIL(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->down_stream));
+        SageFeature* dst_f = out + (size_t)c0 * rp;
+        uint32_t* dst_c = out_count + c0;
+        if (!out_locked) {
+            const size_t fb = (((size_t)(c1 - c0) * rp * sizeof(SageFeature) + 63) / 64) * 64;
+            const hipError_t e_ = o.h_out.reserve(fb + (size_t)(c1 - c0) * 4);
+            if (e_ != hipSuccess) return bail(fail(SAGE_HIP_ERR_HIP, hipGetErrorString(e_)));
+            dst_f = (SageFeature*)o.h_out.p;
+            dst_c = (uint32_t*)(o.h_out.p + fb);
+        }
+        HIP_TRY_BAIL(hipMemcpyAsync(dst_c, o.out_count.p, (size_t)(c1 - c0) * 4, hipMemcpyDeviceToHost, s->down_stream));
+        if (!direct)
+            HIP_TRY_BAIL(hipMemcpyAsync(dst_f, o.features.p, (size_t)(c1 - c0) * rp * sizeof(SageFeature), hipMemcpyDeviceToHost, s->down_stream));
+        HIP_TRY_BAIL(hipEventRecord(o.down_done.e, s->down_stream));
+        return SAGE_HIP_OK;
+    };
+    auto finish = [&](int slot) -> int {
+        if (!has[slot]) return SAGE_HIP_OK;
+        has[slot] = false;
+        OutSet& o = s->outs[slot];
+        HIP_TRY_BAIL(hipEventSynchronize(o.down_done.e));
+        bool ovf = false, redo = false;
+        int rc = collect(s, o, &ovf, &redo);
+        if (rc != SAGE_HIP_OK) return bail(rc);
+        if (redo) {
+            // the chunk held large windows although the sample said otherwise: once more with the large-window kernels (its
+            // input is still resident; the working set is shared, so behind whatever the compute stream is doing now)
+            est.maybe_wide = true;
+            rc = launch(slot, pend[slot].c0, pend[slot].c1, true);
+            if (rc != SAGE_HIP_OK) return rc;
+            HIP_TRY_BAIL(hipEventSynchronize(o.down_done.e));
+            rc = collect(s, o, &ovf, nullptr);
+            if (rc != SAGE_HIP_OK) return bail(rc);
+        }
+        if (!out_locked) {
+            const uint32_t c0 = pend[slot].c0, cn = pend[slot].c1 - pend[slot].c0;
+            std::memcpy(out + (size_t)c0 * rp, o.h_out.p, (size_t)cn * rp * sizeof(SageFeature));
+            std::memcpy(out_count + c0, o.h_out.p + (((size_t)cn * rp * sizeof(SageFeature) + 63) / 64) * 64, (size_t)cn * 4);
+        }
+        if (ovf) overflowed.push_back({pend[slot].c0, pend[slot].c1});
+        return SAGE_HIP_OK;
+    };
     int k = 0;
     for (uint32_t c0 = r0; c0 < r1; c0 += chunk, k++) {
         const uint32_t c1 = (uint32_t)std::min<uint64_t>((uint64_t)c0 + chunk, r1);
         const int slot = k & 1;
         int rc = finish(slot);  // chunk k - 2 used this slot: its records are home, its buffers are free
-        if (rc != SAGE_HIP_OK) return bail(rc);
+        if (rc != SAGE_HIP_OK) return rc;
         SageDeviceBatch& in = s->slots[slot];
-        OutSet& o = s->outs[slot];
         // (the uploads of chunk k - 2 finished long ago — its kernels ran — so the staging block may be rewritten)
-        rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, probe, s->up_stream);
+        rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, est, s->up_stream);
         if (rc != SAGE_HIP_OK) return bail(rc);
-        HIP_TRY(hipStreamWaitEvent(s->stream, in.up_done.e, 0));
-        rc = enqueue_compute(s, in.view, o, true, mode, s->stream);
-        if (rc != SAGE_HIP_OK) return bail(rc);
-        HIP_TRY(hipEventRecord(o.comp_done.e, s->stream));
-        // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
-        // download, which itself follows its kernels: no device-side guard is needed for the input buffers
-        HIP_TRY(hipStreamWaitEvent(s->down_stream, o.comp_done.e, 0));
-        HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->down_stream));
-        SageFeature* dst_f = out + (size_t)c0 * rp;
-        uint32_t* dst_c = out_count + c0;
-        if (!out_locked) {
-            const size_t fb = (((size_t)(c1 - c0) * rp * sizeof(SageFeature) + 63) / 64) * 64;
-            HIP_TRY(o.h_out.reserve(fb + (size_t)(c1 - c0) * 4));
-            dst_f = (SageFeature*)o.h_out.p;
-            dst_c = (uint32_t*)(o.h_out.p + fb);
-        }
-        HIP_TRY(hipMemcpyAsync(dst_c, o.out_count.p, (size_t)(c1 - c0) * 4, hipMemcpyDeviceToHost, s->down_stream));
-        HIP_TRY(hipMemcpyAsync(dst_f, o.features.p, (size_t)(c1 - c0) * rp * sizeof(SageFeature), hipMemcpyDeviceToHost, s->down_stream));
-        HIP_TRY(hipEventRecord(o.down_done.e, s->down_stream));
+        HIP_TRY_BAIL(hipStreamWaitEvent(s->stream, in.up_done.e, 0));
+        rc = launch(slot, c0, c1, est.maybe_wide);
+        if (rc != SAGE_HIP_OK) return rc;
         pend[slot] = Pending{c0, c1, slot};
         has[slot] = true;
     }
+#undef HIP_TRY_BAIL
     // the working set (candidate lists, arena) is shared by both slots: kernels run in order on one stream, and a chunk's
     // records leave through its own OutSet, so the next chunk's kernels may start while they are being downloaded
     int rc = finish(k & 1);
-    if (rc != SAGE_HIP_OK) return bail(rc);
+    if (rc != SAGE_HIP_OK) return rc;
     return finish((k + 1) & 1);
 }
 
@@ -1337,9 +1464,9 @@ int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature*
     const uint32_t n = b->n_spectra;
     if (n == 0) return SAGE_HIP_OK;
     const bool peaks_locked = is_page_locked(b->masses) && is_page_locked(b->intensities);
-    const uint32_t probe = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    const WindowEstimate est = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
     std::vector<std::pair<uint32_t, uint32_t>> todo, next;
-    rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, probe, todo);
+    rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, est, todo);
     if (rc != SAGE_HIP_OK) return rc;
     // chunks whose large-window candidates did not fit the arena: again in halves (the arena is sized for the chunk, so a
     // piece with the same arena and half the spectra has twice the room per spectrum)
@@ -1350,7 +1477,7 @@ int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature*
             if (len <= 1)
                 return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted by a single spectrum (" +
                                                           std::to_string(s->ws.arena.n >> 18) + " MiB): raise SAGE_HIP_ARENA_MB");
-            rc = score_range(s, b, r.first, r.second, out, out_count, (len + 1) / 2, peaks_locked, probe, next);
+            rc = score_range(s, b, r.first, r.second, out, out_count, (len + 1) / 2, peaks_locked, est, next);
             if (rc != SAGE_HIP_OK) return rc;
         }
         todo.swap(next);

@@ -61,6 +61,7 @@ struct DevScorer {
     uint32_t wcap;       // candidate-slot capacity of the LDS counter array of the narrow kernel: spectra with a
                          // larger precursor window go to the tiled large-window kernel
     uint32_t dbg_flags;  // timing experiments only (SAGE_HIP_DEBUG_FLAGS)
+    uint32_t xcd_chunk;  // consecutive schedule positions one XCD takes at a time (kernels.hip: xcd_position); 0: round-robin
     uint32_t exact;      // 1: every trim_hits replays bounded_min_heapify, so the preliminary list has the reference's heap
                          //    layout.  0: each trim keeps the same SET of candidates (the k largest) without replaying the
                          //    heap; the layout is only observable through equal hyperscores at a reported rank, which the
@@ -104,6 +105,9 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t cnt8;         // count in u8 (first pass of a two-pass search only: overflowing spectra go to the u16 retry pass)
     uint32_t reuse;        // retry pass: the large-window counts of the first pass are reused through item_of (kernels.hip: query_slot)
     uint32_t* item_of;     // [n] spectrum -> its item in the first pass's queue; bit 31: count again (a u8 counter may have wrapped)
+    uint32_t* ready;       // [n] search_kernel: == epoch once the spectrum's preliminary list is in HBM (written with agent-scope release)
+    uint32_t epoch;        //     of this launch (never 0; the array is zeroed when it is allocated)
+    uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
@@ -116,8 +120,10 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     unsigned long long* dbg;  // optional [2][8] per-phase cycle accumulators (null in production)
 };
 
-enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3 };
+enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
+       ST_DONE = 4 };  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
+       CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
        CTR_COUNT = 8 };
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
@@ -156,6 +162,14 @@ size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
+size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b);
+// the narrow search as ONE launch of two kinds of workgroups (preliminary / rescoring, kernels.hip: search_kernel)
+size_t search_lds_bytes(const DevScorer& sc, const DevBatchView& b);
+void launch_search(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                   uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
+// the fused narrow-search kernel: preliminary matching + k-select + rescoring of every spectrum whose windows fit the LDS counters
+void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                   uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
 uint32_t queries_per_spectrum(const DevScorer& sc);

@@ -17,6 +17,8 @@
 // and the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_types.h"
 
 using namespace sagecore;
@@ -58,9 +60,40 @@ struct PhaseClock {
             t = n;
         }
     }
+    __device__ __forceinline__ void rebase(uint32_t kernel) {  // go on accounting under another kernel's row
+        if (slot) slot += (int)kernel * 8 - row_base;
+        row_base = (int)kernel * 8;
+    }
+};
+
+// the same interface compiled to nothing: what the production instances of the per-spectrum kernels carry (a run-time
+// "profiling off" check costs scalar registers and branches in kernels that are short of both)
+struct NoClock {
+    static constexpr unsigned long long* slot = nullptr;
+    __device__ __forceinline__ void bytes(int, unsigned long long) {}
+    __device__ __forceinline__ void start(unsigned long long*, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void rebase(uint32_t) {}
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// XCD-aware schedule position.  Workgroup b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup
+// dispatch"; a speed matter only, nothing here depends on it), each XCD with a private 4 MiB L2.  The per-spectrum kernels walk
+// the batch in precursor-mass order so that neighbouring wavefronts read overlapping index ranges; dealt round-robin, all eight
+// L2s would see the whole mass front (a dozen index tiles: more than one L2 holds).  With this bijective remap the schedule is
+// cut into chunks of `chunk` consecutive positions, chunk c goes to XCD c % 8 and every XCD walks its chunks in order: one L2
+// serves one narrow mass front, and every XCD still gets every mass range (heavy precursors cost more: contiguous eighths
+// would leave the last XCD with the long tail).  The ragged end (fewer than 8 chunks) stays round-robin.
+constexpr uint32_t N_XCD = 8;
+__device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t n, uint32_t chunk) {
+    if (chunk & 0x80000000u) return n - 1 - xcd_position(b, n, chunk & 0x7FFFFFFFu);  // heaviest precursors first
+    if (chunk == 0) return b;
+    const uint32_t group = N_XCD * chunk;
+    if (b >= n / group * group) return b;
+    const uint32_t x = b % N_XCD, i = b / N_XCD;  // the i-th workgroup of XCD x
+    return ((i / chunk) * N_XCD + x) * chunk + i % chunk;
+}
 
 // wave-uniform values that come out of memory land in VGPRs; these move them to SGPRs (the value must be uniform)
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -215,44 +248,76 @@ __device__ __forceinline__ void wh_offer(WaveHeap& h, uint32_t k, uint64_t v) { 
     if (k && v > wh_get(h, 0)) wh_sift_from(h, k, 0, v);  // slice.swap(i, 0): the displaced minimum is truncated away
 }
 
-// The same heap with 32-bit keys, for the k-select of ONE precursor-window query of the narrow kernel: charge and isotope
-// error are constant inside a query, so PreScore's order is (matched, peptide) = (matched, candidate slot), and with at
-// most 65536 slots `matched << 16 | slot` orders identically (an empty slot is key 0).  Scalar compares, one readlane per
-// node, half the cross-lane traffic.
-__device__ __forceinline__ uint32_t wh32_get(uint32_t h, uint32_t idx) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)h, (int)__builtin_amdgcn_readfirstlane(idx));
+// The same heap with 32-bit keys, for the k-select of ONE precursor-window query: charge and isotope error are constant inside a
+// query, so PreScore's order is (matched, peptide) = (matched, candidate slot), and `matched << S | slot` orders identically (an
+// empty slot is key 0; no key is 0xFFFFFFFF).  This replay is the latency chain of the exact retry pass — a wavefront does
+// ~100 of these sifts one after the other — so it is written for latency: next to the heap (lane i = node i) every lane keeps
+// ITS CHILDREN's values (hl, hr), which makes "the right child is the smaller one", for all nodes at once, ONE v_cmp into a
+// scalar mask; the root-to-leaf path then follows from scalar bit operations alone, its values are read with independent
+// v_readlane's (no cross-lane permutes, no LDS), and the shift along the path is a handful of lane-select writes.
+struct Heap32 {
+    uint32_t h;       // node `lane`
+    uint32_t hl, hr;  // its children 2 * lane + 1, 2 * lane + 2 (0xFFFFFFFF: none)
+};
+__device__ __forceinline__ uint32_t wh32_get(const Heap32& H, uint32_t idx) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)__builtin_amdgcn_readfirstlane(idx));
 }
-__device__ __forceinline__ void wh32_sift_from(uint32_t& h, uint32_t len, uint32_t index, uint32_t moving) {
+__device__ __forceinline__ void wh32_set(Heap32& H, uint32_t node, uint32_t val) {  // node, val: wave-uniform
+    const uint32_t lane = lane_id();
+    H.h = lane == node ? val : H.h;  // (v_writelane as compare + select: no lane-select hazards for the compiler to miss)
+    // the parent's copy: child 2p + 1 is odd, 2p + 2 even; node 0 has no parent (lane 64 does not exist)
+    const uint32_t pl = (node & 1u) ? (node - 1u) >> 1 : 64u, pr = (node && !(node & 1u)) ? (node - 1u) >> 1 : 64u;
+    H.hl = lane == pl ? val : H.hl;
+    H.hr = lane == pr ? val : H.hr;
+}
+__device__ __forceinline__ void wh32_init(Heap32& H, uint32_t keys, uint32_t k) {  // lane i brings element i (i < k)
     const uint32_t lane = lane_id();
     const uint32_t l = 2 * lane + 1, r = l + 1;
-    const uint32_t vl = (uint32_t)__shfl((int)h, (int)(l & 63u), 64), vr = (uint32_t)__shfl((int)h, (int)(r & 63u), 64);
-    const uint64_t rightmin = __ballot(r < len && vr < vl);  // bit p: the right child of node p is strictly smaller
+    const uint32_t vl = (uint32_t)__shfl((int)keys, (int)(l & 63u), 64), vr = (uint32_t)__shfl((int)keys, (int)(r & 63u), 64);
+    H.h = keys;
+    H.hl = l < k ? vl : 0xFFFFFFFFu;
+    H.hr = r < k ? vr : 0xFFFFFFFFu;
+}
+// sift_down (heap.rs:40-60) of value `moving` placed at `index`.  sift_down always descends to the smaller child (the left one
+// on a tie), a path that does not depend on the value being sifted; values along a heap path never decrease, so `moving` stops
+// at the first path value that is not smaller.  All control flow is wave-uniform.
+__device__ __forceinline__ void wh32_sift_from(Heap32& H, uint32_t len, uint32_t index, uint32_t moving) {
+    const uint64_t rightmin = __ballot(H.hr < H.hl);  // bit p: the right child of node p is strictly smaller
     index = __builtin_amdgcn_readfirstlane(index);
     moving = __builtin_amdgcn_readfirstlane(moving);
     uint32_t path[7], pv[7];
-    uint32_t n = 0, dst = index;
+    bool on[7];
     path[0] = index;
-    bool go = true;
+    on[0] = true;
 #pragma unroll
-    for (uint32_t j = 0; j < 6; j++) {
+    for (uint32_t j = 0; j < 6; j++) {  // the whole path first (scalar), then its values (independent reads)
         const uint32_t lc = 2 * path[j] + 1;
-        go = go && lc < len;
-        path[j + 1] = go ? lc + (uint32_t)((rightmin >> (path[j] & 63u)) & 1ull) : 0;
-        pv[j + 1] = go ? wh32_get(h, path[j + 1]) : 0xFFFFFFFFu;
-        go = go && pv[j + 1] < moving;
-        n += go ? 1u : 0u;
-        dst = go ? path[j + 1] : dst;
+        on[j + 1] = on[j] && lc < len;
+        path[j + 1] = on[j + 1] ? lc + (uint32_t)((rightmin >> (path[j] & 63u)) & 1ull) : 0u;
     }
 #pragma unroll
+    for (uint32_t j = 1; j <= 6; j++) pv[j] = (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)path[j]);
+    uint32_t n = 0;  // nodes below `index` on the path that hold a value smaller than `moving`
+    bool go = true;
+#pragma unroll
+    for (uint32_t j = 1; j <= 6; j++) {
+        go = go && on[j] && pv[j] < moving;
+        n += go ? 1u : 0u;
+    }
+    // shift the path up by one level and drop `moving` where it stopped (slice.swap at every level)
+#pragma unroll
     for (uint32_t j = 0; j < 6; j++)
-        if (j < n) h = lane == path[j] ? pv[j + 1] : h;
-    h = lane == dst ? moving : h;
+        if (j < n) wh32_set(H, path[j], pv[j + 1]);
+    uint32_t dst = index;
+#pragma unroll
+    for (uint32_t j = 1; j <= 6; j++) dst = j == n ? path[j] : dst;
+    wh32_set(H, dst, moving);
 }
-__device__ __forceinline__ void wh32_build(uint32_t& h, uint32_t k) {  // heap.rs:13-15
-    for (uint32_t i = k / 2; i-- > 0;) wh32_sift_from(h, k, i, wh32_get(h, i));
+__device__ __forceinline__ void wh32_build(Heap32& H, uint32_t k) {  // heap.rs:13-15
+    for (uint32_t i = k / 2; i-- > 0;) wh32_sift_from(H, k, i, wh32_get(H, i));
 }
-__device__ __forceinline__ void wh32_offer(uint32_t& h, uint32_t k, uint32_t v) {  // heap.rs:21-27
-    if (k && v > wh32_get(h, 0)) wh32_sift_from(h, k, 0, v);
+__device__ __forceinline__ void wh32_offer(Heap32& H, uint32_t k, uint32_t v) {  // heap.rs:21-27
+    if (k && v > wh32_get(H, 0)) wh32_sift_from(H, k, 0, v);
 }
 
 // CList (core.h) with wave-uniform bookkeeping: every lane holds the same stored/len, appends are
@@ -356,6 +421,14 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     l.ptab = (uint32_t*)(smem + off); off += b.probe ? (size_t)3 * PROBE_BATCH_WORDS * 4 : 0;
     l.cnt = (uint32_t*)(smem + off);
     return l;
+}
+
+__host__ __device__ inline size_t prelim_layout_bytes(const DevScorer& sc, const DevBatchView& b) {
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 +
+               (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)3 * PROBE_BATCH_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
+    n += ((size_t)sc.wcap / 2 + 1) * 4;
+    return (n + 15) & ~(size_t)15;
 }
 
 // ---- shared by both preliminary kernels ----------------------------------------------------------
@@ -504,6 +577,14 @@ constexpr uint32_t PROBE_BATCH = PROBE_PER_LANE * 64;  // (a power of two: the o
 constexpr uint32_t PROBE_CELLS = SAGE_PROBE_CELLS;
 constexpr uint32_t NO_WINDOW = 0xFFFFFFFFu;
 static_assert((PROBE_BATCH & (PROBE_BATCH - 1)) == 0, "PROBE_BATCH must be a power of two");
+#ifndef SAGE_NARROW_WAVES
+#define SAGE_NARROW_WAVES 5  // the fused narrow kernel
+#endif
+#if SAGE_NARROW_WAVES
+#define SAGE_NARROW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SAGE_NARROW_WAVES, SAGE_NARROW_WAVES)))
+#else
+#define SAGE_NARROW_WAVES_ATTR
+#endif
 #if SAGE_PRELIM_WAVES
 #define SAGE_PRELIM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SAGE_PRELIM_WAVES, SAGE_PRELIM_WAVES)))
 #else
@@ -514,25 +595,22 @@ static_assert((PROBE_BATCH & (PROBE_BATCH - 1)) == 0, "PROBE_BATCH must be a pow
 #else
 #define SAGE_RESCORE_WAVES_ATTR
 #endif
-template <bool PROBE>
-__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// Scorer::initial_hits (scoring.rs:418-462) of ONE spectrum by one wavefront: the final preliminary list ends up in L.listB.
+// `exact`: every trim_hits replays bounded_min_heapify (the list is in the reference's heap layout); else the order-free trims.
+struct PrelimResult {
+    uint32_t stored;            // entries of the preliminary list, L.listB[0 .. stored)
+    uint32_t matched, scored;   // InitialHits.matched_peaks, .scored_candidates
+    bool ok;                    // false: a candidate list overflowed its LDS capacity
+    bool deferred;              // some precursor window exceeds the LDS counters: the spectrum belongs to the large-window kernels
+};
+template <bool PROBE, class PC>
+__device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
+                                                        const SpecInfo& si, const bool exact, PC& pc) {
     const uint32_t lane = lane_id();
-    const PrelimLds L = carve_prelim(smem, sc, b);
     Counters cnt;
     cnt.p = L.cnt;
-
-    uint32_t n_batch = b.n;
-    if (b.n_dev) {  // retry pass: the count is a device-side counter of the first pass
-        const uint32_t nd = uni(*b.n_dev);
-        n_batch = nd < n_batch ? nd : n_batch;
-    }
-    for (uint32_t blk = blockIdx.x; blk < n_batch; blk += gridDim.x) {
-        const uint32_t spec = b.order ? uni(b.order[blk]) : blk;
-        __syncthreads();
-        PhaseClock pc;
-        pc.start(w.dbg, blk, 0);
-        const SpecInfo si = load_spec(sc, b, spec);
+    PrelimResult res{0u, 0u, 0u, true, false};
+    {
         const uint32_t P = si.P, nfz_max = si.nfz_max;
         const float* __restrict__ masses = b.masses + si.p0;
 
@@ -752,33 +830,34 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                         const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
                         ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
                     }
-                } else if (!sc.exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
+                } else if (!exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
                     // (done: the k largest slots by (count, slot) without replaying the heap)
                 } else {
                     // keys `matched << 16 | slot` (potential <= wcap <= 65536): same order as PreScore inside one query
                     scored = 0;
-                    uint32_t h;
+                    Heap32 hp;
                     {
                         const uint32_t c = lane < k ? cnt.get(lane) : 0;
-                        h = c ? (c << 16) | lane : 0u;
+                        wh32_init(hp, c ? (c << 16) | lane : 0u, k);
                         scored += (uint32_t)__popcll(__ballot(c > 0));
                     }
-                    wh32_build(h, k);
+                    wh32_build(hp, k);
                     for (uint32_t base = k; base < potential; base += WAVE) {
                         const uint32_t i = base + lane;
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
                         const uint32_t v = (c << 16) | i;
                         // in slot order; a slot can only enter if its count reaches the heap minimum's (heap.rs:22: later
                         // slots have larger peptide indices, so equal counts do enter)
-                        uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> 16));
+                        uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> 16));
                         scored += (uint32_t)__popcll(__ballot(c > 0));
                         if (pc.slot && lane == 0) atomicAdd(&pc.slot[5], (unsigned long long)__popcll(mask));
                         while (mask) {
                             const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                             mask &= mask - 1;
-                            wh32_offer(h, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                            wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
                         }
                     }
+                    const uint32_t h = hp.h;
                     ulist_append(target, h ? pack_prescore(h >> 16, left + (h & 0xFFFFu), z, iso) : PRESCORE_EMPTY, k, sc.kmax);
                 }
                 tot_scored += scored;
@@ -786,7 +865,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
                 pc.mark(3);
             }
             if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
-                ulist_trim(A, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);
+                ulist_trim(A, sc.report_psms, exact || sc.list_cap > 4 * WAVE);
                 __syncthreads();
                 for (uint32_t base = 0; base < A.stored; base += WAVE) {
                     const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
@@ -797,6 +876,40 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
             }
         }
         if (deferred) {  // some precursor window of this spectrum is too large for the LDS counters
+            res.deferred = true;
+            return res;
+        }
+        ulist_trim(B, sc.report_psms, exact || sc.list_cap > 4 * WAVE);  // scoring.rs:460
+        __syncthreads();
+        res.stored = B.stored;
+        res.matched = tot_matched;
+        res.scored = tot_scored;
+        res.ok = A.ok && B.ok;
+    }
+    return res;
+}
+
+template <bool PROBE, bool PROF>
+__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+    typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const PrelimLds L = carve_prelim(smem, sc, b);
+
+    uint32_t n_batch = b.n;
+    if (b.n_dev) {  // retry pass: the count is a device-side counter of the first pass
+        const uint32_t nd = uni(*b.n_dev);
+        n_batch = nd < n_batch ? nd : n_batch;
+    }
+    for (uint32_t blk = blockIdx.x; blk < n_batch; blk += gridDim.x) {
+        const uint32_t pos = xcd_position(blk, n_batch, sc.xcd_chunk);
+        const uint32_t spec = b.order ? uni(b.order[pos]) : pos;
+        __syncthreads();
+        Clock pc;
+        pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
+        const SpecInfo si = load_spec(sc, b, spec);
+        const PrelimResult r = prelim_spectrum<PROBE>(db, sc, b, L, si, sc.exact != 0, pc);
+        if (r.deferred) {
             if (lane == 0) {
                 w.status[spec] = ST_DEFERRED;
                 const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
@@ -805,16 +918,14 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
             }
             continue;
         }
-        ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
-        __syncthreads();
         if (lane == 0) {
-            if (!(A.ok && B.ok)) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
-            w.status[spec] = (A.ok && B.ok) ? ST_OK : ST_OVERFLOW;
-            w.cand_len[spec] = B.stored;
-            w.totals[2 * spec] = tot_matched;
-            w.totals[2 * spec + 1] = tot_scored;
+            if (!r.ok) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
+            w.status[spec] = r.ok ? ST_OK : ST_OVERFLOW;
+            w.cand_len[spec] = r.stored;
+            w.totals[2 * spec] = r.matched;
+            w.totals[2 * spec + 1] = r.scored;
         }
-        for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
+        for (uint32_t i = lane; i < r.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
         pc.mark(4);
     }
 }
@@ -1664,8 +1775,9 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
     const bool small_keys = !(sc.dbg_flags & 2u) && rec.potential <= (1u << K32_SLOT_BITS) && !(rec.pad[0] & 1u);
     const uint32_t seed_c = lane < k ? w.seeds[qid * 64 + lane] : 0u;
     if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
-        uint32_t h = seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u;
-        wh32_build(h, k);
+        Heap32 hp;
+        wh32_init(hp, seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u, k);
+        wh32_build(hp, k);
         for (uint32_t d = 0; d < rec.n_dir; d++) {
             const DirRun r = dir_run(w, rec, d);
             for (uint32_t j = 0; j < r.n; j += WAVE) {
@@ -1673,15 +1785,15 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
                 const uint32_t c = e >> 16;
                 const uint32_t v = (c << K32_SLOT_BITS) | (r.tile_base + (e & 0xFFFFu) - rec.left);
                 // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
-                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(h, 0) >> K32_SLOT_BITS));
+                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> K32_SLOT_BITS));
                 while (mask) {
                     const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    wh32_offer(h, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                    wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
                 }
             }
         }
-        if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(h, rec.left, z, iso);
+        if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
     } else {
         WaveHeap h;
         const uint64_t sv = seed_c ? pack_prescore(seed_c, rec.left + lane, z, iso) : PRESCORE_EMPTY;
@@ -1842,7 +1954,8 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
 // COOP_MAX_LANES candidates of the spectrum are that heavy (with many heavy candidates — an open search keeps the 50 best of a
 // million — every lane is busy anyway and the lanes work on their own)
 constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COOP_MAX_LANES;
-constexpr uint32_t TILE_GRID_CAP = 32768;  // blocks of the per-query / per-item kernels of the large-window path
+constexpr uint32_t TILE_GRID_CAP = 32768;
+constexpr uint32_t RETRY_GRID_CAP = 8192;   // blocks of the narrow exact retry pass  // blocks of the per-query / per-item kernels of the large-window path
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
     const uint32_t lane = lane_id();
     const PeakBitmap pb = peak_bitmap_params(P ? pm[P - 1] : 0.0f, P ? pm[0] : 0.0f, t);
@@ -1931,63 +2044,88 @@ __device__ __forceinline__ bool quick_gt(const QuickKey& a, const QuickKey& b) {
     return a.iso > b.iso;
 }
 
-__global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
-                                                     const double* __restrict__ lnfact_table, uint32_t lnfact_n,
-                                                     SageFeature* __restrict__ out,
-                                                     uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
-    // keep != nullptr: Scorer::quick_score with prefilter_low_memory (scoring.rs:270-289) instead of build_features
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t lane = lane_id();
-    if (blockIdx.x >= b.n) return;
-    if (b.n_dev && blockIdx.x >= *b.n_dev) return;  // retry pass: device-side count
-    const uint32_t spec = b.order ? b.order[blockIdx.x] : blockIdx.x;
-    // LDS carve
-    uint32_t* pbm = (uint32_t*)smem;                          // [PBM_WORDS] peak presence bitmap (at offset 0: its reads, one per
-                                                              // (ion, charge) item, then address LDS with an immediate base)
-    uint32_t* plut = pbm + PBM_WORDS;                         // [PLUT_BINS] peak position table
-    double* s_sorted = (double*)(plut + PLUT_BINS);           // [64] hyperscores by rank
-    long long* s_key = (long long*)(s_sorted + 64);           // [64] sort keys by lane
-    float* pm = (float*)(s_key + 64);                         // [pcap] peak masses
-    float* pi = pm + b.pcap;                                  // [pcap] peak intensities
-    uint8_t* rm = (uint8_t*)(pi + b.pcap);                    // [pcap] chimera: peak selected by the winner
-    uint8_t* rm2 = rm + b.pcap;
-    QuickKey* qkeys = (QuickKey*)(smem + (((size_t)(rm2 + b.pcap - smem) + 7) & ~(size_t)7));  // [64] quick_score only
+// LDS of the rescoring phase.  Two parts: `scratch` (tables and sort keys of one rescoring round; at offset 0 so that the
+// bitmap reads — one per (ion, charge) item — address LDS with an immediate base) and `fixed` (the spectrum's peaks, which the
+// chimera loop edits in place, and the staging slots of the Feature records).  In the fused narrow kernel the scratch part
+// shares its bytes with the LDS of the preliminary phase, which is over when rescoring starts.
+struct RescoreLds {
+    uint32_t* pbm;        // [PBM_WORDS] peak presence bitmap
+    uint32_t* plut;       // [PLUT_BINS] peak position table
+    double* s_sorted;     // [64] hyperscores by rank
+    long long* s_key;     // [64] sort keys by lane
+    QuickKey* qkeys;      // [64] quick_score only
+    float* pm;            // [pcap] peak masses
+    float* pi;            // [pcap] peak intensities
+    uint8_t* rm;          // [pcap] chimera: peak selected by the winner
+    uint8_t* rm2;         // [pcap]
+    uint32_t* stage;      // [stage_records * 30] Feature records on their way out (written by their lanes, stored by the wavefront)
+};
+constexpr uint32_t FEATURE_WORDS = sizeof(SageFeature) / 4;
+static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dwords");
+__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.chimera ? 1u : sc.report_psms; }
+__host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
+    return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
+}
+__host__ __device__ inline size_t rescore_fixed_bytes(const DevScorer& sc, const DevBatchView& b) {
+    const size_t n = (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7) + (size_t)stage_records(sc) * sizeof(SageFeature);
+    return (n + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsigned char* fixed, const DevBatchView& b) {
+    RescoreLds l;
+    l.pbm = (uint32_t*)scratch;
+    l.plut = l.pbm + PBM_WORDS;
+    l.s_sorted = (double*)(l.plut + PLUT_BINS);
+    l.s_key = (long long*)(l.s_sorted + 64);
+    l.qkeys = (QuickKey*)(l.s_key + 64);
+    l.pm = (float*)fixed;
+    l.pi = l.pm + b.pcap;
+    l.rm = (uint8_t*)(l.pi + b.pcap);
+    l.rm2 = l.rm + b.pcap;
+    l.stage = (uint32_t*)(fixed + (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7));
+    return l;
+}
 
-    if (w.status[spec] != ST_OK) {
-        if (lane == 0 && !keep) out_count[spec] = 0;
-        return;
-    }
-    PhaseClock pc;
-    pc.start(w.dbg, blockIdx.x, 1);
-    const uint64_t p0 = b.peak_off[spec];
-    uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
-    for (uint32_t i = lane; i < P; i += WAVE) {
-        pm[i] = b.masses[p0 + i];
-        pi[i] = b.intensities[p0 + i];
-    }
+// Scorer::build_features / score_chimera_fast / quick_score (scoring.rs:478-595, 648-672, 255-298) of ONE spectrum by one
+// wavefront.  Lane i holds candidate i of the trimmed preliminary list (`mine`, PRESCORE_EMPTY beyond its end); the peaks are in
+// R.pm / R.pi already (P of them).
+//
+// The stable sort of scoring.rs:495 makes the ORDER of the preliminary list observable where equal hyperscores meet at a
+// reported rank.  `list_is_exact`: the list is in the reference's heap-layout order (lane order decides ties).  Otherwise it
+// came from order-free trims — the right candidates in some other order — and such a tie cannot be settled
+// here: the function returns false with nothing final reported (`queue_on_tie`: after queueing the spectrum for the exact
+// retry pass; else the caller settles it itself).
+template <class PC>
+__device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
+                                                 const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                 SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
+                                                 uint8_t* __restrict__ keep, const RescoreLds& R, const uint32_t spec, uint32_t P,
+                                                 const uint64_t mine, const uint32_t tot_matched, const uint32_t tot_scored,
+                                                 const bool list_is_exact, const bool queue_on_tie, PC& pc) {
+    // keep != nullptr: Scorer::quick_score with prefilter_low_memory (scoring.rs:270-289) instead of build_features
+    const uint32_t lane = lane_id();
+    uint32_t* const pbm = R.pbm;
+    uint32_t* const plut = R.plut;
+    float* const pm = R.pm;
+    float* const pi = R.pi;
     float tic = b.tic[spec];
-    const uint32_t ncand = w.cand_len[spec];
-    const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
     const uint32_t pep = prescore_peptide(mine);
     const bool valid = pep != 0xFFFFFFFFu;  // scoring.rs:489
     const uint32_t z = prescore_charge(mine);
     const int iso = prescore_iso(mine);
-    const uint32_t mfc = max_fragment_charge(sc.max_fragment_charge, z);
-    const uint32_t nfz = mfc - 1;
+    const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
     uint64_t ion_base = 0;
-    uint32_t lm1 = 0, info = 0;
-    float calc = 0.f;
+    uint32_t lm1 = 0;
     if (valid) {
         const uint64_t o1 = db.ion_off[pep + 1];
         ion_base = db.ion_off[pep];
         lm1 = db.n_kinds ? (uint32_t)((o1 - ion_base) / db.n_kinds) : 0;
-        info = db.pep_info[pep];
-        calc = db.pep_mono[pep];
     }
-    const uint32_t n_items = valid ? db.n_kinds * lm1 * nfz : 0;  // (ion, fragment charge) pairs of this candidate
+    // (registers are what this kernel is short of: whatever only a reporting lane needs — the peptide's record, its mass — is
+    // read when the record is written, and nothing is kept that two instructions recompute)
+#define SAGE_N_ITEMS (valid ? db.n_kinds * lm1 * nfz : 0u)  /* (ion, fragment charge) pairs of this candidate */
 
-    const double lambda = (double)w.totals[2 * spec] / (double)w.totals[2 * spec + 1];  // scoring.rs:499
-    const float mzp = b.precursor_mz[spec] - PROTON;                                   // scoring.rs:502
+    const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
+    const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
     const float rt = b.rt ? b.rt[spec] : 0.0f;
     float ims = 0.0f;
     if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
@@ -1996,10 +2134,11 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     pc.mark(0);
     if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
         const uint32_t ion_bytes = wave_sum(valid ? 4u * db.n_kinds * lm1 + 24u : 0u);
+        const uint32_t ncand = (uint32_t)__popcll(__ballot(mine != PRESCORE_EMPTY));
         if (lane == 0) pc.bytes(DBG_RESCORE, 8ull * P + 8ull * ncand + ion_bytes);
         // shape of the work: (ion, charge) items of all candidates, of the longest candidate, candidates, peaks
-        const uint32_t items = wave_sum(n_items);
-        uint32_t longest = n_items;
+        const uint32_t items = wave_sum(SAGE_N_ITEMS);
+        uint32_t longest = SAGE_N_ITEMS;
         for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)longest, o, 64); longest = v > longest ? v : longest; }
         const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
         if (lane == 0) { atomicAdd(&pc.slot[5], items); atomicAdd(&pc.slot[6], longest); atomicAdd(&pc.slot[7], nvalid); }
@@ -2020,9 +2159,9 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
         if (round == 0) build_peak_bitmap(pbm, inv_wb, pm, P, sc.fragment_tol);
         __syncthreads();
         Score s;
-        s.peptide = pep;
-        s.precursor_charge = z;
-        s.isotope_error = iso;
+        s.peptide = 0;  // (the lane's pep / z / iso stand in for the fields of the same name)
+        s.precursor_charge = 0;
+        s.isotope_error = 0;
         s.matched_b = s.matched_y = 0;
         s.summed_b = s.summed_y = 0.0f;
         s.ppm_difference = 0.0f;
@@ -2204,12 +2343,12 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
             // largest elements.  heap.rs compares with `<` / `>`, i.e. the DERIVED PartialOrd of Score — lexicographic
             // in field order, peptide first (scoring.rs:17-30) — not its hyperscore Ord.  The set of the k largest does
             // not depend on the heap's internal order, so rank each passing candidate by that order directly.
-            QuickKey* qk = qkeys;
-            QuickKey mine;
-            mine.peptide = pep; mine.matched_b = s.matched_b; mine.matched_y = s.matched_y;
-            mine.summed_b = s.summed_b; mine.summed_y = s.summed_y; mine.longest_b = s.longest_b; mine.longest_y = s.longest_y;
-            mine.hyperscore = h; mine.ppm_difference = s.ppm_difference; mine.charge = z; mine.iso = iso;
-            qk[lane] = mine;
+            QuickKey* qk = R.qkeys;
+            QuickKey mk;
+            mk.peptide = pep; mk.matched_b = s.matched_b; mk.matched_y = s.matched_y;
+            mk.summed_b = s.summed_b; mk.summed_y = s.summed_y; mk.longest_b = s.longest_b; mk.longest_y = s.longest_y;
+            mk.hyperscore = h; mk.ppm_difference = s.ppm_difference; mk.charge = z; mk.iso = iso;
+            qk[lane] = mk;
             const uint64_t pmask = __ballot(pass);
             const uint32_t npass = (uint32_t)__popcll(pmask);
             const uint32_t kq = sc.report_psms < npass ? sc.report_psms : npass;  // scoring.rs:284
@@ -2220,11 +2359,11 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
                 while (m) {
                     const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
                     m &= m - 1;
-                    above += j != lane && quick_gt(qk[j], mine);
+                    above += j != lane && quick_gt(qk[j], mk);
                 }
                 if (above < kq) keep[pep] = 1;
             }
-            return;
+            return true;
         }
         // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation
         const long long key = order_key64(h);
@@ -2244,40 +2383,38 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
             rank = pass && lane == wl ? 0u : 1u;
             best_h = from_order_key64(best_key);
             next_h = npass > 1 ? from_order_key64(second_key) : 0.0;
-            tie = pass && rank == 0 && npass > 1 && second_key == best_key;
+            tie = (wins & (wins - 1)) != 0ull;
         } else {
-            s_key[lane] = key;
+            R.s_key[lane] = key;
             __syncthreads();
             if (pass) {
                 uint64_t m = pmask;
                 while (m) {
                     const uint32_t j = (uint32_t)__ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const long long kj = s_key[j];
+                    const long long kj = R.s_key[j];
                     rank += (kj > key) || (kj == key && j < lane);
                 }
-                s_sorted[rank] = h;
+                R.s_sorted[rank] = h;
             }
             __syncthreads();
             if (pass && rank < per_round) {
-                next_h = rank + 1 < npass ? s_sorted[rank + 1] : 0.0;
-                best_h = s_sorted[0];
-                tie = rank + 1 < npass && __double_as_longlong(s_sorted[rank]) == __double_as_longlong(s_sorted[rank + 1]);
+                next_h = rank + 1 < npass ? R.s_sorted[rank + 1] : 0.0;
+                best_h = R.s_sorted[0];
+                tie = rank + 1 < npass && __double_as_longlong(R.s_sorted[rank]) == __double_as_longlong(R.s_sorted[rank + 1]);
             }
+        }
+        if (!list_is_exact && __ballot(tie) != 0ull) {
+            // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two equal
+            // hyperscores meet at a reported rank (i, i + 1 with i < per_round).  Otherwise: the exact heap layouts are needed.
+            if (queue_on_tie && lane == 0) {
+                w.status[spec] = ST_RETRY;
+                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+                out_count[spec] = 0;
+            }
+            return false;
         }
         pc.mark(3);
-        if (!sc.exact) {
-            // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two
-            // equal hyperscores meet at a reported rank (i, i+1 with i < per_round).  Otherwise: back through the exact path.
-            if (__ballot(tie) != 0ull) {
-                if (lane == 0) {
-                    w.status[spec] = ST_RETRY;
-                    w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
-                    out_count[spec] = 0;
-                }
-                return;
-            }
-        }
         if (pass && rank < per_round) {  // scoring.rs:504-594
             const double next = next_h, best = best_h;
             const float precursor_mass = mzp * (float)z;
@@ -2285,6 +2422,8 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
             const double log10_poisson =
                 ((double)k * log(lambda) - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
             const float isotope_error = (float)iso * NEUTRON;
+            const uint32_t info = db.pep_info[pep];
+            const float calc = db.pep_mono[pep];
             const float delta_mass =
                 (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
             const uint32_t plen = info & 0xFFFF;
@@ -2310,30 +2449,269 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
             f.matched_peaks = k;
             f.longest_b = s.longest_b;
             f.longest_y = s.longest_y;
-            f.scored_candidates = w.totals[2 * spec + 1];
+            f.scored_candidates = tot_scored;
             f.peptide_len = plen;
             f.file_id = fid;
             f.charge = (uint8_t)z;
             f.missed_cleavages = (uint8_t)(info >> 24);
             for (int q = 0; q < 6; q++) f.pad[q] = 0;
-            out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
+            *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
+        }
+        const uint32_t emitted = npass < per_round ? npass : per_round;
+        // the records of this round leave together: consecutive ranks are consecutive records, so the wavefront stores them as
+        // one contiguous run of dwords (full write requests, whether `out` is HBM or the caller's page-locked host memory)
+        __syncthreads();
+        {
+            uint32_t* __restrict__ dst = (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
+            for (uint32_t i = lane; i < emitted * FEATURE_WORDS; i += WAVE) dst[i] = R.stage[i];
         }
         pc.mark(4);
-        const uint32_t emitted = npass < per_round ? npass : per_round;
         n_emitted += emitted;
         if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
 
         // ---- remove_matched_peaks(winner), scoring.rs:598-644 ----
         const uint64_t wmask = __ballot(pass && rank == 0);
         const uint32_t wl = (uint32_t)__ffsll((long long)wmask) - 1;
-        const uint32_t wmfc = __shfl(mfc, wl, 64);
-        const uint32_t w_items = __shfl(n_items, wl, 64);
+        const uint32_t wmfc = __shfl(nfz + 1, wl, 64);
+        const uint32_t w_items = __shfl(SAGE_N_ITEMS, wl, 64);
         const unsigned long long w_base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(ion_base >> 32), (int)wl, 64) << 32) |
                                           (uint32_t)__shfl((int)(uint32_t)ion_base, (int)wl, 64);
         const float* wions = db.ions + w_base;
-        remove_matched_peaks_dev(pm, pi, rm, rm2, P, tic, wions, w_items, wmfc, sc.fragment_tol);
+        remove_matched_peaks_dev(pm, pi, R.rm, R.rm2, P, tic, wions, w_items, wmfc, sc.fragment_tol);
     }
     if (lane == 0) out_count[spec] = n_emitted;
+    return true;
+#undef SAGE_N_ITEMS
+}
+
+// scratch bytes of the fused kernel: the preliminary phase's LDS and the rescoring scratch take turns in them
+__host__ __device__ inline size_t narrow_scratch_bytes(const DevScorer& sc, const DevBatchView& b) {
+    const size_t a = prelim_layout_bytes(sc, b), c = (rescore_scratch_bytes(false) + 15) & ~(size_t)15;
+    return a > c ? a : c;
+}
+
+// Rescoring as a kernel of its own, behind prelim_kernel / the large-window kernels (candidate lists in HBM).  A spectrum whose
+// reported ranks tie in hyperscore is queued for the exact retry pass.  (Settling the tie here — the preliminary phase once more
+// with exact trims, inline or behind a call — was measured: the extra code costs the hot path its registers, rescoring went
+// from 3.7 to 6.0 resp. 7.2 ms per 500 000 C3 spectra.  DESIGN.md 4.7.)
+template <bool PROF>
+__global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+                                                     const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                     SageFeature* __restrict__ out,
+                                                     uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
+    typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    if (blockIdx.x >= b.n) return;
+    uint32_t n_batch = b.n;
+    if (b.n_dev) {  // retry pass: device-side count
+        n_batch = *b.n_dev < n_batch ? *b.n_dev : n_batch;
+        if (blockIdx.x >= n_batch) return;
+    }
+    const uint32_t pos = xcd_position(blockIdx.x, n_batch, sc.xcd_chunk);
+    const uint32_t spec = b.order ? b.order[pos] : pos;
+    const uint32_t st = w.status[spec];
+    if (st == ST_DONE) return;  // reported by the fused narrow kernel of this pass
+    if (st != ST_OK) {
+        if (lane == 0 && !keep) out_count[spec] = 0;
+        return;
+    }
+    const RescoreLds R = carve_rescore(smem, smem + ((rescore_scratch_bytes(keep != nullptr) + 15) & ~(size_t)15), b);
+    Clock pc;
+    pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blockIdx.x, 1);
+    const uint64_t p0 = b.peak_off[spec];
+    const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        R.pm[i] = b.masses[p0 + i];
+        R.pi[i] = b.intensities[p0 + i];
+    }
+    const uint32_t ncand = w.cand_len[spec];
+    const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
+    rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
+                     sc.exact != 0, true, pc);
+}
+
+// ---- the first pass of a narrow search as ONE launch of two kinds of workgroups ----------------------------------------------------
+// Matching + k-select (prelim_spectrum) and rescoring (rescore_spectrum) are separate wavefronts, as in prelim_kernel /
+// rescore_kernel — each body keeps its own register allocation; one wavefront doing both (narrow_kernel) pays 70-100 spills — but
+// they share a launch: workgroup ids alternate between the two roles in groups of eight (one of each kind per XCD), the
+// rescoring workgroup of a spectrum trailing its preliminary workgroup by SEARCH_LAG ids, and the hand-over is a per-spectrum
+// word in HBM (DevWork::ready == the launch's epoch; payload and word are agent-scope write-through stores, the consumer polls the
+// word and reads the payload with agent-scope loads — no fences: a release per spectrum writes the L2 back every time).
+// What that buys over two launches: one cold start instead of two (every launch begins with empty L2s: ~0.13 ms per kernel on
+// C3, a third of a 62 500-spectrum step), no drain between the phases, and CUs that run memory-bound matching next to VALU-bound
+// rescoring all the time.  Forward progress: a workgroup only ever waits for one with a smaller id, which was dispatched before
+// it and waits for nobody.
+constexpr uint32_t SEARCH_LAG = 8192;  // ids (a multiple of 8): ~1.6 x the wavefronts resident on the GPU, so the wait is rare
+struct SearchRole {
+    bool rescoring;
+    uint32_t v;  // the role's virtual workgroup id (v % 8 == the XCD it runs on, like a plain launch of that role)
+};
+__host__ __device__ inline uint32_t search_slots(uint32_t n) { return (n + 7u) & ~7u; }
+__host__ __device__ inline uint32_t search_lag(uint32_t n, uint32_t want) {
+    want = want ? (want + 7u) & ~7u : SEARCH_LAG;
+    return search_slots(n) < want ? search_slots(n) : want;
+}
+__host__ __device__ inline SearchRole search_role(uint32_t b, uint32_t n, uint32_t want_lag) {
+    const uint32_t np = search_slots(n), lag = search_lag(n, want_lag);
+    SearchRole r;
+    if (b < lag) {  // head: preliminary only
+        r.rescoring = false;
+        r.v = b;
+    } else if (b < 2 * np - lag) {  // groups of eight, alternating
+        const uint32_t q = (b - lag) >> 3, i = (b - lag) & 7u;
+        r.rescoring = (q & 1u) != 0;
+        r.v = (r.rescoring ? 0u : lag) + (q >> 1) * 8u + i;
+    } else {  // tail: the last `lag` rescoring workgroups
+        r.rescoring = true;
+        r.v = np - lag + (b - (2 * np - lag));
+    }
+    return r;
+}
+template <bool PROBE, bool PROF>
+__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+                                                                           const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                                           SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+    typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const SearchRole role = search_role(blockIdx.x, b.n, w.search_lag);
+    if (role.v >= b.n) return;
+    const uint32_t pos = xcd_position(role.v, b.n, sc.xcd_chunk);
+    const uint32_t spec = b.order ? uni(b.order[pos]) : pos;
+    if (!role.rescoring) {
+        const PrelimLds L = carve_prelim(smem, sc, b);
+        Clock pc;
+        pc.start(w.dbg, role.v, 0);
+        const SpecInfo si = load_spec(sc, b, spec);
+        const PrelimResult r = prelim_spectrum<PROBE>(db, sc, b, L, si, false, pc);
+        // hand-over (cdna_hip_programming.md, guideline 16): the payload goes out WRITE-THROUGH (agent-scope stores: no release fence,
+        // which would write back the whole L2 once per spectrum — measured: 4 x the kernel time), the wavefront waits for its
+        // stores, one lane sets the word
+        if (r.deferred) {
+            if (lane == 0) {
+                __hip_atomic_store(w.status + spec, (uint32_t)ST_DEFERRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
+                w.queue[it] = spec;  // (read by the kernels of later launches)
+                w.item_of[spec] = it;
+            }
+        } else {
+            if (lane == 0) {
+                if (!r.ok) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
+                __hip_atomic_store(w.status + spec, (uint32_t)(r.ok ? ST_OK : ST_OVERFLOW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w.cand_len + spec, r.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w.totals + 2 * spec, r.matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w.totals + 2 * spec + 1, r.scored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (uint32_t i = lane; i < r.stored; i += WAVE)
+                __hip_atomic_store(w.cand + (size_t)spec * sc.kmax + i, L.listB[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pc.mark(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(w.ready + spec, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- rescoring role ----
+    const RescoreLds R = carve_rescore(smem, smem + ((rescore_scratch_bytes(false) + 15) & ~(size_t)15), b);
+    Clock pc;
+    pc.start(w.dbg, role.v, 1);
+    const uint64_t p0 = b.peak_off[spec];
+    const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+    for (uint32_t i = lane; i < P; i += WAVE) {  // (the peaks do not depend on the preliminary workgroup: in flight under the wait)
+        R.pm[i] = b.masses[p0 + i];
+        R.pi[i] = b.intensities[p0 + i];
+    }
+    // the consumer polls the one word (relaxed), then reads the payload with agent-scope loads: they take the vector path around
+    // this XCD's L2 lines and the scalar cache, which may hold the previous step's values of the same addresses
+    while (__hip_atomic_load(w.ready + spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch) __builtin_amdgcn_s_sleep(32);
+    asm volatile("" ::: "memory");
+    const uint32_t st = __hip_atomic_load(w.status + spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st != ST_OK) {  // queued for the large-window kernels (their rescoring follows in a launch of its own), or overflowed
+        if (lane == 0 && st == ST_OVERFLOW) out_count[spec] = 0;
+        return;
+    }
+    const uint32_t ncand = __hip_atomic_load(w.cand_len + spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tot_m = __hip_atomic_load(w.totals + 2 * spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tot_s = __hip_atomic_load(w.totals + 2 * spec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t mine = lane < ncand ? __hip_atomic_load(w.cand + (size_t)spec * sc.kmax + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : PRESCORE_EMPTY;
+    const bool done = rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s, false,
+                                       true, pc);
+    if (done && lane == 0) w.status[spec] = ST_DONE;  // (a rescore_kernel behind the large-window kernels leaves it alone)
+}
+
+// ---- the narrow search in ONE launch ---------------------------------------------------------------------------------------------
+// Scorer::score of a spectrum whose precursor windows fit the LDS counters: preliminary matching + k-select (prelim_spectrum)
+// and rescoring (rescore_spectrum) by the same wavefront; the candidate list never leaves the chip.  Spectra with a larger
+// window are queued for the large-window kernels exactly as prelim_kernel queues them.
+// Two uses.  (1) THE EXACT RETRY PASS (DevScorer::exact, spectrum list + count on the device): the spectra whose reported ranks
+// tied in rescore_kernel, again with bounded_min_heapify replayed — one launch, no candidate round trip, so the latency chain
+// a small batch pays for its ~3 % tied spectra is one wavefront's lifetime.  (2) SAGE_HIP_FUSED=1: the whole first pass, order-free
+// trims first and, on a tie, the same wavefront once more with exact trims.  On MI355X (2) is 10-17 % slower than prelim_kernel +
+// rescore_kernel although it executes the same instructions: the union of the two phases leaves the register allocator with
+// 70-100 spills to scratch (each a memory round trip the wavefront waits for) where the separate kernels have 0 and ~30
+// (profiles/r03_fused_vs_separate.md).
+template <bool PROBE, bool PROF>
+__global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+                                                                           const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                                           SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+    typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    uint32_t n_batch = b.n;
+    if (b.n_dev) {  // retry pass: the count is a device-side counter of the first pass
+        const uint32_t nd = uni(*b.n_dev);
+        n_batch = nd < n_batch ? nd : n_batch;
+    }
+    const PrelimLds L = carve_prelim(smem, sc, b);
+    const RescoreLds R = carve_rescore(smem, smem + narrow_scratch_bytes(sc, b), b);
+#pragma unroll 1
+    for (uint32_t blk = blockIdx.x; blk < n_batch; blk += gridDim.x) {
+        const uint32_t pos = xcd_position(blk, n_batch, sc.xcd_chunk);
+        const uint32_t spec = b.order ? uni(b.order[pos]) : pos;
+        const SpecInfo si = load_spec(sc, b, spec);
+        bool exact = sc.exact != 0;
+        uint32_t final_status = ST_DONE;
+#pragma unroll 1
+        for (;;) {
+            __syncthreads();
+            Clock pc;
+            pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
+            // the rescoring phase's copy of the peaks (its own: the chimera loop edits it); in flight under the window query
+            for (uint32_t i = lane; i < si.P; i += WAVE) {
+                R.pm[i] = b.masses[si.p0 + i];
+                R.pi[i] = b.intensities[si.p0 + i];
+            }
+            const PrelimResult r = prelim_spectrum<PROBE>(db, sc, b, L, si, exact, pc);
+            if (r.deferred) {
+                if (lane == 0) {
+                    const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
+                    w.queue[it] = spec;
+                    if (!w.reuse) w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
+                }
+                final_status = ST_DEFERRED;
+                break;
+            }
+            if (!r.ok) {
+                if (lane == 0) {
+                    atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
+                    out_count[spec] = 0;
+                }
+                final_status = ST_OVERFLOW;
+                break;
+            }
+            const uint64_t mine = lane < r.stored ? L.listB[lane] : PRESCORE_EMPTY;
+            pc.mark(4);
+            pc.rebase(1);  // (the rescoring phase accounts under kernel 1)
+            __syncthreads();  // the list is in registers: the preliminary phase's LDS is free
+            if (rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
+                                 exact, false, pc) || exact)
+                break;
+            exact = true;  // equal hyperscores at a reported rank: once more, with bounded_min_heapify replayed (heap.rs:7-28)
+            if (lane == 0) atomicAdd(w.n_deferred + CTR_TIED, 1u);
+        }
+        if (lane == 0) w.status[spec] = final_status;
+    }
 }
 
 // quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
@@ -2414,13 +2792,7 @@ __global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc
 
 }  // namespace
 
-size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
-    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 +
-               (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)3 * PROBE_BATCH_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
-    n += ((size_t)sc.wcap / 2 + 1) * 4;
-    return (n + 15) & ~(size_t)15;
-}
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return prelim_layout_bytes(sc, b); }
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8) {
     return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8);
 }
@@ -2433,18 +2805,38 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
-size_t rescore_lds_bytes(const DevScorer&, const DevBatchView& b, uint32_t, bool quick) {
-    size_t n = PBM_WORDS * 4 + PLUT_BINS * 4 + 128 * 8 + (size_t)b.pcap * 8 + (size_t)b.pcap * 2;
-    n = ((n + 7) & ~(size_t)7) + (quick ? 64 * sizeof(QuickKey) : 0);  // (the key array is quick_score's)
-    return (n + 15) & ~(size_t)15;
+size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, bool quick) {
+    return ((rescore_scratch_bytes(quick) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b);
 }
+size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return narrow_scratch_bytes(sc, b) + rescore_fixed_bytes(sc, b); }
 
+size_t search_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
+    const size_t a = prelim_layout_bytes(sc, b), r = rescore_lds_bytes(sc, b, 0, false);
+    return a > r ? a : r;
+}
+void launch_search(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                   uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream) {
+    if (b.n == 0) return;
+    auto k = b.probe ? (w.dbg ? search_kernel<true, true> : search_kernel<true, false>)
+                     : (w.dbg ? search_kernel<false, true> : search_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(2 * search_slots(b.n)), dim3(64), search_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w, lnfact_table,
+                       lnfact_n, out, out_count);
+}
+void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                   uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream) {
+    if (b.n == 0) return;
+    auto k = b.probe ? (w.dbg ? narrow_kernel<true, true> : narrow_kernel<true, false>)
+                     : (w.dbg ? narrow_kernel<false, true> : narrow_kernel<false, false>);
+    // (a retry pass holds a few per cent of the batch: a capped grid strides over the device-side list)
+    const uint32_t grid = b.n_dev ? (b.n < RETRY_GRID_CAP ? b.n : RETRY_GRID_CAP) : b.n;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), narrow_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out,
+                       out_count);
+}
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0) return;
-    if (b.probe)
-        hipLaunchKernelGGL(prelim_kernel<true>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
-    else
-        hipLaunchKernelGGL(prelim_kernel<false>, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
+    auto k = b.probe ? (w.dbg ? prelim_kernel<true, true> : prelim_kernel<true, false>)
+                     : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0 || w.tile_blocks == 0) return;
@@ -2481,8 +2873,8 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
-    hipLaunchKernelGGL(rescore_kernel, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, db,
-                       sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
+    hipLaunchKernelGGL(w.dbg ? rescore_kernel<true> : rescore_kernel<false>, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
+                       (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
     if (b.n == 0) return;

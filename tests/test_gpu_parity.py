@@ -273,7 +273,8 @@ def test_quick_score_prefilter(small_world, low_memory):
 def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     """Order-free trims (the default) are only valid while no two equal hyperscores meet at a reported rank; isoleucine /
     leucine twins (identical masses and fragments) tie exactly, so those spectra must come back through the exact heap
-    replay — and still equal the oracle, whose order is the reference's heap layout."""
+    replay — inside the fused narrow kernel (n_tied), in the retry pass for large windows or the separate kernels (n_retry) —
+    and still equal the oracle, whose order is the reference's heap layout."""
     monkeypatch.delenv("SAGE_HIP_EXACT", raising=False)
     fasta = synthetic_fasta(60, seed=17)
     twin = fasta.replace("I", "#").replace("L", "I").replace("#", "L").replace(">sp|SYN", ">sp|TWN")
@@ -287,9 +288,28 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     assert t["n_retry"] > 10 and t["n_wide"] > 0
     n, t = w.check(ScorerParams(chimera=True, report_psms=3), "I/L twins, chimera")
     assert t["n_retry"] > 50
+    monkeypatch.setenv("SAGE_HIP_FUSED", "1")  # the fused narrow kernel: the wavefront goes round again with exact trims
+    n, t = w.check(ScorerParams(report_psms=2), "I/L twins, narrow, fused kernel")
+    assert t["n_tied"] > 50 and t["n_retry"] == 0
+    n, t = w.check(ScorerParams(chimera=True, report_psms=3), "I/L twins, chimera, fused kernel")
+    assert t["n_tied"] > 50
+    n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2), "I/L twins, isotope errors, fused kernel")
+    monkeypatch.delenv("SAGE_HIP_FUSED")
+    monkeypatch.setenv("SAGE_HIP_ONE_LAUNCH", "1")  # preliminary and rescoring workgroups in one launch, handing over through HBM
+    n, t = w.check(ScorerParams(report_psms=2), "I/L twins, narrow, one launch")
+    assert t["n_retry"] > 50
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0), chimera=True, report_psms=3), "I/L twins, mixed routing, chimera, one launch")
+    monkeypatch.delenv("SAGE_HIP_ONE_LAUNCH")
+    n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2), "I/L twins, isotope errors")
+    assert t["n_retry"] > 50 and t["n_tied"] == 0
+    monkeypatch.setenv("SAGE_HIP_ASSUME_NARROW", "1")  # a batch wrongly taken for narrow-only is scored again with the large-window kernels
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -200.0, 200.0), report_psms=3), "I/L twins, large windows, wrong guess",
+                   batch=w.batch.subset(np.arange(0, 300, 3)))
+    assert t["n_wide"] > 0
+    monkeypatch.delenv("SAGE_HIP_ASSUME_NARROW")
     monkeypatch.setenv("SAGE_HIP_EXACT", "1")  # every trim replays the heap: no retries by construction
     n, t = w.check(ScorerParams(report_psms=2), "I/L twins, exact mode")
-    assert t["n_retry"] == 0
+    assert t["n_retry"] == 0 and t["n_tied"] == 0
 
 
 def test_index_built_on_device(small_world):
@@ -399,7 +419,7 @@ def test_streaming_pipeline_chunks(small_world, monkeypatch):
             valid = np.arange(gf.shape[1])[None, :] < gc[:, None]
             assert np.array_equal(gf["spec_index"][valid], np.broadcast_to(np.arange(batch.n)[:, None], gf.shape)[valid])
         t = scorer.last_timing()
-        assert n > 100 and t["n_launches"] >= 10 * 12  # ten chunks, two passes each
+        assert n > 100 and t["n_launches"] >= 10 * 3  # ten chunks: two kernels + the retry pass each, more with the large-window path
     # a chunk boundary that leaves a last chunk of one spectrum, and a batch smaller than a chunk
     scorer = Scorer(small_world.dev, ScorerParams())
     for m in (65, 64, 3, 1):
