@@ -180,6 +180,8 @@ struct SageScorer {
     std::mutex mu;                   // entry points taking this handle serialise on it (clone the scorer for concurrency)
     hipStream_t stream = nullptr;    // compute (and, for resident batches, the result download)
     hipStream_t up_stream = nullptr, down_stream = nullptr;  // streaming pipeline: H2D of batch c + 1, D2H of batch c - 1
+    hipStream_t side_stream = nullptr;  // kernels of one batch that may run next to each other (the two heap-replay kernels)
+    Event side_fork, side_join;
     DevBuf<double> lnfact;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
@@ -673,6 +675,9 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    HIP_TRY(s->side_fork.create(false));
+    HIP_TRY(s->side_join.create(false));
     for (OutSet& o : s->outs) {
         for (auto& e : o.ev) HIP_TRY(e.create(true));
         HIP_TRY(o.comp_done.create(false));
@@ -719,7 +724,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
 
 static void scorer_release(SageScorer* s) {
     (void)hipSetDevice(s->db->device);
-    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream})
+    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream, s->side_stream})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
@@ -1230,6 +1235,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         w2.reuse = 1;
         w2.arena_ptr = w1.arena_ptr;
     }
+    const SideStream side{s->side_stream, s->side_fork.e, s->side_join.e};
     DevScorer sc1 = sc, sc2 = sc;
     sc1.exact = mode == MODE_EXACT ? 1u : 0u;
     sc2.exact = 1u;
@@ -1243,7 +1249,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         launch_prelim(s->db->view, sc1, view, w1, st);
     HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
     if (wide) {
-        launch_prelim_tile(s->db->view, sc1, view, w1, st);
+        launch_prelim_tile(s->db->view, sc1, view, w1, st, &side);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(o.ev[1].e, st));
@@ -1254,7 +1260,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
         HIP_TRY(hipGetLastError());
         if (wide) {
-            launch_prelim_tile(s->db->view, sc2, v2, w2, st);
+            launch_prelim_tile(s->db->view, sc2, v2, w2, st, &side);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(o.ev[3].e, st));

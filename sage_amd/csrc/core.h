@@ -493,4 +493,22 @@ SAGE_HD uint32_t peak_bitmap_bin(float inv_wb, float mz) {
 #endif
 }
 
+// The bins of one ion for fragment charges 1..3 from ONE conversion: inv_wb is a power of two (or 0), so x = ion * inv_wb is
+// exact and floor(floor(x) / c) == floor(x / c) is the bin of the EXACT quotient ion / c — at least as close to the reference's
+// rounded ion / charge as the approximate quotients peak_bitmap_bin is fed (the slack in D covers half an ulp either way).  The
+// conversion is clamped at 3 * PBM_BITS - 1 rather than PBM_BITS - 1: an ion beyond the bitmap's span may still have its half or
+// its third inside it.  bins[c - 1] <= PBM_BITS - 1.
+SAGE_HD uint32_t peak_bitmap_index3(float inv_wb, float ion) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_fmed3f(ion * inv_wb, 0.0f, (float)(3 * PBM_BITS - 1));
+#else
+    const float f = ion * inv_wb;
+    return (uint32_t)(f > 0.0f ? (f < (float)(3 * PBM_BITS - 1) ? f : (float)(3 * PBM_BITS - 1)) : 0.0f);  // (also maps NaN to 0)
+#endif
+}
+SAGE_HD uint32_t peak_bitmap_bin_c1(uint32_t idx3) { return idx3 < PBM_BITS - 1 ? idx3 : PBM_BITS - 1; }
+SAGE_HD uint32_t peak_bitmap_bin_c2(uint32_t idx3) { return (idx3 >> 1) < PBM_BITS - 1 ? (idx3 >> 1) : PBM_BITS - 1; }
+SAGE_HD uint32_t peak_bitmap_bin_c3(uint32_t idx3) { return (idx3 * 43691u) >> 17; }  // == idx3 / 3 for idx3 < 2^16 (43691 = ceil(2^17 / 3))
+static_assert(3 * PBM_BITS - 1 < 65536, "the multiply-shift division by three holds below 2^16");
+
 }  // namespace sagecore

@@ -137,6 +137,7 @@ struct QueryRec {
     uint32_t pad[2];      // [0] bit 0: some count >= 63 (clipped histogram), bits 8..: k-th largest count T; [1] slots == T to skip
     uint32_t n_dir;       // directory entries: tiles of the window x wavefronts of the count kernel, in slot order
     uint32_t t0;          // first tile of the window
+    uint32_t n_cand;      // candidate words behind the directory (the length of the stream a heap replay walks)
 };
 
 // device-side SageFragments (sage_hip.h)
@@ -171,7 +172,14 @@ void launch_search(const DevDbView& db, const DevScorer& sc, const DevBatchView&
 void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
                    uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
-void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
+// `side`: a second stream + two events (hipStream_t, hipEvent_t x 2) for the launches that may run next to each other, or null
+struct SideStream {
+    void* stream;
+    void* fork;
+    void* join;
+};
+void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
+                        const SideStream* side = nullptr);
 uint32_t queries_per_spectrum(const DevScorer& sc);
 // index_build.hip (both return a hipError_t)
 int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,

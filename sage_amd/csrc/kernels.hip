@@ -250,68 +250,44 @@ __device__ __forceinline__ void wh_offer(WaveHeap& h, uint32_t k, uint64_t v) { 
 
 // The same heap with 32-bit keys, for the k-select of ONE precursor-window query: charge and isotope error are constant inside a
 // query, so PreScore's order is (matched, peptide) = (matched, candidate slot), and `matched << S | slot` orders identically (an
-// empty slot is key 0; no key is 0xFFFFFFFF).  This replay is the latency chain of the exact retry pass — a wavefront does
-// ~100 of these sifts one after the other — so it is written for latency: next to the heap (lane i = node i) every lane keeps
-// ITS CHILDREN's values (hl, hr), which makes "the right child is the smaller one", for all nodes at once, ONE v_cmp into a
-// scalar mask; the root-to-leaf path then follows from scalar bit operations alone, its values are read with independent
-// v_readlane's (no cross-lane permutes, no LDS), and the shift along the path is a handful of lane-select writes.
+// empty slot is key 0).  This replay is THE serial chain of the exact retry pass — a large-window query feeds it thousands of
+// offers, one after the other, in a wavefront that runs almost alone on its SIMD — and such a wavefront retires an instruction
+// every ~7 cycles whatever the instruction: what counts is how many there are.  So: plain sift_down, scalar control flow, two
+// v_readlane per level for the children, one v_writelane per level; no cross-lane permutes, no ballots, no per-node copies
+// (three earlier versions that shortened the dependency chain instead executed 2-3 x the instructions and were slower;
+// profiles/r03_replay.md).
 struct Heap32 {
-    uint32_t h;       // node `lane`
-    uint32_t hl, hr;  // its children 2 * lane + 1, 2 * lane + 2 (0xFFFFFFFF: none)
+    uint32_t h;  // node `lane`
 };
 __device__ __forceinline__ uint32_t wh32_get(const Heap32& H, uint32_t idx) {
     return (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)__builtin_amdgcn_readfirstlane(idx));
 }
-__device__ __forceinline__ void wh32_set(Heap32& H, uint32_t node, uint32_t val) {  // node, val: wave-uniform
-    const uint32_t lane = lane_id();
-    H.h = lane == node ? val : H.h;  // (v_writelane as compare + select: no lane-select hazards for the compiler to miss)
-    // the parent's copy: child 2p + 1 is odd, 2p + 2 even; node 0 has no parent (lane 64 does not exist)
-    const uint32_t pl = (node & 1u) ? (node - 1u) >> 1 : 64u, pr = (node && !(node & 1u)) ? (node - 1u) >> 1 : 64u;
-    H.hl = lane == pl ? val : H.hl;
-    H.hr = lane == pr ? val : H.hr;
+// vdst[lane `sel`] = val, both wave-uniform: one v_writelane_b32 (no builtin for it in this toolchain).  gfx9 lets a VALU
+// instruction read ONE scalar register, so the lane select travels in M0; the compiler's hazard recogniser does not look inside
+// an asm statement, hence the wait states behind the M0 write are spelled out.
+__device__ __forceinline__ void writelane(uint32_t& vdst, uint32_t val, uint32_t sel) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %1, m0" : "+v"(vdst) : "s"(val), "s"(sel) : "m0");
 }
-__device__ __forceinline__ void wh32_init(Heap32& H, uint32_t keys, uint32_t k) {  // lane i brings element i (i < k)
-    const uint32_t lane = lane_id();
-    const uint32_t l = 2 * lane + 1, r = l + 1;
-    const uint32_t vl = (uint32_t)__shfl((int)keys, (int)(l & 63u), 64), vr = (uint32_t)__shfl((int)keys, (int)(r & 63u), 64);
-    H.h = keys;
-    H.hl = l < k ? vl : 0xFFFFFFFFu;
-    H.hr = r < k ? vr : 0xFFFFFFFFu;
-}
-// sift_down (heap.rs:40-60) of value `moving` placed at `index`.  sift_down always descends to the smaller child (the left one
-// on a tie), a path that does not depend on the value being sifted; values along a heap path never decrease, so `moving` stops
-// at the first path value that is not smaller.  All control flow is wave-uniform.
+__device__ __forceinline__ void wh32_init(Heap32& H, uint32_t keys, uint32_t k) { H.h = lane_id() < k ? keys : 0xFFFFFFFFu; }
+// sift_down (heap.rs:40-60) of value `moving` placed at `index`: descend to the smaller child (the left one on a tie) while it
+// is smaller than `moving`, shifting it up (slice.swap at every level).  All control flow is wave-uniform.
 __device__ __forceinline__ void wh32_sift_from(Heap32& H, uint32_t len, uint32_t index, uint32_t moving) {
-    const uint64_t rightmin = __ballot(H.hr < H.hl);  // bit p: the right child of node p is strictly smaller
-    index = __builtin_amdgcn_readfirstlane(index);
+    uint32_t p = __builtin_amdgcn_readfirstlane(index);
     moving = __builtin_amdgcn_readfirstlane(moving);
-    uint32_t path[7], pv[7];
-    bool on[7];
-    path[0] = index;
-    on[0] = true;
-#pragma unroll
-    for (uint32_t j = 0; j < 6; j++) {  // the whole path first (scalar), then its values (independent reads)
-        const uint32_t lc = 2 * path[j] + 1;
-        on[j + 1] = on[j] && lc < len;
-        path[j + 1] = on[j + 1] ? lc + (uint32_t)((rightmin >> (path[j] & 63u)) & 1ull) : 0u;
+    for (;;) {
+        const uint32_t l = 2 * p + 1;
+        if (l >= len) break;
+        uint32_t c = l;
+        uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)l);
+        if (l + 1 < len) {
+            const uint32_t rv = (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)(l + 1));
+            if (rv < cv) { cv = rv; c = l + 1; }
+        }
+        if (!(cv < moving)) break;
+        writelane(H.h, cv, p);
+        p = c;
     }
-#pragma unroll
-    for (uint32_t j = 1; j <= 6; j++) pv[j] = (uint32_t)__builtin_amdgcn_readlane((int)H.h, (int)path[j]);
-    uint32_t n = 0;  // nodes below `index` on the path that hold a value smaller than `moving`
-    bool go = true;
-#pragma unroll
-    for (uint32_t j = 1; j <= 6; j++) {
-        go = go && on[j] && pv[j] < moving;
-        n += go ? 1u : 0u;
-    }
-    // shift the path up by one level and drop `moving` where it stopped (slice.swap at every level)
-#pragma unroll
-    for (uint32_t j = 0; j < 6; j++)
-        if (j < n) wh32_set(H, path[j], pv[j + 1]);
-    uint32_t dst = index;
-#pragma unroll
-    for (uint32_t j = 1; j <= 6; j++) dst = j == n ? path[j] : dst;
-    wh32_set(H, dst, moving);
+    writelane(H.h, moving, p);
 }
 __device__ __forceinline__ void wh32_build(Heap32& H, uint32_t k) {  // heap.rs:13-15
     for (uint32_t i = k / 2; i-- > 0;) wh32_sift_from(H, k, i, wh32_get(H, i));
@@ -993,7 +969,7 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     return (off + 15) & ~(size_t)15;
 }
 
-enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_DIR, SH_ARENA_OK, SH_CHUNK_CUR, SH_CHUNK_LIM, SH_THR, SH_OVF };
+enum { SH_ITEM = 0, SH_LEFT, SH_RIGHT, SH_FIRST, SH_END, SH_MATCHED, SH_SCORED, SH_DIR, SH_ARENA_OK, SH_CHUNK_CUR, SH_CHUNK_LIM, SH_THR, SH_OVF, SH_NCAND };
 constexpr uint32_t ARENA_CHUNK = 1u << 16;  // entries a workgroup takes from the global arena at a time
 
 __device__ __forceinline__ uint32_t query_index(const DevScorer& sc, const SpecInfo& si, uint32_t z, int iso) {
@@ -1126,7 +1102,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
-                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0;
+                        l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0; l_sh[SH_NCAND] = 0;
                         const uint32_t lp = q.right < db.np ? q.right : db.np - 1;
                         const uint32_t nt = db.np ? (lp >> TSH) - (q.left >> TSH) + 1 : 1;
                         const uint32_t words = (nt * TILE_WAVES * DIR_WORDS + 3u) & ~3u;
@@ -1283,8 +1259,10 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     unit_cells = uni(psA.x + psA.y + psA.z + psA.w + psB.x + psB.y + psB.z + psB.w);
                     if (pc.slot && tid == 0) {
                         const uint32_t pb = (u % nb) * TILE_THREADS;
-                        pc.bytes(DBG_TILE_LUT, 8ull * (nprobe - pb < TILE_THREADS ? nprobe - pb : TILE_THREADS));
-                        pc.bytes(DBG_TILE_CELLS, 16ull * unit_cells);
+                        if (!(sc.dbg_flags & 1024u)) {
+                            pc.bytes(DBG_TILE_LUT, 8ull * (nprobe - pb < TILE_THREADS ? nprobe - pb : TILE_THREADS));
+                            pc.bytes(DBG_TILE_CELLS, 16ull * unit_cells);
+                        }
                     }
                 };
                 issue_lut(0);
@@ -1395,6 +1373,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             const uint32_t d = dir + ((t - t0) * TILE_WAVES + wave) * DIR_WORDS;
                             w.arena[d] = at;
                             w.arena[d + 1] = n_out;
+                            if (n_out) atomicAdd(&l_sh[SH_NCAND], n_out);
                             if (w.dbg) atomicAdd(w.dbg + (size_t)(item % DBG_BLOCKS) * 32 + DBG_TILE_CAND, 4ull * n_out + 8ull);
                         }
                         run_at = uni(at);
@@ -1505,6 +1484,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         r.pad[1] = T ? n_eq - (k - n_gt) : 0;             // slots equal to T to skip
                         r.n_dir = dir != NONE32 ? (t1 - t0 + 1) * TILE_WAVES : 0;
                         r.t0 = t0;
+                        r.n_cand = l_sh[SH_NCAND];
                         w.qrec[qid] = r;
                     }
                 }
@@ -1536,6 +1516,39 @@ __device__ __forceinline__ DirRun dir_run(const DevWork& w, const QueryRec& rec,
     r.n = ((uint64_t)v.x + v.y <= w.arena_cap) ? v.y : 0u;
     r.tile_base = (rec.t0 + d / TILE_WAVES) << w.tile_shift;
     return r;
+}
+
+// A query's candidate stream by ONE WAVEFRONT, 64 words at a time in slot order, whatever runs they sit in: the runs of a window
+// are many and short (one per tile and count-kernel wavefront, a handful of candidates each), and walking them one by one is two
+// dependent HBM round trips per run.  Here 64 directory entries are read at once (a lane each), a prefix sum of their lengths
+// turns "word k of the block" into (run, offset) — the owner search is six cross-lane reads — and the next 64 words are in
+// flight while f(word, tile base of the word's run) works on the current ones.  Holes (words with count 0) are passed on.
+template <class F>
+__device__ __forceinline__ void for_each_candidate_batch(const DevWork& w, const QueryRec& rec, F&& f) {
+    const uint32_t lane = lane_id();
+    for (uint32_t d0 = 0; d0 < rec.n_dir; d0 += WAVE) {
+        DirRun r{0u, 0u, 0u};
+        if (d0 + lane < rec.n_dir) r = dir_run(w, rec, d0 + lane);
+        const uint32_t incl = wave_incl_scan_dpp(r.n), excl = incl - r.n;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        auto fetch = [&](uint32_t base, uint32_t& e, uint32_t& tb) {
+            const uint32_t k = base + lane;
+            uint32_t own = 0;  // the largest lane whose run starts at or before word k (empty runs share their successor's start)
+#pragma unroll
+            for (uint32_t step = WAVE / 2; step; step >>= 1) own += (uint32_t)__shfl((int)excl, (int)(own + step), 64) <= k ? step : 0u;
+            const uint32_t at = (uint32_t)__shfl((int)r.at, (int)own, 64), first = (uint32_t)__shfl((int)excl, (int)own, 64);
+            tb = (uint32_t)__shfl((int)r.tile_base, (int)own, 64);
+            e = k < total ? w.arena[at + (k - first)] : 0u;
+        };
+        uint32_t e = 0, tb = 0, e_next = 0, tb_next = 0;
+        if (total) fetch(0, e, tb);
+        for (uint32_t base = 0; base < total; base += WAVE) {
+            if (base + WAVE < total) fetch(base + WAVE, e_next, tb_next);
+            f(e, tb);
+            e = e_next;
+            tb = tb_next;
+        }
+    }
 }
 
 // strided sift_down (heap.rs:40-60): element i of this lane's heap lives at hp[i * 64]
@@ -1685,7 +1698,8 @@ __device__ __forceinline__ uint64_t query_slot(const DevWork& w, uint64_t qid) {
     const uint32_t item = (uint32_t)(qid / w.qmax), q = (uint32_t)(qid % w.qmax);
     return (uint64_t)(w.item_of[w.queue[item]] & 0x7FFFFFFFu) * w.qmax + q;
 }
-__device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const DevWork& w, uint64_t* heap, uint64_t n_q, uint32_t blk) {
+__device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_t n_q, uint64_t wave_max);
+__device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const DevWork& w, uint64_t* heap, uint64_t n_q, uint32_t blk, uint64_t wave_max) {
     const uint32_t lane = lane_id();
     const uint64_t qid_in = (uint64_t)blk * 64 + lane;
     const uint64_t qid = qid_in < n_q ? query_slot(w, qid_in) : qid_in;
@@ -1699,6 +1713,7 @@ __device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const Dev
     const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
     // order-free mode: the heap is only replayed for queries tile_select_kernel cannot take (clipped histogram)
     if (!sc.exact && !(rec.pad[0] & 1u)) live = false;
+    if (live && replay_by_wavefront(rec, n_q, wave_max)) live = false;  // (the wavefront-per-query kernel's)
     if (__ballot(live) == 0ull) return;
     const bool small_keys = !(sc.dbg_flags & 2u) &&  // (SAGE_HIP_DEBUG_FLAGS=2: tests force the 64-bit path)
                             __ballot(live && (rec.potential > (1u << K32_SLOT_BITS) || (rec.pad[0] & 1u) != 0)) == 0ull;
@@ -1707,14 +1722,14 @@ __device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const Dev
 }
 // The grids of the four kernels below are capped (TILE_GRID_CAP) and stride over the device-side count of queued spectra:
 // a narrow search queues none, and half a million blocks that only read the counter and leave would cost ~0.3 ms per kernel.
-// (lo, hi]: the kernel only runs when the device-side query count lies in that range — the retry pass launches both replay
-// flavours and the count, which the host never sees, picks one)
-__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w, uint64_t lo, uint64_t hi) {
+// Both replay flavours are launched; the device-side query count, which the host never sees, and each query's stream length
+// decide which of the two takes a query (replay_by_wavefront).
+__global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w, uint64_t wave_max) {
     __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    if (n_q <= lo || n_q > hi) return;
+    if (n_q <= wave_max) return;
     for (uint64_t blk = blockIdx.x; blk * 64 < n_q; blk += gridDim.x) {
-        tile_replay_block(sc, w, heap, n_q, (uint32_t)blk);
+        tile_replay_block(sc, w, heap, n_q, (uint32_t)blk, wave_max);
         __syncthreads();
     }
 }
@@ -1744,15 +1759,11 @@ __device__ __forceinline__ void tile_select_query(const DevScorer& sc, const Dev
         eq_seen += (uint32_t)__popcll(eqm);
     };
     offer(lane < k ? w.seeds[qid * 64 + lane] : 0u, rec.left + lane);  // the first k slots
-    for (uint32_t d = 0; d < rec.n_dir; d++) {
-        const DirRun r = dir_run(w, rec, d);
-        for (uint32_t j = 0; j < r.n; j += WAVE) {
-            const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
-            // (a candidate below T can never be taken: skip the wavefront's bookkeeping when the whole row is below)
-            if (__ballot((e >> 16) >= T && e != 0u) == 0ull) continue;
-            offer(e >> 16, r.tile_base + (e & 0xFFFFu));
-        }
-    }
+    for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+        // (a candidate below T can never be taken: skip the wavefront's bookkeeping when the whole batch is below)
+        if (__ballot((e >> 16) >= T && e != 0u) == 0ull) return;
+        offer(e >> 16, tile_base + (e & 0xFFFFu));
+    });
     for (uint32_t i = (nsel < k ? nsel : k) + lane; i < k; i += WAVE) out[i] = PRESCORE_EMPTY;  // fewer than k non-empty slots
 }
 __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w) {
@@ -1763,36 +1774,46 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
 // The same replay with ONE WAVEFRONT per query (heap one element per lane, wh32_* / wh_* above): ~10x more work per
 // query than the lane-per-query kernel, but every query proceeds in parallel — the better choice while the batch has
 // fewer queries than the GPU has wavefront slots (an open search of ~10^4 spectra, or an exact retry pass).
-__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in) {
+// Which of the two replay kernels takes a query when both are launched (more queries than `wave_max`): the lane-per-query
+// kernel lasts as long as the longest stream among its 64 lanes, one word per round, so streams above LANE_MAX_CAND words go
+// to the wavefront-per-query kernel, which skims 64 words per step and only pays for the offers that enter the heap.
+constexpr uint32_t LANE_MAX_CAND = 4096;
+__device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_t n_q, uint64_t wave_max) {
+    if (wave_max == 0) return false;  // (SAGE_HIP_REPLAY_WAVE_MAX=0: tests force the lane-per-query kernel)
+    return n_q <= wave_max || rec.n_cand > LANE_MAX_CAND;
+}
+__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in, uint64_t n_q, uint64_t wave_max) {
     const uint32_t lane = lane_id();
     const uint64_t qid = query_slot(w, qid_in);
     const QueryRec rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
     if (rec.potential <= k || rec.matched == 0) return;        // no k-select: the assembler takes the slots verbatim
     if (!sc.exact && !(rec.pad[0] & 1u)) return;               // order-free mode: tile_select_kernel took it
+    if (!replay_by_wavefront(rec, n_q, wave_max)) return;      // a short stream among many: the lane-per-query kernel's
     const uint32_t z = rec.z_iso & 0xFFu;
     const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
     const bool small_keys = !(sc.dbg_flags & 2u) && rec.potential <= (1u << K32_SLOT_BITS) && !(rec.pad[0] & 1u);
     const uint32_t seed_c = lane < k ? w.seeds[qid * 64 + lane] : 0u;
+    // profiling builds of the numbers only (DevWork::dbg, row of kernel 3): [0] cycles, [1] offers that passed the ballot; the
+    // large-window byte counter rows [29] / [30] get the replayed queries / their stream words (SAGE_HIP_DEBUG_FLAGS=1024)
+    const long long t_start = w.dbg ? clock64() : 0;
+    uint32_t n_offers = 0;
     if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
         Heap32 hp;
         wh32_init(hp, seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u, k);
         wh32_build(hp, k);
-        for (uint32_t d = 0; d < rec.n_dir; d++) {
-            const DirRun r = dir_run(w, rec, d);
-            for (uint32_t j = 0; j < r.n; j += WAVE) {
-                const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
-                const uint32_t c = e >> 16;
-                const uint32_t v = (c << K32_SLOT_BITS) | (r.tile_base + (e & 0xFFFFu) - rec.left);
-                // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
-                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> K32_SLOT_BITS));
-                while (mask) {
-                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
-                }
+        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+            const uint32_t c = e >> 16;
+            const uint32_t v = (c << K32_SLOT_BITS) | (tile_base + (e & 0xFFFFu) - rec.left);
+            // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
+            uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> K32_SLOT_BITS));
+            n_offers += (uint32_t)__popcll(mask);
+            while (mask) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
             }
-        }
+        });
         if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
     } else {
         WaveHeap h;
@@ -1800,27 +1821,31 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
         h.lo = (uint32_t)sv;
         h.hi = (uint32_t)(sv >> 32);
         wh_build(h, k);
-        for (uint32_t d = 0; d < rec.n_dir; d++) {
-            const DirRun r = dir_run(w, rec, d);
-            for (uint32_t j = 0; j < r.n; j += WAVE) {
-                const uint32_t e = j + lane < r.n ? w.arena[r.at + j + lane] : 0u;
-                const uint32_t c = e >> 16;
-                const uint64_t v = pack_prescore(c, r.tile_base + (e & 0xFFFFu), z, iso);
-                uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
-                while (mask) {
-                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    wh_offer(h, k, lane_value(v, bit));
-                }
+        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+            const uint32_t c = e >> 16;
+            const uint64_t v = pack_prescore(c, tile_base + (e & 0xFFFFu), z, iso);
+            uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
+            while (mask) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                wh_offer(h, k, lane_value(v, bit));
             }
-        }
+        });
         if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
     }
+    if (w.dbg && lane == 0) {
+        unsigned long long* row = w.dbg + (size_t)(qid_in % DBG_BLOCKS) * 32 + 24;
+        atomicAdd(row + 0, (unsigned long long)(clock64() - t_start));
+        atomicAdd(row + 1, (unsigned long long)n_offers);
+        if (sc.dbg_flags & 1024u) {
+            atomicAdd(row + 5, 1ull);
+            atomicAdd(row + 6, (unsigned long long)rec.n_cand);
+        }
+    }
 }
-__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w, uint64_t lo, uint64_t hi) {
+__global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w, uint64_t wave_max) {
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    if (n_q <= lo || n_q > hi) return;
-    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid);
+    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid, n_q, wave_max);
 }
 
 __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const DevBatchView& b, const DevWork& w, unsigned char* smem,
@@ -1970,6 +1995,9 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, c
         peak_bitmap_span(pb, m, b0, b1);
         for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[bin >> 5], 1u << (bin & 31u));
     }
+}
+__device__ __forceinline__ uint32_t bitmap_bit(const uint32_t* bm, uint32_t bin) {
+    return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
 }
 __device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
     const uint32_t bin = peak_bitmap_bin(inv_wb, mz);
@@ -2196,19 +2224,20 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                         for (uint32_t r = 0; r < n_here; r += 4) {
                             const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
                             n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
-                            const uint32_t t1 = peak_bitmap_test(pbm, inv_wb, i0) | (peak_bitmap_test(pbm, inv_wb, i1) << 1) |
-                                                (peak_bitmap_test(pbm, inv_wb, i2) << 2) | (peak_bitmap_test(pbm, inv_wb, i3) << 3);
+                            // one conversion per ion; the bins of its charge states are integer halves / thirds of it (core.h)
+                            const uint32_t x0 = peak_bitmap_index3(inv_wb, i0), x1 = peak_bitmap_index3(inv_wb, i1),
+                                           x2 = peak_bitmap_index3(inv_wb, i2), x3 = peak_bitmap_index3(inv_wb, i3);
+                            const uint32_t t1 = bitmap_bit(pbm, peak_bitmap_bin_c1(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x1)) << 1) |
+                                                (bitmap_bit(pbm, peak_bitmap_bin_c1(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x3)) << 3);
                             m1 |= (uint64_t)t1 << r;
                             if (any_fz2) {  // (wave-uniform: some candidate of this spectrum has fragment charge 2)
-                                // an approximate ion / charge is enough to pick the bin: D carries the slack
-                                const uint32_t t2 = peak_bitmap_test(pbm, inv_wb, i0 * 0.5f) | (peak_bitmap_test(pbm, inv_wb, i1 * 0.5f) << 1) |
-                                                    (peak_bitmap_test(pbm, inv_wb, i2 * 0.5f) << 2) | (peak_bitmap_test(pbm, inv_wb, i3 * 0.5f) << 3);
+                                const uint32_t t2 = bitmap_bit(pbm, peak_bitmap_bin_c2(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x1)) << 1) |
+                                                    (bitmap_bit(pbm, peak_bitmap_bin_c2(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x3)) << 3);
                                 m2 |= (uint64_t)t2 << r;
                             }
                             if (any_fz3) {
-                                const float third = 1.0f / 3.0f;
-                                const uint32_t t3 = peak_bitmap_test(pbm, inv_wb, i0 * third) | (peak_bitmap_test(pbm, inv_wb, i1 * third) << 1) |
-                                                    (peak_bitmap_test(pbm, inv_wb, i2 * third) << 2) | (peak_bitmap_test(pbm, inv_wb, i3 * third) << 3);
+                                const uint32_t t3 = bitmap_bit(pbm, peak_bitmap_bin_c3(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x1)) << 1) |
+                                                    (bitmap_bit(pbm, peak_bitmap_bin_c3(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x3)) << 3);
                                 m3 |= (uint64_t)t3 << r;
                             }
                         }
@@ -2838,7 +2867,8 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
                      : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
     hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
 }
-void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
+                        const SideStream* side) {
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
     if (w.cnt8)
@@ -2852,19 +2882,26 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
-    // the case with order-free trims, where only queries with a clipped histogram are replayed — else a lane per query (far fewer
-    // instructions per offer, but a wavefront lasts as long as its longest query)
+    // the case with order-free trims, where only queries with a clipped histogram are replayed; with more queries than that, a
+    // lane per query (far fewer instructions per offer, but a wavefront lasts as long as its longest stream) for all but the
+    // long streams
     uint64_t wave_max = 32768;
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint64_t)atoll(e);
-    const uint64_t all = ~0ull;
-    if (b.n_dev != nullptr) {
-        // the exact retry pass: how many spectra it holds is only known on the device
-        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, wave_max);
-        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w, wave_max, all);
-    } else if ((!sc.exact && wave_max) || nq <= wave_max) {
-        hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, all);
-    } else {
-        hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sc, w, (uint64_t)0, all);
+    if (!sc.exact && wave_max) wave_max = ~0ull;
+    // (the two take disjoint sets of queries: side by side when the caller lends a second stream — the long streams of the one
+    // are a few serial wavefronts, the other fills the rest of the GPU)
+    const bool both = sc.exact || !wave_max;
+    hipStream_t lane_stream = (hipStream_t)stream;
+    if (both && side) {
+        lane_stream = (hipStream_t)side->stream;
+        if (hipEventRecord((hipEvent_t)side->fork, (hipStream_t)stream) != hipSuccess) return;
+        if (hipStreamWaitEvent(lane_stream, (hipEvent_t)side->fork, 0) != hipSuccess) return;
+    }
+    if (both) hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, lane_stream, sc, w, wave_max);
+    hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, wave_max);
+    if (both && side) {
+        if (hipEventRecord((hipEvent_t)side->join, lane_stream) != hipSuccess) return;
+        if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)side->join, 0) != hipSuccess) return;
     }
     hipLaunchKernelGGL(tile_assemble_kernel, dim3(capped(b.n)), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
                        (hipStream_t)stream, sc, b, w);

@@ -87,8 +87,8 @@ int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, fl
 
 // rescore_kernel's peak-presence filter (core.h: peak_bitmap_*) against the thing it must never contradict: for every ion and
 // fragment charge 1..3, "some peak lies inside Tolerance::bounds(ion / charge)" implies "the bit of the ion's bin is set".
-// The bin is taken from the same approximate ion / charge the kernel uses (x * 0.5f, x * (1 / 3.0f)); the window from the
-// exact quotient.  Returns the number of violations; counts matches and set bits among the items for the statistics.
+// The bin is taken the way the kernel takes it (peak_bitmap_index3: one conversion of the ion, integer halves and thirds) and
+// also from the approximate quotients x * 0.5f, x * (1 / 3.0f) (peak_bitmap_bin); the window from the exact quotient.  Returns the number of violations; counts matches and set bits among the items for the statistics.
 uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, float tlo, float thi, const float* ions, uint32_t m,
                                     uint32_t* n_match, uint32_t* n_set, int* filter_active) {
     Tol t{kind, tlo, thi};
@@ -112,7 +112,12 @@ uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, f
             tol_bounds(t, exact, lo, hi);
             bool match = false;
             for (uint32_t i = 0; i < n && !match; i++) match = masses[i] >= lo && masses[i] <= hi;  // spectrum.rs:147-157
-            const uint32_t bin = peak_bitmap_bin(pb.inv_wb, approx);
+            const uint32_t bin_a = peak_bitmap_bin(pb.inv_wb, approx);
+            // the kernel's form: the bins of all three charges from one conversion of the ion (peak_bitmap_index3)
+            const uint32_t i3 = peak_bitmap_index3(pb.inv_wb, ions[j]);
+            const uint32_t bin = c == 1 ? peak_bitmap_bin_c1(i3) : c == 2 ? peak_bitmap_bin_c2(i3) : peak_bitmap_bin_c3(i3);
+            if (peak_bitmap_bin_c3(i3) != i3 / 3) bad++;  // (the multiply-shift is a division by three)
+            bad += match && !((bm[bin_a >> 5] >> (bin_a & 31u)) & 1u);  // (the older form stays conservative, too)
             const bool set = (bm[bin >> 5] >> (bin & 31u)) & 1u;
             *n_match += match;
             *n_set += set;
