@@ -1,4 +1,6 @@
-// detmath.h — the arithmetic contract of the post-search rescoring (rescore.hip), shared with its CPU checker.
+// detmath_oracle.h — the CHECKER's copy of the arithmetic contract of the post-search rescoring (the product's is
+// sage_amd/csrc/detmath.h; oracle/selftest.cpp holds the two to each other bit for bit and to the platform libm within 1 ulp).
+// Test infrastructure: nothing under sage_amd/ includes this file.
 //
 // Why this exists.  Sage's LDA fit (crates/sage/src/ml/linear_discriminant.rs:57-127) ends in a Gauss-Jordan elimination whose
 // pivot search compares matrix entries with `>=` and `== 0.0` (ml/gauss.rs:89-124) and whose success test is exact
@@ -37,32 +39,28 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#define SAGE_DM_HD __host__ __device__ inline
-#else
-#define SAGE_DM_HD inline
-#endif
+#define ORC_DM inline
 
-namespace sagedet {
+namespace orcdet {
 
 constexpr uint32_t DET_BLOCK = 1024;  // elements per block of the blocked summation order
 
-SAGE_DM_HD uint64_t d2u(double d) {
+ORC_DM uint64_t d2u(double d) {
     union { double d; uint64_t u; } c;
     c.d = d;
     return c.u;
 }
-SAGE_DM_HD double u2d(uint64_t u) {
+ORC_DM double u2d(uint64_t u) {
     union { double d; uint64_t u; } c;
     c.u = u;
     return c.d;
 }
-SAGE_DM_HD int32_t hi_word(double d) { return (int32_t)(d2u(d) >> 32); }
-SAGE_DM_HD double with_hi_word(double d, int32_t hi) { return u2d((d2u(d) & 0xFFFFFFFFull) | ((uint64_t)(uint32_t)hi << 32)); }
+ORC_DM int32_t hi_word(double d) { return (int32_t)(d2u(d) >> 32); }
+ORC_DM double with_hi_word(double d, int32_t hi) { return u2d((d2u(d) & 0xFFFFFFFFull) | ((uint64_t)(uint32_t)hi << 32)); }
 
 // ln(1 + x).  Argument reduction 1 + x = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2), with the rounding error of 1 + x
 // carried as a correction term; log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)), s = f / (2 + f), R a degree-7 minimax polynomial.
-SAGE_DM_HD double det_log1p(double x) {
+ORC_DM double det_log1p(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, two54 = 1.80143985094819840000e+16;
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
@@ -130,11 +128,11 @@ SAGE_DM_HD double det_log1p(double x) {
 }
 
 // f32 ln_1p (runner.rs:287 `(-poisson as f32).ln_1p()`): evaluated in f64 and rounded once
-SAGE_DM_HD float det_log1pf(float x) { return (float)det_log1p((double)x); }
+ORC_DM float det_log1pf(float x) { return (float)det_log1p((double)x); }
 
 // e^x.  x = k ln2 + r, |r| <= 0.5 ln2 (ln2 split in two so that k ln2_hi is exact); e^r = 1 + 2r / (R(r^2) - r) with a
 // degree-5 minimax polynomial; scaled by 2^k through the exponent field.
-SAGE_DM_HD double det_exp(double x) {
+ORC_DM double det_exp(double x) {
     const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
     const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
@@ -190,4 +188,4 @@ inline double blocked_sum(uint64_t n, Term term) {
     return total;
 }
 
-}  // namespace sagedet
+}  // namespace orcdet

@@ -31,18 +31,20 @@
 #include <numeric>
 #include <vector>
 
-// The arithmetic contract the PRODUCT fixes for this step (deterministic ln_1p / exp, blocked summation order).  Including it
-// here does not make the checker depend on the product's results: the header is pure arithmetic, pinned against the platform
-// libm in oracle/selftest.cpp, and the reference-order mode below does not use it.
-#include "../sage_amd/csrc/detmath.h"
+// The arithmetic contract the PRODUCT fixes for this step (deterministic ln_1p / exp, blocked order of the KDE sums), in the
+// checker's own copy: pure arithmetic, pinned against the platform libm and against the product's header in
+// oracle/selftest.cpp; the reference-order mode below does not use it.
+#include "detmath_oracle.h"
+namespace sagedet = orcdet;
 
 namespace {
 
 // Two evaluation modes of the same restatement:
 //   det == 0  the reference's own order: every sum strictly left to right (`iter().sum()`), ln_1p / exp from the platform
 //             libm (what Rust's f64::ln_1p / exp call).  Kde::pdf, whose order the reference leaves to rayon, in sample order.
-//   det == 1  the order and elementary functions the device evaluates (detmath.h): sums in blocks of DET_BLOCK (identical to
+//   det == 1  the order and elementary functions the device evaluates: KDE / bandwidth sums in blocks of DET_BLOCK (identical to
 //             det == 0 for n <= DET_BLOCK), ln_1p / exp from IEEE basic operations.  The device is held to this bit for bit.
+//   The LDA sums (lda_train) are strictly sequential in both modes — and on the device.
 thread_local int g_det = 0;
 
 double ln1p(double x) { return g_det ? sagedet::det_log1p(x) : std::log1p(x); }
@@ -237,24 +239,16 @@ Estimator kde_build(const std::vector<double>& scores, const std::vector<uint8_t
     return e;
 }
 
-// LinearDiscriminantAnalysis::train, linear_discriminant.rs:57-127.  rows: n x d row-major.
-// det mode: rows are cut into consecutive blocks of DET_BLOCK (both classes together); a block's contribution to a class
-// accumulator is summed left to right over the block's rows of that class, and the block contributions are added in block
-// order (a block without rows of a class contributes +0.0) — the order of the device's class_sum / scatter kernels.
+// LinearDiscriminantAnalysis::train, linear_discriminant.rs:57-127.  rows: n x d row-major.  Both passes run strictly in row
+// order, one running sum per accumulator, exactly as the reference's loops do — in both modes: these sums decide, through the
+// pivot search of the elimination, whether the model is fitted at all, and the device evaluates them in this order too.
 bool lda_train(const double* rows, size_t n, size_t d, const uint8_t* decoy, std::vector<double>& coef) {
-    const size_t block = g_det ? (size_t)sagedet::DET_BLOCK : (n ? n : 1);
     std::vector<double> class_sum[2] = {std::vector<double>(d, 0.0), std::vector<double>(d, 0.0)};
     size_t class_count[2] = {0, 0};
-    for (size_t b0 = 0; b0 < n; b0 += block) {
-        const size_t b1 = std::min(n, b0 + block);
-        std::vector<double> part[2] = {std::vector<double>(d, 0.0), std::vector<double>(d, 0.0)};
-        for (size_t i = b0; i < b1; ++i) {
-            int cls = decoy[i] ? 0 : 1;
-            for (size_t j = 0; j < d; ++j) part[cls][j] += rows[i * d + j];
-            class_count[cls]++;
-        }
-        for (int c = 0; c < 2; ++c)
-            for (size_t j = 0; j < d; ++j) class_sum[c][j] += part[c][j];  // (one block: 0.0 + part == part, the reference's sum)
+    for (size_t i = 0; i < n; ++i) {  // :70-82
+        int cls = decoy[i] ? 0 : 1;
+        for (size_t j = 0; j < d; ++j) class_sum[cls][j] += rows[i * d + j];
+        class_count[cls]++;
     }
     if (class_count[0] == 0 || class_count[1] == 0) return false;
     std::vector<double> class_mean[2] = {std::vector<double>(d), std::vector<double>(d)};
@@ -262,17 +256,11 @@ bool lda_train(const double* rows, size_t n, size_t d, const uint8_t* decoy, std
         for (size_t j = 0; j < d; ++j) class_mean[c][j] = class_sum[c][j] / (double)class_count[c];
     Matrix scatter[2] = {Matrix(d, d), Matrix(d, d)};
     std::vector<double> centered(d);
-    for (size_t b0 = 0; b0 < n; b0 += block) {
-        const size_t b1 = std::min(n, b0 + block);
-        Matrix part[2] = {Matrix(d, d), Matrix(d, d)};
-        for (size_t i = b0; i < b1; ++i) {
-            int cls = decoy[i] ? 0 : 1;
-            for (size_t j = 0; j < d; ++j) centered[j] = rows[i * d + j] - class_mean[cls][j];
-            for (size_t j = 0; j < d; ++j)
-                for (size_t k = 0; k < d; ++k) part[cls].at(j, k) += centered[j] * centered[k];
-        }
-        for (int c = 0; c < 2; ++c)
-            for (size_t e = 0; e < d * d; ++e) scatter[c].data[e] += part[c].data[e];
+    for (size_t i = 0; i < n; ++i) {  // :92-103
+        int cls = decoy[i] ? 0 : 1;
+        for (size_t j = 0; j < d; ++j) centered[j] = rows[i * d + j] - class_mean[cls][j];
+        for (size_t j = 0; j < d; ++j)
+            for (size_t k = 0; k < d; ++k) scatter[cls].at(j, k) += centered[j] * centered[k];
     }
     Matrix within(d, d);
     for (int c = 0; c < 2; ++c)

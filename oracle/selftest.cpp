@@ -9,7 +9,8 @@
 #include <vector>
 
 #include "sage_oracle.hpp"
-#include "../sage_amd/csrc/detmath.h"
+#include "../sage_amd/csrc/detmath.h"  // the PRODUCT's elementary functions: checked here, never used by the checker itself
+#include "detmath_oracle.h"            // the checker's own copy
 #include <cstring>
 
 using namespace sage_oracle;
@@ -395,6 +396,8 @@ static void test_detmath() {
         worst_l = std::max(worst_l, ulps(sagedet::det_log1p(x), std::log1p(x)));
         const double y = (i % 3 == 0) ? u(rng) : -std::exp2(e(rng));
         worst_e = std::max(worst_e, ulps(sagedet::det_exp(y), std::exp(y)));
+        // the checker's copy and the product's header are the same functions, bit for bit
+        CHECK(ulps(orcdet::det_log1p(x), sagedet::det_log1p(x)) == 0 && ulps(orcdet::det_exp(y), sagedet::det_exp(y)) == 0);
         const float xf = (float)std::fabs(x);
         const float a = sagedet::det_log1pf(xf), b = std::log1p(xf);
         worst_f = std::max(worst_f, a == b ? 0L : (std::nextafterf(a, b) == b ? 1L : 2L));

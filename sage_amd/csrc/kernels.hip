@@ -266,7 +266,9 @@ __device__ __forceinline__ uint32_t wh32_get(const Heap32& H, uint32_t idx) {
 // instruction read ONE scalar register, so the lane select travels in M0; the compiler's hazard recogniser does not look inside
 // an asm statement, hence the wait states behind the M0 write are spelled out.
 __device__ __forceinline__ void writelane(uint32_t& vdst, uint32_t val, uint32_t sel) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %1, m0" : "+v"(vdst) : "s"(val), "s"(sel) : "m0");
+    // (M0 is a reserved register: the compiler never keeps a value in it across statements, it loads it right in front of the
+    // few instructions that read it — so it is not, and cannot be, listed as clobbered)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %1, m0" : "+v"(vdst) : "s"(val), "s"(sel));
 }
 __device__ __forceinline__ void wh32_init(Heap32& H, uint32_t keys, uint32_t k) { H.h = lane_id() < k ? keys : 0xFFFFFFFFu; }
 // sift_down (heap.rs:40-60) of value `moving` placed at `index`: descend to the smaller child (the left one on a tie) while it

@@ -45,8 +45,6 @@ constexpr int NF = 20;           // FEATURES, linear_discriminant.rs:19
 constexpr int RB = 256;          // threads of a row-parallel block
 constexpr int MAX_BLOCKS = 512;  // partials per (order-free) reduction
 constexpr uint32_t DB = sagedet::DET_BLOCK;  // elements per block of the blocked summation order
-constexpr int SCATTER_THREADS = 448;  // >= 400 matrix entries, whole waves
-constexpr int SCATTER_STAGE = 64;     // rows staged in LDS at a time
 
 struct KdeDev {  // kde::Estimator on the device
     const double* bins;
@@ -233,68 +231,80 @@ __global__ __launch_bounds__(RB) void rows_kernel(const SageFeature* __restrict_
     r[19] = sqrt(dims < 0.001 ? 0.001 : (dims > 0.999 ? 0.999 : dims));
 }
 
-// pass 1 of train (linear_discriminant.rs:70-82): partial[b][cls][j] = sum, left to right, of column j over the rows of
-// class cls in row block b (DET_BLOCK consecutive rows).  Thread (cls, j) owns one chain; rows are staged through LDS.
-constexpr int CSUM_THREADS = 64;
-__global__ __launch_bounds__(CSUM_THREADS) void class_sum_kernel(const double* __restrict__ rows,
-                                                                 const uint8_t* __restrict__ decoy, uint64_t n,
-                                                                 double* __restrict__ partial) {
-    __shared__ double stage[SCATTER_STAGE][NF];
-    __shared__ uint8_t stage_cls[SCATTER_STAGE];
-    const uint64_t lo = (uint64_t)blockIdx.x * DB, hi = lo + DB < n ? lo + DB : n;
-    const int cls = threadIdx.x / NF, j = threadIdx.x % NF;  // threads >= 2 * NF only help staging
-    double acc = 0.0;
-    for (uint64_t base = lo; base < hi; base += SCATTER_STAGE) {
-        const uint32_t cnt = (uint32_t)(hi - base < SCATTER_STAGE ? hi - base : SCATTER_STAGE);
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < cnt * NF; e += CSUM_THREADS) {
-            const uint32_t r = e / NF, c = e % NF;
-            stage[r][c] = rows[(base + r) * NF + c];
-            if (c == 0) stage_cls[r] = decoy[base + r] ? 0 : 1;
+// train's two passes over the rows (linear_discriminant.rs:70-82 class sums, :92-103 within-class scatter) in the REFERENCE'S
+// ORDER: every accumulator is one running f64 sum over the rows of its class, strictly in row order — these sums decide,
+// through the signed-maximum pivot search of the elimination (gauss.rs:97-108), whether the model is fitted at all, so a
+// blocked order is not good enough.  One lane per accumulator, one workgroup (8 wavefronts) per CLASS: 20 chains
+// for the class sums (SCATTER == false), 400 matrix entries for the scatter.  The workgroup walks ALL rows, 128 at a time: its
+// 512 threads stage the tile's rows OF THEIR CLASS into LDS, compacted in row order (two ballots give the class mask; for the
+// scatter the rows are centred on the way in, `row[j] - mu[j]` as the reference forms it), so the chain of a lane is two LDS
+// reads, a multiply and THE add per row, nothing else; the next tile's loads are in flight meanwhile.  A wavefront that runs
+// nearly alone retires an instruction every ~6 cycles, so instructions per row are what this costs: ~25 ms per million rows
+// for both passes (a blocked order took 2 ms; a lane-per-accumulator walk with a class test per row 110 ms).
+constexpr int SEQ_TILE = 128;                                     // rows per staged tile
+constexpr int SEQ_THREADS = 512;
+constexpr int SEQ_PER_THREAD = SEQ_TILE * NF / SEQ_THREADS;       // elements of a tile a thread moves (5)
+static_assert(SEQ_TILE * NF % SEQ_THREADS == 0 && SEQ_TILE == 128, "two 64-row class masks per tile");
+template <bool SCATTER>
+__global__ __launch_bounds__(SEQ_THREADS) void seq_lda_kernel(const double* __restrict__ rows, const uint8_t* __restrict__ decoy,
+                                                              uint64_t n, const double* __restrict__ class_mean /* [2][20], SCATTER only */,
+                                                              double* __restrict__ out /* [2][20] resp. [2][400] */) {
+    __shared__ double stage[2][SEQ_TILE][NF];
+    __shared__ unsigned long long cmask[2][2];  // [buffer][rows 0..63 | 64..127]: bit r = the row belongs to this workgroup's class
+    __shared__ double mu[NF];
+    const uint32_t t = threadIdx.x;
+    const uint32_t cls = blockIdx.y;  // 0 = decoys, 1 = targets (linear_discriminant.rs:73)
+    const bool owner = SCATTER ? t < NF * NF : t < NF;
+    const uint32_t ej = owner ? (SCATTER ? t / NF : t) : 0, ek = owner && SCATTER ? t % NF : 0;
+    if (SCATTER && t < NF) mu[t] = class_mean[cls * NF + t];
+    __syncthreads();
+    double reg[SEQ_PER_THREAD];
+    bool reg_mine = false;
+    auto load_tile = [&](uint64_t base) {  // element e = t + 512 i of the tile: row e / 20, column e % 20; thread t < 128: row t's class
+        const uint64_t cnt = n - base < SEQ_TILE ? n - base : SEQ_TILE;
+#pragma unroll
+        for (int i = 0; i < SEQ_PER_THREAD; ++i) {
+            const uint32_t e = t + (uint32_t)SEQ_THREADS * (uint32_t)i;
+            reg[i] = e < cnt * NF ? rows[base * NF + e] : 0.0;
+        }
+        reg_mine = t < cnt && (decoy[base + t] ? 0u : 1u) == cls;
+    };
+    auto store_tile = [&](int buf) {  // (every thread calls it: there is a barrier inside)
+        if (t < SEQ_TILE) {
+            const unsigned long long m = __ballot(reg_mine);
+            if ((t & 63u) == 0) cmask[buf][t >> 6] = m;
         }
         __syncthreads();
-        if (threadIdx.x < 2 * NF)
-            for (uint32_t r = 0; r < cnt; ++r)
-                if (stage_cls[r] == cls) acc += stage[r][j];
-    }
-    if (threadIdx.x < 2 * NF) partial[(uint64_t)blockIdx.x * 2 * NF + threadIdx.x] = acc;
-}
-
-// pass 2 of train (:92-103): partial[b][cls][j][k] = sum, left to right over the rows of class cls in row block b, of
-// (x_j - mu_j)(x_k - mu_k).  Thread (j, k) owns the chain of one matrix entry for both classes; centred rows are staged
-// through LDS 64 at a time.
-__global__ __launch_bounds__(SCATTER_THREADS) void scatter_kernel(const double* __restrict__ rows,
-                                                                  const uint8_t* __restrict__ decoy, uint64_t n,
-                                                                  const double* __restrict__ class_mean /* [2][20] */,
-                                                                  double* __restrict__ partial) {
-    __shared__ double stage[SCATTER_STAGE][NF];
-    __shared__ uint8_t stage_cls[SCATTER_STAGE];
-    __shared__ double mu[2][NF];
-    if (threadIdx.x < 2 * NF) mu[threadIdx.x / NF][threadIdx.x % NF] = class_mean[threadIdx.x];
-    const uint64_t lo = (uint64_t)blockIdx.x * DB, hi = lo + DB < n ? lo + DB : n;
-    const int j = threadIdx.x / NF, k = threadIdx.x % NF;
-    double acc[2] = {0.0, 0.0};
-    for (uint64_t base = lo; base < hi; base += SCATTER_STAGE) {
-        const uint32_t cnt = (uint32_t)(hi - base < SCATTER_STAGE ? hi - base : SCATTER_STAGE);
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < cnt * NF; e += SCATTER_THREADS) {
-            const uint32_t r = e / NF, c = e % NF;
-            const int cls = decoy[base + r] ? 0 : 1;
-            stage[r][c] = rows[(base + r) * NF + c] - mu[cls][c];
-            if (c == 0) stage_cls[r] = (uint8_t)cls;
-        }
-        __syncthreads();
-        if (threadIdx.x < NF * NF)
-            for (uint32_t r = 0; r < cnt; ++r) {
-                const double v = stage[r][j] * stage[r][k];
-                if (stage_cls[r]) acc[1] += v;
-                else acc[0] += v;
+        const unsigned long long m0 = cmask[buf][0], m1 = cmask[buf][1];
+#pragma unroll
+        for (int i = 0; i < SEQ_PER_THREAD; ++i) {
+            const uint32_t e = t + (uint32_t)SEQ_THREADS * (uint32_t)i, r = e / NF, c = e % NF;
+            const unsigned long long half = r < 64 ? m0 : m1, bit = 1ull << (r & 63u);
+            if (half & bit) {  // the row's place among the tile's rows of this class, in row order
+                const uint32_t rank = (r < 64 ? 0u : (uint32_t)__popcll(m0)) + (uint32_t)__popcll(half & (bit - 1ull));
+                stage[buf][rank][c] = SCATTER ? reg[i] - mu[c] : reg[i];
             }
+        }
+    };
+    double acc = 0.0;
+    if (n) load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (uint64_t base = 0; base < n; base += SEQ_TILE, buf ^= 1) {
+        const bool more = base + SEQ_TILE < n;
+        if (more) load_tile(base + SEQ_TILE);
+        if (owner) {
+            const uint32_t cnt = (uint32_t)(__popcll(cmask[buf][0]) + __popcll(cmask[buf][1]));
+            const double* pj = &stage[buf][0][ej];
+            const double* pk = &stage[buf][0][ek];
+#pragma unroll 4
+            for (uint32_t r = 0; r < cnt; ++r) acc += SCATTER ? pj[r * NF] * pk[r * NF] : pj[r * NF];  // in row order
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
     }
-    if (threadIdx.x < NF * NF) {
-        partial[((uint64_t)blockIdx.x * 2 + 0) * NF * NF + threadIdx.x] = acc[0];
-        partial[((uint64_t)blockIdx.x * 2 + 1) * NF * NF + threadIdx.x] = acc[1];
-    }
+    if (owner) out[(size_t)cls * (SCATTER ? NF * NF : NF) + t] = acc;
 }
 
 // out[c] = sum over blocks (in block order) of partial[b][c]
@@ -953,12 +963,9 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
     if (!kde_build(cx, dmass.p, decoy.p, n, false, mass_bins, bw_adjust, mass_model)) return false;
     rows_kernel<<<g, RB, 0, cx.stream>>>(feats.p, n, dmass.p, mass_model.dev, a_rt.p, d_rt.p, d_ims.p, rows.p);
 
-    // train (:57-127): class sums -> means -> scatter -> solve
-    const uint32_t nb = (uint32_t)((n + DB - 1) / DB);  // row blocks of the blocked order
-    RS_TRY(partial.alloc((size_t)nb * 2 * NF * NF));
+    // train (:57-127): class sums -> means -> scatter -> solve; both passes in the reference's row order (seq_lda_kernel)
     RS_TRY(folded.alloc(2 * NF * NF + 2 * NF));
-    class_sum_kernel<<<nb, CSUM_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, partial.p);
-    fold_partials_kernel<<<1, RB, 0, cx.stream>>>(partial.p, nb, 2 * NF, folded.p);
+    seq_lda_kernel<false><<<dim3(1, 2), SEQ_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, nullptr, folded.p);
     double class_sum[2][NF];
     RS_TRY(hipMemcpyAsync(class_sum, folded.p, sizeof(class_sum), hipMemcpyDeviceToHost, cx.stream));
     // class counts: the decoy flags summed by the mass-model fit would do; recount on the host from the labels instead
@@ -973,8 +980,7 @@ bool rescore_impl(Ctx& cx, const SageRescoreInput& in, SageRescoreOutput& out) {
             for (int j = 0; j < NF; ++j) class_mean[c][j] = class_sum[c][j] / (double)class_count[c];
         double* d_mean = folded.p + 2 * NF * NF;
         RS_TRY(hipMemcpyAsync(d_mean, class_mean, sizeof(class_mean), hipMemcpyHostToDevice, cx.stream));
-        scatter_kernel<<<nb, SCATTER_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, d_mean, partial.p);
-        fold_partials_kernel<<<grid_for(2 * NF * NF, RB), RB, 0, cx.stream>>>(partial.p, nb, 2 * NF * NF, folded.p);
+        seq_lda_kernel<true><<<dim3(1, 2), SEQ_THREADS, 0, cx.stream>>>(rows.p, decoy.p, n, d_mean, folded.p);
         std::vector<double> scatter(2 * NF * NF);
         RS_TRY(hipMemcpyAsync(scatter.data(), folded.p, scatter.size() * 8, hipMemcpyDeviceToHost, cx.stream));
         RS_TRY(hipStreamSynchronize(cx.stream));

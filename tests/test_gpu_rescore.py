@@ -1,11 +1,15 @@
 """GPU parity of the post-search rescoring (rescore.hip, through sage_hip_rescore) against the CPU oracle.
 
-The device evaluates the arithmetic contract of sage_amd/csrc/detmath.h (blocked summation order, IEEE-only ln_1p / exp) and
-the oracle is run in the same mode (`det=True`): every bit that reaches the Gauss-Jordan pivot search is then the same on both
-sides, so the fit-or-heuristic decision, the coefficients, the discriminants, every q-value and the output order are held
-EQUAL — also on data with constant columns (ims == 0 is the normal case without ion mobility), where the elimination pivots
-on rounding noise.  The one exception is log10 of the posterior error (device libm vs glibc): 2 f32 ulps.
-How far the contract is from the reference's own order + platform libm is measured on the CPU in test_rescore_oracle.py.
+The LDA sums (class means, within-class scatter) run strictly in row order on the device, as in the reference; what the product
+fixes beyond that is in sage_amd/csrc/detmath.h (IEEE-only ln_1p / exp, blocked order of the kernel-density sums, whose order
+the reference leaves to rayon).  Two comparisons per data set:
+  * against the oracle in the same mode (`det=True`): every bit that reaches the Gauss-Jordan pivot search is then the same on
+    both sides, so the fit-or-heuristic decision, the coefficients, the discriminants, every q-value and the output order are
+    held EQUAL — also on data with constant columns (ims == 0 is the normal case without ion mobility), where the elimination
+    pivots on rounding noise.  The one exception is log10 of the posterior error (device libm vs glibc): 2 f32 ulps;
+  * against the oracle in the reference's own mode (`det=False`: platform libm, every sum sequential): the same
+    fit-or-heuristic decision on every data set, and — where no column is constant, i.e. where the coefficients mean
+    anything — coefficients to 1e-9 and spectrum q-values equal.
 """
 import numpy as np
 import pytest
@@ -39,6 +43,13 @@ def compare(f, tol, pk, npk, prk, npr, context, **opt):
         assert _same(got, exp), (context, name, np.flatnonzero(got != exp)[:5])
     assert np.array_equal(g.order, o["order"]), context
     assert (int(g.passing_spectrum), int(g.passing_peptide), int(g.passing_protein)) == tuple(int(x) for x in o["passing"]), context
+    # ... and against the reference's own arithmetic (platform libm, sequential sums)
+    r = oracle_lib.rescore(f, tol, pk, npk, prk, npr, det=False, want_rows=True, **opt)
+    assert g.lda_fitted == r["lda_fitted"], (context, "fit-or-heuristic decision differs from the reference order")
+    if g.lda_fitted and all(np.ptp(r["rows"][:, j]) > 0 for j in range(r["rows"].shape[1])):
+        scale = np.abs(r["coef"]).max()
+        assert np.allclose(g.coef, r["coef"], rtol=1e-9, atol=1e-9 * scale), (context, np.abs(g.coef - r["coef"]).max() / scale)
+        assert np.mean(g.spectrum_q == r["spectrum_q"]) > 0.9999, context
     return g, o
 
 

@@ -284,11 +284,26 @@ def test_predict_rt_block_properties():
     assert np.all(r0["delta_rt_model"] == np.float32(0.999)) and np.all(r0["predicted_rt"] == 0.0)
 
 
+def test_fit_or_heuristic_decision_is_the_reference_orders():
+    """Constant ims column (every search without ion mobility): whether the LDA is fitted or the heuristic discriminant is used
+    hangs on the signs of rounding noise in the elimination (gauss.rs:97-108).  The LDA sums run in the reference's row order in
+    both modes of the oracle (and on the device), so the contract's elementary functions — an ulp from the libm here and there —
+    are all that could still tip it: they do not, on any of these data sets."""
+    tol = Tolerance("ppm", -10.0, 10.0)
+    seen = set()
+    for n, seed in ((4000, 3), (900, 14), (12000, 15), (50000, 16), (2500, 17), (8000, 18), (20000, 19)):
+        f, pk, npk, prk, npr = synthetic_features(n, seed=seed, zero_ims=True)
+        a = oracle_lib.rescore(f, tol, pk, npk, prk, npr, det=False)
+        b = oracle_lib.rescore(f, tol, pk, npk, prk, npr, det=True)
+        assert a["lda_fitted"] == b["lda_fitted"], (n, seed)
+        seen.add(bool(a["lda_fitted"]))
+    assert seen == {True, False}  # (both branches occur in this set)
+
+
 def test_det_contract_against_reference_order():
-    """How far the arithmetic contract the device evaluates (sage_amd/csrc/detmath.h: blocked sums, IEEE-only ln_1p / exp) is
-    from the reference's own strictly sequential order with the platform libm: identical for n <= DET_BLOCK rows up to the
-    1-ulp differences of det_exp / det_log1p, rounding-level beyond — coefficients of the non-constant columns to 1e-6,
-    discriminants to 1e-5, q-values equal on > 99.9 % of PSMs."""
+    """How far the arithmetic contract the device evaluates (sage_amd/csrc/detmath.h: IEEE-only ln_1p / exp, blocked order of
+    the kernel-density sums; the LDA sums are sequential either way) is from the reference's own order with the platform libm:
+    the design agrees to an ulp, coefficients to 1e-10, discriminants and q-values are equal."""
     tol = Tolerance("ppm", -10.0, 10.0)
     for n, seed in ((800, 21), (30000, 22)):
         f, pk, npk, prk, npr = synthetic_features(n, seed=seed)
@@ -299,12 +314,11 @@ def test_det_contract_against_reference_order():
         assert np.allclose(a["rows"], b["rows"], rtol=1e-13, atol=1e-15)
         live = np.array([np.ptp(a["rows"][:, j]) > 0 for j in range(20)])
         scale = np.abs(a["coef"][live]).max()
-        assert np.allclose(a["coef"][live], b["coef"][live], rtol=1e-6, atol=1e-7 * scale)
-        off = float(np.median(a["discriminant_score"].astype(np.float64) - b["discriminant_score"]))
-        assert np.allclose(a["discriminant_score"] - off, b["discriminant_score"], rtol=1e-5, atol=1e-5)
+        assert np.allclose(a["coef"][live], b["coef"][live], rtol=1e-10, atol=1e-10 * scale)
+        assert np.allclose(a["discriminant_score"], b["discriminant_score"], rtol=1e-6, atol=1e-6)
         for k in ("spectrum_q", "peptide_q", "protein_q"):
-            assert np.mean(np.isclose(a[k], b[k], rtol=1e-4, atol=1e-7)) > 0.999, k
-        assert abs(int(a["passing"][0]) - int(b["passing"][0])) <= max(2, int(a["passing"][0]) // 500)
+            assert np.mean(a[k] == b[k]) > 0.9999, k
+        assert abs(int(a["passing"][0]) - int(b["passing"][0])) <= 1
 
 
 def test_det_math_against_libm():
