@@ -1016,14 +1016,21 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
         rcap = std::max<uint32_t>(rcap, (uint32_t)(raw->peak_off[i + 1] - raw->peak_off[i]));
     }
     if (total && (!raw->mz || !raw->intensities)) return fail(SAGE_HIP_ERR_INVALID, "missing peak arrays");
-    uint32_t rpow2 = 1;
+    // the LDS instance of the kernel takes spectra up to PROCESS_LDS_PEAKS raw peaks (what three workgroups per CU can hold);
+    // larger ones go through the global-workspace instance, whatever their size
+    constexpr uint32_t PROCESS_LDS_PEAKS = 2048;
+    const uint32_t big_cap = rcap;
+    std::vector<uint32_t> big;
+    if (rcap > PROCESS_LDS_PEAKS) {
+        for (uint32_t i = 0; i < n; i++)
+            if (raw->peak_off[i + 1] - raw->peak_off[i] > PROCESS_LDS_PEAKS) big.push_back(i);
+        rcap = PROCESS_LDS_PEAKS;
+    }
+    uint32_t rpow2 = 1, big_pow2 = 1;
     while (rpow2 < rcap) rpow2 <<= 1;
-    const size_t lds = process_lds_bytes(rcap, rpow2);
-    if (lds > 160 * 1024)
-        return fail(SAGE_HIP_ERR_UNSUPPORTED, "a spectrum has more raw peaks than the LDS staging holds (" + std::to_string(rcap) +
-                                                  "): preprocess it with sage_hip_process_ms2");
+    while (big_pow2 < big_cap) big_pow2 <<= 1;
     HIP_TRY((hipError_t)process_kernel_prepare(160 * 1024));
-    const uint32_t stride = (uint32_t)std::min<uint64_t>(take_top_n, rcap);
+    const uint32_t stride = (uint32_t)std::min<uint64_t>(take_top_n, big_cap);
     DevBuf<uint64_t> raw_off;
     DevBuf<float> raw_mz, raw_int, sm, si;
     DevBuf<uint8_t> zbuf;
@@ -1039,6 +1046,15 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     launch_process(n, raw_off.p, raw_mz.p, raw_int.p, zbuf.p, (uint32_t)take_top_n, deisotope != 0, min_deisotope_mz, rcap, rpow2,
                    stride, sm.p, si.p, d->tic.p, cnt.p, s->stream);
     HIP_TRY(hipGetLastError());
+    DevBuf<uint32_t> big_list;
+    DevBuf<unsigned char> big_ws;
+    if (!big.empty()) {
+        HIP_TRY(big_list.upload(big.data(), big.size()));
+        HIP_TRY(big_ws.alloc(big.size() * process_lds_bytes(big_cap, big_pow2)));
+        launch_process_big((uint32_t)big.size(), big_list.p, big_ws.p, raw_off.p, raw_mz.p, raw_int.p, zbuf.p, (uint32_t)take_top_n,
+                           deisotope != 0, min_deisotope_mz, big_cap, big_pow2, stride, sm.p, si.p, d->tic.p, cnt.p, s->stream);
+        HIP_TRY(hipGetLastError());
+    }
     std::vector<uint32_t> counts(n);
     HIP_TRY(hipMemcpyAsync(counts.data(), cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -202,6 +202,10 @@ int process_kernel_prepare(size_t max_lds_bytes);
 void launch_process(uint32_t n, const uint64_t* raw_off, const float* raw_mz, const float* raw_int, const uint8_t* charge,
                     uint32_t take_top_n, bool deisotope, float min_deisotope_mz, uint32_t rcap, uint32_t rpow2, uint32_t stride,
                     float* out_mass, float* out_int, float* out_tic, uint32_t* out_count, void* stream);
+void launch_process_big(uint32_t n_big, const uint32_t* big_list, unsigned char* workspace, const uint64_t* raw_off, const float* raw_mz,
+                        const float* raw_int, const uint8_t* charge, uint32_t take_top_n, bool deisotope, float min_deisotope_mz,
+                        uint32_t big_cap, uint32_t big_pow2, uint32_t stride, float* out_mass, float* out_int, float* out_tic,
+                        uint32_t* out_count, void* stream);
 void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const float* sm, const float* si, float* masses,
                     float* intens, void* stream);
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,

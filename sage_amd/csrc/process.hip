@@ -3,7 +3,10 @@
 // ProcessedSpectrum arrays (masses ascending, intensities, total ion current) come out IN HBM, where the scoring kernels
 // read them — no host round trip between the mzML decode and Scorer::score.
 //
-// One 64-lane wavefront owns one spectrum; the spectrum lives in LDS.
+// One 64-lane wavefront owns one spectrum; the spectrum lives in LDS — or, for the rare spectrum with more raw peaks than a
+// reasonable LDS share holds (PROCESS_LDS_PEAKS), in a slice of a global-memory workspace: the same code through generic
+// pointers (process_kernel<true>), slower per access but without a limit on the peak count, and without making every other
+// wavefront of the batch carry that spectrum's LDS footprint.
 //   deisotope (spectrum.rs:179-227) is a sequential two-pointer loop whose `+=` chain runs from high to low m/z and whose
 //     quirks (the `j == 0` break, the "already part of an envelope of another charge" skip) are observable: lane 0
 //     replays it verbatim out of LDS;
@@ -58,16 +61,23 @@ __device__ __forceinline__ void bitonic_sort(uint32_t* perm, uint32_t npow2, Bef
     }
 }
 
+// BIG == false: block b owns spectrum b, skipped when it has more than rcap raw peaks (the other instance's); working arrays in
+// LDS.  BIG == true: block b owns spectrum big_list[b]; working arrays in workspace + b * ws_stride (rcap / rpow2 are the
+// capacity of a slice).
+template <bool BIG>
 __global__ __launch_bounds__(64) void process_kernel(uint32_t n_spectra, const uint64_t* __restrict__ raw_off,
                                                      const float* __restrict__ raw_mz, const float* __restrict__ raw_int,
                                                      const uint8_t* __restrict__ precursor_charge, uint32_t take_top_n,
                                                      uint32_t deisotope, float min_deisotope_mz, uint32_t rcap, uint32_t rpow2,
                                                      uint32_t stride, float* __restrict__ out_mass, float* __restrict__ out_int,
-                                                     float* __restrict__ out_tic, uint32_t* __restrict__ out_count) {
-    extern __shared__ __align__(16) unsigned char smem[];
+                                                     float* __restrict__ out_tic, uint32_t* __restrict__ out_count,
+                                                     const uint32_t* __restrict__ big_list, unsigned char* workspace, size_t ws_stride) {
+    extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t spec = blockIdx.x;
-    if (spec >= n_spectra) return;
+    if (blockIdx.x >= n_spectra) return;
+    const uint32_t spec = BIG ? big_list[blockIdx.x] : blockIdx.x;
+    if (!BIG && raw_off[spec + 1] - raw_off[spec] > rcap) return;
+    unsigned char* const smem = BIG ? workspace + (size_t)blockIdx.x * ws_stride : lds;
     ProcLds L;
     L.mz = (float*)smem;
     L.inten = L.mz + rcap;
@@ -229,16 +239,28 @@ __global__ __launch_bounds__(64) void compact_kernel(uint32_t n_spectra, const u
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2) { return ((size_t)rcap * 18 + (size_t)rpow2 * 4 + 15) & ~(size_t)15; }
 
 int process_kernel_prepare(size_t max_lds_bytes) {
-    return (int)hipFuncSetAttribute((const void*)process_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    return (int)hipFuncSetAttribute((const void*)process_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
 }
 
 void launch_process(uint32_t n, const uint64_t* raw_off, const float* raw_mz, const float* raw_int, const uint8_t* charge,
                     uint32_t take_top_n, bool deisotope, float min_deisotope_mz, uint32_t rcap, uint32_t rpow2, uint32_t stride,
                     float* out_mass, float* out_int, float* out_tic, uint32_t* out_count, void* stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(process_kernel, dim3(n), dim3(64), process_lds_bytes(rcap, rpow2), (hipStream_t)stream, n, raw_off, raw_mz,
+    hipLaunchKernelGGL(process_kernel<false>, dim3(n), dim3(64), process_lds_bytes(rcap, rpow2), (hipStream_t)stream, n, raw_off, raw_mz,
                        raw_int, charge, take_top_n, deisotope ? 1u : 0u, min_deisotope_mz, rcap, rpow2, stride, out_mass, out_int,
-                       out_tic, out_count);
+                       out_tic, out_count, (const uint32_t*)nullptr, (unsigned char*)nullptr, (size_t)0);
+}
+
+// the spectra `big_list` names (n_big of them, more raw peaks than the LDS instance takes), each in a workspace slice of
+// process_lds_bytes(big_cap, big_pow2) bytes
+void launch_process_big(uint32_t n_big, const uint32_t* big_list, unsigned char* workspace, const uint64_t* raw_off, const float* raw_mz,
+                        const float* raw_int, const uint8_t* charge, uint32_t take_top_n, bool deisotope, float min_deisotope_mz,
+                        uint32_t big_cap, uint32_t big_pow2, uint32_t stride, float* out_mass, float* out_int, float* out_tic,
+                        uint32_t* out_count, void* stream) {
+    if (n_big == 0) return;
+    hipLaunchKernelGGL(process_kernel<true>, dim3(n_big), dim3(64), 0, (hipStream_t)stream, n_big, raw_off, raw_mz, raw_int, charge,
+                       take_top_n, deisotope ? 1u : 0u, min_deisotope_mz, big_cap, big_pow2, stride, out_mass, out_int, out_tic, out_count,
+                       big_list, workspace, process_lds_bytes(big_cap, big_pow2));
 }
 
 void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const float* sm, const float* si, float* masses,

@@ -391,6 +391,44 @@ def test_device_spectrum_processing(small_world, deisotope, top_n):
     assert_features_equal(sub_f, sub_c, of, oc, "device-processed batch")
 
 
+@pytest.mark.parametrize("deisotope", [True, False])
+def test_large_raw_spectra_and_a_thousand_peaks(small_world, deisotope):
+    """Raw spectra far beyond the preprocessing kernel's LDS share (20 000 and 3 000 raw peaks: the global-workspace instance of
+    process_kernel) next to ordinary ones, max_peaks = 1000 (input.rs:366 is user-set): processed peaks bit-exact, then the
+    search over those 1000-peak spectra against the oracle (spectrum.rs:279-412, scoring.rs:300-309)."""
+    rng = np.random.default_rng(41)
+    raws = list(synthetic_spectra(small_world.host, 12, seed=78))
+    for k, n_extra in enumerate((20000, 3000, 2100)):
+        r = raws[k]
+        mz = np.concatenate([r.mz, rng.uniform(120.0, 1900.0, n_extra).astype(np.float32)])
+        it = np.concatenate([r.intensity * np.float32(50.0), rng.gamma(2.0, 20.0, n_extra).astype(np.float32)])
+        o = np.argsort(mz, kind="stable")
+        raws.append(RawSpectrum(mz[o], it[o], r.precursor_mz, r.precursor_charge, r.isolation_window, r.scan_start_time, None, 0, f"big={n_extra}"))
+    top_n = 1000
+    scorer = Scorer(small_world.dev, ScorerParams())
+    dbatch, npk = scorer.process_upload(RawBatch(raws), take_top_n=top_n, deisotope=deisotope, min_deisotope_mz=0.0, min_peaks=0)
+    off, m, it, tic = dbatch.download()
+    for i, r in enumerate(raws):
+        om, oi, otic = oracle_lib.process_ms2(top_n, deisotope, 0.0, r.mz, r.intensity, r.precursor_charge)
+        a, b = int(off[i]), int(off[i + 1])
+        assert b - a == len(om) == npk[i], f"spectrum {r.id}: {b - a} peaks vs oracle {len(om)}"
+        np.testing.assert_array_equal(m[a:b], om, err_msg=f"masses of {r.id}")
+        np.testing.assert_array_equal(it[a:b], oi, err_msg=f"intensities of {r.id}")
+        assert np.float32(tic[i]) == np.float32(otic), f"TIC of {r.id}"
+    assert npk.max() == top_n
+    gf, gc = scorer.score_resident(dbatch)
+    sp = SpectrumProcessor(top_n, deisotope, 0.0)
+    hb = SpectrumBatch.from_spectra([sp.process(r) for r in raws])
+    of, oc, _, _ = small_world.orc.score(ScorerParams(), hb)
+    assert assert_features_equal(gf, gc, of, oc, "1000-peak spectra") >= 10
+    # ... and through the large-window kernels (peaks x fragment charges in the count kernel's LDS)
+    params = ScorerParams(precursor_tol=Tolerance("da", -300.0, 300.0), report_psms=2)
+    scorer2 = Scorer(small_world.dev, params)
+    gf, gc = scorer2.score(hb)
+    of, oc, _, _ = small_world.orc.score(params, hb)
+    assert_features_equal(gf, gc, of, oc, "1000-peak spectra, large windows")
+
+
 def test_error_paths(small_world):
     with pytest.raises(L.SageHipError):
         Scorer(small_world.dev, ScorerParams(report_psms=0))
