@@ -35,6 +35,36 @@ from sage_amd.workloads import CONFIGS, DEFAULT_CONFIG, SPECTRA_CHUNK, build_hos
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def host_cpu_budget():
+    """How many CPUs this process may really use: the scheduler affinity mask, cut down by the cgroup CPU quota when there is
+    one (cpu.max / cfs_quota_us) — os.cpu_count() is the machine's count, not ours.  Returns (cpus, details)."""
+    details = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        details["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        details["affinity"] = details["os_cpu_count"]
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            with open(path) as fh:
+                q, per = parse(fh.read())
+            if per is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = fh.read().strip()
+            details["cgroup_cpu_max"] = f"{q} {per}"
+            if q not in ("max", "-1") and float(per) > 0:
+                quota = float(q) / float(per)
+            break
+        except (OSError, ValueError):
+            continue
+    details["cgroup_quota_cpus"] = quota
+    cpus = details["affinity"]
+    if quota is not None:
+        cpus = max(1, min(cpus, int(quota + 0.5)))
+    return cpus, details
+
+
 def _tol_str(t):
     return f"{t.kind}[{t.lo:g},{t.hi:g}]"
 
@@ -467,9 +497,14 @@ def main():
             # sample grows with the thread count so that each entry is a few seconds of work
             with oracle_lib.use("fast"):
                 fast = oracle_lib.OracleDb.from_product(host)
-            ncpu = os.cpu_count() or 1
+            # thread counts up to the CPUs this process is ALLOWED (affinity mask, cgroup quota), threads bound to cores and
+            # spread over the sockets; threads beyond the quota only get throttled (round 2's table fell above 16 for that reason)
+            ncpu, cpu_details = host_cpu_budget()
+            os.environ.setdefault("OMP_PROC_BIND", "spread")
+            os.environ.setdefault("OMP_PLACES", "cores")
             table = {}
-            for th in sorted({t for t in (1, 8, 16, 32, 64, 128, 256) if t <= ncpu} | {ncpu}):
+            ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t <= ncpu} | {ncpu})
+            for th in ladder:
                 m = min(n_cpu, max(512, n_cpu // 64) * th) if not args.no_extras else n_cpu
                 if args.no_extras and th != ncpu:
                     continue
@@ -483,10 +518,11 @@ def main():
             what = f"all {batch.n} spectra of the workload" if n_cpu == batch.n else \
                 f"the first {n_cpu} of the {batch.n} spectra of the workload"
             cpu = {"value": table[best]["spectra_per_s"], "unit": "spectra/s", "cores": int(best), "kind": "port",
-                   "host_cpus": ncpu,
+                   "host_cpus_allowed": ncpu, "host_cpu_details": cpu_details,
                    "sample": f"{what} (smaller prefixes at low thread counts), one pass after a warm-up per thread count, OpenMP "
-                             f"dynamic schedule, performance build of the restated reference CPU path (oracle/Makefile FASTFLAGS; not "
-                             f"Sage itself); value = the best thread count",
+                             f"dynamic schedule, threads bound to cores (OMP_PROC_BIND=spread), performance build of the restated "
+                             f"reference CPU path (oracle/Makefile FASTFLAGS; not Sage itself); value = the best thread count "
+                             f"up to the {ncpu} CPUs this process may use",
                    "threads_table": table,
                    "parity": f"{parity_psms} PSMs identical to the GPU result (ints/f32 exact, f64 within 1e-12)"}
             rescore_bytes = 4 * work["rescored"] + 5 * work["rescored_residues"] + 64 * work["reported"]

@@ -8,6 +8,7 @@ Names and argument meaning follow the reference (crates/sage/src):
 All compute happens in libsage_hip.so; nothing here falls back to Python arithmetic.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -387,16 +388,18 @@ class SpectrumBatch:
         peaks by DMA straight out of these arrays instead of staging them.  What a caller that owns its spectrum arena
         (the mzML reader, a Rust Vec allocated through the C ABI) would hand over."""
         lib = L.load()
-        keep = []
 
         def lock(a):
             if a is None:
                 return None
+            # the block lives exactly as long as something refers to the array made over it (a view, a to_c() struct holding
+            # the array, this batch): the ctypes buffer is the ndarray's base, and its finalizer frees the block
             p = C.c_void_p()
             L.check(lib.sage_hip_host_alloc(max(a.nbytes, 1), C.byref(p)))
-            out = np.frombuffer((C.c_char * max(a.nbytes, 1)).from_address(p.value), dtype=a.dtype, count=a.size).reshape(a.shape)
+            buf = (C.c_char * max(a.nbytes, 1)).from_address(p.value)
+            weakref.finalize(buf, lib.sage_hip_host_free, C.c_void_p(p.value))
+            out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
             out[...] = a
-            keep.append(p)
             return out
 
         b = SpectrumBatch.__new__(SpectrumBatch)
@@ -404,19 +407,7 @@ class SpectrumBatch:
                   "isolation_hi", "scan_start_time", "inverse_ion_mobility", "file_id"):
             setattr(b, k, lock(getattr(self, k)))
         b.n = self.n
-        b._locked = keep
         return b
-
-    def __del__(self):
-        locked = getattr(self, "_locked", None)
-        if locked:
-            try:
-                lib = L.load()
-                for p in locked:
-                    lib.sage_hip_host_free(p)
-            except Exception:
-                pass
-            self._locked = None
 
     def subset(self, idx) -> "SpectrumBatch":
         idx = np.asarray(idx)

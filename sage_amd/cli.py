@@ -111,18 +111,21 @@ def read_text(path: str) -> str:
 
 
 def parse_devices(spec, n_visible: int):
-    """--devices all | 0-7 | 0,2,3 (a device may be named twice: two workers share it)"""
+    """--devices all | 0-7 | 0,2,3 (a device may be named twice: two workers share it, on one copy of the index)"""
     if spec is None:
         return None
     if spec == "all":
         return list(range(n_visible))
     out = []
-    for part in str(spec).split(","):
-        if "-" in part:
-            a, b = part.split("-")
-            out += list(range(int(a), int(b) + 1))
-        else:
-            out.append(int(part))
+    try:
+        for part in str(spec).split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                out += list(range(int(a), int(b) + 1))
+            else:
+                out.append(int(part))
+    except ValueError:
+        raise SystemExit(f"sage_amd.cli: --devices {spec}: expected `all`, a list like 0,2,3 or a range like 0-7")
     bad = [d for d in out if d < 0 or d >= n_visible]
     if bad or not out:
         raise SystemExit(f"sage_amd.cli: --devices {spec}: {n_visible} HIP device(s) visible")
@@ -218,10 +221,14 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     if host is None:
         host = dbp.build(fasta_text, peptides_only=True)  # digest / modify / sort / dedup on the host ...
     # ... build_from_peptides on the device (index_build.hip): the index is replicated on every device that searches
-    workers = []
-    for d in devices:
-        dev_db = DeviceDatabase(host, d)
-        workers.append((dev_db, Scorer(dev_db, params)))
+    workers, first = [], {}
+    for d in devices:  # one copy of the index per distinct device; a device named again gets a second handle on it
+        if d in first:
+            workers.append((first[d][0], first[d][1].clone()))  # (sage_hip_scorer_clone: own streams and working set)
+        else:
+            dev_db = DeviceDatabase(host, d)
+            first[d] = (dev_db, Scorer(dev_db, params))
+            workers.append(first[d])
     log(f"generated {host.n_peptides} peptides and their fragment index in {int((time.time() - t0) * 1000)}ms" +
         (f" on {len(devices)} devices" if len(devices) > 1 else ""))
     os.makedirs(output_directory, exist_ok=True)

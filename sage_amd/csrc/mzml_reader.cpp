@@ -214,6 +214,10 @@ bool parse_spectrum(Tag t, const char*& p, const char* e, int ms_level, Spectrum
     bool bda_f32 = false, bda_zlib = false;
     int bda_kind = 0;  // 1 m/z, 2 intensity
     std::string_view bda_text;
+    struct Pending {
+        std::string_view text;
+        bool f32, zlib, set;
+    } pending[2] = {{std::string_view(), false, false, false}, {std::string_view(), false, false, false}};
     bool closed = t.self_closing;
     while (!closed && next_tag(p, e, t)) {
         if (t.closing) {
@@ -236,29 +240,10 @@ bool parse_spectrum(Tag t, const char*& p, const char* e, int ms_level, Spectrum
                 in_scan = false;
             } else if (in_bda && t.name == "binaryDataArray" && depth == bda_depth) {
                 in_bda = false;
-                if (!bda_text.empty() && bda_kind) {
-                    base64_decode(bda_text, raw);
-                    const std::vector<uint8_t>* bytes = &raw;
-                    if (bda_zlib) {
-                        if (!inflate_all(raw, plain)) {
-                            err = "malformed mzML: zlib stream of spectrum " + id;
-                            return false;
-                        }
-                        bytes = &plain;
-                    }
-                    std::vector<float>& dst = bda_kind == 1 ? mz : inten;
-                    if (bda_f32) {
-                        dst.resize(bytes->size() / 4);
-                        std::memcpy(dst.data(), bytes->data(), dst.size() * 4);
-                    } else {
-                        dst.resize(bytes->size() / 8);
-                        for (size_t i = 0; i < dst.size(); ++i) {
-                            double d;
-                            std::memcpy(&d, bytes->data() + 8 * i, 8);
-                            dst[i] = (float)d;
-                        }
-                    }
-                }
+                // (decoded behind the closing </spectrum>, and only when the spectrum passes the level / TIC filters: an MS1
+                // survey scan in profile mode is megabytes of base64 + zlib nobody asked for — the reference's parser drops
+                // those arrays undecoded, too, mzml.rs:300-330)
+                if (!bda_text.empty() && bda_kind) pending[bda_kind - 1] = Pending{bda_text, bda_f32, bda_zlib, true};
             }
             --depth;
             continue;
@@ -356,9 +341,35 @@ bool parse_spectrum(Tag t, const char*& p, const char* e, int ms_level, Spectrum
     }
     o.keep = !(tic_zero || (ms_level >= 0 && (!have_level || level != ms_level)));
     o.id.swap(id);
-    inten.resize(mz.size(), 0.0f);  // (a spectrum with arrays of different lengths is malformed; keep the peak table rectangular)
-    o.mz.swap(mz);
-    o.inten.swap(inten);
+    if (o.keep) {
+        for (int k = 0; k < 2; ++k) {
+            if (!pending[k].set) continue;
+            base64_decode(pending[k].text, raw);
+            const std::vector<uint8_t>* bytes = &raw;
+            if (pending[k].zlib) {
+                if (!inflate_all(raw, plain)) {
+                    err = "malformed mzML: zlib stream of spectrum " + o.id;
+                    return false;
+                }
+                bytes = &plain;
+            }
+            std::vector<float>& dst = k == 0 ? mz : inten;
+            if (pending[k].f32) {
+                dst.resize(bytes->size() / 4);
+                std::memcpy(dst.data(), bytes->data(), dst.size() * 4);
+            } else {
+                dst.resize(bytes->size() / 8);
+                for (size_t i = 0; i < dst.size(); ++i) {
+                    double d;
+                    std::memcpy(&d, bytes->data() + 8 * i, 8);
+                    dst[i] = (float)d;
+                }
+            }
+        }
+        inten.resize(mz.size(), 0.0f);  // (a spectrum with arrays of different lengths is malformed; keep the peak table rectangular)
+        o.mz.swap(mz);
+        o.inten.swap(inten);
+    }
     o.scan_start = scan_start;
     o.prec_mz = prec_mz;
     o.prec_ims = prec_ims;
@@ -400,11 +411,12 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
             return false;
         }
         std::string plain_text;
-        plain_text.resize(std::max<size_t>(text.size() * 6, 1 << 16));
+        plain_text.resize(std::max<size_t>(text.size() * 2, 1 << 16));  // (base64 + zlib payload compresses 1.3-3 x; grows geometrically)
         zs.next_in = (Bytef*)text.data();
         zs.avail_in = (uInt)std::min<size_t>(text.size(), 0xFFFFFFFFu);
         size_t consumed_in = zs.avail_in, have = 0;
         int rc = Z_OK;
+        bool member_done = false;  // at least one complete gzip member has been inflated
         for (;;) {
             if (have == plain_text.size()) plain_text.resize(plain_text.size() * 2);
             zs.next_out = (Bytef*)&plain_text[have];
@@ -413,12 +425,17 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
             rc = inflate(&zs, Z_NO_FLUSH);
             have += room - zs.avail_out;
             if (rc == Z_STREAM_END) {
+                member_done = true;
                 if (zs.avail_in == 0 && consumed_in == text.size()) break;
                 if (inflateReset(&zs) != Z_OK) break;  // (concatenated gzip members)
                 if (zs.avail_in == 0) break;
                 continue;
             }
-            if (rc != Z_OK) break;
+            if (rc != Z_OK) {
+                // bytes behind the last complete member that are no gzip member (padding, a signature block): the end of the input
+                if (member_done && zs.total_out == 0 && (rc == Z_DATA_ERROR || rc == Z_BUF_ERROR)) rc = Z_STREAM_END;
+                break;
+            }
             if (zs.avail_in == 0 && consumed_in < text.size()) {  // (inputs above 4 GiB: feed the next piece)
                 const size_t more = std::min<size_t>(text.size() - consumed_in, 0xFFFFFFFFu);
                 zs.next_in = (Bytef*)text.data() + consumed_in;

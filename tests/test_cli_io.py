@@ -462,12 +462,21 @@ def test_gzip_inputs_and_device_lists(tmp_path):
     open(p + ".gz", "wb").write(gzip.compress(open(p, "rb").read()))
     a, b = read_mzml_native(p, 0), read_mzml_native(p + ".gz", 0)  # sage-cloudpath lib.rs:44-90: gz inputs are inflated
     assert a.n == b.n == 25 and a.ids == b.ids and np.array_equal(a.mz, b.mz) and np.array_equal(a.precursor_mz, b.precursor_mz)
+    # two concatenated gzip members, then bytes that are no gzip member at all (padding): the members are the file
+    half = len(open(p, "rb").read()) // 2
+    data = open(p, "rb").read()
+    open(p + ".2.gz", "wb").write(gzip.compress(data[:half]) + gzip.compress(data[half:]) + b"\0" * 512)
+    c = read_mzml_native(p + ".2.gz", 0)
+    assert c.n == 25 and c.ids == a.ids and np.array_equal(c.mz, a.mz)
     fa = str(tmp_path / "db.fasta.gz")
     open(fa, "wb").write(gzip.compress(fasta.encode()))
     assert cli.read_text(fa) == fasta
     assert cli.parse_devices("all", 4) == [0, 1, 2, 3] and cli.parse_devices("0-2,1", 4) == [0, 1, 2, 1] and cli.parse_devices(None, 4) is None
     with pytest.raises(SystemExit):
         cli.parse_devices("0-8", 4)
+    for bad in ("-1", "a-b", "0,,1", ""):
+        with pytest.raises(SystemExit):
+            cli.parse_devices(bad, 4)
 
 
 def test_unsearchable_spectra_are_refused(tmp_path):
