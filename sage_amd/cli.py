@@ -142,6 +142,7 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate):
     from .sharding import plan_shards
     shards = plan_shards(raw.peak_off, len(workers)) if len(workers) > 1 else [(0, raw.n)]
     results = [None] * len(workers)
+    stage_ms = [(0.0, 0.0, 0.0)] * len(workers)  # per worker: preprocess + upload, score, annotate
     errors = []
 
     def work(k):
@@ -151,13 +152,17 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate):
             part = raw if (b, e) == (0, raw.n) else raw.slice(b, e)
             if part.n == 0:
                 return
+            t0 = time.time()
             dbatch, ids = _upload(scorer, processor, part, sp, host_preprocess)
             if dbatch is None:
                 return
+            t1 = time.time()
             feats, counts = scorer.score_resident(dbatch)
             feats, counts = feats.copy(), counts.copy()
+            t2 = time.time()
             ann = scorer.annotate(dbatch, feats, counts) if annotate else None
             dbatch.close()
+            stage_ms[k] = ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.time() - t2) * 1e3)
             valid = np.arange(feats.shape[1])[None, :] < counts[:, None]
             feats["spec_index"][valid] += np.uint32(b)  # position in the file, not in the shard
             results[k] = (feats, counts, ids, ann)
@@ -188,6 +193,7 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate):
             for k in arrs:
                 arrs[k].append(arr[k])
         ann = (np.concatenate(offs + [np.array([base], dtype=np.uint64)]), {k: np.concatenate(v) for k, v in arrs.items()})
+    search_file.last_stage_ms = tuple(max(x[i] for x in stage_ms) for i in range(3))  # (the slowest worker's, per stage)
     return feats, counts, ids, ann
 
 
@@ -236,6 +242,8 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     psm_id = 1  # PSM_COUNTER starts at 1 (scoring.rs:163)
     n_searched = 0
     search_ms = 0.0
+    stage_totals = {"file_io_ms": 0.0, "preprocess_upload_ms": 0.0, "score_ms": 0.0, "annotate_ms": 0.0}
+    t_run = time.time()
     # The reader works one file ahead of the search (the reference reads and preprocesses its files in parallel batches,
     # runner.rs:450-461): file k + 1 is parsed on the host threads (csrc/mzml_reader.cpp decodes the spectra of a file in
     # parallel, outside the GIL) while the devices score file k.
@@ -269,6 +277,13 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         search_ms += dt
         n_searched += n_batch
         log(f"- search:  {int(dt):8d} ms ({int(n_batch * 1000 / (dt + 1))} spectra/s)")  # runner.rs:327-330
+        pre_ms, score_ms, ann_ms = getattr(search_file, "last_stage_ms", (0.0, 0.0, 0.0))
+        log(f"    of which preprocessing + upload {pre_ms:.1f} ms, Scorer::score on the device {score_ms:.1f} ms" +
+            (f", fragment annotation {ann_ms:.1f} ms" if sp["annotate_matches"] else ""))
+        stage_totals["file_io_ms"] += io_ms
+        stage_totals["preprocess_upload_ms"] += pre_ms
+        stage_totals["score_ms"] += score_ms
+        stage_totals["annotate_ms"] += ann_ms
         off, arr = ann if ann is not None else (None, None)
         name = os.path.basename(path)
         # the PSMs of the file in (spectrum, rank) order — the order Scorer::score results are collected in (runner.rs:325)
@@ -320,7 +335,10 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
                            "q_protein": res.passing_protein, "rescore_ms": (time.time() - t0) * 1000.0,
                            "rescore_device_ms": res.device_ms}
 
+    if rescore_summary:
+        log(f"- rescoring (RT / IM models, LDA, q-values, picked FDR): {int(rescore_summary['rescore_ms']):8d} ms")
     # writers: C++ (sage_hip_write_results) — byte-identical to output.feature_row / pin_row, which tests/test_cli_io.py checks
+    t_write = time.time()
     filenames = [os.path.basename(p) for p in mzml_paths]
     psm_ids = [m[0] for m in meta]
     spec_ids = [m[2] for m in meta]
@@ -335,8 +353,11 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         pp = os.path.join(output_directory, "results.sage.pin")
         output.write_results_native(pp, "pin", host, flat, list(order), psm_ids, filenames, spec_ids, [rtp, post])
         paths.append(pp)
+    stage_totals["write_ms"] = (time.time() - t_write) * 1e3
+    log(f"- writing: {int(stage_totals['write_ms']):8d} ms")
+    stage_totals["total_after_index_ms"] = (time.time() - t_run) * 1e3
     summary = {"version": "sage-hip 0.1 (search-and-score path of sage 0.15.0-beta.2)", "psms": len(flat),
-               "spectra_searched": n_searched, "search_ms": search_ms, "output_paths": paths, **rescore_summary}
+               "spectra_searched": n_searched, "search_ms": search_ms, "stages": stage_totals, "output_paths": paths, **rescore_summary}
     with open(os.path.join(output_directory, "results.json"), "w") as fh:
         json.dump(dict(cfg, output_paths=paths, summary=summary), fh, indent=2, default=str)
     return summary

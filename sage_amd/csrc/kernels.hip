@@ -1964,10 +1964,33 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 // select_most_intense_peak through a direct-index table over the peak masses (core.h: peak_lut_width / peak_lut_entry /
 // select_peak_lut, shared with the host: tests/test_core_emulation.py holds it to select_most_intense_peak)
 __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, const float* pm, uint32_t P) {
+    // plut[b] = number of peaks with mass < b * W in the total order (core.h: peak_lut_entry) — by counting instead of 256
+    // binary searches: W is a power of two, so bin(m) = floor(m / W) is exact and `mass < b * W` <=> bin(m) < b; masses below
+    // +0.0 in the total order (negative, -0.0, negative NaN) lie before every edge, +inf / NaN behind every edge.  A histogram
+    // shifted by one bin, then its inclusive prefix sum.
     const uint32_t lane = lane_id();
     const float w = peak_lut_width(P ? pm[P - 1] : 0.0f);
     inv_w = 1.0f / w;
-    for (uint32_t b = lane; b < PLUT_BINS; b += WAVE) plut[b] = peak_lut_entry(pm, P, b, w);
+    static_assert(PLUT_BINS == 4 * WAVE, "four consecutive bins per lane");
+    __syncthreads();
+    *(uint4*)(plut + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        const float m = pm[i];
+        if (order_key(m) < 0) {
+            atomicAdd(&plut[0], 1u);  // before every edge
+        } else if (m == m) {
+            const float f = __builtin_floorf(m * inv_w);
+            if (f < (float)(PLUT_BINS - 1)) atomicAdd(&plut[(uint32_t)f + 1u], 1u);  // bin f: counted from edge f + 1 on
+        }
+    }
+    __syncthreads();
+    uint4 h = *(const uint4*)(plut + 4 * lane);
+    h.y += h.x;
+    h.z += h.y;
+    h.w += h.z;
+    const uint32_t before = wave_incl_scan_dpp(h.w) - h.w;
+    *(uint4*)(plut + 4 * lane) = make_uint4(h.x + before, h.y + before, h.z + before, h.w + before);
 }
 // The peak-presence bitmap that filters score_candidate's lookups (core.h: peak_bitmap_params / _span / _bin, shared with the
 // host so that the CPU suite can test that the filter never drops a match).
@@ -2146,9 +2169,11 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     uint64_t ion_base = 0;
     uint32_t lm1 = 0;
     if (valid) {
-        const uint64_t o1 = db.ion_off[pep + 1];
         ion_base = db.ion_off[pep];
-        lm1 = db.n_kinds ? (uint32_t)((o1 - ion_base) / db.n_kinds) : 0;
+        // ions per kind = peptide length - 1 (ion_series.rs:68-85; the ion table holds n_kinds * (L - 1) values per peptide): from
+        // the peptide's record, not as (ion_off[pep + 1] - ion_off[pep]) / n_kinds — a 64-bit division per candidate
+        const uint32_t plen = db.pep_info[pep] & 0xFFFFu;
+        lm1 = db.n_kinds && plen ? plen - 1u : 0u;
     }
     // (registers are what this kernel is short of: whatever only a reporting lane needs — the peptide's record, its mass — is
     // read when the record is written, and nothing is kept that two instructions recompute)

@@ -39,6 +39,39 @@ def synthetic_fasta(n_proteins: int, seed: int, mu: float = 6.0, sigma: float = 
     return "".join(out)
 
 
+def paralog_fasta(n_families: int, copies: int, seed: int, mutation_rate: float = 0.01, il_swap_rate: float = 0.5,
+                  repeat_frac: float = 0.15) -> str:
+    """A proteome shaped like a real one where it hurts a k-select: families of `copies` paralogs — the family's founder with
+    point mutations at `mutation_rate` of the residues, isoleucine / leucine swapped at `il_swap_rate` of their positions
+    (identical masses: such peptides tie in every score) — and a `repeat_frac` of the families carrying a domain repeated in
+    tandem.  Tryptic peptides are shared between paralogs, differ by one residue, or differ by nothing a mass spectrometer sees;
+    the i.i.d. proteomes of synthetic_fasta have none of that."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(_AA.encode(), dtype=np.uint8)
+    base = synthetic_fasta(n_families, seed)
+    founders = ["".join(b.split("\n")[1:]) for b in base.split(">")[1:]]
+    out = []
+    I, Lc = ord("I"), ord("L")
+    for f, seq in enumerate(founders):
+        a = np.frombuffer(seq.encode(), dtype=np.uint8).copy()
+        if rng.random() < repeat_frac and len(a) > 120:  # a domain of 40-80 residues, two or three times in a row
+            s0 = int(rng.integers(0, len(a) - 80))
+            dom = a[s0:s0 + int(rng.integers(40, 80))]
+            a = np.concatenate([a[:s0], np.tile(dom, int(rng.integers(2, 4))), a[s0:]])
+        for c in range(copies):
+            v = a.copy()
+            if c:
+                hit = rng.random(len(v)) < mutation_rate
+                v[hit] = letters[rng.choice(len(_AA), size=int(hit.sum()), p=_FREQ)]
+                il = ((v == I) | (v == Lc)) & (rng.random(len(v)) < il_swap_rate)
+                v[il] = np.where(v[il] == I, Lc, I)
+            sq = v.tobytes().decode()
+            out.append(f">sp|FAM{f:05d}P{c}|FAM{f:05d}P{c}_SYNTH family {f} paralog {c}\n")
+            for j in range(0, len(sq), 60):
+                out.append(sq[j:j + 60] + "\n")
+    return "".join(out)
+
+
 def synthetic_spectra(db: IndexedDatabase, n_spectra: int, seed: int, noise_peaks: int = 80, pure_noise_frac: float = 0.10,
                       keep_prob: float = 0.5, ppm_sigma: float = 3.0, charges=((2, 0.6), (3, 0.3), (4, 0.1)),
                       annotate_charge: bool = True, mass_shift_frac: float = 0.0, chimeric: int = 1,

@@ -34,6 +34,14 @@ CONFIGS = {
                scorer=dict(wide_window=True, chimera=True, report_psms=5, min_precursor_charge=2, max_precursor_charge=4),
                spectra_kwargs=dict(chimeric=3, isolation_half_width=6.0, annotate_charge=False), cpu_sample=4096,
                metric="spectra/sec (whole node), fragment-index search-and-score, chimeric wide-window search"),
+    # not a BASELINE.json configuration: C3's digest and search over a proteome of paralog families (synthetic.paralog_fasta:
+    # shared and near-identical peptides, I/L twins, tandem repeats), where equal hyperscores at the reported rank are common —
+    # the parity suite's tie-rich case (tests/test_gpu_config_scale.py) and the retry-pass stress of scripts/ab_env.py
+    "C3T": dict(name="C3T: C3's search over 5100 paralog families x 4 (shared / near-identical / I-L-twin peptides)", proteins=5100,
+                fasta_seed=1012, spectra=500000, spectra_seed=2012, fasta="paralog", paralog_copies=4,
+                db=dict(_DB, enzyme=_ENZ1, variable_mods={"M": [15.9949], "[": [42.010565]}, max_variable_mods=2),
+                scorer=dict(), spectra_kwargs=dict(varmod_frac=0.15), cpu_sample=16384,
+                metric="spectra/sec (whole node), fragment-index search-and-score, human tryptic narrow search, tie-rich proteome"),
 }
 DEFAULT_CONFIG = "C3"  # BASELINE.json's metric is quoted on the human tryptic narrow search; it fits one GPU
 
@@ -53,8 +61,11 @@ def scorer_params(cfg):
 
 def build_host_db(cfg, proteins: Optional[int] = None, peptides_only: bool = False):
     from .api import DatabaseParameters
-    from .synthetic import synthetic_fasta
-    fasta = synthetic_fasta(proteins or cfg["proteins"], cfg["fasta_seed"])
+    from .synthetic import paralog_fasta, synthetic_fasta
+    if cfg.get("fasta") == "paralog":
+        fasta = paralog_fasta(proteins or cfg["proteins"], cfg["paralog_copies"], cfg["fasta_seed"])
+    else:
+        fasta = synthetic_fasta(proteins or cfg["proteins"], cfg["fasta_seed"])
     return DatabaseParameters(**cfg["db"]).build(fasta, peptides_only=peptides_only)
 
 

@@ -2,7 +2,7 @@
 # One GPU-box pass for the round's evidence: the full GPU test suite, then per config the bench line (live PMC traffic, CPU
 # thread table) and a rocprofv3 kernel trace, summarised into profiles/.
 # usage: scripts/gpu_round.sh <tag> [configs...]      (run through gpurun from the repo root)
-TAG=${1:-r02}; shift; CFGS=${@:-C3 C2 C4 C5}
+TAG=${1:-r03}; shift; CFGS=${@:-C3 C2 C4 C5}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1; tail -1 $OUT/build.log
 ( time timeout 1500 python -m pytest tests -m gpu -q --durations=10 ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -18 $OUT/pytest_gpu.log

@@ -41,13 +41,15 @@ def world_for(name):
     return _worlds[key]
 
 
-def _check(name, every, monkeypatch=None, n=N_SPECTRA, env=None, begin=0):
+def _check(name, every, monkeypatch=None, n=N_SPECTRA, env=None, begin=0, params=None, edit=None):
     w = world_for(name)
     cfg = CONFIGS[name]
-    params = scorer_params(cfg)
+    params = params or scorer_params(cfg)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
     batch, _ = workload_batch(cfg, w.host, begin, begin + n)
+    if edit:
+        batch = edit(batch)
     scorer = Scorer(w.dev, params)
     dbatch = scorer.upload(batch)
     gf, gc = scorer.score_resident(dbatch)
@@ -90,6 +92,31 @@ def test_c5_few_workgroups_cross_arena_chunks(gpu_required, monkeypatch):
     run through several 64 Ki-entry arena chunks (kernels.hip: ARENA_CHUNK) — chunk boundaries inside a query's chain."""
     batch, n_psm, t = _check("C5", every=0, monkeypatch=monkeypatch, env={"SAGE_HIP_TILE_BLOCKS": "48"})
     assert t["arena_entries"] > 2 * 48 * 65536, t  # more than the first two chunks of every workgroup
+
+
+def test_c3t_paralog_families_tie_at_the_reported_rank(gpu_required):
+    """C3's search over a proteome of paralog families (synthetic.paralog_fasta: peptides shared between paralogs, one residue
+    apart, isoleucine / leucine twins, tandem repeats): equal hyperscores meet at the reported rank for a large share of the
+    spectra, so the ORDER of the preliminary list — the reference's heap layout — decides which peptide is reported.  Every
+    such spectrum goes through the exact retry pass and must come out as the oracle has it, heap order included."""
+    batch, n_psm, t = _check("C3T", every=8)
+    assert batch.n >= 4000 and n_psm > 0.8 * batch.n * 0.85 and t["n_wide"] == 0
+    assert t["n_retry"] > 0.2 * batch.n, t  # (>= 20 % of the spectra tie at rank 1: the point of this workload)
+
+
+def test_c3t_unknown_charge_and_isotope_errors(gpu_required):
+    """The same database at config scale with the fan-out of scoring.rs:384-462 switched on: no precursor charge in the
+    spectra (charges 2..4 are tried, scoring.rs:437-450), isotope errors -1..3 folded per charge (scoring.rs:391-405),
+    three reported PSMs."""
+    from sage_amd.api import ScorerParams, SpectrumBatch
+
+    def no_charge(b):
+        return SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current,
+                             b.isolation_lo, b.isolation_hi, b.scan_start_time, b.inverse_ion_mobility, b.file_id)
+
+    params = ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=3)
+    batch, n_psm, t = _check("C3T", every=16, n=2048, params=params, edit=no_charge, begin=N_SPECTRA)
+    assert n_psm > 2 * 0.8 * batch.n * 0.85 and t["n_retry"] > 0
 
 
 def test_c4_open_search(gpu_required):
