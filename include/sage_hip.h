@@ -299,6 +299,8 @@ typedef struct SageTiming {
     uint32_t n_retry;  /* spectra with equal hyperscores at a reported rank, re-run with exact heap layouts (the retry pass) */
     float retry_ms;    /* of total_ms: that retry pass */
     uint32_t n_tied;   /* SAGE_HIP_FUSED=1 only: narrow spectra with such a tie, settled inside the fused first-pass kernel */
+    uint32_t n_ways;   /* sage_hip_score_resident: parts of the batch scored next to each other on their own streams (then
+                        * prelim_ms / rescore_ms are sums over parts that overlap in time; total_ms is the wall span) */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
 

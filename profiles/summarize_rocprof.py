@@ -16,14 +16,14 @@ def main():
     tag, config, trace = sys.argv[1], sys.argv[2], sys.argv[3]
     bench = sys.argv[4] if len(sys.argv) > 4 else None
     out = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --steps 5 --warmup 2 --no-extras   ({tag})\n",
-           "# 7 calls of score_resident (2 warm-up + 5 timed); the search kernels show twice per call (first pass + exact retry pass)\n"]
+           "# 7 calls of score_resident (2 warm-up + 5 timed); narrow_kernel is the exact retry pass, the large-window kernels show twice per call\n"]
     con = sqlite3.connect(trace)
     out.append(f"{'kernel':<70} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'pct':>6}\n")
     per_step = {}
     for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         s = short(name)
         out.append(f"{s:<70} {calls:>6} {total / 1e3:>10.2f} {avg:>10.1f} {pct:>6.2f}\n")   # the view is in microseconds
-        if s.startswith(("prelim_", "tile_", "rescore", "schedule")):
+        if s.startswith(("prelim_", "tile_", "rescore", "schedule", "narrow_", "search_")):
             per_step[s] = total / 1e3 / 7.0
     out.append("\n# search kernels, ms per step (total / 7 calls):\n")
     for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
@@ -33,7 +33,7 @@ def main():
         q = ("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, sgpr_count, count(*) "
              "from kernels group by name, grid_x, workgroup_x, lds_size")
         for r in con.execute(q):
-            if short(r[0]).startswith(("prelim_", "tile_", "rescore")):
+            if short(r[0]).startswith(("prelim_", "tile_", "rescore", "narrow_", "search_")):
                 out.append(f"  {short(r[0]):<40} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]} n={r[7]}\n")
     except sqlite3.Error as e:
         out.append(f"(resource query failed: {e})\n")

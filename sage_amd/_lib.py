@@ -148,6 +148,7 @@ class SageTiming(C.Structure):
         ("n_retry", C.c_uint32),
         ("retry_ms", C.c_float),
         ("n_tied", C.c_uint32),
+        ("n_ways", C.c_uint32),
     ]
 
 

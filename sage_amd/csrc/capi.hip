@@ -182,6 +182,13 @@ struct SageScorer {
     hipStream_t up_stream = nullptr, down_stream = nullptr;  // streaming pipeline: H2D of batch c + 1, D2H of batch c - 1
     hipStream_t side_stream = nullptr;  // kernels of one batch that may run next to each other (the two heap-replay kernels)
     Event side_fork, side_join;
+    // a resident narrow-search step in `ways` parts, each with its own stream (part 0: `stream`): the parts' kernels overlap each
+    // other's cold starts, tails and retry chains (what two scorer handles on two host threads get, inside one call)
+    uint32_t ways = 1;               // SAGE_HIP_WAYS=2..4 (measured on C3: -1 % wall at 500 000 spectra, -6 % at 62 500 with two
+                                     // parts, nothing more with three or four; off by default: a launch that shares the GPU
+                                     // has no duration one could hold against a roofline)
+    hipStream_t way_stream[3] = {nullptr, nullptr, nullptr};
+    Event way_fork, way_join[3], way_begin, way_end;
     DevBuf<double> lnfact;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
@@ -198,7 +205,7 @@ struct SageScorer {
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
     uint32_t qmax = 1;
     WorkSet ws;
-    OutSet outs[2];
+    OutSet outs[4];             // [0..1]: the two slots of the streaming pipeline; [0..ways): the concurrent parts of a resident step
     SageDeviceBatch slots[2];   // input double buffer of the streaming pipeline
     uint32_t chunk = 65536;     // spectra per pipeline stage (SAGE_HIP_CHUNK)
     // scratch of sage_hip_annotate_resident / sage_hip_quick_score_resident, grow-only
@@ -676,6 +683,12 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
+    for (hipStream_t& ws : s->way_stream) HIP_TRY(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
+    HIP_TRY(s->way_fork.create(false));
+    for (Event& e : s->way_join) HIP_TRY(e.create(false));
+    HIP_TRY(s->way_begin.create(true));
+    HIP_TRY(s->way_end.create(true));
     HIP_TRY(s->side_fork.create(false));
     HIP_TRY(s->side_join.create(false));
     for (OutSet& o : s->outs) {
@@ -724,7 +737,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
 
 static void scorer_release(SageScorer* s) {
     (void)hipSetDevice(s->db->device);
-    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream, s->side_stream})
+    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream, s->side_stream, s->way_stream[0], s->way_stream[1], s->way_stream[2]})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
@@ -1218,11 +1231,14 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
 //   repeats the batch with wide == true if the guess was wrong.  SAGE_HIP_FUSED=1: narrow_kernel as the first pass, too.
 //   Other modes: preliminary kernel, large-window kernels, rescoring kernel.
 // `rec`: where the PSM records go — device memory (null: the OutSet's buffer) or the device-side view of page-locked host memory.
+// `list_off` / `count_buf`: a part of a batch scored next to other parts (score_resident_locked): its queue / retry lists start
+// at that offset of the shared arrays, and the PSM counts of all parts go to one buffer (they are indexed by spectrum).
 static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st,
-                           SageFeature* rec = nullptr, bool wide = true) {
+                           SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr) {
     int rc = ensure_work(s, view.n);
     if (rc != SAGE_HIP_OK) return rc;
     if (!rec) rec = o.features.p;
+    if (!count_buf) count_buf = o.out_count.p;
     DevScorer sc = s->dev;
     const bool production = mode == MODE_SCORE && with_rescore;
     const bool fused = s->fused && production;
@@ -1239,10 +1255,14 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     o.wide_launched = wide;
     o.n = view.n;
     DevBatchView v2 = view;
-    v2.order = s->ws.retry.p;  // filled by the rescoring kernel of the first pass, in no particular order
+    v2.order = s->ws.retry.p + list_off;  // filled by the rescoring kernel of the first pass, in no particular order
     v2.n_dev = o.counters.p + CTR_RETRY;
     if (one_launch && ++s->ws.epoch == 0) s->ws.epoch = 1;
     DevWork w1 = make_work(s, o, 0), w2 = make_work(s, o, 1);
+    for (DevWork* w : {&w1, &w2}) {
+        w->queue += list_off;
+        w->retry += list_off;
+    }
     if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
@@ -1258,9 +1278,9 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
     HIP_TRY(hipEventRecord(o.ev[0].e, st));
     if (fused)
-        launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
+        launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
     else if (one_launch)
-        launch_search(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
+        launch_search(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
     else
         launch_prelim(s->db->view, sc1, view, w1, st);
     HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
@@ -1270,10 +1290,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     }
     HIP_TRY(hipEventRecord(o.ev[1].e, st));
     if (with_rescore && (wide || !(fused || one_launch)))  // (behind search_kernel / the fused kernel: only the spectra the large-window kernels assembled)
-        launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, o.out_count.p, nullptr, st);
+        launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
     HIP_TRY(hipEventRecord(o.ev[2].e, st));
     if (o.two_pass) {
-        launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, o.out_count.p, st);
+        launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
         HIP_TRY(hipGetLastError());
         if (wide) {
             launch_prelim_tile(s->db->view, sc2, v2, w2, st, &side);
@@ -1281,7 +1301,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         }
         HIP_TRY(hipEventRecord(o.ev[3].e, st));
         if (wide)
-            launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, o.out_count.p, nullptr, st);
+            launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
         HIP_TRY(hipEventRecord(o.ev[4].e, st));
     }
     HIP_TRY(hipGetLastError());
@@ -1345,21 +1365,58 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
     reset_timing(s);
     OutSet& o = s->outs[0];
     SageFeature* direct = s->zero_copy && b->n ? (SageFeature*)device_view(out) : nullptr;
+    const size_t rec_bytes = (size_t)b->n * s->params.report_psms * sizeof(SageFeature);
     for (int attempt = 0;; attempt++) {
-        int rc = enqueue_compute(s, b->view, o, true, s->exact_always ? MODE_EXACT : MODE_SCORE, s->stream, direct, b->maybe_wide);
+        // A narrow-search batch in `ways` parts of the launch schedule (consecutive precursor masses), each on its own stream:
+        // a part's kernels fill the GPU while another part's kernel starts cold, drains, or waits on the few wavefronts of its
+        // retry pass.  Large-window batches go as one (their steps are long; the parts would fight over the candidate arena).
+        const uint32_t ways = (!b->maybe_wide && !s->exact_always && b->n >= 8192u * s->ways) ? s->ways : 1u;
+        int rc = ensure_work(s, b->n);
         if (rc != SAGE_HIP_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
+        SageFeature* const rec = direct ? direct : o.features.p;
+        HIP_TRY(hipEventRecord(s->way_begin.e, s->stream));
+        if (ways > 1) HIP_TRY(hipEventRecord(s->way_fork.e, s->stream));
+        for (uint32_t wy = 0; wy < ways; wy++) {
+            const uint32_t start = (uint32_t)((uint64_t)b->n * wy / ways), end = (uint32_t)((uint64_t)b->n * (wy + 1) / ways);
+            hipStream_t st = wy ? s->way_stream[wy - 1] : s->stream;
+            if (wy) HIP_TRY(hipStreamWaitEvent(st, s->way_fork.e, 0));
+            DevBatchView v = b->view;
+            v.order += start;
+            v.n = end - start;
+            OutSet& ow = s->outs[wy];
+            rc = enqueue_compute(s, v, ow, true, s->exact_always ? MODE_EXACT : MODE_SCORE, st, rec, b->maybe_wide, start, o.out_count.p);
+            if (rc != SAGE_HIP_OK) {
+                for (uint32_t k = 0; k < wy; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
+                return rc;
+            }
+            HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+            if (wy) {
+                HIP_TRY(hipEventRecord(s->way_join[wy - 1].e, st));
+                HIP_TRY(hipStreamWaitEvent(s->stream, s->way_join[wy - 1].e, 0));
+            }
+        }
+        HIP_TRY(hipEventRecord(s->way_end.e, s->stream));
         if (b->n) {
             HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-            if (!direct)
-                HIP_TRY(hipMemcpyAsync(out, o.features.p, (size_t)b->n * s->params.report_psms * sizeof(SageFeature), hipMemcpyDeviceToHost,
-                                       s->stream));
+            if (!direct) HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, s->stream));
         }
         HIP_TRY(hipStreamSynchronize(s->stream));
         bool redo = false;
-        rc = collect(s, o, nullptr, &redo);
-        if (rc != SAGE_HIP_OK || !redo) return rc;
+        for (uint32_t wy = 0; wy < ways; wy++) {
+            bool r = false;
+            rc = collect(s, s->outs[wy], nullptr, &r);
+            if (rc != SAGE_HIP_OK) return rc;
+            redo = redo || r;
+        }
+        if (!redo) {
+            float wall = 0.f;
+            HIP_TRY(hipEventElapsedTime(&wall, s->way_begin.e, s->way_end.e));
+            s->timing.total_ms = wall;  // (prelim_ms / rescore_ms: summed over the parts, which overlap in time)
+            s->timing.n_ways = ways;
+            return SAGE_HIP_OK;
+        }
         if (attempt) return fail(SAGE_HIP_ERR_INTERNAL, "large-window queue not drained");
+        reset_timing(s);
         b->maybe_wide = true;  // (and stays so: the batch holds large windows after all)
     }
 }

@@ -58,6 +58,15 @@ for s in sets:
         ref = (f, c)
     else:
         same = "same PSMs" if bench.same_psms(f, c, ref[0], ref[1]) else "DIFFERENT PSMs"
-    print(f"{name} n={batch.n} [{s or 'default'}]: {ms:.3f} ms/step  {batch.n / ms / 1e3:.2f} M spectra/s  prelim {np.mean(pm):.3f}  "
-          f"rescore {np.mean(rm):.3f}  retry pass {t['retry_ms']:.3f}  wide {t['n_wide']} retry {t['n_retry']} tied {t['n_tied']}  psms {int(c.sum())}  {same}", flush=True)
+    h2h = ""
+    if os.environ.get("AB_H2H"):  # host arrays in, host records out (sage_hip_score_batch), page-locked
+        locked = batch.page_locked()
+        scorer.score(locked)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scorer.score(locked)
+        h2h = f"  host-to-host {batch.n * steps / (time.perf_counter() - t0) / 1e6:.2f} M spectra/s"
+        del locked
+    print(f"{name} n={batch.n} [{s or 'default'}]:{h2h} {ms:.3f} ms/step  {batch.n / ms / 1e3:.2f} M spectra/s  prelim {np.mean(pm):.3f}  "
+          f"rescore {np.mean(rm):.3f}  retry pass {t['retry_ms']:.3f}  wide {t['n_wide']} retry {t['n_retry']} tied {t['n_tied']} ways {t['n_ways']} wall {t['total_ms']:.3f}  psms {int(c.sum())}  {same}", flush=True)
     scorer.close()

@@ -295,6 +295,16 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     assert t["n_tied"] > 50
     n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2), "I/L twins, isotope errors, fused kernel")
     monkeypatch.delenv("SAGE_HIP_FUSED")
+    monkeypatch.setenv("SAGE_HIP_WAYS", "3")  # a resident step in three parts on three streams (needs >= 8192 spectra per part)
+    big = w.batch.subset(np.arange(3 * 8192) % w.batch.n)
+    p2 = ScorerParams(report_psms=2)
+    scorer = Scorer(w.dev, p2)
+    gf, gc = scorer.score_resident(scorer.upload(big))
+    t = scorer.last_timing()
+    of, oc, _, _ = w.orc.score(p2, big)
+    assert_features_equal(gf, gc, of, oc, "I/L twins, narrow, three parts side by side")
+    assert t["n_ways"] == 3 and t["n_retry"] > 50
+    monkeypatch.delenv("SAGE_HIP_WAYS")
     monkeypatch.setenv("SAGE_HIP_ONE_LAUNCH", "1")  # preliminary and rescoring workgroups in one launch, handing over through HBM
     n, t = w.check(ScorerParams(report_psms=2), "I/L twins, narrow, one launch")
     assert t["n_retry"] > 50
