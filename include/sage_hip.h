@@ -215,7 +215,7 @@ typedef struct SageFeature {
 
 /* Scorer::score for every spectrum of the batch (scoring.rs:300-309), results in input order:
  * out[i*report_psms + r] for r < out_count[i], Feature.spec_index == i.
- * Host memory in, host memory out, as a three-stage pipeline over chunks of the batch (SAGE_HIP_CHUNK spectra, default 65536):
+ * Host memory in, host memory out, as a three-stage pipeline over chunks of the batch (SAGE_HIP_CHUNK spectra, default 131072):
  * chunk c + 1 is staged and uploaded on a copy stream while chunk c is scored and the PSM records of chunk c - 1 come back —
  * the reader / processor / search overlap of runner.rs:365-375, 450-461 at the PCIe boundary.  Arrays allocated with
  * sage_hip_host_alloc (page-locked) move by DMA at full PCIe rate; pageable arrays are accepted and staged through
@@ -224,7 +224,9 @@ typedef struct SageFeature {
 int sage_hip_score_batch(SageScorer* scorer, const SageSpectrumBatch* batch, SageFeature* out,
                          uint32_t* out_count);
 
-/* The same split in two so a batch can stay resident in HBM across calls. */
+/* The same split in two so a batch can stay resident in HBM across calls.  `out` allocated with sage_hip_host_alloc
+ * (page-locked, mapped) is written by the rescoring kernels themselves — no download phase; it holds the results when the
+ * call returns.  Any other host memory gets a device buffer and a copy. */
 int sage_hip_batch_upload(SageScorer* scorer, const SageSpectrumBatch* batch, SageDeviceBatch** out);
 void sage_hip_batch_free(SageDeviceBatch* batch);
 int sage_hip_score_resident(SageScorer* scorer, SageDeviceBatch* batch, SageFeature* out, uint32_t* out_count);

@@ -207,7 +207,7 @@ struct SageScorer {
     WorkSet ws;
     OutSet outs[4];             // [0..1]: the two slots of the streaming pipeline; [0..ways): the concurrent parts of a resident step
     SageDeviceBatch slots[2];   // input double buffer of the streaming pipeline
-    uint32_t chunk = 65536;     // spectra per pipeline stage (SAGE_HIP_CHUNK)
+    uint32_t chunk = 131072;    // spectra per pipeline stage (SAGE_HIP_CHUNK): 39.9 M spectra/s host to host on C3 against 38.2 M at 65 536 and 37.3 M at 262 144
     // scratch of sage_hip_annotate_resident / sage_hip_quick_score_resident, grow-only
     DevBuf<SageFeature> an_feats;
     DevBuf<uint32_t> an_counts;
