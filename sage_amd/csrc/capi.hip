@@ -200,6 +200,8 @@ struct SageScorer {
     bool one_launch = false;    // SAGE_HIP_ONE_LAUNCH=1: the first pass of narrow windows as one launch of two kinds of workgroups
                                 // (kernels.hip: search_kernel) instead of prelim_kernel, then rescore_kernel — measured slower, like
                                 // the fused kernel: the larger kernel body costs scalar-register spills
+    uint32_t search_lag = 0;         // SAGE_HIP_SEARCH_LAG (DevWork::search_lag)
+    uint64_t replay_split = 32768;   // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split)
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
@@ -675,6 +677,9 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_SCHED_DESC")) d.xcd_chunk |= atoi(e) ? 0x80000000u : 0u;
     if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_FUSED")) s->fused = atoi(e) != 0;
+    if (const char* e = getenv("SAGE_HIP_SEARCH_LAG")) s->search_lag = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) s->replay_split = (uint64_t)atoll(e) & 0xFFFFFFFFull;
+    if (const char* e = getenv("SAGE_HIP_REPLAY_LANE_MAX")) s->replay_split |= (uint64_t)(uint32_t)atoll(e) << 32;
     if (const char* e = getenv("SAGE_HIP_ONE_LAUNCH")) s->one_launch = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_NO_ZEROCOPY")) s->zero_copy = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
@@ -1200,8 +1205,8 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
     w.item_of = ws.item_of.p;
     w.ready = ws.ready.p;
     w.epoch = ws.epoch;
-    w.search_lag = 0;
-    if (const char* e = getenv("SAGE_HIP_SEARCH_LAG")) w.search_lag = (uint32_t)std::max(0, atoi(e));
+    w.search_lag = s->search_lag;
+    w.replay_split = s->replay_split;
     w.reuse = 0;
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.tile_blocks = s->tile_blocks;
@@ -1665,7 +1670,7 @@ int sage_hip_initial_hits(SageScorer* s, SageDeviceBatch* b, uint64_t* packed, u
     HIP_TRY(hipMemcpy(tot.data(), s->ws.totals.p, tot.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(st.data(), s->ws.status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) {
-        if (st[i] != ST_OK) return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": status " + std::to_string(st[i]));
+        if (st[i] != ST_OK && st[i] != ST_OK_ORDERED) return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum " + std::to_string(i) + ": status " + std::to_string(st[i]));
         for (uint32_t j = 0; j < len[i]; j++) packed[(size_t)i * cap + j] = c[(size_t)i * kmax + j];
         if (matched_peaks) matched_peaks[i] = tot[2 * i];
         if (scored_candidates) scored_candidates[i] = tot[2 * i + 1];

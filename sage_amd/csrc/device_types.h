@@ -107,6 +107,9 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* item_of;     // [n] spectrum -> its item in the first pass's queue; bit 31: count again (a u8 counter may have wrapped)
     uint32_t* ready;       // [n] search_kernel: == epoch once the spectrum's preliminary list is in HBM (written with agent-scope release)
     uint32_t epoch;        //     of this launch (never 0; the array is zeroed when it is allocated)
+    uint64_t replay_split; // which heap-replay kernel takes a query: low 32 bits = queries up to which every query gets a wavefront
+                           //     (SAGE_HIP_REPLAY_WAVE_MAX, default 32768), high 32 bits = stream words above which a query does
+                           //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
@@ -121,7 +124,8 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
 };
 
 enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
-       ST_DONE = 4 };  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
+       ST_DONE = 4,
+       ST_OK_ORDERED = 5 };  // ST_OK, and no trim_hits of the spectrum dropped anything: the order-free list IS the reference's list  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
        CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
        CTR_COUNT = 8 };

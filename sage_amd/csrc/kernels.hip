@@ -580,6 +580,8 @@ struct PrelimResult {
     uint32_t matched, scored;   // InitialHits.matched_peaks, .scored_candidates
     bool ok;                    // false: a candidate list overflowed its LDS capacity
     bool deferred;              // some precursor window exceeds the LDS counters: the spectrum belongs to the large-window kernels
+    bool untrimmed;             // no trim_hits had anything to drop (every list stayed within its k): the list is the reference's
+                                //     Vec as it stands, whatever the trim mode — a tie at a reported rank needs no exact pass
 };
 template <bool PROBE, class PC>
 __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
@@ -587,7 +589,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
     const uint32_t lane = lane_id();
     Counters cnt;
     cnt.p = L.cnt;
-    PrelimResult res{0u, 0u, 0u, true, false};
+    PrelimResult res{0u, 0u, 0u, true, false, true};
     {
         const uint32_t P = si.P, nfz_max = si.nfz_max;
         const float* __restrict__ masses = b.masses + si.p0;
@@ -810,8 +812,10 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                     }
                 } else if (!exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
                     // (done: the k largest slots by (count, slot) without replaying the heap)
+                    res.untrimmed = false;
                 } else {
                     // keys `matched << 16 | slot` (potential <= wcap <= 65536): same order as PreScore inside one query
+                    res.untrimmed = false;
                     scored = 0;
                     Heap32 hp;
                     {
@@ -843,6 +847,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                 pc.mark(3);
             }
             if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
+                if (A.len > trim_k(A.len, sc.report_psms)) res.untrimmed = false;
                 ulist_trim(A, sc.report_psms, exact || sc.list_cap > 4 * WAVE);
                 __syncthreads();
                 for (uint32_t base = 0; base < A.stored; base += WAVE) {
@@ -857,6 +862,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
             res.deferred = true;
             return res;
         }
+        if (B.len > trim_k(B.len, sc.report_psms)) res.untrimmed = false;
         ulist_trim(B, sc.report_psms, exact || sc.list_cap > 4 * WAVE);  // scoring.rs:460
         __syncthreads();
         res.stored = B.stored;
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         }
         if (lane == 0) {
             if (!r.ok) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
-            w.status[spec] = r.ok ? ST_OK : ST_OVERFLOW;
+            w.status[spec] = r.ok ? (r.untrimmed ? ST_OK_ORDERED : ST_OK) : ST_OVERFLOW;
             w.cand_len[spec] = r.stored;
             w.totals[2 * spec] = r.matched;
             w.totals[2 * spec + 1] = r.scored;
@@ -1729,7 +1735,7 @@ __device__ __forceinline__ void tile_replay_block(const DevScorer& sc, const Dev
 __global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w, uint64_t wave_max) {
     __shared__ uint64_t heap[64 * 64];  // heap[i * 64 + lane]: conflict-free whatever i each lane is at
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    if (n_q <= wave_max) return;
+    if (n_q <= (wave_max & 0xFFFFFFFFull)) return;
     for (uint64_t blk = blockIdx.x; blk * 64 < n_q; blk += gridDim.x) {
         tile_replay_block(sc, w, heap, n_q, (uint32_t)blk, wave_max);
         __syncthreads();
@@ -1779,10 +1785,12 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
 // Which of the two replay kernels takes a query when both are launched (more queries than `wave_max`): the lane-per-query
 // kernel lasts as long as the longest stream among its 64 lanes, one word per round, so streams above LANE_MAX_CAND words go
 // to the wavefront-per-query kernel, which skims 64 words per step and only pays for the offers that enter the heap.
-constexpr uint32_t LANE_MAX_CAND = 4096;
+constexpr uint32_t LANE_MAX_CAND = 4096;  // (SAGE_HIP_REPLAY_LANE_MAX overrides it: the upper 32 bits of the kernels' `wave_max`)
 __device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_t n_q, uint64_t wave_max) {
+    const uint32_t lane_max = (uint32_t)(wave_max >> 32) ? (uint32_t)(wave_max >> 32) : LANE_MAX_CAND;
+    wave_max &= 0xFFFFFFFFull;
     if (wave_max == 0) return false;  // (SAGE_HIP_REPLAY_WAVE_MAX=0: tests force the lane-per-query kernel)
-    return n_q <= wave_max || rec.n_cand > LANE_MAX_CAND;
+    return n_q <= wave_max || rec.n_cand > lane_max;
 }
 __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in, uint64_t n_q, uint64_t wave_max) {
     const uint32_t lane = lane_id();
@@ -2568,7 +2576,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     const uint32_t spec = b.order ? b.order[pos] : pos;
     const uint32_t st = w.status[spec];
     if (st == ST_DONE) return;  // reported by the fused narrow kernel of this pass
-    if (st != ST_OK) {
+    if (st != ST_OK && st != ST_OK_ORDERED) {
         if (lane == 0 && !keep) out_count[spec] = 0;
         return;
     }
@@ -2583,8 +2591,9 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     }
     const uint32_t ncand = w.cand_len[spec];
     const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
+    // (a list no trim touched is the reference's list already: equal hyperscores are ranked by it, no retry)
     rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
-                     sc.exact != 0, true, pc);
+                     sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
 // ---- the first pass of a narrow search as ONE launch of two kinds of workgroups ----------------------------------------------------
@@ -2654,7 +2663,8 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
         } else {
             if (lane == 0) {
                 if (!r.ok) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
-                __hip_atomic_store(w.status + spec, (uint32_t)(r.ok ? ST_OK : ST_OVERFLOW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w.status + spec, (uint32_t)(r.ok ? (r.untrimmed ? ST_OK_ORDERED : ST_OK) : ST_OVERFLOW), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(w.cand_len + spec, r.stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(w.totals + 2 * spec, r.matched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(w.totals + 2 * spec + 1, r.scored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2682,7 +2692,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
     while (__hip_atomic_load(w.ready + spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != w.epoch) __builtin_amdgcn_s_sleep(32);
     asm volatile("" ::: "memory");
     const uint32_t st = __hip_atomic_load(w.status + spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (st != ST_OK) {  // queued for the large-window kernels (their rescoring follows in a launch of its own), or overflowed
+    if (st != ST_OK && st != ST_OK_ORDERED) {  // queued for the large-window kernels (their rescoring follows in a launch of its own), or overflowed
         if (lane == 0 && st == ST_OVERFLOW) out_count[spec] = 0;
         return;
     }
@@ -2691,8 +2701,8 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
     const uint32_t tot_s = __hip_atomic_load(w.totals + 2 * spec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t mine = lane < ncand ? __hip_atomic_load(w.cand + (size_t)spec * sc.kmax + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                        : PRESCORE_EMPTY;
-    const bool done = rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s, false,
-                                       true, pc);
+    const bool done = rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s,
+                                       st == ST_OK_ORDERED, true, pc);
     if (done && lane == 0) w.status[spec] = ST_DONE;  // (a rescore_kernel behind the large-window kernels leaves it alone)
 }
 
@@ -2761,7 +2771,7 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
             pc.rebase(1);  // (the rescoring phase accounts under kernel 1)
             __syncthreads();  // the list is in registers: the preliminary phase's LDS is free
             if (rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
-                                 exact, false, pc) || exact)
+                                 exact || r.untrimmed, false, pc) || exact)
                 break;
             exact = true;  // equal hyperscores at a reported rank: once more, with bounded_min_heapify replayed (heap.rs:7-28)
             if (lane == 0) atomicAdd(w.n_deferred + CTR_TIED, 1u);
@@ -2773,7 +2783,7 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
 // quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
 __global__ __launch_bounds__(256) void quick_mark_kernel(DevScorer sc, uint32_t n, DevWork w, uint8_t* __restrict__ keep) {
     const uint32_t spec = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63u;
-    if (spec >= n || w.status[spec] != ST_OK) return;
+    if (spec >= n || (w.status[spec] != ST_OK && w.status[spec] != ST_OK_ORDERED)) return;
     if (lane < w.cand_len[spec]) {
         const uint32_t pep = prescore_peptide(w.cand[(size_t)spec * sc.kmax + lane]);
         if (pep != 0xFFFFFFFFu) keep[pep] = 1;
@@ -2912,12 +2922,11 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     // the case with order-free trims, where only queries with a clipped histogram are replayed; with more queries than that, a
     // lane per query (far fewer instructions per offer, but a wavefront lasts as long as its longest stream) for all but the
     // long streams
-    uint64_t wave_max = 32768;
-    if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) wave_max = (uint64_t)atoll(e);
-    if (!sc.exact && wave_max) wave_max = ~0ull;
+    uint64_t wave_max = w.replay_split;
+    if (!sc.exact && (wave_max & 0xFFFFFFFFull)) wave_max |= 0xFFFFFFFFull;
     // (the two take disjoint sets of queries: side by side when the caller lends a second stream — the long streams of the one
     // are a few serial wavefronts, the other fills the rest of the GPU)
-    const bool both = sc.exact || !wave_max;
+    const bool both = sc.exact || !(wave_max & 0xFFFFFFFFull);
     hipStream_t lane_stream = (hipStream_t)stream;
     if (both && side) {
         lane_stream = (hipStream_t)side->stream;
