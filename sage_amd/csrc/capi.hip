@@ -200,13 +200,15 @@ struct SageScorer {
     bool one_launch = false;    // SAGE_HIP_ONE_LAUNCH=1: the first pass of narrow windows as one launch of two kinds of workgroups
                                 // (kernels.hip: search_kernel) instead of prelim_kernel, then rescore_kernel — measured slower, like
                                 // the fused kernel: the larger kernel body costs scalar-register spills
+    bool two_lanes = true;           // streaming pipeline: two chunks of a narrow batch side by side (SAGE_HIP_ONE_LANE=1: one at a time)
     uint32_t search_lag = 0;         // SAGE_HIP_SEARCH_LAG (DevWork::search_lag)
     uint64_t replay_split = 32768;   // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split)
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
     uint32_t qmax = 1;
-    WorkSet ws;
+    WorkSet ws;                 // the working set (lane 0)
+    WorkSet ws2;                // a second one: the streaming pipeline scores two chunks of a narrow batch side by side (lane 1)
     OutSet outs[4];             // [0..1]: the two slots of the streaming pipeline; [0..ways): the concurrent parts of a resident step
     SageDeviceBatch slots[2];   // input double buffer of the streaming pipeline
     uint32_t chunk = 131072;    // spectra per pipeline stage (SAGE_HIP_CHUNK): 39.9 M spectra/s host to host on C3 against 38.2 M at 65 536 and 37.3 M at 262 144
@@ -677,6 +679,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_SCHED_DESC")) d.xcd_chunk |= atoi(e) ? 0x80000000u : 0u;
     if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_FUSED")) s->fused = atoi(e) != 0;
+    if (const char* e = getenv("SAGE_HIP_ONE_LANE")) s->two_lanes = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_SEARCH_LAG")) s->search_lag = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) s->replay_split = (uint64_t)atoll(e) & 0xFFFFFFFFull;
     if (const char* e = getenv("SAGE_HIP_REPLAY_LANE_MAX")) s->replay_split |= (uint64_t)(uint32_t)atoll(e) << 32;
@@ -1165,8 +1168,8 @@ static uint64_t arena_entries_for(const SageScorer* s, uint32_t n) {
     return e;
 }
 
-static int ensure_work(SageScorer* s, uint32_t n) {
-    WorkSet& w = s->ws;
+static int ensure_work(SageScorer* s, uint32_t n, int lane = 0) {
+    WorkSet& w = lane ? s->ws2 : s->ws;
     for (OutSet& o : s->outs) {
         HIP_TRY(o.features.reserve((size_t)n * s->params.report_psms));
         HIP_TRY(o.out_count.reserve(n));
@@ -1192,9 +1195,9 @@ static int ensure_work(SageScorer* s, uint32_t n) {
     return SAGE_HIP_OK;
 }
 
-static DevWork make_work(SageScorer* s, OutSet& o, int pass) {
+static DevWork make_work(SageScorer* s, OutSet& o, int pass, int lane = 0) {
     DevWork w{};
-    WorkSet& ws = s->ws;
+    WorkSet& ws = lane ? s->ws2 : s->ws;
     w.cand = ws.cand.p;
     w.cand_len = ws.cand_len.p;
     w.totals = ws.totals.p;
@@ -1238,9 +1241,14 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
 // `rec`: where the PSM records go — device memory (null: the OutSet's buffer) or the device-side view of page-locked host memory.
 // `list_off` / `count_buf`: a part of a batch scored next to other parts (score_resident_locked): its queue / retry lists start
 // at that offset of the shared arrays, and the PSM counts of all parts go to one buffer (they are indexed by spectrum).
+// `lane`: which of the scorer's two working sets (a lane-1 batch never takes the large-window path: the replay kernels' side
+// stream is lane 0's).
 static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st,
-                           SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr) {
-    int rc = ensure_work(s, view.n);
+                           SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr,
+                           int lane = 0) {
+    if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
+    WorkSet& wset = lane ? s->ws2 : s->ws;
+    int rc = ensure_work(s, view.n, lane);
     if (rc != SAGE_HIP_OK) return rc;
     if (!rec) rec = o.features.p;
     if (!count_buf) count_buf = o.out_count.p;
@@ -1260,10 +1268,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     o.wide_launched = wide;
     o.n = view.n;
     DevBatchView v2 = view;
-    v2.order = s->ws.retry.p + list_off;  // filled by the rescoring kernel of the first pass, in no particular order
+    v2.order = wset.retry.p + list_off;  // filled by the rescoring kernel of the first pass, in no particular order
     v2.n_dev = o.counters.p + CTR_RETRY;
-    if (one_launch && ++s->ws.epoch == 0) s->ws.epoch = 1;
-    DevWork w1 = make_work(s, o, 0), w2 = make_work(s, o, 1);
+    if (one_launch && ++wset.epoch == 0) wset.epoch = 1;
+    DevWork w1 = make_work(s, o, 0, lane), w2 = make_work(s, o, 1, lane);
     for (DevWork* w : {&w1, &w2}) {
         w->queue += list_off;
         w->retry += list_off;
@@ -1453,6 +1461,7 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
     auto bail = [&](int rc) -> int {
         (void)hipStreamSynchronize(s->up_stream);
         (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamSynchronize(s->way_stream[0]);
         (void)hipStreamSynchronize(s->down_stream);
         s->outs[0].in_flight = s->outs[1].in_flight = false;
         return rc;
@@ -1463,12 +1472,19 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         if (e_ != hipSuccess) return bail(fail(SAGE_HIP_ERR_HIP, hipGetErrorString(e_)));   \
     } while (0)
     // kernels + the way home of the records of one chunk (its input is resident in s->slots[slot])
+    // Two chunks of a batch WITHOUT large windows are scored side by side, chunk k on compute lane k & 1 (own stream, own working
+    // set): the cold start, the tail and the retry chain of one chunk's kernels are filled by the other's (what two scorer
+    // handles on two host threads do, §6 of DESIGN.md, here inside the pipeline).  With large windows: lane 0 only.
+    auto lane_of = [&](int slot, bool wide) { return (!wide && mode == MODE_SCORE && s->two_lanes) ? slot : 0; };
     auto launch = [&](int slot, uint32_t c0, uint32_t c1, bool wide) -> int {
         SageDeviceBatch& in = s->slots[slot];
         OutSet& o = s->outs[slot];
-        int rc = enqueue_compute(s, in.view, o, true, mode, s->stream, direct ? direct + (size_t)c0 * rp : nullptr, wide);
+        const int lane = lane_of(slot, wide);
+        hipStream_t cs = lane ? s->way_stream[0] : s->stream;
+        HIP_TRY_BAIL(hipStreamWaitEvent(cs, in.up_done.e, 0));
+        int rc = enqueue_compute(s, in.view, o, true, mode, cs, direct ? direct + (size_t)c0 * rp : nullptr, wide, 0, nullptr, lane);
         if (rc != SAGE_HIP_OK) return bail(rc);
-        HIP_TRY_BAIL(hipEventRecord(o.comp_done.e, s->stream));
+        HIP_TRY_BAIL(hipEventRecord(o.comp_done.e, cs));
         // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
         // download, which itself follows its kernels: no device-side guard is needed for the input buffers
         HIP_TRY_BAIL(hipStreamWaitEvent(s->down_stream, o.comp_done.e, 0));
@@ -1524,7 +1540,6 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         // (the uploads of chunk k - 2 finished long ago — its kernels ran — so the staging block may be rewritten)
         rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, est, s->up_stream);
         if (rc != SAGE_HIP_OK) return bail(rc);
-        HIP_TRY_BAIL(hipStreamWaitEvent(s->stream, in.up_done.e, 0));
         rc = launch(slot, c0, c1, est.maybe_wide);
         if (rc != SAGE_HIP_OK) return rc;
         pend[slot] = Pending{c0, c1, slot};

@@ -27,6 +27,9 @@ n = int(args[1]) if len(args) > 1 else cfg["spectra"]
 steps = int(os.environ.get("AB_STEPS", "10"))
 host = build_host_db(cfg, peptides_only=True)
 batch, _ = bench.generate_workload(cfg, host, n)
+if os.environ.get("AB_SORT"):  # what a mass-ordered copy of the batch in HBM would buy: hand the batch over sorted already
+    z = np.where(batch.precursor_charge == 0, 2, batch.precursor_charge).astype(np.float32)
+    batch = batch.subset(np.argsort((batch.precursor_mz - np.float32(1.0072764)) * z, kind="stable"))
 dev = DeviceDatabase(host, 0, build_on_device=True)
 ref = None
 for s in sets:
