@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -165,6 +166,7 @@ struct SageDeviceBatch {
     DevBuf<uint8_t> charge;
     DevBuf<uint32_t> file_id, order, sort_a, sort_b, sort_idx;
     DevBuf<uint8_t> sort_tmp;
+    DevBuf<uint8_t> meta;    // streaming pipeline: the per-spectrum arrays in one block, the image of the staging block (one copy)
     bool maybe_wide = true;  // some precursor window may exceed the narrow kernel's LDS counters (estimated at upload; a wrong
                              // "no" is noticed after the step — the queue counter — and the step is repeated with the
                              // large-window kernels)
@@ -209,8 +211,8 @@ struct SageScorer {
     uint32_t qmax = 1;
     WorkSet ws;                 // the working set (lane 0)
     WorkSet ws2;                // a second one: the streaming pipeline scores two chunks of a narrow batch side by side (lane 1)
-    OutSet outs[4];             // [0..1]: the two slots of the streaming pipeline; [0..ways): the concurrent parts of a resident step
-    SageDeviceBatch slots[2];   // input double buffer of the streaming pipeline
+    OutSet outs[4];             // [k % 4]: the slots of the streaming pipeline; [0..ways): the concurrent parts of a resident step
+    SageDeviceBatch slots[4];   // input buffers of the streaming pipeline (chunk k in slot k % 4: uploads run ahead of the kernels)
     uint32_t chunk = 131072;    // spectra per pipeline stage (SAGE_HIP_CHUNK): 39.9 M spectra/s host to host on C3 against 38.2 M at 65 536 and 37.3 M at 262 144
     // scratch of sage_hip_annotate_resident / sage_hip_quick_score_resident, grow-only
     DevBuf<SageFeature> an_feats;
@@ -817,7 +819,7 @@ static WindowEstimate choose_probe(const SageScorer* s, uint32_t n, const float*
                                    const float* isolation_lo, const float* isolation_hi) {
     const SageScorerParams& p = s->params;
     const std::vector<float>& pm = s->db->h_pep_mono;
-    const uint32_t step = std::max<uint32_t>(1, n / 4096);
+    const uint32_t step = std::max<uint32_t>(1, n / 1024);  // (each sample costs two searches over the whole peptide list: ~0.2 us)
     double sum = 0.0;
     uint64_t widest = 0;
     uint32_t cnt = 0;
@@ -837,7 +839,12 @@ static WindowEstimate choose_probe(const SageScorer* s, uint32_t n, const float*
             }
             float lo, hi;
             sagecore::tol_bounds(tol, center, lo, hi);
-            const uint64_t wdw = (uint64_t)(std::upper_bound(pm.begin(), pm.end(), hi) - std::lower_bound(pm.begin(), pm.end(), lo));
+            // the window's upper end is searched for from its lower end, in doubling strides (windows are short next to the list)
+            const auto first = std::lower_bound(pm.begin(), pm.end(), lo);
+            size_t reach = 64;
+            while ((size_t)(pm.end() - first) > reach && first[reach] <= hi) reach *= 2;
+            const auto last = std::upper_bound(first, (size_t)(pm.end() - first) > reach ? first + reach : pm.end(), hi);
+            const uint64_t wdw = (uint64_t)(last - first);
             if (z == z0) sum += (double)wdw;
             widest = std::max(widest, wdw);
         }
@@ -880,19 +887,8 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     const bool has_iso = b->isolation_lo && b->isolation_hi, has_rt = b->scan_start_time != nullptr,
                has_ims = b->inverse_ion_mobility != nullptr, has_fid = b->file_id != nullptr;
     d->n = n;
-    HIP_TRY(d->peak_off.reserve((size_t)n + 1));
     HIP_TRY(d->masses.reserve(total));
     HIP_TRY(d->intensities.reserve(total));
-    HIP_TRY(d->precursor_mz.reserve(n));
-    HIP_TRY(d->charge.reserve(n));
-    HIP_TRY(d->tic.reserve(n));
-    if (has_iso) {
-        HIP_TRY(d->iso_lo.reserve(n));
-        HIP_TRY(d->iso_hi.reserve(n));
-    }
-    if (has_rt) HIP_TRY(d->rt.reserve(n));
-    if (has_ims) HIP_TRY(d->ims.reserve(n));
-    if (has_fid) HIP_TRY(d->file_id.reserve(n));
     HIP_TRY(d->order.reserve(n));
     HIP_TRY(d->sort_a.reserve(n));
     HIP_TRY(d->sort_b.reserve(n));
@@ -901,6 +897,7 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     HIP_TRY(d->sort_tmp.reserve(sort_bytes));
     const size_t small = ((size_t)n + 1) * 8 + (size_t)n * (4 * 7 + 1) + 64 * 12;
     HIP_TRY(d->stage.reserve(small + (peaks_locked ? 0 : total * 8 + 128)));
+    HIP_TRY(d->meta.reserve(small));
     unsigned char* cur = d->stage.p;
     uint64_t* h_off = carve<uint64_t>(cur, (size_t)n + 1);
     float* h_mz = carve<float>(cur, n);
@@ -935,6 +932,8 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
         if (has_ims) std::memcpy(h_ims, b->inverse_ion_mobility + c0, (size_t)n * 4);
         if (has_fid) std::memcpy(h_fid, b->file_id + c0, (size_t)n * 4);
     }
+    const size_t meta_bytes = (size_t)(cur - d->stage.p);
+    auto image = [&](const void* h) { return h ? d->meta.p + ((const unsigned char*)h - d->stage.p) : nullptr; };
     const float* src_m = b->masses ? b->masses + base : nullptr;
     const float* src_i = b->intensities ? b->intensities + base : nullptr;
     if (!peaks_locked && total) {
@@ -949,24 +948,15 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
         src_i = h_i;
     }
     if (n) {
-        HIP_TRY(hipMemcpyAsync(d->peak_off.p, h_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d->precursor_mz.p, h_mz, (size_t)n * 4, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d->charge.p, h_z, n, hipMemcpyHostToDevice, up));
-        HIP_TRY(hipMemcpyAsync(d->tic.p, h_tic, (size_t)n * 4, hipMemcpyHostToDevice, up));
-        if (has_iso) {
-            HIP_TRY(hipMemcpyAsync(d->iso_lo.p, h_lo, (size_t)n * 4, hipMemcpyHostToDevice, up));
-            HIP_TRY(hipMemcpyAsync(d->iso_hi.p, h_hi, (size_t)n * 4, hipMemcpyHostToDevice, up));
-        }
-        if (has_rt) HIP_TRY(hipMemcpyAsync(d->rt.p, h_rt, (size_t)n * 4, hipMemcpyHostToDevice, up));
-        if (has_ims) HIP_TRY(hipMemcpyAsync(d->ims.p, h_ims, (size_t)n * 4, hipMemcpyHostToDevice, up));
-        if (has_fid) HIP_TRY(hipMemcpyAsync(d->file_id.p, h_fid, (size_t)n * 4, hipMemcpyHostToDevice, up));
+        // the per-spectrum arrays: one copy of the staging block's head, the device pointers are its image
+        HIP_TRY(hipMemcpyAsync(d->meta.p, d->stage.p, meta_bytes, hipMemcpyHostToDevice, up));
         if (total) {
             HIP_TRY(hipMemcpyAsync(d->masses.p, src_m, total * 4, hipMemcpyHostToDevice, up));
             HIP_TRY(hipMemcpyAsync(d->intensities.p, src_i, total * 4, hipMemcpyHostToDevice, up));
         }
         // the launch schedule (ascending neutral precursor mass), sorted on the device right behind the uploads
-        HIP_TRY((hipError_t)schedule_on_device(n, d->precursor_mz.p, d->charge.p, s->params.min_precursor_charge, d->sort_a.p, d->sort_b.p,
-                                               d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, up));
+        HIP_TRY((hipError_t)schedule_on_device(n, (const float*)image(h_mz), (const uint8_t*)image(h_z), s->params.min_precursor_charge,
+                                               d->sort_a.p, d->sort_b.p, d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, up));
     }
     HIP_TRY(hipEventRecord(d->up_done.e, up));
     DevBatchView& v = d->view;
@@ -974,17 +964,17 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     v.n = n;
     v.n_dev = nullptr;
     v.spec_base = c0;
-    v.peak_off = d->peak_off.p;
+    v.peak_off = (const uint64_t*)image(h_off);
     v.masses = d->masses.p;
     v.intensities = d->intensities.p;
-    v.precursor_mz = d->precursor_mz.p;
-    v.precursor_charge = d->charge.p;
-    v.isolation_lo = has_iso ? d->iso_lo.p : nullptr;
-    v.isolation_hi = has_iso ? d->iso_hi.p : nullptr;
-    v.tic = d->tic.p;
-    v.rt = has_rt ? d->rt.p : nullptr;
-    v.ims = has_ims ? d->ims.p : nullptr;
-    v.file_id = has_fid ? d->file_id.p : nullptr;
+    v.precursor_mz = (const float*)image(h_mz);
+    v.precursor_charge = (const uint8_t*)image(h_z);
+    v.isolation_lo = (const float*)image(h_lo);
+    v.isolation_hi = (const float*)image(h_hi);
+    v.tic = (const float*)image(h_tic);
+    v.rt = (const float*)image(h_rt);
+    v.ims = (const float*)image(h_ims);
+    v.file_id = (const uint32_t*)image(h_fid);
     v.order = d->order.p;
     v.probe = probe;
     v.pcap = pcap;
@@ -1143,12 +1133,12 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
 int sage_hip_batch_download(SageDeviceBatch* b, uint64_t* peak_off, float* masses, float* intensities, float* tic) {
     if (!b || !peak_off) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(b->device));
-    if (b->n) HIP_TRY(hipMemcpy(peak_off, b->peak_off.p, ((size_t)b->n + 1) * 8, hipMemcpyDeviceToHost));
+    if (b->n) HIP_TRY(hipMemcpy(peak_off, b->view.peak_off, ((size_t)b->n + 1) * 8, hipMemcpyDeviceToHost));
     else peak_off[0] = 0;
     const uint64_t total = b->n ? peak_off[b->n] : 0;
-    if (masses && total) HIP_TRY(hipMemcpy(masses, b->masses.p, total * 4, hipMemcpyDeviceToHost));
-    if (intensities && total) HIP_TRY(hipMemcpy(intensities, b->intensities.p, total * 4, hipMemcpyDeviceToHost));
-    if (tic && b->n) HIP_TRY(hipMemcpy(tic, b->tic.p, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    if (masses && total) HIP_TRY(hipMemcpy(masses, b->view.masses, total * 4, hipMemcpyDeviceToHost));
+    if (intensities && total) HIP_TRY(hipMemcpy(intensities, b->view.intensities, total * 4, hipMemcpyDeviceToHost));
+    if (tic && b->n) HIP_TRY(hipMemcpy(tic, b->view.tic, (size_t)b->n * 4, hipMemcpyDeviceToHost));
     return SAGE_HIP_OK;
 }
 
@@ -1455,15 +1445,24 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         uint32_t c0, c1;
         int slot;
     };
-    Pending pend[2];
-    bool has[2] = {false, false};
+    constexpr int NSLOT = 4;
+    Pending pend[NSLOT];
+    bool has[NSLOT] = {false, false, false, false};
+    // SAGE_HIP_TIMING=1: host-side wall clock of the pipeline's steps on stderr (microseconds since the call began)
+    static const bool trace_on = std::getenv("SAGE_HIP_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto trace = [&](const char* what, int k_) {
+        if (trace_on)
+            fprintf(stderr, "[sage_hip] score_range %8.1f us  %s %d\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), what, k_);
+    };
     // an error with chunks still in flight: nothing may keep writing into the caller's arrays after the call has returned
     auto bail = [&](int rc) -> int {
         (void)hipStreamSynchronize(s->up_stream);
         (void)hipStreamSynchronize(s->stream);
         (void)hipStreamSynchronize(s->way_stream[0]);
         (void)hipStreamSynchronize(s->down_stream);
-        s->outs[0].in_flight = s->outs[1].in_flight = false;
+        for (OutSet& o : s->outs) o.in_flight = false;
         return rc;
     };
 #define HIP_TRY_BAIL(expr)                                                                  \
@@ -1475,7 +1474,7 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
     // Two chunks of a batch WITHOUT large windows are scored side by side, chunk k on compute lane k & 1 (own stream, own working
     // set): the cold start, the tail and the retry chain of one chunk's kernels are filled by the other's (what two scorer
     // handles on two host threads do, §6 of DESIGN.md, here inside the pipeline).  With large windows: lane 0 only.
-    auto lane_of = [&](int slot, bool wide) { return (!wide && mode == MODE_SCORE && s->two_lanes) ? slot : 0; };
+    auto lane_of = [&](int slot, bool wide) { return (!wide && mode == MODE_SCORE && s->two_lanes) ? (slot & 1) : 0; };
     auto launch = [&](int slot, uint32_t c0, uint32_t c1, bool wide) -> int {
         SageDeviceBatch& in = s->slots[slot];
         OutSet& o = s->outs[slot];
@@ -1485,7 +1484,7 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         int rc = enqueue_compute(s, in.view, o, true, mode, cs, direct ? direct + (size_t)c0 * rp : nullptr, wide, 0, nullptr, lane);
         if (rc != SAGE_HIP_OK) return bail(rc);
         HIP_TRY_BAIL(hipEventRecord(o.comp_done.e, cs));
-        // the next upload into this slot (chunk k + 2) is enqueued only after finish(slot) has waited for this chunk's
+        // the next upload into this slot (chunk k + 4) is enqueued only after finish(slot) has waited for this chunk's
         // download, which itself follows its kernels: no device-side guard is needed for the input buffers
         HIP_TRY_BAIL(hipStreamWaitEvent(s->down_stream, o.comp_done.e, 0));
         HIP_TRY_BAIL(hipMemcpyAsync(o.h_counters, o.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, s->down_stream));
@@ -1530,27 +1529,37 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         if (ovf) overflowed.push_back({pend[slot].c0, pend[slot].c1});
         return SAGE_HIP_OK;
     };
+    // (pieces of equal size: short first and last pieces — the kernels start earlier, less is left when the link goes quiet — were
+    // measured and lose, C3 44.5 against 46.9 M spectra/s: every piece costs three dependent kernels' cold starts and tails)
     int k = 0;
     for (uint32_t c0 = r0; c0 < r1; c0 += chunk, k++) {
         const uint32_t c1 = (uint32_t)std::min<uint64_t>((uint64_t)c0 + chunk, r1);
-        const int slot = k & 1;
-        int rc = finish(slot);  // chunk k - 2 used this slot: its records are home, its buffers are free
+        const int slot = k % NSLOT;
+        trace("wait for slot of chunk", k);
+        int rc = finish(slot);  // chunk k - 4 used this slot: its records are home, its buffers are free
         if (rc != SAGE_HIP_OK) return rc;
+        trace("stage chunk", k);
         SageDeviceBatch& in = s->slots[slot];
-        // (the uploads of chunk k - 2 finished long ago — its kernels ran — so the staging block may be rewritten)
+        // (the uploads of chunk k - 4 finished long ago — its kernels ran — so the staging block may be rewritten)
         rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, est, s->up_stream);
         if (rc != SAGE_HIP_OK) return bail(rc);
+        trace("launch chunk", k);
         rc = launch(slot, c0, c1, est.maybe_wide);
         if (rc != SAGE_HIP_OK) return rc;
+        trace("launched chunk", k);
         pend[slot] = Pending{c0, c1, slot};
         has[slot] = true;
     }
 #undef HIP_TRY_BAIL
-    // the working set (candidate lists, arena) is shared by both slots: kernels run in order on one stream, and a chunk's
-    // records leave through its own OutSet, so the next chunk's kernels may start while they are being downloaded
-    int rc = finish(k & 1);
-    if (rc != SAGE_HIP_OK) return rc;
-    return finish((k + 1) & 1);
+    // a working set (candidate lists, arena) is shared by the chunks of its lane: their kernels run in order on the lane's
+    // stream, and a chunk's records leave through its own OutSet, so the next chunk's kernels may start while they are on the way
+    trace("drain", k);
+    for (int j = 0; j < NSLOT; j++) {  // oldest first
+        const int rc = finish((k + j) % NSLOT);
+        if (rc != SAGE_HIP_OK) return rc;
+    }
+    trace("done", k);
+    return SAGE_HIP_OK;
 }
 
 int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature* out, uint32_t* out_count) {
@@ -1562,8 +1571,12 @@ int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature*
     reset_timing(s);
     const uint32_t n = b->n_spectra;
     if (n == 0) return SAGE_HIP_OK;
+    const auto t_call = std::chrono::steady_clock::now();
     const bool peaks_locked = is_page_locked(b->masses) && is_page_locked(b->intensities);
     const WindowEstimate est = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    if (std::getenv("SAGE_HIP_TIMING"))
+        fprintf(stderr, "[sage_hip] score_batch: window estimate %.1f us\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count());
     std::vector<std::pair<uint32_t, uint32_t>> todo, next;
     rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, est, todo);
     if (rc != SAGE_HIP_OK) return rc;

@@ -453,8 +453,8 @@ def test_error_paths(small_world):
 
 
 def test_streaming_pipeline_chunks(small_world, monkeypatch):
-    """sage_hip_score_batch as a pipeline over chunks (here 64 spectra instead of 65536, so ten chunks rotate through the two
-    slots): pageable and page-locked inputs, page-locked and pageable outputs, spec_index in the caller's numbering; narrow,
+    """sage_hip_score_batch as a pipeline over chunks (here 64 spectra instead of 65536, so ten chunks rotate through the four
+    input slots and, without large windows, the two compute lanes): pageable and page-locked inputs, page-locked and pageable outputs, spec_index in the caller's numbering; narrow,
     isotope-folded / unknown-charge, mixed narrow / tiled, chimera."""
     monkeypatch.setenv("SAGE_HIP_CHUNK", "64")
     b = small_world.batch
@@ -474,6 +474,22 @@ def test_streaming_pipeline_chunks(small_world, monkeypatch):
             assert np.array_equal(gf["spec_index"][valid], np.broadcast_to(np.arange(batch.n)[:, None], gf.shape)[valid])
         t = scorer.last_timing()
         assert n > 100 and t["n_launches"] >= 10 * 3  # ten chunks: two kernels + the retry pass each, more with the large-window path
+    # the estimate says "no large windows" and is wrong: the first chunk that notices is scored again with the large-window
+    # kernels while its neighbours are in flight on the other lane, and the chunks after it take the large-window route at once
+    monkeypatch.setenv("SAGE_HIP_ASSUME_NARROW", "1")
+    params = ScorerParams(precursor_tol=Tolerance("da", -200.0, 200.0), report_psms=2)
+    scorer = Scorer(small_world.dev, params)
+    sub = b.subset(np.arange(0, 3 * (b.n // 3), 3)[:200])
+    of, oc, _, _ = small_world.orc.score(params, sub)
+    for inp, pinned_out in ((sub, True), (sub.page_locked(), True), (sub, False)):
+        assert_features_equal(*scorer.score(inp, pinned_out=pinned_out), of, oc, "pipeline, large windows, wrong guess")
+    assert scorer.last_timing()["n_wide"] > 0
+    monkeypatch.delenv("SAGE_HIP_ASSUME_NARROW")
+    monkeypatch.setenv("SAGE_HIP_ONE_LANE", "1")  # all chunks on one compute stream
+    scorer = Scorer(small_world.dev, ScorerParams(report_psms=3))
+    of, oc, _, _ = small_world.orc.score(ScorerParams(report_psms=3), b)
+    assert_features_equal(*scorer.score(b), of, oc, "pipeline, one lane")
+    monkeypatch.delenv("SAGE_HIP_ONE_LANE")
     # a chunk boundary that leaves a last chunk of one spectrum, and a batch smaller than a chunk
     scorer = Scorer(small_world.dev, ScorerParams())
     for m in (65, 64, 3, 1):
