@@ -202,6 +202,7 @@ struct SageScorer {
     bool one_launch = false;    // SAGE_HIP_ONE_LAUNCH=1: the first pass of narrow windows as one launch of two kinds of workgroups
                                 // (kernels.hip: search_kernel) instead of prelim_kernel, then rescore_kernel — measured slower, like
                                 // the fused kernel: the larger kernel body costs scalar-register spills
+    uint32_t kstride = 64;           // entries per query of the large-window pipeline's seed / heap arrays (DevWork::kstride)
     bool two_lanes = true;           // streaming pipeline: two chunks of a narrow batch side by side (SAGE_HIP_ONE_LANE=1: one at a time)
     uint32_t search_lag = 0;         // SAGE_HIP_SEARCH_LAG (DevWork::search_lag)
     uint64_t replay_split = 32768;   // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split)
@@ -694,6 +695,14 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
+    if (d.kmax > 64) {
+        // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
+        // in LDS, every trim exact (no order-free trims, hence no retry pass), rescoring 64 candidates at a time.
+        s->kstride = ((d.kmax + 63) / 64) * 64;
+        s->exact_always = true;
+        s->fused = s->one_launch = false;
+        s->ways = 1;
+    }
     for (hipStream_t& ws : s->way_stream) HIP_TRY(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
     HIP_TRY(s->way_fork.create(false));
     for (Event& e : s->way_join) HIP_TRY(e.create(false));
@@ -758,7 +767,7 @@ static void scorer_release(SageScorer* s) {
 int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
     if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
-    if (p->report_psms > 32) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32 (k-select wider than one wavefront)");
+    if (p->report_psms > 128) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 128 (preliminary lists longer than 256 candidates)");
     if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
     if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
         return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
@@ -1177,8 +1186,8 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane = 0) {
     w.epoch = 0;
     // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
     HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
-    HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * 64));
-    HIP_TRY(w.qres.reserve((size_t)n * s->qmax * 64));
+    HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * s->kstride));
+    HIP_TRY(w.qres.reserve((size_t)n * s->qmax * s->kstride));
     const uint64_t arena_entries = arena_entries_for(s, n);
     if (arena_entries > w.arena.n) HIP_TRY(w.arena.alloc(arena_entries));
     w.cap_n = n;
@@ -1200,6 +1209,7 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass, int lane = 0) {
     w.epoch = ws.epoch;
     w.search_lag = s->search_lag;
     w.replay_split = s->replay_split;
+    w.kstride = s->kstride;
     w.reuse = 0;
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.tile_blocks = s->tile_blocks;

@@ -110,12 +110,13 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint64_t replay_split; // which heap-replay kernel takes a query: low 32 bits = queries up to which every query gets a wavefront
                            //     (SAGE_HIP_REPLAY_WAVE_MAX, default 32768), high 32 bits = stream words above which a query does
                            //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
+    uint32_t kstride;      // entries per query of `seeds` / `qres`: kmax rounded up to a multiple of 64 (64 unless report_psms > 32)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
-    uint16_t* seeds;       // [n * qmax * 64] matched counts of the first min(k, potential) candidate slots
-    uint64_t* qres;        // [n * qmax * 64] heap of each k-selected query, in the reference's layout order
+    uint16_t* seeds;       // [n * qmax * kstride] matched counts of the first min(k, potential) candidate slots
+    uint64_t* qres;        // [n * qmax * kstride] heap of each k-selected query, in the reference's layout order
     uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
     uint32_t arena_cap;    // entries
     uint32_t qmax;

@@ -320,8 +320,8 @@ __device__ __forceinline__ void ulist_append(UList& c, uint64_t v, uint32_t nval
 }
 __device__ __forceinline__ void ulist_append_empties(UList& c, uint64_t n, uint32_t kmax) {  // clist_push_empties
     const uint64_t room = c.len < kmax ? kmax - c.len : 0;
-    const uint32_t lit = (uint32_t)(n < room ? n : room);  // < kmax <= 64
-    if (lit) ulist_append(c, PRESCORE_EMPTY, lit, kmax);
+    const uint32_t lit = (uint32_t)(n < room ? n : room);  // <= kmax (one trip unless report_psms > 32)
+    for (uint32_t done = 0; done < lit; done += WAVE) ulist_append(c, PRESCORE_EMPTY, lit - done < WAVE ? lit - done : WAVE, kmax);
     c.len += n - lit;
 }
 // trim_hits (scoring.rs:322-329); called by one whole wavefront (the list lives in LDS).
@@ -369,6 +369,44 @@ __device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms, bool 
             if (keep_r[q] < k) c.items[keep_r[q]] = keep_v[q];
         for (uint32_t i = nst + lane; i < k; i += WAVE) c.items[i] = PRESCORE_EMPTY;  // fewer stored than k: defaults fill up
         wave_sync();
+    }
+    c.stored = k;
+    c.len = k;
+}
+
+// ---- k-select wider than a wavefront: report_psms > 32, k = max(50, 2 * report_psms) up to 256 (BIGK instantiations) ------------
+// bounded_min_heapify (heap.rs:7-60) with the heap in LDS, replayed by lane 0 with core.h's sift_down (the host's, the oracle's);
+// the wavefront only skims: 64 offers at a time are tested against the current minimum — the minimum never decreases, so an offer
+// that fails now would fail later — and the survivors are handed to lane 0 in order.  Slow next to the register heaps above and
+// meant to be: a search that reports more than 32 PSMs per spectrum is a rare configuration, it has to be RIGHT.
+__device__ __forceinline__ void lh_build(uint64_t* a, uint32_t k) {
+    wave_sync();
+    if (lane_id() == 0) heap_build(a, k);
+    wave_sync();
+}
+// lane i offers v (has: it has one), lanes in the list's order
+__device__ __forceinline__ void lh_offer_batch(uint64_t* a, uint32_t k, uint64_t v, bool has) {
+    if (!k) return;
+    uint64_t mask = __ballot(has && v > a[0]);
+    if (!mask) return;
+    while (mask) {
+        const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const uint64_t o = lane_value(v, bit);
+        if (lane_id() == 0) heap_offer(a, k, o);
+    }
+    wave_sync();
+}
+// trim_hits (scoring.rs:322-329) of a list in LDS, in place as the reference does it (the heap is the slice's first k entries)
+__device__ __forceinline__ void ulist_trim_big(UList& c, uint32_t report_psms) {
+    const uint32_t lane = lane_id();
+    const uint32_t k = trim_k(c.len, report_psms);
+    if (c.len > k) {
+        lh_build(c.items, k);
+        for (uint32_t base = k; base < c.stored; base += WAVE) {
+            const bool has = base + lane < c.stored;
+            lh_offer_batch(c.items, k, has ? c.items[base + lane] : 0ull, has);
+        }
     }
     c.stored = k;
     c.len = k;
@@ -583,7 +621,7 @@ struct PrelimResult {
     bool untrimmed;             // no trim_hits had anything to drop (every list stayed within its k): the list is the reference's
                                 //     Vec as it stands, whatever the trim mode — a tie at a reported rank needs no exact pass
 };
-template <bool PROBE, class PC>
+template <bool PROBE, bool BIGK = false, class PC>
 __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
                                                         const SpecInfo& si, const bool exact, PC& pc) {
     const uint32_t lane = lane_id();
@@ -810,6 +848,25 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                         const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
                         ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
                     }
+                } else if (BIGK) {
+                    // k > 64 (report_psms > 32): the heap in LDS (always exact; see lh_build)
+                    res.untrimmed = false;
+                    uint64_t* hp = L.heap;
+                    for (uint32_t base = 0; base < k; base += WAVE) {
+                        const uint32_t i = base + lane;
+                        const uint32_t c = i < k ? cnt.get(i) : 0;
+                        if (i < k) hp[i] = c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY;
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
+                    }
+                    lh_build(hp, k);
+                    for (uint32_t base = k; base < potential; base += WAVE) {
+                        const uint32_t i = base + lane;
+                        const uint32_t c = i < potential ? cnt.get(i) : 0;
+                        scored += (uint32_t)__popcll(__ballot(c > 0));
+                        lh_offer_batch(hp, k, pack_prescore(c, left + i, z, iso), c > 0);
+                    }
+                    for (uint32_t base = 0; base < k; base += WAVE)
+                        ulist_append(target, base + lane < k ? hp[base + lane] : PRESCORE_EMPTY, k - base < WAVE ? k - base : WAVE, sc.kmax);
                 } else if (!exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
                     // (done: the k largest slots by (count, slot) without replaying the heap)
                     res.untrimmed = false;
@@ -848,7 +905,8 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
             }
             if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
                 if (A.len > trim_k(A.len, sc.report_psms)) res.untrimmed = false;
-                ulist_trim(A, sc.report_psms, exact || sc.list_cap > 4 * WAVE);
+                if (BIGK) ulist_trim_big(A, sc.report_psms);
+                else ulist_trim(A, sc.report_psms, exact || sc.list_cap > 4 * WAVE);
                 __syncthreads();
                 for (uint32_t base = 0; base < A.stored; base += WAVE) {
                     const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
@@ -863,7 +921,8 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
             return res;
         }
         if (B.len > trim_k(B.len, sc.report_psms)) res.untrimmed = false;
-        ulist_trim(B, sc.report_psms, exact || sc.list_cap > 4 * WAVE);  // scoring.rs:460
+        if (BIGK) ulist_trim_big(B, sc.report_psms);
+        else ulist_trim(B, sc.report_psms, exact || sc.list_cap > 4 * WAVE);  // scoring.rs:460
         __syncthreads();
         res.stored = B.stored;
         res.matched = tot_matched;
@@ -873,7 +932,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
     return res;
 }
 
-template <bool PROBE, bool PROF>
+template <bool PROBE, bool PROF, bool BIGK = false>
 __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
     typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -892,7 +951,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         Clock pc;
         pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
         const SpecInfo si = load_spec(sc, b, spec);
-        const PrelimResult r = prelim_spectrum<PROBE>(db, sc, b, L, si, sc.exact != 0, pc);
+        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc);
         if (r.deferred) {
             if (lane == 0) {
                 w.status[spec] = ST_DEFERRED;
@@ -1125,7 +1184,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         l_sh[SH_DIR] = dir;
                     }
                     l_hist[lane] = 0;
-                    w.seeds[qid * 64 + lane] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
+                    for (uint32_t i = lane; i < w.kstride; i += WAVE) w.seeds[qid * w.kstride + i] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
                 const uint32_t left = uni(l_sh[SH_LEFT]), right = uni(l_sh[SH_RIGHT]), first = uni(l_sh[SH_FIRST]), end = uni(l_sh[SH_END]);
@@ -1427,7 +1486,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             if (gx >= left && gx - left < nseed && x_lo + i < TS) {
                                 const uint32_t x = x_lo + i;
                                 const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
-                                if (c) w.seeds[qid * 64 + (gx - left)] = (uint16_t)c;
+                                if (c) w.seeds[qid * w.kstride + (gx - left)] = (uint16_t)c;
                             }
                         }
                     }
@@ -1657,7 +1716,7 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
     uint32_t rightmin = 0;  // bit p: the right child of node p is strictly smaller than the left one
     uint32_t hmin = 0;
     if (live) {
-        for (uint32_t i = 0; i < k; i++) hp[i * 64] = RK::make(w.seeds[qid * 64 + i], i, rec.left, z, iso);  // first k slots verbatim
+        for (uint32_t i = 0; i < k; i++) hp[i * 64] = RK::make(w.seeds[qid * w.kstride + i], i, rec.left, z, iso);  // first k slots verbatim
         for (uint32_t i = k / 2; i-- > 0;) sift_down_strided<K>(hp, k, i, hp[i * 64]);                       // heap.rs:13-15
         for (uint32_t p = 0; 2 * p + 2 < k; p++)
             if (hp[(2 * p + 2) * 64] < hp[(2 * p + 1) * 64]) rightmin |= 1u << p;
@@ -1696,7 +1755,7 @@ __device__ __forceinline__ void replay_queries(K* hp, const DevWork& w, const Qu
     }
     pc.mark(1);
     if (live)
-        for (uint32_t i = 0; i < k; i++) w.qres[qid * 64 + i] = RK::unpack(hp[i * 64], rec.left, z, iso);
+        for (uint32_t i = 0; i < k; i++) w.qres[qid * w.kstride + i] = RK::unpack(hp[i * 64], rec.left, z, iso);
 }
 
 // query `qid` of the queue (item * qmax + query) -> where its records live: the same place, or — retry pass reusing the first
@@ -1754,7 +1813,7 @@ __device__ __forceinline__ void tile_select_query(const DevScorer& sc, const Dev
     const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
     const uint32_t T = rec.pad[0] >> 8, skip_eq = rec.pad[1];
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint64_t* out = w.qres + qid * 64;
+    uint64_t* out = w.qres + qid * w.kstride;
     uint32_t nsel = 0, eq_seen = 0;
     auto offer = [&](uint32_t c, uint32_t pep) {  // one slot per lane (c == 0: none), lanes in slot order
         const uint64_t eqm = __ballot(T != 0 && c == T);
@@ -1766,7 +1825,7 @@ __device__ __forceinline__ void tile_select_query(const DevScorer& sc, const Dev
         nsel += (uint32_t)__popcll(tm);
         eq_seen += (uint32_t)__popcll(eqm);
     };
-    offer(lane < k ? w.seeds[qid * 64 + lane] : 0u, rec.left + lane);  // the first k slots
+    offer(lane < k ? w.seeds[qid * w.kstride + lane] : 0u, rec.left + lane);  // the first k slots
     for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
         // (a candidate below T can never be taken: skip the wavefront's bookkeeping when the whole batch is below)
         if (__ballot((e >> 16) >= T && e != 0u) == 0ull) return;
@@ -1803,7 +1862,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
     const uint32_t z = rec.z_iso & 0xFFu;
     const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
     const bool small_keys = !(sc.dbg_flags & 2u) && rec.potential <= (1u << K32_SLOT_BITS) && !(rec.pad[0] & 1u);
-    const uint32_t seed_c = lane < k ? w.seeds[qid * 64 + lane] : 0u;
+    const uint32_t seed_c = lane < k ? w.seeds[qid * w.kstride + lane] : 0u;
     // profiling builds of the numbers only (DevWork::dbg, row of kernel 3): [0] cycles, [1] offers that passed the ballot; the
     // large-window byte counter rows [29] / [30] get the replayed queries / their stream words (SAGE_HIP_DEBUG_FLAGS=1024)
     const long long t_start = w.dbg ? clock64() : 0;
@@ -1824,7 +1883,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
                 wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
             }
         });
-        if (lane < k) w.qres[qid * 64 + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
+        if (lane < k) w.qres[qid * w.kstride + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
     } else {
         WaveHeap h;
         const uint64_t sv = seed_c ? pack_prescore(seed_c, rec.left + lane, z, iso) : PRESCORE_EMPTY;
@@ -1841,7 +1900,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
                 wh_offer(h, k, lane_value(v, bit));
             }
         });
-        if (lane < k) w.qres[qid * 64 + lane] = ((uint64_t)h.hi << 32) | h.lo;
+        if (lane < k) w.qres[qid * w.kstride + lane] = ((uint64_t)h.hi << 32) | h.lo;
     }
     if (w.dbg && lane == 0) {
         unsigned long long* row = w.dbg + (size_t)(qid_in % DBG_BLOCKS) * 32 + 24;
@@ -1858,6 +1917,34 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
     for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid, n_q, wave_max);
 }
 
+// The replay for k > 64 (report_psms > 32): a wavefront per query, the heap in LDS (lh_build / lh_offer_batch), 64-bit keys.
+__global__ __launch_bounds__(64) void tile_replay_big_kernel(DevScorer sc, DevWork w) {
+    __shared__ uint64_t heap[256];
+    const uint32_t lane = lane_id();
+    const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
+    for (uint64_t qid_in = blockIdx.x; qid_in < n_q; qid_in += gridDim.x) {
+        const uint64_t qid = query_slot(w, qid_in);
+        const QueryRec rec = w.qrec[qid];
+        const uint32_t k = trim_k(rec.potential, sc.report_psms);
+        if (rec.potential <= k || rec.matched == 0) continue;  // no k-select: the assembler takes the slots verbatim
+        const uint32_t z = rec.z_iso & 0xFFu;
+        const int iso = (int)((rec.z_iso >> 8) & 0xFFu) - 128;
+        __syncthreads();
+        for (uint32_t i = lane; i < k; i += WAVE) {
+            const uint32_t c = w.seeds[qid * w.kstride + i];
+            heap[i] = c ? pack_prescore(c, rec.left + i, z, iso) : PRESCORE_EMPTY;
+        }
+        lh_build(heap, k);
+        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+            const uint32_t c = e >> 16;
+            lh_offer_batch(heap, k, pack_prescore(c, tile_base + (e & 0xFFFFu), z, iso), c > 0);
+        });
+        wave_sync();
+        for (uint32_t i = lane; i < k; i += WAVE) w.qres[qid * w.kstride + i] = heap[i];
+    }
+}
+
+template <bool BIGK>
 __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const DevBatchView& b, const DevWork& w, unsigned char* smem,
                                                    const uint32_t item) {
     const uint32_t lane = lane_id();
@@ -1887,15 +1974,28 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
                 continue;
             }
             tot_scored += rec.scored;
-            if (rec.potential > k) {  // trim_hits of this query (scoring.rs:380), replayed by tile_replay_kernel
-                ulist_append(target, lane < k ? w.qres[qid * 64 + lane] : PRESCORE_EMPTY, k, sc.kmax);
+            if (BIGK) {  // k up to 256: the same, 64 entries at a time
+                const uint32_t m = rec.potential > k ? k : rec.potential;
+                for (uint32_t base = 0; base < m; base += WAVE) {
+                    const uint32_t i = base + lane;
+                    uint64_t v = PRESCORE_EMPTY;
+                    if (i < m && rec.potential > k) v = w.qres[qid * w.kstride + i];
+                    else if (i < m) {
+                        const uint32_t c = w.seeds[qid * w.kstride + i];
+                        if (c) v = pack_prescore(c, rec.left + i, z, iso);
+                    }
+                    ulist_append(target, v, m - base < WAVE ? m - base : WAVE, sc.kmax);
+                }
+            } else if (rec.potential > k) {  // trim_hits of this query (scoring.rs:380), replayed by tile_replay_kernel
+                ulist_append(target, lane < k ? w.qres[qid * w.kstride + lane] : PRESCORE_EMPTY, k, sc.kmax);
             } else {
-                const uint32_t c = lane < rec.potential ? w.seeds[qid * 64 + lane] : 0;
+                const uint32_t c = lane < rec.potential ? w.seeds[qid * w.kstride + lane] : 0;
                 ulist_append(target, c ? pack_prescore(c, rec.left + lane, z, iso) : PRESCORE_EMPTY, rec.potential, sc.kmax);
             }
         }
         if (fold) {  // scoring.rs:405 then `hits +=` at :432 / :450
-            ulist_trim(A, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);
+            if (BIGK) ulist_trim_big(A, sc.report_psms);
+            else ulist_trim(A, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);
             wave_sync();
             for (uint32_t base = 0; base < A.stored; base += WAVE) {
                 const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
@@ -1905,7 +2005,8 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
             wave_sync();
         }
     }
-    ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
+    if (BIGK) ulist_trim_big(B, sc.report_psms);
+    else ulist_trim(B, sc.report_psms, sc.exact != 0 || sc.list_cap > 4 * WAVE);  // scoring.rs:460
     wave_sync();
     if (cnt_overflow) {  // a u8 counter of the count kernel may have wrapped: the spectrum goes through the retry pass (u16 counters)
         if (lane == 0) {
@@ -1924,11 +2025,12 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     }
     for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
 }
+template <bool BIGK>
 __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_items = w.n_deferred[CTR_QUEUED];
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        tile_assemble_item(sc, b, w, smem, item);
+        tile_assemble_item<BIGK>(sc, b, w, smem, item);
         __syncthreads();
     }
 }
@@ -2146,6 +2248,226 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
     return l;
 }
 
+// ---- score_candidate (scoring.rs:699-759) of the wavefront's 64 candidates: lane i scores ITS candidate (ion table at
+//      db.ions + ion_base, `lm1` ions per kind, `nfz` fragment charges; !valid: none) against the spectrum in LDS (peaks pm / pi,
+//      presence bitmap pbm, position table plut) and leaves matched / summed / ppm sum / longest runs in `s` — in the
+//      reference's (kind, index, charge) order, in chunks of 64 ions: first every (ion, charge) item of the chunk is tested against the
+//      peak-presence bitmap — one hit mask per fragment charge 1..3, four ions per trip so that their LDS reads are
+//      in flight together, no division — then only the items whose bin is set go through Tolerance::bounds +
+//      select_most_intense_peak (direct-index table) and are accumulated, in item order, so the f32 sums are
+//      the reference's.  ~90 % of the items of a candidate match nothing.  (Fragment charges above 3 — precursor
+//      charge 5+ — are not filtered.)
+//      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles — so what counts is
+//      instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
+//      A candidate with many hits in a chunk (the true peptide: ~35 of its ~47 ions) would keep its lane busy
+//      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
+//      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
+//      adds per match) and handed back to the candidate's lane.
+__device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
+                                                 const float* pm, const float* pi, const uint32_t P, const float inv_w, const float inv_wb,
+                                                 const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
+                                                 const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
+                                                 Score& s) {
+    const uint32_t lane = lane_id();
+    Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
+    const bool scored = valid && lm1 && nfz;
+    const float* __restrict__ my = db.ions + ion_base;
+    const uint32_t nions = scored ? db.n_kinds * lm1 : 0u;
+    for (uint32_t j0 = 0; __ballot(j0 < nions) != 0ull; j0 += 64u) {  // (wave-uniform trip count)
+        const bool act = j0 < nions;
+        const uint32_t n_here = !act ? 0u : nions - j0 < 64u ? nions - j0 : 64u;
+        uint64_t m1 = 0, m2 = 0, m3 = 0;
+        if (act) {
+            // (the ion table is padded by 8: reading past the candidate's last ion is harmless, those bits are masked below)
+            const float* __restrict__ q = my + j0;
+            float n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+            for (uint32_t r = 0; r < n_here; r += 4) {
+                const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
+                n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
+                // one conversion per ion; the bins of its charge states are integer halves / thirds of it (core.h)
+                const uint32_t x0 = peak_bitmap_index3(inv_wb, i0), x1 = peak_bitmap_index3(inv_wb, i1),
+                               x2 = peak_bitmap_index3(inv_wb, i2), x3 = peak_bitmap_index3(inv_wb, i3);
+                const uint32_t t1 = bitmap_bit(pbm, peak_bitmap_bin_c1(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x1)) << 1) |
+                                    (bitmap_bit(pbm, peak_bitmap_bin_c1(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x3)) << 3);
+                m1 |= (uint64_t)t1 << r;
+                if (any_fz2) {  // (wave-uniform: some candidate of this spectrum has fragment charge 2)
+                    const uint32_t t2 = bitmap_bit(pbm, peak_bitmap_bin_c2(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x1)) << 1) |
+                                        (bitmap_bit(pbm, peak_bitmap_bin_c2(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x3)) << 3);
+                    m2 |= (uint64_t)t2 << r;
+                }
+                if (any_fz3) {
+                    const uint32_t t3 = bitmap_bit(pbm, peak_bitmap_bin_c3(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x1)) << 1) |
+                                        (bitmap_bit(pbm, peak_bitmap_bin_c3(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x3)) << 3);
+                    m3 |= (uint64_t)t3 << r;
+                }
+            }
+            const uint64_t in_chunk = n_here >= 64u ? ~0ull : (1ull << n_here) - 1ull;
+            m1 &= in_chunk;
+            m2 = nfz >= 2 ? m2 & in_chunk : 0ull;
+            m3 = nfz >= 3 ? m3 & in_chunk : 0ull;
+            if (nfz > 3) m1 = m2 = m3 = in_chunk;  // (charges above 3 are not filtered: every ion goes through)
+        }
+        // ---- chunks with many hits: the whole wavefront on one candidate at a time
+        const uint32_t hc = act && nfz <= 3 ? (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3)) : 0u;
+        uint64_t bigs = (sc.dbg_flags & 32u) ? 0ull : __ballot(hc > COOP_MIN_HITS);  // (SAGE_HIP_DEBUG_FLAGS=32: tests switch it off)
+        if ((uint32_t)__popcll(bigs) > COOP_MAX_LANES && !(sc.dbg_flags & 64u)) bigs = 0ull;  // (64: tests take every heavy lane)
+        while (bigs) {
+            const uint32_t L = (uint32_t)__ffsll((long long)bigs) - 1;
+            bigs &= bigs - 1;
+            const uint64_t M1 = lane_value(m1, L), M2 = lane_value(m2, L), M3 = lane_value(m3, L);
+            const uint64_t base_L = lane_value((uint64_t)ion_base, L);
+            const uint32_t lm1_L = (uint32_t)__builtin_amdgcn_readlane((int)lm1, (int)L);
+            const bool on1 = (M1 >> lane) & 1ull, on2 = (M2 >> lane) & 1ull, on3 = (M3 >> lane) & 1ull;
+            float it1 = 0.f, it2 = 0.f, it3 = 0.f, tm1 = 0.f, tm2 = 0.f, tm3 = 0.f;
+            bool ok1 = false, ok2 = false, ok3 = false;
+            if (on1 || on2 || on3) {
+                const float ionv = db.ions[base_L + j0 + lane];
+#define SAGE_COOP_LOOKUP(C, ON, OK, IT, TM)                                                              \
+    if (ON) {                                                                                            \
+        const float mz = (C) == 1 ? ionv : ionv / (float)(C);                                            \
+        float flo, fhi;                                                                                  \
+        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);                                          \
+        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);                                \
+        if (pk >= 0) {                                                                                   \
+const float peak_mass = pm[pk], peak_intensity = pi[pk];                                     \
+OK = true;                                                                                   \
+IT = peak_intensity;                                                                         \
+TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);             \
+        }                                                                                                \
+    }
+                SAGE_COOP_LOOKUP(1, on1, ok1, it1, tm1)
+                SAGE_COOP_LOOKUP(2, on2, ok2, it2, tm2)
+                SAGE_COOP_LOOKUP(3, on3, ok3, it3, tm3)
+#undef SAGE_COOP_LOOKUP
+            }
+            const uint64_t K1 = __ballot(ok1), K2 = __ballot(ok2), K3 = __ballot(ok3);
+            // the candidate's accumulators, wave-uniform while its matches are added in (ion, charge) order
+            float u_sb = lane_valuef(s.summed_b, L), u_sy = lane_valuef(s.summed_y, L), u_pp = lane_valuef(s.ppm_difference, L);
+            uint32_t u_mb = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_b, (int)L);
+            uint32_t u_my = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_y, (int)L);
+            Run u_b, u_y;
+            u_b.start = (uint32_t)__builtin_amdgcn_readlane((int)b_run.start, (int)L);
+            u_b.length = (uint32_t)__builtin_amdgcn_readlane((int)b_run.length, (int)L);
+            u_b.last = (uint32_t)__builtin_amdgcn_readlane((int)b_run.last, (int)L);
+            u_b.longest = (uint32_t)__builtin_amdgcn_readlane((int)b_run.longest, (int)L);
+            u_y.start = (uint32_t)__builtin_amdgcn_readlane((int)y_run.start, (int)L);
+            u_y.length = (uint32_t)__builtin_amdgcn_readlane((int)y_run.length, (int)L);
+            u_y.last = (uint32_t)__builtin_amdgcn_readlane((int)y_run.last, (int)L);
+            u_y.longest = (uint32_t)__builtin_amdgcn_readlane((int)y_run.longest, (int)L);
+            uint64_t anyK = K1 | K2 | K3;
+            while (anyK) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)anyK) - 1;
+                anyK &= anyK - 1;
+                uint32_t kind_i = 0, idx = j0 + bit;
+                while (idx >= lm1_L) { idx -= lm1_L; kind_i++; }
+                const bool nterm = (nterm_mask >> kind_i) & 1u;
+#define SAGE_COOP_ADD(K, IT, TM)                                                   \
+    if ((K >> bit) & 1ull) {                                                       \
+        const float it = lane_valuef(IT, bit), tm = lane_valuef(TM, bit);          \
+        u_pp += tm;                                                                \
+        if (nterm) { u_mb += 1; u_sb += it; run_matched(u_b, idx); }               \
+        else       { u_my += 1; u_sy += it; run_matched(u_y, idx); }               \
+    }
+                SAGE_COOP_ADD(K1, it1, tm1)
+                SAGE_COOP_ADD(K2, it2, tm2)
+                SAGE_COOP_ADD(K3, it3, tm3)
+#undef SAGE_COOP_ADD
+            }
+            if (lane == L) {
+                s.summed_b = u_sb; s.summed_y = u_sy; s.ppm_difference = u_pp;
+                s.matched_b = u_mb; s.matched_y = u_my;
+                b_run = u_b; y_run = u_y;
+                m1 = m2 = m3 = 0ull;  // done
+            }
+        }
+        // ---- everybody else: the lane walks its own hits
+        uint64_t any = m1 | m2 | m3;
+        if (!any) continue;
+        uint32_t bit = (uint32_t)__ffsll((long long)any) - 1;
+        float ionv = my[j0 + bit];
+        while (any) {
+            any &= any - 1;
+            const uint32_t nbit = any ? (uint32_t)__ffsll((long long)any) - 1 : bit;
+            const float nion = my[j0 + nbit];  // (the next item's ion is in flight while this one is matched)
+            const uint32_t jj = j0 + bit;
+            uint32_t kind_i = 0, idx = jj;
+            while (idx >= lm1) { idx -= lm1; kind_i++; }
+            for (uint32_t c = 1; c <= nfz; c++) {
+                if (c <= 3 && !(((c == 1 ? m1 : c == 2 ? m2 : m3) >> bit) & 1ull)) continue;
+                const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
+                float flo, fhi;
+                tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
+                if (pk < 0) continue;
+                const float peak_mass = pm[pk], peak_intensity = pi[pk];
+                s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
+                if ((nterm_mask >> kind_i) & 1u) {
+                    s.matched_b += 1;
+                    s.summed_b += peak_intensity;
+                    run_matched(b_run, idx);
+                } else {
+                    s.matched_y += 1;
+                    s.summed_y += peak_intensity;
+                    run_matched(y_run, idx);
+                }
+            }
+            bit = nbit;
+            ionv = nion;
+        }
+    }
+    s.longest_b = b_run.longest;
+    s.longest_y = y_run.longest;
+}
+
+// One Feature record (scoring.rs:504-594) of a scored candidate: `rank_field` is Feature.rank, `next` / `best` the hyperscores of
+// the next rank (0 if none) and of rank 0.
+__device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const DevBatchView& b, const uint32_t spec, const uint32_t pep,
+                                                    const uint32_t z, const int iso, const Score& s, const double h, const double next,
+                                                    const double best, const uint32_t rank_field, const double lambda, const float mzp,
+                                                    const float rt, const float ims, const uint32_t fid, const float tic,
+                                                    const uint32_t tot_scored, const double* __restrict__ lnfact_table,
+                                                    const uint32_t lnfact_n) {
+    const float precursor_mass = mzp * (float)z;
+    const uint32_t k = s.matched_b + s.matched_y;
+    const double log10_poisson =
+        ((double)k * log(lambda) - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
+    const float isotope_error = (float)iso * NEUTRON;
+    const uint32_t info = db.pep_info[pep];
+    const float calc = db.pep_mono[pep];
+    const float delta_mass =
+        (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
+    const uint32_t plen = info & 0xFFFF;
+    SageFeature f;
+    f.spec_index = b.spec_base + spec;
+    f.peptide_idx = pep;
+    f.rank = rank_field;  // scoring.rs:541, 664
+    f.label = ((info >> 16) & 0xFF) ? -1 : 1;
+    f.expmass = precursor_mass;
+    f.calcmass = calc;
+    f.rt = rt;
+    f.ims = ims;
+    f.delta_mass = delta_mass;
+    f.isotope_error = isotope_error;
+    f.average_ppm = s.ppm_difference;
+    f.longest_y_pct = (float)s.longest_y / (float)plen;
+    f.matched_intensity_pct = 100.0f * (s.summed_b + s.summed_y) / tic;
+    f.ms2_intensity = s.summed_b + s.summed_y;
+    f.hyperscore = h;
+    f.delta_next = h - next;
+    f.delta_best = best - h;
+    f.poisson = __builtin_isfinite(log10_poisson) ? log10_poisson : -__builtin_huge_val();
+    f.matched_peaks = k;
+    f.longest_b = s.longest_b;
+    f.longest_y = s.longest_y;
+    f.scored_candidates = tot_scored;
+    f.peptide_len = plen;
+    f.file_id = fid;
+    f.charge = (uint8_t)z;
+    f.missed_cleavages = (uint8_t)(info >> 24);
+    for (int q = 0; q < 6; q++) f.pad[q] = 0;
+    return f;
+}
+
 // Scorer::build_features / score_chimera_fast / quick_score (scoring.rs:478-595, 648-672, 255-298) of ONE spectrum by one
 // wavefront.  Lane i holds candidate i of the trimmed preliminary list (`mine`, PRESCORE_EMPTY beyond its end); the peaks are in
 // R.pm / R.pi already (P of them).
@@ -2229,172 +2551,8 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.summed_b = s.summed_y = 0.0f;
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
-        {
-            // ---- score_candidate (scoring.rs:699-759), one lane per candidate, in the reference's (kind, index, charge)
-            //      order, in chunks of 64 ions: first every (ion, charge) item of the chunk is tested against the
-            //      peak-presence bitmap — one hit mask per fragment charge 1..3, four ions per trip so that their LDS reads are
-            //      in flight together, no division — then only the items whose bin is set go through Tolerance::bounds +
-            //      select_most_intense_peak (direct-index table) and are accumulated, in item order, so the f32 sums are
-            //      the reference's.  ~90 % of the items of a candidate match nothing.  (Fragment charges above 3 — precursor
-            //      charge 5+ — are not filtered.)
-            //      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles — so what counts is
-            //      instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
-            //      A candidate with many hits in a chunk (the true peptide: ~35 of its ~47 ions) would keep its lane busy
-            //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
-            //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
-            //      adds per match) and handed back to the candidate's lane.
-            {
-                Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
-                const bool scored = valid && lm1 && nfz;
-                const float* __restrict__ my = db.ions + ion_base;
-                const uint32_t nions = scored ? db.n_kinds * lm1 : 0u;
-                for (uint32_t j0 = 0; __ballot(j0 < nions) != 0ull; j0 += 64u) {  // (wave-uniform trip count)
-                    const bool act = j0 < nions;
-                    const uint32_t n_here = !act ? 0u : nions - j0 < 64u ? nions - j0 : 64u;
-                    uint64_t m1 = 0, m2 = 0, m3 = 0;
-                    if (act) {
-                        // (the ion table is padded by 8: reading past the candidate's last ion is harmless, those bits are masked below)
-                        const float* __restrict__ q = my + j0;
-                        float n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-                        for (uint32_t r = 0; r < n_here; r += 4) {
-                            const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
-                            n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
-                            // one conversion per ion; the bins of its charge states are integer halves / thirds of it (core.h)
-                            const uint32_t x0 = peak_bitmap_index3(inv_wb, i0), x1 = peak_bitmap_index3(inv_wb, i1),
-                                           x2 = peak_bitmap_index3(inv_wb, i2), x3 = peak_bitmap_index3(inv_wb, i3);
-                            const uint32_t t1 = bitmap_bit(pbm, peak_bitmap_bin_c1(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x1)) << 1) |
-                                                (bitmap_bit(pbm, peak_bitmap_bin_c1(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x3)) << 3);
-                            m1 |= (uint64_t)t1 << r;
-                            if (any_fz2) {  // (wave-uniform: some candidate of this spectrum has fragment charge 2)
-                                const uint32_t t2 = bitmap_bit(pbm, peak_bitmap_bin_c2(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x1)) << 1) |
-                                                    (bitmap_bit(pbm, peak_bitmap_bin_c2(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x3)) << 3);
-                                m2 |= (uint64_t)t2 << r;
-                            }
-                            if (any_fz3) {
-                                const uint32_t t3 = bitmap_bit(pbm, peak_bitmap_bin_c3(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x1)) << 1) |
-                                                    (bitmap_bit(pbm, peak_bitmap_bin_c3(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x3)) << 3);
-                                m3 |= (uint64_t)t3 << r;
-                            }
-                        }
-                        const uint64_t in_chunk = n_here >= 64u ? ~0ull : (1ull << n_here) - 1ull;
-                        m1 &= in_chunk;
-                        m2 = nfz >= 2 ? m2 & in_chunk : 0ull;
-                        m3 = nfz >= 3 ? m3 & in_chunk : 0ull;
-                        if (nfz > 3) m1 = m2 = m3 = in_chunk;  // (charges above 3 are not filtered: every ion goes through)
-                    }
-                    // ---- chunks with many hits: the whole wavefront on one candidate at a time
-                    const uint32_t hc = act && nfz <= 3 ? (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3)) : 0u;
-                    uint64_t bigs = (sc.dbg_flags & 32u) ? 0ull : __ballot(hc > COOP_MIN_HITS);  // (SAGE_HIP_DEBUG_FLAGS=32: tests switch it off)
-                    if ((uint32_t)__popcll(bigs) > COOP_MAX_LANES && !(sc.dbg_flags & 64u)) bigs = 0ull;  // (64: tests take every heavy lane)
-                    while (bigs) {
-                        const uint32_t L = (uint32_t)__ffsll((long long)bigs) - 1;
-                        bigs &= bigs - 1;
-                        const uint64_t M1 = lane_value(m1, L), M2 = lane_value(m2, L), M3 = lane_value(m3, L);
-                        const uint64_t base_L = lane_value((uint64_t)ion_base, L);
-                        const uint32_t lm1_L = (uint32_t)__builtin_amdgcn_readlane((int)lm1, (int)L);
-                        const bool on1 = (M1 >> lane) & 1ull, on2 = (M2 >> lane) & 1ull, on3 = (M3 >> lane) & 1ull;
-                        float it1 = 0.f, it2 = 0.f, it3 = 0.f, tm1 = 0.f, tm2 = 0.f, tm3 = 0.f;
-                        bool ok1 = false, ok2 = false, ok3 = false;
-                        if (on1 || on2 || on3) {
-                            const float ionv = db.ions[base_L + j0 + lane];
-#define SAGE_COOP_LOOKUP(C, ON, OK, IT, TM)                                                              \
-    if (ON) {                                                                                            \
-        const float mz = (C) == 1 ? ionv : ionv / (float)(C);                                            \
-        float flo, fhi;                                                                                  \
-        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);                                          \
-        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);                                \
-        if (pk >= 0) {                                                                                   \
-            const float peak_mass = pm[pk], peak_intensity = pi[pk];                                     \
-            OK = true;                                                                                   \
-            IT = peak_intensity;                                                                         \
-            TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);             \
-        }                                                                                                \
-    }
-                            SAGE_COOP_LOOKUP(1, on1, ok1, it1, tm1)
-                            SAGE_COOP_LOOKUP(2, on2, ok2, it2, tm2)
-                            SAGE_COOP_LOOKUP(3, on3, ok3, it3, tm3)
-#undef SAGE_COOP_LOOKUP
-                        }
-                        const uint64_t K1 = __ballot(ok1), K2 = __ballot(ok2), K3 = __ballot(ok3);
-                        // the candidate's accumulators, wave-uniform while its matches are added in (ion, charge) order
-                        float u_sb = lane_valuef(s.summed_b, L), u_sy = lane_valuef(s.summed_y, L), u_pp = lane_valuef(s.ppm_difference, L);
-                        uint32_t u_mb = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_b, (int)L);
-                        uint32_t u_my = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_y, (int)L);
-                        Run u_b, u_y;
-                        u_b.start = (uint32_t)__builtin_amdgcn_readlane((int)b_run.start, (int)L);
-                        u_b.length = (uint32_t)__builtin_amdgcn_readlane((int)b_run.length, (int)L);
-                        u_b.last = (uint32_t)__builtin_amdgcn_readlane((int)b_run.last, (int)L);
-                        u_b.longest = (uint32_t)__builtin_amdgcn_readlane((int)b_run.longest, (int)L);
-                        u_y.start = (uint32_t)__builtin_amdgcn_readlane((int)y_run.start, (int)L);
-                        u_y.length = (uint32_t)__builtin_amdgcn_readlane((int)y_run.length, (int)L);
-                        u_y.last = (uint32_t)__builtin_amdgcn_readlane((int)y_run.last, (int)L);
-                        u_y.longest = (uint32_t)__builtin_amdgcn_readlane((int)y_run.longest, (int)L);
-                        uint64_t anyK = K1 | K2 | K3;
-                        while (anyK) {
-                            const uint32_t bit = (uint32_t)__ffsll((long long)anyK) - 1;
-                            anyK &= anyK - 1;
-                            uint32_t kind_i = 0, idx = j0 + bit;
-                            while (idx >= lm1_L) { idx -= lm1_L; kind_i++; }
-                            const bool nterm = (nterm_mask >> kind_i) & 1u;
-#define SAGE_COOP_ADD(K, IT, TM)                                                   \
-    if ((K >> bit) & 1ull) {                                                       \
-        const float it = lane_valuef(IT, bit), tm = lane_valuef(TM, bit);          \
-        u_pp += tm;                                                                \
-        if (nterm) { u_mb += 1; u_sb += it; run_matched(u_b, idx); }               \
-        else       { u_my += 1; u_sy += it; run_matched(u_y, idx); }               \
-    }
-                            SAGE_COOP_ADD(K1, it1, tm1)
-                            SAGE_COOP_ADD(K2, it2, tm2)
-                            SAGE_COOP_ADD(K3, it3, tm3)
-#undef SAGE_COOP_ADD
-                        }
-                        if (lane == L) {
-                            s.summed_b = u_sb; s.summed_y = u_sy; s.ppm_difference = u_pp;
-                            s.matched_b = u_mb; s.matched_y = u_my;
-                            b_run = u_b; y_run = u_y;
-                            m1 = m2 = m3 = 0ull;  // done
-                        }
-                    }
-                    // ---- everybody else: the lane walks its own hits
-                    uint64_t any = m1 | m2 | m3;
-                    if (!any) continue;
-                    uint32_t bit = (uint32_t)__ffsll((long long)any) - 1;
-                    float ionv = my[j0 + bit];
-                    while (any) {
-                        any &= any - 1;
-                        const uint32_t nbit = any ? (uint32_t)__ffsll((long long)any) - 1 : bit;
-                        const float nion = my[j0 + nbit];  // (the next item's ion is in flight while this one is matched)
-                        const uint32_t jj = j0 + bit;
-                        uint32_t kind_i = 0, idx = jj;
-                        while (idx >= lm1) { idx -= lm1; kind_i++; }
-                        for (uint32_t c = 1; c <= nfz; c++) {
-                            if (c <= 3 && !(((c == 1 ? m1 : c == 2 ? m2 : m3) >> bit) & 1ull)) continue;
-                            const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
-                            float flo, fhi;
-                            tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
-                            const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
-                            if (pk < 0) continue;
-                            const float peak_mass = pm[pk], peak_intensity = pi[pk];
-                            s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
-                            if ((nterm_mask >> kind_i) & 1u) {
-                                s.matched_b += 1;
-                                s.summed_b += peak_intensity;
-                                run_matched(b_run, idx);
-                            } else {
-                                s.matched_y += 1;
-                                s.summed_y += peak_intensity;
-                                run_matched(y_run, idx);
-                            }
-                        }
-                        bit = nbit;
-                        ionv = nion;
-                    }
-                }
-                s.longest_b = b_run.longest;
-                s.longest_y = y_run.longest;
-            }
-            pc.mark(1);
-        }
+        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, inv_wb, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
+        pc.mark(1);
         double h = 0.0;
         bool pass = false;
         if (valid) {
@@ -2480,45 +2638,8 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         }
         pc.mark(3);
         if (pass && rank < per_round) {  // scoring.rs:504-594
-            const double next = next_h, best = best_h;
-            const float precursor_mass = mzp * (float)z;
-            const uint32_t k = s.matched_b + s.matched_y;
-            const double log10_poisson =
-                ((double)k * log(lambda) - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
-            const float isotope_error = (float)iso * NEUTRON;
-            const uint32_t info = db.pep_info[pep];
-            const float calc = db.pep_mono[pep];
-            const float delta_mass =
-                (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
-            const uint32_t plen = info & 0xFFFF;
-            SageFeature f;
-            f.spec_index = b.spec_base + spec;
-            f.peptide_idx = pep;
-            f.rank = sc.chimera ? round + 1 : rank + 1;  // scoring.rs:541, 664
-            f.label = ((info >> 16) & 0xFF) ? -1 : 1;
-            f.expmass = precursor_mass;
-            f.calcmass = calc;
-            f.rt = rt;
-            f.ims = ims;
-            f.delta_mass = delta_mass;
-            f.isotope_error = isotope_error;
-            f.average_ppm = s.ppm_difference;
-            f.longest_y_pct = (float)s.longest_y / (float)plen;
-            f.matched_intensity_pct = 100.0f * (s.summed_b + s.summed_y) / tic;
-            f.ms2_intensity = s.summed_b + s.summed_y;
-            f.hyperscore = h;
-            f.delta_next = h - next;
-            f.delta_best = best - h;
-            f.poisson = __builtin_isfinite(log10_poisson) ? log10_poisson : -__builtin_huge_val();
-            f.matched_peaks = k;
-            f.longest_b = s.longest_b;
-            f.longest_y = s.longest_y;
-            f.scored_candidates = tot_scored;
-            f.peptide_len = plen;
-            f.file_id = fid;
-            f.charge = (uint8_t)z;
-            f.missed_cleavages = (uint8_t)(info >> 24);
-            for (int q = 0; q < 6; q++) f.pad[q] = 0;
+            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, mzp, rt, ims,
+                                               fid, tic, tot_scored, lnfact_table, lnfact_n);
             *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
         }
         const uint32_t emitted = npass < per_round ? npass : per_round;
@@ -2546,6 +2667,198 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     if (lane == 0) out_count[spec] = n_emitted;
     return true;
 #undef SAGE_N_ITEMS
+}
+
+// ---- rescoring of a preliminary list longer than a wavefront: report_psms > 32, up to BIG_K = 256 candidates -------------------------
+// The same steps as rescore_spectrum — score_candidates / hyperscore / stable sort by hyperscore / Feature records, the chimera
+// loop, quick_score's k-select — 64 candidates at a time, the per-candidate results parked in LDS between the steps.  The list is
+// always the reference's (exact trims: no tie can be mis-ranked, no retry).  Records leave lane by lane.
+constexpr uint32_t BIG_K = 256;
+struct BigScore {  // what a Feature needs of a candidate's Score
+    uint32_t matched_b, matched_y;
+    float summed_b, summed_y, ppm_difference;
+    uint32_t longest_b, longest_y;
+};
+__host__ __device__ inline size_t rescore_big_bytes(bool quick) {
+    // total_cmp keys of the hyperscores by list position (lowest: did not pass), hyperscores by rank, the scores; quick_score's keys
+    return (size_t)BIG_K * (8 + 8 + sizeof(BigScore)) + (quick ? (size_t)BIG_K * sizeof(QuickKey) : 0);
+}
+__global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
+                                                         const double* __restrict__ lnfact_table, uint32_t lnfact_n,
+                                                         SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
+                                                         uint8_t* __restrict__ keep) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    const size_t scratch = (rescore_scratch_bytes(false) + 15) & ~(size_t)15;
+    const size_t fixed = rescore_fixed_bytes(sc, b);
+    for (uint32_t blk = blockIdx.x; blk < b.n; blk += gridDim.x) {
+        const uint32_t spec = b.order ? b.order[blk] : blk;
+        const uint32_t st = w.status[spec];
+        __syncthreads();
+        if (st != ST_OK && st != ST_OK_ORDERED) {
+            if (lane == 0 && !keep) out_count[spec] = 0;
+            continue;
+        }
+        const RescoreLds R = carve_rescore(smem, smem + scratch, b);
+        unsigned char* gp = smem + scratch + fixed;
+        long long* const g_key = (long long*)gp;
+        double* const g_sorted = (double*)(g_key + BIG_K);
+        BigScore* const g_score = (BigScore*)(g_sorted + BIG_K);
+        QuickKey* const g_qk = (QuickKey*)(g_score + BIG_K);  // (sizeof(BigScore) * 256 is a multiple of 8)
+        uint32_t* const pbm = R.pbm;
+        uint32_t* const plut = R.plut;
+        float* const pm = R.pm;
+        float* const pi = R.pi;
+        const uint64_t p0 = b.peak_off[spec];
+        uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+        for (uint32_t i = lane; i < P; i += WAVE) {
+            pm[i] = b.masses[p0 + i];
+            pi[i] = b.intensities[p0 + i];
+        }
+        const uint32_t ncand = w.cand_len[spec] < BIG_K ? w.cand_len[spec] : BIG_K;
+        const uint64_t* __restrict__ list = w.cand + (size_t)spec * sc.kmax;
+        const uint32_t tot_matched = w.totals[2 * spec], tot_scored = w.totals[2 * spec + 1];
+        float tic = b.tic[spec];
+        const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
+        const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
+        const float rt = b.rt ? b.rt[spec] : 0.0f;
+        float ims = 0.0f;
+        if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
+        const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
+        const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
+        const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
+        const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
+        uint32_t nterm_mask = 0;
+        for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
+        const long long lowest = (long long)0x8000000000000000ull;
+        uint32_t n_emitted = 0;
+        float inv_wb = 0.0f;
+        __syncthreads();
+        for (uint32_t round = 0; round < rounds; round++) {
+            float inv_w;
+            build_peak_lut(plut, inv_w, pm, P);
+            if (round == 0) build_peak_bitmap(pbm, inv_wb, pm, P, sc.fragment_tol);
+            __syncthreads();
+            uint32_t npass = 0;
+            for (uint32_t base = 0; base < ncand; base += WAVE) {
+                const uint32_t i = base + lane;
+                const uint64_t mine = i < ncand ? list[i] : PRESCORE_EMPTY;
+                const uint32_t pep = prescore_peptide(mine);
+                const bool valid = pep != 0xFFFFFFFFu;  // scoring.rs:489
+                const uint32_t z = prescore_charge(mine);
+                const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+                uint64_t ion_base = 0;
+                uint32_t lm1 = 0;
+                if (valid) {
+                    ion_base = db.ion_off[pep];
+                    const uint32_t plen = db.pep_info[pep] & 0xFFFFu;
+                    lm1 = db.n_kinds && plen ? plen - 1u : 0u;
+                }
+                const bool any_fz2 = __ballot(valid && nfz >= 2) != 0ull, any_fz3 = __ballot(valid && nfz >= 3) != 0ull;
+                Score s;
+                s.peptide = 0;
+                s.precursor_charge = 0;
+                s.isotope_error = 0;
+                s.matched_b = s.matched_y = 0;
+                s.summed_b = s.summed_y = 0.0f;
+                s.ppm_difference = 0.0f;
+                s.longest_b = s.longest_y = 0;
+                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, inv_wb, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
+                double h = 0.0;
+                bool pass = false;
+                if (valid) {
+                    s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
+                    h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
+                    pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
+                }
+                npass += (uint32_t)__popcll(__ballot(pass));
+                if (i < ncand) {
+                    g_key[i] = pass ? order_key64(h) : lowest;
+                    BigScore q;
+                    q.matched_b = s.matched_b; q.matched_y = s.matched_y; q.summed_b = s.summed_b; q.summed_y = s.summed_y;
+                    q.ppm_difference = s.ppm_difference; q.longest_b = s.longest_b; q.longest_y = s.longest_y;
+                    g_score[i] = q;
+                    if (keep) {
+                        QuickKey mk;
+                        mk.peptide = pep;
+                        mk.matched_b = s.matched_b; mk.matched_y = s.matched_y; mk.summed_b = s.summed_b; mk.summed_y = s.summed_y;
+                        mk.longest_b = s.longest_b; mk.longest_y = s.longest_y; mk.hyperscore = h; mk.ppm_difference = s.ppm_difference;
+                        mk.charge = z; mk.iso = prescore_iso(mine);
+                        g_qk[i] = mk;
+                    }
+                }
+            }
+            __syncthreads();
+            if (keep) {
+                // quick_score, prefilter_low_memory (scoring.rs:270-289): the report_psms largest passing candidates by Score's
+                // derived order (see rescore_spectrum)
+                const uint32_t kq = sc.report_psms < npass ? sc.report_psms : npass;  // scoring.rs:284
+                for (uint32_t i = lane; i < ncand; i += WAVE) {
+                    const QuickKey mk = g_qk[i];
+                    if (g_key[i] == lowest) continue;  // did not pass min_matched_peaks
+                    uint32_t above = 0;
+                    for (uint32_t j = 0; j < ncand; j++) above += j != i && g_key[j] != lowest && quick_gt(g_qk[j], mk);
+                    if (above < kq) keep[mk.peptide] = 1;
+                }
+                break;
+            }
+            // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation over the whole list
+            for (uint32_t i = lane; i < ncand; i += WAVE) {
+                const long long key = g_key[i];
+                if (key == lowest) continue;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < ncand; j++) {
+                    const long long kj = g_key[j];  // (an LDS broadcast)
+                    rank += kj != lowest && ((kj > key) || (kj == key && j < i));
+                }
+                g_sorted[rank] = from_order_key64(key);
+            }
+            __syncthreads();
+            const uint32_t emitted = npass < per_round ? npass : per_round;
+            uint32_t winner = 0xFFFFFFFFu;
+            for (uint32_t base = 0; base < ncand; base += WAVE) {
+                const uint32_t i = base + lane;
+                bool reports = false;
+                uint32_t rank = 0;
+                long long key = lowest;
+                if (i < ncand) key = g_key[i];
+                if (key != lowest) {
+                    for (uint32_t j = 0; j < ncand; j++) {
+                        const long long kj = g_key[j];
+                        rank += kj != lowest && ((kj > key) || (kj == key && j < i));
+                    }
+                    reports = rank < per_round;
+                }
+                if (reports) {  // scoring.rs:504-594
+                    const uint64_t mine = list[i];
+                    const BigScore q = g_score[i];
+                    Score s;
+                    s.peptide = 0; s.precursor_charge = 0; s.isotope_error = 0;
+                    s.matched_b = q.matched_b; s.matched_y = q.matched_y; s.summed_b = q.summed_b; s.summed_y = q.summed_y;
+                    s.ppm_difference = q.ppm_difference; s.longest_b = q.longest_b; s.longest_y = q.longest_y;
+                    const double h = g_sorted[rank];
+                    const double next = rank + 1 < npass ? g_sorted[rank + 1] : 0.0, best = g_sorted[0];
+                    const SageFeature f = make_feature(db, b, spec, prescore_peptide(mine), prescore_charge(mine), prescore_iso(mine), s, h, next, best,
+                                                       sc.chimera ? round + 1 : rank + 1, lambda, mzp, rt, ims, fid, tic, tot_scored, lnfact_table,
+                                                       lnfact_n);
+                    out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
+                }
+                const uint64_t wm = __ballot(reports && rank == 0);
+                if (wm) winner = base + (uint32_t)__ffsll((long long)wm) - 1;
+            }
+            n_emitted += emitted;
+            if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
+            // ---- remove_matched_peaks(winner), scoring.rs:598-644 ----
+            const uint64_t wmine = list[winner];
+            const uint32_t wpep = prescore_peptide(wmine);
+            const uint32_t wmfc = max_fragment_charge(sc.max_fragment_charge, prescore_charge(wmine));
+            const uint32_t wplen = db.pep_info[wpep] & 0xFFFFu;
+            const uint32_t wlm1 = db.n_kinds && wplen ? wplen - 1u : 0u;
+            __syncthreads();
+            remove_matched_peaks_dev(pm, pi, R.rm, R.rm2, P, tic, db.ions + db.ion_off[wpep], db.n_kinds * wlm1 * (wmfc - 1), wmfc, sc.fragment_tol);
+        }
+        if (lane == 0 && !keep) out_count[spec] = n_emitted;
+    }
 }
 
 // scratch bytes of the fused kernel: the preliminary phase's LDS and the rescoring scratch take turns in them
@@ -2784,8 +3097,8 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
 __global__ __launch_bounds__(256) void quick_mark_kernel(DevScorer sc, uint32_t n, DevWork w, uint8_t* __restrict__ keep) {
     const uint32_t spec = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63u;
     if (spec >= n || (w.status[spec] != ST_OK && w.status[spec] != ST_OK_ORDERED)) return;
-    if (lane < w.cand_len[spec]) {
-        const uint32_t pep = prescore_peptide(w.cand[(size_t)spec * sc.kmax + lane]);
+    for (uint32_t i = lane; i < w.cand_len[spec]; i += WAVE) {
+        const uint32_t pep = prescore_peptide(w.cand[(size_t)spec * sc.kmax + i]);
         if (pep != 0xFFFFFFFFu) keep[pep] = 1;
     }
 }
@@ -2872,6 +3185,8 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, bool quick) {
+    if (sc.kmax > WAVE)  // report_psms > 32: rescore_big_kernel
+        return ((rescore_scratch_bytes(false) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b) + rescore_big_bytes(quick);
     return ((rescore_scratch_bytes(quick) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b);
 }
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return narrow_scratch_bytes(sc, b) + rescore_fixed_bytes(sc, b); }
@@ -2902,6 +3217,7 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     if (b.n == 0) return;
     auto k = b.probe ? (w.dbg ? prelim_kernel<true, true> : prelim_kernel<true, false>)
                      : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
+    if (sc.kmax > WAVE) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
     hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
@@ -2917,6 +3233,12 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
+    const size_t assemble_lds = ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
+    if (sc.kmax > WAVE) {  // report_psms > 32: heaps in LDS, always exact
+        hipLaunchKernelGGL(tile_replay_big_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
+        hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
+        return;
+    }
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
     // the case with order-free trims, where only queries with a clipped histogram are replayed; with more queries than that, a
@@ -2939,13 +3261,18 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
         if (hipEventRecord((hipEvent_t)side->join, lane_stream) != hipSuccess) return;
         if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)side->join, 0) != hipSuccess) return;
     }
-    hipLaunchKernelGGL(tile_assemble_kernel, dim3(capped(b.n)), dim3(64), ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15,
-                       (hipStream_t)stream, sc, b, w);
+    hipLaunchKernelGGL(tile_assemble_kernel<false>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
 }
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
+    if (sc.kmax > WAVE) {  // report_psms > 32
+        hipLaunchKernelGGL(rescore_big_kernel, dim3(b.n < TILE_GRID_CAP ? b.n : TILE_GRID_CAP), dim3(64),
+                           rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out,
+                           out_count, keep);
+        return;
+    }
     hipLaunchKernelGGL(w.dbg ? rescore_kernel<true> : rescore_kernel<false>, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
                        (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }

@@ -112,6 +112,54 @@ def test_report_psms_and_score_types(small_world):
     small_world.check(ScorerParams(report_psms=30, precursor_tol=Tolerance("da", -3.0, 3.0)), "report_psms=30 (k=60)")
 
 
+def test_report_psms_beyond_a_wavefront(small_world, monkeypatch):
+    """report_psms > 32: trim_hits keeps k = max(50, 2 * report_psms) > 64 candidates (scoring.rs:322-329), preliminary lists wider
+    than a wavefront — the BIGK kernels (heaps in LDS, every trim exact, rescoring 64 candidates at a time).  Lists (initial_hits)
+    and PSMs equal to the oracle's for 50, 100 and 128 PSMs per spectrum: narrow and large windows, mixed routing, isotope errors x
+    charges (folded lists), chimera, wide windows, quick_score; resident and streamed."""
+    w = small_world
+    b = w.batch
+    wide = Tolerance("da", -20.0, 20.0)  # windows of a few hundred candidates: longer than k, inside the narrow kernel's counters
+    n, t = w.check(ScorerParams(report_psms=50, precursor_tol=wide), "report_psms=50 (k=100), +-20 Da")
+    assert t["n_retry"] == 0
+    # (min_matched_peaks = 1: most of a list passes scoring.rs:491, so the ranks beyond 32 and 64 are really reported)
+    n, t = w.check(ScorerParams(report_psms=50, precursor_tol=wide, min_matched_peaks=1), "report_psms=50, min_matched_peaks=1")
+    assert n > b.n * 35
+    n, t = w.check(ScorerParams(report_psms=100, precursor_tol=wide, min_matched_peaks=1), "report_psms=100 (k=200), +-20 Da")
+    assert n > b.n * 40
+    # (min_matched_peaks = 2 here: with 1, a spectrum of this case holds candidates that match the same single peak as a b- and as
+    # a y-ion — hyperscores ln(i) + lnfact(1) + lnfact(0) and ln(i) + lnfact(0) + lnfact(1), scoring.rs:163-201 — which glibc's
+    # log rounds to one double and the device's to two neighbours: the 1e-12 of the north star, but a different order)
+    n, t = w.check(ScorerParams(report_psms=128, precursor_tol=Tolerance("da", -60.0, 60.0), min_matched_peaks=2,
+                                fragment_tol=Tolerance("da", -0.3, 0.3)),
+                   "report_psms=128 (k=256), +-60 Da", batch=b.subset(np.arange(0, b.n, 2)))
+    assert n > (b.n // 2) * 64  # (on average more PSMs per spectrum than a wavefront has lanes)
+    w.check(ScorerParams(report_psms=40), "report_psms=40, +-10 ppm (windows shorter than k)")
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current,
+                            b.isolation_lo, b.isolation_hi, b.scan_start_time, b.inverse_ion_mobility, b.file_id)
+    w.check(ScorerParams(report_psms=50, precursor_tol=Tolerance("da", -8.0, 8.0), min_isotope_err=-1, max_isotope_err=2),
+            "report_psms=50, iso -1..2 x charges 2..4", batch=unknown.subset(np.arange(0, b.n, 2)))
+    # large windows: the tile kernels' seeds / heaps of k entries, replayed in LDS; and both routes in one batch
+    n, t = w.check(ScorerParams(report_psms=50, precursor_tol=Tolerance("da", -300.0, 300.0)), "report_psms=50, open search",
+                   batch=b.subset(np.arange(0, b.n, 4)))
+    assert t["n_wide"] > 100
+    w.check(ScorerParams(report_psms=100, precursor_tol=Tolerance("da", -150.0, 150.0), min_isotope_err=0, max_isotope_err=1),
+            "report_psms=100, +-150 Da x iso 0..1", batch=unknown.subset(np.arange(0, b.n, 6)))
+    monkeypatch.setenv("SAGE_HIP_WCAP", "128")
+    n, t = w.check(ScorerParams(report_psms=50, precursor_tol=wide), "report_psms=50, mixed routing")
+    assert 0 < t["n_wide"] < b.n
+    monkeypatch.delenv("SAGE_HIP_WCAP")
+    w.check(ScorerParams(report_psms=40, chimera=True, precursor_tol=wide, min_matched_peaks=2), "report_psms=40, chimera",
+            batch=b.subset(np.arange(0, b.n, 3)))
+    for low_memory in (False, True):
+        params = ScorerParams(report_psms=50, precursor_tol=wide)
+        scorer = Scorer(w.dev, params)
+        gk = scorer.quick_score(scorer.upload(b), low_memory)
+        np.testing.assert_array_equal(gk, w.orc.quick_score(params, b, low_memory), err_msg=f"quick_score report_psms=50 low_memory={low_memory}")
+    with pytest.raises(L.SageHipError):
+        Scorer(w.dev, ScorerParams(report_psms=129))
+
+
 def test_isotope_errors_and_fragment_charge(small_world):
     small_world.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, precursor_tol=Tolerance("ppm", -20.0, 20.0)),
                       "isotope -1..3")
@@ -202,6 +250,8 @@ def test_chimera_and_wide_window(gpu_required):
     w.check(ScorerParams(chimera=True, report_psms=5), "chimera, charge None")
     w.check(ScorerParams(chimera=True, wide_window=True, report_psms=5), "chimera + wide_window (DIA-style)")
     w.check(ScorerParams(wide_window=True, report_psms=3), "wide_window only")
+    w.check(ScorerParams(chimera=True, wide_window=True, report_psms=40), "chimera + wide_window, 40 rounds (lists of 80 candidates)")
+    w.check(ScorerParams(wide_window=True, report_psms=64), "wide_window, report_psms=64 (k=128)")
     no_iso = SpectrumBatch(w.batch.peak_off, w.batch.masses, w.batch.intensities, w.batch.precursor_mz,
                            w.batch.precursor_charge, w.batch.total_ion_current)
     w.check(ScorerParams(wide_window=True), "wide_window without isolation window (Da ±2.4 default)", batch=no_iso)
