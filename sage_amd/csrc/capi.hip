@@ -186,9 +186,8 @@ struct SageScorer {
     Event side_fork, side_join;
     // a resident narrow-search step in `ways` parts, each with its own stream (part 0: `stream`): the parts' kernels overlap each
     // other's cold starts, tails and retry chains (what two scorer handles on two host threads get, inside one call)
-    uint32_t ways = 1;               // SAGE_HIP_WAYS=2..4 (measured on C3: -1 % wall at 500 000 spectra, -6 % at 62 500 with two
-                                     // parts, nothing more with three or four; off by default: a launch that shares the GPU
-                                     // has no duration one could hold against a roofline)
+    uint32_t ways = 0;               // SAGE_HIP_WAYS=1..4; 0: by batch size (score_resident_locked).  Measured on C3: two parts
+                                     // -1 % wall at 500 000 spectra, -6 % at 62 500, nothing more with three or four
     hipStream_t way_stream[3] = {nullptr, nullptr, nullptr};
     Event way_fork, way_join[3], way_begin, way_end;
     DevBuf<double> lnfact;
@@ -1383,7 +1382,11 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         // A narrow-search batch in `ways` parts of the launch schedule (consecutive precursor masses), each on its own stream:
         // a part's kernels fill the GPU while another part's kernel starts cold, drains, or waits on the few wavefronts of its
         // retry pass.  Large-window batches go as one (their steps are long; the parts would fight over the candidate arena).
-        const uint32_t ways = (!b->maybe_wide && !s->exact_always && b->n >= 8192u * s->ways) ? s->ways : 1u;
+        // Default (no SAGE_HIP_WAYS): two parts for batches up to 98 304 spectra — the shard of a rank of an 8-GPU strong-scaling
+        // run — where a third of the step is cold starts, tails and the retry pass's handful of wavefronts (C3, 62 500 spectra:
+        // -6 %); one part above (125 000: -1 %), where the kernels' durations are what the roofline is held against.
+        const uint32_t want = s->ways ? s->ways : (b->n <= 98304u ? 2u : 1u);
+        const uint32_t ways = (!b->maybe_wide && !s->exact_always && b->n >= 8192u * want) ? want : 1u;
         int rc = ensure_work(s, b->n);
         if (rc != SAGE_HIP_OK) return rc;
         SageFeature* const rec = direct ? direct : o.features.p;
