@@ -25,6 +25,10 @@ name = args[0] if args else "C3"
 cfg = CONFIGS[name]
 n = int(args[1]) if len(args) > 1 else cfg["spectra"]
 steps = int(os.environ.get("AB_STEPS", "10"))
+params = scorer_params(cfg)
+if os.environ.get("AB_REPORT_PSMS"):  # e.g. 50: the kernels for lists wider than a wavefront
+    from dataclasses import replace
+    params = replace(params, report_psms=int(os.environ["AB_REPORT_PSMS"]))
 host = build_host_db(cfg, peptides_only=True)
 batch, _ = bench.generate_workload(cfg, host, n)
 if os.environ.get("AB_SORT"):  # what a mass-ordered copy of the batch in HBM would buy: hand the batch over sorted already
@@ -37,7 +41,7 @@ for s in sets:
     old = {k: os.environ.get(k) for k in kv}
     os.environ.update(kv)
     try:
-        scorer = Scorer(dev, scorer_params(cfg))
+        scorer = Scorer(dev, params)
     finally:
         for k, v in old.items():
             if v is None:

@@ -81,6 +81,18 @@ def test_c3_human_narrow_exact_mode(gpu_required, monkeypatch):
     assert t["n_retry"] == 0 and n_psm > 0
 
 
+def test_c3_and_c5_with_fifty_psms_per_spectrum(gpu_required):
+    """report_psms = 50 at configuration scale (lists of 100 candidates: the BIGK kernels): the C3 search, and
+    C5's wide-window search (large windows: seeds / heaps of 100 entries per query through the tile kernels) without the chimera
+    loop."""
+    from dataclasses import replace
+    batch, n_psm, t = _check("C3", every=64, n=1024, begin=2 * N_SPECTRA, params=replace(scorer_params(CONFIGS["C3"]), report_psms=50, min_matched_peaks=2))
+    assert t["n_retry"] == 0 and n_psm > 5 * batch.n
+    batch, n_psm, t = _check("C5", every=64, n=256, begin=N_SPECTRA,
+                             params=replace(scorer_params(CONFIGS["C5"]), report_psms=50, chimera=False))
+    assert t["n_wide"] == batch.n and n_psm > 10 * batch.n
+
+
 def test_c5_chimeric_wide_window(gpu_required):
     """wide_window + chimera + report_psms 5, three precursor charges per spectrum: every spectrum takes the tiled pipeline."""
     batch, n_psm, t = _check("C5", every=64)
