@@ -156,6 +156,11 @@ def test_report_psms_beyond_a_wavefront(small_world, monkeypatch):
         scorer = Scorer(w.dev, params)
         gk = scorer.quick_score(scorer.upload(b), low_memory)
         np.testing.assert_array_equal(gk, w.orc.quick_score(params, b, low_memory), err_msg=f"quick_score report_psms=50 low_memory={low_memory}")
+    # the other score type, a capped fragment charge, and the Fragments of 40 PSMs per spectrum
+    w.check(ScorerParams(report_psms=50, precursor_tol=wide, score_type="OpenMSHyperScore", min_matched_peaks=2, max_fragment_charge=1),
+            "report_psms=50, OpenMS score, fragment charge 1", batch=b.subset(np.arange(0, b.n, 3)))
+    _check_annotation(w, ScorerParams(annotate_matches=True, report_psms=40, precursor_tol=wide, min_matched_peaks=2),
+                      b.subset(np.arange(0, b.n, 4)), "annotate, report 40")
     with pytest.raises(L.SageHipError):
         Scorer(w.dev, ScorerParams(report_psms=129))
 
