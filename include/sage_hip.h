@@ -215,9 +215,10 @@ typedef struct SageFeature {
 
 /* Scorer::score for every spectrum of the batch (scoring.rs:300-309), results in input order:
  * out[i*report_psms + r] for r < out_count[i], Feature.spec_index == i.
- * Host memory in, host memory out, as a three-stage pipeline over chunks of the batch (SAGE_HIP_CHUNK spectra, default 131072):
- * chunk c + 1 is staged and uploaded on a copy stream while chunk c is scored and the PSM records of chunk c - 1 come back —
- * the reader / processor / search overlap of runner.rs:365-375, 450-461 at the PCIe boundary.  Arrays allocated with
+ * Host memory in, host memory out, as a pipeline over chunks of the batch (SAGE_HIP_CHUNK spectra, default 131072): the
+ * uploads run up to three chunks ahead on a copy stream while earlier chunks are scored (two at a time when the batch has no
+ * large precursor windows) and their PSM records come back — the reader / processor / search overlap of runner.rs:365-375,
+ * 450-461 at the PCIe boundary.  Arrays allocated with
  * sage_hip_host_alloc (page-locked) move by DMA at full PCIe rate; pageable arrays are accepted and staged through
  * page-locked blocks by a few host threads.  A chunk whose large-window candidates exhaust the device arena is scored again
  * in halves (never an error unless a single spectrum does not fit). */

@@ -1076,6 +1076,8 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     const DevDbView& db = kp.db;
     const DevScorer& sc = kp.sc;
     const DevBatchView& b = kp.b;
+    // entries per query of `seeds` (the u8 instance only runs in the two-pass production mode, never with report_psms > 32)
+    const uint32_t kstride = C8 ? WAVE : kp.w.kstride;
     const DevWork& w = kp.w;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool w0 = wave == 0;
@@ -1184,7 +1186,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         l_sh[SH_DIR] = dir;
                     }
                     l_hist[lane] = 0;
-                    for (uint32_t i = lane; i < w.kstride; i += WAVE) w.seeds[qid * w.kstride + i] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
+                    for (uint32_t i = lane; i < kstride; i += WAVE) w.seeds[qid * kstride + i] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
                 const uint32_t left = uni(l_sh[SH_LEFT]), right = uni(l_sh[SH_RIGHT]), first = uni(l_sh[SH_FIRST]), end = uni(l_sh[SH_END]);
@@ -1486,7 +1488,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             if (gx >= left && gx - left < nseed && x_lo + i < TS) {
                                 const uint32_t x = x_lo + i;
                                 const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
-                                if (c) w.seeds[qid * w.kstride + (gx - left)] = (uint16_t)c;
+                                if (c) w.seeds[qid * kstride + (gx - left)] = (uint16_t)c;
                             }
                         }
                     }
@@ -2258,7 +2260,12 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
 //      the reference's.  ~90 % of the items of a candidate match nothing.  (Fragment charges above 3 — precursor
 //      charge 5+ — are not filtered.)
 //      (The kernel is bound by VALU issue — rocprofv3: ~100 % of a SIMD's issue cycles — so what counts is
-//      instructions per item; wave-uniform loops over candidates cost 64x per candidate.)
+//      instructions per item; wave-uniform loops over candidates cost 64x per candidate.  And it sits on a knife's edge of
+//      register allocation — 96 VGPRs at five wavefronts per SIMD, 52 dwords spilled: two round-3 edits that each removed
+//      work — the four-ion trip below cut from ~112 to ~86 VALU instructions (bitmap at a constant LDS address, no clamp per
+//      lookup, 32-bit mask halves); the candidate's first ions requested before the bitmap is built, behind LDS-only
+//      barriers — each moved the spills (208 -> 224 bytes of scratch) and made the kernel 8-9 % SLOWER, 3.61 -> 3.9 ms per
+//      500 000 C3 spectra.  DESIGN.md 4.3.)
 //      A candidate with many hits in a chunk (the true peptide: ~35 of its ~47 ions) would keep its lane busy
 //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
 //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
