@@ -237,7 +237,9 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
             cmd = ["rocprofv3", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config",
                    args.config, "--spectra", str(n_spec), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
                    "--no-extras"] + (["--proteins", str(args.proteins)] if args.proteins else [])
-            env = dict(os.environ, TMPDIR="/tmp")
+            # (SAGE_HIP_WAYS=1: a step of this size would run as two parts — two dispatches per kernel, each over half the
+            # spectra — and the largest dispatch below would no longer be the whole pass)
+            env = dict(os.environ, TMPDIR="/tmp", SAGE_HIP_WAYS="1")
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=args.traffic_timeout)
             if p.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {p.returncode}): {p.stderr[-200:]}"
@@ -617,7 +619,10 @@ def main():
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],
-                                "exact_retry_for_tied_hyperscores": last_t["n_retry"], "launches_per_step": last_t["n_launches"]},
+                                "exact_retry_for_tied_hyperscores": last_t["n_retry"], "launches_per_step": last_t["n_launches"],
+                                # > 1: the step ran as that many parts on their own streams (steps of up to 98 304 spectra without
+                                # large windows) and kernel_ms are sums over launches that overlap in time
+                                "parts_per_step": last_t["n_ways"]},
                     "note": "achieved / frac: SURVEY 8(d) algorithmic bytes of the reference's algorithm (binary-search probes "
                             "at 4-8 B each + scanned entries) over the dominant phase's kernel time (HIP events on the scorer's "
                             "stream). achieved_traffic / frac_traffic: the bytes the GPU kernels really moved (128-byte lines; a "
