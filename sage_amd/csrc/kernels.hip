@@ -2250,6 +2250,18 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
     return l;
 }
 
+// Run (scoring.rs:771-793; core.h: Run / run_matched) in ONE register.  After any update `last == index` and `start + length ==
+// index + 1`, so (next = start + length, length, longest) is the whole state — `last` is next - 1, or the initial 0 while next
+// is still 0 (the reference's quirk that a first match at index 0 is ignored is kept) — 10 bits each: ion indices stay below
+// 1023 (capi.hip refuses longer peptides).  Two runs per candidate: 2 registers instead of 8 in a kernel that spills.
+__device__ __forceinline__ void run_matched_packed(uint32_t& r, uint32_t index) {
+    const uint32_t next = r & 1023u, length = (r >> 10) & 1023u, longest = r >> 20;
+    if ((next ? next - 1u : 0u) == index) return;  // self.last == index
+    const uint32_t nl = next == index ? length + 1u : 1u;
+    r = (index + 1u) | (nl << 10) | ((nl > longest ? nl : longest) << 20);
+}
+__device__ __forceinline__ uint32_t run_longest_packed(uint32_t r) { return r >> 20; }
+
 // ---- score_candidate (scoring.rs:699-759) of the wavefront's 64 candidates: lane i scores ITS candidate (ion table at
 //      db.ions + ion_base, `lm1` ions per kind, `nfz` fragment charges; !valid: none) against the spectrum in LDS (peaks pm / pi,
 //      presence bitmap pbm, position table plut) and leaves matched / summed / ppm sum / longest runs in `s` — in the
@@ -2276,7 +2288,8 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
                                                  const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
                                                  Score& s) {
     const uint32_t lane = lane_id();
-    Run b_run = {0, 0, 0, 0}, y_run = {0, 0, 0, 0};
+    uint32_t b_run = 0, y_run = 0;  // (run_matched_packed)
+    uint32_t mm = 0;                // matched_b | matched_y << 16 (u16 in the reference)
     const bool scored = valid && lm1 && nfz;
     const float* __restrict__ my = db.ions + ion_base;
     const uint32_t nions = scored ? db.n_kinds * lm1 : 0u;
@@ -2350,17 +2363,9 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             const uint64_t K1 = __ballot(ok1), K2 = __ballot(ok2), K3 = __ballot(ok3);
             // the candidate's accumulators, wave-uniform while its matches are added in (ion, charge) order
             float u_sb = lane_valuef(s.summed_b, L), u_sy = lane_valuef(s.summed_y, L), u_pp = lane_valuef(s.ppm_difference, L);
-            uint32_t u_mb = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_b, (int)L);
-            uint32_t u_my = (uint32_t)__builtin_amdgcn_readlane((int)s.matched_y, (int)L);
-            Run u_b, u_y;
-            u_b.start = (uint32_t)__builtin_amdgcn_readlane((int)b_run.start, (int)L);
-            u_b.length = (uint32_t)__builtin_amdgcn_readlane((int)b_run.length, (int)L);
-            u_b.last = (uint32_t)__builtin_amdgcn_readlane((int)b_run.last, (int)L);
-            u_b.longest = (uint32_t)__builtin_amdgcn_readlane((int)b_run.longest, (int)L);
-            u_y.start = (uint32_t)__builtin_amdgcn_readlane((int)y_run.start, (int)L);
-            u_y.length = (uint32_t)__builtin_amdgcn_readlane((int)y_run.length, (int)L);
-            u_y.last = (uint32_t)__builtin_amdgcn_readlane((int)y_run.last, (int)L);
-            u_y.longest = (uint32_t)__builtin_amdgcn_readlane((int)y_run.longest, (int)L);
+            uint32_t u_mm = (uint32_t)__builtin_amdgcn_readlane((int)mm, (int)L);
+            uint32_t u_b = (uint32_t)__builtin_amdgcn_readlane((int)b_run, (int)L);
+            uint32_t u_y = (uint32_t)__builtin_amdgcn_readlane((int)y_run, (int)L);
             uint64_t anyK = K1 | K2 | K3;
             while (anyK) {
                 const uint32_t bit = (uint32_t)__ffsll((long long)anyK) - 1;
@@ -2372,8 +2377,8 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
     if ((K >> bit) & 1ull) {                                                       \
         const float it = lane_valuef(IT, bit), tm = lane_valuef(TM, bit);          \
         u_pp += tm;                                                                \
-        if (nterm) { u_mb += 1; u_sb += it; run_matched(u_b, idx); }               \
-        else       { u_my += 1; u_sy += it; run_matched(u_y, idx); }               \
+        if (nterm) { u_mm += 1u; u_sb += it; run_matched_packed(u_b, idx); }       \
+        else       { u_mm += 0x10000u; u_sy += it; run_matched_packed(u_y, idx); } \
     }
                 SAGE_COOP_ADD(K1, it1, tm1)
                 SAGE_COOP_ADD(K2, it2, tm2)
@@ -2382,7 +2387,7 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             }
             if (lane == L) {
                 s.summed_b = u_sb; s.summed_y = u_sy; s.ppm_difference = u_pp;
-                s.matched_b = u_mb; s.matched_y = u_my;
+                mm = u_mm;
                 b_run = u_b; y_run = u_y;
                 m1 = m2 = m3 = 0ull;  // done
             }
@@ -2409,21 +2414,23 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
                 const float peak_mass = pm[pk], peak_intensity = pi[pk];
                 s.ppm_difference += peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
                 if ((nterm_mask >> kind_i) & 1u) {
-                    s.matched_b += 1;
+                    mm += 1u;
                     s.summed_b += peak_intensity;
-                    run_matched(b_run, idx);
+                    run_matched_packed(b_run, idx);
                 } else {
-                    s.matched_y += 1;
+                    mm += 0x10000u;
                     s.summed_y += peak_intensity;
-                    run_matched(y_run, idx);
+                    run_matched_packed(y_run, idx);
                 }
             }
             bit = nbit;
             ionv = nion;
         }
     }
-    s.longest_b = b_run.longest;
-    s.longest_y = y_run.longest;
+    s.matched_b = mm & 0xFFFFu;
+    s.matched_y = mm >> 16;
+    s.longest_b = run_longest_packed(b_run);
+    s.longest_y = run_longest_packed(y_run);
 }
 
 // One Feature record (scoring.rs:504-594) of a scored candidate: `rank_field` is Feature.rank, `next` / `best` the hyperscores of
