@@ -471,7 +471,8 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     uint32_t max_ions = 0;
     for (uint64_t i = 0; i < np; i++) {
         const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
-        if (len > 0xFFFF) return fail(SAGE_HIP_ERR_UNSUPPORTED, "peptide longer than 65535 residues");
+        // (the rescoring kernel keeps a candidate's longest-run state in 10-bit fields: kernels.hip, run_matched_packed)
+        if (len > 1023) return fail(SAGE_HIP_ERR_UNSUPPORTED, "peptide longer than 1023 residues");
         const uint64_t cnt = (len ? len - 1 : 0) * nk;
         ion_off[i + 1] = ion_off[i] + cnt;
         max_ions = std::max<uint32_t>(max_ions, (uint32_t)cnt);

@@ -317,6 +317,18 @@ SAGE_HD void run_matched(Run& r, uint32_t index) {
     r.last = index;
 }
 
+// Run in ONE register (the rescoring kernel is short of them).  After any update `last == index` and `start + length ==
+// index + 1`, so (next = start + length, length, longest) is the whole state — `last` is next - 1, or the initial 0 while next
+// is still 0 (the reference's quirk that a first match at index 0 is ignored is kept) — 10 bits each: ion indices stay below
+// 1023 (capi.hip refuses longer peptides).  tests/test_core_emulation.py holds it to run_matched.
+SAGE_HD void run_matched_packed(uint32_t& r, uint32_t index) {
+    const uint32_t next = r & 1023u, length = (r >> 10) & 1023u, longest = r >> 20;
+    if ((next ? next - 1u : 0u) == index) return;  // self.last == index
+    const uint32_t nl = next == index ? length + 1u : 1u;
+    r = (index + 1u) | (nl << 10) | ((nl > longest ? nl : longest) << 20);
+}
+SAGE_HD uint32_t run_longest_packed(uint32_t r) { return r >> 20; }
+
 // ---- Score (scoring.rs:17-30) -------------------------------------------------------------------
 struct Score {
     uint32_t peptide;

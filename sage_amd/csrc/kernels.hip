@@ -2250,18 +2250,6 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
     return l;
 }
 
-// Run (scoring.rs:771-793; core.h: Run / run_matched) in ONE register.  After any update `last == index` and `start + length ==
-// index + 1`, so (next = start + length, length, longest) is the whole state — `last` is next - 1, or the initial 0 while next
-// is still 0 (the reference's quirk that a first match at index 0 is ignored is kept) — 10 bits each: ion indices stay below
-// 1023 (capi.hip refuses longer peptides).  Two runs per candidate: 2 registers instead of 8 in a kernel that spills.
-__device__ __forceinline__ void run_matched_packed(uint32_t& r, uint32_t index) {
-    const uint32_t next = r & 1023u, length = (r >> 10) & 1023u, longest = r >> 20;
-    if ((next ? next - 1u : 0u) == index) return;  // self.last == index
-    const uint32_t nl = next == index ? length + 1u : 1u;
-    r = (index + 1u) | (nl << 10) | ((nl > longest ? nl : longest) << 20);
-}
-__device__ __forceinline__ uint32_t run_longest_packed(uint32_t r) { return r >> 20; }
-
 // ---- score_candidate (scoring.rs:699-759) of the wavefront's 64 candidates: lane i scores ITS candidate (ion table at
 //      db.ions + ion_base, `lm1` ions per kind, `nfz` fragment charges; !valid: none) against the spectrum in LDS (peaks pm / pi,
 //      presence bitmap pbm, position table plut) and leaves matched / summed / ppm sum / longest runs in `s` — in the
@@ -2277,7 +2265,8 @@ __device__ __forceinline__ uint32_t run_longest_packed(uint32_t r) { return r >>
 //      work — the four-ion trip below cut from ~112 to ~86 VALU instructions (bitmap at a constant LDS address, no clamp per
 //      lookup, 32-bit mask halves); the candidate's first ions requested before the bitmap is built, behind LDS-only
 //      barriers — each moved the spills (208 -> 224 bytes of scratch) and made the kernel 8-9 % SLOWER, 3.61 -> 3.9 ms per
-//      500 000 C3 spectra.  DESIGN.md 4.3.)
+//      500 000 C3 spectra; shrinking the live state instead (run_matched_packed, the packed match counts) made it 5.5 %
+//      faster.  DESIGN.md 4.3.)
 //      A candidate with many hits in a chunk (the true peptide: ~35 of its ~47 ions) would keep its lane busy
 //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
 //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few

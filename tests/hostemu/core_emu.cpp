@@ -126,4 +126,17 @@ uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, f
     return bad;
 }
 
+// Run::matched (scoring.rs:771-793) fed the same index sequence through core.h's four-field Run and the one-register form the
+// rescoring kernel keeps: returns the number of steps after which `longest` differs (0 = equivalent on this sequence).
+uint32_t emu_run_packed_mismatches(const uint32_t* indices, uint32_t n) {
+    Run r{0, 0, 0, 0};
+    uint32_t p = 0, bad = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        run_matched(r, indices[i]);
+        run_matched_packed(p, indices[i]);
+        bad += run_longest_packed(p) != r.longest || (p & 1023u) != r.start + r.length || ((p >> 10) & 1023u) != r.length;
+    }
+    return bad;
+}
+
 }  // extern "C"

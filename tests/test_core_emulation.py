@@ -39,6 +39,8 @@ def emu():
     lib.emu_lut_windows.argtypes = [f32p, C.c_uint32, C.c_float, C.c_uint32, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.emu_select_peak_lut.restype = C.c_int
     lib.emu_select_peak_lut.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float]
+    lib.emu_run_packed_mismatches.restype = C.c_uint32
+    lib.emu_run_packed_mismatches.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
     lib.emu_peak_bitmap_violations.restype = C.c_uint32
     lib.emu_peak_bitmap_violations.argtypes = [f32p, C.c_uint32, C.c_int, C.c_float, C.c_float, f32p, C.c_uint32,
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
@@ -287,3 +289,19 @@ def test_position_table_windows_need_no_safety_margin(emu):
         dl = np.array([5.0, np.nan, 1.0, -10.0, top * 100.0, top * 1.4], dtype=np.float32)
         dh = np.array([4.0, 1.0, np.nan, -5.0, top * 200.0, np.inf], dtype=np.float32)
         assert emu.emu_lut_windows(fp(mz), n, scale, stride, fp(dl), fp(dh), len(dl), C.byref(run)) == 0
+
+
+def test_packed_run_state_equals_run_matched(emu):
+    """The rescoring kernel keeps Run (scoring.rs:771-793) as (start + length, length, longest) in one register
+    (core.h: run_matched_packed): identical `longest` — and identical state — after every step of ascending index sequences
+    (the order score_candidate walks the ions of a kind in), with repeats (several fragment charges of one ion), gaps, a first
+    match at index 0 (which the reference ignores: `last` starts at 0) and the largest index the packing admits."""
+    rng = np.random.default_rng(7)
+    seqs = [[0], [0, 0, 1, 2], [1, 2, 3], [0, 1, 2, 3], [5, 5, 5, 6, 7, 9, 10, 11, 12], [1020, 1021, 1022], list(range(0, 1023)), [3, 2, 1, 1, 2, 3]]
+    for _ in range(300):
+        n = int(rng.integers(1, 60))
+        idx = np.sort(rng.integers(0, int(rng.integers(2, 80)), n))
+        seqs.append(np.repeat(idx, rng.integers(1, 4, n)).tolist())
+    for q in seqs:
+        a = np.asarray(q, dtype=np.uint32)
+        assert emu.emu_run_packed_mismatches(a.ctypes.data_as(C.POINTER(C.c_uint32)), len(a)) == 0, q
