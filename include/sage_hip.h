@@ -154,7 +154,8 @@ int sage_hip_device_count(void);
 /* Upload an IndexedDatabase to HBM on `device` and derive the device layouts.
  * Stands in for the `&'db IndexedDatabase` borrow of Scorer (scoring.rs:211).
  * With view->fragments == NULL the fragment index is generated ON THE DEVICE from the peptide list
- * (Parameters::build_from_peptides, database.rs:265-346: ion series, stored-ion filter by view->min_ion_index, sort). */
+ * (Parameters::build_from_peptides, database.rs:265-346: ion series, stored-ion filter by view->min_ion_index, sort).
+ * Peptides of more than 1023 residues: SAGE_HIP_ERR_UNSUPPORTED (the reference's default max_len is 50). */
 int sage_hip_db_create(const SageDbView* view, int device, SageDeviceDb** out);
 void sage_hip_db_destroy(SageDeviceDb* db);
 uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db);
