@@ -612,8 +612,8 @@ def main():
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
                     "limiters": "both narrow-search kernels are bound by VALU issue, not by HBM (rocprofv3 SQ counters, "
-                                "profiles/r03_C3_pmc_sq_*.txt: prelim 2 065 and rescore 3 172 VALU instructions per spectrum at 5 "
-                                "wavefronts per SIMD = 72 % / 75 % of the VALU cycles); with the XCD-aware schedule the preliminary kernel's "
+                                "profiles/r03_C3_pmc_sq_*.txt: prelim 2 065 and rescore 3 072 VALU instructions per spectrum at 5 "
+                                "wavefronts per SIMD = 75 % / 78 % of the VALU cycles); with the XCD-aware schedule the preliminary kernel's "
                                 "L2 misses halve (30 -> 15 KB per spectrum) and its time does not move — so byte fractions say how "
                                 "far the memory system is from being the limit, not how good the kernels are",
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
