@@ -505,4 +505,11 @@ void orc_tol_bounds(OrcTolerance t, float center, float* lo, float* hi) {
 }
 int orc_max_threads() { return omp_get_max_threads(); }
 
+// f64::ln of the reference: 0 = the platform libm (default), 1 = correctly rounded (libquadmath) — sage_oracle.cpp
+void orc_set_log_mode(int mode) { set_log_mode(mode); }
+int orc_get_log_mode() { return get_log_mode(); }
+void orc_ln_batch(int mode, const double* x, uint64_t n, double* out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = mode ? ln_correctly_rounded(x[i]) : std::log(x[i]);
+}
+
 }  // extern "C"

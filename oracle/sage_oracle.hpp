@@ -329,6 +329,11 @@ struct SpectrumProcessor {  // spectrum.rs:39-44, 263-413
 enum class ScoreType : int { SageHyperScore = 0, OpenMSHyperScore = 1 };
 
 double lnfact(uint16_t n);  // scoring.rs:170-177
+// f64::ln (sage_oracle.cpp): mode 0 = the platform libm, 1 = correctly rounded through libquadmath
+void set_log_mode(int mode);
+int get_log_mode();
+double ln(double x);
+double ln_correctly_rounded(double x);
 double score_type_score(ScoreType t, uint16_t matched_b, uint16_t matched_y, float summed_b,
                         float summed_y);  // scoring.rs:179-201
 uint8_t max_fragment_charge(std::optional<uint8_t> max_fragment_charge, uint8_t precursor_charge);  // :239-247

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("SAGE_HIP_LIB") or os.path.join(HERE, "libsage_hip.so")  # (override: kernel experiments)
 SOURCES = ["kernels.hip", "process.hip", "index_build.hip", "rescore.hip", "capi.hip", "host_db.cpp", "writers.cpp", "mzml_reader.cpp"]
-HEADERS = ["core.h", "detmath.h", "device_types.h", "host_db.hpp", os.path.join("..", "..", "include", "sage_hip.h")]
+HEADERS = ["core.h", "crlog.h", "crlog_tables.h", "detmath.h", "device_types.h", "host_db.hpp", os.path.join("..", "..", "include", "sage_hip.h")]
 ARCH = "gfx950"
 
 

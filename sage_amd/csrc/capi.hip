@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "crlog.h"
 #include "device_types.h"
 #include "host_db.hpp"
 
@@ -721,13 +722,13 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         b.device = db->device;
         HIP_TRY(b.up_done.create(false));
     }
-    // lnfact (scoring.rs:170-177) tabulated with the host libm so the factorial terms are bit-identical
-    // to a CPU evaluation
-    std::vector<double> tbl(4096);
+    // lnfact (scoring.rs:170-177) tabulated on the host with the SAME correctly rounded ln the kernels use (crlog.h): the
+    // factorial terms do not depend on the host's libm
+    std::vector<double> tbl(131072);  // every u16 count and every sum of two (Score.matched_b/y are u16, scoring.rs:17-30)
     tbl[0] = 1.0;
     for (uint32_t n = 1; n < tbl.size(); n++) {
         const double x = (double)n;
-        tbl[n] = x * std::log(x) - x + 0.5 * std::log(x) + 0.5 * std::log(M_PI * 2.0 * x);
+        tbl[n] = x * sagecore::cr_log(x) - x + 0.5 * sagecore::cr_log(x) + 0.5 * sagecore::cr_log(M_PI * 2.0 * x);
     }
     HIP_TRY(s->lnfact.upload(tbl.data(), tbl.size()));
     // large-window kernel: persistent workgroups, as many as the LDS tiles allow to be resident
@@ -1287,7 +1288,9 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     const SideStream side{s->side_stream, s->side_fork.e, s->side_join.e};
     DevScorer sc1 = sc, sc2 = sc;
     sc1.exact = mode == MODE_EXACT ? 1u : 0u;
+    sc1.fast_log = o.two_pass ? 1u : 0u;  // (an undecided logarithm is settled by the retry pass: launch_rescore)
     sc2.exact = 1u;
+    sc2.fast_log = 0u;
     HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
     HIP_TRY(hipEventRecord(o.ev[0].e, st));
     if (fused)

@@ -62,6 +62,8 @@ struct DevScorer {
                          // larger precursor window go to the tiled large-window kernel
     uint32_t dbg_flags;  // timing experiments only (SAGE_HIP_DEBUG_FLAGS)
     uint32_t xcd_chunk;  // consecutive schedule positions one XCD takes at a time (kernels.hip: xcd_position); 0: round-robin
+    uint32_t fast_log;   // 1: this pass is followed by the exact retry pass, so its rescoring kernel may carry the fast phase of the
+                         //    correctly rounded logarithm only and queue the (rare) spectrum it cannot round for (crlog.h)
     uint32_t exact;      // 1: every trim_hits replays bounded_min_heapify, so the preliminary list has the reference's heap
                          //    layout.  0: each trim keeps the same SET of candidates (the k largest) without replaying the
                          //    heap; the layout is only observable through equal hyperscores at a reported rank, which the

@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "crlog.h"
 #include "device_types.h"
 
 using namespace sagecore;
@@ -86,13 +87,18 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // serves one narrow mass front, and every XCD still gets every mass range (heavy precursors cost more: contiguous eighths
 // would leave the last XCD with the long tail).  The ragged end (fewer than 8 chunks) stays round-robin.
 constexpr uint32_t N_XCD = 8;
-__device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t n, uint32_t chunk) {
-    if (chunk & 0x80000000u) return n - 1 - xcd_position(b, n, chunk & 0x7FFFFFFFu);  // heaviest precursors first
+__device__ __forceinline__ uint32_t xcd_position_fwd(uint32_t b, uint32_t n, uint32_t chunk) {
     if (chunk == 0) return b;
     const uint32_t group = N_XCD * chunk;
     if (b >= n / group * group) return b;
     const uint32_t x = b % N_XCD, i = b / N_XCD;  // the i-th workgroup of XCD x
     return ((i / chunk) * N_XCD + x) * chunk + i % chunk;
+}
+// (not recursive: a self-call cannot be inlined, and one real call in a kernel costs it the calling convention — a stack
+// pointer, callee-saved registers around the call — in kernels that are short of scalar registers)
+__device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t n, uint32_t chunk) {
+    const uint32_t p = xcd_position_fwd(b, n, chunk & 0x7FFFFFFFu);
+    return (chunk & 0x80000000u) ? n - 1 - p : p;  // bit 31: heaviest precursors first
 }
 
 // wave-uniform values that come out of memory land in VGPRs; these move them to SGPRs (the value must be uniform)
@@ -2049,22 +2055,50 @@ __device__ __forceinline__ long long wave_max_i64(long long v) {
 __device__ __forceinline__ double from_order_key64(long long k) {  // inverse of order_key64 (the mapping is an involution)
     return __longlong_as_double(k ^ (long long)(((unsigned long long)(k >> 63)) >> 1));
 }
+// lnfact (scoring.rs:170-177) from the table the host makes with the same correctly rounded ln (capi.hip: scorer_init; it
+// covers every u16 argument and every sum of two)
 __device__ __forceinline__ double lnfact_dev(uint32_t n, const double* __restrict__ table, uint32_t table_n) {
-    if (n < table_n) return table[n];
-    const double x = (double)n;  // scoring.rs:170-177
-    return x * log(x) - x + 0.5 * log(x) + 0.5 * log(3.14159265358979323846 * 2.0 * x);
+    return table[n < table_n ? n : table_n - 1u];
 }
 
-__device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s, const double* table, uint32_t tn) {
-    double score;  // ScoreType::score, scoring.rs:179-201
+// ScoreType::score, scoring.rs:179-201.  `ln_i` = ln((summed_b + 1) as f64 * (summed_y + 1) as f64), correctly rounded
+// (cr_log_pair below); OpenMSHyperScore takes its f32 ln_1p here.
+__device__ __forceinline__ double hyperscore_arg(const Score& s) { return (double)(s.summed_b + 1.0f) * (double)(s.summed_y + 1.0f); }
+__device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s, const double ln_i, const double* table, uint32_t tn) {
+    double score;
     if (score_type == 0) {
-        const double i = (double)(s.summed_b + 1.0f) * (double)(s.summed_y + 1.0f);
-        score = log(i) + lnfact_dev(s.matched_b, table, tn) + lnfact_dev(s.matched_y, table, tn);
+        score = ln_i + lnfact_dev(s.matched_b, table, tn) + lnfact_dev(s.matched_y, table, tn);
     } else {
         const float si = s.summed_b + s.summed_y;
         score = (double)log1pf(si) + lnfact_dev(s.matched_b, table, tn) + lnfact_dev(s.matched_y, table, tn);
     }
     return __builtin_isfinite(score) ? score : 255.0;
+}
+// The two logarithms of a rescoring round through ONE inlined copy of cr_log (crlog.h): ln(x) always, ln(lambda) when
+// `with_lambda` (a spectrum's first round; scoring.rs:522-523).  Two call sites would be two copies of the code in kernels
+// that live at the edge of their register budget (eleven copies of both phases cost rescore_kernel 500 scalar spills).
+// ACC == false (the hot first-pass instance of rescore_kernel): the fast phase only; `undecided` is set where it could not
+// round (~2^-17 of the arguments) and the spectrum goes through the retry pass, whose kernels carry both phases.
+template <bool ACC>
+__device__ __forceinline__ double cr_log_pair(const double x, const double lambda, const bool with_lambda, double& ln_lambda, bool& undecided) {
+    double ln_x = 0.0;
+    undecided = false;
+#pragma nounroll
+    for (int it = with_lambda ? 0 : 1; it < 2; it++) {
+        double y;
+        if (ACC) {
+            y = cr_log(it ? x : lambda);
+        } else {
+            const CrLogArg a = cr_log_reduce(it ? x : lambda);
+            bool decided;
+            y = cr_log_fast(a, decided);
+            if (a.is_special) y = a.special;
+            else if (!decided) undecided = true;
+        }
+        if (it) ln_x = y;
+        else ln_lambda = y;
+    }
+    return ln_x;
 }
 
 // Rescoring is split in two phases per candidate chunk so that all 64 lanes stay busy and the
@@ -2426,14 +2460,14 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
 // the next rank (0 if none) and of rank 0.
 __device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const DevBatchView& b, const uint32_t spec, const uint32_t pep,
                                                     const uint32_t z, const int iso, const Score& s, const double h, const double next,
-                                                    const double best, const uint32_t rank_field, const double lambda, const float mzp,
+                                                    const double best, const uint32_t rank_field, const double lambda, const double ln_lambda, const float mzp,
                                                     const float rt, const float ims, const uint32_t fid, const float tic,
                                                     const uint32_t tot_scored, const double* __restrict__ lnfact_table,
                                                     const uint32_t lnfact_n) {
     const float precursor_mass = mzp * (float)z;
     const uint32_t k = s.matched_b + s.matched_y;
     const double log10_poisson =
-        ((double)k * log(lambda) - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
+        ((double)k * ln_lambda - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
     const float isotope_error = (float)iso * NEUTRON;
     const uint32_t info = db.pep_info[pep];
     const float calc = db.pep_mono[pep];
@@ -2480,7 +2514,7 @@ __device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const D
 // came from order-free trims — the right candidates in some other order — and such a tie cannot be settled
 // here: the function returns false with nothing final reported (`queue_on_tie`: after queueing the spectrum for the exact
 // retry pass; else the caller settles it itself).
-template <class PC>
+template <bool ACC, class PC>
 __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                                                  const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                  SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
@@ -2513,6 +2547,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
 #define SAGE_N_ITEMS (valid ? db.n_kinds * lm1 * nfz : 0u)  /* (ion, fragment charge) pairs of this candidate */
 
     const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
+    double ln_lambda = 0.0;                                           // (cr_log_pair, first round)
     const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
     const float rt = b.rt ? b.rt[spec] : 0.0f;
     float ims = 0.0f;
@@ -2558,9 +2593,20 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         pc.mark(1);
         double h = 0.0;
         bool pass = false;
+        bool ln_undecided;
+        const double ln_i = cr_log_pair<ACC>(hyperscore_arg(s), lambda, round == 0, ln_lambda, ln_undecided);
+        if (!ACC && __ballot(ln_undecided && (valid || round == 0)) != 0ull) {
+            // (the hot instance carries the logarithm's fast phase only: this spectrum again in the retry pass, like a tie)
+            if (queue_on_tie && lane == 0) {
+                w.status[spec] = ST_RETRY;
+                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+                out_count[spec] = 0;
+            }
+            return false;
+        }
         if (valid) {
             s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
-            h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
+            h = hyperscore_dev(sc.score_type, s, ln_i, lnfact_table, lnfact_n);
             pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
         }
         if (keep) {
@@ -2641,7 +2687,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         }
         pc.mark(3);
         if (pass && rank < per_round) {  // scoring.rs:504-594
-            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, mzp, rt, ims,
+            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
                                                fid, tic, tot_scored, lnfact_table, lnfact_n);
             *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
         }
@@ -2723,6 +2769,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
         const uint32_t tot_matched = w.totals[2 * spec], tot_scored = w.totals[2 * spec + 1];
         float tic = b.tic[spec];
         const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
+        double ln_lambda = 0.0;
         const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
         const float rt = b.rt ? b.rt[spec] : 0.0f;
         float ims = 0.0f;
@@ -2769,9 +2816,11 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                 score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, inv_wb, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
                 double h = 0.0;
                 bool pass = false;
+                bool ln_undecided;  // (never: both phases)
+                const double ln_i = cr_log_pair<true>(hyperscore_arg(s), lambda, round == 0 && base == 0, ln_lambda, ln_undecided);
                 if (valid) {
                     s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
-                    h = hyperscore_dev(sc.score_type, s, lnfact_table, lnfact_n);
+                    h = hyperscore_dev(sc.score_type, s, ln_i, lnfact_table, lnfact_n);
                     pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
                 }
                 npass += (uint32_t)__popcll(__ballot(pass));
@@ -2842,7 +2891,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                     const double h = g_sorted[rank];
                     const double next = rank + 1 < npass ? g_sorted[rank + 1] : 0.0, best = g_sorted[0];
                     const SageFeature f = make_feature(db, b, spec, prescore_peptide(mine), prescore_charge(mine), prescore_iso(mine), s, h, next, best,
-                                                       sc.chimera ? round + 1 : rank + 1, lambda, mzp, rt, ims, fid, tic, tot_scored, lnfact_table,
+                                                       sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims, fid, tic, tot_scored, lnfact_table,
                                                        lnfact_n);
                     out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
                 }
@@ -2874,7 +2923,7 @@ __host__ __device__ inline size_t narrow_scratch_bytes(const DevScorer& sc, cons
 // reported ranks tie in hyperscore is queued for the exact retry pass.  (Settling the tie here — the preliminary phase once more
 // with exact trims, inline or behind a call — was measured: the extra code costs the hot path its registers, rescoring went
 // from 3.7 to 6.0 resp. 7.2 ms per 500 000 C3 spectra.  DESIGN.md 4.7.)
-template <bool PROF>
+template <bool PROF, bool ACC>
 __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                      const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                      SageFeature* __restrict__ out,
@@ -2908,7 +2957,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     const uint32_t ncand = w.cand_len[spec];
     const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
     // (a list no trim touched is the reference's list already: equal hyperscores are ranked by it, no retry)
-    rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
+    rescore_spectrum<ACC>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
                      sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
@@ -3017,7 +3066,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
     const uint32_t tot_s = __hip_atomic_load(w.totals + 2 * spec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t mine = lane < ncand ? __hip_atomic_load(w.cand + (size_t)spec * sc.kmax + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                        : PRESCORE_EMPTY;
-    const bool done = rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s,
+    const bool done = rescore_spectrum<true>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s,
                                        st == ST_OK_ORDERED, true, pc);
     if (done && lane == 0) w.status[spec] = ST_DONE;  // (a rescore_kernel behind the large-window kernels leaves it alone)
 }
@@ -3086,7 +3135,7 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
             pc.mark(4);
             pc.rebase(1);  // (the rescoring phase accounts under kernel 1)
             __syncthreads();  // the list is in registers: the preliminary phase's LDS is free
-            if (rescore_spectrum(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
+            if (rescore_spectrum<true>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
                                  exact || r.untrimmed, false, pc) || exact)
                 break;
             exact = true;  // equal hyperscores at a reported rank: once more, with bounded_min_heapify replayed (heap.rs:7-28)
@@ -3276,7 +3325,9 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                            out_count, keep);
         return;
     }
-    hipLaunchKernelGGL(w.dbg ? rescore_kernel<true> : rescore_kernel<false>, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
+    // the first pass of a two-pass search (sc.fast_log) runs the instance with the logarithm's fast phase only (crlog.h)
+    const auto kern = w.dbg ? rescore_kernel<true, true> : (sc.fast_log && !keep) ? rescore_kernel<false, false> : rescore_kernel<false, true>;
+    hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
                        (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {

@@ -107,6 +107,13 @@ def load(kind=None):
     lib.orc_db_merge_kept.restype = vp
     lib.orc_db_merge_kept.argtypes = [C.POINTER(vp), C.POINTER(L.c_u8_p), C.c_uint32, C.POINTER(L.SageDbParams)]
     dp = C.POINTER(C.c_double)
+    # f64::ln of the reference: 0 = the platform libm, 1 = correctly rounded through libquadmath (oracle/sage_oracle.cpp: ln).
+    # The checker build compares in mode 1 — the product's contract (sage_amd/csrc/crlog.h), bit for bit; the performance build
+    # that bench.py times as cpu_baseline keeps the platform libm, the reference's arithmetic on this host.
+    lib.orc_set_log_mode.argtypes = [C.c_int]
+    lib.orc_get_log_mode.restype = C.c_int
+    lib.orc_ln_batch.argtypes = [C.c_int, dp, C.c_uint64, dp]
+    lib.orc_set_log_mode(0 if kind == "fast" else 1)
     lib.orc_rescore_mode.argtypes = [C.c_int]
     lib.orc_lda_train.restype = C.c_int
     lib.orc_lda_train.argtypes = [dp, C.c_uint64, C.c_uint64, L.c_u8_p, dp]
@@ -421,3 +428,32 @@ def predict_rt(features, n_files, seq_off, seq, mono):
                           L.as_ptr(mono, C.c_float), *[L.as_ptr(outs[k], C.c_float) for k in names], L.as_ptr(align, C.c_float),
                           fitted.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(r2))
     return dict(outs, alignments=align, fitted=fitted.astype(bool), r2=r2)
+
+
+def log_mode(kind=None):
+    """0: the oracle's ln() is the platform libm's; 1: correctly rounded (libquadmath) — the default of the checker build."""
+    return load(kind).orc_get_log_mode()
+
+
+class LogMode:
+    """with oracle_lib.LogMode(0): ...  — the oracle with the platform libm's ln() (the reference's arithmetic on this host)."""
+
+    def __init__(self, mode, kind=None):
+        self.mode, self.kind = mode, kind
+
+    def __enter__(self):
+        self.prev = log_mode(self.kind)
+        load(self.kind).orc_set_log_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        load(self.kind).orc_set_log_mode(self.prev)
+
+
+def ln_batch(x, mode):
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    load().orc_ln_batch(mode, x.ctypes.data_as(dp), len(x), out.ctypes.data_as(dp))
+    return out

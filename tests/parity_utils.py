@@ -6,21 +6,28 @@ EXACT_FIELDS = ["spec_index", "peptide_idx", "rank", "label", "charge", "matched
                 # f32 values produced by the same IEEE operations in the same order on both sides
                 "expmass", "calcmass", "rt", "ims", "delta_mass", "isotope_error", "average_ppm", "longest_y_pct",
                 "matched_intensity_pct", "ms2_intensity"]
-# f64 values that go through ln(): device libm vs glibc may differ in the last ulp.  The north star's
-# tolerance for hyperscore is 1e-4 relative; we hold the device to 1e-12.
+# f64 values that go through ln().  The product computes a correctly rounded ln (sage_amd/csrc/crlog.h) and the same IEEE f64
+# operations in the same order as the reference around it, so against the oracle in its correctly-rounded mode (libquadmath,
+# oracle_lib's default) these fields are held to EQUALITY.  Against the oracle with the platform libm (oracle_lib.LogMode(0):
+# glibc 2.35 here, 0.52 ulp) the last bit may differ for ~0.01 % of the arguments: REL_TOL, and at least MIN_EQUAL of the values
+# equal.  (The north star's tolerance for hyperscore is 1e-4 relative.)
 REL_FIELDS = ["hyperscore", "delta_next", "delta_best", "poisson"]
-REL_TOL = 1e-12
-# differences of two ~equal hyperscores amplify the ulp error: absolute tolerance on the deltas
-DELTA_ABS = 1e-10
+REL_TOL = 1e-15
+MIN_EQUAL = 0.995
+# differences of two ~equal hyperscores amplify the ulp error: absolute tolerance on the deltas (platform-libm mode only)
+DELTA_ABS = 1e-13
 
 
-def assert_features_equal(gf, gc, of, oc, context="", rel_tol=None):
+def assert_features_equal(gf, gc, of, oc, context="", rel_tol=None, exact_f64=None):
+    import oracle_lib
+    if exact_f64 is None:
+        exact_f64 = rel_tol is None and oracle_lib.log_mode() == 1
     rel = REL_TOL if rel_tol is None else rel_tol
     np.testing.assert_array_equal(gc, oc, err_msg=f"{context}: PSM counts differ")
     n, r = gf.shape
     mask = np.arange(r)[None, :] < gc[:, None]
     g, o = gf[mask], of[mask]
-    for f in EXACT_FIELDS:
+    for f in EXACT_FIELDS + (REL_FIELDS if exact_f64 else []):
         a, b = g[f], o[f]
         if a.dtype.kind == "f":
             same = (a == b) | (np.isnan(a) & np.isnan(b))
@@ -28,9 +35,9 @@ def assert_features_equal(gf, gc, of, oc, context="", rel_tol=None):
             same = a == b
         if not np.all(same):
             bad = np.flatnonzero(~same)[:5]
-            raise AssertionError(f"{context}: field {f} differs at {bad}: gpu={a[bad]} oracle={b[bad]} "
+            raise AssertionError(f"{context}: field {f} differs at {bad}: gpu={a[bad]!r} oracle={b[bad]!r} "
                                  f"(spec {g['spec_index'][bad]})")
-    for f in REL_FIELDS:
+    for f in ([] if exact_f64 else REL_FIELDS):
         a, b = g[f], o[f]
         both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
         tol = rel * np.maximum(np.abs(b), 1.0) + (max(DELTA_ABS, 100 * rel) if f.startswith("delta") else 0.0)
@@ -38,6 +45,9 @@ def assert_features_equal(gf, gc, of, oc, context="", rel_tol=None):
         if not np.all(ok):
             bad = np.flatnonzero(~ok)[:5]
             raise AssertionError(f"{context}: field {f} differs at {bad}: gpu={a[bad]} oracle={b[bad]}")
+        if rel_tol is None and len(a) >= 1000:
+            frac = float(np.mean((a == b) | both_inf))
+            assert frac >= MIN_EQUAL, f"{context}: field {f}: only {frac:.4f} of the values equal the platform libm's"
     return int(mask.sum())
 
 

@@ -28,8 +28,9 @@ class World:
         self.batch = SpectrumBatch.from_spectra([sp.process(r) for r in raw])
 
     def check(self, params, context, hits=True, batch=None, every=1, dev=None):
-        # OpenMSHyperScore goes through f32 ln_1p: device libm and glibc may differ by an f32 ulp (~6e-8
-        # relative); SageHyperScore only uses f64 ln and is held to 1e-12.  North-star tolerance: 1e-4.
+        # OpenMSHyperScore goes through f32 ln_1p: device libm and glibc may differ by an f32 ulp (~6e-8 relative).
+        # SageHyperScore uses f64 ln only — correctly rounded on both sides: the f64 fields are held to EQUALITY
+        # (parity_utils.assert_features_equal).  North-star tolerance: 1e-4.
         rel_tol = 1e-6 if params.score_type == "OpenMSHyperScore" else None
         batch = batch or self.batch
         scorer = Scorer(dev or self.dev, params)
@@ -67,6 +68,22 @@ def test_c1_known_answer_on_gpu(gpu_required):
     of, oc, _, _ = orc.score(params, batch)
     assert_features_equal(feats, counts, of, oc, "C1")
     assert_initial_hits_equal(scorer, scorer.upload(batch), orc, params, batch, "C1")
+
+
+def test_hyperscores_against_the_platform_libm(small_world):
+    """The product's ln is correctly rounded (crlog.h); every other parity test compares with the oracle in its correctly rounded
+    mode, bit for bit.  Here the oracle calls the platform libm instead — what the reference itself does on this host (glibc 2.35:
+    0.52 ulp): the f64 fields agree within an ulp or two and the overwhelming majority are equal (parity_utils.MIN_EQUAL)."""
+    w = small_world
+    params = ScorerParams(report_psms=5, min_matched_peaks=1, precursor_tol=Tolerance("da", -3.0, 3.0))
+    scorer = Scorer(w.dev, params)
+    gf, gc = scorer.score_resident(scorer.upload(w.batch))
+    with oracle_lib.LogMode(0):
+        of, oc, _, _ = w.orc.score(params, w.batch)
+        n = assert_features_equal(gf, gc, of, oc, "platform libm")
+    assert n > 1000
+    of1, oc1, _, _ = w.orc.score(params, w.batch)
+    assert_features_equal(gf, gc, of1, oc1, "correctly rounded")
 
 
 def test_narrow_search_known_charge(small_world):
@@ -127,12 +144,14 @@ def test_report_psms_beyond_a_wavefront(small_world, monkeypatch):
     assert n > b.n * 35
     n, t = w.check(ScorerParams(report_psms=100, precursor_tol=wide, min_matched_peaks=1), "report_psms=100 (k=200), +-20 Da")
     assert n > b.n * 40
-    # (min_matched_peaks = 2 here: with 1, a spectrum of this case holds candidates that match the same single peak as a b- and as
-    # a y-ion — hyperscores ln(i) + lnfact(1) + lnfact(0) and ln(i) + lnfact(0) + lnfact(1), scoring.rs:163-201 — which glibc's
-    # log rounds to one double and the device's to two neighbours: the 1e-12 of the north star, but a different order)
-    n, t = w.check(ScorerParams(report_psms=128, precursor_tol=Tolerance("da", -60.0, 60.0), min_matched_peaks=2,
+    # (min_matched_peaks = 1: a spectrum of this case holds candidates that match the same single peak as a b- and as a y-ion —
+    # hyperscores ln(i) + lnfact(1) + lnfact(0) and ln(i) + lnfact(0) + lnfact(1), scoring.rs:163-201, two DIFFERENT sums that land
+    # on one double or on two neighbours depending on the last bit of ln(i).  Round 3's device ln (ocml) differed from the host's
+    # there and ordered such pairs differently among the 128 reported PSMs; with the correctly rounded ln on both sides
+    # (crlog.h / the oracle's libquadmath mode) hyperscores and order are equal.)
+    n, t = w.check(ScorerParams(report_psms=128, precursor_tol=Tolerance("da", -60.0, 60.0), min_matched_peaks=1,
                                 fragment_tol=Tolerance("da", -0.3, 0.3)),
-                   "report_psms=128 (k=256), +-60 Da", batch=b.subset(np.arange(0, b.n, 2)))
+                   "report_psms=128 (k=256), +-60 Da, min_matched_peaks=1", batch=b.subset(np.arange(0, b.n, 2)))
     assert n > (b.n // 2) * 64  # (on average more PSMs per spectrum than a wavefront has lanes)
     w.check(ScorerParams(report_psms=40), "report_psms=40, +-10 ppm (windows shorter than k)")
     unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current,
