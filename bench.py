@@ -11,9 +11,11 @@ rescoring + Feature assembly + the exact retry pass over tied spectra, PSM recor
 (sage_hip_score_resident: the rescoring kernels store them there themselves; one host synchronisation per step).
 
 Multi-GPU (one process per GPU, index replicated, no collective on the data path):
-  --scaling strong (default): THE workload (all 500 000 spectra of C3) is cut into contiguous work-balanced shards
-      (sage_amd.sharding.plan_shards), rank r scores shard r; N = 1 scores all of it.  After the timed region the ranks'
-      records are gathered in input order and rank 0 checks them against its own single-GPU pass over the whole workload.
+  --scaling strong (default): THE workload (all 500 000 spectra of C3) is cut into N contiguous shards of equal spectrum counts
+      (whole 4096-spectrum chunks of the synthetic run, which every rank generates for itself: the run is shuffled, so equal
+      counts are equal work; a real run is cut by sage_amd.sharding.plan_shards with estimate_work's weights — cli.py), rank r
+      scores shard r; N = 1 scores all of it.  After the timed region the ranks' records are gathered in input order and
+      rank 0 generates the whole run and checks the gathered result against its own single-GPU pass over it.
   --scaling weak: every rank scores its own full-size copy of the workload (different seeds).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scaling strong|weak]
@@ -145,18 +147,51 @@ def _gen_chunk(c):
     return c, b, g
 
 
-def generate_workload(cfg, host, total, seed_shift=0, workers=None):
-    """All `total` spectra of the configuration's synthetic run, preprocessed (workloads.processed_spectra), as ONE
-    SpectrumBatch + the global index of every kept spectrum.  Chunks are generated by forked workers (the host database is
-    shared copy-on-write); chunk c depends only on (seed, c), so the result does not depend on the worker count."""
+_BATCH_FIELDS = ("peak_off", "masses", "intensities", "precursor_mz", "precursor_charge", "total_ion_current", "isolation_lo",
+                 "isolation_hi", "scan_start_time", "inverse_ion_mobility", "file_id")
+
+
+def save_batch(path, batch):
+    import numpy as np
+    np.savez(path, **{k: getattr(batch, k) for k in _BATCH_FIELDS if getattr(batch, k) is not None})
+
+
+def load_batch(path):
+    import numpy as np
+
+    from sage_amd.api import SpectrumBatch
+    z = np.load(path)
+    return SpectrumBatch(*[z[k] if k in z.files else None for k in _BATCH_FIELDS])
+
+
+def _whole_run_worker(conn, cfg, host, total, seed_shift, workers, path):
+    """Forked by rank 0 of a strong-scaling run BEFORE it touches the GPU (a process that holds a HIP context must not fork):
+    sleeps until the timed region is over, then generates the whole run for the single-GPU check and leaves it in `path`."""
+    try:
+        if conn.recv() != "go":
+            return
+        batch, _ = generate_workload(cfg, host, total, seed_shift, workers)
+        save_batch(path, batch)
+        conn.send("ok")
+    except BaseException as e:  # noqa: BLE001
+        conn.send(f"error: {e!r}")
+
+
+def generate_workload(cfg, host, total, seed_shift=0, workers=None, chunks=None):
+    """The `total` spectra of the configuration's synthetic run — or, with `chunks` = (c0, c1), only its chunks [c0, c1) of
+    SPECTRA_CHUNK spectra each — preprocessed (workloads.processed_spectra), as ONE SpectrumBatch + the global index of every
+    kept spectrum.  Chunks are generated by forked workers (the host database is shared copy-on-write); chunk c depends only
+    on (seed, c), so the result depends neither on the worker count nor on which rank generates it."""
     import multiprocessing as mp
 
     import numpy as np
 
     from sage_amd.api import SpectrumBatch
-    n_chunks = (total + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK
+    n_all = (total + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK
+    c0, c1 = chunks if chunks is not None else (0, n_all)
+    n_chunks = max(c1 - c0, 0)
     _gen_state.update(cfg=cfg, host=host, total=total, seed_shift=seed_shift)
-    workers = workers or min(32, os.cpu_count() or 1, n_chunks)
+    workers = workers or min(32, os.cpu_count() or 1, max(n_chunks, 1))
     _gen_chunk_warm = workload_batch(dict(cfg, spectra_seed=cfg["spectra_seed"] + seed_shift), host, 0, 1, total)  # per-database caches, before the fork
     del _gen_chunk_warm
     parts = None
@@ -166,7 +201,7 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None):
             # handler inherited through the fork (rocprofv3 --pmc) turns into a hang
             pool = mp.get_context("fork").Pool(workers)
             try:
-                parts = pool.map(_gen_chunk, range(n_chunks), chunksize=1)
+                parts = pool.map(_gen_chunk, range(c0, c1), chunksize=1)
             finally:
                 pool.close()
                 pool.join()
@@ -174,7 +209,9 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None):
             print(f"bench.py: parallel workload generation failed ({e!r}); generating serially", file=sys.stderr)
             parts = None
     if parts is None:
-        parts = [_gen_chunk(c) for c in range(n_chunks)]
+        parts = [_gen_chunk(c) for c in range(c0, c1)]
+    if not parts:
+        return workload_batch(cfg, host, 0, 0, total)
     parts.sort(key=lambda p: p[0])
     bs = [p[1] for p in parts]
     off = np.zeros(sum(b.n for b in bs) + 1, dtype=np.uint64)
@@ -321,15 +358,31 @@ def main():
     t_db = time.time() - t0
     t0 = time.time()
     seed_shift = rank if args.scaling == "weak" else 0
-    batch_all, gidx = generate_workload(cfg, host, total, seed_shift)
-    t_spec = time.time() - t0
-    from sage_amd.sharding import plan_shards
-    if args.scaling == "strong":
-        shards = plan_shards(batch_all.peak_off, world)
-        lo, hi = shards[rank]
-        batch = batch_all if world == 1 else batch_all.subset(np.arange(lo, hi))
+    gen_workers = max(1, min(32, int(host_cpu_budget()[0]) // world))  # (the ranks of a node share its CPUs)
+    batch_all = None
+    if args.scaling == "strong" and world > 1:
+        # Every rank generates ITS shard only: the run is a sequence of independent chunks of SPECTRA_CHUNK spectra, cut into
+        # `world` contiguous runs of chunks of (as near as possible) equal spectrum counts.  The synthetic run is shuffled, so
+        # equal counts are equal work to ~0.5 % (sharding.plan_shards with sharding.estimate_work's weights is what a real,
+        # retention-time-ordered run needs: sage_amd/cli.py).  Rank 0 generates the whole run AFTER the timed region, for the
+        # check of the gathered result against a single-GPU pass.
+        n_chunks_all = (total + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK
+        my_chunks = (n_chunks_all * rank // world, n_chunks_all * (rank + 1) // world)
+        batch, gidx = generate_workload(cfg, host, total, seed_shift, gen_workers, chunks=my_chunks)
+        shards, lo, hi = None, None, None  # (positions in the whole run: known after the ranks have exchanged their counts)
+        whole_run = None
+        if rank == 0:
+            import multiprocessing as mp
+            ctx = mp.get_context("fork")
+            whole_conn, child_conn = ctx.Pipe()
+            whole_path = os.path.join(tempfile.gettempdir(), f"sage_bench_whole_run_{os.getpid()}.npz")
+            whole_run = ctx.Process(target=_whole_run_worker, daemon=True,
+                                    args=(child_conn, cfg, host, total, seed_shift, max(1, int(host_cpu_budget()[0])), whole_path))
+            whole_run.start()
     else:
+        batch_all, gidx = generate_workload(cfg, host, total, seed_shift, gen_workers)
         shards, lo, hi, batch = None, 0, batch_all.n, batch_all
+    t_spec = time.time() - t0
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libsage_hip has no CPU fallback)")
@@ -456,9 +509,22 @@ def main():
     if world > 1 and args.scaling == "strong":
         from sage_amd.sharding import gather_features
         t0 = time.perf_counter()
+        sizes = [None] * world
+        dist.all_gather_object(sizes, int(batch.n))
+        lo = int(sum(sizes[:rank]))
+        hi = lo + int(batch.n)
+        shards = [(int(sum(sizes[:r])), int(sum(sizes[:r + 1]))) for r in range(world)]
         gf, gc = gather_features(feats, counts, lo)  # host-side, input order, spec_index rebased
         t_gather = time.perf_counter() - t0
         if rank == 0:
+            whole_conn.send("go")
+            msg = whole_conn.recv()
+            whole_run.join(timeout=60)
+            if msg != "ok":
+                raise SystemExit(f"bench.py: generating the whole run for the single-GPU check failed: {msg}")
+            batch_all = load_batch(whole_path)
+            os.unlink(whole_path)
+            assert batch_all.n == shards[-1][1], (batch_all.n, shards)
             ref_scorer = Scorer(dev, params)
             rf, rc = ref_scorer.score(batch_all)  # the N = 1 result, through the streaming entry point
             same = same_psms(gf, gc, rf, rc)

@@ -1,5 +1,9 @@
-// detmath_oracle.h — the CHECKER's copy of the arithmetic contract of the post-search rescoring (the product's is
-// sage_amd/csrc/detmath.h; oracle/selftest.cpp holds the two to each other bit for bit and to the platform libm within 1 ulp).
+// detmath_oracle.h — a COPY of sage_amd/csrc/detmath.h (the arithmetic contract of the post-search rescoring) with the namespace
+// and include guard renamed, so that the checker does not include product headers; oracle/selftest.cpp holds the two to each
+// other bit for bit and to the platform libm within 1 ulp.  It is not an independent implementation: comparing the device with
+// the oracle's `det` mode proves that the device evaluates the stated contract; the independent check of the contract itself is
+// the oracle's other mode (platform libm, every sum sequential — the reference's own arithmetic), against which the device's
+// coefficients, discriminants, posterior errors and q-values are compared in tests/test_gpu_rescore.py.
 // Test infrastructure: nothing under sage_amd/ includes this file.
 //
 // Why this exists.  Sage's LDA fit (crates/sage/src/ml/linear_discriminant.rs:57-127) ends in a Gauss-Jordan elimination whose

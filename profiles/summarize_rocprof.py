@@ -29,14 +29,16 @@ def main():
     for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
         out.append(f"  {k:<40} {v:8.3f}\n")
     try:
-        out.append("\n# per-dispatch resources\n")
-        q = ("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, sgpr_count, count(*) "
-             "from kernels group by name, grid_x, workgroup_x, lds_size")
+        # Launch geometry only.  rocprofv3's scratch_size / vgpr_count / sgpr_count columns are allocation granules of the dispatch
+        # packet (round 3's summaries printed `scratch=1024 vgpr=48 sgpr=112` for every narrow kernel), not the kernel's registers
+        # and spills: those are in the compiler's own table, profiles/<tag>_kernel_resources.txt (scripts/kernel_resources.py).
+        out.append("\n# per-dispatch launch geometry (registers / spills / scratch: the compiler's table, profiles/%s_kernel_resources.txt)\n" % tag)
+        q = ("select name, grid_x, workgroup_x, lds_size, count(*) from kernels group by name, grid_x, workgroup_x, lds_size")
         for r in con.execute(q):
             if short(r[0]).startswith(("prelim_", "tile_", "rescore", "narrow_", "search_")):
-                out.append(f"  {short(r[0]):<40} grid={r[1]} wg={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]} n={r[7]}\n")
+                out.append(f"  {short(r[0]):<40} grid={r[1]} wg={r[2]} dynamic_lds={r[3]} n={r[4]}\n")
     except sqlite3.Error as e:
-        out.append(f"(resource query failed: {e})\n")
+        out.append(f"(geometry query failed: {e})\n")
     if bench:
         try:
             j = json.loads([ln for ln in open(bench) if ln.startswith("{")][-1])

@@ -132,15 +132,21 @@ def parse_devices(spec, n_visible: int):
     return out
 
 
-def search_file(workers, processor, raw, sp, host_preprocess, annotate):
+def search_file(workers, processor, raw, sp, host_preprocess, annotate, pep_mono=None):
     """Scorer::score over every MS2 spectrum of one file (runner.rs:311-325), on all the workers' devices at once: the file's
     spectra are cut into contiguous work-balanced shards (sharding.plan_shards: index replicated, no exchange between
     devices), one host thread per device preprocesses, scores and — if asked — annotates its shard, and the shards' results
     are concatenated in input order, as `collect()` does.  Returns (features[n, report], counts[n], ids, annotation | None)."""
     import threading
 
-    from .sharding import plan_shards
-    shards = plan_shards(raw.peak_off, len(workers)) if len(workers) > 1 else [(0, raw.n)]
+    from .sharding import estimate_work, plan_shards
+    shards = [(0, raw.n)]
+    if len(workers) > 1:
+        # work per spectrum ~ peaks x queries x candidates in the precursor window (precursor mass drifts with retention time, and
+        # in an open search the window size spans orders of magnitude): sharding.estimate_work
+        weights = None if pep_mono is None else estimate_work(raw.peak_off, raw.precursor_mz, raw.precursor_charge, scorer_params(sp), pep_mono,
+                                                              raw.isolation_lo, raw.isolation_hi)
+        shards = plan_shards(raw.peak_off, len(workers), weights)
     results = [None] * len(workers)
     stage_ms = [(0.0, 0.0, 0.0)] * len(workers)  # per worker: preprocess + upload, score, annotate
     errors = []
@@ -268,7 +274,7 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
         if raw.n == 0:
             continue
         t0 = time.time()
-        found = search_file(workers, processor, raw, sp, host_preprocess, sp["annotate_matches"])
+        found = search_file(workers, processor, raw, sp, host_preprocess, sp["annotate_matches"], host.pep_mono)
         if found is None:
             continue
         feats, counts, ids, ann = found

@@ -137,7 +137,8 @@ struct WorkSet {
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
     DevBuf<uint32_t> arena;
-    uint32_t cap_n = 0;
+    uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
+    uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
 };
 
 // What a batch leaves behind: PSM records, counters, timing events.  Double-buffered by the streaming pipeline (batch c + 1 is
@@ -881,6 +882,23 @@ static uint32_t batch_fzcap(const SageScorerParams& p, uint32_t zmax, bool any_u
     return fzcap;
 }
 
+// Score.matched_b / matched_y are u16 in the reference (scoring.rs:21-22) and the rescoring kernel keeps the pair packed in one
+// register (core.h: the `mm` counter): a peptide / charge combination that could match more than 65535 ions of one side would
+// carry from one half into the other where the reference's release build wraps a u16 (and its debug build panics).  Refuse it:
+// n-terminal resp. c-terminal ion kinds x ions per kind x fragment charges of the batch.
+static int check_match_counters(const SageScorer* s, uint32_t fzcap) {
+    const DevDbView& db = s->db->view;
+    uint32_t nterm = 0;
+    for (uint32_t k = 0; k < db.n_kinds; k++) nterm += db.ion_kinds[k] <= 2 ? 1u : 0u;
+    const uint64_t per_kind = db.n_kinds ? s->db->max_ions / db.n_kinds : 0;  // (max_ions: ions of the longest peptide, all kinds)
+    const uint64_t worst = std::max<uint64_t>(nterm, db.n_kinds - nterm) * per_kind * fzcap;
+    if (worst > 65535)
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "a candidate could match " + std::to_string(worst) + " ions of one terminus (" +
+                                                  std::to_string(per_kind) + " ions per kind x fragment charges up to " + std::to_string(fzcap) +
+                                                  "): beyond the u16 match counters of Score (scoring.rs:21-22)");
+    return SAGE_HIP_OK;
+}
+
 // Spectra [c0, c1) of a host batch -> the device arrays of `d`, asynchronously on `up`:
 //   * the per-spectrum arrays (40 bytes per spectrum) are staged through d's page-locked block (peak offsets rebased to the
 //     range, the launch limits pcap / fzcap found on the way);
@@ -989,7 +1007,7 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     v.probe = probe;
     v.pcap = pcap;
     v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
-    return SAGE_HIP_OK;
+    return check_match_counters(s, v.fzcap);
 }
 
 static int check_batch_args(const SageSpectrumBatch* b) {
@@ -1047,9 +1065,8 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
             if (raw->peak_off[i + 1] - raw->peak_off[i] > PROCESS_LDS_PEAKS) big.push_back(i);
         rcap = PROCESS_LDS_PEAKS;
     }
-    uint32_t rpow2 = 1, big_pow2 = 1;
+    uint32_t rpow2 = 1;
     while (rpow2 < rcap) rpow2 <<= 1;
-    while (big_pow2 < big_cap) big_pow2 <<= 1;
     HIP_TRY((hipError_t)process_kernel_prepare(160 * 1024));
     const uint32_t stride = (uint32_t)std::min<uint64_t>(take_top_n, big_cap);
     DevBuf<uint64_t> raw_off;
@@ -1070,11 +1087,53 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     DevBuf<uint32_t> big_list;
     DevBuf<unsigned char> big_ws;
     if (!big.empty()) {
+        // Groups of similar size, each with slices sized for ITS largest spectrum, launched one after the other over one
+        // workspace of bounded size (stream order makes the reuse safe): a batch with one 50 000-peak outlier among thousands of
+        // 3 000-peak spectra must not ask for (number of big spectra) x (the outlier's slice).
+        std::sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) {
+            const uint64_t na = raw->peak_off[a + 1] - raw->peak_off[a], nb = raw->peak_off[b + 1] - raw->peak_off[b];
+            return na != nb ? na < nb : a < b;
+        });
+        auto slice_of = [&](uint32_t spec, uint32_t* cap_out, uint32_t* pow2_out) {
+            const uint32_t cap = (uint32_t)(raw->peak_off[spec + 1] - raw->peak_off[spec]);
+            uint32_t p2 = 1;
+            while (p2 < cap) p2 <<= 1;
+            if (cap_out) *cap_out = cap;
+            if (pow2_out) *pow2_out = p2;
+            return process_lds_bytes(cap, p2);
+        };
+        const size_t budget = (size_t)1 << 30;  // bytes of workspace per launch (a single larger spectrum still gets its slice)
+        struct Group { size_t first, count; uint32_t cap, pow2; size_t slice; };
+        std::vector<Group> groups;
+        for (size_t i = 0; i < big.size();) {
+            // grow the group while (members) x (slice of the candidate member, the largest so far) fits the budget
+            size_t j = i;
+            uint32_t cap = 0, p2 = 0;
+            size_t slice = 0;
+            while (j < big.size()) {
+                uint32_t c, q;
+                const size_t sl = slice_of(big[j], &c, &q);
+                if (j > i && (j - i + 1) * sl > budget) break;
+                cap = c; p2 = q; slice = sl;
+                j++;
+            }
+            groups.push_back(Group{i, j - i, cap, p2, slice});
+            i = j;
+        }
+        size_t ws_bytes = 0;
+        for (const Group& g : groups) ws_bytes = std::max(ws_bytes, g.count * g.slice);
         HIP_TRY(big_list.upload(big.data(), big.size()));
-        HIP_TRY(big_ws.alloc(big.size() * process_lds_bytes(big_cap, big_pow2)));
-        launch_process_big((uint32_t)big.size(), big_list.p, big_ws.p, raw_off.p, raw_mz.p, raw_int.p, zbuf.p, (uint32_t)take_top_n,
-                           deisotope != 0, min_deisotope_mz, big_cap, big_pow2, stride, sm.p, si.p, d->tic.p, cnt.p, s->stream);
-        HIP_TRY(hipGetLastError());
+        if (hipError_t e = big_ws.alloc(ws_bytes); e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP,
+                        "preprocessing workspace of " + std::to_string(ws_bytes >> 20) + " MiB for a spectrum of " + std::to_string(big_cap) +
+                            " raw peaks: " + hipGetErrorString(e) + " (sage_hip_process_ms2 preprocesses a spectrum on the host)");
+        }
+        for (const Group& g : groups) {
+            launch_process_big((uint32_t)g.count, big_list.p + g.first, big_ws.p, raw_off.p, raw_mz.p, raw_int.p, zbuf.p, (uint32_t)take_top_n,
+                               deisotope != 0, min_deisotope_mz, g.cap, g.pow2, stride, sm.p, si.p, d->tic.p, cnt.p, s->stream);
+            HIP_TRY(hipGetLastError());
+        }
     }
     std::vector<uint32_t> counts(n);
     HIP_TRY(hipMemcpyAsync(counts.data(), cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
@@ -1136,6 +1195,7 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     d->maybe_wide = est.maybe_wide;
     v.pcap = pcap;
     v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
+    if (int rc = check_match_counters(s, v.fzcap); rc != SAGE_HIP_OK) return rc;
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -1168,30 +1228,41 @@ static uint64_t arena_entries_for(const SageScorer* s, uint32_t n) {
     return e;
 }
 
-static int ensure_work(SageScorer* s, uint32_t n, int lane = 0) {
+// The device working set of a launch of n spectra.  `lane`: which of the scorer's two sets (the streaming pipeline's second compute
+// lane never takes the large-window path, so it never owns that path's buffers — the candidate arena alone is 64 KiB per
+// spectrum).  `wide`: the large-window kernels will be launched (lane 0 only).  `st`: the stream the kernels will run on.
+static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream_t st) {
     WorkSet& w = lane ? s->ws2 : s->ws;
-    for (OutSet& o : s->outs) {
-        HIP_TRY(o.features.reserve((size_t)n * s->params.report_psms));
-        HIP_TRY(o.out_count.reserve(n));
+    if (n > w.cap_n) {
+        HIP_TRY(w.cand.reserve((size_t)n * s->dev.kmax));
+        HIP_TRY(w.cand_len.reserve(n));
+        HIP_TRY(w.totals.reserve((size_t)n * 2));
+        HIP_TRY(w.status.reserve(n));
+        HIP_TRY(w.queue.reserve(n));
+        HIP_TRY(w.retry.reserve(n));
+        HIP_TRY(w.item_of.reserve(n));
+        HIP_TRY(w.ready.reserve(n));
+        // (no launch has the epoch 0.  On the stream of the kernels that read it: the scorer's streams do not synchronise with
+        // the null stream, and a plain hipMemset could land after a producer's epoch store)
+        HIP_TRY(hipMemsetAsync(w.ready.p, 0, (size_t)w.ready.n * 4, st));
+        w.epoch = 0;
+        w.cap_n = n;
     }
-    if (n <= w.cap_n) return SAGE_HIP_OK;
-    HIP_TRY(w.cand.reserve((size_t)n * s->dev.kmax));
-    HIP_TRY(w.cand_len.reserve(n));
-    HIP_TRY(w.totals.reserve((size_t)n * 2));
-    HIP_TRY(w.status.reserve(n));
-    HIP_TRY(w.queue.reserve(n));
-    HIP_TRY(w.retry.reserve(n));
-    HIP_TRY(w.item_of.reserve(n));
-    HIP_TRY(w.ready.reserve(n));
-    HIP_TRY(hipMemset(w.ready.p, 0, (size_t)w.ready.n * 4));  // (no launch has the epoch 0)
-    w.epoch = 0;
-    // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
-    HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
-    HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * s->kstride));
-    HIP_TRY(w.qres.reserve((size_t)n * s->qmax * s->kstride));
-    const uint64_t arena_entries = arena_entries_for(s, n);
-    if (arena_entries > w.arena.n) HIP_TRY(w.arena.alloc(arena_entries));
-    w.cap_n = n;
+    if (wide && lane == 0 && n > w.cap_wide) {
+        // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
+        HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
+        HIP_TRY(w.seeds.reserve((size_t)n * s->qmax * s->kstride));
+        HIP_TRY(w.qres.reserve((size_t)n * s->qmax * s->kstride));
+        const uint64_t arena_entries = arena_entries_for(s, n);
+        if (arena_entries > w.arena.n) HIP_TRY(w.arena.alloc(arena_entries));
+        w.cap_wide = n;
+    }
+    return SAGE_HIP_OK;
+}
+// PSM counts always; a device-side record buffer only when the records do not go straight to the caller's page-locked array
+static int ensure_out(SageScorer* s, OutSet& o, uint32_t n, bool need_features) {
+    HIP_TRY(o.out_count.reserve(n));
+    if (need_features) HIP_TRY(o.features.reserve((size_t)n * s->params.report_psms));
     return SAGE_HIP_OK;
 }
 
@@ -1249,14 +1320,16 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
                            int lane = 0) {
     if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
     WorkSet& wset = lane ? s->ws2 : s->ws;
-    int rc = ensure_work(s, view.n, lane);
-    if (rc != SAGE_HIP_OK) return rc;
-    if (!rec) rec = o.features.p;
-    if (!count_buf) count_buf = o.out_count.p;
     DevScorer sc = s->dev;
     const bool production = mode == MODE_SCORE && with_rescore;
     const bool fused = s->fused && production;
     if (!production) wide = true;
+    int rc = ensure_work(s, view.n, lane, wide, st);
+    if (rc != SAGE_HIP_OK) return rc;
+    rc = ensure_out(s, o, view.n, rec == nullptr);
+    if (rc != SAGE_HIP_OK) return rc;
+    if (!rec) rec = o.features.p;
+    if (!count_buf) count_buf = o.out_count.p;
     const bool one_launch = production && !fused && s->one_launch;
     const size_t lds_p = std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
                  lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
@@ -1391,7 +1464,11 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         // -6 %); one part above (125 000: -1 %), where the kernels' durations are what the roofline is held against.
         const uint32_t want = s->ways ? s->ways : (b->n <= 98304u ? 2u : 1u);
         const uint32_t ways = (!b->maybe_wide && !s->exact_always && b->n >= 8192u * want) ? want : 1u;
-        int rc = ensure_work(s, b->n);
+        // (sized for the whole batch: the parts of a step index the working set by spectrum and share outs[0]'s count buffer and,
+        // if any, its record buffer)
+        int rc = ensure_work(s, b->n, 0, b->maybe_wide || s->exact_always, s->stream);
+        if (rc != SAGE_HIP_OK) return rc;
+        rc = ensure_out(s, o, b->n, direct == nullptr);
         if (rc != SAGE_HIP_OK) return rc;
         SageFeature* const rec = direct ? direct : o.features.p;
         HIP_TRY(hipEventRecord(s->way_begin.e, s->stream));

@@ -416,7 +416,6 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
         zs.avail_in = (uInt)std::min<size_t>(text.size(), 0xFFFFFFFFu);
         size_t consumed_in = zs.avail_in, have = 0;
         int rc = Z_OK;
-        bool member_done = false;  // at least one complete gzip member has been inflated
         for (;;) {
             if (have == plain_text.size()) plain_text.resize(plain_text.size() * 2);
             zs.next_out = (Bytef*)&plain_text[have];
@@ -425,17 +424,18 @@ bool read_mzml(const char* path, uint32_t file_id, int ms_level, MzmlRun& run, s
             rc = inflate(&zs, Z_NO_FLUSH);
             have += room - zs.avail_out;
             if (rc == Z_STREAM_END) {
-                member_done = true;
                 if (zs.avail_in == 0 && consumed_in == text.size()) break;
-                if (inflateReset(&zs) != Z_OK) break;  // (concatenated gzip members)
                 if (zs.avail_in == 0) break;
-                continue;
+                // More input behind a complete member.  Another gzip member (1f 8b: concatenated members, `cat a.gz b.gz`) is
+                // inflated like the first, and damage inside it is an error; anything else (zero padding, a signature block)
+                // cannot be a member and ends the input.
+                if (zs.avail_in >= 2 && zs.next_in[0] == 0x1f && zs.next_in[1] == 0x8b) {
+                    if (inflateReset(&zs) != Z_OK) { rc = Z_DATA_ERROR; break; }
+                    continue;
+                }
+                break;  // (rc == Z_STREAM_END: trailing bytes ignored)
             }
-            if (rc != Z_OK) {
-                // bytes behind the last complete member that are no gzip member (padding, a signature block): the end of the input
-                if (member_done && zs.total_out == 0 && (rc == Z_DATA_ERROR || rc == Z_BUF_ERROR)) rc = Z_STREAM_END;
-                break;
-            }
+            if (rc != Z_OK) break;  // a damaged member — also a second or later one: the spectrum list would be silently truncated
             if (zs.avail_in == 0 && consumed_in < text.size()) {  // (inputs above 4 GiB: feed the next piece)
                 const size_t more = std::min<size_t>(text.size() - consumed_in, 0xFFFFFFFFu);
                 zs.next_in = (Bytef*)text.data() + consumed_in;

@@ -7,13 +7,71 @@ PSM records in input order — the reference's `collect()` preserves input order
 import numpy as np
 
 
-def plan_shards(peak_off: np.ndarray, world: int):
-    """Contiguous, work-balanced shards: split the spectrum list where the cumulative peak count crosses
-    k/world of the total (work per spectrum ~ number of peaks x queries).  Returns [(begin, end)] * world."""
+PROTON = np.float32(1.0072764)
+NEUTRON = np.float32(1.00335)
+
+
+def estimate_work(peak_off, precursor_mz, precursor_charge, params, pep_mono, isolation_lo=None, isolation_hi=None):
+    """Per-spectrum work estimate  P x sum over queries of (W + W0)  (peaks x queries x window size):
+    P = peaks, one query per (precursor charge, isotope error) the scorer will evaluate (scoring.rs:384-462), W = candidates in
+    the query's precursor window — two binary searches over the mass-sorted peptide list per query, IndexedDatabase::query's own
+    lookup (database.rs:402-425) — and W0 = 64 for the per-query cost that does not depend on the window.  On a real run precursor
+    mass, hence W, drifts with retention time, so contiguous shards of equal peak counts are not shards of equal work; in an open
+    search W spans orders of magnitude.  float64 arithmetic: an estimate, not the kernels' window."""
+    pep_mono = np.asarray(pep_mono, dtype=np.float64)
+    n = len(peak_off) - 1
+    peaks = np.diff(np.asarray(peak_off).astype(np.int64)).astype(np.float64)
+    mz = np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)
+    z_in = np.asarray(precursor_charge).astype(np.int64)
+    ranged = params.wide_window or params.override_precursor_charge
+    isos = range(params.min_isotope_err, params.max_isotope_err + 1)
+    work = np.zeros(n)
+    for z in range(1, 256):
+        use = (z_in == z) & (not ranged)
+        if params.min_precursor_charge <= z <= params.max_precursor_charge:
+            use = use | (z_in == 0) | ranged
+        if not np.any(use):
+            continue
+        mass = mz[use] * z
+        if params.wide_window:  # the isolation window scaled by the charge (scoring.rs:437-441), +-2.4 Th when absent
+            lo_t = np.full(mass.shape, -2.4) if isolation_lo is None else np.where(np.isnan(isolation_lo[use]), -2.4, isolation_lo[use])
+            hi_t = np.full(mass.shape, 2.4) if isolation_hi is None else np.where(np.isnan(isolation_hi[use]), 2.4, isolation_hi[use])
+            lo_of = lambda c: c + lo_t * z  # noqa: E731
+            hi_of = lambda c: c + hi_t * z  # noqa: E731
+        else:
+            t = params.precursor_tol
+            if t.kind == "ppm":
+                lo_of = lambda c: c * (1.0 + t.lo * 1e-6)  # noqa: E731
+                hi_of = lambda c: c * (1.0 + t.hi * 1e-6)  # noqa: E731
+            elif t.kind == "pct":
+                lo_of = lambda c: c * (1.0 + t.lo * 1e-2)  # noqa: E731
+                hi_of = lambda c: c * (1.0 + t.hi * 1e-2)  # noqa: E731
+            else:
+                lo_of = lambda c: c + t.lo  # noqa: E731
+                hi_of = lambda c: c + t.hi  # noqa: E731
+        acc = np.zeros(mass.shape)
+        for iso in isos:
+            c = mass - iso * float(NEUTRON)
+            w = np.searchsorted(pep_mono, hi_of(c), side="right") - np.searchsorted(pep_mono, lo_of(c), side="left")
+            acc += np.maximum(w, 0) + 64.0
+        work[use] += acc
+    return (peaks + 1.0) * np.maximum(work, 64.0)
+
+
+def plan_shards(peak_off: np.ndarray, world: int, weights=None):
+    """Contiguous, work-balanced shards: split the spectrum list where the cumulative work crosses k/world of the total.
+    `weights`: per-spectrum work (estimate_work: peaks x queries x candidates in the precursor window); without it the peak
+    count + 1 stands in (enough for a shuffled narrow search, where every window holds about as many candidates).
+    Returns [(begin, end)] * world."""
     n = len(peak_off) - 1
     if world <= 1 or n == 0:
         return [(0, n)] + [(n, n)] * (max(world, 1) - 1)
-    cum = peak_off[1:].astype(np.float64) + np.arange(1, n + 1)  # +1 per spectrum: empty spectra still cost a launch slot
+    if weights is None:
+        cum = peak_off[1:].astype(np.float64) + np.arange(1, n + 1)  # +1 per spectrum: empty spectra still cost a launch slot
+    else:
+        w = np.asarray(weights, dtype=np.float64)
+        assert len(w) == n and np.all(w >= 0)
+        cum = np.cumsum(np.maximum(w, 1e-9))
     total = cum[-1]
     cuts = [0]
     for k in range(1, world):

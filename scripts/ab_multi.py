@@ -1,0 +1,112 @@
+"""GPU A/B of library builds x environment settings x batch sizes in ONE gpurun call (not a pytest).
+
+    python scripts/ab_multi.py C3 --sizes 62500,500000 --steps 30 -- base "" "newfilter" "newfilter:SAGE_HIP_WAYS=1"
+
+Each variant is `<lib>[:ENV=V,ENV=V]`; lib `base` (or empty) = sage_amd/libsage_hip.so, else sage_amd/libsage_hip_<lib>.so
+(scripts/variants.sh builds those).  The workload is generated once and handed to one child process per variant through an
+.npz file (a process can load only one build of the library).  Per (variant, size): wall ms per step over `steps` calls of
+score_resident, the HIP-event phase times of the last call, and an md5 of the PSM records — equal across variants or it says so."""
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(cfg_name, path, sizes, steps, h2h):
+    import numpy as np
+
+    import bench
+    from sage_amd.api import DeviceDatabase, Scorer
+    from sage_amd.workloads import CONFIGS, build_host_db, scorer_params
+    cfg = CONFIGS[cfg_name]
+    params = scorer_params(cfg)
+    if os.environ.get("AB_REPORT_PSMS"):
+        from dataclasses import replace
+        params = replace(params, report_psms=int(os.environ["AB_REPORT_PSMS"]))
+    host = build_host_db(cfg, peptides_only=True)
+    batch_all = bench.load_batch(path)
+    dev = DeviceDatabase(host, 0, build_on_device=True)
+    scorer = Scorer(dev, params)
+    for n in sizes:
+        batch = batch_all if n >= batch_all.n else batch_all.subset(np.arange(n))
+        db = scorer.upload(batch)
+        for _ in range(3):
+            f, c = scorer.score_resident(db)
+        valid = np.arange(f.shape[1])[None, :] < c[:, None]
+        digest = hashlib.md5(f[valid].tobytes()).hexdigest()[:12]
+        best = 1e9
+        tot = 0.0
+        for rep in range(3):  # best of three blocks: a box's first blocks run slower
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                scorer.score_resident(db)
+            ms = (time.perf_counter() - t0) * 1e3 / steps
+            best = min(best, ms)
+            tot += ms
+        t = scorer.last_timing()
+        extra = ""
+        if h2h:
+            locked = batch.page_locked()
+            scorer.score(locked)
+            t0 = time.perf_counter()
+            for _ in range(max(steps // 3, 3)):
+                scorer.score(locked)
+            extra = f" h2h {batch.n * max(steps // 3, 3) / (time.perf_counter() - t0) / 1e6:.2f}M/s"
+            del locked
+        print(f"RESULT n={batch.n:>7} ms/step best {best:.4f} mean {tot / 3:.4f}  {batch.n / best / 1e3:7.2f} M/s  prelim {t['prelim_ms']:.3f} "
+              f"rescore {t['rescore_ms']:.3f} retry {t['retry_ms']:.3f} wall {t['total_ms']:.3f} n_retry {t['n_retry']} ways {t['n_ways']} "
+              f"psms {int(c.sum())} md5 {digest}{extra}", flush=True)
+        db.close()
+    scorer.close()
+
+
+def main():
+    args = sys.argv[1:]
+    if args and args[0] == "--child":
+        child(args[1], args[2], [int(x) for x in args[3].split(",")], int(args[4]), args[5] == "1")
+        return
+    variants = [""]
+    if "--" in args:
+        i = args.index("--")
+        args, variants = args[:i], args[i + 1:]
+    cfg_name = args[0] if args and not args[0].startswith("-") else "C3"
+    sizes, steps, h2h = "62500,500000", 30, False
+    for i, a in enumerate(args):
+        if a == "--sizes":
+            sizes = args[i + 1]
+        if a == "--steps":
+            steps = int(args[i + 1])
+        if a == "--h2h":
+            h2h = True
+    import bench
+    from sage_amd.workloads import CONFIGS, build_host_db
+    cfg = CONFIGS[cfg_name]
+    nmax = max(int(x) for x in sizes.split(","))
+    path = f"/tmp/ab_multi_{cfg_name}_{nmax}.npz"
+    if not os.path.exists(path):
+        host = build_host_db(cfg, peptides_only=True)
+        batch, _ = bench.generate_workload(cfg, host, min(nmax, cfg["spectra"]))
+        bench.save_batch(path, batch)
+        del host, batch
+    for v in variants:
+        lib, _, envs = v.partition(":")
+        env = dict(os.environ)
+        if lib and lib != "base":
+            env["SAGE_HIP_LIB"] = os.path.join(ROOT, "sage_amd", f"libsage_hip_{lib}.so")
+        for kv in envs.split(","):
+            if kv:
+                k, _, val = kv.partition("=")
+                env[k] = val
+        print(f"== {cfg_name} [{v or 'base'}]", flush=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg_name, path, sizes, str(steps), "1" if h2h else "0"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        out = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        print("\n".join(out) if out else f"FAILED rc={r.returncode}\n{r.stderr[-1500:]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

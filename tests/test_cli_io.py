@@ -468,6 +468,14 @@ def test_gzip_inputs_and_device_lists(tmp_path):
     open(p + ".2.gz", "wb").write(gzip.compress(data[:half]) + gzip.compress(data[half:]) + b"\0" * 512)
     c = read_mzml_native(p + ".2.gz", 0)
     assert c.n == 25 and c.ids == a.ids and np.array_equal(c.mz, a.mz)
+    # ... but a second member with a damaged body is a corrupt file, not the end of the input (a silently truncated spectrum list)
+    from sage_amd._lib import SageHipError
+    second = bytearray(gzip.compress(data[half:]))
+    second[len(second) // 2] ^= 0xFF
+    second[len(second) // 2 + 1] ^= 0xFF
+    open(p + ".3.gz", "wb").write(gzip.compress(data[:half]) + bytes(second))
+    with pytest.raises(SageHipError, match="corrupt gzip"):
+        read_mzml_native(p + ".3.gz", 0)
     fa = str(tmp_path / "db.fasta.gz")
     open(fa, "wb").write(gzip.compress(fasta.encode()))
     assert cli.read_text(fa) == fasta

@@ -77,3 +77,40 @@ def test_plan_shards_properties():
             if n == 1000 and world > 1:
                 work = [int(off[e] - off[b]) for b, e in shards]
                 assert max(work) < 1.2 * (sum(work) / world) + 400
+
+
+def test_shards_weighted_by_window_size():
+    """shards balanced on peaks x queries x candidates-in-window.  A run whose precursor masses drift upwards (as they do
+    with retention time) through a peptide list that gets denser with mass: equal peak counts are then not equal work, the weighted
+    plan is; and the estimate's window counts are IndexedDatabase::query's (two binary searches over the mass-sorted list)."""
+    from sage_amd.api import ScorerParams, Tolerance
+    from sage_amd.sharding import estimate_work, plan_shards
+    rng = np.random.default_rng(3)
+    pep_mono = np.sort(rng.uniform(500.0, 5000.0, 200_000) ** 1.0).astype(np.float32)
+    pep_mono = np.sort((500.0 + 4500.0 * rng.beta(4.0, 1.5, 200_000)).astype(np.float32))  # dense at high mass
+    n = 6000
+    z = rng.choice([2, 3], n).astype(np.uint8)
+    mass = np.sort(rng.uniform(600.0, 4800.0, n))  # "retention-time" drift
+    mz = (mass / z + 1.0072764).astype(np.float32)
+    peaks = rng.integers(80, 150, n)
+    off = np.concatenate([[0], np.cumsum(peaks)]).astype(np.uint64)
+    for params in (ScorerParams(precursor_tol=Tolerance("da", -50.0, 50.0)),
+                   ScorerParams(precursor_tol=Tolerance("ppm", -10.0, 10.0), min_isotope_err=-1, max_isotope_err=3)):
+        w = estimate_work(off, mz, z, params, pep_mono)
+        assert w.shape == (n,) and np.all(w > 0)
+        # spot-check the window count of a few spectra against a direct count
+        if params.precursor_tol.kind == "da":
+            for i in (0, n // 2, n - 1):
+                c = float(mz[i] - np.float32(1.0072764)) * int(z[i])
+                direct = int(np.sum((pep_mono >= c - 50.0) & (pep_mono <= c + 50.0)))
+                assert abs(w[i] / (peaks[i] + 1.0) - (direct + 64.0)) <= 2.0
+        world = 8
+        plain, weighted = plan_shards(off, world), plan_shards(off, world, w)
+        load = lambda shards: np.array([w[b:e].sum() for b, e in shards])  # noqa: E731
+        assert weighted[0][0] == 0 and weighted[-1][1] == n and all(b == c for (_, b), (c, _) in zip(weighted, weighted[1:]))
+        assert load(weighted).max() / load(weighted).mean() < 1.05
+        if params.precursor_tol.kind == "da":
+            assert load(plain).max() / load(plain).mean() > 1.3  # what balancing on peak counts alone leaves on the table
+    # unknown charges: one query per charge of the configured range
+    w2 = estimate_work(off, mz, np.zeros(n, np.uint8), ScorerParams(min_precursor_charge=2, max_precursor_charge=4), pep_mono)
+    assert np.all(w2 >= (peaks + 1.0) * 3 * 64.0)
