@@ -12,7 +12,7 @@ rescoring + Feature assembly + the exact retry pass over tied spectra, PSM recor
 
 Multi-GPU (one process per GPU, index replicated, no collective on the data path):
   --scaling strong (default): THE workload (all 500 000 spectra of C3) is cut into N contiguous shards of equal spectrum counts
-      (whole 4096-spectrum chunks of the synthetic run, which every rank generates for itself: the run is shuffled, so equal
+      (each rank generates its own spectra [total r / N, total (r + 1) / N) of the synthetic run: the run is shuffled, so equal
       counts are equal work; a real run is cut by sage_amd.sharding.plan_shards with estimate_work's weights — cli.py), rank r
       scores shard r; N = 1 scores all of it.  After the timed region the ranks' records are gathered in input order and
       rank 0 generates the whole run and checks the gathered result against its own single-GPU pass over it.
@@ -142,8 +142,9 @@ _gen_state = {}
 
 def _gen_chunk(c):
     cfg, host, total, seed_shift = _gen_state["cfg"], _gen_state["host"], _gen_state["total"], _gen_state["seed_shift"]
+    lo, hi = _gen_state.get("span") or (0, total)
     cfg = dict(cfg, spectra_seed=cfg["spectra_seed"] + seed_shift)
-    b, g = workload_batch(cfg, host, c * SPECTRA_CHUNK, (c + 1) * SPECTRA_CHUNK, total)
+    b, g = workload_batch(cfg, host, max(c * SPECTRA_CHUNK, lo), min((c + 1) * SPECTRA_CHUNK, hi), total)
     return c, b, g
 
 
@@ -177,20 +178,21 @@ def _whole_run_worker(conn, cfg, host, total, seed_shift, workers, path):
         conn.send(f"error: {e!r}")
 
 
-def generate_workload(cfg, host, total, seed_shift=0, workers=None, chunks=None):
-    """The `total` spectra of the configuration's synthetic run — or, with `chunks` = (c0, c1), only its chunks [c0, c1) of
-    SPECTRA_CHUNK spectra each — preprocessed (workloads.processed_spectra), as ONE SpectrumBatch + the global index of every
-    kept spectrum.  Chunks are generated by forked workers (the host database is shared copy-on-write); chunk c depends only
-    on (seed, c), so the result depends neither on the worker count nor on which rank generates it."""
+def generate_workload(cfg, host, total, seed_shift=0, workers=None, span=None):
+    """The `total` spectra of the configuration's synthetic run — or, with `span` = (lo, hi), only its spectra [lo, hi) —
+    preprocessed (workloads.processed_spectra), as ONE SpectrumBatch + the global index of every kept spectrum.  The run is a
+    sequence of chunks of SPECTRA_CHUNK spectra generated by forked workers (the host database is shared copy-on-write);
+    chunk c depends only on (seed, c), so the result depends neither on the worker count nor on which rank generates it."""
     import multiprocessing as mp
 
     import numpy as np
 
     from sage_amd.api import SpectrumBatch
-    n_all = (total + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK
-    c0, c1 = chunks if chunks is not None else (0, n_all)
+    lo, hi = span if span is not None else (0, total)
+    lo, hi = max(lo, 0), min(hi, total)
+    c0, c1 = (lo // SPECTRA_CHUNK, (hi + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK) if hi > lo else (0, 0)
     n_chunks = max(c1 - c0, 0)
-    _gen_state.update(cfg=cfg, host=host, total=total, seed_shift=seed_shift)
+    _gen_state.update(cfg=cfg, host=host, total=total, seed_shift=seed_shift, span=(lo, hi))
     workers = workers or min(32, os.cpu_count() or 1, max(n_chunks, 1))
     _gen_chunk_warm = workload_batch(dict(cfg, spectra_seed=cfg["spectra_seed"] + seed_shift), host, 0, 1, total)  # per-database caches, before the fork
     del _gen_chunk_warm
@@ -361,14 +363,12 @@ def main():
     gen_workers = max(1, min(32, int(host_cpu_budget()[0]) // world))  # (the ranks of a node share its CPUs)
     batch_all = None
     if args.scaling == "strong" and world > 1:
-        # Every rank generates ITS shard only: the run is a sequence of independent chunks of SPECTRA_CHUNK spectra, cut into
-        # `world` contiguous runs of chunks of (as near as possible) equal spectrum counts.  The synthetic run is shuffled, so
+        # Every rank generates ITS shard only: spectra [total r / N, total (r + 1) / N) of the run (whole chunks of SPECTRA_CHUNK
+        # spectra except at the two ends; chunk c depends on (seed, c) only).  The synthetic run is shuffled, so
         # equal counts are equal work to ~0.5 % (sharding.plan_shards with sharding.estimate_work's weights is what a real,
         # retention-time-ordered run needs: sage_amd/cli.py).  Rank 0 generates the whole run AFTER the timed region, for the
         # check of the gathered result against a single-GPU pass.
-        n_chunks_all = (total + SPECTRA_CHUNK - 1) // SPECTRA_CHUNK
-        my_chunks = (n_chunks_all * rank // world, n_chunks_all * (rank + 1) // world)
-        batch, gidx = generate_workload(cfg, host, total, seed_shift, gen_workers, chunks=my_chunks)
+        batch, gidx = generate_workload(cfg, host, total, seed_shift, gen_workers, span=(total * rank // world, total * (rank + 1) // world))
         shards, lo, hi = None, None, None  # (positions in the whole run: known after the ranks have exchanged their counts)
         whole_run = None
         if rank == 0:

@@ -137,6 +137,12 @@ struct WorkSet {
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
     DevBuf<uint32_t> arena;
+    // cheap ties (device_types.h: DevWork::cnt_store ...): window counts of every narrow single-query spectrum, the tied
+    // candidates' parked records
+    DevBuf<uint32_t> cnt_store, tie_list;
+    DevBuf<QInfo> qinfo;
+    DevBuf<SageFeature> tie_rec;
+    uint32_t cap_tie = 0;
     uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
     uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
 };
@@ -210,6 +216,9 @@ struct SageScorer {
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
+    bool fast_ties = true;      // one reported PSM, no chimera: ties at the top settled by tie_kernel from stored window counts
+                                // (SAGE_HIP_NO_FAST_TIES=1: every tie through the exact retry pass, as in round 3)
+    uint32_t cnt_stride = 0;    // words per spectrum of WorkSet::cnt_store
     uint32_t qmax = 1;
     WorkSet ws;                 // the working set (lane 0)
     WorkSet ws2;                // a second one: the streaming pipeline scores two chunks of a narrow batch side by side (lane 1)
@@ -690,6 +699,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_REPLAY_LANE_MAX")) s->replay_split |= (uint64_t)(uint32_t)atoll(e) << 32;
     if (const char* e = getenv("SAGE_HIP_ONE_LAUNCH")) s->one_launch = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_NO_ZEROCOPY")) s->zero_copy = atoi(e) == 0;
+    if (const char* e = getenv("SAGE_HIP_NO_FAST_TIES")) s->fast_ties = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)
     if (const char* e = getenv("SAGE_HIP_CHUNK")) s->chunk = (uint32_t)std::min(1 << 22, std::max(64, atoi(e)));
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -697,6 +707,9 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
+    // cheap ties: only where the tied candidates' records are final whichever wins (one reported PSM, no chimera rounds)
+    if (p->report_psms != 1 || p->chimera) s->fast_ties = false;
+    s->cnt_stride = ((d.wcap + 1) / 2 + 3u) & ~3u;
     if (d.kmax > 64) {
         // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
         // in LDS, every trim exact (no order-free trims, hence no retry pass), rescoring 64 candidates at a time.
@@ -1248,6 +1261,13 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream
         w.epoch = 0;
         w.cap_n = n;
     }
+    if (s->fast_ties && n > w.cap_tie) {
+        HIP_TRY(w.cnt_store.reserve((size_t)n * s->cnt_stride));
+        HIP_TRY(w.qinfo.reserve(n));
+        HIP_TRY(w.tie_list.reserve(n));
+        HIP_TRY(w.tie_rec.reserve((size_t)n * TIE_RECS));
+        w.cap_tie = n;
+    }
     if (wide && lane == 0 && n > w.cap_wide) {
         // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena
         HIP_TRY(w.qrec.reserve((size_t)n * s->qmax));
@@ -1284,6 +1304,11 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass, int lane = 0) {
     w.kstride = s->kstride;
     w.reuse = 0;
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
+    w.cnt_store = nullptr;  // (enqueue_compute switches the cheap ties on for the first pass of a production search)
+    w.cnt_stride = s->cnt_stride;
+    w.qinfo = nullptr;
+    w.tie_list = nullptr;
+    w.tie_rec = nullptr;
     w.tile_blocks = s->tile_blocks;
     w.qrec = ws.qrec.p;
     w.seeds = ws.seeds.p;
@@ -1350,6 +1375,13 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         w->queue += list_off;
         w->retry += list_off;
     }
+    const bool fast_ties = s->fast_ties && production && !fused && !one_launch && o.two_pass;
+    if (fast_ties) {  // (parts of a step index cnt_store / qinfo by spectrum and own the range [list_off, ...) of the two lists)
+        w1.cnt_store = wset.cnt_store.p;
+        w1.qinfo = wset.qinfo.p;
+        w1.tie_list = wset.tie_list.p + list_off;
+        w1.tie_rec = wset.tie_rec.p + (size_t)list_off * TIE_RECS;
+    }
     if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
@@ -1381,6 +1413,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     if (with_rescore && (wide || !(fused || one_launch)))  // (behind search_kernel / the fused kernel: only the spectra the large-window kernels assembled)
         launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
     HIP_TRY(hipEventRecord(o.ev[2].e, st));
+    if (fast_ties) {  // ties between the best candidates of a spectrum, from the window counts the first pass kept (one lane each)
+        launch_tie(sc1, w1, view.n, rec, count_buf, st);
+        HIP_TRY(hipGetLastError());
+    }
     if (o.two_pass) {
         launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
         HIP_TRY(hipGetLastError());
@@ -1428,7 +1464,7 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
-    t.n_tied += c1[CTR_TIED];
+    t.n_tied += c1[CTR_TIED] + c1[CTR_FAST_TIE];
     if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
         if (arena_overflow) {
             *arena_overflow = true;

@@ -15,9 +15,9 @@
 //       ln x = e' ln2 + lc_k + log1p(r),     e' = e + (k >= SPLIT),  lc_k = -ln(c_k) resp. -ln(2 c_k)  (double-double).
 //   The three terms cancel nowhere: e' != 0 gives |ln x| >= 0.34; e' == 0 with lc_k != 0 gives |ln x| >= 2^-7.01; in the two
 //   cells next to 1 (k = 0 with e = 0, k = 127 with e = -1) both leading terms are exactly zero and ln x = log1p(r), r = x - 1.
-//   fast phase: exact leading sum by TwoSum with r^2 and r^3 as exact products, the series from r^4 on in double; relative
-//               error < 2^-73 (bound used: 2^-71).  If both ends of the error interval round to the same double, that is the
-//               result — all but ~2^-17 of the arguments.  The hot rescoring kernel carries ONLY this phase and sends a
+//   fast phase: exact leading sum by TwoSum with r^2, r^3 and r^4 as exact products, the series from r^5 on in double; relative
+//               error < 2^-81 (bound used: 2^-79).  If both ends of the error interval round to the same double, that is the
+//               result — all but ~2^-25 of the arguments.  The hot rescoring kernel carries ONLY this phase and sends a
 //               spectrum with an undecided logarithm through the retry pass, whose kernels carry both (kernels.hip).
 //   accurate phase: the series up to r^8 in double-double, 9..18 in double, ln2 as a triple; relative error < 2^-98, so the
 //               rounding is wrong only when ln x lies within 2^-98 |ln x| of a midpoint of two doubles (probability ~2^-44 per
@@ -159,11 +159,13 @@ SAGE_HD CrLogArg cr_log_reduce(double x) {
     return a;
 }
 
-// The fast phase: ln x as an unevaluated sum y.h + y.l with a relative error < 2^-73 (the bound used is 2^-71):
-//   the leading sum e LN2_HI + lc.h + r - r^2/2 + r^3/3 exactly as a chain of TwoSums (r^2 and r^3 as exact products, 1/3 as a
-//   double-double), the series from r^4 on in double (its rounding error is 2^-52 r^4/4 <= 2^-75 of the result: the result is at
-//   least 2^-7.01 unless it is log1p(r) itself, where the same ratio is 2^-52 r^3/4), truncated after r^12/12 (r^13/13 <= 2^-87).
-// `decided`: both ends of the error interval round to the same double — the correctly rounded result.
+// The fast phase: ln x as an unevaluated sum y.h + y.l with a relative error < 2^-81 (the bound used is 2^-79):
+//   the leading sum e LN2_HI + lc.h + r - r^2/2 + r^3/3 - r^4/4 exactly as a chain of TwoSums (r^2, r^3, r^4 as exact products,
+//   1/3 as a double-double), the series from r^5 on in double (its rounding error is 2^-52 r^5/5 <= 2^-82 of the result: the
+//   result is at least 2^-7.01 unless it is log1p(r) itself, where the same ratio is 2^-52 r^4/5), truncated after r^13/13
+//   (r^14/14 <= 2^-94).  Everything of the order 2^-53 of the result and below is summed in plain double: its rounding is 2^-106.
+// `decided`: both ends of the error interval round to the same double — the correctly rounded result.  Undecided: ~2^-25 of
+// the arguments.
 SAGE_HD double cr_log_fast(const CrLogArg& a, bool& decided) {
     const double e = a.e, r = a.r;
     const dd s1 = two_sum(e * SAGE_CRLOG_LN2_HI, a.t.lh);  // (e * LN2_HI is exact)
@@ -175,7 +177,11 @@ SAGE_HD double cr_log_fast(const CrLogArg& a, bool& decided) {
     dd u = two_prod(r3.h, 0x1.5555555555555p-2);            // r^3 / 3, 1/3 = 0x1.5555555555555p-2 + 0x1.5555555555555p-56
     u.l = crl_fma(r3.h, 0x1.5555555555555p-56, crl_fma(r3.l, 0x1.5555555555555p-2, u.l));
     const dd s4 = two_sum(s3.h, u.h);
-    double q = -0x1.5555555555555p-4;                       // -1/12
+    dd r4 = two_prod(r2.h, r2.h);                           // r^4 = r2.h^2 + 2 r2.h r2.l (+ r2.l^2 <= 2^-106 r^4)
+    r4.l = crl_fma(2.0 * r2.h, r2.l, r4.l);
+    const dd s5 = two_sum(s4.h, -0.25 * r4.h);
+    double q = 0x1.3b13b13b13b14p-4;                        // 1/13
+    q = crl_fma(q, r, -0x1.5555555555555p-4);               // -1/12
     q = crl_fma(q, r, 0x1.745d1745d1746p-4);                // 1/11
     q = crl_fma(q, r, -0x1.999999999999ap-4);               // -1/10
     q = crl_fma(q, r, 0x1.c71c71c71c71cp-4);                // 1/9
@@ -183,11 +189,11 @@ SAGE_HD double cr_log_fast(const CrLogArg& a, bool& decided) {
     q = crl_fma(q, r, 0x1.2492492492492p-3);                // 1/7
     q = crl_fma(q, r, -0x1.5555555555555p-3);               // -1/6
     q = crl_fma(q, r, 0.2);
-    q = crl_fma(q, r, -0.25);
-    q *= r2.h * r2.h;
-    const double low = (((s1.l + s2.l) + (s3.l + s4.l)) + crl_fma(e, SAGE_CRLOG_LN2_MID, a.t.ll)) + ((u.l - 0.5 * r2.l) + q);
-    const dd y = fast_two_sum(s4.h, low);
-    const double err = __builtin_fabs(y.h) * 0x1p-71;
+    q *= r4.h * r;
+    const double low = ((((s1.l + s2.l) + (s3.l + s4.l)) + s5.l) + crl_fma(e, SAGE_CRLOG_LN2_MID, a.t.ll)) +
+                       (((u.l - 0.5 * r2.l) - 0.25 * r4.l) + q);
+    const dd y = fast_two_sum(s5.h, low);
+    const double err = __builtin_fabs(y.h) * 0x1p-79;
     const double lo = y.h + (y.l - err), hi = y.h + (y.l + err);
     decided = lo == hi;
     return lo;

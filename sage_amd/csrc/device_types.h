@@ -93,6 +93,10 @@ struct DevBatchView {
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
 };
 
+struct QInfo {
+    uint32_t left, potential;
+};
+
 struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint64_t* cand;        // [n * kmax] packed PreScore in the reference's heap-layout order
     uint32_t* cand_len;    // [n]
@@ -114,6 +118,16 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
                            //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
     uint32_t kstride;      // entries per query of `seeds` / `qres`: kmax rounded up to a multiple of 64 (64 unless report_psms > 32)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
+    // Cheap ties (kernels.hip: tie_kernel).  The preliminary kernel leaves the window counts of every narrow single-query spectrum
+    // in HBM; where the hyperscores of a spectrum's best candidates tie (and report_psms == 1, no chimera), the rescoring kernel
+    // leaves the Feature record of each of the (up to TIE_RECS) tied candidates instead of queueing the spectrum for the exact
+    // retry pass, and tie_kernel — one LANE per spectrum — replays bounded_min_heapify from the stored counts, finds which of the
+    // tied candidates comes first in the reference's preliminary list and copies its record out.
+    uint32_t* cnt_store;   // [n * cnt_stride] u16 count pairs of the spectrum's query, slot order (null: off)
+    uint32_t cnt_stride;   //     words per spectrum (>= wcap / 2, a multiple of 4)
+    struct QInfo* qinfo;   // [n] {left, potential} of that query; potential == 0: no stored counts (several queries, large window)
+    uint32_t* tie_list;    // [n] spectra for tie_kernel; their count is n_deferred[CTR_FAST_TIE]
+    SageFeature* tie_rec;  // [n * TIE_RECS] the tied candidates' records of tie_list[i] at i * TIE_RECS (.pad[0] of the first: how many)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
@@ -131,7 +145,9 @@ enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
        ST_OK_ORDERED = 5 };  // ST_OK, and no trim_hits of the spectrum dropped anything: the order-free list IS the reference's list  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
        CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
+       CTR_FAST_TIE = 7,  // spectra in DevWork::tie_list: ties tie_kernel settles from the stored counts
        CTR_COUNT = 8 };
+constexpr uint32_t TIE_RECS = 4;  // tied candidates whose records the rescoring kernel parks for tie_kernel (more: the exact retry pass)
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
 struct QueryRec {
@@ -218,6 +234,8 @@ void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream);
+// the cheap-tie pass over DevWork::tie_list (count on the device): grid capped, strides over the list
+void launch_tie(const DevScorer& sc, const DevWork& w, uint32_t n_max, SageFeature* out, uint32_t* out_count, void* stream);
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream);
 void launch_annotate(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const SageFeature* feats,
                      const uint32_t* counts, const uint64_t* psm_off, const DevFragments& out, void* stream);

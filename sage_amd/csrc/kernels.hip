@@ -627,9 +627,11 @@ struct PrelimResult {
     bool untrimmed;             // no trim_hits had anything to drop (every list stayed within its k): the list is the reference's
                                 //     Vec as it stands, whatever the trim mode — a tie at a reported rank needs no exact pass
 };
+// `cnt_out` / `qinfo_out` (null: nothing kept): where a single-query spectrum leaves its window counts for tie_kernel
 template <bool PROBE, bool BIGK = false, class PC>
 __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
-                                                        const SpecInfo& si, const bool exact, PC& pc) {
+                                                        const SpecInfo& si, const bool exact, PC& pc, uint32_t* __restrict__ cnt_out = nullptr,
+                                                        QInfo* __restrict__ qinfo_out = nullptr) {
     const uint32_t lane = lane_id();
     Counters cnt;
     cnt.p = L.cnt;
@@ -837,6 +839,10 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                 const uint32_t matched = wave_sum(acc);
                 __syncthreads();
                 pc.mark(2);
+                if (cnt_out) {  // (the caller passes it for single-query spectra only: this loop body runs once)
+                    for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt_out[i] = L.cnt[i];
+                    if (lane == 0) *qinfo_out = QInfo{left, potential};
+                }
                 tot_matched += matched;
                 UList& target = fold ? A : B;
                 if (matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
@@ -957,7 +963,11 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         Clock pc;
         pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
         const SpecInfo si = load_spec(sc, b, spec);
-        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc);
+        // one precursor-window query (known charge, one isotope error): its counts stay in HBM for tie_kernel
+        const bool keep_counts = !BIGK && w.cnt_store && si.z0 == si.z1 && sc.min_isotope_err == sc.max_isotope_err;
+        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc,
+                                                            keep_counts ? w.cnt_store + (size_t)spec * w.cnt_stride : nullptr, w.qinfo + spec);
+        if (w.cnt_store && (!keep_counts || r.deferred) && lane == 0) w.qinfo[spec] = QInfo{0u, 0u};
         if (r.deferred) {
             if (lane == 0) {
                 w.status[spec] = ST_DEFERRED;
@@ -2261,7 +2271,10 @@ struct RescoreLds {
 };
 constexpr uint32_t FEATURE_WORDS = sizeof(SageFeature) / 4;
 static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dwords");
-__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.chimera ? 1u : sc.report_psms; }
+// (one reported PSM per spectrum: room for the records of up to TIE_RECS tied candidates, which tie_kernel chooses from)
+__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) {
+    return sc.chimera ? 1u : sc.report_psms > TIE_RECS ? sc.report_psms : TIE_RECS;
+}
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
@@ -2643,6 +2656,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         uint32_t rank = 0;
         double next_h = 0.0, best_h = 0.0;  // hyperscore of the next rank (0 if none) and of rank 0
         bool tie = false;                   // equal hyperscores meet at a reported rank
+        uint64_t tied_best = 0ull;          // one reported PSM: the lanes that share the best hyperscore, when more than one
         if (per_round == 1) {
             // one reported PSM: the sort reduces to the largest key (first lane on ties — the sort is stable) and the
             // largest key among the others
@@ -2655,6 +2669,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             best_h = from_order_key64(best_key);
             next_h = npass > 1 ? from_order_key64(second_key) : 0.0;
             tie = (wins & (wins - 1)) != 0ull;
+            tied_best = tie ? wins : 0ull;
         } else {
             R.s_key[lane] = key;
             __syncthreads();
@@ -2675,30 +2690,56 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                 tie = rank + 1 < npass && __double_as_longlong(R.s_sorted[rank]) == __double_as_longlong(R.s_sorted[rank + 1]);
             }
         }
+        uint32_t n_tied = 0;  // > 0: the tied candidates' records go to tie_kernel instead of a PSM to `out`
         if (!list_is_exact && __ballot(tie) != 0ull) {
             // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two equal
-            // hyperscores meet at a reported rank (i, i + 1 with i < per_round).  Otherwise: the exact heap layouts are needed.
-            if (queue_on_tie && lane == 0) {
-                w.status[spec] = ST_RETRY;
-                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
-                out_count[spec] = 0;
+            // hyperscores meet at a reported rank (i, i + 1 with i < per_round).  Otherwise the exact heap layout decides.
+            // Cheap when ONE PSM is reported: whichever of the tied candidates wins, its record is final already (rank 1,
+            // delta_next = delta_best = 0: the runner-up has the same hyperscore) — so the (few) tied candidates all write their
+            // records, and tie_kernel only has to find out which of them comes first in the reference's list (from the window
+            // counts prelim_kernel left behind).  Everything else — several reported PSMs, chimera rounds, several queries or a
+            // large window behind the list, more than TIE_RECS candidates — takes the exact retry pass.
+            const uint32_t nt = (uint32_t)__popcll(tied_best);
+            if (queue_on_tie && w.tie_rec && per_round == 1 && !sc.chimera && nt <= TIE_RECS && uni(w.qinfo[spec].potential) != 0u) {
+                n_tied = nt;
+            } else {
+                if (queue_on_tie && lane == 0) {
+                    w.status[spec] = ST_RETRY;
+                    w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+                    out_count[spec] = 0;
+                }
+                return false;
             }
-            return false;
         }
         pc.mark(3);
-        if (pass && rank < per_round) {  // scoring.rs:504-594
-            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
-                                               fid, tic, tot_scored, lnfact_table, lnfact_n);
-            *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
+        const bool reports = n_tied ? ((tied_best >> lane) & 1ull) != 0ull : (pass && rank < per_round);
+        const uint32_t stage_slot = n_tied ? (uint32_t)__popcll(tied_best & ((1ull << lane) - 1ull)) : sc.chimera ? 0u : rank;
+        if (reports) {  // scoring.rs:504-594
+            SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, n_tied ? best_h : next_h, best_h,
+                                         n_tied ? 1u : sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
+                                         fid, tic, tot_scored, lnfact_table, lnfact_n);
+            if (n_tied && stage_slot == 0) f.pad[0] = (uint8_t)n_tied;  // (tie_kernel clears it)
+            *(SageFeature*)(R.stage + (size_t)stage_slot * FEATURE_WORDS) = f;
         }
-        const uint32_t emitted = npass < per_round ? npass : per_round;
+        const uint32_t emitted = n_tied ? n_tied : npass < per_round ? npass : per_round;
         // the records of this round leave together: consecutive ranks are consecutive records, so the wavefront stores them as
         // one contiguous run of dwords (full write requests, whether `out` is HBM or the caller's page-locked host memory)
         __syncthreads();
         {
-            uint32_t* __restrict__ dst = (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
+            uint32_t tie_entry = 0;
+            if (n_tied) {
+                if (lane == 0) {
+                    tie_entry = atomicAdd(w.n_deferred + CTR_FAST_TIE, 1u);
+                    w.tie_list[tie_entry] = spec;
+                    out_count[spec] = 0;
+                }
+                tie_entry = uni(tie_entry);
+            }
+            uint32_t* __restrict__ dst = n_tied ? (uint32_t*)(w.tie_rec + (size_t)tie_entry * TIE_RECS)
+                                                : (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
             for (uint32_t i = lane; i < emitted * FEATURE_WORDS; i += WAVE) dst[i] = R.stage[i];
         }
+        if (n_tied) return false;
         pc.mark(4);
         n_emitted += emitted;
         if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
@@ -3145,6 +3186,96 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
     }
 }
 
+// ---- ties settled from the stored window counts: one LANE per spectrum ------------------------------------------------------------
+// The spectra rescore_kernel put on DevWork::tie_list: one PSM reported, its best candidates (2..TIE_RECS of them) share one
+// hyperscore, their finished records wait in tie_rec.  Which one the reference reports is decided by the stable sort of
+// scoring.rs:495, i.e. by the candidates' positions in the preliminary list — the layout bounded_min_heapify (heap.rs:7-28) leaves
+// behind.  prelim_kernel kept the query's window counts (cnt_store, slot order), so nothing has to be matched again: every lane
+// replays the heap of ITS spectrum (keys `count << 16 | slot`, PreScore's order inside one query; the heap column-interleaved
+// in LDS), looks up where the tied candidates ended up and the earliest one's record goes out.  64 spectra per wavefront, a few
+// thousand instructions each: a tie costs ~1 % of what the exact retry pass (matching + replay + rescoring by a whole
+// wavefront) costs, and the chain behind the last rescoring wavefront of a step is one short launch.
+__global__ __launch_bounds__(64) void tie_kernel(DevScorer sc, DevWork w, uint32_t n_max, SageFeature* __restrict__ out,
+                                                 uint32_t* __restrict__ out_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* const heap = (uint32_t*)smem;  // [kmax][64]
+    const uint32_t lane = lane_id();
+    uint32_t n = uni(w.n_deferred[CTR_FAST_TIE]);
+    n = n < n_max ? n : n_max;
+    for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
+        const bool act = base + lane < n;
+        uint32_t spec = 0, left = 0, potential = 0;
+        if (act) {
+            spec = w.tie_list[base + lane];
+            const QInfo q = w.qinfo[spec];
+            left = q.left;
+            potential = q.potential;
+        }
+        const uint32_t k = trim_k(potential, sc.report_psms);
+        const bool trimmed = potential > k;  // heap.rs:8-10: otherwise the slice stays as it is (slot order)
+        const uint4* __restrict__ cnt4 = (const uint4*)(w.cnt_store + (size_t)spec * w.cnt_stride);
+        uint32_t* const hp = heap + lane;
+        const uint32_t n_chunks = trimmed ? (potential + 7) / 8 : 0u;  // 8 slots (four words of u16 pairs) at a time
+        uint4 nxt = n_chunks ? cnt4[0] : make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t c = 0; __ballot(c < n_chunks) != 0ull; c++) {
+            const uint4 cur = nxt;
+            if (c + 1 < n_chunks) nxt = cnt4[c + 1];  // (in flight under this chunk's sifts)
+            if (c >= n_chunks) continue;
+#pragma unroll 1
+            for (uint32_t t = 0; t < 8; t++) {
+                const uint32_t slot = c * 8 + t;
+                if (slot >= potential) break;
+                const uint32_t word = t < 2 ? cur.x : t < 4 ? cur.y : t < 6 ? cur.z : cur.w;
+                const uint32_t cv = (word >> ((t & 1u) * 16u)) & 0xFFFFu;
+                const uint32_t key = cv ? (cv << 16) | slot : 0u;  // (PreScore::default() is the smallest key)
+                if (slot < k) {
+                    hp[slot * 64] = key;
+                    if (slot + 1 == k)
+                        for (uint32_t i = k / 2; i-- > 0;) sift_down_strided<uint32_t>(hp, k, i, hp[i * 64]);  // heap.rs:13-15
+                } else if (key > hp[0]) {
+                    sift_down_strided<uint32_t>(hp, k, 0, key);  // heap.rs:22-25: slice.swap(i, 0); sift_down
+                }
+            }
+        }
+        // the earliest tied candidate of the list
+        uint32_t win = 0;
+        if (act) {
+            const SageFeature* __restrict__ recs = w.tie_rec + (size_t)(base + lane) * TIE_RECS;
+            const uint32_t m = recs[0].pad[0] < TIE_RECS ? recs[0].pad[0] : TIE_RECS;
+            uint32_t best_pos = 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < m; j++) {
+                const uint32_t slot = recs[j].peptide_idx - left;
+                uint32_t pos = 0xFFFFFFFEu;
+                if (!trimmed) {
+                    pos = slot;
+                } else {
+                    for (uint32_t i = 0; i < k; i++) {
+                        const uint32_t v = hp[i * 64];
+                        if (v != 0u && (v & 0xFFFFu) == slot) pos = i;
+                    }
+                }
+                if (pos < best_pos) { best_pos = pos; win = j; }
+            }
+        }
+        // records leave as contiguous 120-byte runs, two per step (lanes 0..29 and 32..61), like the rescoring kernel's
+        const uint32_t n_here = n - base < WAVE ? n - base : WAVE;
+        for (uint32_t e0 = 0; e0 < n_here; e0 += 2) {
+            const uint32_t e = e0 + (lane >> 5), i = lane & 31u;
+            const uint32_t src_lane = e < n_here ? e : e0;
+            const uint32_t e_spec = (uint32_t)__shfl((int)spec, (int)src_lane, 64), e_win = (uint32_t)__shfl((int)win, (int)src_lane, 64);
+            if (e < n_here && i < FEATURE_WORDS) {
+                uint32_t v = ((const uint32_t*)(w.tie_rec + (size_t)(base + e) * TIE_RECS + e_win))[i];
+                if (i == 28) v &= 0x0000FFFFu;  // (pad[0] carried the number of tied records)
+                ((uint32_t*)(out + (size_t)e_spec * sc.report_psms))[i] = v;
+            }
+        }
+        if (act) {
+            out_count[spec] = 1;
+            w.status[spec] = ST_DONE;
+        }
+    }
+}
+
 // quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
 __global__ __launch_bounds__(256) void quick_mark_kernel(DevScorer sc, uint32_t n, DevWork w, uint8_t* __restrict__ keep) {
     const uint32_t spec = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63u;
@@ -3329,6 +3460,12 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
     const auto kern = w.dbg ? rescore_kernel<true, true> : (sc.fast_log && !keep) ? rescore_kernel<false, false> : rescore_kernel<false, true>;
     hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
                        (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
+}
+void launch_tie(const DevScorer& sc, const DevWork& w, uint32_t n_max, SageFeature* out, uint32_t* out_count, void* stream) {
+    if (n_max == 0 || !w.tie_rec) return;
+    const uint32_t blocks = (n_max + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(tie_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(64), (size_t)sc.kmax * WAVE * 4, (hipStream_t)stream, sc, w, n_max,
+                       out, out_count);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
     if (b.n == 0) return;

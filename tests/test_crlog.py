@@ -83,7 +83,7 @@ def test_against_the_oracles_quadmath_ln_on_a_million_arguments(emu):
         undecided[name] = float(und.mean())
     # the hot rescoring kernel carries the fast phase only and sends the spectrum of an undecided logarithm through the retry
     # pass: that must stay rare on the arguments it sees
-    assert undecided["hyperscore"] < 1e-4 and undecided["lambda"] < 1e-4, undecided
+    assert undecided["hyperscore"] < 1e-5 and undecided["lambda"] < 1e-5, undecided
 
 
 def test_special_arguments(emu):

@@ -366,6 +366,53 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -200.0, 200.0), report_psms=3), "I/L twins, large windows",
                    batch=w.batch.subset(np.arange(0, 300, 3)))
     assert t["n_retry"] > 10 and t["n_wide"] > 0
+    # ONE reported PSM (the default): whichever of the tied candidates wins, its record is final — rescore_kernel parks the
+    # candidates' records and tie_kernel (a lane per spectrum) replays bounded_min_heapify from the window counts the first pass
+    # kept, instead of the exact retry pass (n_tied counts those; n_retry what still took the retry pass)
+    n, t = w.check(ScorerParams(precursor_tol=wide), "I/L twins, narrow, one PSM: cheap ties")
+    assert t["n_tied"] > 50 and t["n_retry"] <= 2 and t["n_wide"] == 0
+    n, t = w.check(ScorerParams(precursor_tol=wide, min_matched_peaks=1, fragment_tol=Tolerance("da", -0.5, 0.5)), "one PSM, loose fragments")
+    assert t["n_tied"] > 50
+    monkeypatch.setenv("SAGE_HIP_NO_FAST_TIES", "1")
+    n, t = w.check(ScorerParams(precursor_tol=wide), "I/L twins, narrow, one PSM, cheap ties off")
+    assert t["n_retry"] > 50 and t["n_tied"] == 0
+    monkeypatch.delenv("SAGE_HIP_NO_FAST_TIES")
+    monkeypatch.setenv("SAGE_HIP_WCAP", "128")  # some windows beyond the narrow kernel's counters: those ties take the retry pass
+    n, t = w.check(ScorerParams(precursor_tol=wide), "one PSM, mixed routing")
+    assert t["n_wide"] > 0 and t["n_tied"] > 0
+    monkeypatch.delenv("SAGE_HIP_WCAP")
+    b0 = w.batch  # no charge annotation: several queries per spectrum — no stored counts, the retry pass settles the tie
+    unknown = SpectrumBatch(b0.peak_off, b0.masses, b0.intensities, b0.precursor_mz, np.zeros(b0.n, np.uint8), b0.total_ion_current,
+                            b0.isolation_lo, b0.isolation_hi, b0.scan_start_time, b0.inverse_ion_mobility, b0.file_id)
+    n, t = w.check(ScorerParams(precursor_tol=wide), "one PSM, unknown charges", batch=unknown)
+    assert t["n_retry"] > 20 and t["n_tied"] == 0
+    # families of EIGHT peptides with identical masses and fragments (isoleucine / leucine at three positions): more candidates
+    # share the best hyperscore than rescore_kernel parks records for (TIE_RECS = 4) — those spectra take the retry pass
+    rng = np.random.default_rng(41)
+    fam = []
+    for t_ in range(40):
+        L_ = int(rng.integers(10, 18))
+        body = [str(c) for c in rng.choice(list("ADEFGHMNQSTVWY"), L_)]
+        xs = sorted(rng.choice(L_, 3, replace=False).tolist())
+        for combo in range(8):
+            q = list(body)
+            for bit, pos in enumerate(xs):
+                q[pos] = "IL"[(combo >> bit) & 1]
+            fam.append(f">sp|FAM{t_:02d}{combo}|FAM{t_:02d}{combo}\n{''.join(q)}K\n")
+    wf = World("".join(fam), DatabaseParameters(bucket_size=1024, enzyme=dict(missed_cleavages=0, cleave_at="KR", restrict="P")), {}, 150,
+               seed=43)
+    n, t = wf.check(ScorerParams(precursor_tol=Tolerance("da", -600.0, 600.0)), "one PSM, eight-fold ties")
+    assert t["n_retry"] > 20 and t["n_wide"] == 0
+    monkeypatch.setenv("SAGE_HIP_WAYS", "3")
+    big1 = w.batch.subset(np.arange(3 * 8192) % w.batch.n)
+    p1 = ScorerParams(precursor_tol=wide)
+    scorer = Scorer(w.dev, p1)
+    gf, gc = scorer.score_resident(scorer.upload(big1))
+    t = scorer.last_timing()
+    of, oc, _, _ = w.orc.score(p1, big1)
+    assert_features_equal(gf, gc, of, oc, "I/L twins, one PSM, three parts side by side")
+    assert t["n_ways"] == 3 and t["n_tied"] > 50
+    monkeypatch.delenv("SAGE_HIP_WAYS")
     n, t = w.check(ScorerParams(chimera=True, report_psms=3, precursor_tol=wide), "I/L twins, chimera")
     assert t["n_retry"] > 50
     monkeypatch.setenv("SAGE_HIP_FUSED", "1")  # the fused narrow kernel: the wavefront goes round again with exact trims
