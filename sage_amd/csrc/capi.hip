@@ -139,9 +139,9 @@ struct WorkSet {
     DevBuf<uint32_t> arena;
     // cheap ties (device_types.h: DevWork::cnt_store ...): window counts of every narrow single-query spectrum, the tied
     // candidates' parked records
-    DevBuf<uint32_t> cnt_store, tie_list;
-    DevBuf<QInfo> qinfo;
-    DevBuf<SageFeature> tie_rec;
+    DevBuf<uint32_t> cnt_store;
+    DevBuf<TieEntry> tie_ent;
+    DevBuf<TieCand> tie_cand;
     uint32_t cap_tie = 0;
     uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
     uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
@@ -709,7 +709,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
     // cheap ties: only where the tied candidates' records are final whichever wins (one reported PSM, no chimera rounds)
     if (p->report_psms != 1 || p->chimera) s->fast_ties = false;
-    s->cnt_stride = ((d.wcap + 1) / 2 + 3u) & ~3u;
+    s->cnt_stride = 4u + (((d.wcap + 1) / 2 + 3u) & ~3u);  // (kernels.hip: CNT_ROW_HEADER)
     if (d.kmax > 64) {
         // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
         // in LDS, every trim exact (no order-free trims, hence no retry pass), rescoring 64 candidates at a time.
@@ -1263,9 +1263,8 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream
     }
     if (s->fast_ties && n > w.cap_tie) {
         HIP_TRY(w.cnt_store.reserve((size_t)n * s->cnt_stride));
-        HIP_TRY(w.qinfo.reserve(n));
-        HIP_TRY(w.tie_list.reserve(n));
-        HIP_TRY(w.tie_rec.reserve((size_t)n * TIE_RECS));
+        HIP_TRY(w.tie_ent.reserve(n));
+        HIP_TRY(w.tie_cand.reserve((size_t)n * TIE_CANDS_AVG));
         w.cap_tie = n;
     }
     if (wide && lane == 0 && n > w.cap_wide) {
@@ -1306,9 +1305,9 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass, int lane = 0) {
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.cnt_store = nullptr;  // (enqueue_compute switches the cheap ties on for the first pass of a production search)
     w.cnt_stride = s->cnt_stride;
-    w.qinfo = nullptr;
-    w.tie_list = nullptr;
-    w.tie_rec = nullptr;
+    w.tie_cand = nullptr;
+    w.tie_ent = nullptr;
+    w.tie_cap = 0;
     w.tile_blocks = s->tile_blocks;
     w.qrec = ws.qrec.p;
     w.seeds = ws.seeds.p;
@@ -1376,11 +1375,11 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         w->retry += list_off;
     }
     const bool fast_ties = s->fast_ties && production && !fused && !one_launch && o.two_pass;
-    if (fast_ties) {  // (parts of a step index cnt_store / qinfo by spectrum and own the range [list_off, ...) of the two lists)
-        w1.cnt_store = wset.cnt_store.p;
-        w1.qinfo = wset.qinfo.p;
-        w1.tie_list = wset.tie_list.p + list_off;
-        w1.tie_rec = wset.tie_rec.p + (size_t)list_off * TIE_RECS;
+    if (fast_ties) {  // (each part of a step owns the rows / entries [list_off, list_off + n) of these arrays)
+        w1.cnt_store = wset.cnt_store.p + (size_t)list_off * s->cnt_stride;  // (rows by schedule position within the part)
+        w1.tie_ent = wset.tie_ent.p + list_off;
+        w1.tie_cand = wset.tie_cand.p + (size_t)list_off * TIE_CANDS_AVG;
+        w1.tie_cap = view.n * TIE_CANDS_AVG;
     }
     if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
@@ -1414,7 +1413,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
     HIP_TRY(hipEventRecord(o.ev[2].e, st));
     if (fast_ties) {  // ties between the best candidates of a spectrum, from the window counts the first pass kept (one lane each)
-        launch_tie(sc1, w1, view.n, rec, count_buf, st);
+        launch_tie(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
         HIP_TRY(hipGetLastError());
     }
     if (o.two_pass) {
@@ -1464,7 +1463,7 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
-    t.n_tied += c1[CTR_TIED] + c1[CTR_FAST_TIE];
+    t.n_tied += c1[CTR_TIED] + c1[CTR_TIE_PAIR];
     if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
         if (arena_overflow) {
             *arena_overflow = true;
@@ -1480,6 +1479,17 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
 }
 
 static void reset_timing(SageScorer* s) { s->timing = SageTiming{}; }
+
+// Wait for a stream by polling first: a blocked hipStreamSynchronize wakes up tens of microseconds after the last command — a
+// twentieth of a small step.  (Bounded: a long wait falls back to the blocking call.)
+static hipError_t wait_for_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipStreamSynchronize(st);
+    }
+}
 
 // score a resident batch on the compute stream: kernels, record download, ONE host synchronisation.  Page-locked result
 // arrays receive the records straight from the kernels (the stores cross PCIe while the other wavefronts compute: no download
@@ -1507,6 +1517,8 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         rc = ensure_out(s, o, b->n, direct == nullptr);
         if (rc != SAGE_HIP_OK) return rc;
         SageFeature* const rec = direct ? direct : o.features.p;
+        uint32_t* const count_view = s->zero_copy && b->n ? (uint32_t*)device_view(out_count) : nullptr;
+        const bool epilogue = count_view != nullptr;  // (page-locked count array: the small results go home in one launch)
         HIP_TRY(hipEventRecord(s->way_begin.e, s->stream));
         if (ways > 1) HIP_TRY(hipEventRecord(s->way_fork.e, s->stream));
         for (uint32_t wy = 0; wy < ways; wy++) {
@@ -1522,18 +1534,29 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
                 for (uint32_t k = 0; k < wy; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
                 return rc;
             }
-            HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
-            if (wy) {
-                HIP_TRY(hipEventRecord(s->way_join[wy - 1].e, st));
-                HIP_TRY(hipStreamWaitEvent(s->stream, s->way_join[wy - 1].e, 0));
+            if (!epilogue) HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+            // The step ends on the LAST part's stream: that part started last and finishes last, so the waits for the others are
+            // (nearly always) satisfied when it gets there and the epilogue follows its last kernel back to back — joining on the
+            // first part's stream instead cost a cross-stream wake-up (~25 us) at the end of every step.
+            if (wy + 1 < ways) HIP_TRY(hipEventRecord(s->way_join[wy].e, st));
+        }
+        hipStream_t fin = ways > 1 ? s->way_stream[ways - 2] : s->stream;
+        for (uint32_t wy = 0; wy + 1 < ways; wy++) HIP_TRY(hipStreamWaitEvent(fin, s->way_join[wy].e, 0));
+        HIP_TRY(hipEventRecord(s->way_end.e, fin));
+        if (epilogue) {  // the PSM counts and every part's counters in one launch, straight into the page-locked destinations
+            EpilogueParts parts{};
+            parts.n = ways;
+            for (uint32_t wy = 0; wy < ways; wy++) {
+                parts.src[wy] = s->outs[wy].counters.p;
+                parts.dst[wy] = (uint32_t*)device_view(s->outs[wy].h_counters);
             }
+            launch_epilogue(o.out_count.p, b->n, count_view, parts, fin);
+            HIP_TRY(hipGetLastError());
+        } else if (b->n) {
+            HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, fin));
         }
-        HIP_TRY(hipEventRecord(s->way_end.e, s->stream));
-        if (b->n) {
-            HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, s->stream));
-            if (!direct) HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, s->stream));
-        }
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (b->n && !direct) HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, fin));
+        HIP_TRY(wait_for_stream(fin));
         bool redo = false;
         for (uint32_t wy = 0; wy < ways; wy++) {
             bool r = false;

@@ -167,32 +167,41 @@ SAGE_HD CrLogArg cr_log_reduce(double x) {
 // `decided`: both ends of the error interval round to the same double — the correctly rounded result.  Undecided: ~2^-25 of
 // the arguments.
 SAGE_HD double cr_log_fast(const CrLogArg& a, bool& decided) {
+    // (written to keep few values alive at a time — the callers are kernels at the edge of their register budget: the small terms
+    // are folded into ONE running sum `low` as they appear; they are all below 2^-36 of the result, so the order of these
+    // additions is immaterial at the 2^-89 level)
     const double e = a.e, r = a.r;
-    const dd s1 = two_sum(e * SAGE_CRLOG_LN2_HI, a.t.lh);  // (e * LN2_HI is exact)
-    const dd s2 = two_sum(s1.h, r);
-    const dd r2 = two_prod(r, r);                           // r^2 exactly
-    const dd s3 = two_sum(s2.h, -0.5 * r2.h);
-    dd r3 = two_prod(r2.h, r);                              // r^3 = r2.h r + r2.l r
-    r3.l = crl_fma(r2.l, r, r3.l);
-    dd u = two_prod(r3.h, 0x1.5555555555555p-2);            // r^3 / 3, 1/3 = 0x1.5555555555555p-2 + 0x1.5555555555555p-56
-    u.l = crl_fma(r3.h, 0x1.5555555555555p-56, crl_fma(r3.l, 0x1.5555555555555p-2, u.l));
-    const dd s4 = two_sum(s3.h, u.h);
-    dd r4 = two_prod(r2.h, r2.h);                           // r^4 = r2.h^2 + 2 r2.h r2.l (+ r2.l^2 <= 2^-106 r^4)
-    r4.l = crl_fma(2.0 * r2.h, r2.l, r4.l);
-    const dd s5 = two_sum(s4.h, -0.25 * r4.h);
-    double q = 0x1.3b13b13b13b14p-4;                        // 1/13
-    q = crl_fma(q, r, -0x1.5555555555555p-4);               // -1/12
-    q = crl_fma(q, r, 0x1.745d1745d1746p-4);                // 1/11
-    q = crl_fma(q, r, -0x1.999999999999ap-4);               // -1/10
-    q = crl_fma(q, r, 0x1.c71c71c71c71cp-4);                // 1/9
+    const dd r2 = two_prod(r, r);                            // r^2 exactly
+    double r3h = r2.h * r, r3l = crl_fma(r2.h, r, -r3h);     // r^3 = r2.h r + r2.l r
+    r3l = crl_fma(r2.l, r, r3l);
+    const double uh = r3h * 0x1.5555555555555p-2;            // r^3 / 3, 1/3 = 0x1.5555555555555p-2 + 0x1.5555555555555p-56
+    double low = crl_fma(r3h, 0x1.5555555555555p-2, -uh);
+    low = crl_fma(r3h, 0x1.5555555555555p-56, crl_fma(r3l, 0x1.5555555555555p-2, low));
+    low = crl_fma(-0.5, r2.l, low);
+    const double r4h = r2.h * r2.h;                          // r^4 = r2.h^2 + 2 r2.h r2.l (+ r2.l^2 <= 2^-106 r^4)
+    low = crl_fma(-0.25, crl_fma(2.0 * r2.h, r2.l, crl_fma(r2.h, r2.h, -r4h)), low);
+    double q = 0x1.3b13b13b13b14p-4;                         // 1/13
+    q = crl_fma(q, r, -0x1.5555555555555p-4);                // -1/12
+    q = crl_fma(q, r, 0x1.745d1745d1746p-4);                 // 1/11
+    q = crl_fma(q, r, -0x1.999999999999ap-4);                // -1/10
+    q = crl_fma(q, r, 0x1.c71c71c71c71cp-4);                 // 1/9
     q = crl_fma(q, r, -0.125);
-    q = crl_fma(q, r, 0x1.2492492492492p-3);                // 1/7
-    q = crl_fma(q, r, -0x1.5555555555555p-3);               // -1/6
+    q = crl_fma(q, r, 0x1.2492492492492p-3);                 // 1/7
+    q = crl_fma(q, r, -0x1.5555555555555p-3);                // -1/6
     q = crl_fma(q, r, 0.2);
-    q *= r4.h * r;
-    const double low = ((((s1.l + s2.l) + (s3.l + s4.l)) + s5.l) + crl_fma(e, SAGE_CRLOG_LN2_MID, a.t.ll)) +
-                       (((u.l - 0.5 * r2.l) - 0.25 * r4.l) + q);
-    const dd y = fast_two_sum(s5.h, low);
+    low = crl_fma(q, r4h * r, low);
+    low += crl_fma(e, SAGE_CRLOG_LN2_MID, a.t.ll);
+    dd s = two_sum(e * SAGE_CRLOG_LN2_HI, a.t.lh);           // (e * LN2_HI is exact)
+    low += s.l;
+    s = two_sum(s.h, r);
+    low += s.l;
+    s = two_sum(s.h, -0.5 * r2.h);
+    low += s.l;
+    s = two_sum(s.h, uh);
+    low += s.l;
+    s = two_sum(s.h, -0.25 * r4h);
+    low += s.l;
+    const dd y = fast_two_sum(s.h, low);
     const double err = __builtin_fabs(y.h) * 0x1p-79;
     const double lo = y.h + (y.l - err), hi = y.h + (y.l + err);
     decided = lo == hi;

@@ -93,8 +93,20 @@ struct DevBatchView {
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
 };
 
-struct QInfo {
-    uint32_t left, potential;
+struct TieEntry {
+    uint32_t spec;   // the spectrum
+    uint32_t row;    // its row of cnt_store (the schedule position of its workgroups)
+    uint32_t first;  // its candidates: tie_cand[first .. first + n)
+    uint32_t n;
+};
+struct TieCand {  // what the Feature of a candidate needs beyond the spectrum's own data (Score, scoring.rs:17-30)
+    uint32_t peptide;
+    uint32_t z_iso;  // precursor charge | (isotope error + 128) << 8
+    uint32_t matched_b, matched_y;
+    float summed_b, summed_y, ppm_difference;
+    uint32_t longest_b, longest_y;
+    uint32_t pad;
+    double hyperscore;
 };
 
 struct DevWork {  // per-spectrum outputs of the preliminary pass
@@ -118,16 +130,19 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
                            //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
     uint32_t kstride;      // entries per query of `seeds` / `qres`: kmax rounded up to a multiple of 64 (64 unless report_psms > 32)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
-    // Cheap ties (kernels.hip: tie_kernel).  The preliminary kernel leaves the window counts of every narrow single-query spectrum
-    // in HBM; where the hyperscores of a spectrum's best candidates tie (and report_psms == 1, no chimera), the rescoring kernel
-    // leaves the Feature record of each of the (up to TIE_RECS) tied candidates instead of queueing the spectrum for the exact
-    // retry pass, and tie_kernel — one LANE per spectrum — replays bounded_min_heapify from the stored counts, finds which of the
-    // tied candidates comes first in the reference's preliminary list and copies its record out.
-    uint32_t* cnt_store;   // [n * cnt_stride] u16 count pairs of the spectrum's query, slot order (null: off)
-    uint32_t cnt_stride;   //     words per spectrum (>= wcap / 2, a multiple of 4)
-    struct QInfo* qinfo;   // [n] {left, potential} of that query; potential == 0: no stored counts (several queries, large window)
-    uint32_t* tie_list;    // [n] spectra for tie_kernel; their count is n_deferred[CTR_FAST_TIE]
-    SageFeature* tie_rec;  // [n * TIE_RECS] the tied candidates' records of tie_list[i] at i * TIE_RECS (.pad[0] of the first: how many)
+    // Cheap ties (kernels.hip: tie_wave_kernel / tie_kernel).  The preliminary kernel leaves the window counts of every narrow
+    // single-query spectrum in HBM; where the hyperscores of a spectrum's best candidates tie (and report_psms == 1, no chimera),
+    // the rescoring kernel parks the tied candidates' Scores (TieCand) instead of queueing the spectrum for the exact retry pass,
+    // and a tie kernel replays bounded_min_heapify from the stored counts, finds which of the tied candidates comes first in the
+    // reference's preliminary list and writes its Feature record.
+    uint32_t* cnt_store;   // [n * cnt_stride] one row per SCHEDULE POSITION of the launch (null: off): {left, potential, -, -} of the
+                           //     spectrum's query — potential == 0: nothing kept (several queries, large window) — then its u16
+                           //     counts in slot order, two per word
+    uint32_t cnt_stride;   //     words per row (4 + wcap / 2, a multiple of 4)
+    struct TieEntry* tie_ent;  // [n] the tied spectra; their number and the number of parked candidates: the 64-bit counter at
+                               //     n_deferred[CTR_TIE_PAIR] (low word: entries, high word: candidates)
+    struct TieCand* tie_cand;  // [tie_cap] the tied candidates, spectrum after spectrum
+    uint32_t tie_cap;          //     (a spectrum whose candidates do not fit takes the retry pass)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
@@ -145,9 +160,9 @@ enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
        ST_OK_ORDERED = 5 };  // ST_OK, and no trim_hits of the spectrum dropped anything: the order-free list IS the reference's list  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
        CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
-       CTR_FAST_TIE = 7,  // spectra in DevWork::tie_list: ties tie_kernel settles from the stored counts
-       CTR_COUNT = 8 };
-constexpr uint32_t TIE_RECS = 4;  // tied candidates whose records the rescoring kernel parks for tie_kernel (more: the exact retry pass)
+       CTR_TIE_PAIR = 8,  // + 9: ONE 64-bit counter — low word: entries of DevWork::tie_ent, high word: candidates taken from tie_cand
+       CTR_COUNT = 16 };
+constexpr uint32_t TIE_CANDS_AVG = 4;  // parked candidates per spectrum DevWork::tie_cand is sized for
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
 struct QueryRec {
@@ -234,8 +249,16 @@ void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream);
-// the cheap-tie pass over DevWork::tie_list (count on the device): grid capped, strides over the list
-void launch_tie(const DevScorer& sc, const DevWork& w, uint32_t n_max, SageFeature* out, uint32_t* out_count, void* stream);
+// the cheap-tie pass over DevWork::tie_ent (count on the device): two launches of which one has work (kernels.hip)
+void launch_tie(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
+// counts[n] -> h_counts (device view of page-locked memory) and the counter blocks (2 * CTR_COUNT words) of up to four parts
+struct EpilogueParts {
+    const uint32_t* src[4];
+    uint32_t* dst[4];
+    uint32_t n;
+};
+void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream);
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream);
 void launch_annotate(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const SageFeature* feats,
                      const uint32_t* counts, const uint64_t* psm_off, const DevFragments& out, void* stream);

@@ -29,6 +29,7 @@ namespace sagehip {
 namespace {
 
 constexpr uint32_t WAVE = 64;
+constexpr uint32_t CNT_ROW_HEADER = 4;  // DevWork::cnt_store: words in front of a row's counts (keeps them 16-byte aligned)
 #ifndef SAGE_PROBE_PER_LANE
 #define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
 #endif
@@ -626,16 +627,16 @@ struct PrelimResult {
     bool deferred;              // some precursor window exceeds the LDS counters: the spectrum belongs to the large-window kernels
     bool untrimmed;             // no trim_hits had anything to drop (every list stayed within its k): the list is the reference's
                                 //     Vec as it stands, whatever the trim mode — a tie at a reported rank needs no exact pass
+    uint32_t q_left, q_potential;  // the LAST precursor-window query: first candidate slot's peptide and the number of slots; its
+                                   //     counts are still in L.cnt when prelim_spectrum returns
 };
-// `cnt_out` / `qinfo_out` (null: nothing kept): where a single-query spectrum leaves its window counts for tie_kernel
 template <bool PROBE, bool BIGK = false, class PC>
 __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
-                                                        const SpecInfo& si, const bool exact, PC& pc, uint32_t* __restrict__ cnt_out = nullptr,
-                                                        QInfo* __restrict__ qinfo_out = nullptr) {
+                                                        const SpecInfo& si, const bool exact, PC& pc) {
     const uint32_t lane = lane_id();
     Counters cnt;
     cnt.p = L.cnt;
-    PrelimResult res{0u, 0u, 0u, true, false, true};
+    PrelimResult res{0u, 0u, 0u, true, false, true, 0u, 0u};
     {
         const uint32_t P = si.P, nfz_max = si.nfz_max;
         const float* __restrict__ masses = b.masses + si.p0;
@@ -839,10 +840,8 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                 const uint32_t matched = wave_sum(acc);
                 __syncthreads();
                 pc.mark(2);
-                if (cnt_out) {  // (the caller passes it for single-query spectra only: this loop body runs once)
-                    for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt_out[i] = L.cnt[i];
-                    if (lane == 0) *qinfo_out = QInfo{left, potential};
-                }
+                res.q_left = left;            // (of the last query: what prelim_kernel keeps of a single-query spectrum)
+                res.q_potential = potential;
                 tot_matched += matched;
                 UList& target = fold ? A : B;
                 if (matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
@@ -963,11 +962,25 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         Clock pc;
         pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
         const SpecInfo si = load_spec(sc, b, spec);
-        // one precursor-window query (known charge, one isotope error): its counts stay in HBM for tie_kernel
-        const bool keep_counts = !BIGK && w.cnt_store && si.z0 == si.z1 && sc.min_isotope_err == sc.max_isotope_err;
-        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc,
-                                                            keep_counts ? w.cnt_store + (size_t)spec * w.cnt_stride : nullptr, w.qinfo + spec);
-        if (w.cnt_store && (!keep_counts || r.deferred) && lane == 0) w.qinfo[spec] = QInfo{0u, 0u};
+        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc);
+        if (!BIGK && w.cnt_store) {
+            // One precursor-window query (known charge, one isotope error): its window counts — still in LDS — stay in HBM for
+            // tie_kernel.  (Here, behind prelim_spectrum, not inside it: nothing of this is live in the matching loops.)
+            // Rows in SCHEDULE order (row `pos`, not row `spec`): the wavefronts running at any time write one moving window of a
+            // few MB, not 2 KB pieces scattered over the whole GB — the stores of a random row per wavefront cost 5 % of the kernel
+            // (address translation).  A row: {left, potential, -, -} then the u16 counts, two per word.
+            const bool keep = !r.deferred && si.z0 == si.z1 && sc.min_isotope_err == sc.max_isotope_err;
+            uint32_t* __restrict__ row = w.cnt_store + (size_t)pos * w.cnt_stride;
+#ifndef SAGE_CNT_MODE
+#define SAGE_CNT_MODE 0  // (measurement variants: 1 = the row header only, 2 = the counts only)
+#endif
+            if (keep && SAGE_CNT_MODE != 1)
+                for (uint32_t i = lane; i < (r.q_potential + 1) / 2; i += WAVE) row[CNT_ROW_HEADER + i] = L.cnt[i];
+            if (lane == 0 && SAGE_CNT_MODE != 2) {
+                row[0] = keep ? r.q_left : 0u;
+                row[1] = keep ? r.q_potential : 0u;  // (0: no counts kept — several queries, or a large window)
+            }
+        }
         if (r.deferred) {
             if (lane == 0) {
                 w.status[spec] = ST_DEFERRED;
@@ -2271,10 +2284,7 @@ struct RescoreLds {
 };
 constexpr uint32_t FEATURE_WORDS = sizeof(SageFeature) / 4;
 static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dwords");
-// (one reported PSM per spectrum: room for the records of up to TIE_RECS tied candidates, which tie_kernel chooses from)
-__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) {
-    return sc.chimera ? 1u : sc.report_psms > TIE_RECS ? sc.report_psms : TIE_RECS;
-}
+__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.chimera ? 1u : sc.report_psms; }
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
@@ -2608,7 +2618,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         bool pass = false;
         bool ln_undecided;
         const double ln_i = cr_log_pair<ACC>(hyperscore_arg(s), lambda, round == 0, ln_lambda, ln_undecided);
-        if (!ACC && __ballot(ln_undecided && (valid || round == 0)) != 0ull) {
+        if (__builtin_expect(!ACC && __ballot(ln_undecided && (valid || round == 0)) != 0ull, 0)) {
             // (the hot instance carries the logarithm's fast phase only: this spectrum again in the retry pass, like a tie)
             if (queue_on_tie && lane == 0) {
                 w.status[spec] = ST_RETRY;
@@ -2656,7 +2666,6 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         uint32_t rank = 0;
         double next_h = 0.0, best_h = 0.0;  // hyperscore of the next rank (0 if none) and of rank 0
         bool tie = false;                   // equal hyperscores meet at a reported rank
-        uint64_t tied_best = 0ull;          // one reported PSM: the lanes that share the best hyperscore, when more than one
         if (per_round == 1) {
             // one reported PSM: the sort reduces to the largest key (first lane on ties — the sort is stable) and the
             // largest key among the others
@@ -2669,7 +2678,6 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             best_h = from_order_key64(best_key);
             next_h = npass > 1 ? from_order_key64(second_key) : 0.0;
             tie = (wins & (wins - 1)) != 0ull;
-            tied_best = tie ? wins : 0ull;
         } else {
             R.s_key[lane] = key;
             __syncthreads();
@@ -2690,56 +2698,65 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                 tie = rank + 1 < npass && __double_as_longlong(R.s_sorted[rank]) == __double_as_longlong(R.s_sorted[rank + 1]);
             }
         }
-        uint32_t n_tied = 0;  // > 0: the tied candidates' records go to tie_kernel instead of a PSM to `out`
-        if (!list_is_exact && __ballot(tie) != 0ull) {
+        if (__builtin_expect(!list_is_exact && __ballot(tie) != 0ull, 0)) {  // (cold: spill code belongs in here, not around it)
             // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two equal
             // hyperscores meet at a reported rank (i, i + 1 with i < per_round).  Otherwise the exact heap layout decides.
-            // Cheap when ONE PSM is reported: whichever of the tied candidates wins, its record is final already (rank 1,
-            // delta_next = delta_best = 0: the runner-up has the same hyperscore) — so the (few) tied candidates all write their
-            // records, and tie_kernel only has to find out which of them comes first in the reference's list (from the window
-            // counts prelim_kernel left behind).  Everything else — several reported PSMs, chimera rounds, several queries or a
-            // large window behind the list, more than TIE_RECS candidates — takes the exact retry pass.
-            const uint32_t nt = (uint32_t)__popcll(tied_best);
-            if (queue_on_tie && w.tie_rec && per_round == 1 && !sc.chimera && nt <= TIE_RECS && uni(w.qinfo[spec].potential) != 0u) {
-                n_tied = nt;
-            } else {
-                if (queue_on_tie && lane == 0) {
-                    w.status[spec] = ST_RETRY;
-                    w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+            // Cheap when ONE PSM is reported: whichever of the tied candidates wins, its Feature is known already (rank 1,
+            // delta_next = delta_best = 0: the runner-up has the same hyperscore) — the tied candidates park their Scores (48 bytes
+            // each, straight from their lanes) and a tie kernel finds out which of them comes first in the reference's list, from
+            // the window counts prelim_kernel left behind (a spectrum without stored counts it passes on to the retry pass), and
+            // writes that candidate's record.  Everything else — several reported PSMs, chimera rounds — takes the exact retry pass.
+            // (Nothing here is live in the hot path: mask and slot are recomputed, no staging, no barrier.)
+#ifndef SAGE_NO_TIE_BRANCH
+            if (queue_on_tie && w.tie_ent && per_round == 1 && !sc.chimera) {
+                const bool is_best = pass && __double_as_longlong(h) == __double_as_longlong(best_h);
+                const uint64_t tb = __ballot(is_best);
+                const uint32_t nt = (uint32_t)__popcll(tb);
+                unsigned long long at = 0ull;
+                if (lane == 0) at = atomicAdd((unsigned long long*)(w.n_deferred + CTR_TIE_PAIR), ((unsigned long long)nt << 32) | 1ull);
+                const uint32_t entry = uni((uint32_t)at), first = uni((uint32_t)(at >> 32));
+                const bool fits = first + nt <= w.tie_cap;
+                if (lane == 0) {  // (an entry without candidates when they do not fit: the tie kernels skip it, the retry pass takes the spectrum)
+                    w.tie_ent[entry] = TieEntry{spec, xcd_position(blockIdx.x, b.n, sc.xcd_chunk), first, fits ? nt : 0u};
                     out_count[spec] = 0;
                 }
-                return false;
+                if (fits) {
+                    if (is_best) {
+                        TieCand c;
+                        c.peptide = pep;
+                        c.z_iso = z | ((uint32_t)(iso + 128) << 8);
+                        c.matched_b = s.matched_b; c.matched_y = s.matched_y;
+                        c.summed_b = s.summed_b; c.summed_y = s.summed_y; c.ppm_difference = s.ppm_difference;
+                        c.longest_b = s.longest_b; c.longest_y = s.longest_y;
+                        c.pad = 0;
+                        c.hyperscore = h;
+                        w.tie_cand[first + (uint32_t)__popcll(tb & ((1ull << lane) - 1ull))] = c;
+                    }
+                    return false;
+                }
             }
+#endif
+            if (queue_on_tie && lane == 0) {
+                w.status[spec] = ST_RETRY;
+                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+                out_count[spec] = 0;
+            }
+            return false;
         }
         pc.mark(3);
-        const bool reports = n_tied ? ((tied_best >> lane) & 1ull) != 0ull : (pass && rank < per_round);
-        const uint32_t stage_slot = n_tied ? (uint32_t)__popcll(tied_best & ((1ull << lane) - 1ull)) : sc.chimera ? 0u : rank;
-        if (reports) {  // scoring.rs:504-594
-            SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, n_tied ? best_h : next_h, best_h,
-                                         n_tied ? 1u : sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
-                                         fid, tic, tot_scored, lnfact_table, lnfact_n);
-            if (n_tied && stage_slot == 0) f.pad[0] = (uint8_t)n_tied;  // (tie_kernel clears it)
-            *(SageFeature*)(R.stage + (size_t)stage_slot * FEATURE_WORDS) = f;
+        if (pass && rank < per_round) {  // scoring.rs:504-594
+            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
+                                               fid, tic, tot_scored, lnfact_table, lnfact_n);
+            *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
         }
-        const uint32_t emitted = n_tied ? n_tied : npass < per_round ? npass : per_round;
+        const uint32_t emitted = npass < per_round ? npass : per_round;
         // the records of this round leave together: consecutive ranks are consecutive records, so the wavefront stores them as
         // one contiguous run of dwords (full write requests, whether `out` is HBM or the caller's page-locked host memory)
         __syncthreads();
         {
-            uint32_t tie_entry = 0;
-            if (n_tied) {
-                if (lane == 0) {
-                    tie_entry = atomicAdd(w.n_deferred + CTR_FAST_TIE, 1u);
-                    w.tie_list[tie_entry] = spec;
-                    out_count[spec] = 0;
-                }
-                tie_entry = uni(tie_entry);
-            }
-            uint32_t* __restrict__ dst = n_tied ? (uint32_t*)(w.tie_rec + (size_t)tie_entry * TIE_RECS)
-                                                : (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
+            uint32_t* __restrict__ dst = (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
             for (uint32_t i = lane; i < emitted * FEATURE_WORDS; i += WAVE) dst[i] = R.stage[i];
         }
-        if (n_tied) return false;
         pc.mark(4);
         n_emitted += emitted;
         if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
@@ -3186,37 +3203,73 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
     }
 }
 
-// ---- ties settled from the stored window counts: one LANE per spectrum ------------------------------------------------------------
-// The spectra rescore_kernel put on DevWork::tie_list: one PSM reported, its best candidates (2..TIE_RECS of them) share one
-// hyperscore, their finished records wait in tie_rec.  Which one the reference reports is decided by the stable sort of
-// scoring.rs:495, i.e. by the candidates' positions in the preliminary list — the layout bounded_min_heapify (heap.rs:7-28) leaves
-// behind.  prelim_kernel kept the query's window counts (cnt_store, slot order), so nothing has to be matched again: every lane
-// replays the heap of ITS spectrum (keys `count << 16 | slot`, PreScore's order inside one query; the heap column-interleaved
-// in LDS), looks up where the tied candidates ended up and the earliest one's record goes out.  64 spectra per wavefront, a few
-// thousand instructions each: a tie costs ~1 % of what the exact retry pass (matching + replay + rescoring by a whole
-// wavefront) costs, and the chain behind the last rescoring wavefront of a step is one short launch.
-__global__ __launch_bounds__(64) void tie_kernel(DevScorer sc, DevWork w, uint32_t n_max, SageFeature* __restrict__ out,
-                                                 uint32_t* __restrict__ out_count) {
+// ---- ties settled from the stored window counts -----------------------------------------------------------------------------------
+// The spectra rescore_kernel put on DevWork::tie_ent: one PSM reported, its best candidates (2 .. 64 of them) share one
+// hyperscore, their Scores wait in tie_cand.  Which one the reference reports is decided by the stable sort of scoring.rs:495,
+// i.e. by the candidates' positions in the preliminary list — the layout bounded_min_heapify (heap.rs:7-28) leaves behind.
+// prelim_kernel kept the query's window counts (cnt_store, slot order), so nothing is matched or rescored again: the heap is
+// replayed (keys `count << 16 | slot`, PreScore's order inside one query), the tied candidates are looked up in it, and the
+// Feature of the earliest one is written (make_feature, as in the rescoring kernel: rank 1, delta_next = delta_best = 0).
+// Two kernels, one of which runs (the count of tied spectra lives on the device; both are launched, the other one's workgroups
+// leave at once): up to TIE_WAVE_MAX tied spectra a WAVEFRONT each (tie_wave_kernel: the heap one element per lane — the
+// latency of one replay whatever the number of spectra, which is what a step of a narrow search waits for behind its last
+// rescoring wavefront), beyond that a LANE each (tie_kernel: the heap column-interleaved in LDS, 64 lock-step replays per
+// wavefront: ~64 x fewer instructions per spectrum at ~5 x the latency — tie-rich proteomes, where a third of a batch ties).
+constexpr uint32_t TIE_WAVE_MAX = 16384;
+__device__ __forceinline__ SageFeature tie_feature(const DevDbView& db, const DevBatchView& b, const DevWork& w, const TieCand& c, uint32_t spec,
+                                                   const double* __restrict__ lnfact_table, uint32_t lnfact_n) {
+    Score s;
+    s.peptide = 0; s.precursor_charge = 0; s.isotope_error = 0;
+    s.matched_b = c.matched_b; s.matched_y = c.matched_y;
+    s.summed_b = c.summed_b; s.summed_y = c.summed_y; s.ppm_difference = c.ppm_difference;
+    s.longest_b = c.longest_b; s.longest_y = c.longest_y;
+    const uint32_t tot_matched = w.totals[2 * spec], tot_scored = w.totals[2 * spec + 1];
+    const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
+    const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
+    const float rt = b.rt ? b.rt[spec] : 0.0f;
+    float ims = 0.0f;
+    if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
+    const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
+    return make_feature(db, b, spec, c.peptide, c.z_iso & 0xFFu, (int)((c.z_iso >> 8) & 0xFFu) - 128, s, c.hyperscore, c.hyperscore, c.hyperscore, 1u,
+                        lambda, cr_log(lambda), mzp, rt, ims, fid, b.tic[spec], tot_scored, lnfact_table, lnfact_n);
+}
+
+__global__ __launch_bounds__(64) void tie_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w, const double* __restrict__ lnfact_table,
+                                                 uint32_t lnfact_n, SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* const heap = (uint32_t*)smem;  // [kmax][64]
+    uint32_t* const heap = (uint32_t*)smem;                         // [kmax][64]
+    uint32_t* const rec_stage = heap + (size_t)sc.kmax * WAVE;      // [64][FEATURE_WORDS] the winners' records on their way out
+    uint32_t* const spec_stage = rec_stage + WAVE * FEATURE_WORDS;  // [64] their spectra (NONE32: nothing to write)
     const uint32_t lane = lane_id();
-    uint32_t n = uni(w.n_deferred[CTR_FAST_TIE]);
-    n = n < n_max ? n : n_max;
+    uint32_t n = uni(w.n_deferred[CTR_TIE_PAIR]);
+    n = n < b.n ? n : b.n;
+    if (n <= TIE_WAVE_MAX && !(sc.dbg_flags & 2048u)) return;  // tie_wave_kernel's (SAGE_HIP_DEBUG_FLAGS=2048: tests force this one)
     for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
-        const bool act = base + lane < n;
-        uint32_t spec = 0, left = 0, potential = 0;
+        bool act = base + lane < n;
+        TieEntry ent{0u, 0u, 0u, 0u};
+        uint32_t left = 0, potential = 0;
+        const uint32_t* __restrict__ row = w.cnt_store;
         if (act) {
-            spec = w.tie_list[base + lane];
-            const QInfo q = w.qinfo[spec];
-            left = q.left;
-            potential = q.potential;
+            ent = w.tie_ent[base + lane];
+            row = w.cnt_store + (size_t)ent.row * w.cnt_stride;
+            left = row[0];
+            potential = row[1];
+            if (ent.n == 0) {  // its candidates did not fit tie_cand: rescore_kernel queued it for the retry pass itself
+                act = false;
+            } else if (potential == 0) {  // no stored counts (several queries, or the list came from the large-window kernels): the retry pass
+                w.status[ent.spec] = ST_RETRY;
+                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = ent.spec;
+                act = false;
+            }
         }
+        const uint32_t spec = ent.spec;
         const uint32_t k = trim_k(potential, sc.report_psms);
-        const bool trimmed = potential > k;  // heap.rs:8-10: otherwise the slice stays as it is (slot order)
-        const uint4* __restrict__ cnt4 = (const uint4*)(w.cnt_store + (size_t)spec * w.cnt_stride);
+        const bool trimmed = act && potential > k;  // heap.rs:8-10: otherwise the slice stays as it is (slot order)
+        const uint4* __restrict__ cnt4 = (const uint4*)(row + CNT_ROW_HEADER);
         uint32_t* const hp = heap + lane;
         const uint32_t n_chunks = trimmed ? (potential + 7) / 8 : 0u;  // 8 slots (four words of u16 pairs) at a time
         uint4 nxt = n_chunks ? cnt4[0] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t hmin = 0;  // the heap's minimum once it is built (heap.rs:22 compares against it): kept in a register
         for (uint32_t c = 0; __ballot(c < n_chunks) != 0ull; c++) {
             const uint4 cur = nxt;
             if (c + 1 < n_chunks) nxt = cnt4[c + 1];  // (in flight under this chunk's sifts)
@@ -3230,21 +3283,20 @@ __global__ __launch_bounds__(64) void tie_kernel(DevScorer sc, DevWork w, uint32
                 const uint32_t key = cv ? (cv << 16) | slot : 0u;  // (PreScore::default() is the smallest key)
                 if (slot < k) {
                     hp[slot * 64] = key;
-                    if (slot + 1 == k)
+                    if (slot + 1 == k) {
                         for (uint32_t i = k / 2; i-- > 0;) sift_down_strided<uint32_t>(hp, k, i, hp[i * 64]);  // heap.rs:13-15
-                } else if (key > hp[0]) {
+                        hmin = hp[0];
+                    }
+                } else if (key > hmin) {
                     sift_down_strided<uint32_t>(hp, k, 0, key);  // heap.rs:22-25: slice.swap(i, 0); sift_down
+                    hmin = hp[0];
                 }
             }
         }
-        // the earliest tied candidate of the list
-        uint32_t win = 0;
-        if (act) {
-            const SageFeature* __restrict__ recs = w.tie_rec + (size_t)(base + lane) * TIE_RECS;
-            const uint32_t m = recs[0].pad[0] < TIE_RECS ? recs[0].pad[0] : TIE_RECS;
-            uint32_t best_pos = 0xFFFFFFFFu;
-            for (uint32_t j = 0; j < m; j++) {
-                const uint32_t slot = recs[j].peptide_idx - left;
+        if (act) {  // the earliest tied candidate of the list; its record
+            uint32_t win = 0, best_pos = 0xFFFFFFFFu;
+            for (uint32_t j = 0; j < ent.n; j++) {
+                const uint32_t slot = w.tie_cand[ent.first + j].peptide - left;
                 uint32_t pos = 0xFFFFFFFEu;
                 if (!trimmed) {
                     pos = slot;
@@ -3256,24 +3308,116 @@ __global__ __launch_bounds__(64) void tie_kernel(DevScorer sc, DevWork w, uint32
                 }
                 if (pos < best_pos) { best_pos = pos; win = j; }
             }
+            const SageFeature f = tie_feature(db, b, w, w.tie_cand[ent.first + win], spec, lnfact_table, lnfact_n);
+            *(SageFeature*)(rec_stage + (size_t)lane * FEATURE_WORDS) = f;
         }
+        spec_stage[lane] = act ? spec : NONE32;
+        wave_sync();
         // records leave as contiguous 120-byte runs, two per step (lanes 0..29 and 32..61), like the rescoring kernel's
         const uint32_t n_here = n - base < WAVE ? n - base : WAVE;
         for (uint32_t e0 = 0; e0 < n_here; e0 += 2) {
             const uint32_t e = e0 + (lane >> 5), i = lane & 31u;
-            const uint32_t src_lane = e < n_here ? e : e0;
-            const uint32_t e_spec = (uint32_t)__shfl((int)spec, (int)src_lane, 64), e_win = (uint32_t)__shfl((int)win, (int)src_lane, 64);
             if (e < n_here && i < FEATURE_WORDS) {
-                uint32_t v = ((const uint32_t*)(w.tie_rec + (size_t)(base + e) * TIE_RECS + e_win))[i];
-                if (i == 28) v &= 0x0000FFFFu;  // (pad[0] carried the number of tied records)
-                ((uint32_t*)(out + (size_t)e_spec * sc.report_psms))[i] = v;
+                const uint32_t e_spec = spec_stage[e];
+                if (e_spec != NONE32) ((uint32_t*)(out + (size_t)e_spec * sc.report_psms))[i] = rec_stage[e * FEATURE_WORDS + i];
             }
         }
         if (act) {
             out_count[spec] = 1;
             w.status[spec] = ST_DONE;
         }
+        wave_sync();
     }
+}
+
+// the same decision by one wavefront per tied spectrum: counts staged in LDS, the heap in registers (Heap32, as in the exact path
+// of prelim_spectrum), the tied candidates found by a ballot each, the record built by lane 0 and stored by 30 lanes
+// (eight wavefronts per SIMD — 64 VGPRs, the cold Feature code spills — so that every tied spectrum of a batch is resident at once)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tie_wave_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w, const double* __restrict__ lnfact_table,
+                                                      uint32_t lnfact_n, SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = lane_id();
+    uint32_t n = uni(w.n_deferred[CTR_TIE_PAIR]);
+    n = n < b.n ? n : b.n;
+    if (n > TIE_WAVE_MAX || (sc.dbg_flags & 2048u)) return;  // tie_kernel's
+    uint32_t* const rec = (uint32_t*)smem;  // [FEATURE_WORDS + 2] the record on its way out
+    Counters cnt;
+    cnt.p = rec + FEATURE_WORDS + 2;        // [wcap / 2 + 1] the window counts
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const TieEntry ent = w.tie_ent[e];
+        const uint32_t spec = uni(ent.spec), first = uni(ent.first), m = uni(ent.n) < WAVE ? uni(ent.n) : WAVE;
+        const uint32_t* __restrict__ row = w.cnt_store + (size_t)uni(ent.row) * w.cnt_stride;
+        const uint32_t left = uni(row[0]), potential = uni(row[1]);
+        if (m == 0) continue;  // its candidates did not fit tie_cand: rescore_kernel queued it for the retry pass itself
+        if (potential == 0) {  // no stored counts (several queries, or the list came from the large-window kernels): the retry pass
+            if (lane == 0) {
+                w.status[spec] = ST_RETRY;
+                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
+            }
+            continue;
+        }
+        const uint32_t k = trim_k(potential, sc.report_psms);
+        // lane j < m: the j-th tied candidate — its whole Feature now, all candidates side by side and their loads in flight
+        // together with the counts', so that nothing but the replay itself stands between the counts and the record
+        SageFeature mine_f;
+        uint32_t my_pep = 0u;
+        wave_sync();
+        for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt.p[i] = row[CNT_ROW_HEADER + i];
+        if (lane < m) {
+            const TieCand c = w.tie_cand[first + lane];
+            my_pep = c.peptide;
+            mine_f = tie_feature(db, b, w, c, spec, lnfact_table, lnfact_n);
+        }
+        wave_sync();
+        uint32_t h = 0;  // lane j: entry j of the trimmed list (key `count << 16 | slot`, 0: PreScore::default())
+        if (potential > k) {
+            Heap32 hp;
+            {
+                const uint32_t c = lane < k ? cnt.get(lane) : 0;
+                wh32_init(hp, c ? (c << 16) | lane : 0u, k);
+            }
+            wh32_build(hp, k);
+            for (uint32_t base = k; base < potential; base += WAVE) {
+                const uint32_t i = base + lane;
+                const uint32_t c = i < potential ? cnt.get(i) : 0;
+                const uint32_t v = (c << 16) | i;
+                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> 16));  // (prelim_spectrum's exact path)
+                while (mask) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                }
+            }
+            h = hp.h;
+        } else {  // heap.rs:8-10: the slice stays as it is — slot order
+            const uint32_t c = lane < potential ? cnt.get(lane) : 0;
+            h = c ? (c << 16) | lane : 0u;
+        }
+        uint32_t win = 0, best_pos = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)my_pep, (int)j) - left;
+            const uint64_t at = __ballot(lane < k && h != 0u && (h & 0xFFFFu) == slot);
+            const uint32_t pos = at ? (uint32_t)__ffsll((long long)at) - 1 : 0xFFFFFFFEu;
+            if (pos < best_pos) { best_pos = pos; win = j; }
+        }
+        if (lane == win) *(SageFeature*)rec = mine_f;
+        wave_sync();
+        if (lane < FEATURE_WORDS) ((uint32_t*)(out + (size_t)spec * sc.report_psms))[lane] = rec[lane];
+        if (lane == 0) {
+            out_count[spec] = 1;
+            w.status[spec] = ST_DONE;
+        }
+    }
+}
+
+// The way home of a step's small results in ONE launch (page-locked, mapped destinations): the PSM counts of every spectrum and
+// the counter blocks of the step's parts.  Three copy commands at the end of a 1 ms step cost ~60 us of command gaps.
+__global__ __launch_bounds__(256) void epilogue_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ h_counts,
+                                                       EpilogueParts parts) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_counts[i] = counts[i];
+    if (blockIdx.x == 0)
+        for (uint32_t p = 0; p < parts.n; p++)
+            for (uint32_t i = threadIdx.x; i < 2 * CTR_COUNT; i += blockDim.x) parts.dst[p][i] = parts.src[p][i];
 }
 
 // quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
@@ -3461,11 +3605,23 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
     hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
                        (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
 }
-void launch_tie(const DevScorer& sc, const DevWork& w, uint32_t n_max, SageFeature* out, uint32_t* out_count, void* stream) {
-    if (n_max == 0 || !w.tie_rec) return;
-    const uint32_t blocks = (n_max + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL(tie_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(64), (size_t)sc.kmax * WAVE * 4, (hipStream_t)stream, sc, w, n_max,
-                       out, out_count);
+void launch_tie(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
+                uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream) {
+    if (b.n == 0 || !w.tie_ent) return;
+    // (both: which one has work is known on the device only — tie_wave_kernel up to TIE_WAVE_MAX tied spectra, tie_kernel beyond)
+    hipLaunchKernelGGL(tie_wave_kernel, dim3(b.n < 8192u ? b.n : 8192u), dim3(64), ((size_t)FEATURE_WORDS + 2 + sc.wcap / 2 + 2) * 4,
+                       (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
+    if (b.n > TIE_WAVE_MAX || (sc.dbg_flags & 2048u)) {
+        const uint32_t blocks = (b.n + WAVE - 1) / WAVE;
+        const size_t lds = ((size_t)sc.kmax * WAVE + (size_t)WAVE * FEATURE_WORDS + WAVE) * 4;
+        hipLaunchKernelGGL(tie_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(64), lds, (hipStream_t)stream, db, sc, b, w, lnfact_table,
+                           lnfact_n, out, out_count);
+    }
+}
+void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream) {
+    const uint32_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(epilogue_kernel, dim3(blocks ? (blocks < 512u ? blocks : 512u) : 1u), dim3(256), 0, (hipStream_t)stream, counts, n, h_counts,
+                       parts);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
     if (b.n == 0) return;

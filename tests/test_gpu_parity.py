@@ -373,6 +373,10 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     assert t["n_tied"] > 50 and t["n_retry"] <= 2 and t["n_wide"] == 0
     n, t = w.check(ScorerParams(precursor_tol=wide, min_matched_peaks=1, fragment_tol=Tolerance("da", -0.5, 0.5)), "one PSM, loose fragments")
     assert t["n_tied"] > 50
+    monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", "2048")  # the lane-per-spectrum tie kernel (by itself it takes over above 16 384 ties)
+    n, t = w.check(ScorerParams(precursor_tol=wide), "I/L twins, narrow, one PSM: cheap ties, a lane per spectrum")
+    assert t["n_tied"] > 50 and t["n_retry"] <= 2
+    monkeypatch.delenv("SAGE_HIP_DEBUG_FLAGS")
     monkeypatch.setenv("SAGE_HIP_NO_FAST_TIES", "1")
     n, t = w.check(ScorerParams(precursor_tol=wide), "I/L twins, narrow, one PSM, cheap ties off")
     assert t["n_retry"] > 50 and t["n_tied"] == 0
@@ -385,7 +389,7 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     unknown = SpectrumBatch(b0.peak_off, b0.masses, b0.intensities, b0.precursor_mz, np.zeros(b0.n, np.uint8), b0.total_ion_current,
                             b0.isolation_lo, b0.isolation_hi, b0.scan_start_time, b0.inverse_ion_mobility, b0.file_id)
     n, t = w.check(ScorerParams(precursor_tol=wide), "one PSM, unknown charges", batch=unknown)
-    assert t["n_retry"] > 20 and t["n_tied"] == 0
+    assert t["n_retry"] > 20 and t["n_retry"] >= t["n_tied"]  # (parked by rescore_kernel, passed on by the tie kernel: every one retried)
     # families of EIGHT peptides with identical masses and fragments (isoleucine / leucine at three positions): more candidates
     # share the best hyperscore than rescore_kernel parks records for (TIE_RECS = 4) — those spectra take the retry pass
     rng = np.random.default_rng(41)
