@@ -698,6 +698,12 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_REPLAY_WAVE_MAX")) s->replay_split = (uint64_t)atoll(e) & 0xFFFFFFFFull;
     if (const char* e = getenv("SAGE_HIP_REPLAY_LANE_MAX")) s->replay_split |= (uint64_t)(uint32_t)atoll(e) << 32;
     if (const char* e = getenv("SAGE_HIP_ONE_LAUNCH")) s->one_launch = atoi(e) != 0;
+#ifndef SAGE_HIP_EXPERIMENTS
+    // the losing first-pass experiments of DESIGN.md 4.7 (search_kernel, the fused kernel as the first pass) are compiled into
+    // builds with -DSAGE_HIP_EXPERIMENTS only (scripts/variants.sh exp:"-DSAGE_HIP_EXPERIMENTS")
+    if (s->one_launch || s->fused || getenv("SAGE_HIP_SEARCH_LAG"))
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "SAGE_HIP_ONE_LAUNCH / SAGE_HIP_FUSED / SAGE_HIP_SEARCH_LAG need a build with -DSAGE_HIP_EXPERIMENTS");
+#endif
     if (const char* e = getenv("SAGE_HIP_NO_ZEROCOPY")) s->zero_copy = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_NO_FAST_TIES")) s->fast_ties = atoi(e) == 0;
     if (const char* e = getenv("SAGE_HIP_WCAP")) d.wcap = (uint32_t)std::min(16384, std::max(64, atoi(e)));  // (32-bit heap keys need <= 65536)

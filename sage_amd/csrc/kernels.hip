@@ -3019,6 +3019,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
                      sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
+#ifdef SAGE_HIP_EXPERIMENTS  // (measured slower than the two kernels, DESIGN.md 4.7: compiled only into experiment builds)
 // ---- the first pass of a narrow search as ONE launch of two kinds of workgroups ----------------------------------------------------
 // Matching + k-select (prelim_spectrum) and rescoring (rescore_spectrum) are separate wavefronts, as in prelim_kernel /
 // rescore_kernel — each body keeps its own register allocation; one wavefront doing both (narrow_kernel) pays 70-100 spills — but
@@ -3128,6 +3129,8 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
                                        st == ST_OK_ORDERED, true, pc);
     if (done && lane == 0) w.status[spec] = ST_DONE;  // (a rescore_kernel behind the large-window kernels leaves it alone)
 }
+
+#endif  // SAGE_HIP_EXPERIMENTS
 
 // ---- the narrow search in ONE launch ---------------------------------------------------------------------------------------------
 // Scorer::score of a spectrum whose precursor windows fit the LDS counters: preliminary matching + k-select (prelim_spectrum)
@@ -3518,6 +3521,7 @@ size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, b
 }
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return narrow_scratch_bytes(sc, b) + rescore_fixed_bytes(sc, b); }
 
+#ifdef SAGE_HIP_EXPERIMENTS
 size_t search_lds_bytes(const DevScorer& sc, const DevBatchView& b) {
     const size_t a = prelim_layout_bytes(sc, b), r = rescore_lds_bytes(sc, b, 0, false);
     return a > r ? a : r;
@@ -3530,6 +3534,10 @@ void launch_search(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     hipLaunchKernelGGL(k, dim3(2 * search_slots(b.n)), dim3(64), search_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w, lnfact_table,
                        lnfact_n, out, out_count);
 }
+#else
+size_t search_lds_bytes(const DevScorer&, const DevBatchView&) { return 0; }
+void launch_search(const DevDbView&, const DevScorer&, const DevBatchView&, const DevWork&, const double*, uint32_t, SageFeature*, uint32_t*, void*) {}
+#endif
 void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
                    uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream) {
     if (b.n == 0) return;

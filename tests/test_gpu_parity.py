@@ -344,6 +344,20 @@ def test_quick_score_prefilter(small_world, low_memory):
         assert gk.sum() > 10
 
 
+def _experiments_built(world, monkeypatch):
+    """The library was built with -DSAGE_HIP_EXPERIMENTS (search_kernel, the fused kernel as a first pass): a default build refuses
+    their environment switches when a scorer is created."""
+    monkeypatch.setenv("SAGE_HIP_ONE_LAUNCH", "1")
+    try:
+        Scorer(world.dev, ScorerParams()).close()
+        return True
+    except L.SageHipError as e:
+        assert "SAGE_HIP_EXPERIMENTS" in str(e)
+        return False
+    finally:
+        monkeypatch.delenv("SAGE_HIP_ONE_LAUNCH")
+
+
 def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     """Order-free trims (the default) are only valid while no two equal hyperscores meet at a reported rank; isoleucine /
     leucine twins (identical masses and fragments) tie exactly, so those spectra must come back through the exact heap
@@ -419,13 +433,14 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     monkeypatch.delenv("SAGE_HIP_WAYS")
     n, t = w.check(ScorerParams(chimera=True, report_psms=3, precursor_tol=wide), "I/L twins, chimera")
     assert t["n_retry"] > 50
-    monkeypatch.setenv("SAGE_HIP_FUSED", "1")  # the fused narrow kernel: the wavefront goes round again with exact trims
-    n, t = w.check(ScorerParams(report_psms=2, precursor_tol=wide), "I/L twins, narrow, fused kernel")
-    assert t["n_tied"] > 50 and t["n_retry"] == 0
-    n, t = w.check(ScorerParams(chimera=True, report_psms=3, precursor_tol=wide), "I/L twins, chimera, fused kernel")
-    assert t["n_tied"] > 50
-    n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2, precursor_tol=wide), "I/L twins, isotope errors, fused kernel")
-    monkeypatch.delenv("SAGE_HIP_FUSED")
+    if _experiments_built(w, monkeypatch):  # (the losing first-pass experiments of DESIGN.md 4.7: builds with -DSAGE_HIP_EXPERIMENTS only)
+        monkeypatch.setenv("SAGE_HIP_FUSED", "1")  # the fused narrow kernel: the wavefront goes round again with exact trims
+        n, t = w.check(ScorerParams(report_psms=2, precursor_tol=wide), "I/L twins, narrow, fused kernel")
+        assert t["n_tied"] > 50 and t["n_retry"] == 0
+        n, t = w.check(ScorerParams(chimera=True, report_psms=3, precursor_tol=wide), "I/L twins, chimera, fused kernel")
+        assert t["n_tied"] > 50
+        n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2, precursor_tol=wide), "I/L twins, isotope errors, fused kernel")
+        monkeypatch.delenv("SAGE_HIP_FUSED")
     monkeypatch.setenv("SAGE_HIP_WAYS", "3")  # a resident step in three parts on three streams (needs >= 8192 spectra per part)
     big = w.batch.subset(np.arange(3 * 8192) % w.batch.n)
     p2 = ScorerParams(report_psms=2, precursor_tol=wide)
@@ -436,11 +451,12 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     assert_features_equal(gf, gc, of, oc, "I/L twins, narrow, three parts side by side")
     assert t["n_ways"] == 3 and t["n_retry"] > 50
     monkeypatch.delenv("SAGE_HIP_WAYS")
-    monkeypatch.setenv("SAGE_HIP_ONE_LAUNCH", "1")  # preliminary and rescoring workgroups in one launch, handing over through HBM
-    n, t = w.check(ScorerParams(report_psms=2, precursor_tol=wide), "I/L twins, narrow, one launch")
-    assert t["n_retry"] > 50
-    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0), chimera=True, report_psms=3), "I/L twins, mixed routing, chimera, one launch")
-    monkeypatch.delenv("SAGE_HIP_ONE_LAUNCH")
+    if _experiments_built(w, monkeypatch):
+        monkeypatch.setenv("SAGE_HIP_ONE_LAUNCH", "1")  # preliminary and rescoring workgroups in one launch, handing over through HBM
+        n, t = w.check(ScorerParams(report_psms=2, precursor_tol=wide), "I/L twins, narrow, one launch")
+        assert t["n_retry"] > 50
+        n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0), chimera=True, report_psms=3), "I/L twins, mixed routing, chimera, one launch")
+        monkeypatch.delenv("SAGE_HIP_ONE_LAUNCH")
     n, t = w.check(ScorerParams(min_isotope_err=-1, max_isotope_err=3, report_psms=2, precursor_tol=wide), "I/L twins, isotope errors")
     assert t["n_retry"] > 50 and t["n_tied"] == 0
     monkeypatch.setenv("SAGE_HIP_ASSUME_NARROW", "1")  # a batch wrongly taken for narrow-only is scored again with the large-window kernels
