@@ -454,75 +454,49 @@ SAGE_HD int select_peak_lut(const float* pm, const float* pi, uint32_t P, const 
 }
 
 // ---- peak-presence bitmap (rescore_kernel's filter in front of select_most_intense_peak) --------------------------------
-// PBM_BITS mass bins of width wb (a power of two, so bin() is exact).  Every peak sets the bins that overlap [mass - D,
-// mass + D], where D bounds |peak - mz| over every (mz, matching peak) pair the fragment tolerance admits below the bitmap's
-// span; an ion whose own bin is clear cannot match any peak.  Conservative by construction (never drops a match —
-// tests/test_core_emulation.py checks it against Tolerance::bounds on adversarial inputs); when that cannot be guaranteed
-// (non-finite masses, a tolerance of a quarter of the mass range and more, more than 64 bins per peak) `ok` is false and
-// every bin counts as set.
-// (16 384 bins, 2 KB of LDS: a +-10 ppm search bins a 2 000 Da spectrum at 0.125 Da and ~1.2 % of the bins are set — about as many
-// false positives as true matches; with 8 192 bins the hits to examine were 30 % more and rescore_kernel 2 % slower)
+// PBM_BITS mass bins of a FIXED width of 1/8 Da, the bin index taken modulo PBM_BITS (masses 2048 Da apart share a bin: a
+// Bloom filter with one hash).  Every peak sets the bins that overlap [mass - D, mass + D], D bounding |mz - mass| over every
+// m/z whose tolerance window (Tolerance::bounds, mass.rs:21-35) contains the peak, plus the roundings; an ion whose bin is clear
+// cannot match any peak.  The bin of an ion's m/z at fragment charge c is the bin of the EXACT quotient: x = floor(8 ion) (the
+// product by a power of two is exact), floor(x / c) == floor(8 ion / c).  Round 3 sized the bins per spectrum (a power of two
+// covering the spectrum's span): that cost a multiply by a per-spectrum scale, a clamp of the conversion (v_med3_f32) and a
+// clamp per charge; with the fixed width and the modulo none of them is needed — the conversion saturates on its own, and
+// wherever that could matter (negative, non-finite or absurd masses) the bitmap is all ones.
+// Conservative by construction (tests/test_core_emulation.py checks it against Tolerance::bounds on adversarial inputs); when
+// that cannot be guaranteed (non-finite or negative masses, non-finite tolerances, a relative tolerance of a quarter and more,
+// D above 4 Da) every bin is set.
 constexpr uint32_t PBM_BITS = 16384, PBM_WORDS = PBM_BITS / 32;
-struct PeakBitmap {
-    float inv_wb;  // 1 / bin width; 0 when !ok (every mz then lands in bin 0 of an all-ones bitmap)
-    float D;
-    bool ok;
-};
-// top / first: the largest and the smallest peak mass (the peaks are mass-sorted); n_peaks == 0: top = first = 0
-SAGE_HD PeakBitmap peak_bitmap_params(float top, float first, const Tol& t) {
+constexpr float PBM_INV_W = 8.0f;  // bins per Da (a power of two: mass * PBM_INV_W is exact)
+constexpr float PBM_MAX_D = 4.0f;  // 32 bins either side
+// x of an ion: floor(8 ion), saturating (a negative or NaN ion gives 0, an absurd one 2^32 - 1: such ions match no peak of a
+// spectrum the filter is active for)
+SAGE_HD uint32_t pbm_index(float ion) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(ion * PBM_INV_W);  // v_mul_f32 + v_cvt_u32_f32 (saturating, NaN -> 0)
+#else
+    const float f = ion * PBM_INV_W;
+    return f >= 4294967296.0f ? 0xFFFFFFFFu : f > 0.0f ? (uint32_t)f : 0u;  // (also maps NaN to 0)
+#endif
+}
+SAGE_HD uint32_t pbm_bin_c1(uint32_t x) { return x & (PBM_BITS - 1u); }
+SAGE_HD uint32_t pbm_bin_c2(uint32_t x) { return (x >> 1) & (PBM_BITS - 1u); }
+SAGE_HD uint32_t pbm_bin_c3(uint32_t x) { return (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33) & (PBM_BITS - 1u); }  // x / 3 for every u32
+// D of a peak of mass m; false: no safe bound (every bin of the bitmap is to be set)
+SAGE_HD bool pbm_peak_reach(const Tol& t, float m, float& D) {
     const float tmax = __builtin_fmaxf(__builtin_fabsf(t.lo), __builtin_fabsf(t.hi));
-    // Tolerance::bounds (mass.rs:21-35): a window relative to the centre (ppm, pct) or absolute (Da)
-    const bool relative = t.kind != 2;
     const float rel = t.kind == 0 ? tmax * 1.0e-6f : t.kind == 1 ? tmax * 1.0e-2f : 0.0f;
-    bool ok = top == top && top < 1.0e30f && tmax == tmax && (relative ? rel < 0.25f : tmax < 1.0e30f) && first == first;
-    // span = PBM_BITS * wb must exceed every mz that can still reach a peak: top * (1 + 2 tol) + 1, resp. top + 2 tol + 1
-    const float reach = relative ? top * (1.0f + 2.0f * rel) + 1.0f : top + 2.0f * tmax + 1.0f;
-    float wb = 1.0f / 64.0f;
-    while (ok && (float)PBM_BITS * wb <= reach && wb < 1.0e30f) wb *= 2.0f;
-    const float span = (float)PBM_BITS * wb;
-    // D: the widest half window below `span`, a relative 1e-4 for the roundings inside Tolerance::bounds, and 8 ulp(span)
-    // for the rounding of mz / charge through a reciprocal and of mass -+ D
-    PeakBitmap r;
-    r.D = (relative ? span * rel : tmax) * 1.0001f + span * (1.0f / 1048576.0f);
-    if (r.D > 32.0f * wb) ok = false;  // (a peak would set more than 64 bins: no filter)
-    r.ok = ok;
-    r.inv_wb = ok ? 1.0f / wb : 0.0f;
-    return r;
+    D = 0.0f;
+    if (!(tmax == tmax) || !(tmax < 1.0e30f) || !(rel < 0.25f) || !(m >= 0.0f) || !(m < 8388608.0f)) return false;
+    // relative tolerances: the window of centre c contains m only if |c - m| <= m rel / (1 - rel); 1e-4 for the roundings inside
+    // Tolerance::bounds, 2^-20 m for those of ion / charge and of m -+ D, 2^-20 absolute for tiny masses
+    D = (t.kind == 2 ? tmax : m * (rel / (1.0f - rel))) * 1.0001f + m * (1.0f / 1048576.0f) + (1.0f / 1048576.0f);
+    return D <= PBM_MAX_D;
 }
-// bins [b0, b1] a peak of mass m sets (m is not NaN)
-SAGE_HD void peak_bitmap_span(const PeakBitmap& pb, float m, uint32_t& b0, uint32_t& b1) {
-    float f0 = (m - pb.D) * pb.inv_wb, f1 = (m + pb.D) * pb.inv_wb;
-    f0 = f0 > 0.0f ? f0 : 0.0f;
-    f1 = f1 > 0.0f ? f1 : 0.0f;
-    b0 = f0 < (float)(PBM_BITS - 1) ? (uint32_t)f0 : PBM_BITS - 1;
-    b1 = f1 < (float)(PBM_BITS - 1) ? (uint32_t)f1 : PBM_BITS - 1;
+// bins [b0, b1] (before the modulo) a peak of mass m >= 0 sets
+SAGE_HD void pbm_peak_span(float m, float D, uint32_t& b0, uint32_t& b1) {
+    const float f0 = (m - D) * PBM_INV_W, f1 = (m + D) * PBM_INV_W;
+    b0 = f0 > 0.0f ? (uint32_t)f0 : 0u;
+    b1 = f1 > 0.0f ? (uint32_t)f1 : 0u;
 }
-// bin of an ion's m/z (an approximate ion / charge is enough: D carries the slack): clamp to [0, PBM_BITS - 1], truncate
-SAGE_HD uint32_t peak_bitmap_bin(float inv_wb, float mz) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_fmed3f(mz * inv_wb, 0.0f, (float)(PBM_BITS - 1));  // one v_med3_f32; a NaN comes out as a bound
-#else
-    const float f = mz * inv_wb;
-    return (uint32_t)(f > 0.0f ? (f < (float)(PBM_BITS - 1) ? f : (float)(PBM_BITS - 1)) : 0.0f);  // (also maps NaN to 0)
-#endif
-}
-
-// The bins of one ion for fragment charges 1..3 from ONE conversion: inv_wb is a power of two (or 0), so x = ion * inv_wb is
-// exact and floor(floor(x) / c) == floor(x / c) is the bin of the EXACT quotient ion / c — at least as close to the reference's
-// rounded ion / charge as the approximate quotients peak_bitmap_bin is fed (the slack in D covers half an ulp either way).  The
-// conversion is clamped at 3 * PBM_BITS - 1 rather than PBM_BITS - 1: an ion beyond the bitmap's span may still have its half or
-// its third inside it.  bins[c - 1] <= PBM_BITS - 1.
-SAGE_HD uint32_t peak_bitmap_index3(float inv_wb, float ion) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_fmed3f(ion * inv_wb, 0.0f, (float)(3 * PBM_BITS - 1));
-#else
-    const float f = ion * inv_wb;
-    return (uint32_t)(f > 0.0f ? (f < (float)(3 * PBM_BITS - 1) ? f : (float)(3 * PBM_BITS - 1)) : 0.0f);  // (also maps NaN to 0)
-#endif
-}
-SAGE_HD uint32_t peak_bitmap_bin_c1(uint32_t idx3) { return idx3 < PBM_BITS - 1 ? idx3 : PBM_BITS - 1; }
-SAGE_HD uint32_t peak_bitmap_bin_c2(uint32_t idx3) { return (idx3 >> 1) < PBM_BITS - 1 ? (idx3 >> 1) : PBM_BITS - 1; }
-SAGE_HD uint32_t peak_bitmap_bin_c3(uint32_t idx3) { return (idx3 * 43691u) >> 17; }  // == idx3 / 3 for idx3 < 2^16 (43691 = ceil(2^17 / 3))
-static_assert(3 * PBM_BITS - 1 < 65536, "the multiply-shift division by three holds below 2^16");
 
 }  // namespace sagecore

@@ -2175,27 +2175,35 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
 constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COOP_MAX_LANES;
 constexpr uint32_t TILE_GRID_CAP = 32768;
 constexpr uint32_t RETRY_GRID_CAP = 8192;   // blocks of the narrow exact retry pass  // blocks of the per-query / per-item kernels of the large-window path
-__device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, float& inv_wb, const float* pm, uint32_t P, const Tol& t) {
+__device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm, uint32_t P, const Tol& t) {
     const uint32_t lane = lane_id();
-    const PeakBitmap pb = peak_bitmap_params(P ? pm[P - 1] : 0.0f, P ? pm[0] : 0.0f, t);
-    inv_wb = pb.inv_wb;
-    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = pb.ok ? 0u : 0xFFFFFFFFu;
+    // usable at all?  every peak needs a finite, non-negative mass and a reach D of at most 32 bins (core.h: pbm_peak_reach)
+    bool bad = false;
+    for (uint32_t i = lane; i < P; i += WAVE) {
+        float D;
+        bad = bad || !pbm_peak_reach(t, pm[i], D);
+    }
+    const bool ok = __ballot(bad) == 0ull;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)bm != 0u) __builtin_trap();  // (pbm_bit: the bitmap at LDS address 0)
+    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = ok ? 0u : 0xFFFFFFFFu;
     __syncthreads();
-    if (!pb.ok) return;
+    if (!ok) return;
     for (uint32_t i = lane; i < P; i += WAVE) {
         const float m = pm[i];
-        if (!(m == m)) continue;  // (a NaN mass never satisfies `mass >= lo && mass <= hi`)
+        float D;
+        pbm_peak_reach(t, m, D);
         uint32_t b0, b1;
-        peak_bitmap_span(pb, m, b0, b1);
-        for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[bin >> 5], 1u << (bin & 31u));
+        pbm_peak_span(m, D, b0, b1);
+        for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[(bin & (PBM_BITS - 1u)) >> 5], 1u << (bin & 31u));
     }
 }
-__device__ __forceinline__ uint32_t bitmap_bit(const uint32_t* bm, uint32_t bin) {
-    return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
-}
-__device__ __forceinline__ uint32_t peak_bitmap_test(const uint32_t* bm, float inv_wb, float mz) {
-    const uint32_t bin = peak_bitmap_bin(inv_wb, mz);
-    return __builtin_amdgcn_ubfe(bm[bin >> 5], bin, 1u);  // (v_bfe_u32 takes the offset modulo 32)
+// The bit of bin `x` modulo PBM_BITS (x: pbm_index of the ion, halved or divided by three for charges 2 and 3).  The bitmap sits at
+// LDS address 0 (the scratch part of the rescoring LDS comes first in every kernel that rescores, none of which has static LDS;
+// build_peak_bitmap checks it), so the word's byte offset IS its LDS address: (x >> 3) & 0x7FC, ds_read_b32, v_bfe_u32.
+typedef const __attribute__((address_space(3))) uint32_t* LdsWordPtr;
+__device__ __forceinline__ uint32_t pbm_bit(uint32_t x) {
+    const uint32_t w = *(LdsWordPtr)(uintptr_t)((x >> 3) & ((PBM_WORDS - 1u) << 2));
+    return __builtin_amdgcn_ubfe(w, x, 1u);  // (v_bfe_u32 takes the offset modulo 32)
 }
 
 // remove_matched_peaks (scoring.rs:598-644) on the LDS copy of the spectrum: drop every peak whose (mass, intensity)
@@ -2329,7 +2337,7 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
 //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
 //      adds per match) and handed back to the candidate's lane.
 __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
-                                                 const float* pm, const float* pi, const uint32_t P, const float inv_w, const float inv_wb,
+                                                 const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
                                                  const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
                                                  Score& s) {
@@ -2350,20 +2358,17 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
             for (uint32_t r = 0; r < n_here; r += 4) {
                 const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
                 n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
-                // one conversion per ion; the bins of its charge states are integer halves / thirds of it (core.h)
-                const uint32_t x0 = peak_bitmap_index3(inv_wb, i0), x1 = peak_bitmap_index3(inv_wb, i1),
-                               x2 = peak_bitmap_index3(inv_wb, i2), x3 = peak_bitmap_index3(inv_wb, i3);
-                const uint32_t t1 = bitmap_bit(pbm, peak_bitmap_bin_c1(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x1)) << 1) |
-                                    (bitmap_bit(pbm, peak_bitmap_bin_c1(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c1(x3)) << 3);
+                // one conversion per ion; the bins of its charge states are integer halves / thirds of it (core.h: pbm_index)
+                const uint32_t x0 = pbm_index(i0), x1 = pbm_index(i1), x2 = pbm_index(i2), x3 = pbm_index(i3);
+                const uint32_t t1 = pbm_bit(x0) | (pbm_bit(x1) << 1) | (pbm_bit(x2) << 2) | (pbm_bit(x3) << 3);
                 m1 |= (uint64_t)t1 << r;
                 if (any_fz2) {  // (wave-uniform: some candidate of this spectrum has fragment charge 2)
-                    const uint32_t t2 = bitmap_bit(pbm, peak_bitmap_bin_c2(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x1)) << 1) |
-                                        (bitmap_bit(pbm, peak_bitmap_bin_c2(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c2(x3)) << 3);
+                    const uint32_t t2 = pbm_bit(x0 >> 1) | (pbm_bit(x1 >> 1) << 1) | (pbm_bit(x2 >> 1) << 2) | (pbm_bit(x3 >> 1) << 3);
                     m2 |= (uint64_t)t2 << r;
                 }
                 if (any_fz3) {
-                    const uint32_t t3 = bitmap_bit(pbm, peak_bitmap_bin_c3(x0)) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x1)) << 1) |
-                                        (bitmap_bit(pbm, peak_bitmap_bin_c3(x2)) << 2) | (bitmap_bit(pbm, peak_bitmap_bin_c3(x3)) << 3);
+                    const uint32_t t3 = pbm_bit(__umulhi(x0, 0xAAAAAAABu) >> 1) | (pbm_bit(__umulhi(x1, 0xAAAAAAABu) >> 1) << 1) |
+                                        (pbm_bit(__umulhi(x2, 0xAAAAAAABu) >> 1) << 2) | (pbm_bit(__umulhi(x3, 0xAAAAAAABu) >> 1) << 3);
                     m3 |= (uint64_t)t3 << r;
                 }
             }
@@ -2596,13 +2601,12 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
-    float inv_wb = 0.0f;
     const bool any_fz2 = __ballot(valid && nfz >= 2) != 0ull, any_fz3 = __ballot(valid && nfz >= 3) != 0ull;
     for (uint32_t round = 0; round < rounds; round++) {
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
         // (built once: after remove_matched_peaks the bitmap is a superset of the remaining peaks' bins — still conservative)
-        if (round == 0) build_peak_bitmap(pbm, inv_wb, pm, P, sc.fragment_tol);
+        if (round == 0) build_peak_bitmap(pbm, pm, P, sc.fragment_tol);
         __syncthreads();
         Score s;
         s.peptide = 0;  // (the lane's pep / z / iso stand in for the fields of the same name)
@@ -2612,7 +2616,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.summed_b = s.summed_y = 0.0f;
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
-        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, inv_wb, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
+        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
         pc.mark(1);
         double h = 0.0;
         bool pass = false;
@@ -2840,12 +2844,11 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
         for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
         const long long lowest = (long long)0x8000000000000000ull;
         uint32_t n_emitted = 0;
-        float inv_wb = 0.0f;
         __syncthreads();
         for (uint32_t round = 0; round < rounds; round++) {
             float inv_w;
             build_peak_lut(plut, inv_w, pm, P);
-            if (round == 0) build_peak_bitmap(pbm, inv_wb, pm, P, sc.fragment_tol);
+            if (round == 0) build_peak_bitmap(pbm, pm, P, sc.fragment_tol);
             __syncthreads();
             uint32_t npass = 0;
             for (uint32_t base = 0; base < ncand; base += WAVE) {
@@ -2871,7 +2874,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                 s.summed_b = s.summed_y = 0.0f;
                 s.ppm_difference = 0.0f;
                 s.longest_b = s.longest_y = 0;
-                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, inv_wb, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
+                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
                 double h = 0.0;
                 bool pass = false;
                 bool ln_undecided;  // (never: both phases)

@@ -85,44 +85,47 @@ int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, fl
     return select_peak_lut(masses, intens, n, plut.data(), 1.0f / w, lo, hi);
 }
 
-// rescore_kernel's peak-presence filter (core.h: peak_bitmap_*) against the thing it must never contradict: for every ion and
-// fragment charge 1..3, "some peak lies inside Tolerance::bounds(ion / charge)" implies "the bit of the ion's bin is set".
-// The bin is taken the way the kernel takes it (peak_bitmap_index3: one conversion of the ion, integer halves and thirds) and
-// also from the approximate quotients x * 0.5f, x * (1 / 3.0f) (peak_bitmap_bin); the window from the exact quotient.  Returns the number of violations; counts matches and set bits among the items for the statistics.
+// rescore_kernel's peak-presence filter (core.h: pbm_*) against the thing it must never contradict: for every ion and fragment
+// charge 1..3, "some peak lies inside Tolerance::bounds(ion / charge)" implies "the bit of the ion's bin is set".  The bitmap is
+// built as build_peak_bitmap (kernels.hip) builds it, the bins are taken the way the kernel takes them (one conversion of the
+// ion, integer halves and thirds, modulo the bitmap).  Returns the number of violations; counts matches and set bits among the
+// items for the statistics.
 uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, float tlo, float thi, const float* ions, uint32_t m,
                                     uint32_t* n_match, uint32_t* n_set, int* filter_active) {
     Tol t{kind, tlo, thi};
-    const PeakBitmap pb = peak_bitmap_params(n ? masses[n - 1] : 0.0f, n ? masses[0] : 0.0f, t);
-    std::vector<uint32_t> bm(PBM_WORDS, pb.ok ? 0u : 0xFFFFFFFFu);
-    if (pb.ok)
+    bool ok = true;
+    for (uint32_t i = 0; i < n && ok; i++) {
+        float D;
+        ok = pbm_peak_reach(t, masses[i], D);  // (a NaN or negative mass: the filter is switched off)
+    }
+    std::vector<uint32_t> bm(PBM_WORDS, ok ? 0u : 0xFFFFFFFFu);
+    if (ok)
         for (uint32_t i = 0; i < n; i++) {
-            if (!(masses[i] == masses[i])) continue;
+            float D;
+            pbm_peak_reach(t, masses[i], D);
             uint32_t b0, b1;
-            peak_bitmap_span(pb, masses[i], b0, b1);
-            for (uint32_t b = b0; b <= b1; b++) bm[b >> 5] |= 1u << (b & 31u);
+            pbm_peak_span(masses[i], D, b0, b1);
+            for (uint32_t b = b0; b <= b1; b++) bm[(b & (PBM_BITS - 1u)) >> 5] |= 1u << (b & 31u);
         }
-    *filter_active = pb.ok ? 1 : 0;
+    *filter_active = ok ? 1 : 0;
     uint32_t bad = 0;
     *n_match = *n_set = 0;
-    for (uint32_t j = 0; j < m; j++)
+    for (uint32_t j = 0; j < m; j++) {
+        const uint32_t x = pbm_index(ions[j]);
+        if (pbm_bin_c3(x) != ((x / 3u) & (PBM_BITS - 1u))) bad++;  // (the multiply-shift is a division by three)
         for (uint32_t c = 1; c <= 3; c++) {
-            const float exact = c == 1 ? ions[j] : ions[j] / (float)c;
-            const float approx = c == 1 ? ions[j] : c == 2 ? ions[j] * 0.5f : ions[j] * (1.0f / 3.0f);
+            const float mz = c == 1 ? ions[j] : ions[j] / (float)c;  // scoring.rs:707: the reference's own quotient
             float lo, hi;
-            tol_bounds(t, exact, lo, hi);
+            tol_bounds(t, mz, lo, hi);
             bool match = false;
             for (uint32_t i = 0; i < n && !match; i++) match = masses[i] >= lo && masses[i] <= hi;  // spectrum.rs:147-157
-            const uint32_t bin_a = peak_bitmap_bin(pb.inv_wb, approx);
-            // the kernel's form: the bins of all three charges from one conversion of the ion (peak_bitmap_index3)
-            const uint32_t i3 = peak_bitmap_index3(pb.inv_wb, ions[j]);
-            const uint32_t bin = c == 1 ? peak_bitmap_bin_c1(i3) : c == 2 ? peak_bitmap_bin_c2(i3) : peak_bitmap_bin_c3(i3);
-            if (peak_bitmap_bin_c3(i3) != i3 / 3) bad++;  // (the multiply-shift is a division by three)
-            bad += match && !((bm[bin_a >> 5] >> (bin_a & 31u)) & 1u);  // (the older form stays conservative, too)
+            const uint32_t bin = c == 1 ? pbm_bin_c1(x) : c == 2 ? pbm_bin_c2(x) : pbm_bin_c3(x);
             const bool set = (bm[bin >> 5] >> (bin & 31u)) & 1u;
             *n_match += match;
             *n_set += set;
             bad += match && !set;
         }
+    }
     return bad;
 }
 
