@@ -137,11 +137,8 @@ struct WorkSet {
     DevBuf<uint16_t> seeds;
     DevBuf<uint64_t> qres;
     DevBuf<uint32_t> arena;
-    // cheap ties (device_types.h: DevWork::cnt_store ...): window counts of every narrow single-query spectrum, the tied
-    // candidates' parked records
+    // cheap ties (device_types.h: DevWork::cnt_store): the window counts of every narrow single-query spectrum
     DevBuf<uint32_t> cnt_store;
-    DevBuf<TieEntry> tie_ent;
-    DevBuf<TieCand> tie_cand;
     uint32_t cap_tie = 0;
     uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
     uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
@@ -216,7 +213,7 @@ struct SageScorer {
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)
-    bool fast_ties = true;      // one reported PSM, no chimera: ties at the top settled by tie_kernel from stored window counts
+    bool fast_ties = true;      // one reported PSM, no chimera: ties at the top settled by rescore_kernel from stored window counts
                                 // (SAGE_HIP_NO_FAST_TIES=1: every tie through the exact retry pass, as in round 3)
     uint32_t cnt_stride = 0;    // words per spectrum of WorkSet::cnt_store
     uint32_t qmax = 1;
@@ -531,7 +528,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         uint32_t* lut_p = nullptr;
         if (be == hipSuccess)
             be = (hipError_t)build_tile_copy_on_device(d->pm_frag.p, nf, tile_shift, (uint32_t)n_tiles, d_tile_off.p, lut_scale,
-                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr);
+                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr, /*transposed=*/true);
         if (be != hipSuccess)
             return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
         d->tm_lut.p = lut_p;
@@ -586,15 +583,15 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
             for (size_t t = tb; t < te; t++) {
                 uint64_t pos = tile_off[t];
                 const uint64_t tend = tile_off[t + 1];
-                uint32_t* row = lut.data() + t * lut_stride;
+                uint32_t* col = lut.data() + t;  // (transposed: entry (t, c) at c * n_tiles + t — DevDbView::tm_lut)
                 for (uint32_t c = 0; c < lut_stride; c++) {
                     const double edge = (double)c / (double)lut_scale;
                     // NaN and m/z beyond the table (non-finite or > 250 kDa) compare false and stay in the last cell's run
                     while (pos < tend && (double)tm[pos].fragment_mz < edge) pos++;
-                    row[c] = (uint32_t)pos;
+                    col[(size_t)c * n_tiles] = (uint32_t)pos;
                 }
-                row[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
-                row[lut_stride - 1] = (uint32_t)tend;
+                col[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
+                col[(size_t)(lut_stride - 1) * n_tiles] = (uint32_t)tend;
             }
         });
         HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));
@@ -1269,8 +1266,6 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream
     }
     if (s->fast_ties && n > w.cap_tie) {
         HIP_TRY(w.cnt_store.reserve((size_t)n * s->cnt_stride));
-        HIP_TRY(w.tie_ent.reserve(n));
-        HIP_TRY(w.tie_cand.reserve((size_t)n * TIE_CANDS_AVG));
         w.cap_tie = n;
     }
     if (wide && lane == 0 && n > w.cap_wide) {
@@ -1311,9 +1306,6 @@ static DevWork make_work(SageScorer* s, OutSet& o, int pass, int lane = 0) {
     w.arena_ptr = w.n_deferred + CTR_ARENA_PTR;
     w.cnt_store = nullptr;  // (enqueue_compute switches the cheap ties on for the first pass of a production search)
     w.cnt_stride = s->cnt_stride;
-    w.tie_cand = nullptr;
-    w.tie_ent = nullptr;
-    w.tie_cap = 0;
     w.tile_blocks = s->tile_blocks;
     w.qrec = ws.qrec.p;
     w.seeds = ws.seeds.p;
@@ -1383,9 +1375,6 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     const bool fast_ties = s->fast_ties && production && !fused && !one_launch && o.two_pass;
     if (fast_ties) {  // (each part of a step owns the rows / entries [list_off, list_off + n) of these arrays)
         w1.cnt_store = wset.cnt_store.p + (size_t)list_off * s->cnt_stride;  // (rows by schedule position within the part)
-        w1.tie_ent = wset.tie_ent.p + list_off;
-        w1.tie_cand = wset.tie_cand.p + (size_t)list_off * TIE_CANDS_AVG;
-        w1.tie_cap = view.n * TIE_CANDS_AVG;
     }
     if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
@@ -1418,10 +1407,6 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     if (with_rescore && (wide || !(fused || one_launch)))  // (behind search_kernel / the fused kernel: only the spectra the large-window kernels assembled)
         launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
     HIP_TRY(hipEventRecord(o.ev[2].e, st));
-    if (fast_ties) {  // ties between the best candidates of a spectrum, from the window counts the first pass kept (one lane each)
-        launch_tie(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
-        HIP_TRY(hipGetLastError());
-    }
     if (o.two_pass) {
         launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
         HIP_TRY(hipGetLastError());
@@ -1469,7 +1454,7 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
-    t.n_tied += c1[CTR_TIED] + c1[CTR_TIE_PAIR];
+    t.n_tied += c1[CTR_TIED] + c1[CTR_FAST_TIE];
     if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
         if (arena_overflow) {
             *arena_overflow = true;

@@ -23,7 +23,8 @@ struct DevDbView {
     const uint32_t* pep_info;        // [np] len | decoy<<16 | missed_cleavages<<24
     // tile-major copy of the fragments for large precursor windows: tile = peptide_index >> tile_shift,
     // ascending m/z inside a tile, plus a per-tile position table:
-    //   tm_lut[t * lut_stride + c] = position in tm_frag of tile t's first fragment with m/z >= c / lut_scale
+    //   tm_lut[c * n_tiles + t] = position in tm_frag of tile t's first fragment with m/z >= c / lut_scale   (TRANSPOSED: the
+    //   words one fragment-tolerance window needs from the consecutive tiles of a precursor window share cache lines)
     // (the last cell of a tile is its end position).  A (peak window, tile) lookup is two table reads and a
     // short contiguous run of entries; the tile's candidate counters fit in LDS.
     const SageTheoretical* tm_frag;  // [nf + 2]
@@ -93,22 +94,6 @@ struct DevBatchView {
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
 };
 
-struct TieEntry {
-    uint32_t spec;   // the spectrum
-    uint32_t row;    // its row of cnt_store (the schedule position of its workgroups)
-    uint32_t first;  // its candidates: tie_cand[first .. first + n)
-    uint32_t n;
-};
-struct TieCand {  // what the Feature of a candidate needs beyond the spectrum's own data (Score, scoring.rs:17-30)
-    uint32_t peptide;
-    uint32_t z_iso;  // precursor charge | (isotope error + 128) << 8
-    uint32_t matched_b, matched_y;
-    float summed_b, summed_y, ppm_difference;
-    uint32_t longest_b, longest_y;
-    uint32_t pad;
-    double hyperscore;
-};
-
 struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint64_t* cand;        // [n * kmax] packed PreScore in the reference's heap-layout order
     uint32_t* cand_len;    // [n]
@@ -130,19 +115,14 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
                            //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
     uint32_t kstride;      // entries per query of `seeds` / `qres`: kmax rounded up to a multiple of 64 (64 unless report_psms > 32)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)
-    // Cheap ties (kernels.hip: tie_wave_kernel / tie_kernel).  The preliminary kernel leaves the window counts of every narrow
-    // single-query spectrum in HBM; where the hyperscores of a spectrum's best candidates tie (and report_psms == 1, no chimera),
-    // the rescoring kernel parks the tied candidates' Scores (TieCand) instead of queueing the spectrum for the exact retry pass,
-    // and a tie kernel replays bounded_min_heapify from the stored counts, finds which of the tied candidates comes first in the
-    // reference's preliminary list and writes its Feature record.
+    // Cheap ties (kernels.hip: rescore_spectrum).  The preliminary kernel leaves the window counts of every narrow single-query
+    // spectrum in HBM; where the hyperscores of a spectrum's best candidates tie (and report_psms == 1, no chimera), the rescoring
+    // wavefront replays bounded_min_heapify from them on the spot, finds which of the tied candidates comes first in the
+    // reference's preliminary list and reports it — instead of queueing the spectrum for the exact retry pass.
     uint32_t* cnt_store;   // [n * cnt_stride] one row per SCHEDULE POSITION of the launch (null: off): {left, potential, -, -} of the
                            //     spectrum's query — potential == 0: nothing kept (several queries, large window) — then its u16
                            //     counts in slot order, two per word
     uint32_t cnt_stride;   //     words per row (4 + wcap / 2, a multiple of 4)
-    struct TieEntry* tie_ent;  // [n] the tied spectra; their number and the number of parked candidates: the 64-bit counter at
-                               //     n_deferred[CTR_TIE_PAIR] (low word: entries, high word: candidates)
-    struct TieCand* tie_cand;  // [tie_cap] the tied candidates, spectrum after spectrum
-    uint32_t tie_cap;          //     (a spectrum whose candidates do not fit takes the retry pass)
     uint32_t* arena_ptr;   // the arena's bump pointer (the first pass's counter in both passes when the retry pass reuses its candidates)
     // large-window pipeline (count -> replay -> assemble); query id = queue position * qmax + (z - z0) * n_iso + iso index
     struct QueryRec* qrec; // [n * qmax]
@@ -160,9 +140,8 @@ enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
        ST_OK_ORDERED = 5 };  // ST_OK, and no trim_hits of the spectrum dropped anything: the order-free list IS the reference's list  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
        CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
-       CTR_TIE_PAIR = 8,  // + 9: ONE 64-bit counter — low word: entries of DevWork::tie_ent, high word: candidates taken from tie_cand
-       CTR_COUNT = 16 };
-constexpr uint32_t TIE_CANDS_AVG = 4;  // parked candidates per spectrum DevWork::tie_cand is sized for
+       CTR_FAST_TIE = 7,  // spectra whose tie at the top rescore_kernel settled from the stored window counts (statistics)
+       CTR_COUNT = 8 };
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
 struct QueryRec {
@@ -226,7 +205,7 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
                                  void* stream);
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
-                              uint32_t* lut_stride_out, void* stream);
+                              uint32_t* lut_stride_out, void* stream, bool transposed = false);
 // rescore.hip
 int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err);
 int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, std::string& err);
@@ -249,9 +228,6 @@ void launch_compact(uint32_t n, const uint64_t* peak_off, uint32_t stride, const
 void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream);
-// the cheap-tie pass over DevWork::tie_ent (count on the device): two launches of which one has work (kernels.hip)
-void launch_tie(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
-                uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
 // counts[n] -> h_counts (device view of page-locked memory) and the counter blocks (2 * CTR_COUNT words) of up to four parts
 struct EpilogueParts {
     const uint32_t* src[4];

@@ -101,13 +101,25 @@ __global__ __launch_bounds__(256) void decode_kernel(uint64_t nf, uint32_t tile_
     tm[i] = SageTheoretical{pep, __int_as_float(o)};
 }
 
-// tm_lut[t][c] = first position of tile t whose m/z is >= c / scale (row[0] = tile start, row[last] = tile end)
+// the position table of a tile-major copy: entry (t, c) = first position of tile t whose m/z is >= c / scale (c == 0: the tile's
+// start, c == last: its end).  Row-major, lut[t][c] — the small tiles of the narrow kernel, where a window meets one or two tiles —
+// or TRANSPOSED, lut[c][t] — the large tiles of the open-search kernel, where ONE window is looked up in the ~100 consecutive
+// tiles of a precursor window: the words of consecutive tiles then share a cache line (32 tiles per 128 bytes) instead of
+// costing a line each.
+template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void lut_kernel(uint32_t n_tiles, uint32_t lut_stride, float lut_scale,
                                                   const uint64_t* __restrict__ tile_off, const SageTheoretical* __restrict__ tm,
                                                   uint32_t* __restrict__ lut) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (uint64_t)n_tiles * lut_stride) return;
-    const uint32_t t = (uint32_t)(gid / lut_stride), c = (uint32_t)(gid - (uint64_t)t * lut_stride);
+    uint32_t t, c;
+    if (TRANSPOSED) {
+        c = (uint32_t)(gid / n_tiles);
+        t = (uint32_t)(gid - (uint64_t)c * n_tiles);
+    } else {
+        t = (uint32_t)(gid / lut_stride);
+        c = (uint32_t)(gid - (uint64_t)t * lut_stride);
+    }
     static_assert(sizeof(SageTheoretical) == 8, "m/z is every second float of the entry array");
     lut[gid] = sagecore::lut_entry(&tm[0].fragment_mz, 2, tile_off[t], tile_off[t + 1], c, lut_stride, lut_scale);
 }
@@ -155,7 +167,7 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
 // the table is allocated here (its width depends on the largest fragment m/z).
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
-                              uint32_t* lut_stride_out, void* stream_) {
+                              uint32_t* lut_stride_out, void* stream_, bool transposed) {
     hipStream_t stream = (hipStream_t)stream_;
     // largest finite fragment m/z -> table width
     uint32_t* d_max = nullptr;
@@ -190,8 +202,12 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
     uint32_t* d_lut = nullptr;
     const uint64_t lut_n = (uint64_t)n_tiles * lut_stride;
     BUILD_TRY(hipMalloc((void**)&d_lut, (lut_n ? lut_n : 1) * 4));
-    hipLaunchKernelGGL(lut_kernel, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
-                       d_tile_off, d_tm_frag, d_lut);
+    if (transposed)
+        hipLaunchKernelGGL(lut_kernel<true>, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
+                           d_tile_off, d_tm_frag, d_lut);
+    else
+        hipLaunchKernelGGL(lut_kernel<false>, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
+                           d_tile_off, d_tm_frag, d_lut);
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipStreamSynchronize(stream));
     (void)hipFree(k_in);

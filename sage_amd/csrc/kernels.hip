@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc);
         if (!BIGK && w.cnt_store) {
             // One precursor-window query (known charge, one isotope error): its window counts — still in LDS — stay in HBM for
-            // tie_kernel.  (Here, behind prelim_spectrum, not inside it: nothing of this is live in the matching loops.)
+            // rescore_kernel's tie settlement.  (Here, behind prelim_spectrum, not inside it: nothing of this is live in the matching loops.)
             // Rows in SCHEDULE order (row `pos`, not row `spec`): the wavefronts running at any time write one moving window of a
             // few MB, not 2 KB pieces scattered over the whole GB — the stores of a random row per wavefront cost 5 % of the kernel
             // (address translation).  A row: {left, potential, -, -} then the u16 counts, two per word.
@@ -1260,9 +1260,10 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     probe_bounds(pr, lo, hi);
                     probe_cells(lo, hi, icl, ich);
                     if (pr < nprobe && first < end && lo <= hi) {
-                        const uint32_t* __restrict__ lut = db.tm_lut + (size_t)t * db.lut_stride;
-                        np0 = lut[icl];
-                        np1 = lut[ich];
+                        // (the table is transposed, lut[cell][tile]: this window's words of the window's consecutive tiles share
+                        // cache lines — a quarter of the kernel's HBM lines used to be table words fetched a line apiece)
+                        np0 = db.tm_lut[(size_t)icl * db.n_tiles + t];
+                        np1 = db.tm_lut[(size_t)ich * db.n_tiles + t];
                     }
                 };
                 // cells of the CURRENT unit in flight — named scalars, not arrays (arrays captured by the lambdas below end up in
@@ -2705,47 +2706,73 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         if (__builtin_expect(!list_is_exact && __ballot(tie) != 0ull, 0)) {  // (cold: spill code belongs in here, not around it)
             // The preliminary list came from order-free trims, so the stable sort above is only trustworthy when no two equal
             // hyperscores meet at a reported rank (i, i + 1 with i < per_round).  Otherwise the exact heap layout decides.
-            // Cheap when ONE PSM is reported: whichever of the tied candidates wins, its Feature is known already (rank 1,
-            // delta_next = delta_best = 0: the runner-up has the same hyperscore) — the tied candidates park their Scores (48 bytes
-            // each, straight from their lanes) and a tie kernel finds out which of them comes first in the reference's list, from
-            // the window counts prelim_kernel left behind (a spectrum without stored counts it passes on to the retry pass), and
-            // writes that candidate's record.  Everything else — several reported PSMs, chimera rounds — takes the exact retry pass.
-            // (Nothing here is live in the hot path: mask and slot are recomputed, no staging, no barrier.)
-#ifndef SAGE_NO_TIE_BRANCH
-            if (queue_on_tie && w.tie_ent && per_round == 1 && !sc.chimera) {
-                const bool is_best = pass && __double_as_longlong(h) == __double_as_longlong(best_h);
-                const uint64_t tb = __ballot(is_best);
-                const uint32_t nt = (uint32_t)__popcll(tb);
-                unsigned long long at = 0ull;
-                if (lane == 0) at = atomicAdd((unsigned long long*)(w.n_deferred + CTR_TIE_PAIR), ((unsigned long long)nt << 32) | 1ull);
-                const uint32_t entry = uni((uint32_t)at), first = uni((uint32_t)(at >> 32));
-                const bool fits = first + nt <= w.tie_cap;
-                if (lane == 0) {  // (an entry without candidates when they do not fit: the tie kernels skip it, the retry pass takes the spectrum)
-                    w.tie_ent[entry] = TieEntry{spec, xcd_position(blockIdx.x, b.n, sc.xcd_chunk), first, fits ? nt : 0u};
-                    out_count[spec] = 0;
-                }
-                if (fits) {
-                    if (is_best) {
-                        TieCand c;
-                        c.peptide = pep;
-                        c.z_iso = z | ((uint32_t)(iso + 128) << 8);
-                        c.matched_b = s.matched_b; c.matched_y = s.matched_y;
-                        c.summed_b = s.summed_b; c.summed_y = s.summed_y; c.ppm_difference = s.ppm_difference;
-                        c.longest_b = s.longest_b; c.longest_y = s.longest_y;
-                        c.pad = 0;
-                        c.hyperscore = h;
-                        w.tie_cand[first + (uint32_t)__popcll(tb & ((1ull << lane) - 1ull))] = c;
+            // Cheap when ONE PSM is reported: whichever of the tied candidates wins, its Feature is what its lane would report
+            // anyway (rank 1, delta_next = delta_best = 0: the runner-up has the same hyperscore) — only WHICH of them comes first in
+            // the reference's list has to be found out.  Everything else (several reported PSMs, chimera rounds, several queries or a
+            // large window behind the list) takes the exact retry pass.
+            // Settled RIGHT HERE when the first pass kept the window counts of this spectrum's (single) query: the wavefront
+            // replays bounded_min_heapify from them (Heap32, as the exact path of prelim_spectrum does; the counts staged in the
+            // LDS of the bitmap and the peak table, which are dead by now), looks the tied candidates up in the replayed list
+            // and the earliest one reports through the ordinary path below — no parking, no extra launch behind the step's last
+            // rescoring wavefront.  ~25 us for the 3 % of the wavefronts that get here.
+            if (queue_on_tie && w.cnt_store && per_round == 1 && !sc.chimera) {
+                const uint32_t* __restrict__ row = w.cnt_store + (size_t)xcd_position(blockIdx.x, b.n, sc.xcd_chunk) * w.cnt_stride;
+                const uint32_t left = uni(row[0]), potential = uni(row[1]);
+                if (potential != 0u) {
+                    const bool is_best = pass && __double_as_longlong(h) == __double_as_longlong(best_h);
+                    uint64_t tb = __ballot(is_best);
+                    const uint32_t k = trim_k(potential, sc.report_psms);
+                    Counters cnt;
+                    cnt.p = pbm;  // [(wcap + 1) / 2] words <= the 3 KB of bitmap + peak table
+                    __syncthreads();
+                    for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt.p[i] = row[CNT_ROW_HEADER + i];
+                    __syncthreads();
+                    uint32_t hl = 0;  // lane j: entry j of the trimmed list (key `count << 16 | slot`, 0: PreScore::default())
+                    if (potential > k) {
+                        Heap32 hp;
+                        {
+                            const uint32_t c = lane < k ? cnt.get(lane) : 0;
+                            wh32_init(hp, c ? (c << 16) | lane : 0u, k);
+                        }
+                        wh32_build(hp, k);
+                        for (uint32_t base = k; base < potential; base += WAVE) {
+                            const uint32_t i = base + lane;
+                            const uint32_t c = i < potential ? cnt.get(i) : 0;
+                            const uint32_t v = (c << 16) | i;
+                            uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> 16));
+                            while (mask) {
+                                const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
+                                mask &= mask - 1;
+                                wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                            }
+                        }
+                        hl = hp.h;
+                    } else {  // heap.rs:8-10: the slice stays as it is — slot order
+                        const uint32_t c = lane < potential ? cnt.get(lane) : 0;
+                        hl = c ? (c << 16) | lane : 0u;
                     }
-                    return false;
+                    uint32_t win = 0, best_pos = 0xFFFFFFFFu;
+                    while (tb) {
+                        const uint32_t j = (uint32_t)__ffsll((long long)tb) - 1;
+                        tb &= tb - 1;
+                        const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)pep, (int)j) - left;
+                        const uint64_t at = __ballot(lane < k && hl != 0u && (hl & 0xFFFFu) == slot);
+                        const uint32_t pos = at ? (uint32_t)__ffsll((long long)at) - 1 : 0xFFFFFFFEu;
+                        if (pos < best_pos) { best_pos = pos; win = j; }
+                    }
+                    rank = pass && lane == win ? 0u : 1u;  // (next_h == best_h already: the runner-up has the same hyperscore)
+                    tie = false;
+                    if (lane == 0) atomicAdd(w.n_deferred + CTR_FAST_TIE, 1u);  // (statistics: SageTiming::n_tied)
                 }
             }
-#endif
+            if (__ballot(tie) != 0ull) {
             if (queue_on_tie && lane == 0) {
                 w.status[spec] = ST_RETRY;
                 w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
                 out_count[spec] = 0;
             }
             return false;
+            }
         }
         pc.mark(3);
         if (pass && rank < per_round) {  // scoring.rs:504-594
@@ -3209,213 +3236,6 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
     }
 }
 
-// ---- ties settled from the stored window counts -----------------------------------------------------------------------------------
-// The spectra rescore_kernel put on DevWork::tie_ent: one PSM reported, its best candidates (2 .. 64 of them) share one
-// hyperscore, their Scores wait in tie_cand.  Which one the reference reports is decided by the stable sort of scoring.rs:495,
-// i.e. by the candidates' positions in the preliminary list — the layout bounded_min_heapify (heap.rs:7-28) leaves behind.
-// prelim_kernel kept the query's window counts (cnt_store, slot order), so nothing is matched or rescored again: the heap is
-// replayed (keys `count << 16 | slot`, PreScore's order inside one query), the tied candidates are looked up in it, and the
-// Feature of the earliest one is written (make_feature, as in the rescoring kernel: rank 1, delta_next = delta_best = 0).
-// Two kernels, one of which runs (the count of tied spectra lives on the device; both are launched, the other one's workgroups
-// leave at once): up to TIE_WAVE_MAX tied spectra a WAVEFRONT each (tie_wave_kernel: the heap one element per lane — the
-// latency of one replay whatever the number of spectra, which is what a step of a narrow search waits for behind its last
-// rescoring wavefront), beyond that a LANE each (tie_kernel: the heap column-interleaved in LDS, 64 lock-step replays per
-// wavefront: ~64 x fewer instructions per spectrum at ~5 x the latency — tie-rich proteomes, where a third of a batch ties).
-constexpr uint32_t TIE_WAVE_MAX = 16384;
-__device__ __forceinline__ SageFeature tie_feature(const DevDbView& db, const DevBatchView& b, const DevWork& w, const TieCand& c, uint32_t spec,
-                                                   const double* __restrict__ lnfact_table, uint32_t lnfact_n) {
-    Score s;
-    s.peptide = 0; s.precursor_charge = 0; s.isotope_error = 0;
-    s.matched_b = c.matched_b; s.matched_y = c.matched_y;
-    s.summed_b = c.summed_b; s.summed_y = c.summed_y; s.ppm_difference = c.ppm_difference;
-    s.longest_b = c.longest_b; s.longest_y = c.longest_y;
-    const uint32_t tot_matched = w.totals[2 * spec], tot_scored = w.totals[2 * spec + 1];
-    const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
-    const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
-    const float rt = b.rt ? b.rt[spec] : 0.0f;
-    float ims = 0.0f;
-    if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
-    const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
-    return make_feature(db, b, spec, c.peptide, c.z_iso & 0xFFu, (int)((c.z_iso >> 8) & 0xFFu) - 128, s, c.hyperscore, c.hyperscore, c.hyperscore, 1u,
-                        lambda, cr_log(lambda), mzp, rt, ims, fid, b.tic[spec], tot_scored, lnfact_table, lnfact_n);
-}
-
-__global__ __launch_bounds__(64) void tie_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w, const double* __restrict__ lnfact_table,
-                                                 uint32_t lnfact_n, SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* const heap = (uint32_t*)smem;                         // [kmax][64]
-    uint32_t* const rec_stage = heap + (size_t)sc.kmax * WAVE;      // [64][FEATURE_WORDS] the winners' records on their way out
-    uint32_t* const spec_stage = rec_stage + WAVE * FEATURE_WORDS;  // [64] their spectra (NONE32: nothing to write)
-    const uint32_t lane = lane_id();
-    uint32_t n = uni(w.n_deferred[CTR_TIE_PAIR]);
-    n = n < b.n ? n : b.n;
-    if (n <= TIE_WAVE_MAX && !(sc.dbg_flags & 2048u)) return;  // tie_wave_kernel's (SAGE_HIP_DEBUG_FLAGS=2048: tests force this one)
-    for (uint32_t base = blockIdx.x * WAVE; base < n; base += gridDim.x * WAVE) {
-        bool act = base + lane < n;
-        TieEntry ent{0u, 0u, 0u, 0u};
-        uint32_t left = 0, potential = 0;
-        const uint32_t* __restrict__ row = w.cnt_store;
-        if (act) {
-            ent = w.tie_ent[base + lane];
-            row = w.cnt_store + (size_t)ent.row * w.cnt_stride;
-            left = row[0];
-            potential = row[1];
-            if (ent.n == 0) {  // its candidates did not fit tie_cand: rescore_kernel queued it for the retry pass itself
-                act = false;
-            } else if (potential == 0) {  // no stored counts (several queries, or the list came from the large-window kernels): the retry pass
-                w.status[ent.spec] = ST_RETRY;
-                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = ent.spec;
-                act = false;
-            }
-        }
-        const uint32_t spec = ent.spec;
-        const uint32_t k = trim_k(potential, sc.report_psms);
-        const bool trimmed = act && potential > k;  // heap.rs:8-10: otherwise the slice stays as it is (slot order)
-        const uint4* __restrict__ cnt4 = (const uint4*)(row + CNT_ROW_HEADER);
-        uint32_t* const hp = heap + lane;
-        const uint32_t n_chunks = trimmed ? (potential + 7) / 8 : 0u;  // 8 slots (four words of u16 pairs) at a time
-        uint4 nxt = n_chunks ? cnt4[0] : make_uint4(0u, 0u, 0u, 0u);
-        uint32_t hmin = 0;  // the heap's minimum once it is built (heap.rs:22 compares against it): kept in a register
-        for (uint32_t c = 0; __ballot(c < n_chunks) != 0ull; c++) {
-            const uint4 cur = nxt;
-            if (c + 1 < n_chunks) nxt = cnt4[c + 1];  // (in flight under this chunk's sifts)
-            if (c >= n_chunks) continue;
-#pragma unroll 1
-            for (uint32_t t = 0; t < 8; t++) {
-                const uint32_t slot = c * 8 + t;
-                if (slot >= potential) break;
-                const uint32_t word = t < 2 ? cur.x : t < 4 ? cur.y : t < 6 ? cur.z : cur.w;
-                const uint32_t cv = (word >> ((t & 1u) * 16u)) & 0xFFFFu;
-                const uint32_t key = cv ? (cv << 16) | slot : 0u;  // (PreScore::default() is the smallest key)
-                if (slot < k) {
-                    hp[slot * 64] = key;
-                    if (slot + 1 == k) {
-                        for (uint32_t i = k / 2; i-- > 0;) sift_down_strided<uint32_t>(hp, k, i, hp[i * 64]);  // heap.rs:13-15
-                        hmin = hp[0];
-                    }
-                } else if (key > hmin) {
-                    sift_down_strided<uint32_t>(hp, k, 0, key);  // heap.rs:22-25: slice.swap(i, 0); sift_down
-                    hmin = hp[0];
-                }
-            }
-        }
-        if (act) {  // the earliest tied candidate of the list; its record
-            uint32_t win = 0, best_pos = 0xFFFFFFFFu;
-            for (uint32_t j = 0; j < ent.n; j++) {
-                const uint32_t slot = w.tie_cand[ent.first + j].peptide - left;
-                uint32_t pos = 0xFFFFFFFEu;
-                if (!trimmed) {
-                    pos = slot;
-                } else {
-                    for (uint32_t i = 0; i < k; i++) {
-                        const uint32_t v = hp[i * 64];
-                        if (v != 0u && (v & 0xFFFFu) == slot) pos = i;
-                    }
-                }
-                if (pos < best_pos) { best_pos = pos; win = j; }
-            }
-            const SageFeature f = tie_feature(db, b, w, w.tie_cand[ent.first + win], spec, lnfact_table, lnfact_n);
-            *(SageFeature*)(rec_stage + (size_t)lane * FEATURE_WORDS) = f;
-        }
-        spec_stage[lane] = act ? spec : NONE32;
-        wave_sync();
-        // records leave as contiguous 120-byte runs, two per step (lanes 0..29 and 32..61), like the rescoring kernel's
-        const uint32_t n_here = n - base < WAVE ? n - base : WAVE;
-        for (uint32_t e0 = 0; e0 < n_here; e0 += 2) {
-            const uint32_t e = e0 + (lane >> 5), i = lane & 31u;
-            if (e < n_here && i < FEATURE_WORDS) {
-                const uint32_t e_spec = spec_stage[e];
-                if (e_spec != NONE32) ((uint32_t*)(out + (size_t)e_spec * sc.report_psms))[i] = rec_stage[e * FEATURE_WORDS + i];
-            }
-        }
-        if (act) {
-            out_count[spec] = 1;
-            w.status[spec] = ST_DONE;
-        }
-        wave_sync();
-    }
-}
-
-// the same decision by one wavefront per tied spectrum: counts staged in LDS, the heap in registers (Heap32, as in the exact path
-// of prelim_spectrum), the tied candidates found by a ballot each, the record built by lane 0 and stored by 30 lanes
-// (eight wavefronts per SIMD — 64 VGPRs, the cold Feature code spills — so that every tied spectrum of a batch is resident at once)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tie_wave_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w, const double* __restrict__ lnfact_table,
-                                                      uint32_t lnfact_n, SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t lane = lane_id();
-    uint32_t n = uni(w.n_deferred[CTR_TIE_PAIR]);
-    n = n < b.n ? n : b.n;
-    if (n > TIE_WAVE_MAX || (sc.dbg_flags & 2048u)) return;  // tie_kernel's
-    uint32_t* const rec = (uint32_t*)smem;  // [FEATURE_WORDS + 2] the record on its way out
-    Counters cnt;
-    cnt.p = rec + FEATURE_WORDS + 2;        // [wcap / 2 + 1] the window counts
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const TieEntry ent = w.tie_ent[e];
-        const uint32_t spec = uni(ent.spec), first = uni(ent.first), m = uni(ent.n) < WAVE ? uni(ent.n) : WAVE;
-        const uint32_t* __restrict__ row = w.cnt_store + (size_t)uni(ent.row) * w.cnt_stride;
-        const uint32_t left = uni(row[0]), potential = uni(row[1]);
-        if (m == 0) continue;  // its candidates did not fit tie_cand: rescore_kernel queued it for the retry pass itself
-        if (potential == 0) {  // no stored counts (several queries, or the list came from the large-window kernels): the retry pass
-            if (lane == 0) {
-                w.status[spec] = ST_RETRY;
-                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
-            }
-            continue;
-        }
-        const uint32_t k = trim_k(potential, sc.report_psms);
-        // lane j < m: the j-th tied candidate — its whole Feature now, all candidates side by side and their loads in flight
-        // together with the counts', so that nothing but the replay itself stands between the counts and the record
-        SageFeature mine_f;
-        uint32_t my_pep = 0u;
-        wave_sync();
-        for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt.p[i] = row[CNT_ROW_HEADER + i];
-        if (lane < m) {
-            const TieCand c = w.tie_cand[first + lane];
-            my_pep = c.peptide;
-            mine_f = tie_feature(db, b, w, c, spec, lnfact_table, lnfact_n);
-        }
-        wave_sync();
-        uint32_t h = 0;  // lane j: entry j of the trimmed list (key `count << 16 | slot`, 0: PreScore::default())
-        if (potential > k) {
-            Heap32 hp;
-            {
-                const uint32_t c = lane < k ? cnt.get(lane) : 0;
-                wh32_init(hp, c ? (c << 16) | lane : 0u, k);
-            }
-            wh32_build(hp, k);
-            for (uint32_t base = k; base < potential; base += WAVE) {
-                const uint32_t i = base + lane;
-                const uint32_t c = i < potential ? cnt.get(i) : 0;
-                const uint32_t v = (c << 16) | i;
-                uint64_t mask = __ballot(c > 0 && c >= (wh32_get(hp, 0) >> 16));  // (prelim_spectrum's exact path)
-                while (mask) {
-                    const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
-                }
-            }
-            h = hp.h;
-        } else {  // heap.rs:8-10: the slice stays as it is — slot order
-            const uint32_t c = lane < potential ? cnt.get(lane) : 0;
-            h = c ? (c << 16) | lane : 0u;
-        }
-        uint32_t win = 0, best_pos = 0xFFFFFFFFu;
-        for (uint32_t j = 0; j < m; j++) {
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)my_pep, (int)j) - left;
-            const uint64_t at = __ballot(lane < k && h != 0u && (h & 0xFFFFu) == slot);
-            const uint32_t pos = at ? (uint32_t)__ffsll((long long)at) - 1 : 0xFFFFFFFEu;
-            if (pos < best_pos) { best_pos = pos; win = j; }
-        }
-        if (lane == win) *(SageFeature*)rec = mine_f;
-        wave_sync();
-        if (lane < FEATURE_WORDS) ((uint32_t*)(out + (size_t)spec * sc.report_psms))[lane] = rec[lane];
-        if (lane == 0) {
-            out_count[spec] = 1;
-            w.status[spec] = ST_DONE;
-        }
-    }
-}
-
 // The way home of a step's small results in ONE launch (page-locked, mapped destinations): the PSM counts of every spectrum and
 // the counter blocks of the step's parts.  Three copy commands at the end of a 1 ms step cost ~60 us of command gaps.
 __global__ __launch_bounds__(256) void epilogue_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ h_counts,
@@ -3615,19 +3435,6 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
     const auto kern = w.dbg ? rescore_kernel<true, true> : (sc.fast_log && !keep) ? rescore_kernel<false, false> : rescore_kernel<false, true>;
     hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
                        (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
-}
-void launch_tie(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
-                uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream) {
-    if (b.n == 0 || !w.tie_ent) return;
-    // (both: which one has work is known on the device only — tie_wave_kernel up to TIE_WAVE_MAX tied spectra, tie_kernel beyond)
-    hipLaunchKernelGGL(tie_wave_kernel, dim3(b.n < 8192u ? b.n : 8192u), dim3(64), ((size_t)FEATURE_WORDS + 2 + sc.wcap / 2 + 2) * 4,
-                       (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
-    if (b.n > TIE_WAVE_MAX || (sc.dbg_flags & 2048u)) {
-        const uint32_t blocks = (b.n + WAVE - 1) / WAVE;
-        const size_t lds = ((size_t)sc.kmax * WAVE + (size_t)WAVE * FEATURE_WORDS + WAVE) * 4;
-        hipLaunchKernelGGL(tie_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(64), lds, (hipStream_t)stream, db, sc, b, w, lnfact_table,
-                           lnfact_n, out, out_count);
-    }
 }
 void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream) {
     const uint32_t blocks = (n + 1023) / 1024;
