@@ -151,6 +151,8 @@ struct OutSet {
     DevBuf<uint32_t> out_count;
     DevBuf<uint32_t> counters;       // [2 * CTR_COUNT]: first pass, exact retry pass
     uint32_t* h_counters = nullptr;  // pinned [2 * CTR_COUNT]
+    uint32_t* h_counters_view = nullptr;  // ... as the kernels address it
+    bool counters_clean = false;  // the last command on the counters was the epilogue kernel's reset (and the host waited for it)
     Pinned h_out;                    // landing block for the records when the caller's arrays are pageable
     Event ev[5];                     // start, prelim 1, rescore 1, prelim 2, rescore 2
     Event comp_done, down_done;
@@ -734,6 +736,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         HIP_TRY(o.down_done.create(false));
         HIP_TRY(o.counters.alloc(2 * CTR_COUNT));
         HIP_TRY(hipHostMalloc((void**)&o.h_counters, 2 * CTR_COUNT * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void**)&o.h_counters_view, o.h_counters, 0));
     }
     for (SageDeviceBatch& b : s->slots) {
         b.device = db->device;
@@ -1390,7 +1393,9 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     sc1.fast_log = o.two_pass ? 1u : 0u;  // (an undecided logarithm is settled by the retry pass: launch_rescore)
     sc2.exact = 1u;
     sc2.fast_log = 0u;
-    HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
+    // (score_resident's epilogue kernel leaves the counters zeroed for the next step: one command less ahead of the first kernel)
+    if (!o.counters_clean) HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
+    o.counters_clean = false;
     HIP_TRY(hipEventRecord(o.ev[0].e, st));
     if (fused)
         launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
@@ -1510,6 +1515,7 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         SageFeature* const rec = direct ? direct : o.features.p;
         uint32_t* const count_view = s->zero_copy && b->n ? (uint32_t*)device_view(out_count) : nullptr;
         const bool epilogue = count_view != nullptr;  // (page-locked count array: the small results go home in one launch)
+        bool reset_done = false;
         HIP_TRY(hipEventRecord(s->way_begin.e, s->stream));
         if (ways > 1) HIP_TRY(hipEventRecord(s->way_fork.e, s->stream));
         for (uint32_t wy = 0; wy < ways; wy++) {
@@ -1539,15 +1545,18 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             parts.n = ways;
             for (uint32_t wy = 0; wy < ways; wy++) {
                 parts.src[wy] = s->outs[wy].counters.p;
-                parts.dst[wy] = (uint32_t*)device_view(s->outs[wy].h_counters);
+                parts.dst[wy] = s->outs[wy].h_counters_view;
             }
             launch_epilogue(o.out_count.p, b->n, count_view, parts, fin);
             HIP_TRY(hipGetLastError());
+            reset_done = true;
         } else if (b->n) {
             HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, fin));
         }
         if (b->n && !direct) HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, fin));
         HIP_TRY(wait_for_stream(fin));
+        if (reset_done)
+            for (uint32_t wy = 0; wy < ways; wy++) s->outs[wy].counters_clean = true;
         bool redo = false;
         for (uint32_t wy = 0; wy < ways; wy++) {
             bool r = false;

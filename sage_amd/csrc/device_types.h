@@ -230,7 +230,7 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     uint32_t* out_count, uint8_t* keep, void* stream);
 // counts[n] -> h_counts (device view of page-locked memory) and the counter blocks (2 * CTR_COUNT words) of up to four parts
 struct EpilogueParts {
-    const uint32_t* src[4];
+    uint32_t* src[4];  // (reset by the kernel after the copy)
     uint32_t* dst[4];
     uint32_t n;
 };

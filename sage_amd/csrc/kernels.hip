@@ -3238,12 +3238,16 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
 
 // The way home of a step's small results in ONE launch (page-locked, mapped destinations): the PSM counts of every spectrum and
 // the counter blocks of the step's parts.  Three copy commands at the end of a 1 ms step cost ~60 us of command gaps.
+// The counter blocks are left ZEROED for the next step (its first command is then a kernel, not a fill).
 __global__ __launch_bounds__(256) void epilogue_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ h_counts,
                                                        EpilogueParts parts) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_counts[i] = counts[i];
     if (blockIdx.x == 0)
         for (uint32_t p = 0; p < parts.n; p++)
-            for (uint32_t i = threadIdx.x; i < 2 * CTR_COUNT; i += blockDim.x) parts.dst[p][i] = parts.src[p][i];
+            for (uint32_t i = threadIdx.x; i < 2 * CTR_COUNT; i += blockDim.x) {
+                parts.dst[p][i] = parts.src[p][i];
+                parts.src[p][i] = 0u;
+            }
 }
 
 // quick_score without prefilter_low_memory (scoring.rs:290-296): every peptide of the trimmed preliminary list
