@@ -668,6 +668,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     DevScorer& d = s->dev;
     d.precursor_tol = {p->precursor_tol.kind, p->precursor_tol.lo, p->precursor_tol.hi};
     d.fragment_tol = {p->fragment_tol.kind, p->fragment_tol.lo, p->fragment_tol.hi};
+    d.pbm_reach = sagecore::pbm_reach_of(d.fragment_tol);
     d.min_matched_peaks = p->min_matched_peaks;
     d.min_isotope_err = p->min_isotope_err;
     d.max_isotope_err = p->max_isotope_err;

@@ -414,10 +414,27 @@ SAGE_HD uint32_t lut_entry(const float* mz, uint32_t step, uint64_t begin, uint6
 // exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same peaks considered and
 // the same filtered scan as select_most_intense_peak above.
 constexpr uint32_t PLUT_BINS = 256;
-SAGE_HD float peak_lut_width(float top) {  // smallest power of two with PLUT_BINS * w > the largest mass
-    float w = 1.0f;
-    while (top == top && (float)PLUT_BINS * w <= top && w < 1.0e30f) w *= 2.0f;
+SAGE_HD float peak_lut_width(float top) {  // a power of two w >= 1 with PLUT_BINS * w > the largest mass (any power of two is CORRECT:
+    // masses beyond the table share its last bin; this one keeps the walks of select_peak_lut short)
+    // top = 2^e f, 1 <= f < 2: 2^(e - 7) > top / 256 >= 2^(e - 8).  From the exponent field, no loop (wave-uniform float work runs
+    // on the vector ALU all the same); capped at 2^100; a negative, zero or tiny top gives 1, a NaN the cap.
+    uint32_t bits;
+    __builtin_memcpy(&bits, &top, 4);
+    const uint32_t e = (bits >> 23) & 0xFFu;  // biased
+    uint32_t we = (bits >> 31) || e < 134u ? 127u : e - 7u;
+    we = we > 227u ? 227u : we;
+    const uint32_t wb = we << 23;
+    float w;
+    __builtin_memcpy(&w, &wb, 4);
     return w;
+}
+SAGE_HD float pow2_reciprocal(float w) {  // exact 1 / w for a normal power of two (peak_lut_width's)
+    uint32_t bits;
+    __builtin_memcpy(&bits, &w, 4);
+    bits = 0x7F000000u - bits;
+    float r;
+    __builtin_memcpy(&r, &bits, 4);
+    return r;
 }
 SAGE_HD uint32_t peak_lut_entry(const float* pm, uint32_t P, uint32_t b, float w) {
     const int32_t edge = order_key((float)b * w);
@@ -481,16 +498,29 @@ SAGE_HD uint32_t pbm_index(float ion) {
 SAGE_HD uint32_t pbm_bin_c1(uint32_t x) { return x & (PBM_BITS - 1u); }
 SAGE_HD uint32_t pbm_bin_c2(uint32_t x) { return (x >> 1) & (PBM_BITS - 1u); }
 SAGE_HD uint32_t pbm_bin_c3(uint32_t x) { return (uint32_t)(((uint64_t)x * 0xAAAAAAABull) >> 33) & (PBM_BITS - 1u); }  // x / 3 for every u32
-// D of a peak of mass m; false: no safe bound (every bin of the bitmap is to be set)
-SAGE_HD bool pbm_peak_reach(const Tol& t, float m, float& D) {
+// D of a peak of mass m is fma(m, a, b): the two coefficients depend on the tolerance alone and are worked out once per scorer
+// (the kernel spends ONE instruction per peak on D — every instruction of the one-wavefront-per-spectrum kernels is paid once
+// per spectrum whether 1 or 64 lanes need it; round 4: the per-peak form with its division cost ~300 instructions per
+// spectrum).  a < 0: no safe bound for this tolerance (every bin of the bitmap is set).
+struct PbmReach {
+    float a, b;
+};
+SAGE_HD PbmReach pbm_reach_of(const Tol& t) {
     const float tmax = __builtin_fmaxf(__builtin_fabsf(t.lo), __builtin_fabsf(t.hi));
     const float rel = t.kind == 0 ? tmax * 1.0e-6f : t.kind == 1 ? tmax * 1.0e-2f : 0.0f;
-    D = 0.0f;
-    if (!(tmax == tmax) || !(tmax < 1.0e30f) || !(rel < 0.25f) || !(m >= 0.0f) || !(m < 8388608.0f)) return false;
-    // relative tolerances: the window of centre c contains m only if |c - m| <= m rel / (1 - rel); 1e-4 for the roundings inside
-    // Tolerance::bounds, 2^-20 m for those of ion / charge and of m -+ D, 2^-20 absolute for tiny masses
-    D = (t.kind == 2 ? tmax : m * (rel / (1.0f - rel))) * 1.0001f + m * (1.0f / 1048576.0f) + (1.0f / 1048576.0f);
-    return D <= PBM_MAX_D;
+    PbmReach r{-1.0f, 0.0f};
+    if (!(tmax == tmax) || !(tmax < 1.0e30f) || !(rel < 0.25f)) return r;
+    // relative tolerances: the window of centre c contains m only if |c - m| <= m rel / (1 - rel); 2e-4 relative for the roundings
+    // inside Tolerance::bounds and of these coefficients, 2^-20 m for those of ion / charge and of m -+ D, 2^-20 absolute for
+    // tiny masses
+    r.a = (rel / (1.0f - rel)) * 1.0002f + (1.0f / 1048576.0f);
+    r.b = (t.kind == 2 ? tmax * 1.0002f : 0.0f) + (1.0f / 1048576.0f);
+    return r;
+}
+// D of one peak; false: no safe bound (a negative, non-finite or absurd mass, D above PBM_MAX_D)
+SAGE_HD bool pbm_peak_reach(const PbmReach& r, float m, float& D) {
+    D = __builtin_fmaf(m, r.a, r.b);
+    return r.a >= 0.0f && m >= 0.0f && m < 8388608.0f && D <= PBM_MAX_D;
 }
 // bins [b0, b1] (before the modulo) a peak of mass m >= 0 sets
 SAGE_HD void pbm_peak_span(float m, float D, uint32_t& b0, uint32_t& b1) {

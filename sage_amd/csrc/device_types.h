@@ -48,6 +48,7 @@ struct DevDbView {
 
 struct DevScorer {
     sagecore::Tol precursor_tol, fragment_tol;
+    sagecore::PbmReach pbm_reach;  // pbm_reach_of(fragment_tol): the peak-presence bitmap's reach coefficients (core.h)
     uint32_t min_matched_peaks;
     int min_isotope_err, max_isotope_err;
     uint32_t min_precursor_charge, max_precursor_charge;

@@ -2103,17 +2103,22 @@ __device__ __forceinline__ double hyperscore_dev(int score_type, const Score& s,
 // that live at the edge of their register budget (eleven copies of both phases cost rescore_kernel 500 scalar spills).
 // ACC == false (the hot first-pass instance of rescore_kernel): the fast phase only; `undecided` is set where it could not
 // round (~2^-17 of the arguments) and the spectrum goes through the retry pass, whose kernels carry both phases.
+// `spare_lane`: lane 63 holds no candidate (a preliminary list is at most 50 long unless report_psms asks for more): it takes
+// ln(lambda) in the SAME pass as the candidates' ln(x) — one trip through the ~170 f64-heavy instructions instead of two.
 template <bool ACC>
-__device__ __forceinline__ double cr_log_pair(const double x, const double lambda, const bool with_lambda, double& ln_lambda, bool& undecided) {
+__device__ __forceinline__ double cr_log_pair(const double x, const double lambda, const bool with_lambda, const bool spare_lane,
+                                              double& ln_lambda, bool& undecided) {
     double ln_x = 0.0;
     undecided = false;
+    const bool shared = with_lambda && spare_lane;  // (wave-uniform)
+    const double arg = shared && lane_id() == 63u ? lambda : x;
 #pragma nounroll
-    for (int it = with_lambda ? 0 : 1; it < 2; it++) {
+    for (int it = with_lambda && !shared ? 0 : 1; it < 2; it++) {
         double y;
         if (ACC) {
-            y = cr_log(it ? x : lambda);
+            y = cr_log(it ? arg : lambda);
         } else {
-            const CrLogArg a = cr_log_reduce(it ? x : lambda);
+            const CrLogArg a = cr_log_reduce(it ? arg : lambda);
             bool decided;
             y = cr_log_fast(a, decided);
             if (a.is_special) y = a.special;
@@ -2121,6 +2126,11 @@ __device__ __forceinline__ double cr_log_pair(const double x, const double lambd
         }
         if (it) ln_x = y;
         else ln_lambda = y;
+    }
+    if (shared) {
+        const long long bits = __double_as_longlong(ln_x);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), 63);
+        ln_lambda = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
     return ln_x;
 }
@@ -2140,7 +2150,7 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
     // shifted by one bin, then its inclusive prefix sum.
     const uint32_t lane = lane_id();
     const float w = peak_lut_width(P ? pm[P - 1] : 0.0f);
-    inv_w = 1.0f / w;
+    inv_w = pow2_reciprocal(w);
     static_assert(PLUT_BINS == 4 * WAVE, "four consecutive bins per lane");
     __syncthreads();
     *(uint4*)(plut + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
@@ -2176,26 +2186,30 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
 constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COOP_MAX_LANES;
 constexpr uint32_t TILE_GRID_CAP = 32768;
 constexpr uint32_t RETRY_GRID_CAP = 8192;   // blocks of the narrow exact retry pass  // blocks of the per-query / per-item kernels of the large-window path
-__device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm, uint32_t P, const Tol& t) {
+__device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm, uint32_t P, const PbmReach& reach) {
     const uint32_t lane = lane_id();
-    // usable at all?  every peak needs a finite, non-negative mass and a reach D of at most 32 bins (core.h: pbm_peak_reach)
-    bool bad = false;
-    for (uint32_t i = lane; i < P; i += WAVE) {
-        float D;
-        bad = bad || !pbm_peak_reach(t, pm[i], D);
-    }
-    const bool ok = __ballot(bad) == 0ull;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)bm != 0u) __builtin_trap();  // (pbm_bit: the bitmap at LDS address 0)
-    for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = ok ? 0u : 0xFFFFFFFFu;
+    static_assert(PBM_WORDS == 8 * WAVE, "two 16-byte stores per lane clear the bitmap");
+    *(uint4*)(bm + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    *(uint4*)(bm + 4 * (WAVE + lane)) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    if (!ok) return;
+    // ONE pass: every peak sets its bins; a peak without a safe reach (a negative or non-finite mass, D above 32 bins — core.h:
+    // pbm_peak_reach) sets nothing and switches the filter off for the spectrum below
+    bool bad = false;
     for (uint32_t i = lane; i < P; i += WAVE) {
         const float m = pm[i];
         float D;
-        pbm_peak_reach(t, m, D);
-        uint32_t b0, b1;
-        pbm_peak_span(m, D, b0, b1);
-        for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[(bin & (PBM_BITS - 1u)) >> 5], 1u << (bin & 31u));
+        if (pbm_peak_reach(reach, m, D)) {
+            uint32_t b0, b1;
+            pbm_peak_span(m, D, b0, b1);
+            for (uint32_t bin = b0; bin <= b1; bin++) atomicOr(&bm[(bin & (PBM_BITS - 1u)) >> 5], 1u << (bin & 31u));
+        } else {
+            bad = true;
+        }
+    }
+    if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
+        __syncthreads();
+        for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = 0xFFFFFFFFu;
     }
 }
 // The bit of bin `x` modulo PBM_BITS (x: pbm_index of the ion, halved or divided by three for charges 2 and 3).  The bitmap sits at
@@ -2337,11 +2351,12 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
 //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
 //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
 //      adds per match) and handed back to the candidate's lane.
+template <class PC>
 __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
                                                  const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
                                                  const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
-                                                 Score& s) {
+                                                 Score& s, PC& pc) {
     const uint32_t lane = lane_id();
     uint32_t b_run = 0, y_run = 0;  // (run_matched_packed)
     uint32_t mm = 0;                // matched_b | matched_y << 16 (u16 in the reference)
@@ -2379,6 +2394,7 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
             m3 = nfz >= 3 ? m3 & in_chunk : 0ull;
             if (nfz > 3) m1 = m2 = m3 = in_chunk;  // (charges above 3 are not filtered: every ion goes through)
         }
+        pc.mark(6);  // (phase clocks: the bitmap filter)
         // ---- chunks with many hits: the whole wavefront on one candidate at a time
         const uint32_t hc = act && nfz <= 3 ? (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3)) : 0u;
         uint64_t bigs = (sc.dbg_flags & 32u) ? 0ull : __ballot(hc > COOP_MIN_HITS);  // (SAGE_HIP_DEBUG_FLAGS=32: tests switch it off)
@@ -2444,6 +2460,7 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
                 m1 = m2 = m3 = 0ull;  // done
             }
         }
+        pc.mark(7);  // (... the heavy candidates, wavefront-wide)
         // ---- everybody else: the lane walks its own hits
         uint64_t any = m1 | m2 | m3;
         if (!any) continue;
@@ -2593,7 +2610,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         uint32_t longest = SAGE_N_ITEMS;
         for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)longest, o, 64); longest = v > longest ? v : longest; }
         const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
-        if (lane == 0) { atomicAdd(&pc.slot[5], items); atomicAdd(&pc.slot[6], longest); atomicAdd(&pc.slot[7], nvalid); }
+        (void)items; (void)longest; (void)nvalid;  // (slots 5..7 now hold phases)
     }
 
     const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
@@ -2607,7 +2624,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
         // (built once: after remove_matched_peaks the bitmap is a superset of the remaining peaks' bins — still conservative)
-        if (round == 0) build_peak_bitmap(pbm, pm, P, sc.fragment_tol);
+        if (round == 0) build_peak_bitmap(pbm, pm, P, sc.pbm_reach);
         __syncthreads();
         Score s;
         s.peptide = 0;  // (the lane's pep / z / iso stand in for the fields of the same name)
@@ -2617,12 +2634,13 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.summed_b = s.summed_y = 0.0f;
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
-        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
-        pc.mark(1);
+        pc.mark(5);  // (... the peak table and the bitmap)
+        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, pc);
+        pc.mark(1);  // (... the lanes' own hits)
         double h = 0.0;
         bool pass = false;
         bool ln_undecided;
-        const double ln_i = cr_log_pair<ACC>(hyperscore_arg(s), lambda, round == 0, ln_lambda, ln_undecided);
+        const double ln_i = cr_log_pair<ACC>(hyperscore_arg(s), lambda, round == 0, ((__ballot(valid) >> 63) & 1ull) == 0ull, ln_lambda, ln_undecided);
         if (__builtin_expect(!ACC && __ballot(ln_undecided && (valid || round == 0)) != 0ull, 0)) {
             // (the hot instance carries the logarithm's fast phase only: this spectrum again in the retry pass, like a tie)
             if (queue_on_tie && lane == 0) {
@@ -2664,6 +2682,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             }
             return true;
         }
+        pc.mark(2);  // (... ln, hyperscore)
         // stable sort, descending by hyperscore.total_cmp (scoring.rs:495), as a rank computation
         const long long key = order_key64(h);
         const uint64_t pmask = __ballot(pass);
@@ -2875,7 +2894,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
         for (uint32_t round = 0; round < rounds; round++) {
             float inv_w;
             build_peak_lut(plut, inv_w, pm, P);
-            if (round == 0) build_peak_bitmap(pbm, pm, P, sc.fragment_tol);
+            if (round == 0) build_peak_bitmap(pbm, pm, P, sc.pbm_reach);
             __syncthreads();
             uint32_t npass = 0;
             for (uint32_t base = 0; base < ncand; base += WAVE) {
@@ -2901,11 +2920,12 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                 s.summed_b = s.summed_y = 0.0f;
                 s.ppm_difference = 0.0f;
                 s.longest_b = s.longest_y = 0;
-                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s);
+                NoClock nc;
+                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, nc);
                 double h = 0.0;
                 bool pass = false;
                 bool ln_undecided;  // (never: both phases)
-                const double ln_i = cr_log_pair<true>(hyperscore_arg(s), lambda, round == 0 && base == 0, ln_lambda, ln_undecided);
+                const double ln_i = cr_log_pair<true>(hyperscore_arg(s), lambda, round == 0 && base == 0, false, ln_lambda, ln_undecided);
                 if (valid) {
                     s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
                     h = hyperscore_dev(sc.score_type, s, ln_i, lnfact_table, lnfact_n);

@@ -82,7 +82,8 @@ int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, fl
     for (uint32_t b = 0; b < PLUT_BINS; b++) plut[b] = peak_lut_entry(masses, n, b, w);
     float lo, hi;
     tol_bounds(t, center, lo, hi);
-    return select_peak_lut(masses, intens, n, plut.data(), 1.0f / w, lo, hi);
+    if (pow2_reciprocal(w) != 1.0f / w) return -2;  // (the kernel's reciprocal)
+    return select_peak_lut(masses, intens, n, plut.data(), pow2_reciprocal(w), lo, hi);
 }
 
 // rescore_kernel's peak-presence filter (core.h: pbm_*) against the thing it must never contradict: for every ion and fragment
@@ -93,16 +94,17 @@ int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, fl
 uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, float tlo, float thi, const float* ions, uint32_t m,
                                     uint32_t* n_match, uint32_t* n_set, int* filter_active) {
     Tol t{kind, tlo, thi};
+    const PbmReach reach = pbm_reach_of(t);  // (the scorer's, worked out on the host: DevScorer::pbm_reach)
     bool ok = true;
     for (uint32_t i = 0; i < n && ok; i++) {
         float D;
-        ok = pbm_peak_reach(t, masses[i], D);  // (a NaN or negative mass: the filter is switched off)
+        ok = pbm_peak_reach(reach, masses[i], D);  // (a NaN or negative mass: the filter is switched off)
     }
     std::vector<uint32_t> bm(PBM_WORDS, ok ? 0u : 0xFFFFFFFFu);
     if (ok)
         for (uint32_t i = 0; i < n; i++) {
             float D;
-            pbm_peak_reach(t, masses[i], D);
+            pbm_peak_reach(reach, masses[i], D);
             uint32_t b0, b1;
             pbm_peak_span(masses[i], D, b0, b1);
             for (uint32_t b = b0; b <= b1; b++) bm[(b & (PBM_BITS - 1u)) >> 5] |= 1u << (b & 31u);
