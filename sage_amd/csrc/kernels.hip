@@ -2143,6 +2143,13 @@ __device__ __forceinline__ double cr_log_pair(const double x, const double lambd
 
 // select_most_intense_peak through a direct-index table over the peak masses (core.h: peak_lut_width / peak_lut_entry /
 // select_peak_lut, shared with the host: tests/test_core_emulation.py holds it to select_most_intense_peak)
+// Four zero registers made on the spot: a plain make_uint4(0, 0, 0, 0) is hoisted out of the rescoring round loop, SPILLED there
+// (rescore_kernel is out of registers) and comes back as a scratch load in front of the store it feeds.
+__device__ __forceinline__ uint4 fresh_zero4() {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return make_uint4(z, z, z, z);
+}
 __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, const float* pm, uint32_t P) {
     // plut[b] = number of peaks with mass < b * W in the total order (core.h: peak_lut_entry) — by counting instead of 256
     // binary searches: W is a power of two, so bin(m) = floor(m / W) is exact and `mass < b * W` <=> bin(m) < b; masses below
@@ -2153,7 +2160,7 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
     inv_w = pow2_reciprocal(w);
     static_assert(PLUT_BINS == 4 * WAVE, "four consecutive bins per lane");
     __syncthreads();
-    *(uint4*)(plut + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    *(uint4*)(plut + 4 * lane) = fresh_zero4();
     __syncthreads();
     for (uint32_t i = lane; i < P; i += WAVE) {
         const float m = pm[i];
@@ -2175,7 +2182,7 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
 // The peak-presence bitmap that filters score_candidate's lookups (core.h: peak_bitmap_params / _span / _bin, shared with the
 // host so that the CPU suite can test that the filter never drops a match).
 #ifndef SAGE_COOP_MIN_HITS
-#define SAGE_COOP_MIN_HITS 16
+#define SAGE_COOP_MIN_HITS 12
 #endif
 #ifndef SAGE_COOP_MAX_LANES
 #define SAGE_COOP_MAX_LANES 2
@@ -2190,8 +2197,9 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm,
     const uint32_t lane = lane_id();
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)bm != 0u) __builtin_trap();  // (pbm_bit: the bitmap at LDS address 0)
     static_assert(PBM_WORDS == 8 * WAVE, "two 16-byte stores per lane clear the bitmap");
-    *(uint4*)(bm + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
-    *(uint4*)(bm + 4 * (WAVE + lane)) = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 z4 = fresh_zero4();
+    *(uint4*)(bm + 4 * lane) = z4;
+    *(uint4*)(bm + 4 * (WAVE + lane)) = z4;
     __syncthreads();
     // ONE pass: every peak sets its bins; a peak without a safe reach (a negative or non-finite mass, D above 32 bins — core.h:
     // pbm_peak_reach) sets nothing and switches the filter off for the spectrum below
@@ -2475,7 +2483,11 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             while (idx >= lm1) { idx -= lm1; kind_i++; }
             for (uint32_t c = 1; c <= nfz; c++) {
                 if (c <= 3 && !(((c == 1 ? m1 : c == 2 ? m2 : m3) >> bit) & 1ull)) continue;
-                const float mz = c == 1 ? ionv : ionv / (float)c;  // (x / 1.0 == x)
+                // (x / 1.0 == x, x / 2.0 == x * 0.5 bit for bit: the IEEE division only for charges 3 and up; c is wave-uniform)
+                float mz;
+                if (c == 1) mz = ionv;
+                else if (c == 2) mz = ionv * 0.5f;
+                else mz = ionv / (float)c;
                 float flo, fhi;
                 tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
                 const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
