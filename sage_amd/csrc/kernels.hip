@@ -2307,6 +2307,10 @@ struct RescoreLds {
     double* s_sorted;     // [64] hyperscores by rank
     long long* s_key;     // [64] sort keys by lane
     QuickKey* qkeys;      // [64] quick_score only
+    uint32_t* hdr;        // [RESCORE_HDR_WORDS] the spectrum's scalars the Feature record needs (RescoreHdr): parked here across
+                          //      score_candidates instead of in scalar registers the kernel does not have
+    uint2* meta;          // [64] lane i: {pep_info, bits of pep_mono} of candidate i — gathered with the ion offsets, read when the
+                          //      record is written
     float* pm;            // [pcap] peak masses
     float* pi;            // [pcap] peak intensities
     uint8_t* rm;          // [pcap] chimera: peak selected by the winner
@@ -2319,8 +2323,11 @@ __host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return 
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
+constexpr uint32_t RESCORE_HDR_WORDS = 8;
+enum RescoreHdr { HDR_TIC = 0, HDR_MZP = 1, HDR_RT = 2, HDR_IMS = 3, HDR_FILE = 4, HDR_MATCHED = 5, HDR_SCORED = 6 };
+constexpr size_t RESCORE_HEAD_BYTES = RESCORE_HDR_WORDS * 4 + 64 * sizeof(uint2);  // hdr + meta, in front of the peaks
 __host__ __device__ inline size_t rescore_fixed_bytes(const DevScorer& sc, const DevBatchView& b) {
-    const size_t n = (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7) + (size_t)stage_records(sc) * sizeof(SageFeature);
+    const size_t n = RESCORE_HEAD_BYTES + (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7) + (size_t)stage_records(sc) * sizeof(SageFeature);
     return (n + 15) & ~(size_t)15;
 }
 __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsigned char* fixed, const DevBatchView& b) {
@@ -2330,11 +2337,13 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
     l.s_sorted = (double*)(l.plut + PLUT_BINS);
     l.s_key = (long long*)(l.s_sorted + 64);
     l.qkeys = (QuickKey*)(l.s_key + 64);
-    l.pm = (float*)fixed;
+    l.hdr = (uint32_t*)fixed;
+    l.meta = (uint2*)(fixed + RESCORE_HDR_WORDS * 4);
+    l.pm = (float*)(fixed + RESCORE_HEAD_BYTES);
     l.pi = l.pm + b.pcap;
     l.rm = (uint8_t*)(l.pi + b.pcap);
     l.rm2 = l.rm + b.pcap;
-    l.stage = (uint32_t*)(fixed + (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7));
+    l.stage = (uint32_t*)(fixed + RESCORE_HEAD_BYTES + (size_t)b.pcap * 8 + (((size_t)b.pcap * 2 + 7) & ~(size_t)7));
     return l;
 }
 
@@ -2516,7 +2525,7 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
 
 // One Feature record (scoring.rs:504-594) of a scored candidate: `rank_field` is Feature.rank, `next` / `best` the hyperscores of
 // the next rank (0 if none) and of rank 0.
-__device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const DevBatchView& b, const uint32_t spec, const uint32_t pep,
+__device__ __forceinline__ SageFeature make_feature(const uint32_t info, const float calc, const uint32_t spec_index, const uint32_t pep,
                                                     const uint32_t z, const int iso, const Score& s, const double h, const double next,
                                                     const double best, const uint32_t rank_field, const double lambda, const double ln_lambda, const float mzp,
                                                     const float rt, const float ims, const uint32_t fid, const float tic,
@@ -2527,13 +2536,11 @@ __device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const D
     const double log10_poisson =
         ((double)k * ln_lambda - lambda - lnfact_dev(k, lnfact_table, lnfact_n)) / 2.302585092994046;
     const float isotope_error = (float)iso * NEUTRON;
-    const uint32_t info = db.pep_info[pep];
-    const float calc = db.pep_mono[pep];
     const float delta_mass =
         (precursor_mass - calc - isotope_error) * 2E6f / (precursor_mass - isotope_error + calc);
     const uint32_t plen = info & 0xFFFF;
     SageFeature f;
-    f.spec_index = b.spec_base + spec;
+    f.spec_index = spec_index;
     f.peptide_idx = pep;
     f.rank = rank_field;  // scoring.rs:541, 664
     f.label = ((info >> 16) & 0xFF) ? -1 : 1;
@@ -2572,7 +2579,88 @@ __device__ __forceinline__ SageFeature make_feature(const DevDbView& db, const D
 // came from order-free trims — the right candidates in some other order — and such a tie cannot be settled
 // here: the function returns false with nothing final reported (`queue_on_tie`: after queueing the spectrum for the exact
 // retry pass; else the caller settles it itself).
-template <bool ACC, class PC>
+// ---- late arguments -------------------------------------------------------------------------------------------------------------
+// rescore_spectrum needs ~40 scalar registers' worth of arguments only AFTER score_candidates (result pointers, the factorial
+// table, the tie / retry bookkeeping, report_psms ...).  Held in registers across the matching loops they do not fit: round 4's
+// rescore_kernel wrote ~90 of them to spill lanes in front of score_candidates and read ~140 back behind it — a tenth of the
+// kernel's vector-ALU issue slots, once per spectrum.  The kernel's own arguments never need saving: they sit in the kernarg
+// segment, one scalar load away.  LateArgs<K> is how the part of rescore_spectrum behind score_candidates reads them:
+//   K = void:            from the references it was handed (kernels whose argument list is not a RescoreKernargs)
+//   K = RescoreKernargs: from the kernarg segment, through a pointer the compiler cannot see through (`refresh`) — so the loads
+//                        stay where they are written instead of being hoisted to the kernel's entry and spilled.
+struct RescoreKernargs {  // THE argument list of rescore_kernel (one struct, so that the segment's layout is this struct's)
+    DevDbView db;
+    DevScorer sc;
+    DevBatchView b;
+    DevWork w;
+    const double* lnfact_table;
+    uint32_t lnfact_n;
+    SageFeature* out;
+    uint32_t* out_count;
+    uint8_t* keep;
+};
+template <class K>
+struct LateArgs {  // K = void
+    const DevDbView& db;
+    const DevScorer& sc;
+    const DevBatchView& b;
+    const DevWork& w;
+    const double* lnfact_table_;
+    uint32_t lnfact_n_;
+    SageFeature* out_;
+    uint32_t* out_count_;
+    __device__ __forceinline__ LateArgs(const DevDbView& db_, const DevScorer& sc_, const DevBatchView& b_, const DevWork& w_, const double* t,
+                                        uint32_t tn, SageFeature* o, uint32_t* oc)
+        : db(db_), sc(sc_), b(b_), w(w_), lnfact_table_(t), lnfact_n_(tn), out_(o), out_count_(oc) {}
+    __device__ __forceinline__ void refresh() {}
+    __device__ __forceinline__ const float* ions() const { return db.ions; }
+    __device__ __forceinline__ uint32_t report_psms() const { return sc.report_psms; }
+    __device__ __forceinline__ uint32_t chimera() const { return sc.chimera; }
+    __device__ __forceinline__ uint32_t min_matched_peaks() const { return sc.min_matched_peaks; }
+    __device__ __forceinline__ int score_type() const { return sc.score_type; }
+    __device__ __forceinline__ uint32_t xcd_chunk() const { return sc.xcd_chunk; }
+    __device__ __forceinline__ uint32_t batch_n() const { return b.n; }
+    __device__ __forceinline__ uint32_t spec_base() const { return b.spec_base; }
+    __device__ __forceinline__ uint32_t* status() const { return w.status; }
+    __device__ __forceinline__ uint32_t* retry() const { return w.retry; }
+    __device__ __forceinline__ uint32_t* counters() const { return w.n_deferred; }
+    __device__ __forceinline__ const uint32_t* cnt_store() const { return w.cnt_store; }
+    __device__ __forceinline__ uint32_t cnt_stride() const { return w.cnt_stride; }
+    __device__ __forceinline__ const double* lnfact_table() const { return lnfact_table_; }
+    __device__ __forceinline__ uint32_t lnfact_n() const { return lnfact_n_; }
+    __device__ __forceinline__ SageFeature* out() const { return out_; }
+    __device__ __forceinline__ uint32_t* out_count() const { return out_count_; }
+    __device__ __forceinline__ uint8_t* keep(uint8_t* k) const { return k; }
+};
+template <>
+struct LateArgs<RescoreKernargs> {
+    typedef const __attribute__((address_space(4))) RescoreKernargs* Segment;
+    Segment ka;
+    __device__ __forceinline__ LateArgs(const DevDbView&, const DevScorer&, const DevBatchView&, const DevWork&, const double*, uint32_t, SageFeature*,
+                                        uint32_t*)
+        : ka((Segment)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+s"(ka)); }
+    __device__ __forceinline__ const float* ions() const { return ka->db.ions; }
+    __device__ __forceinline__ uint32_t report_psms() const { return ka->sc.report_psms; }
+    __device__ __forceinline__ uint32_t chimera() const { return ka->sc.chimera; }
+    __device__ __forceinline__ uint32_t min_matched_peaks() const { return ka->sc.min_matched_peaks; }
+    __device__ __forceinline__ int score_type() const { return ka->sc.score_type; }
+    __device__ __forceinline__ uint32_t xcd_chunk() const { return ka->sc.xcd_chunk; }
+    __device__ __forceinline__ uint32_t batch_n() const { return ka->b.n; }
+    __device__ __forceinline__ uint32_t spec_base() const { return ka->b.spec_base; }
+    __device__ __forceinline__ uint32_t* status() const { return ka->w.status; }
+    __device__ __forceinline__ uint32_t* retry() const { return ka->w.retry; }
+    __device__ __forceinline__ uint32_t* counters() const { return ka->w.n_deferred; }
+    __device__ __forceinline__ const uint32_t* cnt_store() const { return ka->w.cnt_store; }
+    __device__ __forceinline__ uint32_t cnt_stride() const { return ka->w.cnt_stride; }
+    __device__ __forceinline__ const double* lnfact_table() const { return ka->lnfact_table; }
+    __device__ __forceinline__ uint32_t lnfact_n() const { return ka->lnfact_n; }
+    __device__ __forceinline__ SageFeature* out() const { return ka->out; }
+    __device__ __forceinline__ uint32_t* out_count() const { return ka->out_count; }
+    __device__ __forceinline__ uint8_t* keep(uint8_t*) const { return ka->keep; }
+};
+
+template <bool ACC, class KA, class PC>
 __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                                                  const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                  SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
@@ -2585,7 +2673,6 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     uint32_t* const plut = R.plut;
     float* const pm = R.pm;
     float* const pi = R.pi;
-    float tic = b.tic[spec];
     const uint32_t pep = prescore_peptide(mine);
     const bool valid = pep != 0xFFFFFFFFu;  // scoring.rs:489
     const uint32_t z = prescore_charge(mine);
@@ -2597,20 +2684,24 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         ion_base = db.ion_off[pep];
         // ions per kind = peptide length - 1 (ion_series.rs:68-85; the ion table holds n_kinds * (L - 1) values per peptide): from
         // the peptide's record, not as (ion_off[pep + 1] - ion_off[pep]) / n_kinds — a 64-bit division per candidate
-        const uint32_t plen = db.pep_info[pep] & 0xFFFFu;
+        const uint32_t info = db.pep_info[pep];
+        const uint32_t plen = info & 0xFFFFu;
         lm1 = db.n_kinds && plen ? plen - 1u : 0u;
+        R.meta[lane] = make_uint2(info, __float_as_uint(db.pep_mono[pep]));  // (for the Feature record of a reporting lane)
     }
-    // (registers are what this kernel is short of: whatever only a reporting lane needs — the peptide's record, its mass — is
-    // read when the record is written, and nothing is kept that two instructions recompute)
+    // (registers are what this kernel is short of: what only the Feature record needs waits in LDS — R.meta, R.hdr — and nothing
+    // is kept that two instructions recompute)
+    if (lane == 0) {
+        float ims = 0.0f;
+        if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
+        static_assert(HDR_TIC == 0 && HDR_MZP == 1 && HDR_RT == 2 && HDR_IMS == 3 && HDR_FILE == 4 && HDR_MATCHED == 5 && HDR_SCORED == 6, "two 16-byte stores");
+        *(uint4*)R.hdr = make_uint4(__float_as_uint(b.tic[spec]), __float_as_uint(b.precursor_mz[spec] - PROTON) /* scoring.rs:502 */,
+                                    __float_as_uint(b.rt ? b.rt[spec] : 0.0f), __float_as_uint(ims));
+        *(uint4*)(R.hdr + 4) = make_uint4(b.file_id ? b.file_id[spec] : 0u, tot_matched, tot_scored, 0u);
+    }
 #define SAGE_N_ITEMS (valid ? db.n_kinds * lm1 * nfz : 0u)  /* (ion, fragment charge) pairs of this candidate */
 
-    const double lambda = (double)tot_matched / (double)tot_scored;  // scoring.rs:499
-    double ln_lambda = 0.0;                                           // (cr_log_pair, first round)
-    const float mzp = b.precursor_mz[spec] - PROTON;                // scoring.rs:502
-    const float rt = b.rt ? b.rt[spec] : 0.0f;
-    float ims = 0.0f;
-    if (b.ims) { const float v = b.ims[spec]; ims = v == v ? v : 0.0f; }
-    const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
+    double ln_lambda = 0.0;  // (cr_log_pair, first round)
     __syncthreads();
     pc.mark(0);
     if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
@@ -2625,14 +2716,12 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         (void)items; (void)longest; (void)nvalid;  // (slots 5..7 now hold phases)
     }
 
-    const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
-    const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
     const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
     const bool any_fz2 = __ballot(valid && nfz >= 2) != 0ull, any_fz3 = __ballot(valid && nfz >= 3) != 0ull;
-    for (uint32_t round = 0; round < rounds; round++) {
+    for (uint32_t round = 0;; round++) {
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
         // (built once: after remove_matched_peaks the bitmap is a superset of the remaining peaks' bins — still conservative)
@@ -2649,6 +2738,10 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         pc.mark(5);  // (... the peak table and the bitmap)
         score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, pc);
         pc.mark(1);  // (... the lanes' own hits)
+        // ---- from here on: the arguments through `la`, the spectrum's scalars from R.hdr (see LateArgs) ----
+        LateArgs<KA> la(db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
+        la.refresh();
+        const double lambda = (double)R.hdr[HDR_MATCHED] / (double)R.hdr[HDR_SCORED];  // scoring.rs:499
         double h = 0.0;
         bool pass = false;
         bool ln_undecided;
@@ -2656,17 +2749,20 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         if (__builtin_expect(!ACC && __ballot(ln_undecided && (valid || round == 0)) != 0ull, 0)) {
             // (the hot instance carries the logarithm's fast phase only: this spectrum again in the retry pass, like a tie)
             if (queue_on_tie && lane == 0) {
-                w.status[spec] = ST_RETRY;
-                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
-                out_count[spec] = 0;
+                la.status()[spec] = ST_RETRY;
+                la.retry()[atomicAdd(la.counters() + CTR_RETRY, 1u)] = spec;
+                la.out_count()[spec] = 0;
             }
             return false;
         }
         if (valid) {
             s.ppm_difference /= s.summed_b + s.summed_y;  // scoring.rs:759
-            h = hyperscore_dev(sc.score_type, s, ln_i, lnfact_table, lnfact_n);
-            pass = (s.matched_b + s.matched_y) >= sc.min_matched_peaks;  // scoring.rs:491
+            h = hyperscore_dev(la.score_type(), s, ln_i, la.lnfact_table(), la.lnfact_n());
+            pass = (s.matched_b + s.matched_y) >= la.min_matched_peaks();  // scoring.rs:491
         }
+        const uint32_t report_psms = la.report_psms();
+        const bool chimera = la.chimera() != 0u;
+        const uint32_t per_round = chimera ? 1u : report_psms;
         if (keep) {
             // quick_score, prefilter_low_memory (scoring.rs:270-289): bounded_min_heapify(&mut scores, k) keeps the k
             // largest elements.  heap.rs compares with `<` / `>`, i.e. the DERIVED PartialOrd of Score — lexicographic
@@ -2680,7 +2776,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             qk[lane] = mk;
             const uint64_t pmask = __ballot(pass);
             const uint32_t npass = (uint32_t)__popcll(pmask);
-            const uint32_t kq = sc.report_psms < npass ? sc.report_psms : npass;  // scoring.rs:284
+            const uint32_t kq = report_psms < npass ? report_psms : npass;  // scoring.rs:284
             __syncthreads();
             if (pass) {
                 uint32_t above = 0;
@@ -2690,7 +2786,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                     m &= m - 1;
                     above += j != lane && quick_gt(qk[j], mk);
                 }
-                if (above < kq) keep[pep] = 1;
+                if (above < kq) la.keep(keep)[pep] = 1;
             }
             return true;
         }
@@ -2746,13 +2842,14 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             // LDS of the bitmap and the peak table, which are dead by now), looks the tied candidates up in the replayed list
             // and the earliest one reports through the ordinary path below — no parking, no extra launch behind the step's last
             // rescoring wavefront.  ~25 us for the 3 % of the wavefronts that get here.
-            if (queue_on_tie && w.cnt_store && per_round == 1 && !sc.chimera) {
-                const uint32_t* __restrict__ row = w.cnt_store + (size_t)xcd_position(blockIdx.x, b.n, sc.xcd_chunk) * w.cnt_stride;
+            la.refresh();
+            if (queue_on_tie && la.cnt_store() && per_round == 1 && !chimera) {
+                const uint32_t* __restrict__ row = la.cnt_store() + (size_t)xcd_position(blockIdx.x, la.batch_n(), la.xcd_chunk()) * la.cnt_stride();
                 const uint32_t left = uni(row[0]), potential = uni(row[1]);
                 if (potential != 0u) {
                     const bool is_best = pass && __double_as_longlong(h) == __double_as_longlong(best_h);
                     uint64_t tb = __ballot(is_best);
-                    const uint32_t k = trim_k(potential, sc.report_psms);
+                    const uint32_t k = trim_k(potential, report_psms);
                     Counters cnt;
                     cnt.p = pbm;  // [(wcap + 1) / 2] words <= the 3 KB of bitmap + peak table
                     __syncthreads();
@@ -2793,35 +2890,40 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                     }
                     rank = pass && lane == win ? 0u : 1u;  // (next_h == best_h already: the runner-up has the same hyperscore)
                     tie = false;
-                    if (lane == 0) atomicAdd(w.n_deferred + CTR_FAST_TIE, 1u);  // (statistics: SageTiming::n_tied)
+                    if (lane == 0) atomicAdd(la.counters() + CTR_FAST_TIE, 1u);  // (statistics: SageTiming::n_tied)
                 }
             }
             if (__ballot(tie) != 0ull) {
-            if (queue_on_tie && lane == 0) {
-                w.status[spec] = ST_RETRY;
-                w.retry[atomicAdd(w.n_deferred + CTR_RETRY, 1u)] = spec;
-                out_count[spec] = 0;
-            }
-            return false;
+                if (queue_on_tie && lane == 0) {
+                    la.status()[spec] = ST_RETRY;
+                    la.retry()[atomicAdd(la.counters() + CTR_RETRY, 1u)] = spec;
+                    la.out_count()[spec] = 0;
+                }
+                return false;
             }
         }
         pc.mark(3);
+        la.refresh();
         if (pass && rank < per_round) {  // scoring.rs:504-594
-            const SageFeature f = make_feature(db, b, spec, pep, z, iso, s, h, next_h, best_h, sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims,
-                                               fid, tic, tot_scored, lnfact_table, lnfact_n);
-            *(SageFeature*)(R.stage + (size_t)(sc.chimera ? 0u : rank) * FEATURE_WORDS) = f;
+            const uint2 meta = R.meta[lane];
+            const uint4 h0 = *(const uint4*)R.hdr;         // tic, precursor mass / charge, rt, ims
+            const uint4 h1 = *(const uint4*)(R.hdr + 4);   // file, matched peaks, scored candidates
+            const SageFeature f = make_feature(meta.x, __uint_as_float(meta.y), la.spec_base() + spec, pep, z, iso, s, h, next_h, best_h,
+                                               chimera ? round + 1 : rank + 1, lambda, ln_lambda, __uint_as_float(h0.y), __uint_as_float(h0.z),
+                                               __uint_as_float(h0.w), h1.x, __uint_as_float(h0.x), h1.z, la.lnfact_table(), la.lnfact_n());
+            *(SageFeature*)(R.stage + (size_t)(chimera ? 0u : rank) * FEATURE_WORDS) = f;
         }
         const uint32_t emitted = npass < per_round ? npass : per_round;
         // the records of this round leave together: consecutive ranks are consecutive records, so the wavefront stores them as
         // one contiguous run of dwords (full write requests, whether `out` is HBM or the caller's page-locked host memory)
         __syncthreads();
         {
-            uint32_t* __restrict__ dst = (uint32_t*)(out + (size_t)spec * sc.report_psms + (sc.chimera ? round : 0u));
+            uint32_t* __restrict__ dst = (uint32_t*)(la.out() + (size_t)spec * report_psms + (chimera ? round : 0u));
             for (uint32_t i = lane; i < emitted * FEATURE_WORDS; i += WAVE) dst[i] = R.stage[i];
         }
         pc.mark(4);
         n_emitted += emitted;
-        if (!sc.chimera || emitted == 0 || round + 1 == rounds) break;
+        if (!chimera || emitted == 0 || round + 1 == report_psms) break;  // (chimera: report_psms rounds of one PSM)
 
         // ---- remove_matched_peaks(winner), scoring.rs:598-644 ----
         const uint64_t wmask = __ballot(pass && rank == 0);
@@ -2830,10 +2932,18 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         const uint32_t w_items = __shfl(SAGE_N_ITEMS, wl, 64);
         const unsigned long long w_base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(ion_base >> 32), (int)wl, 64) << 32) |
                                           (uint32_t)__shfl((int)(uint32_t)ion_base, (int)wl, 64);
-        const float* wions = db.ions + w_base;
+        const float* wions = la.ions() + w_base;
+        float tic = __uint_as_float(R.hdr[HDR_TIC]);
         remove_matched_peaks_dev(pm, pi, R.rm, R.rm2, P, tic, wions, w_items, wmfc, sc.fragment_tol);
+        __syncthreads();
+        if (lane == 0) R.hdr[HDR_TIC] = __float_as_uint(tic);
+        __syncthreads();
     }
-    if (lane == 0) out_count[spec] = n_emitted;
+    {
+        LateArgs<KA> la(db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
+        la.refresh();
+        if (lane == 0) la.out_count()[spec] = n_emitted;
+    }
     return true;
 #undef SAGE_N_ITEMS
 }
@@ -3010,7 +3120,8 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                     s.ppm_difference = q.ppm_difference; s.longest_b = q.longest_b; s.longest_y = q.longest_y;
                     const double h = g_sorted[rank];
                     const double next = rank + 1 < npass ? g_sorted[rank + 1] : 0.0, best = g_sorted[0];
-                    const SageFeature f = make_feature(db, b, spec, prescore_peptide(mine), prescore_charge(mine), prescore_iso(mine), s, h, next, best,
+                    const SageFeature f = make_feature(db.pep_info[prescore_peptide(mine)], db.pep_mono[prescore_peptide(mine)], b.spec_base + spec,
+                                                       prescore_peptide(mine), prescore_charge(mine), prescore_iso(mine), s, h, next, best,
                                                        sc.chimera ? round + 1 : rank + 1, lambda, ln_lambda, mzp, rt, ims, fid, tic, tot_scored, lnfact_table,
                                                        lnfact_n);
                     out[(size_t)spec * sc.report_psms + (sc.chimera ? round : rank)] = f;
@@ -3044,10 +3155,17 @@ __host__ __device__ inline size_t narrow_scratch_bytes(const DevScorer& sc, cons
 // with exact trims, inline or behind a call — was measured: the extra code costs the hot path its registers, rescoring went
 // from 3.7 to 6.0 resp. 7.2 ms per 500 000 C3 spectra.  DESIGN.md 4.7.)
 template <bool PROF, bool ACC>
-__global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
-                                                     const double* __restrict__ lnfact_table, uint32_t lnfact_n,
-                                                     SageFeature* __restrict__ out,
-                                                     uint32_t* __restrict__ out_count, uint8_t* __restrict__ keep) {
+__global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(RescoreKernargs A) {
+    // (ONE argument: rescore_spectrum reads what it needs late straight from the kernarg segment — LateArgs<RescoreKernargs>)
+    const DevDbView& db = A.db;
+    const DevScorer& sc = A.sc;
+    const DevBatchView& b = A.b;
+    const DevWork& w = A.w;
+    const double* __restrict__ lnfact_table = A.lnfact_table;
+    const uint32_t lnfact_n = A.lnfact_n;
+    SageFeature* __restrict__ out = A.out;
+    uint32_t* __restrict__ out_count = A.out_count;
+    uint8_t* __restrict__ keep = A.keep;
     typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
@@ -3077,7 +3195,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Dev
     const uint32_t ncand = w.cand_len[spec];
     const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
     // (a list no trim touched is the reference's list already: equal hyperscores are ranked by it, no retry)
-    rescore_spectrum<ACC>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
+    rescore_spectrum<ACC, RescoreKernargs>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
                      sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
@@ -3187,7 +3305,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
     const uint32_t tot_s = __hip_atomic_load(w.totals + 2 * spec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t mine = lane < ncand ? __hip_atomic_load(w.cand + (size_t)spec * sc.kmax + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                        : PRESCORE_EMPTY;
-    const bool done = rescore_spectrum<true>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s,
+    const bool done = rescore_spectrum<true, void>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, P, mine, tot_m, tot_s,
                                        st == ST_OK_ORDERED, true, pc);
     if (done && lane == 0) w.status[spec] = ST_DONE;  // (a rescore_kernel behind the large-window kernels leaves it alone)
 }
@@ -3258,7 +3376,7 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
             pc.mark(4);
             pc.rebase(1);  // (the rescoring phase accounts under kernel 1)
             __syncthreads();  // the list is in registers: the preliminary phase's LDS is free
-            if (rescore_spectrum<true>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
+            if (rescore_spectrum<true, void>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
                                  exact || r.untrimmed, false, pc) || exact)
                 break;
             exact = true;  // equal hyperscores at a reported rank: once more, with bounded_min_heapify replayed (heap.rs:7-28)
@@ -3469,8 +3587,8 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
     }
     // the first pass of a two-pass search (sc.fast_log) runs the instance with the logarithm's fast phase only (crlog.h)
     const auto kern = w.dbg ? rescore_kernel<true, true> : (sc.fast_log && !keep) ? rescore_kernel<false, false> : rescore_kernel<false, true>;
-    hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr),
-                       (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep);
+    const RescoreKernargs args{db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep};
+    hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, args);
 }
 void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream) {
     const uint32_t blocks = (n + 1023) / 1024;
