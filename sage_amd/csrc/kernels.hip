@@ -495,26 +495,26 @@ struct Window {
     uint32_t left, right, first, end;
 };
 template <bool GALLOP>
-__device__ __forceinline__ Window query_window(const DevDbView& db, const Tol& ptol, float center) {
+__device__ __forceinline__ Window query_window(const float* __restrict__ pep_mono, const uint32_t np, const Tol& ptol, float center) {
     float plo, phi;
     tol_bounds(ptol, center, plo, phi);
     Window q;
-    uint32_t left = wave_partition_point<true>(db.pep_mono, 0, db.np, order_key(plo));
+    uint32_t left = wave_partition_point<true>(pep_mono, 0, np, order_key(plo));
     left = left ? left - 1 : 0;
-    uint32_t ghi = db.np;
+    uint32_t ghi = np;
     if (GALLOP) {  // the window is short in a narrow search: bracket it by galloping from `left` before searching
         for (uint64_t span = WAVE;; span *= 16) {
-            ghi = (uint64_t)left + span < db.np ? (uint32_t)(left + span) : db.np;
-            if (ghi == db.np || order_key(db.pep_mono[ghi - 1]) > order_key(phi)) break;
+            ghi = (uint64_t)left + span < np ? (uint32_t)(left + span) : np;
+            if (ghi == np || order_key(pep_mono[ghi - 1]) > order_key(phi)) break;
         }
     }
-    const uint32_t right = wave_partition_point<false>(db.pep_mono, left, ghi, order_key(phi));
+    const uint32_t right = wave_partition_point<false>(pep_mono, left, ghi, order_key(phi));
     q.left = left;
     q.right = right;
     q.first = left;
     q.end = right;
-    if (left < db.np && !(db.pep_mono[left] >= plo)) q.first = left + 1;
-    if (right < db.np && db.pep_mono[right] <= phi) q.end = right + 1;
+    if (left < np && !(pep_mono[left] >= plo)) q.first = left + 1;
+    if (right < np && pep_mono[right] <= phi) q.end = right + 1;
     return q;
 }
 
@@ -618,6 +618,49 @@ static_assert((PROBE_BATCH & (PROBE_BATCH - 1)) == 0, "PROBE_BATCH must be a pow
 #else
 #define SAGE_RESCORE_WAVES_ATTR
 #endif
+// ---- arguments where they are used ---------------------------------------------------------------------------------------------
+// The per-spectrum kernels take ~100 scalar registers' worth of arguments (four views) and have 100 scalar registers.  Loaded at
+// the kernel's entry — where the compiler puts kernarg loads — most of them are written to spill lanes at once and read back
+// phase by phase: v_writelane / v_readlane, vector-ALU issue slots of kernels that are bound by exactly those (round 4:
+// ~350 of prelim_kernel's ~2 000 vector instructions per spectrum).  But a kernel's arguments never need saving: they sit in the
+// kernarg segment, one SCALAR load away.  ArgRef<K> is how prelim_spectrum reads them:
+//   K = void:           from the references it was handed (the kernels whose argument list is something else)
+//   K = PrelimKernargs: from the kernarg segment through a pointer the compiler cannot see through (`refresh()` at the head of
+//                       every phase) — the loads stay at the head of the phase that uses them, nothing lives across phases.
+// (LateArgs, further down, is the same idea for the tail of rescore_spectrum.)
+struct PrelimKernargs {  // THE argument list of prelim_kernel (one struct: the segment's layout is this struct's)
+    DevDbView db;
+    DevScorer sc;
+    DevBatchView b;
+    DevWork w;
+};
+#define SAGE_LOAD_TOL(t) Tol{(t).kind, (t).lo, (t).hi}  /* a Tol out of either address space, field by field */
+template <class K>
+struct ArgRef {  // K = void
+    const DevDbView& db_;
+    const DevScorer& sc_;
+    const DevBatchView& b_;
+    __device__ __forceinline__ ArgRef(const DevDbView& d, const DevScorer& s, const DevBatchView& b) : db_(d), sc_(s), b_(b) {}
+    __device__ __forceinline__ void refresh() {}
+    __device__ __forceinline__ const DevDbView& db() const { return db_; }
+    __device__ __forceinline__ const DevScorer& sc() const { return sc_; }
+    __device__ __forceinline__ const DevBatchView& b() const { return b_; }
+};
+template <>
+struct ArgRef<PrelimKernargs> {
+    typedef const __attribute__((address_space(4))) PrelimKernargs* Segment;
+    Segment ka;
+    __device__ __forceinline__ ArgRef(const DevDbView&, const DevScorer&, const DevBatchView&)
+        : ka((Segment)__builtin_amdgcn_kernarg_segment_ptr()) {}
+    __device__ __forceinline__ void refresh() {  // (from the builtin every time: a `ka` carried across branches would end up in a VGPR)
+        ka = (Segment)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+    }
+    __device__ __forceinline__ const __attribute__((address_space(4))) DevDbView& db() const { return ka->db; }
+    __device__ __forceinline__ const __attribute__((address_space(4))) DevScorer& sc() const { return ka->sc; }
+    __device__ __forceinline__ const __attribute__((address_space(4))) DevBatchView& b() const { return ka->b; }
+};
+
 // Scorer::initial_hits (scoring.rs:418-462) of ONE spectrum by one wavefront: the final preliminary list ends up in L.listB.
 // `exact`: every trim_hits replays bounded_min_heapify (the list is in the reference's heap layout); else the order-free trims.
 struct PrelimResult {
@@ -630,16 +673,20 @@ struct PrelimResult {
     uint32_t q_left, q_potential;  // the LAST precursor-window query: first candidate slot's peptide and the number of slots; its
                                    //     counts are still in L.cnt when prelim_spectrum returns
 };
-template <bool PROBE, bool BIGK = false, class PC>
-__device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const PrelimLds& L,
+template <bool PROBE, bool BIGK = false, class KA = void, class PC>
+__device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, const DevScorer& sc_, const DevBatchView& b_, const PrelimLds& L,
                                                         const SpecInfo& si, const bool exact, PC& pc) {
     const uint32_t lane = lane_id();
+    ArgRef<KA> av(db_, sc_, b_);  // (every argument through `av`, refreshed phase by phase: see ArgRef)
+    av.refresh();
     Counters cnt;
     cnt.p = L.cnt;
     PrelimResult res{0u, 0u, 0u, true, false, true, 0u, 0u};
     {
         const uint32_t P = si.P, nfz_max = si.nfz_max;
-        const float* __restrict__ masses = b.masses + si.p0;
+        const float* __restrict__ masses = av.b().masses + si.p0;
+        const uint32_t pcap = av.b().pcap;
+        const Tol ftol0 = SAGE_LOAD_TOL(av.sc().fragment_tol);
 
         // fragment-tolerance window of every (peak, fragment charge): database.rs:481 on the
         // experimental mass peak*charge of scoring.rs:360
@@ -651,9 +698,9 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
             }
             for (uint32_t fz = 1; fz <= nfz_max; fz++) {
                 float lo, hi;
-                tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
-                L.win_lo[(size_t)(fz - 1) * b.pcap + i] = lo;
-                L.win_hi[(size_t)(fz - 1) * b.pcap + i] = hi;
+                tol_bounds(ftol0, m * (float)fz, lo, hi);
+                L.win_lo[(size_t)(fz - 1) * pcap + i] = lo;
+                L.win_hi[(size_t)(fz - 1) * pcap + i] = hi;
             }
         }
         __syncthreads();
@@ -663,8 +710,8 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
         if (!PROBE) {
             bool mono_ok = true;
             for (uint32_t fz = 0; fz < nfz_max; fz++) {
-                const float* wl = L.win_lo + (size_t)fz * b.pcap;
-                const float* wh = L.win_hi + (size_t)fz * b.pcap;
+                const float* wl = L.win_lo + (size_t)fz * pcap;
+                const float* wh = L.win_hi + (size_t)fz * pcap;
                 for (uint32_t i = lane; i < P; i += WAVE) {
                     mono_ok = mono_ok && (wl[i] <= wh[i]);
                     if (i > 0) mono_ok = mono_ok && (wl[i - 1] <= wl[i]) && (wh[i - 1] <= wh[i]);
@@ -675,26 +722,29 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
         }
         pc.mark(0);
 
-        const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
-        const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+        av.refresh();
+        const bool fold = av.sc().min_isotope_err != av.sc().max_isotope_err;  // scoring.rs:391
+        const int isoA = fold ? av.sc().min_isotope_err : 0, isoB = fold ? av.sc().max_isotope_err : 0;
 
         UList A, B;  // wave-uniform state
-        A.items = L.listA; A.cap = fold ? sc.list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
-        B.items = L.listB; B.cap = sc.list_cap; B.stored = 0; B.len = 0; B.ok = true;
+        A.items = L.listA; A.cap = fold ? av.sc().list_cap : 0; A.stored = 0; A.len = 0; A.ok = true;
+        B.items = L.listB; B.cap = av.sc().list_cap; B.stored = 0; B.len = 0; B.ok = true;
         bool deferred = false;                     // uniform
         uint32_t tot_matched = 0, tot_scored = 0;  // uniform
 
         for (uint32_t z = si.z0; z <= si.z1 && !deferred; z++) {
-            const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+            av.refresh();
+            const uint32_t nfz = max_fragment_charge(av.sc().max_fragment_charge, z) - 1;
             const float precursor_mass = si.mzp * (float)z;
-            const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
+            const Tol ptol = av.sc().wide_window ? tol_scaled(si.iso_tol, (float)z) : SAGE_LOAD_TOL(av.sc().precursor_tol);
             if (fold) { A.stored = 0; A.len = 0; }
             for (int iso = isoA; iso <= isoB && !deferred; iso++) {
                 const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
-                const Window q = query_window<true>(db, ptol, center);
+                av.refresh();
+                const Window q = query_window<true>(av.db().pep_mono, av.db().np, ptol, center);
                 const uint32_t left = q.left;
                 const uint32_t potential = q.right - q.left + 1;  // scoring.rs:351
-                if (potential > sc.wcap) {
+                if (potential > av.sc().wcap) {
                     deferred = true;
                     break;
                 }
@@ -704,22 +754,25 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                 __syncthreads();
                 uint32_t acc = 0;
                 if (!PROBE && q.first < q.end) {
-                    const uint64_t f0 = db.pm_off[q.first], f1 = db.pm_off[q.end];
+                    av.refresh();
+                    const uint64_t f0 = av.db().pm_off[q.first], f1 = av.db().pm_off[q.end];
+                    const SageTheoretical* __restrict__ pm_frag = av.db().pm_frag;
+                    const uint32_t pcap = av.b().pcap;
                     auto count_one = [&](float frag) -> uint32_t {
                         if (!sorted_ok) {
                             uint32_t c = 0;
                             for (uint32_t fz = 0; fz < nfz; fz++)
-                                c += count_windows_scan(L.win_lo + (size_t)fz * b.pcap, L.win_hi + (size_t)fz * b.pcap, P, frag);
+                                c += count_windows_scan(L.win_lo + (size_t)fz * pcap, L.win_hi + (size_t)fz * pcap, P, frag);
                             return c;
                         }
                         switch (nfz) {
-                            case 1: return count_windows_lockstep<1>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
-                            case 2: return count_windows_lockstep<2>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
-                            case 3: return count_windows_lockstep<3>(L.win_lo, L.win_hi, b.pcap, P, ptop, frag);
+                            case 1: return count_windows_lockstep<1>(L.win_lo, L.win_hi, pcap, P, ptop, frag);
+                            case 2: return count_windows_lockstep<2>(L.win_lo, L.win_hi, pcap, P, ptop, frag);
+                            case 3: return count_windows_lockstep<3>(L.win_lo, L.win_hi, pcap, P, ptop, frag);
                             default: {
                                 uint32_t c = 0;
                                 for (uint32_t fz = 0; fz < nfz; fz++)
-                                    c += count_windows_sorted(L.win_lo + (size_t)fz * b.pcap, L.win_hi + (size_t)fz * b.pcap, P, frag);
+                                    c += count_windows_sorted(L.win_lo + (size_t)fz * pcap, L.win_hi + (size_t)fz * pcap, P, frag);
                                 return c;
                             }
                         }
@@ -728,14 +781,14 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                     // loads are issued before this trip's LDS searches
                     SageTheoretical n0{0, 0.f}, n1{0, 0.f};
                     uint64_t j = f0 + lane;
-                    if (j < f1) n0 = db.pm_frag[j];
-                    if (j + WAVE < f1) n1 = db.pm_frag[j + WAVE];
+                    if (j < f1) n0 = pm_frag[j];
+                    if (j + WAVE < f1) n1 = pm_frag[j + WAVE];
                     for (; j < f1; j += 2 * WAVE) {
                         const SageTheoretical fr0 = n0, fr1 = n1;
                         const bool has1 = j + WAVE < f1;
                         const uint64_t jn = j + 2 * WAVE;
-                        if (jn < f1) n0 = db.pm_frag[jn];
-                        if (jn + WAVE < f1) n1 = db.pm_frag[jn + WAVE];
+                        if (jn < f1) n0 = pm_frag[jn];
+                        if (jn + WAVE < f1) n1 = pm_frag[jn + WAVE];
                         const uint32_t c0 = count_one(fr0.fragment_mz);
                         const uint32_t c1 = has1 ? count_one(fr1.fragment_mz) : 0;
                         if (c0) { cnt.add(fr0.peptide_index - left, c0); acc += c0; }
@@ -750,8 +803,13 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                     // dozens of entries), so the runs of a batch of windows are FLATTENED into a list of 16-byte cells (two
                     // entries each) shared evenly by the 64 lanes, each lane's cells in flight together: one round trip for
                     // the table, one for the entries, no lane waiting on another lane's long run.
-                    const uint4* __restrict__ frag2 = (const uint4*)db.tm2_frag;
-                    const uint32_t t0 = q.first >> db.tile2_shift, t1 = (q.end - 1) >> db.tile2_shift;
+                    av.refresh();
+                    const uint4* __restrict__ frag2 = (const uint4*)av.db().tm2_frag;
+                    const uint32_t* __restrict__ tm2_lut = av.db().tm2_lut;
+                    const uint32_t tile2_shift = av.db().tile2_shift, lut2_stride = av.db().lut2_stride;
+                    const float lut2_scale = av.db().lut2_scale;
+                    const Tol ftol = SAGE_LOAD_TOL(av.sc().fragment_tol);
+                    const uint32_t t0 = q.first >> tile2_shift, t1 = (q.end - 1) >> tile2_shift;
                     const uint32_t nprobe = P * nfz;
                     uint32_t* const tp0 = L.ptab;                      // [PROBE_BATCH] first entry of the run
                     uint32_t* const tp1 = L.ptab + PROBE_BATCH;        // [PROBE_BATCH] end entry
@@ -760,11 +818,11 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                         flo = 1.0f; fhi = 0.0f;  // (no such window: empty)
                         if (pr < nprobe) {
                             const uint32_t fz = pr / P, i = pr - fz * P;
-                            tol_bounds(sc.fragment_tol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
+                            tol_bounds(ftol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
                         }
                     };
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
-                        const uint32_t* __restrict__ lut = db.tm2_lut + (size_t)t * db.lut2_stride;
+                        const uint32_t* __restrict__ lut = tm2_lut + (size_t)t * lut2_stride;
                         for (uint32_t pbase = 0; pbase < nprobe; pbase += PROBE_BATCH) {
                             // table reads of up to PROBE_BATCH windows, PROBE_PER_LANE per lane, all in flight together;
                             // window q of the flattened order (lane-major) is window pbase + (q % PPL) * 64 + q / PPL
@@ -774,7 +832,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                                 float flo, fhi;
                                 window_of(pbase + i * WAVE + lane, flo, fhi);
                                 uint32_t icl, ich;  // (core.h: the scale is a power of two, no safety margin needed)
-                                lut_cells(flo, fhi, db.lut2_scale, db.lut2_stride, icl, ich);
+                                lut_cells(flo, fhi, lut2_scale, lut2_stride, icl, ich);
                                 rp0[i] = lut[icl];
                                 rp1[i] = lut[ich];
                             }
@@ -840,16 +898,18 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                 const uint32_t matched = wave_sum(acc);
                 __syncthreads();
                 pc.mark(2);
+                av.refresh();
+                const uint32_t kmax = av.sc().kmax, report_psms = av.sc().report_psms;
                 res.q_left = left;            // (of the last query: what prelim_kernel keeps of a single-query spectrum)
                 res.q_potential = potential;
                 tot_matched += matched;
                 UList& target = fold ? A : B;
                 if (matched == 0) {  // scoring.rs:376-378: the untrimmed all-default vector
-                    ulist_append_empties(target, potential, sc.kmax);
+                    ulist_append_empties(target, potential, kmax);
                     continue;
                 }
                 // ---- trim_hits of this query, scoring.rs:380 ----
-                const uint32_t k = trim_k(potential, sc.report_psms);
+                const uint32_t k = trim_k(potential, report_psms);
                 uint32_t scored = 0;
                 if (potential <= k) {  // no k-select: the slots go to the list verbatim
                     for (uint32_t base = 0; base < potential; base += WAVE) {
@@ -857,7 +917,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                         const uint32_t c = i < potential ? cnt.get(i) : 0;
                         scored += (uint32_t)__popcll(__ballot(c > 0));
                         const uint32_t nvalid = potential - base < WAVE ? potential - base : WAVE;
-                        ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, sc.kmax);
+                        ulist_append(target, c ? pack_prescore(c, left + i, z, iso) : PRESCORE_EMPTY, nvalid, kmax);
                     }
                 } else if (BIGK) {
                     // k > 64 (report_psms > 32): the heap in LDS (always exact; see lh_build)
@@ -877,8 +937,8 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                         lh_offer_batch(hp, k, pack_prescore(c, left + i, z, iso), c > 0);
                     }
                     for (uint32_t base = 0; base < k; base += WAVE)
-                        ulist_append(target, base + lane < k ? hp[base + lane] : PRESCORE_EMPTY, k - base < WAVE ? k - base : WAVE, sc.kmax);
-                } else if (!exact && fast_select(L, cnt, potential, k, left, z, iso, sc.kmax, target, scored)) {
+                        ulist_append(target, base + lane < k ? hp[base + lane] : PRESCORE_EMPTY, k - base < WAVE ? k - base : WAVE, kmax);
+                } else if (!exact && fast_select(L, cnt, potential, k, left, z, iso, kmax, target, scored)) {
                     // (done: the k largest slots by (count, slot) without replaying the heap)
                     res.untrimmed = false;
                 } else {
@@ -908,21 +968,23 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
                         }
                     }
                     const uint32_t h = hp.h;
-                    ulist_append(target, h ? pack_prescore(h >> 16, left + (h & 0xFFFFu), z, iso) : PRESCORE_EMPTY, k, sc.kmax);
+                    ulist_append(target, h ? pack_prescore(h >> 16, left + (h & 0xFFFFu), z, iso) : PRESCORE_EMPTY, k, kmax);
                 }
                 tot_scored += scored;
                 __syncthreads();
                 pc.mark(3);
             }
             if (fold && !deferred) {  // scoring.rs:405 then `hits +=` at :432 / :450
-                if (A.len > trim_k(A.len, sc.report_psms)) res.untrimmed = false;
-                if (BIGK) ulist_trim_big(A, sc.report_psms);
-                else ulist_trim(A, sc.report_psms, exact || sc.list_cap > 4 * WAVE);
+                av.refresh();
+                const uint32_t kmax = av.sc().kmax, report_psms = av.sc().report_psms;
+                if (A.len > trim_k(A.len, report_psms)) res.untrimmed = false;
+                if (BIGK) ulist_trim_big(A, report_psms);
+                else ulist_trim(A, report_psms, exact || av.sc().list_cap > 4 * WAVE);
                 __syncthreads();
                 for (uint32_t base = 0; base < A.stored; base += WAVE) {
                     const uint64_t v = base + lane < A.stored ? A.items[base + lane] : PRESCORE_EMPTY;
                     const uint32_t nvalid = A.stored - base < WAVE ? A.stored - base : WAVE;
-                    ulist_append(B, v, nvalid, sc.kmax);
+                    ulist_append(B, v, nvalid, kmax);
                 }
                 __syncthreads();
             }
@@ -931,9 +993,11 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
             res.deferred = true;
             return res;
         }
-        if (B.len > trim_k(B.len, sc.report_psms)) res.untrimmed = false;
-        if (BIGK) ulist_trim_big(B, sc.report_psms);
-        else ulist_trim(B, sc.report_psms, exact || sc.list_cap > 4 * WAVE);  // scoring.rs:460
+        av.refresh();
+        const uint32_t report_psms = av.sc().report_psms;
+        if (B.len > trim_k(B.len, report_psms)) res.untrimmed = false;
+        if (BIGK) ulist_trim_big(B, report_psms);
+        else ulist_trim(B, report_psms, exact || av.sc().list_cap > 4 * WAVE);  // scoring.rs:460
         __syncthreads();
         res.stored = B.stored;
         res.matched = tot_matched;
@@ -944,7 +1008,12 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db, con
 }
 
 template <bool PROBE, bool PROF, bool BIGK = false>
-__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w) {
+__global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(PrelimKernargs A) {
+    // (ONE argument: prelim_spectrum and the output below read what they need from the kernarg segment, phase by phase — ArgRef)
+    const DevDbView& db = A.db;
+    const DevScorer& sc = A.sc;
+    const DevBatchView& b = A.b;
+    const DevWork& w = A.w;
     typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
@@ -962,15 +1031,20 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         Clock pc;
         pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
         const SpecInfo si = load_spec(sc, b, spec);
-        const PrelimResult r = prelim_spectrum<PROBE, BIGK>(db, sc, b, L, si, sc.exact != 0, pc);
-        if (!BIGK && w.cnt_store) {
+        const PrelimResult r = prelim_spectrum<PROBE, BIGK, PrelimKernargs>(db, sc, b, L, si, sc.exact != 0, pc);
+        // ---- the results leave: the work-set pointers come from the kernarg segment HERE (they were not kept across the matching) ----
+        typedef const __attribute__((address_space(4))) PrelimKernargs* Segment;
+        Segment ka = (Segment)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        uint32_t* const w_cnt_store = ka->w.cnt_store;
+        if (!BIGK && w_cnt_store) {
             // One precursor-window query (known charge, one isotope error): its window counts — still in LDS — stay in HBM for
             // rescore_kernel's tie settlement.  (Here, behind prelim_spectrum, not inside it: nothing of this is live in the matching loops.)
             // Rows in SCHEDULE order (row `pos`, not row `spec`): the wavefronts running at any time write one moving window of a
             // few MB, not 2 KB pieces scattered over the whole GB — the stores of a random row per wavefront cost 5 % of the kernel
             // (address translation).  A row: {left, potential, -, -} then the u16 counts, two per word.
-            const bool keep = !r.deferred && si.z0 == si.z1 && sc.min_isotope_err == sc.max_isotope_err;
-            uint32_t* __restrict__ row = w.cnt_store + (size_t)pos * w.cnt_stride;
+            const bool keep = !r.deferred && si.z0 == si.z1 && ka->sc.min_isotope_err == ka->sc.max_isotope_err;
+            uint32_t* __restrict__ row = w_cnt_store + (size_t)pos * ka->w.cnt_stride;
 #ifndef SAGE_CNT_MODE
 #define SAGE_CNT_MODE 0  // (measurement variants: 1 = the row header only, 2 = the counts only)
 #endif
@@ -983,21 +1057,24 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(DevDb
         }
         if (r.deferred) {
             if (lane == 0) {
-                w.status[spec] = ST_DEFERRED;
-                const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
-                w.queue[it] = spec;
-                if (!w.reuse) w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
+                ka->w.status[spec] = ST_DEFERRED;
+                const uint32_t it = atomicAdd(ka->w.n_deferred + CTR_QUEUED, 1u);
+                ka->w.queue[it] = spec;
+                if (!ka->w.reuse) ka->w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
             }
             continue;
         }
         if (lane == 0) {
-            if (!r.ok) atomicAdd(w.n_deferred + CTR_LIST_OVERFLOW, 1u);
-            w.status[spec] = r.ok ? (r.untrimmed ? ST_OK_ORDERED : ST_OK) : ST_OVERFLOW;
-            w.cand_len[spec] = r.stored;
-            w.totals[2 * spec] = r.matched;
-            w.totals[2 * spec + 1] = r.scored;
+            if (!r.ok) atomicAdd(ka->w.n_deferred + CTR_LIST_OVERFLOW, 1u);
+            ka->w.status[spec] = r.ok ? (r.untrimmed ? ST_OK_ORDERED : ST_OK) : ST_OVERFLOW;
+            ka->w.cand_len[spec] = r.stored;
+            ka->w.totals[2 * spec] = r.matched;
+            ka->w.totals[2 * spec + 1] = r.scored;
         }
-        for (uint32_t i = lane; i < r.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = L.listB[i];
+        {
+            uint64_t* __restrict__ dst = ka->w.cand + (size_t)spec * ka->sc.kmax;
+            for (uint32_t i = lane; i < r.stored; i += WAVE) dst[i] = L.listB[i];
+        }
         pc.mark(4);
     }
 }
@@ -1197,7 +1274,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 const size_t qid = (size_t)slot * w.qmax + query_index(sc, si, z, iso);
                 // ---- IndexedDatabase::query by wavefront 0, shared through LDS; the query's candidate directory ----
                 if (w0) {
-                    const Window q = query_window<false>(db, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
+                    const Window q = query_window<false>(db.pep_mono, db.np, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
                         l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0; l_sh[SH_NCAND] = 0;
@@ -2639,7 +2716,10 @@ struct LateArgs<RescoreKernargs> {
     __device__ __forceinline__ LateArgs(const DevDbView&, const DevScorer&, const DevBatchView&, const DevWork&, const double*, uint32_t, SageFeature*,
                                         uint32_t*)
         : ka((Segment)__builtin_amdgcn_kernarg_segment_ptr()) {}
-    __device__ __forceinline__ void refresh() { asm volatile("" : "+s"(ka)); }
+    __device__ __forceinline__ void refresh() {
+        ka = (Segment)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+    }
     __device__ __forceinline__ const float* ions() const { return ka->db.ions; }
     __device__ __forceinline__ uint32_t report_psms() const { return ka->sc.report_psms; }
     __device__ __forceinline__ uint32_t chimera() const { return ka->sc.chimera; }
@@ -3530,7 +3610,7 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     auto k = b.probe ? (w.dbg ? prelim_kernel<true, true> : prelim_kernel<true, false>)
                      : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
     if (sc.kmax > WAVE) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
-    hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w);
+    hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
                         const SideStream* side) {
