@@ -112,6 +112,7 @@ struct SageHostDb {
 struct SageDeviceDb {
     int device = 0;
     DevBuf<float> pep_mono;
+    DevBuf<uint32_t> pep_lut;  // position table of pep_mono (DevDbView::pep_lut)
     DevBuf<float> ions;
     DevBuf<uint64_t> ion_off;
     DevBuf<uint32_t> pep_info;
@@ -631,6 +632,22 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         d->view.lut2_scale = lut2_scale;
     }
     d->max_ions = max_ions;
+    {  // the position table of the precursor-window search key
+        uint32_t* lut_p = nullptr;
+        uint32_t bins = 0;
+        float inv_w = 0.0f;
+        // (SAGE_HIP_NO_PEP_LUT=1: without — every window through the full search; tests hold the two against each other)
+        const bool off = getenv("SAGE_HIP_NO_PEP_LUT") && getenv("SAGE_HIP_NO_PEP_LUT")[0] == '1';
+        const hipError_t be = off ? hipSuccess
+                                  : (hipError_t)build_peptide_mass_lut(d->pep_mono.p, (uint32_t)np, np ? d->h_pep_mono[np - 1] : 0.0f, &lut_p, &bins, &inv_w, nullptr);
+        if (be != hipSuccess)
+            return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("peptide-mass table: ") + hipGetErrorString(be));
+        d->pep_lut.p = lut_p;
+        d->pep_lut.n = lut_p ? (size_t)bins + 1 : 0;
+        d->view.pep_lut = lut_p;
+        d->view.pep_lut_bins = bins;
+        d->view.pep_lut_inv_w = inv_w;
+    }
     d->view.pep_mono = d->pep_mono.p;
     d->view.np = (uint32_t)np;
     d->view.pm_frag = d->pm_frag.p;
@@ -648,7 +665,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     std::memset(d->view.ion_kinds, 0, sizeof d->view.ion_kinds);
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
-    d->bytes = d->pep_mono.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
+    d->bytes = d->pep_mono.bytes() + d->pep_lut.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
                d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes() + d->tm2_frag.bytes() + d->tm2_lut.bytes();
     *out = d.release();
     return SAGE_HIP_OK;

@@ -470,6 +470,12 @@ SAGE_HD int select_peak_lut(const float* pm, const float* pi, uint32_t P, const 
     return best;
 }
 
+// ---- 65-ary partition point (kernels.hip: wave_partition_point) --------------------------------------------------------------
+// One round of the wavefront-wide search over [lo, hi): 64 pivots at lo + (j + 1) * step - 1, c of them compare true (a prefix);
+// the answer then lies in [lo + c * step, min(lo + (c + 1) * step - 1, hi)].  65 * step - 1 >= span, so that the piece behind
+// the last pivot reaches hi.  Shared with the host emulation (tests/hostemu/core_emu.cpp: every span and answer up to 400).
+SAGE_HD uint32_t wpp_step(uint32_t span) { return span / 65u + 1u; }
+
 // ---- peak-presence bitmap (rescore_kernel's filter in front of select_most_intense_peak) --------------------------------
 // PBM_BITS mass bins of a FIXED width of 1/8 Da, the bin index taken modulo PBM_BITS (masses 2048 Da apart share a bin: a
 // Bloom filter with one hash).  Every peak sets the bins that overlap [mass - D, mass + D], D bounding |mz - mass| over every

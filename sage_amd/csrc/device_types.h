@@ -13,6 +13,11 @@ namespace sagehip {
 struct DevDbView {
     const float* pep_mono;        // [np]   peptide masses, ascending — the precursor-window search key
     uint32_t np;
+    // ... and its position table (index_build.hip: build_peptide_mass_lut): pep_lut[b] = first peptide with mass >= b / pep_lut_inv_w
+    // in the total order, b = 0..pep_lut_bins (pep_lut[pep_lut_bins] == np); pep_lut_bins == 0: none
+    const uint32_t* pep_lut;
+    uint32_t pep_lut_bins;
+    float pep_lut_inv_w;
     // peptide-major copy of IndexedDatabase.fragments: the same (peptide_index, fragment_mz) entries grouped by
     // peptide, so that a precursor window is ONE contiguous, coalesced range (narrow kernel, small windows)
     const SageTheoretical* pm_frag;  // [nf]
@@ -207,6 +212,8 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
                               uint32_t* lut_stride_out, void* stream, bool transposed = false);
+int build_peptide_mass_lut(const float* d_pep_mono, uint32_t np, float top_mass, uint32_t** d_lut_out, uint32_t* bins_out, float* inv_w_out,
+                           void* stream);
 // rescore.hip
 int rescore_on_device(int device, const SageRescoreInput& in, SageRescoreOutput& out, std::string& err);
 int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, std::string& err);

@@ -162,6 +162,44 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
     return (int)hipGetLastError();
 }
 
+// The precursor-window search key's own table: lut[b] = partition_point(order_key(pep_mono[i]) < order_key(b * w)), b = 0..bins,
+// w = 1 / inv_w a power of two — a precursor window's two partition points (IndexedDatabase::query, database.rs:402-425) are then
+// two scalar reads of this table and one wave-wide read of pep_mono each, instead of a five-level search (kernels.hip:
+// query_window).  bins * w > the largest mass, so lut[bins] == np.  bins == 0: no table (an empty database, a top mass that is
+// negative or not finite).
+__global__ __launch_bounds__(256) void pepmass_lut_kernel(const float* __restrict__ pep_mono, uint32_t np, uint32_t bins, float inv_w,
+                                                          uint32_t* __restrict__ lut) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > bins) return;
+    const int32_t edge = sagecore::order_key((float)b / inv_w);  // (b < 2^23, w a power of two: exact)
+    uint32_t lo = 0, hi = np;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (sagecore::order_key(pep_mono[mid]) < edge) lo = mid + 1; else hi = mid;
+    }
+    lut[b] = lo;
+}
+int build_peptide_mass_lut(const float* d_pep_mono, uint32_t np, float top_mass, uint32_t** d_lut_out, uint32_t* bins_out, float* inv_w_out,
+                           void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    *d_lut_out = nullptr;
+    *bins_out = 0;
+    *inv_w_out = 0.0f;
+    if (np == 0 || !(top_mass >= 0.0f) || !(top_mass < 1.0e30f)) return (int)hipSuccess;
+    float inv_w = 128.0f;  // 1/128 Da: ~4 peptides of a human tryptic database per bin on average
+    while ((double)top_mass * inv_w + 2.0 > 4194304.0) inv_w *= 0.5f;
+    const uint32_t bins = (uint32_t)((double)top_mass * inv_w) + 1u;
+    uint32_t* d_lut = nullptr;
+    BUILD_TRY(hipMalloc((void**)&d_lut, ((size_t)bins + 1) * 4));
+    hipLaunchKernelGGL(pepmass_lut_kernel, dim3((bins + 1 + 255) / 256), dim3(256), 0, stream, d_pep_mono, np, bins, inv_w, d_lut);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipStreamSynchronize(stream));
+    *d_lut_out = d_lut;
+    *bins_out = bins;
+    *inv_w_out = inv_w;
+    return (int)hipSuccess;
+}
+
 // A tile-major copy of the peptide-major list for tiles of 2^tile_shift peptides (d_tile_off: [n_tiles + 1] fragment
 // offsets of the tile boundaries) + its position table at `lut_scale` cells per Da.  d_tm_frag ([nf + 2]) is the caller's,
 // the table is allocated here (its width depends on the largest fragment m/z).

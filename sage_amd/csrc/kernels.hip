@@ -144,7 +144,10 @@ __device__ __forceinline__ uint32_t wave_partition_point(const float* __restrict
     const uint32_t lane = lane_id();
     while (hi - lo > WAVE) {
         const uint32_t span = hi - lo;
-        const uint32_t step = (span + WAVE) / (WAVE + 1);
+        // 65 pieces of `step` elements with 65 * step - 1 >= span: when all 64 pivots compare true the answer lies in the LAST piece,
+        // which must reach `hi` (round 4: ceil(span / 65) left it one element short whenever span was a multiple of 65 — never seen
+        // from the full array, at once from the 65-entry brackets of the peptide-mass table)
+        const uint32_t step = wpp_step(span);
         const uint64_t pidx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
         bool t = false;
         if (pidx < hi) {
@@ -494,21 +497,34 @@ __device__ __forceinline__ SpecInfo load_spec(const DevScorer& sc, const DevBatc
 struct Window {
     uint32_t left, right, first, end;
 };
+// `lut` (DevDbView::pep_lut, may be null): the table of pep_mono's partition points at multiples of 1 / inv_w.  Both bounds of an
+// ordinary window (0 <= plo <= phi inside the table) then lie in the one or two bins the table brackets them with: two scalar
+// reads and one wave-wide read each, the same partition points as the full search finds (which everything else still takes).
 template <bool GALLOP>
-__device__ __forceinline__ Window query_window(const float* __restrict__ pep_mono, const uint32_t np, const Tol& ptol, float center) {
+__device__ __forceinline__ Window query_window(const float* __restrict__ pep_mono, const uint32_t np, const Tol& ptol, float center,
+                                               const uint32_t* __restrict__ lut = nullptr, const uint32_t bins = 0, const float inv_w = 0.0f) {
     float plo, phi;
     tol_bounds(ptol, center, plo, phi);
     Window q;
-    uint32_t left = wave_partition_point<true>(pep_mono, 0, np, order_key(plo));
-    left = left ? left - 1 : 0;
-    uint32_t ghi = np;
-    if (GALLOP) {  // the window is short in a narrow search: bracket it by galloping from `left` before searching
-        for (uint64_t span = WAVE;; span *= 16) {
-            ghi = (uint64_t)left + span < np ? (uint32_t)(left + span) : np;
-            if (ghi == np || order_key(pep_mono[ghi - 1]) > order_key(phi)) break;
+    uint32_t left, right;
+    if (lut && plo >= 0.0f && phi >= plo && phi * inv_w < (float)bins) {
+        const uint32_t b0 = uni((uint32_t)(plo * inv_w)), b1 = uni((uint32_t)(phi * inv_w));  // (the scaling is exact: floor)
+        const uint32_t l0 = lut[b0], l1 = lut[b0 + 1], r0 = lut[b1], r1 = lut[b1 + 1];
+        left = wave_partition_point<true>(pep_mono, l0, l1, order_key(plo));
+        left = left ? left - 1 : 0;
+        right = wave_partition_point<false>(pep_mono, r0 > left ? r0 : left, r1, order_key(phi));
+    } else {
+        left = wave_partition_point<true>(pep_mono, 0, np, order_key(plo));
+        left = left ? left - 1 : 0;
+        uint32_t ghi = np;
+        if (GALLOP) {  // the window is short in a narrow search: bracket it by galloping from `left` before searching
+            for (uint64_t span = WAVE;; span *= 16) {
+                ghi = (uint64_t)left + span < np ? (uint32_t)(left + span) : np;
+                if (ghi == np || order_key(pep_mono[ghi - 1]) > order_key(phi)) break;
+            }
         }
+        right = wave_partition_point<false>(pep_mono, left, ghi, order_key(phi));
     }
-    const uint32_t right = wave_partition_point<false>(pep_mono, left, ghi, order_key(phi));
     q.left = left;
     q.right = right;
     q.first = left;
@@ -741,7 +757,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
             for (int iso = isoA; iso <= isoB && !deferred; iso++) {
                 const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
                 av.refresh();
-                const Window q = query_window<true>(av.db().pep_mono, av.db().np, ptol, center);
+                const Window q = query_window<true>(av.db().pep_mono, av.db().np, ptol, center, av.db().pep_lut, av.db().pep_lut_bins, av.db().pep_lut_inv_w);
                 const uint32_t left = q.left;
                 const uint32_t potential = q.right - q.left + 1;  // scoring.rs:351
                 if (potential > av.sc().wcap) {

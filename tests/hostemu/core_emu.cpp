@@ -74,6 +74,37 @@ uint64_t emu_lut_windows(const float* mz, uint32_t n, float scale, uint32_t stri
     return missed;
 }
 
+// wave_partition_point (kernels.hip) with the 64 lanes as a loop: the rounds' arithmetic is core.h's (wpp_step), the pivots /
+// ballot / narrowing as the kernel does them.  partition_point over sorted a[lo..hi) of key(a[i]) < bound (strict) or <= bound.
+uint32_t emu_wave_partition_point(const float* a, uint32_t lo, uint32_t hi, float bound_value, int strict) {
+    const int32_t bound = order_key(bound_value);
+    while (hi - lo > 64u) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = wpp_step(span);
+        uint32_t c = 0;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint64_t pidx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+            bool t = false;
+            if (pidx < hi) {
+                const int32_t k = order_key(a[pidx]);
+                t = strict ? (k < bound) : (k <= bound);
+            }
+            c += t;
+        }
+        const uint64_t nhi = (uint64_t)lo + (uint64_t)(c + 1) * step - 1;
+        const uint32_t new_lo = lo + c * step;
+        hi = nhi < hi ? (uint32_t)nhi : hi;
+        lo = new_lo;
+    }
+    uint32_t c = 0;
+    for (uint32_t lane = 0; lane < 64; lane++)
+        if (lo + lane < hi) {
+            const int32_t k = order_key(a[lo + lane]);
+            c += strict ? (k < bound) : (k <= bound);
+        }
+    return lo + c;
+}
+
 // select_peak_lut (the rescoring kernel's table-driven lookup) next to select_most_intense_peak on the same window
 int emu_select_peak_lut(const float* masses, const float* intens, uint32_t n, float center, int kind, float tlo, float thi) {
     Tol t{kind, tlo, thi};

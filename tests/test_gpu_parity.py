@@ -674,3 +674,35 @@ def test_arena_exhaustion_splits_the_batch(small_world, monkeypatch):
     gf, gc = scorer.score(sub)
     assert_features_equal(gf, gc, of, oc, "arena split")
     assert scorer.last_timing()["n_launches"] > 12  # more than one piece
+
+
+def test_precursor_window_table_finds_the_same_windows(small_world, monkeypatch):
+    """The narrow kernel finds a precursor window's partition points through a position table over the peptide masses
+    (DevDbView::pep_lut, 1/128 Da bins) instead of the full five-level search.  Same candidates, bit for bit: the preliminary
+    lists against the oracle with the table; a database built WITHOUT the table (SAGE_HIP_NO_PEP_LUT=1) gives identical
+    records; windows that leave the table's domain (an absurd precursor m/z beyond the heaviest peptide, a zero one, Da
+    tolerances wider than the first bin) take the full search and agree too."""
+    w = small_world
+    for params, ctx in ((ScorerParams(), "default"), (ScorerParams(precursor_tol=Tolerance("ppm", -5.0, 5.0)), "5 ppm"),
+                        (ScorerParams(precursor_tol=Tolerance("da", -3.0, 1.0), report_psms=2), "-3/+1 Da"),
+                        (ScorerParams(precursor_tol=Tolerance("da", -0.004, 0.004)), "half a bin"),
+                        (ScorerParams(precursor_tol=Tolerance("ppm", -20.0, 20.0), min_isotope_err=-1, max_isotope_err=3), "isotope errors")):
+        w.check(params, "table: " + ctx)
+    monkeypatch.setenv("SAGE_HIP_NO_PEP_LUT", "1")
+    plain = DeviceDatabase(w.host, 0)
+    monkeypatch.delenv("SAGE_HIP_NO_PEP_LUT")
+    for params in (ScorerParams(), ScorerParams(precursor_tol=Tolerance("da", -3.0, 1.0), report_psms=2)):
+        a, b = Scorer(w.dev, params), Scorer(plain, params)
+        fa, ca = a.score(w.batch)
+        fb, cb = b.score(w.batch)
+        np.testing.assert_array_equal(ca, cb)
+        valid = np.arange(fa.shape[1])[None, :] < ca[:, None]
+        assert fa[valid].tobytes() == fb[valid].tobytes()
+    # spectra whose windows leave the table: precursor m/z 0, tiny, and far beyond the heaviest peptide
+    b0 = w.batch.subset(np.arange(12))
+    mz = b0.precursor_mz.copy()
+    mz[0], mz[1], mz[2], mz[3] = 0.0, 1.0e-3, 1.0e5, 3.0e7
+    odd = SpectrumBatch(b0.peak_off, b0.masses, b0.intensities, mz, b0.precursor_charge, b0.total_ion_current, b0.isolation_lo,
+                        b0.isolation_hi, b0.scan_start_time, b0.inverse_ion_mobility, b0.file_id)
+    w.check(ScorerParams(), "table: windows outside its domain", batch=odd)
+    w.check(ScorerParams(precursor_tol=Tolerance("da", -5.0, 5.0)), "table: windows across the table's first bins", batch=odd)
