@@ -1271,7 +1271,7 @@ static uint64_t arena_entries_for(const SageScorer* s, uint32_t n) {
 static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream_t st) {
     WorkSet& w = lane ? s->ws2 : s->ws;
     if (n > w.cap_n) {
-        HIP_TRY(w.cand.reserve((size_t)n * s->dev.kmax));
+        HIP_TRY(w.cand.reserve((size_t)n * s->dev.kmax + 64));  // (+ 64: rescore_kernel reads a full wavefront's worth of every row)
         HIP_TRY(w.cand_len.reserve(n));
         HIP_TRY(w.totals.reserve((size_t)n * 2));
         HIP_TRY(w.status.reserve(n));

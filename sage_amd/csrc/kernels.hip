@@ -180,6 +180,13 @@ struct Counters {
 
 // LDS written by some lanes of a wavefront and read by others of the SAME wavefront: DS operations of one
 // wavefront complete in order, so only the compiler has to be kept from reordering / caching across this point.
+// ... and where global loads are meant to STAY in flight across the point (rescore_spectrum builds its LDS tables while the
+// gathers of the candidates' records are still on their way): wait for the wavefront's own LDS operations only.  One wavefront
+// per workgroup in every kernel that uses it.
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -2252,9 +2259,9 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
     const float w = peak_lut_width(P ? pm[P - 1] : 0.0f);
     inv_w = pow2_reciprocal(w);
     static_assert(PLUT_BINS == 4 * WAVE, "four consecutive bins per lane");
-    __syncthreads();
+    lds_sync();
     *(uint4*)(plut + 4 * lane) = fresh_zero4();
-    __syncthreads();
+    lds_sync();
     for (uint32_t i = lane; i < P; i += WAVE) {
         const float m = pm[i];
         if (order_key(m) < 0) {
@@ -2264,7 +2271,7 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
             if (f < (float)(PLUT_BINS - 1)) atomicAdd(&plut[(uint32_t)f + 1u], 1u);  // bin f: counted from edge f + 1 on
         }
     }
-    __syncthreads();
+    lds_sync();
     uint4 h = *(const uint4*)(plut + 4 * lane);
     h.y += h.x;
     h.z += h.y;
@@ -2293,7 +2300,7 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm,
     const uint4 z4 = fresh_zero4();
     *(uint4*)(bm + 4 * lane) = z4;
     *(uint4*)(bm + 4 * (WAVE + lane)) = z4;
-    __syncthreads();
+    lds_sync();
     // ONE pass: every peak sets its bins; a peak without a safe reach (a negative or non-finite mass, D above 32 bins — core.h:
     // pbm_peak_reach) sets nothing and switches the filter off for the spectrum below
     bool bad = false;
@@ -2309,7 +2316,7 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm,
         }
     }
     if (__builtin_expect(__ballot(bad) != 0ull, 0)) {
-        __syncthreads();
+        lds_sync();
         for (uint32_t i = lane; i < PBM_WORDS; i += WAVE) bm[i] = 0xFFFFFFFFu;
     }
 }
@@ -2466,7 +2473,9 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
                                                  const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
                                                  const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
-                                                 Score& s, PC& pc) {
+                                                 Score& s, PC& pc, const bool have_first = false, const float first0 = 0.f,
+                                                 const float first1 = 0.f, const float first2 = 0.f, const float first3 = 0.f) {
+    // (have_first: the candidate's first four ions were requested by the caller, ahead of its LDS table builds)
     const uint32_t lane = lane_id();
     uint32_t b_run = 0, y_run = 0;  // (run_matched_packed)
     uint32_t mm = 0;                // matched_b | matched_y << 16 (u16 in the reference)
@@ -2480,7 +2489,9 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
         if (act) {
             // (the ion table is padded by 8: reading past the candidate's last ion is harmless, those bits are masked below)
             const float* __restrict__ q = my + j0;
-            float n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+            float n0, n1, n2, n3;
+            if (have_first && j0 == 0) { n0 = first0; n1 = first1; n2 = first2; n3 = first3; }
+            else { n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
             for (uint32_t r = 0; r < n_here; r += 4) {
                 const float i0 = n0, i1 = n1, i2 = n2, i3 = n3;
                 n0 = q[r + 4]; n1 = q[r + 5]; n2 = q[r + 6]; n3 = q[r + 7];  // next trip's ions, in flight under this trip's tests
@@ -2776,14 +2787,12 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
     uint64_t ion_base = 0;
     uint32_t lm1 = 0;
+    uint32_t pep_rec = 0;   // the candidate's record and mass: requested here, first looked at behind the table builds below, which
+    float pep_mass = 0.0f;  // run on LDS alone while these gathers are on their way
     if (valid) {
         ion_base = db.ion_off[pep];
-        // ions per kind = peptide length - 1 (ion_series.rs:68-85; the ion table holds n_kinds * (L - 1) values per peptide): from
-        // the peptide's record, not as (ion_off[pep + 1] - ion_off[pep]) / n_kinds — a 64-bit division per candidate
-        const uint32_t info = db.pep_info[pep];
-        const uint32_t plen = info & 0xFFFFu;
-        lm1 = db.n_kinds && plen ? plen - 1u : 0u;
-        R.meta[lane] = make_uint2(info, __float_as_uint(db.pep_mono[pep]));  // (for the Feature record of a reporting lane)
+        pep_rec = db.pep_info[pep];
+        pep_mass = db.pep_mono[pep];
     }
     // (registers are what this kernel is short of: what only the Feature record needs waits in LDS — R.meta, R.hdr — and nothing
     // is kept that two instructions recompute)
@@ -2798,20 +2807,8 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
 #define SAGE_N_ITEMS (valid ? db.n_kinds * lm1 * nfz : 0u)  /* (ion, fragment charge) pairs of this candidate */
 
     double ln_lambda = 0.0;  // (cr_log_pair, first round)
-    __syncthreads();
+    lds_sync();  // (the peaks are in LDS; the gathers above stay in flight)
     pc.mark(0);
-    if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
-        const uint32_t ion_bytes = wave_sum(valid ? 4u * db.n_kinds * lm1 + 24u : 0u);
-        const uint32_t ncand = (uint32_t)__popcll(__ballot(mine != PRESCORE_EMPTY));
-        if (lane == 0) pc.bytes(DBG_RESCORE, 8ull * P + 8ull * ncand + ion_bytes);
-        // shape of the work: (ion, charge) items of all candidates, of the longest candidate, candidates, peaks
-        const uint32_t items = wave_sum(SAGE_N_ITEMS);
-        uint32_t longest = SAGE_N_ITEMS;
-        for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)longest, o, 64); longest = v > longest ? v : longest; }
-        const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
-        (void)items; (void)longest; (void)nvalid;  // (slots 5..7 now hold phases)
-    }
-
     const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
@@ -2821,8 +2818,36 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         float inv_w;
         build_peak_lut(plut, inv_w, pm, P);
         // (built once: after remove_matched_peaks the bitmap is a superset of the remaining peaks' bins — still conservative)
+#ifndef SAGE_ION_PREFETCH
+#define SAGE_ION_PREFETCH 0  // 1: the candidates' first ions are requested between the two table builds (A/B: see DESIGN.md 4.3)
+#endif
+        float first0 = 0.f, first1 = 0.f, first2 = 0.f, first3 = 0.f;
+        if (round == 0 && valid) {
+            // ions per kind = peptide length - 1 (ion_series.rs:68-85; the ion table holds n_kinds * (L - 1) values per peptide): from
+            // the peptide's record, not as (ion_off[pep + 1] - ion_off[pep]) / n_kinds — a 64-bit division per candidate
+            const uint32_t plen = pep_rec & 0xFFFFu;
+            lm1 = db.n_kinds && plen ? plen - 1u : 0u;
+            R.meta[lane] = make_uint2(pep_rec, __float_as_uint(pep_mass));  // (for the Feature record of a reporting lane)
+            if (SAGE_ION_PREFETCH && lm1 && nfz) {
+                const float* __restrict__ q = db.ions + ion_base;  // (padded by 8: harmless past a short candidate's end)
+                first0 = q[0]; first1 = q[1]; first2 = q[2]; first3 = q[3];
+            }
+        }
         if (round == 0) build_peak_bitmap(pbm, pm, P, sc.pbm_reach);
-        __syncthreads();
+        lds_sync();
+        if (round == 0) {
+        if (pc.slot) {  // bytes this spectrum's rescoring asks for: peaks, candidate records, every candidate's ion table
+            const uint32_t ion_bytes = wave_sum(valid ? 4u * db.n_kinds * lm1 + 24u : 0u);
+            const uint32_t ncand = (uint32_t)__popcll(__ballot(mine != PRESCORE_EMPTY));
+            if (lane == 0) pc.bytes(DBG_RESCORE, 8ull * P + 8ull * ncand + ion_bytes);
+            // shape of the work: (ion, charge) items of all candidates, of the longest candidate, candidates, peaks
+            const uint32_t items = wave_sum(SAGE_N_ITEMS);
+            uint32_t longest = SAGE_N_ITEMS;
+            for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)longest, o, 64); longest = v > longest ? v : longest; }
+            const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid));
+            (void)items; (void)longest; (void)nvalid;  // (slots 5..7 now hold phases)
+        }
+        }
         Score s;
         s.peptide = 0;  // (the lane's pep / z / iso stand in for the fields of the same name)
         s.precursor_charge = 0;
@@ -2832,7 +2857,8 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
         pc.mark(5);  // (... the peak table and the bitmap)
-        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, pc);
+        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, pc,
+                         SAGE_ION_PREFETCH && round == 0, first0, first1, first2, first3);
         pc.mark(1);  // (... the lanes' own hits)
         // ---- from here on: the arguments through `la`, the spectrum's scalars from R.hdr (see LateArgs) ----
         LateArgs<KA> la(db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
@@ -3273,7 +3299,16 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     }
     const uint32_t pos = xcd_position(blockIdx.x, n_batch, sc.xcd_chunk);
     const uint32_t spec = b.order ? b.order[pos] : pos;
+    // Everything that hangs on `spec` alone is requested together, ahead of the first use: the spectrum's status, the whole row
+    // of its preliminary list (unconditionally — the array is padded by a wavefront — so that the load does not wait for the
+    // list's length), the length, the totals, the peak range.  The chain of dependent round trips is then
+    // order -> {status, list, peak range} -> {peaks, ion offsets} -> ions.
     const uint32_t st = w.status[spec];
+    const uint64_t row_word = w.cand[(size_t)spec * sc.kmax + lane];
+    const uint32_t ncand = w.cand_len[spec];
+    const uint32_t tot_m = w.totals[2 * spec], tot_s = w.totals[2 * spec + 1];
+    const uint64_t p0 = b.peak_off[spec];
+    const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
     if (st == ST_DONE) return;  // reported by the fused narrow kernel of this pass
     if (st != ST_OK && st != ST_OK_ORDERED) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -3282,16 +3317,13 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     const RescoreLds R = carve_rescore(smem, smem + ((rescore_scratch_bytes(keep != nullptr) + 15) & ~(size_t)15), b);
     Clock pc;
     pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blockIdx.x, 1);
-    const uint64_t p0 = b.peak_off[spec];
-    const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
     for (uint32_t i = lane; i < P; i += WAVE) {
         R.pm[i] = b.masses[p0 + i];
         R.pi[i] = b.intensities[p0 + i];
     }
-    const uint32_t ncand = w.cand_len[spec];
-    const uint64_t mine = lane < ncand ? w.cand[(size_t)spec * sc.kmax + lane] : PRESCORE_EMPTY;
+    const uint64_t mine = lane < ncand ? row_word : PRESCORE_EMPTY;
     // (a list no trim touched is the reference's list already: equal hyperscores are ranked by it, no retry)
-    rescore_spectrum<ACC, RescoreKernargs>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, w.totals[2 * spec], w.totals[2 * spec + 1],
+    rescore_spectrum<ACC, RescoreKernargs>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, tot_m, tot_s,
                      sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
