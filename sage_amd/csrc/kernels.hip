@@ -711,9 +711,32 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
         const uint32_t pcap = av.b().pcap;
         const Tol ftol0 = SAGE_LOAD_TOL(av.sc().fragment_tol);
 
+        // PROBE: the peak masses are REQUESTED here and staged behind the spectrum's first precursor-window search, whose chain of
+        // dependent reads (position table -> peptide masses -> window edges) does not need them: one round trip less in a row.
+        float pk0 = 0.f, pk1 = 0.f, pk2 = 0.f;
+        Window q_first{0u, 0u, 0u, 0u};
+        bool have_first = false;
+        int iso_first = 0;
+        if (PROBE) {
+            if (lane < P) pk0 = masses[lane];
+            if (lane + WAVE < P) pk1 = masses[lane + WAVE];
+            if (lane + 2 * WAVE < P) pk2 = masses[lane + 2 * WAVE];
+            if (si.z0 <= si.z1) {  // (the same expressions as in the query loops below)
+                const bool fold0 = av.sc().min_isotope_err != av.sc().max_isotope_err;
+                iso_first = fold0 ? av.sc().min_isotope_err : 0;
+                const float precursor_mass = si.mzp * (float)si.z0;
+                const Tol ptol = av.sc().wide_window ? tol_scaled(si.iso_tol, (float)si.z0) : SAGE_LOAD_TOL(av.sc().precursor_tol);
+                const float center = precursor_mass - (float)iso_first * NEUTRON;  // scoring.rs:344
+                q_first = query_window<true>(av.db().pep_mono, av.db().np, ptol, center, av.db().pep_lut, av.db().pep_lut_bins, av.db().pep_lut_inv_w);
+                have_first = true;
+            }
+            if (lane < P) L.win_lo[lane] = pk0;
+            if (lane + WAVE < P) L.win_lo[lane + WAVE] = pk1;
+            if (lane + 2 * WAVE < P) L.win_lo[lane + 2 * WAVE] = pk2;
+        }
         // fragment-tolerance window of every (peak, fragment charge): database.rs:481 on the
         // experimental mass peak*charge of scoring.rs:360
-        for (uint32_t i = lane; i < P; i += WAVE) {
+        for (uint32_t i = PROBE ? lane + 3 * WAVE : lane; i < P; i += WAVE) {
             const float m = masses[i];
             if (PROBE) {
                 L.win_lo[i] = m;
@@ -764,7 +787,9 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
             for (int iso = isoA; iso <= isoB && !deferred; iso++) {
                 const float center = precursor_mass - (float)iso * NEUTRON;  // scoring.rs:344
                 av.refresh();
-                const Window q = query_window<true>(av.db().pep_mono, av.db().np, ptol, center, av.db().pep_lut, av.db().pep_lut_bins, av.db().pep_lut_inv_w);
+                const Window q = have_first && z == si.z0 && iso == iso_first
+                                     ? q_first  // (searched ahead of the staging, above)
+                                     : query_window<true>(av.db().pep_mono, av.db().np, ptol, center, av.db().pep_lut, av.db().pep_lut_bins, av.db().pep_lut_inv_w);
                 const uint32_t left = q.left;
                 const uint32_t potential = q.right - q.left + 1;  // scoring.rs:351
                 if (potential > av.sc().wcap) {
