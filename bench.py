@@ -682,11 +682,13 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": "both narrow-search kernels are bound by VALU issue, not by HBM (rocprofv3 SQ counters, "
-                                "profiles/r03_C3_pmc_sq_*.txt: prelim 2 065 and rescore 3 072 VALU instructions per spectrum at 5 "
-                                "wavefronts per SIMD = 75 % / 78 % of the VALU cycles); with the XCD-aware schedule the preliminary kernel's "
-                                "L2 misses halve (30 -> 15 KB per spectrum) and its time does not move — so byte fractions say how "
-                                "far the memory system is from being the limit, not how good the kernels are",
+                    "limiters": "neither narrow-search kernel is bound by HBM. rescore_kernel is bound by vector-ALU issue at 5 wavefronts "
+                                "per SIMD (instruction counts: profiles/r04_C3_pmc_sq_*.txt; the calibrated issue rate: "
+                                "profiles/r04_valu_calibration.md; where the cycles go phase by phase: profiles/r04_C3_phase_clocks.txt); "
+                                "prelim_kernel by chains of dependent memory / LDS round trips (round 4: a position table for the "
+                                "precursor-window search took three round trips out of it and 9 % off its time, the XCD-aware schedule "
+                                "halves its L2 misses and does not move it) — so byte fractions say how far the memory system is from "
+                                "being the limit, not how good the kernels are",
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],

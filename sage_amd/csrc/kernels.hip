@@ -3477,9 +3477,20 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void search_kernel(DevDb
 // 70-100 spills to scratch (each a memory round trip the wavefront waits for) where the separate kernels have 0 and ~30
 // (profiles/r03_fused_vs_separate.md).
 template <bool PROBE, bool PROF>
-__global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
-                                                                           const double* __restrict__ lnfact_table, uint32_t lnfact_n,
-                                                                           SageFeature* __restrict__ out, uint32_t* __restrict__ out_count) {
+__global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(RescoreKernargs A) {
+    // (rescore_kernel's argument struct, `keep` unused; its first four members are prelim_kernel's: both phases read their
+    // arguments from the kernarg segment where they use them — ArgRef<PrelimKernargs>, LateArgs<RescoreKernargs>)
+    static_assert(offsetof(RescoreKernargs, db) == offsetof(PrelimKernargs, db) && offsetof(RescoreKernargs, sc) == offsetof(PrelimKernargs, sc) &&
+                      offsetof(RescoreKernargs, b) == offsetof(PrelimKernargs, b) && offsetof(RescoreKernargs, w) == offsetof(PrelimKernargs, w),
+                  "the preliminary phase reads the segment as a PrelimKernargs");
+    const DevDbView& db = A.db;
+    const DevScorer& sc = A.sc;
+    const DevBatchView& b = A.b;
+    const DevWork& w = A.w;
+    const double* __restrict__ lnfact_table = A.lnfact_table;
+    const uint32_t lnfact_n = A.lnfact_n;
+    SageFeature* __restrict__ out = A.out;
+    uint32_t* __restrict__ out_count = A.out_count;
     typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
@@ -3507,7 +3518,7 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
                 R.pm[i] = b.masses[si.p0 + i];
                 R.pi[i] = b.intensities[si.p0 + i];
             }
-            const PrelimResult r = prelim_spectrum<PROBE>(db, sc, b, L, si, exact, pc);
+            const PrelimResult r = prelim_spectrum<PROBE, false, PrelimKernargs>(db, sc, b, L, si, exact, pc);
             if (r.deferred) {
                 if (lane == 0) {
                     const uint32_t it = atomicAdd(w.n_deferred + CTR_QUEUED, 1u);
@@ -3529,8 +3540,9 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(DevDb
             pc.mark(4);
             pc.rebase(1);  // (the rescoring phase accounts under kernel 1)
             __syncthreads();  // the list is in registers: the preliminary phase's LDS is free
-            if (rescore_spectrum<true, void>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched, r.scored,
-                                 exact || r.untrimmed, false, pc) || exact)
+            if (rescore_spectrum<true, RescoreKernargs>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr, R, spec, si.P, mine, r.matched,
+                                                        r.scored, exact || r.untrimmed, false, pc) ||
+                exact)
                 break;
             exact = true;  // equal hyperscores at a reported rank: once more, with bounded_min_heapify replayed (heap.rs:7-28)
             if (lane == 0) atomicAdd(w.n_deferred + CTR_TIED, 1u);
@@ -3675,8 +3687,8 @@ void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView&
                      : (w.dbg ? narrow_kernel<false, true> : narrow_kernel<false, false>);
     // (a retry pass holds a few per cent of the batch: a capped grid strides over the device-side list)
     const uint32_t grid = b.n_dev ? (b.n < RETRY_GRID_CAP ? b.n : RETRY_GRID_CAP) : b.n;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), narrow_lds_bytes(sc, b), (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out,
-                       out_count);
+    const RescoreKernargs args{db, sc, b, w, lnfact_table, lnfact_n, out, out_count, nullptr};
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), narrow_lds_bytes(sc, b), (hipStream_t)stream, args);
 }
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
     if (b.n == 0) return;
