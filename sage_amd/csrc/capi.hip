@@ -531,7 +531,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         uint32_t* lut_p = nullptr;
         if (be == hipSuccess)
             be = (hipError_t)build_tile_copy_on_device(d->pm_frag.p, nf, tile_shift, (uint32_t)n_tiles, d_tile_off.p, lut_scale,
-                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr, /*transposed=*/true);
+                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr, TM_LUT_TRANSPOSED);
         if (be != hipSuccess)
             return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
         d->tm_lut.p = lut_p;
@@ -586,15 +586,15 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
             for (size_t t = tb; t < te; t++) {
                 uint64_t pos = tile_off[t];
                 const uint64_t tend = tile_off[t + 1];
-                uint32_t* col = lut.data() + t;  // (transposed: entry (t, c) at c * n_tiles + t — DevDbView::tm_lut)
+                auto cell = [&](uint32_t c) -> uint32_t& { return lut[tm_lut_index((uint32_t)t, c, (uint32_t)n_tiles, lut_stride)]; };
                 for (uint32_t c = 0; c < lut_stride; c++) {
                     const double edge = (double)c / (double)lut_scale;
                     // NaN and m/z beyond the table (non-finite or > 250 kDa) compare false and stay in the last cell's run
                     while (pos < tend && (double)tm[pos].fragment_mz < edge) pos++;
-                    col[(size_t)c * n_tiles] = (uint32_t)pos;
+                    cell(c) = (uint32_t)pos;
                 }
-                col[0] = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
-                col[(size_t)(lut_stride - 1) * n_tiles] = (uint32_t)tend;
+                cell(0) = (uint32_t)tile_off[t];  // a window starting below cell 0 starts at the tile's first entry
+                cell(lut_stride - 1) = (uint32_t)tend;
             }
         });
         HIP_TRY(d->tm_frag.upload(tm.data(), tm.size()));

@@ -28,9 +28,11 @@ struct DevDbView {
     const uint32_t* pep_info;        // [np] len | decoy<<16 | missed_cleavages<<24
     // tile-major copy of the fragments for large precursor windows: tile = peptide_index >> tile_shift,
     // ascending m/z inside a tile, plus a per-tile position table:
-    //   tm_lut[c * n_tiles + t] = position in tm_frag of tile t's first fragment with m/z >= c / lut_scale   (TRANSPOSED: the
-    //   words one fragment-tolerance window needs from the consecutive tiles of a precursor window share cache lines)
-    // (the last cell of a tile is its end position).  A (peak window, tile) lookup is two table reads and a
+    //   tm_lut[tm_lut_index(t, c)] = position in tm_frag of tile t's first fragment with m/z >= c / lut_scale
+    // (the last cell of a tile is its end position), row-major: lut[t][c].  (Round 4 measured the transposed layout, lut[c][t] —
+    // the words one fragment-tolerance window needs from the ~100 consecutive tiles of a precursor window share cache lines:
+    // same kernel time, 16 % MORE HBM traffic on C4 (2.48 against 2.13 MB per spectrum: a tile's windows no longer share the
+    // tile's row) — TM_LUT_TRANSPOSED keeps both layouts buildable.)  A (peak window, tile) lookup is two table reads and a
     // short contiguous run of entries; the tile's candidate counters fit in LDS.
     const SageTheoretical* tm_frag;  // [nf + 2]
     const uint32_t* tm_lut;          // [n_tiles * lut_stride]
@@ -50,6 +52,14 @@ struct DevDbView {
     uint8_t ion_kinds[8];
     uint32_t n_kinds;
 };
+
+#ifndef SAGE_TM_LUT_TRANSPOSED
+#define SAGE_TM_LUT_TRANSPOSED 0
+#endif
+constexpr bool TM_LUT_TRANSPOSED = SAGE_TM_LUT_TRANSPOSED != 0;
+__host__ __device__ inline size_t tm_lut_index(uint32_t t, uint32_t c, uint32_t n_tiles, uint32_t lut_stride) {
+    return TM_LUT_TRANSPOSED ? (size_t)c * n_tiles + t : (size_t)t * lut_stride + c;
+}
 
 struct DevScorer {
     sagecore::Tol precursor_tol, fragment_tol;

@@ -1385,10 +1385,8 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     probe_bounds(pr, lo, hi);
                     probe_cells(lo, hi, icl, ich);
                     if (pr < nprobe && first < end && lo <= hi) {
-                        // (the table is transposed, lut[cell][tile]: this window's words of the window's consecutive tiles share
-                        // cache lines — a quarter of the kernel's HBM lines used to be table words fetched a line apiece)
-                        np0 = db.tm_lut[(size_t)icl * db.n_tiles + t];
-                        np1 = db.tm_lut[(size_t)ich * db.n_tiles + t];
+                        np0 = db.tm_lut[tm_lut_index(t, icl, db.n_tiles, db.lut_stride)];
+                        np1 = db.tm_lut[tm_lut_index(t, ich, db.n_tiles, db.lut_stride)];
                     }
                 };
                 // cells of the CURRENT unit in flight — named scalars, not arrays (arrays captured by the lambdas below end up in
