@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -180,6 +181,7 @@ struct SageDeviceBatch {
                              // large-window kernels)
     Pinned stage;      // host staging of the arrays above (everything but the peaks when those are already page-locked)
     Event up_done;     // uploads of this batch finished (its staging block may be refilled)
+    Event meta_done, sort_done;  // the per-spectrum block is up / the launch schedule is sorted (on the scorer's sort stream, next to the peak copies)
     DevBatchView view{};
 };
 
@@ -191,6 +193,7 @@ struct SageScorer {
     hipStream_t stream = nullptr;    // compute (and, for resident batches, the result download)
     hipStream_t up_stream = nullptr, down_stream = nullptr;  // streaming pipeline: H2D of batch c + 1, D2H of batch c - 1
     hipStream_t side_stream = nullptr;  // kernels of one batch that may run next to each other (the two heap-replay kernels)
+    hipStream_t sort_stream = nullptr;  // the launch-schedule sort of an uploading batch, beside its peak copies (stage_and_upload)
     Event side_fork, side_join;
     // a resident narrow-search step in `ways` parts, each with its own stream (part 0: `stream`): the parts' kernels overlap each
     // other's cold starts, tails and retry chains (what two scorer handles on two host threads get, inside one call)
@@ -729,6 +732,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->sort_stream, hipStreamNonBlocking));
     if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
     // cheap ties: only where the tied candidates' records are final whichever wins (one reported PSM, no chimera rounds)
     if (p->report_psms != 1 || p->chimera) s->fast_ties = false;
@@ -795,7 +799,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
 
 static void scorer_release(SageScorer* s) {
     (void)hipSetDevice(s->db->device);
-    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream, s->side_stream, s->way_stream[0], s->way_stream[1], s->way_stream[2]})
+    for (hipStream_t st : {s->stream, s->up_stream, s->down_stream, s->side_stream, s->sort_stream, s->way_stream[0], s->way_stream[1], s->way_stream[2]})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
@@ -1015,13 +1019,21 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     if (n) {
         // the per-spectrum arrays: one copy of the staging block's head, the device pointers are its image
         HIP_TRY(hipMemcpyAsync(d->meta.p, d->stage.p, meta_bytes, hipMemcpyHostToDevice, up));
+        // the launch schedule (ascending neutral precursor mass) needs that block only: sorted on the device on a stream of its
+        // own WHILE the peaks cross the link (behind the uploads, on their stream, its dozen small kernels left the link idle for
+        // ~0.1 ms per chunk of the streaming pipeline)
+        HIP_TRY(d->meta_done.create(false));
+        HIP_TRY(d->sort_done.create(false));
+        HIP_TRY(hipEventRecord(d->meta_done.e, up));
+        HIP_TRY(hipStreamWaitEvent(s->sort_stream, d->meta_done.e, 0));
+        HIP_TRY((hipError_t)schedule_on_device(n, (const float*)image(h_mz), (const uint8_t*)image(h_z), s->params.min_precursor_charge,
+                                               d->sort_a.p, d->sort_b.p, d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, s->sort_stream));
+        HIP_TRY(hipEventRecord(d->sort_done.e, s->sort_stream));
         if (total) {
             HIP_TRY(hipMemcpyAsync(d->masses.p, src_m, total * 4, hipMemcpyHostToDevice, up));
             HIP_TRY(hipMemcpyAsync(d->intensities.p, src_i, total * 4, hipMemcpyHostToDevice, up));
         }
-        // the launch schedule (ascending neutral precursor mass), sorted on the device right behind the uploads
-        HIP_TRY((hipError_t)schedule_on_device(n, (const float*)image(h_mz), (const uint8_t*)image(h_z), s->params.min_precursor_charge,
-                                               d->sort_a.p, d->sort_b.p, d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, up));
+        HIP_TRY(hipStreamWaitEvent(up, d->sort_done.e, 0));  // (`up_done` below stands for both)
     }
     HIP_TRY(hipEventRecord(d->up_done.e, up));
     DevBatchView& v = d->view;
@@ -1604,8 +1616,11 @@ int sage_hip_score_resident(SageScorer* s, SageDeviceBatch* b, SageFeature* out,
 // Spectra [r0, r1) of a host batch through the three-stage pipeline: while chunk c is scored on the compute stream, chunk
 // c + 1 is staged and uploaded on the copy stream and the PSM records of chunk c - 1 return on the download stream.  Mirrors the
 // reference's reader -> processor -> search overlap (runner.rs:365-375, 450-461) at the PCIe boundary.
+// `pending` (may be null): the window estimate is still being worked out on a helper thread — the first chunk is staged and its
+// upload enqueued without it (neither needs it), then it is waited for and written into the chunk's view (`est` is updated).
 static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, uint32_t r1, SageFeature* out, uint32_t* out_count,
-                       uint32_t chunk, bool peaks_locked, WindowEstimate est, std::vector<std::pair<uint32_t, uint32_t>>& overflowed) {
+                       uint32_t chunk, bool peaks_locked, WindowEstimate& est, std::vector<std::pair<uint32_t, uint32_t>>& overflowed,
+                       std::future<WindowEstimate>* pending = nullptr) {
     const uint32_t rp = s->params.report_psms;
     // page-locked result arrays (sage_hip_host_alloc) receive the records from the kernels' own stores; pageable ones through a
     // page-locked landing block per slot (an asynchronous copy into pageable memory would stall the pipeline)
@@ -1713,6 +1728,12 @@ static int score_range(SageScorer* s, const SageSpectrumBatch* b, uint32_t r0, u
         SageDeviceBatch& in = s->slots[slot];
         // (the uploads of chunk k - 4 finished long ago — its kernels ran — so the staging block may be rewritten)
         rc = stage_and_upload(s, &in, b, c0, c1, peaks_locked, est, s->up_stream);
+        if (pending && pending->valid()) {  // (also on the error path: the helper thread reads the caller's arrays)
+            est = pending->get();
+            in.view.probe = est.probe;
+            in.maybe_wide = est.maybe_wide;
+            trace("window estimate joined", k);
+        }
         if (rc != SAGE_HIP_OK) return bail(rc);
         trace("launch chunk", k);
         rc = launch(slot, c0, c1, est.maybe_wide);
@@ -1744,12 +1765,19 @@ int sage_hip_score_batch(SageScorer* s, const SageSpectrumBatch* b, SageFeature*
     if (n == 0) return SAGE_HIP_OK;
     const auto t_call = std::chrono::steady_clock::now();
     const bool peaks_locked = is_page_locked(b->masses) && is_page_locked(b->intensities);
-    const WindowEstimate est = choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
-    if (std::getenv("SAGE_HIP_TIMING"))
-        fprintf(stderr, "[sage_hip] score_batch: window estimate %.1f us\n",
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count());
+    // The window estimate (1 024 sampled spectra x two searches over the peptide masses: ~0.5 ms of cache misses on a 4.75 M
+    // peptide list) runs on a helper thread while this one stages the first chunk and enqueues its upload, which need neither
+    // of its answers; score_range joins it before the chunk's first launch.
+    std::future<WindowEstimate> pending = std::async(std::launch::async, [s, n, b]() {
+        return choose_probe(s, n, b->precursor_mz, b->precursor_charge, b->isolation_lo, b->isolation_hi);
+    });
+    WindowEstimate est{};
+    est.probe = 1;
+    est.maybe_wide = false;
+    (void)t_call;
     std::vector<std::pair<uint32_t, uint32_t>> todo, next;
-    rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, est, todo);
+    rc = score_range(s, b, 0, n, out, out_count, s->chunk, peaks_locked, est, todo, &pending);
+    if (pending.valid()) est = pending.get();  // (score_range left before its first chunk: an error)
     if (rc != SAGE_HIP_OK) return rc;
     // chunks whose large-window candidates did not fit the arena: again in halves (the arena is sized for the chunk, so a
     // piece with the same arena and half the spectra has twice the room per spectrum)
