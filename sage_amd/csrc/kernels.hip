@@ -80,6 +80,20 @@ struct NoClock {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Staggered start (experiment, -DSAGE_STAGGER_NS=<ns per slot>): the first generation of a per-spectrum kernel's wavefronts — five
+// per SIMD, all launched within microseconds — runs its phases in lockstep (every wavefront waits on memory, then every one wants
+// the vector ALU), which is part of what a "cold start" costs; workgroup b of the first 5 x 1024 is held back by (b / 1024) slots.
+#ifndef SAGE_STAGGER_NS
+#define SAGE_STAGGER_NS 0
+#endif
+__device__ __forceinline__ void staggered_start(uint32_t blk) {
+    if (SAGE_STAGGER_NS > 0 && blk >= 1024u && blk < 5u * 1024u) {
+        const uint32_t slot = blk / 1024u;
+        const long long until = (long long)__builtin_amdgcn_s_memtime() + (long long)slot * (SAGE_STAGGER_NS * 2);  // (s_memtime counts shader clocks here: ~2 per ns)
+        while ((long long)__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // XCD-aware schedule position.  Workgroup b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup
 // dispatch"; a speed matter only, nothing here depends on it), each XCD with a private 4 MiB L2.  The per-spectrum kernels walk
 // the batch in precursor-mass order so that neighbouring wavefronts read overlapping index ranges; dealt round-robin, all eight
@@ -1065,6 +1079,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(Preli
     typedef typename std::conditional<PROF, PhaseClock, NoClock>::type Clock;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
+    staggered_start(blockIdx.x);
     const PrelimLds L = carve_prelim(smem, sc, b);
 
     uint32_t n_batch = b.n;
@@ -3315,6 +3330,7 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     if (blockIdx.x >= b.n) return;
+    staggered_start(blockIdx.x);
     uint32_t n_batch = b.n;
     if (b.n_dev) {  // retry pass: device-side count
         n_batch = *b.n_dev < n_batch ? *b.n_dev : n_batch;
