@@ -144,11 +144,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+// (the total = the scan's last lane: six DPP adds and one v_readlane instead of six ds_bpermute round trips through the LDS crossbar)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(v), 63); }
 
 // partition_point over sorted a[lo..hi) of key(a[i]) < bound (STRICT) or <= bound, all 64 lanes
 // cooperating: 64 pivots per round (log_65 instead of log_2 dependent loads).
@@ -573,18 +570,16 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
     }
     wave_sync();
     const uint32_t mine = hist[lane];
-    uint32_t suffix = mine;  // number of slots with count >= lane
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(suffix, off, 64);
-        if ((int)lane + off < 64) suffix += o;
-    }
-    if (__shfl(mine, 63, 64) != 0) return false;  // a count >= 63: keep the exact path
-    scored = __shfl(suffix, 1, 64);               // slots with count > 0
+    // number of slots with count >= lane: the suffix sum, as total - inclusive prefix + own (DPP scan: no crossbar round trips)
+    const uint32_t incl_pre = wave_incl_scan_dpp(mine);
+    const uint32_t suffix = (uint32_t)__builtin_amdgcn_readlane((int)incl_pre, 63) - incl_pre + mine;
+    // (wave-uniform lane indices: v_readlane, not a trip through the LDS crossbar)
+    if (__builtin_amdgcn_readlane((int)mine, 63) != 0) return false;  // a count >= 63: keep the exact path
+    scored = (uint32_t)__builtin_amdgcn_readlane((int)suffix, 1);     // slots with count > 0
     const uint64_t okm = __ballot(lane >= 1 && suffix >= k);
-    const uint32_t T = okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u;  // k-th largest count (0: fewer than k non-empty)
-    const uint32_t n_gt = __shfl(suffix, (int)(T + 1 < 64 ? T + 1 : 63), 64);  // (T <= 62 here)
-    const uint32_t n_eq = T ? __shfl(mine, (int)T, 64) : 0;
+    const uint32_t T = uni(okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u);  // k-th largest count (0: fewer than k non-empty)
+    const uint32_t n_gt = (uint32_t)__builtin_amdgcn_readlane((int)suffix, (int)(T + 1 < 64 ? T + 1 : 63));  // (T <= 62 here)
+    const uint32_t n_eq = T ? (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)T) : 0;
     const uint32_t take_eq = T ? k - n_gt : 0, skip_eq = n_eq - take_eq;
     wave_sync();
     uint64_t* sel = L.heap;
@@ -901,12 +896,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                             uint32_t tot = 0;
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) tot += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
-                            uint32_t incl = tot;  // inclusive prefix of the lanes' cell counts
-#pragma unroll
-                            for (int off = 1; off < 64; off <<= 1) {
-                                const uint32_t o = __shfl_up(incl, off, 64);
-                                if ((int)lane >= off) incl += o;
-                            }
+                            const uint32_t incl = wave_incl_scan_dpp(tot);  // inclusive prefix of the lanes' cell counts
                             uint32_t run = incl - tot;
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
@@ -2206,13 +2196,27 @@ __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatc
 }
 
 // ---- rescoring -------------------------------------------------------------------------------
+// the largest of 64 signed 64-bit values, wave-uniform: the DPP pattern of wave_incl_scan_dpp with `max` for `+` (a lane without a
+// source keeps its own value), the result read from lane 63 — twelve DPP moves instead of twelve ds_bpermute round trips
 __device__ __forceinline__ long long wave_max_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
+#define SAGE_MAX_STEP(CTRL, ROWS)                                                                        \
+    {                                                                                                    \
+        const int lo = (int)(unsigned long long)v, hi = (int)((unsigned long long)v >> 32);              \
+        const unsigned int tlo = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false); \
+        const unsigned int thi = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false); \
+        const long long t = (long long)(((unsigned long long)thi << 32) | tlo);                           \
+        v = t > v ? t : v;                                                                               \
     }
-    return v;
+    SAGE_MAX_STEP(0x111, 0xf)  // row_shr:1
+    SAGE_MAX_STEP(0x112, 0xf)  // row_shr:2
+    SAGE_MAX_STEP(0x114, 0xf)  // row_shr:4
+    SAGE_MAX_STEP(0x118, 0xf)  // row_shr:8
+    SAGE_MAX_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    SAGE_MAX_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef SAGE_MAX_STEP
+    const unsigned int rlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned long long)v, 63);
+    const unsigned int rhi = (unsigned int)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)rhi << 32) | rlo);
 }
 __device__ __forceinline__ double from_order_key64(long long k) {  // inverse of order_key64 (the mapping is an involution)
     return __longlong_as_double(k ^ (long long)(((unsigned long long)(k >> 63)) >> 1));
