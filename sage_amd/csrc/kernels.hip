@@ -880,19 +880,31 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                     };
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
                         const uint32_t* __restrict__ lut = tm2_lut + (size_t)t * lut2_stride;
-                        for (uint32_t pbase = 0; pbase < nprobe; pbase += PROBE_BATCH) {
-                            // table reads of up to PROBE_BATCH windows, PROBE_PER_LANE per lane, all in flight together;
-                            // window q of the flattened order (lane-major) is window pbase + (q % PPL) * 64 + q / PPL
-                            uint32_t rp0[PROBE_PER_LANE], rp1[PROBE_PER_LANE];
+                        // table reads of up to PROBE_BATCH windows, PROBE_PER_LANE per lane, all in flight together; window q of the
+                        // flattened order (lane-major) is window pbase + (q % PPL) * 64 + q / PPL.  The reads of batch b + 1 are
+                        // issued before the cells of batch b are walked (SAGE_PROBE_PIPELINE): one round trip less per further batch.
+#ifndef SAGE_PROBE_PIPELINE
+#define SAGE_PROBE_PIPELINE 1
+#endif
+                        uint32_t np0[PROBE_PER_LANE], np1[PROBE_PER_LANE];
+                        auto issue = [&](uint32_t pbase) {
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
                                 float flo, fhi;
                                 window_of(pbase + i * WAVE + lane, flo, fhi);
                                 uint32_t icl, ich;  // (core.h: the scale is a power of two, no safety margin needed)
                                 lut_cells(flo, fhi, lut2_scale, lut2_stride, icl, ich);
-                                rp0[i] = lut[icl];
-                                rp1[i] = lut[ich];
+                                np0[i] = lut[icl];
+                                np1[i] = lut[ich];
                             }
+                        };
+                        if (SAGE_PROBE_PIPELINE) issue(0);
+                        for (uint32_t pbase = 0; pbase < nprobe; pbase += PROBE_BATCH) {
+                            if (!SAGE_PROBE_PIPELINE) issue(pbase);
+                            uint32_t rp0[PROBE_PER_LANE], rp1[PROBE_PER_LANE];
+#pragma unroll
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) { rp0[i] = np0[i]; rp1[i] = np1[i]; }
+                            if (SAGE_PROBE_PIPELINE && pbase + PROBE_BATCH < nprobe) issue(pbase + PROBE_BATCH);
                             uint32_t tot = 0;
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) tot += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
