@@ -171,7 +171,7 @@ typedef struct SageScorerParams {
     int16_t max_fragment_charge; /* Option<u8>: -1 == None */
     uint8_t wide_window;
     uint8_t annotate_matches;    /* the Fragments themselves are fetched with sage_hip_annotate_resident */
-    uint32_t report_psms;        /* 1..128 (above 32: the wider, slower kernels of DESIGN.md 4.8; above 128: SAGE_HIP_ERR_UNSUPPORTED) */
+    uint32_t report_psms;        /* 1..512 (above 32: the wider, slower kernels of DESIGN.md 4.8; above 512: SAGE_HIP_ERR_UNSUPPORTED) */
     int32_t score_type;          /* 0 SageHyperScore, 1 OpenMSHyperScore (scoring.rs:10-14) */
 } SageScorerParams;
 

@@ -743,6 +743,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
         // in LDS, every trim exact (no order-free trims, hence no retry pass), rescoring 64 candidates at a time.
         s->kstride = ((d.kmax + 63) / 64) * 64;
+        HIP_TRY((hipError_t)bigk_kernel_prepare(160 * 1024));
         s->exact_always = true;
         s->fused = s->one_launch = false;
         s->ways = 1;
@@ -812,7 +813,7 @@ static void scorer_release(SageScorer* s) {
 int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
     if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
-    if (p->report_psms > 128) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 128 (preliminary lists longer than 256 candidates)");
+    if (p->report_psms > 512) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 512 (preliminary lists longer than 1024 candidates)");
     if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
     if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
         return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
@@ -1396,8 +1397,14 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     const size_t lds_p = std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
                  lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
     const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
-    if (lds_p > 64 * 1024 || lds_r > 64 * 1024 || lds_t > 160 * 1024)
-        return fail(SAGE_HIP_ERR_UNSUPPORTED, "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
+    // (the instances for lists wider than a wavefront may take a whole CU's LDS: bigk_kernel_prepare at scorer creation)
+    const size_t lds_cap = sc.kmax > 64 ? (size_t)160 * 1024 : (size_t)64 * 1024;
+    const size_t lds_a = sc.kmax > 64 ? assemble_lds_bytes(sc) : 0;
+    if (lds_p > lds_cap || lds_r > lds_cap || lds_a > lds_cap || lds_t > 160 * 1024)
+        return fail(SAGE_HIP_ERR_UNSUPPORTED,
+                    sc.kmax > 64 ? "candidate lists too long for the LDS of a compute unit (report_psms x precursor-window queries per spectrum, or peaks x "
+                                   "fragment charges): lower report_psms or narrow the charge / isotope-error ranges"
+                                 : "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
     o.two_pass = production && !(fused && !wide);  // (the fused first pass settles the ties of narrow spectra itself)
     o.with_rescore = with_rescore;
     o.fused = fused || one_launch;

@@ -195,6 +195,8 @@ struct TileParams {
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
+int bigk_kernel_prepare(size_t max_lds_bytes);  // ... of the instances for lists wider than a wavefront (report_psms > 32)
+size_t assemble_lds_bytes(const DevScorer& sc);
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 // the narrow search as ONE launch of two kinds of workgroups (preliminary / rescoring, kernels.hip: search_kernel)

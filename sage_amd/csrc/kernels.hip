@@ -402,7 +402,7 @@ __device__ __forceinline__ void ulist_trim(UList& c, uint32_t report_psms, bool 
     c.len = k;
 }
 
-// ---- k-select wider than a wavefront: report_psms > 32, k = max(50, 2 * report_psms) up to 256 (BIGK instantiations) ------------
+// ---- k-select wider than a wavefront: report_psms > 32, k = max(50, 2 * report_psms) up to BIG_K = 1024 (BIGK instantiations) ------
 // bounded_min_heapify (heap.rs:7-60) with the heap in LDS, replayed by lane 0 with core.h's sift_down (the host's, the oracle's);
 // the wavefront only skims: 64 offers at a time are tested against the current minimum — the minimum never decreases, so an offer
 // that fails now would fail later — and the survivors are handed to lane 0 in order.  Slow next to the register heaps above and
@@ -2090,8 +2090,9 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
 }
 
 // The replay for k > 64 (report_psms > 32): a wavefront per query, the heap in LDS (lh_build / lh_offer_batch), 64-bit keys.
+constexpr uint32_t BIG_K = 1024;  // the longest preliminary list: max(50, 2 * report_psms) for report_psms <= 512 (capi.hip refuses more)
 __global__ __launch_bounds__(64) void tile_replay_big_kernel(DevScorer sc, DevWork w) {
-    __shared__ uint64_t heap[256];
+    __shared__ uint64_t heap[BIG_K];
     const uint32_t lane = lane_id();
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
     for (uint64_t qid_in = blockIdx.x; qid_in < n_q; qid_in += gridDim.x) {
@@ -2473,7 +2474,8 @@ struct RescoreLds {
 };
 constexpr uint32_t FEATURE_WORDS = sizeof(SageFeature) / 4;
 static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dwords");
-__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.chimera ? 1u : sc.report_psms; }
+// (none for lists wider than a wavefront: rescore_big_kernel's records leave lane by lane — and 512 of them would be 60 KB)
+__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.kmax > 64u ? 0u : sc.chimera ? 1u : sc.report_psms; }
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
@@ -3124,11 +3126,10 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
 #undef SAGE_N_ITEMS
 }
 
-// ---- rescoring of a preliminary list longer than a wavefront: report_psms > 32, up to BIG_K = 256 candidates -------------------------
+// ---- rescoring of a preliminary list longer than a wavefront: report_psms > 32, up to BIG_K = 1024 candidates ------------------------
 // The same steps as rescore_spectrum — score_candidates / hyperscore / stable sort by hyperscore / Feature records, the chimera
 // loop, quick_score's k-select — 64 candidates at a time, the per-candidate results parked in LDS between the steps.  The list is
 // always the reference's (exact trims: no tie can be mis-ranked, no retry).  Records leave lane by lane.
-constexpr uint32_t BIG_K = 256;
 struct BigScore {  // what a Feature needs of a candidate's Score
     uint32_t matched_b, matched_y;
     float summed_b, summed_y, ppm_difference;
@@ -3159,7 +3160,8 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
         long long* const g_key = (long long*)gp;
         double* const g_sorted = (double*)(g_key + BIG_K);
         BigScore* const g_score = (BigScore*)(g_sorted + BIG_K);
-        QuickKey* const g_qk = (QuickKey*)(g_score + BIG_K);  // (sizeof(BigScore) * 256 is a multiple of 8)
+        static_assert((sizeof(BigScore) * BIG_K) % 8 == 0, "QuickKey array aligned");
+        QuickKey* const g_qk = (QuickKey*)(g_score + BIG_K);
         uint32_t* const pbm = R.pbm;
         uint32_t* const plut = R.plut;
         float* const pm = R.pm;
@@ -3677,6 +3679,19 @@ size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return pre
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8) {
     return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8);
 }
+// report_psms > 128: lists, heaps and per-candidate scores of up to 1024 entries need more than the 64 KB a kernel gets by default
+size_t assemble_lds_bytes(const DevScorer& sc) {
+    const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+    return ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
+}
+int bigk_kernel_prepare(size_t max_lds_bytes) {
+    for (const void* f : {(const void*)prelim_kernel<true, false, true>, (const void*)prelim_kernel<false, false, true>,
+                          (const void*)rescore_big_kernel, (const void*)tile_assemble_kernel<true>}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipSuccess;
+}
 int tile_kernel_prepare(size_t max_lds_bytes) {
     const hipError_t e = hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
     if (e != hipSuccess) return (int)e;
@@ -3740,7 +3755,8 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
-    const size_t assemble_lds = ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
+    const size_t assemble_lds = assemble_lds_bytes(sc);
+    (void)fold;
     if (sc.kmax > WAVE) {  // report_psms > 32: heaps in LDS, always exact
         hipLaunchKernelGGL(tile_replay_big_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
         hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);

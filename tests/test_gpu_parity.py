@@ -180,8 +180,36 @@ def test_report_psms_beyond_a_wavefront(small_world, monkeypatch):
             "report_psms=50, OpenMS score, fragment charge 1", batch=b.subset(np.arange(0, b.n, 3)))
     _check_annotation(w, ScorerParams(annotate_matches=True, report_psms=40, precursor_tol=wide, min_matched_peaks=2),
                       b.subset(np.arange(0, b.n, 4)), "annotate, report 40")
+    # report_psms above 128 (round 4: lists, heaps and per-candidate scores of up to 1024 entries — a compute unit's whole LDS for
+    # the instances that keep them there): 500 PSMs per spectrum, narrow windows of a few thousand candidates (WCAP raised so that
+    # they stay in the narrow kernel), large windows through the tile kernels, both routes in one batch, chimera rounds
+    few = b.subset(np.arange(0, b.n, 6))
+    monkeypatch.setenv("SAGE_HIP_WCAP", "8192")
+    n, t = w.check(ScorerParams(report_psms=500, precursor_tol=Tolerance("da", -150.0, 150.0), min_matched_peaks=1,
+                                fragment_tol=Tolerance("da", -0.3, 0.3)), "report_psms=500 (k=1000), narrow kernel", batch=few)
+    assert n > few.n * 150 and t["n_wide"] < few.n // 2  # (most windows in the narrow kernel, the widest in the tile kernels)
+    monkeypatch.delenv("SAGE_HIP_WCAP")
+    n, t = w.check(ScorerParams(report_psms=500, precursor_tol=Tolerance("da", -150.0, 150.0), min_matched_peaks=1,
+                                fragment_tol=Tolerance("da", -0.3, 0.3)), "report_psms=500, tile kernels", batch=few)
+    assert n > few.n * 150 and t["n_wide"] > few.n // 2
+    w.check(ScorerParams(report_psms=300, precursor_tol=Tolerance("da", -40.0, 40.0), min_matched_peaks=1), "report_psms=300, mixed sizes",
+            batch=few)
+    w.check(ScorerParams(report_psms=200, chimera=True, precursor_tol=wide, min_matched_peaks=3), "report_psms=200, chimera",
+            batch=b.subset(np.arange(0, b.n, 40)))
+    for low_memory in (True, False):
+        params = ScorerParams(report_psms=400, precursor_tol=Tolerance("da", -60.0, 60.0))
+        scorer = Scorer(w.dev, params)
+        gk = scorer.quick_score(scorer.upload(few), low_memory)
+        np.testing.assert_array_equal(gk, w.orc.quick_score(params, few, low_memory), err_msg=f"quick_score report_psms=400 low_memory={low_memory}")
     with pytest.raises(L.SageHipError):
-        Scorer(w.dev, ScorerParams(report_psms=129))
+        Scorer(w.dev, ScorerParams(report_psms=513))
+    # folded lists of 15 queries per spectrum x 1000 candidates (110 KB of LDS) still fit ...
+    unknown_few = unknown.subset(np.arange(0, b.n, 50))
+    w.check(ScorerParams(report_psms=500, precursor_tol=Tolerance("da", -30.0, 30.0), min_isotope_err=-1, max_isotope_err=3, min_matched_peaks=1),
+            "report_psms=500, iso -1..3 x charges 2..4", batch=unknown_few)
+    # ... and where even a whole compute unit's LDS cannot hold them (eleven isotope errors), a clear refusal
+    with pytest.raises(L.SageHipError, match="lower report_psms"):
+        Scorer(w.dev, ScorerParams(report_psms=500, min_isotope_err=-1, max_isotope_err=9)).score(unknown_few)
 
 
 def test_isotope_errors_and_fragment_charge(small_world):
