@@ -613,7 +613,12 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     }
     {
         // small-tile copy for the narrow kernel (device_types.h: tm2_*), sorted on the device from the peptide-major list
-        uint32_t tile2_shift = 12;
+        // 2^11 peptides per small tile (round 4; 2^12 before): a +-10 ppm window of a human digest holds ~200 candidates, so of a
+        // tile's run for one fragment window only candidates / tile-size are inside the precursor window — the rest is fetched and
+        // thrown away, and prelim_kernel follows its line traffic.  C3, prelim ms per 500 000 spectra by shift 13 / 12 / 11 / 10 / 9 / 8:
+        // 2.26 / 1.86 / 1.68 / 1.67 / 1.83 / 2.20 (smaller tiles: more table rows, each reused by fewer spectra; 62 500-spectrum
+        // steps favour 11 over 10).  The table doubles to 1.5 GB for C3.
+        uint32_t tile2_shift = 11;
         if (const char* e = getenv("SAGE_HIP_TILE2_SHIFT")) tile2_shift = (uint32_t)std::min(16, std::max(6, atoi(e)));
         const float lut2_scale = 32.0f;  // (a power of two, like lut_scale)
         const uint64_t n_tiles2 = std::max<uint64_t>(1, (np + (1ull << tile2_shift) - 1) >> tile2_shift);
