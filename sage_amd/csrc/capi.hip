@@ -620,7 +620,11 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         // steps favour 11 over 10).  The table doubles to 1.5 GB for C3.
         uint32_t tile2_shift = 11;
         if (const char* e = getenv("SAGE_HIP_TILE2_SHIFT")) tile2_shift = (uint32_t)std::min(16, std::max(6, atoi(e)));
-        const float lut2_scale = 32.0f;  // (a power of two, like lut_scale)
+        float lut2_scale = 32.0f;  // cells per Da (a power of two, like lut_scale)
+        if (const char* e = getenv("SAGE_HIP_LUT2_SCALE")) {  // (experiments: 8 .. 256, rounded down to a power of two)
+            const int v = std::min(256, std::max(8, atoi(e)));
+            lut2_scale = (float)(1 << (31 - __builtin_clz((unsigned)v)));
+        }
         const uint64_t n_tiles2 = std::max<uint64_t>(1, (np + (1ull << tile2_shift) - 1) >> tile2_shift);
         std::vector<uint64_t> tile2_off(n_tiles2 + 1, 0);
         for (uint64_t t = 0; t < n_tiles2; t++) tile2_off[t + 1] = host_pm_off[std::min<uint64_t>(np, (t + 1) << tile2_shift)];
