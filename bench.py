@@ -682,13 +682,13 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": "neither narrow-search kernel is bound by HBM. rescore_kernel is bound by vector-ALU issue at 5 wavefronts "
-                                "per SIMD (instruction counts: profiles/r04_C3_pmc_sq_*.txt; the calibrated issue rate: "
-                                "profiles/r04_valu_calibration.md; where the cycles go phase by phase: profiles/r04_C3_phase_clocks.txt); "
-                                "prelim_kernel by chains of dependent memory / LDS round trips (round 4: a position table for the "
-                                "precursor-window search took three round trips out of it and 9 % off its time, the XCD-aware schedule "
-                                "halves its L2 misses and does not move it) — so byte fractions say how far the memory system is from "
-                                "being the limit, not how good the kernels are",
+                    "limiters": "rescore_kernel is bound by vector-ALU issue at 5 wavefronts per SIMD, not by HBM (instruction counts: "
+                                "profiles/r04_C3_pmc_sq_*.txt; the calibrated issue rate: profiles/r04_valu_calibration.md; where the cycles "
+                                "go phase by phase: profiles/r04_C3_phase_clocks.txt) — its byte fractions are small by construction. "
+                                "prelim_kernel follows its HBM LINE traffic (by_kernel.prelim.frac_traffic: ~0.75 of the 8 TB/s peak, ~0.95 "
+                                "of the 6.29 TB/s MI355X_MICROARCH.md calls achievable): a 4-byte table word and a 16-byte index cell each "
+                                "cost a 128-byte line, so it moves three times the bytes it asks for; its `frac` above 1 only says that "
+                                "96 % of SURVEY 8(d)'s bytes are binary-search probes a table-driven kernel never issues",
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],

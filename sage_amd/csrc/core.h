@@ -477,7 +477,7 @@ SAGE_HD int select_peak_lut(const float* pm, const float* pi, uint32_t P, const 
 SAGE_HD uint32_t wpp_step(uint32_t span) { return span / 65u + 1u; }
 
 // ---- peak-presence bitmap (rescore_kernel's filter in front of select_most_intense_peak) --------------------------------
-// PBM_BITS mass bins of a FIXED width of 1/8 Da, the bin index taken modulo PBM_BITS (masses 2048 Da apart share a bin: a
+// PBM_BITS mass bins of a FIXED width of 1/16 Da, the bin index taken modulo PBM_BITS (masses 2048 Da apart share a bin: a
 // Bloom filter with one hash).  Every peak sets the bins that overlap [mass - D, mass + D], D bounding |mz - mass| over every
 // m/z whose tolerance window (Tolerance::bounds, mass.rs:21-35) contains the peak, plus the roundings; an ion whose bin is clear
 // cannot match any peak.  The bin of an ion's m/z at fragment charge c is the bin of the EXACT quotient: x = floor(8 ion) (the
@@ -488,9 +488,15 @@ SAGE_HD uint32_t wpp_step(uint32_t span) { return span / 65u + 1u; }
 // Conservative by construction (tests/test_core_emulation.py checks it against Tolerance::bounds on adversarial inputs); when
 // that cannot be guaranteed (non-finite or negative masses, non-finite tolerances, a relative tolerance of a quarter and more,
 // D above 4 Da) every bin is set.
-constexpr uint32_t PBM_BITS = 16384, PBM_WORDS = PBM_BITS / 32;
-constexpr float PBM_INV_W = 8.0f;  // bins per Da (a power of two: mass * PBM_INV_W is exact)
-constexpr float PBM_MAX_D = 4.0f;  // 32 bins either side
+#ifndef SAGE_PBM_LOG2_BITS
+#define SAGE_PBM_LOG2_BITS 15  // 32 768 bins (4 KB of LDS; round 4 before: 14 with 1/8 Da bins, 2 % slower — DESIGN.md 4.3)
+#endif
+#ifndef SAGE_PBM_LOG2_INV_W
+#define SAGE_PBM_LOG2_INV_W 4  // bins of 1/16 Da
+#endif
+constexpr uint32_t PBM_BITS = 1u << SAGE_PBM_LOG2_BITS, PBM_WORDS = PBM_BITS / 32;
+constexpr float PBM_INV_W = (float)(1u << SAGE_PBM_LOG2_INV_W);  // bins per Da (a power of two: mass * PBM_INV_W is exact)
+constexpr float PBM_MAX_D = 4.0f;  // 64 bins either side
 // x of an ion: floor(8 ion), saturating (a negative or NaN ion gives 0, an absurd one 2^32 - 1: such ions match no peak of a
 // spectrum the filter is active for)
 SAGE_HD uint32_t pbm_index(float ion) {

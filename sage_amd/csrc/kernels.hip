@@ -2351,12 +2351,12 @@ constexpr uint32_t RETRY_GRID_CAP = 8192;   // blocks of the narrow exact retry 
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm, uint32_t P, const PbmReach& reach) {
     const uint32_t lane = lane_id();
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)bm != 0u) __builtin_trap();  // (pbm_bit: the bitmap at LDS address 0)
-    static_assert(PBM_WORDS == 8 * WAVE, "two 16-byte stores per lane clear the bitmap");
+    static_assert(PBM_WORDS % (4 * WAVE) == 0, "16-byte stores per lane clear the bitmap");
     const uint4 z4 = fresh_zero4();
-    *(uint4*)(bm + 4 * lane) = z4;
-    *(uint4*)(bm + 4 * (WAVE + lane)) = z4;
+#pragma unroll
+    for (uint32_t i = 0; i < PBM_WORDS / (4 * WAVE); i++) *(uint4*)(bm + 4 * (i * WAVE + lane)) = z4;
     lds_sync();
-    // ONE pass: every peak sets its bins; a peak without a safe reach (a negative or non-finite mass, D above 32 bins — core.h:
+    // ONE pass: every peak sets its bins; a peak without a safe reach (a negative or non-finite mass, D above 4 Da — core.h:
     // pbm_peak_reach) sets nothing and switches the filter off for the spectrum below
     bool bad = false;
     for (uint32_t i = lane; i < P; i += WAVE) {
@@ -2477,7 +2477,9 @@ static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dword
 // (none for lists wider than a wavefront: rescore_big_kernel's records leave lane by lane — and 512 of them would be 60 KB)
 __host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.kmax > 64u ? 0u : sc.chimera ? 1u : sc.report_psms; }
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
-    return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + 64 * 8 + 64 * 8 + (quick ? 64 * sizeof(QuickKey) : 0);
+    // (the sort keys of a multi-PSM round live in the bitmap's bytes: carve_rescore)
+    static_assert(PBM_WORDS * 4 >= 64 * 8 + 64 * 8, "s_sorted + s_key fit the bitmap");
+    return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
 constexpr uint32_t RESCORE_HDR_WORDS = 8;
 enum RescoreHdr { HDR_TIC = 0, HDR_MZP = 1, HDR_RT = 2, HDR_IMS = 3, HDR_FILE = 4, HDR_MATCHED = 5, HDR_SCORED = 6 };
@@ -2490,9 +2492,11 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
     RescoreLds l;
     l.pbm = (uint32_t*)scratch;
     l.plut = l.pbm + PBM_WORDS;
-    l.s_sorted = (double*)(l.plut + PLUT_BINS);
+    // s_sorted / s_key are written behind score_candidates of a round that reports several PSMs — never a chimera round, so there
+    // is no next round that would read the bitmap again: they take its bytes (1 KB of LDS per wavefront less)
+    l.s_sorted = (double*)l.pbm;
     l.s_key = (long long*)(l.s_sorted + 64);
-    l.qkeys = (QuickKey*)(l.s_key + 64);
+    l.qkeys = (QuickKey*)(l.plut + PLUT_BINS);
     l.hdr = (uint32_t*)fixed;
     l.meta = (uint2*)(fixed + RESCORE_HDR_WORDS * 4);
     l.pm = (float*)(fixed + RESCORE_HEAD_BYTES);
