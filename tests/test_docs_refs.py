@@ -34,3 +34,26 @@ def test_documents_name_files_that_exist():
             if not os.path.exists(os.path.join(ROOT, rel)):
                 missing.append((doc, rel))
     assert not missing, "documents name files that are not in the tree: " + ", ".join(f"{d}: {n}" for d, n in sorted(set(missing)))
+
+
+def test_readme_headline_is_the_committed_bench_line():
+    """README.md's round summary quotes C3 / C3T / C2 / C4 / C5 in M spectra/s: each must be the `value` of the newest committed
+    `profiles/rNN_<config>_bench.json` of that configuration, to the digit shown."""
+    import glob
+    import json
+    text = open(os.path.join(ROOT, "README.md"), encoding="utf-8").read().replace("\n  ", " ")
+    m = re.search(r"\* Round (\d) on one MI355X.*?(?=\n\n|\n```)", text, re.S)
+    assert m, "README.md has no round summary"
+    tag = f"r0{m.group(1)}"
+    para = m.group(0)
+    quoted = {"C3": re.search(r"\*\*([0-9.]+) M spectra/s\*\* resident", para), "C3T": re.search(r"\(C3T\) ([0-9.]+) M", para),
+              "C2": re.search(r"C2 ([0-9.]+) M", para), "C4": re.search(r"C4 ([0-9.]+) M", para), "C5": re.search(r"C5 ([0-9.]+) M", para)}
+    for cfg, mm in quoted.items():
+        assert mm, f"README.md does not quote {cfg}"
+        path = os.path.join(ROOT, "profiles", f"{tag}_{cfg}_bench.json")
+        assert os.path.exists(path), path
+        line = [ln for ln in open(path) if ln.startswith("{")][-1]
+        value = json.loads(line)["value"] / 1e6
+        shown = mm.group(1)
+        digits = len(shown.split(".")[1]) if "." in shown else 0
+        assert abs(value - float(shown)) <= 0.51 * 10 ** -digits, f"{cfg}: README says {shown} M, {os.path.basename(path)} says {value:.3f} M"
