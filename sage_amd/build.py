@@ -25,22 +25,50 @@ def hipcc():
     return "hipcc"
 
 
+def _flags():
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+    return common + os.environ.get("SAGE_HIP_EXTRA_FLAGS", "").split()
+
+
+def source_digest():
+    """sha256 over every source and header of the library (names + contents), this file and the compiler flags: what the
+    shipped .so was built FROM.  Modification times say nothing on a fresh checkout or on the GPU box's snapshot."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(set([os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)])):
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join([ARCH] + _flags()).encode())
+    return h.hexdigest()
+
+
+def _stamp():
+    return LIB + ".srchash"
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True unless the library exists AND carries the digest of the sources / flags in the tree now."""
+    if not os.path.exists(LIB) or not os.path.exists(_stamp()):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(_stamp()) as fh:
+        return fh.read().strip() != source_digest()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-    common += os.environ.get("SAGE_HIP_EXTRA_FLAGS", "").split()
+    common = _flags()
+    digest = source_digest()
+    # objects of the default build beside the sources; a variant's (SAGE_HIP_OBJ_SUFFIX, scripts/variants.sh) under build/,
+    # which neither git nor the GPU box's snapshot carries
+    suffix = os.environ.get("SAGE_HIP_OBJ_SUFFIX", "")
+    objdir = CSRC if not suffix else os.path.join(HERE, "..", "build", "variants", suffix.strip("_"))
+    os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + os.environ.get("SAGE_HIP_OBJ_SUFFIX", "") + ".o")
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc(), f"--offload-arch={ARCH}", *common, "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")
@@ -57,6 +85,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(_stamp(), "w") as fh:
+        fh.write(digest + "\n")
     return LIB
 
 

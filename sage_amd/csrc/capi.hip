@@ -747,6 +747,10 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     if (const char* e = getenv("SAGE_HIP_WAYS")) s->ways = (uint32_t)std::min(4, std::max(1, atoi(e)));
     // cheap ties: only where the tied candidates' records are final whichever wins (one reported PSM, no chimera rounds)
     if (p->report_psms != 1 || p->chimera) s->fast_ties = false;
+    // ... and only where a spectrum's window counts fit the LDS rescore_kernel replays them in (the peak bitmap + the peak table,
+    // dead by then: kernels.hip FAST_TIE_WORDS; wcap <= 2560 — the default is 1024, SAGE_HIP_WCAP raises it).  Larger windows
+    // settle their ties through the exact retry pass.
+    if ((d.wcap + 1) / 2 > fast_tie_lds_words()) s->fast_ties = false;
     s->cnt_stride = 4u + (((d.wcap + 1) / 2 + 3u) & ~3u);  // (kernels.hip: CNT_ROW_HEADER)
     if (d.kmax > 64) {
         // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
@@ -1315,8 +1319,16 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream
         w.cap_n = n;
     }
     if (s->fast_ties && n > w.cap_tie) {
-        HIP_TRY(w.cnt_store.reserve((size_t)n * s->cnt_stride));
-        w.cap_tie = n;
+        // (n rows of ~2 KB: 1 GB for a 500 000-spectrum resident batch.  The search does not need them — without the rows every
+        // tie takes the exact retry pass — so running out of memory HERE switches fast ties off instead of failing the call.)
+        const hipError_t e = w.cnt_store.reserve((size_t)n * s->cnt_stride);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            s->fast_ties = false;
+        } else {
+            HIP_TRY(e);
+            w.cap_tie = n;
+        }
     }
     if (wide && lane == 0 && n > w.cap_wide) {
         // large-window pipeline: per-query records, verbatim slots, replayed heaps, and the candidate arena

@@ -197,6 +197,7 @@ size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchVi
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
 int bigk_kernel_prepare(size_t max_lds_bytes);  // ... of the instances for lists wider than a wavefront (report_psms > 32)
 size_t assemble_lds_bytes(const DevScorer& sc);
+uint32_t fast_tie_lds_words();  // words of LDS rescore_kernel can stage a spectrum's window counts in ((wcap + 1) / 2 must fit)
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 // the narrow search as ONE launch of two kinds of workgroups (preliminary / rescoring, kernels.hip: search_kernel)

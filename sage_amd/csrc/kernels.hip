@@ -29,6 +29,10 @@ namespace sagehip {
 namespace {
 
 constexpr uint32_t WAVE = 64;
+// LDS words the in-line tie replay of rescore_spectrum may overwrite: the peak bitmap and the peak table behind it (both dead by
+// then).  A row of window counts holds (potential + 1) / 2 words, potential <= wcap: capi.hip switches fast ties off for a wcap
+// whose rows would not fit, and the kernel checks every row again.
+constexpr uint32_t FAST_TIE_WORDS = PBM_WORDS + PLUT_BINS;
 constexpr uint32_t CNT_ROW_HEADER = 4;  // DevWork::cnt_store: words in front of a row's counts (keeps them 16-byte aligned)
 #ifndef SAGE_PROBE_PER_LANE
 #define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
@@ -2479,6 +2483,7 @@ __host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return 
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     // (the sort keys of a multi-PSM round live in the bitmap's bytes: carve_rescore)
     static_assert(PBM_WORDS * 4 >= 64 * 8 + 64 * 8, "s_sorted + s_key fit the bitmap");
+    static_assert(FAST_TIE_WORDS == PBM_WORDS + PLUT_BINS, "the fast-tie replay stages its counts over pbm + plut, contiguous below");
     return (size_t)PBM_WORDS * 4 + PLUT_BINS * 4 + (quick ? 64 * sizeof(QuickKey) : 0);
 }
 constexpr uint32_t RESCORE_HDR_WORDS = 8;
@@ -3028,12 +3033,12 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
             if (queue_on_tie && la.cnt_store() && per_round == 1 && !chimera) {
                 const uint32_t* __restrict__ row = la.cnt_store() + (size_t)xcd_position(blockIdx.x, la.batch_n(), la.xcd_chunk()) * la.cnt_stride();
                 const uint32_t left = uni(row[0]), potential = uni(row[1]);
-                if (potential != 0u) {
+                if (potential != 0u && (potential + 1) / 2 <= FAST_TIE_WORDS) {  // (a row that would not fit: the retry pass below)
                     const bool is_best = pass && __double_as_longlong(h) == __double_as_longlong(best_h);
                     uint64_t tb = __ballot(is_best);
                     const uint32_t k = trim_k(potential, report_psms);
                     Counters cnt;
-                    cnt.p = pbm;  // [(wcap + 1) / 2] words <= the 3 KB of bitmap + peak table
+                    cnt.p = pbm;  // [(potential + 1) / 2] words <= FAST_TIE_WORDS: the bitmap + the peak table behind it (carve_rescore)
                     __syncthreads();
                     for (uint32_t i = lane; i < (potential + 1) / 2; i += WAVE) cnt.p[i] = row[CNT_ROW_HEADER + i];
                     __syncthreads();
@@ -3688,6 +3693,7 @@ size_t assemble_lds_bytes(const DevScorer& sc) {
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
     return ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
 }
+uint32_t fast_tie_lds_words() { return FAST_TIE_WORDS; }
 int bigk_kernel_prepare(size_t max_lds_bytes) {
     for (const void* f : {(const void*)prelim_kernel<true, false, true>, (const void*)prelim_kernel<false, false, true>,
                           (const void*)rescore_big_kernel, (const void*)tile_assemble_kernel<true>}) {
