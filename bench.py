@@ -229,6 +229,57 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None, span=None):
     return batch, np.concatenate([p[2] for p in parts])
 
 
+def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
+    """Strong scaling, --shard-by mass: every rank has generated a contiguous span of THE run; the ranks agree on
+    sharding.plan_mass_shards over the whole run (per-spectrum sort mass and work estimate exchanged: 16 bytes per spectrum) and
+    hand each other the spectra through node-local files (the ranks of one node — the driver's contract; workload distribution
+    before the timed region, not a data-path collective: a search process that reads the mzML itself, cli.py --devices, cuts its
+    in-memory spectrum list instead).  Returns (this rank's shard, the global input positions of its spectra, spectra in the run)."""
+    import numpy as np
+
+    from sage_amd.api import SpectrumBatch
+    from sage_amd.sharding import estimate_work, plan_mass_shards, precursor_sort_mass
+    wts = estimate_work(batch.peak_off, batch.precursor_mz, batch.precursor_charge, params, pep_mono, batch.isolation_lo, batch.isolation_hi)
+    mass = precursor_sort_mass(batch.precursor_mz, batch.precursor_charge, params)
+    parts = [None] * world
+    dist.all_gather_object(parts, (rank, mass, wts))
+    parts.sort(key=lambda p: p[0])
+    sizes = [len(p[1]) for p in parts]
+    base = int(sum(sizes[:rank]))
+    n_total = int(sum(sizes))
+    plan = plan_mass_shards(np.concatenate([p[1] for p in parts]), world, np.concatenate([p[2] for p in parts]))
+    xdir = os.path.join(tempfile.gettempdir(), f"sage_bench_xchg_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(xdir, exist_ok=True)
+    for j in range(world):
+        mine = plan[j][(plan[j] >= base) & (plan[j] < base + batch.n)]
+        sub = batch.subset(mine - base)
+        np.savez(os.path.join(xdir, f"from{rank}_to{j}.npz"), index=mine,
+                 **{k: getattr(sub, k) for k in _BATCH_FIELDS if getattr(sub, k) is not None})
+    dist.barrier()
+    got = []
+    for i in range(world):
+        z = np.load(os.path.join(xdir, f"from{i}_to{rank}.npz"))
+        got.append((z["index"], SpectrumBatch(*[z[k] if k in z.files else None for k in _BATCH_FIELDS])))
+    dist.barrier()
+    for j in range(world):
+        try:
+            os.unlink(os.path.join(xdir, f"from{rank}_to{j}.npz"))
+        except OSError:
+            pass
+    bs = [b for _, b in got]  # (sender i's pieces are ascending in the global index and the senders' spans are ordered: so is this)
+    off = np.zeros(sum(b.n for b in bs) + 1, dtype=np.uint64)
+    pos, pbase = 0, 0
+    for b in bs:
+        off[pos + 1:pos + b.n + 1] = b.peak_off[1:] + np.uint64(pbase)
+        pos += b.n
+        pbase += int(b.peak_off[-1])
+    cat = lambda k: None if getattr(bs[0], k) is None else np.concatenate([getattr(b, k) for b in bs])  # noqa: E731
+    shard = SpectrumBatch(off, *[cat(k) for k in _BATCH_FIELDS[1:]])
+    index = np.concatenate([ix for ix, _ in got]).astype(np.int64)
+    assert np.array_equal(index, plan[rank]), "the exchanged shard is not the planned one"
+    return shard, index, n_total
+
+
 def gpu_algorithm_bytes(dev, params, batch, n_sample=8192):
     """Bytes the GPU ALGORITHM asks memory for, per spectrum, counted by the kernels themselves in a profiling pass over a
     prefix of the workload (SAGE_HIP_PHASE_CLOCKS build of the counters, kernels.hip: DBG_*): position-table words (8 B per
@@ -321,12 +372,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--shard-by", default="mass", choices=["mass", "input"],
+                    help="strong scaling: a rank's shard is a contiguous range of PRECURSOR MASS (sharding.plan_mass_shards, the "
+                         "default: a rank walks 1/N of the mass-sorted index) or of input positions (round 4)")
+    ap.add_argument("--slice", default="", metavar="K/N",
+                    help="single GPU: score only the shard rank K of an N-GPU strong-scaling run would get under --shard-by (what one "
+                         "GPU can say about the scaling curve: profiles/r05_shard_sizes.txt)")
     ap.add_argument("--spectra", type=int, default=0, help="override the size of the workload (smoke runs)")
     ap.add_argument("--proteins", type=int, default=0, help="override the number of proteins (smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes (roofline.traffic from profiles/)")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / streaming / thread-table measurements")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="override the number of spectra the CPU baseline scores")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="check only this many spectra against the oracle (default: all of them)")
     ap.add_argument("--traffic-spectra", type=int, default=65536)
     ap.add_argument("--traffic-timeout", type=int, default=300)
     ap.add_argument("--rescore-psms", type=int, default=0,
@@ -362,6 +419,8 @@ def main():
     seed_shift = rank if args.scaling == "weak" else 0
     gen_workers = max(1, min(32, int(host_cpu_budget()[0]) // world))  # (the ranks of a node share its CPUs)
     batch_all = None
+    slice_info = None
+    my_index = None  # strong scaling by mass: the global input positions of this rank's spectra
     if args.scaling == "strong" and world > 1:
         # Every rank generates ITS shard only: spectra [total r / N, total (r + 1) / N) of the run (whole chunks of SPECTRA_CHUNK
         # spectra except at the two ends; chunk c depends on (seed, c) only).  The synthetic run is shuffled, so
@@ -382,6 +441,20 @@ def main():
     else:
         batch_all, gidx = generate_workload(cfg, host, total, seed_shift, gen_workers)
         shards, lo, hi, batch = None, 0, batch_all.n, batch_all
+        if args.slice:
+            from sage_amd.sharding import estimate_work, plan_mass_shards, plan_shards, precursor_sort_mass
+            k_, n_ = (int(x) for x in args.slice.split("/"))
+            params_ = scorer_params(cfg)
+            wts = estimate_work(batch_all.peak_off, batch_all.precursor_mz, batch_all.precursor_charge, params_, host.pep_mono,
+                                batch_all.isolation_lo, batch_all.isolation_hi)
+            if args.shard_by == "mass":
+                idx_ = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params_), n_, wts)[k_]
+            else:
+                b_, e_ = plan_shards(batch_all.peak_off, n_, wts)[k_]
+                idx_ = np.arange(b_, e_)
+            batch = batch_all.subset(idx_)
+            slice_info = {"slice": args.slice, "shard_by": args.shard_by, "spectra": int(batch.n),
+                          "share_of_estimated_work": float(wts[idx_].sum() / wts.sum())}
     t_spec = time.time() - t0
 
     if not torch.cuda.is_available():
@@ -408,6 +481,8 @@ def main():
     dev = DeviceDatabase(host, local_rank, build_on_device=True)  # index_build.hip: the fragment index is generated in HBM
     t_dev = time.time() - t0
     scorer = Scorer(dev, params)
+    if world > 1 and args.scaling == "strong" and args.shard_by == "mass":
+        batch, my_index, n_run = exchange_by_mass(batch, params, host.pep_mono, rank, world, dist)
     dbatch = scorer.upload(batch)  # inputs resident in HBM before the timed region
 
     def barrier():
@@ -507,14 +582,18 @@ def main():
     # ---- strong scaling: ordered gather of the ranks' records, checked against rank 0's own pass over everything ----
     sharding = None
     if world > 1 and args.scaling == "strong":
-        from sage_amd.sharding import gather_features
+        from sage_amd.sharding import gather_features, gather_features_by_index
         t0 = time.perf_counter()
         sizes = [None] * world
         dist.all_gather_object(sizes, int(batch.n))
-        lo = int(sum(sizes[:rank]))
-        hi = lo + int(batch.n)
-        shards = [(int(sum(sizes[:r])), int(sum(sizes[:r + 1]))) for r in range(world)]
-        gf, gc = gather_features(feats, counts, lo)  # host-side, input order, spec_index rebased
+        if my_index is not None:  # shards by precursor mass: a permutation back into input order
+            gf, gc = gather_features_by_index(feats, counts, my_index, n_run)
+            shards = [(0, n_run)]  # (not ranges of the input: sharding.spectra_per_rank has the counts)
+        else:
+            lo = int(sum(sizes[:rank]))
+            hi = lo + int(batch.n)
+            shards = [(int(sum(sizes[:r])), int(sum(sizes[:r + 1]))) for r in range(world)]
+            gf, gc = gather_features(feats, counts, lo)  # host-side, input order, spec_index rebased
         t_gather = time.perf_counter() - t0
         if rank == 0:
             whole_conn.send("go")
@@ -528,7 +607,8 @@ def main():
             ref_scorer = Scorer(dev, params)
             rf, rc = ref_scorer.score(batch_all)  # the N = 1 result, through the streaming entry point
             same = same_psms(gf, gc, rf, rc)
-            sharding = {"shards": [list(s_) for s_ in shards], "gather_s": t_gather, "psms": int(gc.sum()),
+            sharding = {"shard_by": args.shard_by if args.scaling == "strong" else None, "spectra_per_rank": [int(x) for x in sizes],
+                        "shards": [list(s_) for s_ in shards], "gather_s": t_gather, "psms": int(gc.sum()),
                         "identical_to_single_gpu": same}
             if not same:
                 raise SystemExit(f"bench.py: the gathered {world}-GPU result differs from the single-GPU result")
@@ -574,56 +654,91 @@ def main():
             del locked
         # ---- cpu_baseline + algorithmic bytes: the oracle (restated reference CPU path), rank 0, N = 1 only
         cpu = None
+        parity = None
         bytes_per_spec = None
         cache = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")
         cached = json.load(open(cache)) if os.path.exists(cache) else {}
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import hashlib
+
             import oracle_lib
-            from parity_utils import assert_features_equal
-            n_cpu = min(batch.n, args.cpu_sample or cfg["cpu_sample"])
-            sample = batch if n_cpu == batch.n else batch.subset(np.arange(n_cpu))
-            # parity + work counters on the checker build
-            orc = oracle_lib.OracleDb.from_product(host)
-            of, oc, _, work = orc.score(params, sample, threads=0, work=True)
-            parity_psms = assert_features_equal(feats[:n_cpu], counts[:n_cpu], of, oc, "bench parity")  # same inputs
-            # (the checker compares with a correctly rounded ln — libquadmath — like the product's; the build that is TIMED keeps the
-            # platform libm, the reference's own arithmetic on this host, so it is held to the checker in that mode)
-            with oracle_lib.LogMode(0):
-                of0, oc0, _, _ = orc.score(params, sample, threads=0)
-            # timing on the performance build (same sources, -O3; asserted bit-identical), a table over thread counts: the
-            # sample grows with the thread count so that each entry is a few seconds of work
-            with oracle_lib.use("fast"):
-                fast = oracle_lib.OracleDb.from_product(host)
-            # thread counts up to the CPUs this process is ALLOWED (affinity mask, cgroup quota), threads bound to cores and
-            # spread over the sockets; threads beyond the quota only get throttled (round 2's table fell above 16 for that reason)
+            from parity_utils import assert_features_equal, assert_initial_hits_equal
             ncpu, cpu_details = host_cpu_budget()
             os.environ.setdefault("OMP_PROC_BIND", "spread")
             os.environ.setdefault("OMP_PLACES", "cores")
+            # ---- (1) the builds of the checker against each other on a prefix: the -O2 checker build and the -O3 performance
+            #      build (same sources, strict IEEE both) must agree bit for bit, in both ln modes (1: correctly rounded through
+            #      libquadmath = the product's contract, what parity is held against; 0: the platform libm = the reference's own
+            #      arithmetic on this host, what is TIMED)
+            n_x = min(batch.n, 2048)
+            prefix = batch if n_x == batch.n else batch.subset(np.arange(n_x))
+            orc = oracle_lib.OracleDb.from_product(host)
+            with oracle_lib.use("fast"):
+                fast = oracle_lib.OracleDb.from_product(host)
+            of1, oc1, _, _ = orc.score(params, prefix, threads=0)
+            with oracle_lib.LogMode(0):
+                of0, oc0, _, _ = orc.score(params, prefix, threads=0)
+            fast.lib.orc_set_log_mode(1)
+            ff1, fc1, _, _ = fast.score(params, prefix, threads=ncpu)
+            fast.lib.orc_set_log_mode(0)
+            ff0, fc0, _, _ = fast.score(params, prefix, threads=ncpu)
+            if not (same_psms(ff1, fc1, of1, oc1) and same_psms(ff0, fc0, of0, oc0)):
+                raise SystemExit("bench.py: the performance build of the oracle differs from the checker build")
+            # ---- (2) parity over the WHOLE workload of this run (VERDICT r04 task 1): every PSM of every spectrum the GPU scored
+            #      in the timed region against the oracle, every field (ints and f32 bit for bit, the f64 fields through a
+            #      correctly rounded ln on both sides), in slices so that the oracle's records never need more than a slice
+            n_par = batch.n if not args.cpu_sample else min(batch.n, args.cpu_sample)
+            fast.lib.orc_set_log_mode(1)
+            t0 = time.perf_counter()
+            parity_psms, step_ = 0, 65536
+            for lo_ in range(0, n_par, step_):
+                hi_ = min(n_par, lo_ + step_)
+                sl = batch.subset(np.arange(lo_, hi_))
+                of, oc, _, _ = fast.score(params, sl, threads=ncpu)
+                of["spec_index"] += np.uint32(lo_)  # (a slice numbers its spectra from 0)
+                parity_psms += assert_features_equal(feats[lo_:hi_], counts[lo_:hi_], of, oc, f"bench parity [{lo_}, {hi_})", exact_f64=True)
+            t_parity = time.perf_counter() - t0
+            fast.lib.orc_set_log_mode(0)
+            # the preliminary candidate lists, heap order included (Scorer::initial_hits), on every 256th spectrum
+            stride = batch.subset(np.arange(0, n_par, 256))
+            hits_scorer = Scorer(dev, params)
+            assert_initial_hits_equal(hits_scorer, hits_scorer.upload(stride), orc, params, stride, "bench parity, initial hits")
+            hits_scorer.close()
+            valid_ = np.arange(feats.shape[1])[None, :] < counts[:n_par, None]
+            parity = {"spectra_checked": int(n_par), "spectra_in_workload": int(batch.n), "psms": int(parity_psms),
+                      "identical": True,  # (an assertion above would have ended the run otherwise)
+                      "fields": "every Feature field: integers and f32 bit for bit, f64 (hyperscore, delta_next, delta_best, poisson) "
+                                "equal through a correctly rounded ln on both sides",
+                      "initial_hits_checked": int(stride.n), "md5_of_gpu_records": hashlib.md5(feats[:n_par][valid_].tobytes()).hexdigest(),
+                      "oracle": f"performance build of oracle/ (bit-identical to the checker build on the first {n_x} spectra in both "
+                                f"ln modes), {ncpu} threads", "oracle_seconds": round(t_parity, 2)}
+            # ---- (3) algorithmic bytes: the oracle's work counters on a prefix
+            n_cpu = min(batch.n, cfg["cpu_sample"])
+            sample = batch if n_cpu == batch.n else batch.subset(np.arange(n_cpu))
+            _, _, _, work = orc.score(params, sample, threads=0, work=True)
+            # ---- (4) cpu_baseline: the performance build with the platform libm, ONE sample of the workload at every thread
+            #      count of the ladder (threads bound to cores; counts beyond the CPUs this process is allowed only get throttled)
+            n_time = min(batch.n, cfg.get("cpu_time_sample", cfg["cpu_sample"]))
+            tsample = batch if n_time == batch.n else batch.subset(np.arange(n_time))
+            fast.score(params, tsample, threads=ncpu)  # warm-up (page in the index)
             table = {}
             ladder = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t <= ncpu} | {ncpu})
+            if args.no_extras:
+                ladder = [ncpu]
             for th in ladder:
-                m = min(n_cpu, max(512, n_cpu // 64) * th) if not args.no_extras else n_cpu
-                if args.no_extras and th != ncpu:
-                    continue
-                sub = sample if m >= sample.n else sample.subset(np.arange(m))
-                fast.score(params, sub, threads=th)  # warm-up
-                ff, fc, ms, _ = fast.score(params, sub, threads=th)
-                if not same_psms(ff, fc, of0[:sub.n], oc0[:sub.n]):
-                    raise SystemExit("bench.py: the performance build of the oracle differs from the checker build")
-                table[str(th)] = {"spectra_per_s": sub.n * 1000.0 / (ms + 1.0), "spectra": sub.n}  # runner.rs:327-330
+                _, _, ms, _ = fast.score(params, tsample, threads=th)
+                table[str(th)] = {"spectra_per_s": tsample.n * 1000.0 / ms, "spectra": tsample.n, "seconds": ms / 1e3}  # runner.rs:327-330
             best = max(table, key=lambda k: table[k]["spectra_per_s"])
-            what = f"all {batch.n} spectra of the workload" if n_cpu == batch.n else \
-                f"the first {n_cpu} of the {batch.n} spectra of the workload"
             cpu = {"value": table[best]["spectra_per_s"], "unit": "spectra/s", "cores": int(best), "kind": "port",
                    "host_cpus_allowed": ncpu, "host_cpu_details": cpu_details,
-                   "sample": f"{what} (smaller prefixes at low thread counts), one pass after a warm-up per thread count, OpenMP "
-                             f"dynamic schedule, threads bound to cores (OMP_PROC_BIND=spread), performance build of the restated "
-                             f"reference CPU path (oracle/Makefile FASTFLAGS; not Sage itself); value = the best thread count "
-                             f"up to the {ncpu} CPUs this process may use",
+                   "sample": f"the first {tsample.n} of the {batch.n} spectra of the workload — the SAME sample at every thread count "
+                             f"of threads_table, one pass each after one warm-up, OpenMP dynamic schedule, threads bound to cores "
+                             f"(OMP_PROC_BIND=spread), performance build of the restated reference CPU path (oracle/Makefile FASTFLAGS, "
+                             f"platform libm; not Sage itself — no Rust toolchain here); value = the best thread count up to the "
+                             f"{ncpu} CPUs this process may use",
                    "threads_table": table,
-                   "parity": f"{parity_psms} PSMs identical to the GPU result (every field bit for bit: ints, f32, and the f64 "
-                             f"fields through a correctly rounded ln on both sides — sage_amd/csrc/crlog.h vs libquadmath)"}
+                   "parity": f"{parity_psms} PSMs of {n_par} spectra identical to the GPU result (see the line's `parity` object)"}
             rescore_bytes = 4 * work["rescored"] + 5 * work["rescored_residues"] + 64 * work["reported"]
             bytes_per_spec = {"total": work["algorithmic_bytes"] / sample.n,
                               "prelim": (work["algorithmic_bytes"] - rescore_bytes) / sample.n,
@@ -713,13 +828,15 @@ def main():
                        "fragments": host.n_fragments if host.has_fragments else None, "precursor_tol": _tol_str(params.precursor_tol),
                        "fragment_tol": _tol_str(params.fragment_tol), "report_psms": params.report_psms,
                        "chimera": params.chimera, "wide_window": params.wide_window,
-                       "parallelism": f"spectra sharded x{world} ({args.scaling}), index replicated, no collective on the data path",
+                       "parallelism": f"spectra sharded x{world} ({args.scaling}" + (f", contiguous in precursor {args.shard_by}" if world > 1 and args.scaling == "strong" else "") + "), index replicated, no collective on the data path",
+                       "slice": slice_info,
                        "psms_per_step_rank0": n_psm,
                        "setup_s": {("db_build_host_incl_fragments_for_the_oracle" if need_oracle else "db_build_host_peptides"): round(t_db, 2),
                                    "spectra": round(t_spec, 2),
                                    "index_build_on_device": round(t_dev, 2)},
                        "index_device_bytes": dev.device_bytes},
             "roofline": roof, "cpu_baseline": cpu,
+            "parity": parity,  # the whole workload of this run against the oracle (N = 1 only)
             "sustained": sustained,
             "concurrent": concurrent,  # two scorer handles / host threads on the same GPU (see above)
             "host_to_host_value": extras or None,  # PCIe-inclusive: sage_hip_score_batch, this rank's share

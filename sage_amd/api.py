@@ -526,6 +526,18 @@ class RawBatch:
                                     self.isolation_hi[begin:end], self.scan_start_time[begin:end],
                                     self.inverse_ion_mobility[begin:end], self.file_id[begin:end])
 
+    def subset(self, idx) -> "RawBatch":
+        """The spectra at positions `idx` as a batch of their own (a shard that is not contiguous in the file: sharding.plan_mass_shards)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        lens = (self.peak_off[1:] - self.peak_off[:-1])[idx].astype(np.int64)
+        off = np.zeros(len(idx) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        starts = self.peak_off[:-1][idx].astype(np.int64)
+        gather = (np.repeat(starts - off[:-1].astype(np.int64), lens) + np.arange(int(off[-1]))) if len(idx) else np.zeros(0, np.int64)
+        return RawBatch.from_arrays([self.ids[i] for i in idx], off, self.mz[gather], self.intensities[gather], self.precursor_mz[idx],
+                                    self.precursor_charge[idx], self.isolation_lo[idx], self.isolation_hi[idx], self.scan_start_time[idx],
+                                    self.inverse_ion_mobility[idx], self.file_id[idx])
+
     def spectrum(self, i: int) -> RawSpectrum:
         lo, hi = int(self.peak_off[i]), int(self.peak_off[i + 1])
         iso = None if np.isnan(self.isolation_lo[i]) else (float(self.isolation_lo[i]), float(self.isolation_hi[i]))

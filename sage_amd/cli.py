@@ -56,17 +56,19 @@ def scorer_params(sp: dict) -> ScorerParams:
                         annotate_matches=sp["annotate_matches"], score_type=sp["score_type"])
 
 
-def _upload(scorer, processor, raw, sp, host_preprocess):
-    """spectra of one file (RawBatch) -> resident ProcessedSpectrum batch (+ spectrum ids); None when nothing is left to search"""
+def _upload(scorer, processor, raw, sp, host_preprocess, positions=False):
+    """spectra of one file (RawBatch) -> resident ProcessedSpectrum batch (+ spectrum ids); None when nothing is left to search.
+    positions=True: also the positions in `raw` of the spectra the batch holds."""
     if host_preprocess:  # SpectrumProcessor::process on the host (C++), spectra below min_peaks dropped (runner.rs:313)
-        processed = [processor.process(raw.spectrum(i)) for i in range(raw.n)]
-        processed = [p for p in processed if len(p.masses) >= sp["min_peaks"]]
+        processed = [(i, processor.process(raw.spectrum(i))) for i in range(raw.n)]
+        processed = [(i, p) for i, p in processed if len(p.masses) >= sp["min_peaks"]]
         if not processed:
-            return None, []
-        return scorer.upload(SpectrumBatch.from_spectra(processed)), [p.id for p in processed]
+            return (None, [], np.zeros(0, np.int64)) if positions else (None, [])
+        out = scorer.upload(SpectrumBatch.from_spectra([p for _, p in processed])), [p.id for _, p in processed]
+        return out + (np.array([i for i, _ in processed], dtype=np.int64),) if positions else out
     # ... or on the device: raw peaks in, PSMs out; spectra below min_peaks stay in the batch with zero peaks
     dbatch, _ = scorer.process_upload(raw, sp["max_peaks"], sp["deisotope"], 0.0, sp["min_peaks"])
-    return dbatch, list(raw.ids)
+    return (dbatch, list(raw.ids), np.arange(raw.n, dtype=np.int64)) if positions else (dbatch, list(raw.ids))
 
 
 def prefilter_peptides(dbp, fasta_text, chunk, n_targets, sp, mzml_paths, processor, device, host_preprocess, log):
@@ -134,32 +136,36 @@ def parse_devices(spec, n_visible: int):
 
 def search_file(workers, processor, raw, sp, host_preprocess, annotate, pep_mono=None):
     """Scorer::score over every MS2 spectrum of one file (runner.rs:311-325), on all the workers' devices at once: the file's
-    spectra are cut into contiguous work-balanced shards (sharding.plan_shards: index replicated, no exchange between
-    devices), one host thread per device preprocesses, scores and — if asked — annotates its shard, and the shards' results
-    are concatenated in input order, as `collect()` does.  Returns (features[n, report], counts[n], ids, annotation | None)."""
+    spectra are cut into work-balanced shards that are contiguous in PRECURSOR MASS (sharding.plan_mass_shards: index
+    replicated, no exchange between devices, and a device walks 1 / N of the mass-sorted index instead of all of it), one host
+    thread per device preprocesses, scores and — if asked — annotates its shard, and the shards' results are merged back into
+    input order, as `collect()` leaves them.  Returns (features[n, report], counts[n], ids, annotation | None)."""
     import threading
 
-    from .sharding import estimate_work, plan_shards
-    shards = [(0, raw.n)]
+    from .sharding import estimate_work, plan_mass_shards, plan_shards, precursor_sort_mass
+    shards = [np.arange(raw.n, dtype=np.int64)]
     if len(workers) > 1:
         # work per spectrum ~ peaks x queries x candidates in the precursor window (precursor mass drifts with retention time, and
         # in an open search the window size spans orders of magnitude): sharding.estimate_work
-        weights = None if pep_mono is None else estimate_work(raw.peak_off, raw.precursor_mz, raw.precursor_charge, scorer_params(sp), pep_mono,
-                                                              raw.isolation_lo, raw.isolation_hi)
-        shards = plan_shards(raw.peak_off, len(workers), weights)
+        params = scorer_params(sp)
+        if pep_mono is None:  # (no masses to estimate windows from: contiguous ranges of the file, balanced on peak counts)
+            shards = [np.arange(b, e, dtype=np.int64) for b, e in plan_shards(raw.peak_off, len(workers))]
+        else:
+            weights = estimate_work(raw.peak_off, raw.precursor_mz, raw.precursor_charge, params, pep_mono, raw.isolation_lo, raw.isolation_hi)
+            shards = plan_mass_shards(precursor_sort_mass(raw.precursor_mz, raw.precursor_charge, params), len(workers), weights)
     results = [None] * len(workers)
     stage_ms = [(0.0, 0.0, 0.0)] * len(workers)  # per worker: preprocess + upload, score, annotate
     errors = []
 
     def work(k):
         try:
-            b, e = shards[k]
+            idx = shards[k]
             scorer = workers[k][1]
-            part = raw if (b, e) == (0, raw.n) else raw.slice(b, e)
+            part = raw if len(idx) == raw.n else raw.subset(idx)
             if part.n == 0:
                 return
             t0 = time.time()
-            dbatch, ids = _upload(scorer, processor, part, sp, host_preprocess)
+            dbatch, ids, kept = _upload(scorer, processor, part, sp, host_preprocess, positions=True)
             if dbatch is None:
                 return
             t1 = time.time()
@@ -169,9 +175,7 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate, pep_mono
             ann = scorer.annotate(dbatch, feats, counts) if annotate else None
             dbatch.close()
             stage_ms[k] = ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.time() - t2) * 1e3)
-            valid = np.arange(feats.shape[1])[None, :] < counts[:, None]
-            feats["spec_index"][valid] += np.uint32(b)  # position in the file, not in the shard
-            results[k] = (feats, counts, ids, ann)
+            results[k] = (feats, counts, ids, ann, idx[kept])  # (idx[kept]: positions in the file of the batch's spectra)
         except BaseException as exc:  # noqa: BLE001 — re-raised on the calling thread
             errors.append(exc)
 
@@ -186,19 +190,26 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate, pep_mono
     parts = [r for r in results if r is not None]
     if not parts:
         return None
+    # merge: rows in the order of their spectra's positions in the file (one part: already so)
     feats = np.concatenate([p[0] for p in parts], axis=0)
     counts = np.concatenate([p[1] for p in parts])
     ids = [i for p in parts for i in p[2]]
+    where = np.concatenate([p[4] for p in parts])
+    perm = np.argsort(where, kind="stable")
+    report = feats.shape[1]
     ann = None
-    if annotate:  # Fragments offsets are per shard: rebase them onto the concatenated arrays
-        offs, arrs, base = [], {k: [] for k in parts[0][3][1]}, 0
-        for p in parts:
-            off, arr = p[3]
-            offs.append(off[:-1] + np.uint64(base))
-            base += int(off[-1])
-            for k in arrs:
-                arrs[k].append(arr[k])
-        ann = (np.concatenate(offs + [np.array([base], dtype=np.uint64)]), {k: np.concatenate(v) for k, v in arrs.items()})
+    if annotate:  # Fragments: one run per PSM slot, offsets per part — gather the runs in the merged slot order
+        lens = np.concatenate([np.diff(p[3][0].astype(np.int64)) for p in parts])  # per slot (rows x report), concatenated parts
+        starts = np.concatenate([p[3][0][:-1].astype(np.int64) + b for p, b in
+                                 zip(parts, np.cumsum([0] + [int(p[3][0][-1]) for p in parts[:-1]]))])
+        slot = (perm[:, None] * report + np.arange(report)[None, :]).reshape(-1)
+        new_off = np.zeros(len(slot) + 1, dtype=np.uint64)
+        new_off[1:] = np.cumsum(lens[slot])
+        gather = np.repeat(starts[slot] - new_off[:-1].astype(np.int64), lens[slot]) + np.arange(int(new_off[-1]))
+        ann = (new_off, {k: np.concatenate([p[3][1][k] for p in parts])[gather] for k in parts[0][3][1]})
+    feats, counts, ids = feats[perm], counts[perm], [ids[i] for i in perm]
+    valid = np.arange(report)[None, :] < counts[:, None]
+    feats["spec_index"] = np.where(valid, np.arange(len(counts), dtype=np.uint32)[:, None], feats["spec_index"])  # row of `ids`
     search_file.last_stage_ms = tuple(max(x[i] for x in stage_ms) for i in range(3))  # (the slowest worker's, per stage)
     return feats, counts, ids, ann
 

@@ -1,7 +1,9 @@
 """The BASELINE.json configurations (recipes: SURVEY.md §8d) as data, shared by bench.py and the config-scale
 parity tests (tests/test_gpu_config_scale.py), so that what is measured and what is checked is the same workload.
 
-`spectra` is the size the configuration names; a rank of an N-GPU run scores its shard of it (bench.py).
+`spectra` is the size the configuration names; a rank of an N-GPU run scores its shard of it (bench.py).  bench.py checks ALL
+of a run's spectra against the oracle; `cpu_sample` is the prefix its work counters (SURVEY 8d's algorithmic bytes) are taken on,
+`cpu_time_sample` (default: the same) the ONE prefix the CPU baseline is timed on at every thread count.
 """
 from typing import List, Optional
 
@@ -12,13 +14,13 @@ _DB = dict(bucket_size=8192, peptide_min_mass=500.0, peptide_max_mass=5000.0, st
 CONFIGS = {
     "C2": dict(name="C2: 50k synthetic MS2 x yeast-like tryptic digest, ±10 ppm narrow search", proteins=6000,
                fasta_seed=1001, spectra=50000, spectra_seed=2001, db=dict(_DB, enzyme=_ENZ1),
-               scorer=dict(), spectra_kwargs=dict(), cpu_sample=50000,
+               scorer=dict(), spectra_kwargs=dict(), cpu_sample=50000, cpu_time_sample=32768,
                metric="spectra/sec (whole node), fragment-index search-and-score, narrow search"),
     "C3": dict(name="C3: 500k synthetic MS2 x human-like tryptic digest + 2 variable mods (M+15.9949, protein N-term "
                     "+42.0106), ±10 ppm narrow search", proteins=20400,
                fasta_seed=1002, spectra=500000, spectra_seed=2002,
                db=dict(_DB, enzyme=_ENZ1, variable_mods={"M": [15.9949], "[": [42.010565]}, max_variable_mods=2),
-               scorer=dict(), spectra_kwargs=dict(varmod_frac=0.15), cpu_sample=65536,
+               scorer=dict(), spectra_kwargs=dict(varmod_frac=0.15), cpu_sample=65536, cpu_time_sample=32768,
                metric="spectra/sec (whole node), fragment-index search-and-score, human tryptic narrow search"),
     "C4": dict(name="C4: 100k synthetic MS2 x human-like tryptic digest (2 missed cleavages, variable M+15.9949), open "
                     "search da[-500,100]", proteins=20400,

@@ -3,7 +3,8 @@
     python scripts/ab_multi.py C3 --sizes 62500,500000 --steps 30 -- base "" "newfilter" "newfilter:SAGE_HIP_WAYS=1"
 
 Each variant is `<lib>[:ENV=V,ENV=V]`; lib `base` (or empty) = sage_amd/libsage_hip.so, else sage_amd/libsage_hip_<lib>.so
-(scripts/variants.sh builds those).  The workload is generated once and handed to one child process per variant through an
+(scripts/variants.sh builds those).  A size is a spectrum count (a prefix of the run) or `m3/8` / `i3/8`: the shard rank 3 of 8 gets
+under sharding.plan_mass_shards (contiguous in precursor mass) / plan_shards (contiguous in the input).  The workload is generated once and handed to one child process per variant through an
 .npz file (a process can load only one build of the library).  Per (variant, size): wall ms per step over `steps` calls of
 score_resident, the HIP-event phase times of the last call, and an md5 of the PSM records — equal across variants or it says so."""
 import hashlib
@@ -32,7 +33,20 @@ def child(cfg_name, path, sizes, steps, h2h):
     dev = DeviceDatabase(host, 0, build_on_device=True)
     scorer = Scorer(dev, params)
     for n in sizes:
-        batch = batch_all if n >= batch_all.n else batch_all.subset(np.arange(n))
+        if isinstance(n, str):  # "m3/8" / "i3/8": the shard of rank 3 of 8 under sharding.plan_mass_shards / plan_shards
+            from sage_amd.sharding import estimate_work, plan_mass_shards, plan_shards, precursor_sort_mass
+            k_, w_ = (int(x) for x in n[1:].split("/"))
+            wts = estimate_work(batch_all.peak_off, batch_all.precursor_mz, batch_all.precursor_charge, params, host.pep_mono,
+                                batch_all.isolation_lo, batch_all.isolation_hi)
+            if n[0] == "m":
+                idx = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params), w_, wts)[k_]
+            else:
+                b_, e_ = plan_shards(batch_all.peak_off, w_, wts)[k_]
+                idx = np.arange(b_, e_)
+            batch = batch_all.subset(idx)
+            print(f"SLICE {n}: {batch.n} spectra, {wts[idx].sum() / wts.sum():.4f} of the estimated work", flush=True)
+        else:
+            batch = batch_all if n >= batch_all.n else batch_all.subset(np.arange(n))
         if os.environ.get("AB_SORT"):  # what a mass-ordered copy of the batch in HBM would buy: hand the batch over sorted already
             zc = np.where(batch.precursor_charge == 0, 2, batch.precursor_charge).astype(np.float32)
             batch = batch.subset(np.argsort((batch.precursor_mz - np.float32(1.0072764)) * zc, kind="stable"))
@@ -70,7 +84,7 @@ def child(cfg_name, path, sizes, steps, h2h):
 def main():
     args = sys.argv[1:]
     if args and args[0] == "--child":
-        child(args[1], args[2], [int(x) for x in args[3].split(",")], int(args[4]), args[5] == "1")
+        child(args[1], args[2], [int(x) if x.isdigit() else x for x in args[3].split(",")], int(args[4]), args[5] == "1")
         return
     variants = [""]
     if "--" in args:
@@ -88,7 +102,7 @@ def main():
     import bench
     from sage_amd.workloads import CONFIGS, build_host_db
     cfg = CONFIGS[cfg_name]
-    nmax = max(int(x) for x in sizes.split(","))
+    nmax = max(int(x) if x.isdigit() else cfg["spectra"] for x in sizes.split(","))
     path = f"/tmp/ab_multi_{cfg_name}_{nmax}.npz"
     if not os.path.exists(path):
         host = build_host_db(cfg, peptides_only=True)
@@ -107,7 +121,7 @@ def main():
         print(f"== {cfg_name} [{v or 'base'}]", flush=True)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg_name, path, sizes, str(steps), "1" if h2h else "0"],
                            env=env, capture_output=True, text=True, timeout=900)
-        out = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        out = [ln for ln in r.stdout.splitlines() if ln.startswith(("RESULT", "SLICE"))]
         print("\n".join(out) if out else f"FAILED rc={r.returncode}\n{r.stderr[-1500:]}", flush=True)
 
 

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #define CK(x)                                                                                       \
@@ -31,6 +32,8 @@ __global__ __launch_bounds__(64) void valu_kernel(uint32_t trips, float* sink, u
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     uint32_t u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3, u4 = u0 + 4, u5 = u0 + 5, u6 = u0 + 6, u7 = u0 + 7;
     const float k = 1.0000001f;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, s4 = s0 + 4, s5 = s0 + 5, s6 = s0 + 6, s7 = s0 + 7;
+    const uint32_t sk = trips | 1u;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (uint32_t t = 0; t < trips; t++) {
 #pragma unroll
@@ -47,6 +50,31 @@ __global__ __launch_bounds__(64) void valu_kernel(uint32_t trips, float* sink, u
                 asm volatile("v_lshl_or_b32 %0, %0, 1, %8\n\tv_lshl_or_b32 %1, %1, 1, %8\n\tv_lshl_or_b32 %2, %2, 1, %8\n\tv_lshl_or_b32 %3, %3, 1, %8\n\t"
                              "v_lshl_or_b32 %4, %4, 1, %8\n\tv_lshl_or_b32 %5, %5, 1, %8\n\tv_lshl_or_b32 %6, %6, 1, %8\n\tv_lshl_or_b32 %7, %7, 1, %8"
                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(u0 ^ 5u));
+            } else if (OP == 4) {  // s_add_u32: the scalar ALU (ONE per compute unit, shared by its four SIMDs)
+                asm volatile("s_add_u32 %0, %0, %8\n\ts_add_u32 %1, %1, %8\n\ts_add_u32 %2, %2, %8\n\ts_add_u32 %3, %3, %8\n\t"
+                             "s_add_u32 %4, %4, %8\n\ts_add_u32 %5, %5, %8\n\ts_add_u32 %6, %6, %8\n\ts_add_u32 %7, %7, %8"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "s"(sk) : "scc");
+            } else if (OP == 5) {  // v_readlane_b32: a VALU-issued instruction with a scalar destination (what a scalar-register spill costs)
+                asm volatile("v_readlane_b32 %0, %8, 1\n\tv_readlane_b32 %1, %8, 2\n\tv_readlane_b32 %2, %8, 3\n\tv_readlane_b32 %3, %8, 4\n\t"
+                             "v_readlane_b32 %4, %8, 5\n\tv_readlane_b32 %5, %8, 6\n\tv_readlane_b32 %6, %8, 7\n\tv_readlane_b32 %7, %8, 8"
+                             : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) : "v"(u0));
+            } else if (OP == 6) {  // v_writelane_b32
+                asm volatile("v_writelane_b32 %0, %8, 1\n\tv_writelane_b32 %1, %8, 2\n\tv_writelane_b32 %2, %8, 3\n\tv_writelane_b32 %3, %8, 4\n\t"
+                             "v_writelane_b32 %4, %8, 5\n\tv_writelane_b32 %5, %8, 6\n\tv_writelane_b32 %6, %8, 7\n\tv_writelane_b32 %7, %8, 8"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "s"(sk));
+            } else if (OP == 7) {  // s_load_dword from the kernarg segment (an L1-scalar-cache hit), eight in flight, one wait
+                asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x4\n\ts_load_dword %2, %8, 0x8\n\ts_load_dword %3, %8, 0xc\n\t"
+                             "s_load_dword %4, %8, 0x10\n\ts_load_dword %5, %8, 0x14\n\ts_load_dword %6, %8, 0x18\n\ts_load_dword %7, %8, 0x1c\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) : "s"(cycles) : "memory");
+            } else if (OP >= 10) {  // the rescoring kernel's MIX: eight v_fma_f32 + (OP - 10) s_add_u32 per group (64 : 0 / 16 / 32 / 48 / 64)
+                asm volatile("v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
+                             "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+                if (OP - 10 >= 2) asm volatile("s_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, %2" : "+s"(s0), "+s"(s1) : "s"(sk) : "scc");
+                if (OP - 10 >= 4) asm volatile("s_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, %2" : "+s"(s2), "+s"(s3) : "s"(sk) : "scc");
+                if (OP - 10 >= 6) asm volatile("s_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, %2" : "+s"(s4), "+s"(s5) : "s"(sk) : "scc");
+                if (OP - 10 >= 8) asm volatile("s_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, %2" : "+s"(s6), "+s"(s7) : "s"(sk) : "scc");
             } else {  // v_fma_f64 (two registers per operand: four accumulators, counted as eight instructions of half the unroll)
                 double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
                 const double kd = 1.0000001;
@@ -58,7 +86,7 @@ __global__ __launch_bounds__(64) void valu_kernel(uint32_t trips, float* sink, u
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) + (float)(s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7);
     if (s == 1.2345e-30f) sink[0] = s;
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
@@ -76,17 +104,22 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const uint32_t trips = 20000;
-    const char* names[4] = {"v_add_f32", "v_fma_f32", "v_lshl_or_b32", "v_fma_f64"};
-    std::printf("| instruction | waves/SIMD | instr per wave | wave cycles (s_memtime, median) | cycles per instr per SIMD (s_memtime) | wall ms | "
-                "cycles per instr at clockRate (wall) |\n|---|---|---|---|---|---|---|\n");
-    for (int op = 0; op < 4; op++)
-        for (int w = 1; w <= 8; w *= 2) {
+    struct Op { const char* name; int id; double vector_instr, scalar_instr; };
+    const Op ops[] = {{"v_add_f32", 0, 64, 0}, {"v_fma_f32", 1, 64, 0}, {"v_lshl_or_b32", 2, 64, 0}, {"v_fma_f64", 3, 64, 0},
+                      {"s_add_u32", 4, 0, 64}, {"v_readlane_b32", 5, 64, 0}, {"v_writelane_b32", 6, 64, 0}, {"s_load_dword (8 in flight + wait)", 7, 0, 64},
+                      {"mix 64 v_fma_f32 + 0 s_add_u32", 10, 64, 0}, {"mix 64 v_fma_f32 + 16 s_add_u32", 12, 64, 16},
+                      {"mix 64 v_fma_f32 + 32 s_add_u32", 14, 64, 32}, {"mix 64 v_fma_f32 + 48 s_add_u32", 16, 64, 48},
+                      {"mix 64 v_fma_f32 + 64 s_add_u32", 18, 64, 64}};
+    std::printf("| instruction | waves/SIMD | instr per wave (vector + scalar) | wave cycles (s_memtime, median) | SIMD cycles per 64-instruction "
+                "group per wave (s_memtime) | wall ms | CU cycles per group at clockRate (wall), all four SIMDs busy |\n|---|---|---|---|---|---|---|\n");
+    for (const Op& op : ops)
+        for (int w : {1, 2, 4, 5, 8}) {
             const int blocks = n_simd * w;  // single-wavefront workgroups: the dispatcher deals them round-robin over CUs and SIMDs
             auto launch = [&]() {
-                switch (op) {
-                    case 0: hipLaunchKernelGGL(valu_kernel<0>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
-                    case 1: hipLaunchKernelGGL(valu_kernel<1>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
-                    case 2: hipLaunchKernelGGL(valu_kernel<2>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
+                switch (op.id) {
+#define CASE(N) case N: hipLaunchKernelGGL(valu_kernel<N>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
+                    CASE(0) CASE(1) CASE(2) CASE(4) CASE(5) CASE(6) CASE(7) CASE(10) CASE(12) CASE(14) CASE(16) CASE(18)
+#undef CASE
                     default: hipLaunchKernelGGL(valu_kernel<3>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
                 }
             };
@@ -101,10 +134,10 @@ int main() {
             std::vector<unsigned long long> h(blocks);
             CK(hipMemcpy(h.data(), cyc, (size_t)blocks * 8, hipMemcpyDeviceToHost));
             std::nth_element(h.begin(), h.begin() + blocks / 2, h.end());
-            const double n_instr = (double)trips * UNROLL;
+            const double groups = (double)trips * UNROLL / 64.0;  // one group = 64 vector and / or the row's scalar instructions
             const double wave_cycles = (double)h[blocks / 2];
-            std::printf("| %s | %d | %.0f | %.0f | %.2f | %.3f | %.2f |\n", names[op], w, n_instr, wave_cycles, wave_cycles / (n_instr * w), ms,
-                        ms * 1e-3 * prop.clockRate * 1e3 / (n_instr * w));
+            std::printf("| %s | %d | %.0f + %.0f | %.0f | %.1f | %.3f | %.1f |\n", op.name, w, groups * op.vector_instr, groups * op.scalar_instr,
+                        wave_cycles, wave_cycles / (groups * w), ms, ms * 1e-3 * prop.clockRate * 1e3 / (groups * w));
         }
     return 0;
 }

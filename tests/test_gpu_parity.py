@@ -221,6 +221,30 @@ def test_isotope_errors_and_fragment_charge(small_world):
     small_world.check(ScorerParams(fragment_tol=Tolerance("pct", -0.001, 0.001)), "frag pct tol")
 
 
+@pytest.mark.parametrize("variant", ["stream", "probe"])
+def test_asymmetric_and_one_sided_tolerances(small_world, monkeypatch, variant):
+    """Tolerance::bounds takes any (lo, hi) (mass.rs:21-35): windows that lean to one side of the centre or lie entirely beside
+    it — on the fragment side (the position-table cells of both matching variants, the peak bitmap's reach max(|lo|, |hi|), the
+    general branch of the symmetric-ppm shortcut) and on the precursor side (the window query through pep_lut)."""
+    monkeypatch.setenv("SAGE_HIP_NARROW", variant)
+    w = small_world
+    for ftol in (Tolerance("ppm", -20.0, 5.0), Tolerance("ppm", 5.0, 20.0), Tolerance("da", 0.01, 0.3), Tolerance("da", -0.3, -0.01),
+                 Tolerance("pct", -0.002, 0.0005)):
+        n, t = w.check(ScorerParams(fragment_tol=ftol, min_matched_peaks=2), f"{variant}: fragment_tol {ftol}")
+        assert n > (200 if ftol.lo < 0.0 < ftol.hi else 0), (str(ftol), n)  # (beside the centre: chance matches only, 3 ppm noise)
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("ppm", -50.0, 10.0)), f"{variant}: precursor_tol ppm[-50, 10]")
+    assert n > 300
+    w.check(ScorerParams(precursor_tol=Tolerance("ppm", 5.0, 60.0), fragment_tol=Tolerance("ppm", -20.0, 5.0), report_psms=3),
+            f"{variant}: both one-sided / asymmetric, three PSMs")
+    w.check(ScorerParams(precursor_tol=Tolerance("da", -4.0, 0.5), fragment_tol=Tolerance("ppm", 5.0, 20.0), chimera=True, report_psms=2,
+                         max_fragment_charge=3), f"{variant}: da[-4, 0.5], chimera")
+    # large windows (the tiled kernels' own table lookups) with an asymmetric fragment tolerance
+    sub = w.batch.subset(np.arange(0, w.batch.n, 6))
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -300.0, 100.0), fragment_tol=Tolerance("ppm", -20.0, 5.0)),
+                   f"{variant}: open da[-300, 100], fragments ppm[-20, 5]", batch=sub)
+    assert t["n_wide"] > 0
+
+
 def test_unknown_and_overridden_precursor_charge(small_world):
     b = small_world.batch
     unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8),

@@ -18,14 +18,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, plan="input"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     import oracle_lib
     from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch, SpectrumProcessor
-    from sage_amd.sharding import gather_features, plan_shards
+    from sage_amd.sharding import (estimate_work, gather_features, gather_features_by_index, plan_mass_shards, plan_shards,
+                                   precursor_sort_mass)
     from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
     dist.init_process_group("gloo", rank=rank, world_size=world)
     host = DatabaseParameters(static_mods={"C": 57.0215}).build(synthetic_fasta(60, seed=3))
@@ -33,10 +34,17 @@ def _worker(rank, world, port, q):
     batch = SpectrumBatch.from_spectra([sp.process(r) for r in synthetic_spectra(host, 101, seed=4)])
     orc = oracle_lib.OracleDb.from_product(host)
     params = ScorerParams(report_psms=2)
-    b, e = plan_shards(batch.peak_off, world)[rank]
-    shard = batch.subset(np.arange(b, e))
-    f, c, _, _ = orc.score(params, shard, threads=1)
-    gf, gc = gather_features(f, c, b)
+    if plan == "mass":  # shards contiguous in precursor mass, balanced by estimate_work; the gather is a permutation
+        w = estimate_work(batch.peak_off, batch.precursor_mz, batch.precursor_charge, params, host.pep_mono)
+        idx = plan_mass_shards(precursor_sort_mass(batch.precursor_mz, batch.precursor_charge, params), world, w)[rank]
+        b, e = int(idx.min()) if len(idx) else 0, int(idx.max()) + 1 if len(idx) else 0
+        f, c, _, _ = orc.score(params, batch.subset(idx), threads=1)
+        gf, gc = gather_features_by_index(f, c, idx, batch.n)
+    else:
+        b, e = plan_shards(batch.peak_off, world)[rank]
+        shard = batch.subset(np.arange(b, e))
+        f, c, _, _ = orc.score(params, shard, threads=1)
+        gf, gc = gather_features(f, c, b)
     if rank == 0:
         ff, fc, _, _ = orc.score(params, batch, threads=1)
         q.put((np.array_equal(gc, fc), gf.tobytes() == ff.tobytes(), int(gc.sum()), (b, e)))
@@ -44,15 +52,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_shard_and_gather_preserves_input_order(world):
-    """world_size 2 and 8 (the node the path is sharded over): every rank scores its plan_shards range, the gathered records
-    equal a single pass over the whole batch byte for byte."""
+@pytest.mark.parametrize("world,plan", [(2, "input"), (8, "input"), (2, "mass"), (8, "mass")])
+def test_shard_and_gather_preserves_input_order(world, plan):
+    """world_size 2 and 8 (the node the path is sharded over): every rank scores its shard — a plan_shards range of the input or
+    a plan_mass_shards slice of the precursor-mass axis — and the gathered records equal a single pass over the whole batch byte
+    for byte, in input order."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, plan)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=300)
@@ -114,3 +123,29 @@ def test_shards_weighted_by_window_size():
     # unknown charges: one query per charge of the configured range
     w2 = estimate_work(off, mz, np.zeros(n, np.uint8), ScorerParams(min_precursor_charge=2, max_precursor_charge=4), pep_mono)
     assert np.all(w2 >= (peaks + 1.0) * 3 * 64.0)
+
+
+def test_plan_mass_shards_properties():
+    """A partition of the input into `world` slices of the mass axis with equal estimated work: every spectrum in exactly one shard,
+    shard r's masses all <= shard r + 1's, ascending input positions inside a shard, NaN masses (no precursor) at the heavy end."""
+    from sage_amd.sharding import plan_mass_shards
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 5000):
+            m = rng.uniform(500.0, 5000.0, n)
+            if n > 10:
+                m[::97] = np.nan
+                m[5:9] = m[4]  # equal masses: input position breaks the tie
+            w = rng.uniform(1.0, 50.0, n) * (m if n else 1.0) if n <= 10 else rng.uniform(1.0, 50.0, n)
+            shards = plan_mass_shards(m, world, w)
+            assert len(shards) == world
+            assert sorted(np.concatenate(shards).tolist()) == list(range(n))
+            for sh in shards:
+                assert np.all(np.diff(sh) > 0)
+            key = np.where(np.isnan(m), np.inf, m)
+            tops = [key[sh].max() for sh in shards if len(sh)]
+            bots = [key[sh].min() for sh in shards if len(sh)]
+            assert all(t <= b for t, b in zip(tops, bots[1:]))
+            if n == 5000 and world > 1:
+                load = np.array([w[sh].sum() for sh in shards])
+                assert load.max() / load.mean() < 1.02
