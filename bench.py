@@ -231,23 +231,24 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None, span=None):
 
 def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
     """Strong scaling, --shard-by mass: every rank has generated a contiguous span of THE run; the ranks agree on
-    sharding.plan_mass_shards over the whole run (per-spectrum sort mass and work estimate exchanged: 16 bytes per spectrum) and
+    sharding.plan_mass_shards over the whole run (per-spectrum sort mass exchanged: 8 bytes per spectrum) and
     hand each other the spectra through node-local files (the ranks of one node — the driver's contract; workload distribution
     before the timed region, not a data-path collective: a search process that reads the mzML itself, cli.py --devices, cuts its
     in-memory spectrum list instead).  Returns (this rank's shard, the global input positions of its spectra, spectra in the run)."""
     import numpy as np
 
     from sage_amd.api import SpectrumBatch
-    from sage_amd.sharding import estimate_work, plan_mass_shards, precursor_sort_mass
-    wts = estimate_work(batch.peak_off, batch.precursor_mz, batch.precursor_charge, params, pep_mono, batch.isolation_lo, batch.isolation_hi)
+    from sage_amd.sharding import plan_mass_shards, precursor_sort_mass
     mass = precursor_sort_mass(batch.precursor_mz, batch.precursor_charge, params)
     parts = [None] * world
-    dist.all_gather_object(parts, (rank, mass, wts))
+    dist.all_gather_object(parts, (rank, mass))
     parts.sort(key=lambda p: p[0])
     sizes = [len(p[1]) for p in parts]
     base = int(sum(sizes[:rank]))
     n_total = int(sum(sizes))
-    plan = plan_mass_shards(np.concatenate([p[1] for p in parts]), world, np.concatenate([p[2] for p in parts]))
+    # (equal spectrum counts per block: a rank takes every world-th block of the mass axis, so its blocks sample every mass and
+    # the shards balance without a cost model — sharding.plan_mass_shards)
+    plan = plan_mass_shards(np.concatenate([p[1] for p in parts]), world)
     xdir = os.path.join(tempfile.gettempdir(), f"sage_bench_xchg_{os.environ.get('MASTER_PORT', '0')}")
     os.makedirs(xdir, exist_ok=True)
     for j in range(world):
@@ -278,6 +279,37 @@ def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
     index = np.concatenate([ix for ix, _ in got]).astype(np.int64)
     assert np.array_equal(index, plan[rank]), "the exchanged shard is not the planned one"
     return shard, index, n_total
+
+
+# cycles of a SIMD per wave64 instruction at 5 wavefronts per SIMD with all four SIMDs of every compute unit busy — the rescoring
+# kernel's occupancy — from scripts/calib_valu.hip on this hardware (profiles/r05_valu_calibration.md, s_memtime column): a vector
+# instruction 2.39 (v_fma_f32; v_add_f32 1.58, v_lshl_or_b32 2.83, v_fma_f64 5.0), and what a scalar instruction ADDS to a
+# stream of vector ones: (193.0 - 152.8) / 48 = 0.84 (the mix of 64 v_fma_f32 + 48 s_add_u32 against 64 v_fma_f32 alone; alone
+# an s_add_u32 takes 2.6).
+CYCLES_PER_VALU, CYCLES_PER_SALU_ADDED, N_SIMDS = 2.39, 0.84, 1024
+
+
+def issue_slot_model(issue, dom):
+    """The dominant kernel's instruction-issue fraction: (VALU x 2.39 + SALU x 0.84 cycles) x spectra over (the kernel's GPU-active
+    cycles, GRBM_GUI_ACTIVE, x 1024 SIMDs).  One wavefront scores one spectrum, so the counters divide by the spectra of the
+    profiled run.  A model — the vector mix is priced as v_fma_f32 — but calibrated on this chip, and the denominator is measured."""
+    if not issue or not issue.get("by_name"):
+        return None
+    cands = {k: v for k, v in issue["by_name"].items() if k.startswith("rescore_kernel" if dom == "rescore" else ("prelim_kernel", "tile_count"))
+             and all(c in v for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"))}
+    if not cands:
+        return None
+    name = max(cands, key=lambda k: cands[k]["GRBM_GUI_ACTIVE"])
+    v = cands[name]
+    n = issue["n"]
+    valu, salu = v["SQ_INSTS_VALU"] / n, v["SQ_INSTS_SALU"] / n
+    need = valu * CYCLES_PER_VALU + salu * CYCLES_PER_SALU_ADDED
+    have = v["GRBM_GUI_ACTIVE"] * N_SIMDS / n
+    return {"kernel": name, "valu_per_spectrum": valu, "salu_per_spectrum": salu, "cycles_per_valu": CYCLES_PER_VALU,
+            "cycles_per_salu_added": CYCLES_PER_SALU_ADDED, "issue_cycles_per_spectrum": need,
+            "simd_cycles_available_per_spectrum": have, "frac_issue_slots": need / have if have else None,
+            "source": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE in this run over {n} spectra; cycles per instruction: "
+                      "profiles/r05_valu_calibration.md (5 wavefronts per SIMD)"}
 
 
 def gpu_algorithm_bytes(dev, params, batch, n_sample=8192):
@@ -322,9 +354,9 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
     tmp = tempfile.mkdtemp(prefix="sage_pmc_", dir="/tmp")
     res = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = ["rocprofv3", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config",
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE"):
+            d = os.path.join(tmp, ctr.split()[0])
+            cmd = ["rocprofv3", "--pmc", *ctr.split(), "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config",
                    args.config, "--spectra", str(n_spec), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
                    "--no-extras"] + (["--proteins", str(args.proteins)] if args.proteins else [])
             # (SAGE_HIP_WAYS=1: a step of this size would run as two parts — two dispatches per kernel, each over half the
@@ -339,14 +371,18 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
             if not dbs:
                 return None, "rocprofv3 wrote no database"
             con = sqlite3.connect(dbs[0])
-            for name, mx in con.execute("select kernel_name, max(value) from counters_collection where counter_name = ? "
-                                        "group by kernel_name", (ctr,)):
+            for name, cname, mx in con.execute("select kernel_name, counter_name, max(value) from counters_collection "
+                                               "group by kernel_name, counter_name"):
                 short = name.replace("sagehip::(anonymous namespace)::", "").replace("void ", "")
                 key = "prelim" if (short.startswith("prelim_") or short.startswith("tile_")) else \
                     ("rescore" if short.startswith("rescore") else None)
-                if key:  # the full-pass dispatch is the largest one of each kernel (the retry pass is small)
-                    res.setdefault(key, {}).setdefault(ctr, 0.0)
-                    res[key][ctr] += mx
+                if key and cname in ctr.split():  # the full-pass dispatch is the largest one of each kernel (the retry pass is small)
+                    res.setdefault(key, {}).setdefault(cname, 0.0)
+                    res[key][cname] += mx
+                    if cname == "GRBM_GUI_ACTIVE":  # per kernel NAME as well: the issue figures belong to the one dominant kernel
+                        res.setdefault("by_name", {}).setdefault(short.split("(")[0], {})
+                    if cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+                        res.setdefault("by_name", {}).setdefault(short.split("(")[0], {})[cname] = mx
             res["n"] = n_scored
     except subprocess.TimeoutExpired as e:
         tail = (e.stderr or b"")[-300:] if isinstance(e.stderr, (bytes, bytearray)) else str(e.stderr or "")[-300:]
@@ -361,6 +397,7 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
             out[k] = (2.0 * res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024.0 / res["n"]
     if not out:
         return None, "no search kernel found in the counter tables"
+    measure_traffic.issue = {"n": res["n"], "by_name": res.get("by_name", {})}
     return out, f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {res['n']} spectra, " \
                 "(2*FETCH_SIZE + WRITE_SIZE) KiB, factor 2 per profiles/r02_fetch_calibration.md"
 
@@ -448,7 +485,7 @@ def main():
             wts = estimate_work(batch_all.peak_off, batch_all.precursor_mz, batch_all.precursor_charge, params_, host.pep_mono,
                                 batch_all.isolation_lo, batch_all.isolation_hi)
             if args.shard_by == "mass":
-                idx_ = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params_), n_, wts)[k_]
+                idx_ = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params_), n_)[k_]
             else:
                 b_, e_ = plan_shards(batch_all.peak_off, n_, wts)[k_]
                 idx_ = np.arange(b_, e_)
@@ -778,6 +815,7 @@ def main():
                     gab = gpu_algorithm_bytes(dev, params, batch)
                 except Exception as e:  # noqa: BLE001 — a profiling extra must not take the line down
                     gab = {"error": repr(e)}
+            issue = issue_slot_model(getattr(measure_traffic, "issue", None), dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                     # the second fraction: bytes that actually crossed the HBM interface (PMC) over the same kernel time
@@ -787,6 +825,9 @@ def main():
                     # the third figure: what the GPU algorithm itself requests (table words, index cells, candidates, ions)
                     "gpu_algorithm_bytes_per_spectrum": gab,
                     "frac_gpu_algorithm": None if not gab or "error" in gab else gab[dom] * batch.n / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    # the fourth figure, and for an issue-bound kernel the one that IS its roofline (VERDICT r04 task 7): the
+                    # instruction-issue slots the kernel's wavefronts take of the slots its SIMDs had (issue_slot_model)
+                    "issue": issue, "frac_issue_slots": None if not issue else issue["frac_issue_slots"],
                     "kernel_ms": {"prelim": pm, "rescore": rm, "of_which_exact_retry_pass": retry_pass_ms},
                     # both phases, each against the HBM roofline with the same three byte counts (the top-level fields repeat
                     # the entry of the phase that takes longer)
@@ -797,9 +838,13 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": "rescore_kernel is bound by vector-ALU issue at 5 wavefronts per SIMD, not by HBM (instruction counts: "
-                                "profiles/r04_C3_pmc_sq_*.txt; the calibrated issue rate: profiles/r04_valu_calibration.md; where the cycles "
-                                "go phase by phase: profiles/r04_C3_phase_clocks.txt) — its byte fractions are small by construction. "
+                    "limiters": "rescore_kernel is bound by instruction ISSUE at 5 wavefronts per SIMD, not by HBM: `frac_issue_slots` "
+                                "(vector + scalar instructions per spectrum from a live rocprofv3 --pmc pass, priced with the cycles per "
+                                "instruction of profiles/r05_valu_calibration.md, over the cycles its SIMDs had) is its roofline fraction; "
+                                "its byte fractions are small by construction.  The whole path's SURVEY 8(d) bytes over the step time "
+                                "(`whole_path_achieved_GBs`) approach the HBM SPEC peak — 96 % of those bytes are the reference's binary-search "
+                                "probes, which a table-driven kernel never issues: that figure is an algorithmic-work rate, NOT bandwidth, "
+                                "and must not be read against 8 TB/s. "
                                 "prelim_kernel follows its HBM LINE traffic (by_kernel.prelim.frac_traffic: ~0.75 of the 8 TB/s peak, ~0.95 "
                                 "of the 6.29 TB/s MI355X_MICROARCH.md calls achievable): a 4-byte table word and a 16-byte index cell each "
                                 "cost a 128-byte line, so it moves three times the bytes it asks for; its `frac` above 1 only says that "

@@ -151,8 +151,12 @@ def search_file(workers, processor, raw, sp, host_preprocess, annotate, pep_mono
         if pep_mono is None:  # (no masses to estimate windows from: contiguous ranges of the file, balanced on peak counts)
             shards = [np.arange(b, e, dtype=np.int64) for b, e in plan_shards(raw.peak_off, len(workers))]
         else:
+            # eight blocks of the mass axis per device, every len(workers)-th block each: the window sizes of an open search span
+            # orders of magnitude ALONG the mass axis, so within a block the estimate's weights still matter
             weights = estimate_work(raw.peak_off, raw.precursor_mz, raw.precursor_charge, params, pep_mono, raw.isolation_lo, raw.isolation_hi)
-            shards = plan_mass_shards(precursor_sort_mass(raw.precursor_mz, raw.precursor_charge, params), len(workers), weights)
+            narrow = not params.wide_window and params.precursor_tol.kind != "da"
+            shards = plan_mass_shards(precursor_sort_mass(raw.precursor_mz, raw.precursor_charge, params), len(workers),
+                                      None if narrow else weights)
     results = [None] * len(workers)
     stage_ms = [(0.0, 0.0, 0.0)] * len(workers)  # per worker: preprocess + upload, score, annotate
     errors = []

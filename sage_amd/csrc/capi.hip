@@ -1,6 +1,7 @@
 // capi.hip — the C ABI declared in include/sage_hip.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstring>
@@ -204,6 +205,7 @@ struct SageScorer {
                                      // -1 % wall at 500 000 spectra, -6 % at 62 500, nothing more with three or four
     hipStream_t way_stream[3] = {nullptr, nullptr, nullptr};
     Event way_fork, way_join[3], way_begin, way_end;
+    DevBuf<uint32_t> win_max;   // exact_window_check's result word
     DevBuf<double> lnfact;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
@@ -537,11 +539,11 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         uint32_t* lut_p = nullptr;
         if (be == hipSuccess)
             be = (hipError_t)build_tile_copy_on_device(d->pm_frag.p, nf, tile_shift, (uint32_t)n_tiles, d_tile_off.p, lut_scale,
-                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr, TM_LUT_TRANSPOSED);
+                                                       d->tm_frag.p, &lut_p, &lut_stride, nullptr, TM_LUT_LAYOUT);
         if (be != hipSuccess)
             return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
         d->tm_lut.p = lut_p;
-        d->tm_lut.n = (size_t)n_tiles * lut_stride;
+        d->tm_lut.n = (size_t)tm_lut_rows((uint32_t)n_tiles) * lut_stride;
         host_pm_off.swap(pm_off);
         HIP_TRY(d->pep_info.upload(info.data(), np));
     } else {
@@ -587,7 +589,8 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
             if (tm[i].fragment_mz > max_mz && std::isfinite(tm[i].fragment_mz)) max_mz = tm[i].fragment_mz;
         lut_stride = (uint32_t)std::min<double>(std::ceil((double)max_mz * lut_scale) + 3.0, 64.0e6);
         if ((double)n_tiles * lut_stride > 4.0e9) return fail(SAGE_HIP_ERR_UNSUPPORTED, "tile position table larger than 16 GB");
-        std::vector<uint32_t> lut((size_t)n_tiles * lut_stride);
+        // (rows beyond the last tile — padding of the quad layout — are empty tiles at the end of the array)
+        std::vector<uint32_t> lut((size_t)tm_lut_rows((uint32_t)n_tiles) * lut_stride, (uint32_t)tile_off[n_tiles]);
         parallel_for(n_tiles, 1, [&](size_t tb, size_t te, unsigned) {
             for (size_t t = tb; t < te; t++) {
                 uint64_t pos = tile_off[t];
@@ -867,6 +870,35 @@ static void* device_view(const void* p) {
     }
     return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
 }
+// ... remembered per thread for the last few pointers asked about: a caller that scores batch after batch into the same result
+// arrays (every step of a resident loop) otherwise pays two driver queries (~5 us each) in front of the step's first launch.
+// (Keyed by address: a buffer that is freed and another mapped at the same address would have to hit the same slot within the
+// same thread — sage_hip_host_free forgets the entry.)
+struct ViewCache {
+    const void* host[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned next = 0;
+};
+static thread_local ViewCache g_views;
+static std::atomic<uint64_t> g_view_epoch{0};  // bumped by sage_hip_host_free: every thread's cache is stale
+static thread_local uint64_t g_view_seen = 0;
+static void* device_view_cached(const void* p) {
+    if (!p) return nullptr;
+    const uint64_t ep = g_view_epoch.load(std::memory_order_acquire);
+    if (ep != g_view_seen) {
+        g_views = ViewCache{};
+        g_view_seen = ep;
+    }
+    for (int i = 0; i < 4; i++)
+        if (g_views.host[i] == p) return g_views.dev[i];
+    void* d = device_view(p);
+    if (d) {  // (only page-locked memory is remembered: a pageable array may be page-locked later)
+        g_views.host[g_views.next & 3u] = p;
+        g_views.dev[g_views.next & 3u] = d;
+        g_views.next++;
+    }
+    return d;
+}
 static bool is_page_locked(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t at;
@@ -919,7 +951,13 @@ static WindowEstimate choose_probe(const SageScorer* s, uint32_t n, const float*
     }
     const double mean_window = cnt ? sum / cnt : 0.0;
     WindowEstimate e;
-    e.probe = mean_window > 96.0 ? 1u : 0u;
+    // The matching variant: table lookups per (peak, fragment charge) window ("probe") unless the windows hold next to nothing.
+    // Round 5 re-measured the threshold (round 2 had put it at 96 candidates, before the small tiles, the position table of the
+    // peptide masses and the DPP scans made the probe variant 2-3x faster): C2, mean window ~25 candidates — preliminary kernel 0.82 ms
+    // streaming against 0.33 ms probing per 50 000 spectra (the step 0.70 -> 0.50 ms); the heaviest 1/32 of C3 (mean window 67
+    // candidates of ~80 fragments each) 0.79 against 0.12 ms per 15 600 spectra (profiles/r05_shard_sizes.txt).  Streaming walks
+    // candidates x fragments entries with a binary search over the windows each; it can only win where that product is tiny.
+    e.probe = mean_window > 4.0 ? 1u : 0u;
     if (const char* v = getenv("SAGE_HIP_NARROW")) e.probe = std::string(v) == "probe" ? 1u : std::string(v) == "stream" ? 0u : e.probe;
     // (a quarter of headroom between the widest sampled window and the capacity: isotope errors shift the centre, the sample is thin)
     e.maybe_wide = widest + widest / 4 + 2 > s->dev.wcap;
@@ -1088,6 +1126,25 @@ static int check_batch_args(const SageSpectrumBatch* b) {
     return SAGE_HIP_OK;
 }
 
+// A resident batch knows EXACTLY whether any of its precursor windows exceeds the narrow kernel's slot capacity: one small
+// kernel over its spectra behind the upload (window_max_kernel: the partition points of IndexedDatabase::query per query),
+// four bytes back with the upload's synchronisation.  The sample-based estimate (choose_probe) said "maybe" for any batch that
+// is dense where peptides are dense — e.g. the shard of a rank that owns the light end of the mass axis — and a "maybe" costs the
+// step ten empty launches, the second part's overlap, and a longer host turn-around (round 5: 0.75 against 0.69 ms per 62 500
+// C3 spectra).  The streaming pipeline keeps the estimate (it decides before the spectra are on the device).
+static int exact_window_check(SageScorer* s, SageDeviceBatch* d, hipStream_t st) {
+    if (getenv("SAGE_HIP_ASSUME_NARROW") || d->n == 0) return SAGE_HIP_OK;  // (tests force the estimate's answer)
+    HIP_TRY(s->win_max.reserve(1));
+    HIP_TRY(hipMemsetAsync(s->win_max.p, 0, 4, st));
+    launch_window_max(s->dev, d->view, s->db->view.pep_mono, s->db->view.np, s->win_max.p, st);
+    HIP_TRY(hipGetLastError());
+    uint32_t widest = 0;
+    HIP_TRY(hipMemcpyAsync(&widest, s->win_max.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    d->maybe_wide = widest > s->dev.wcap;
+    return SAGE_HIP_OK;
+}
+
 int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceBatch** out) {
     if (!s || !b || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     int rc = check_batch_args(b);
@@ -1102,6 +1159,8 @@ int sage_hip_batch_upload(SageScorer* s, const SageSpectrumBatch* b, SageDeviceB
     rc = stage_and_upload(s, d.get(), b, 0, n, is_page_locked(b->masses) && is_page_locked(b->intensities), est, s->up_stream);
     if (rc != SAGE_HIP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s->up_stream));
+    rc = exact_window_check(s, d.get(), s->up_stream);
+    if (rc != SAGE_HIP_OK) return rc;
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -1266,6 +1325,7 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     v.pcap = pcap;
     v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
     if (int rc = check_match_counters(s, v.fzcap); rc != SAGE_HIP_OK) return rc;
+    if (int rc = exact_window_check(s, d.get(), s->stream); rc != SAGE_HIP_OK) return rc;
     *out = d.release();
     return SAGE_HIP_OK;
 }
@@ -1315,6 +1375,7 @@ static int ensure_work(SageScorer* s, uint32_t n, int lane, bool wide, hipStream
         // (no launch has the epoch 0.  On the stream of the kernels that read it: the scorer's streams do not synchronise with
         // the null stream, and a plain hipMemset could land after a producer's epoch store)
         HIP_TRY(hipMemsetAsync(w.ready.p, 0, (size_t)w.ready.n * 4, st));
+        HIP_TRY(hipStreamSynchronize(st));  // (growth is rare; the parts of a resident step start on their own streams without waiting for this one)
         w.epoch = 0;
         w.cap_n = n;
     }
@@ -1484,9 +1545,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
             launch_prelim_tile(s->db->view, sc2, v2, w2, st, &side);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(o.ev[3].e, st));
-        if (wide)
+        if (wide) {  // (without the large-window kernels the retry pass is ONE launch: no marker inside it)
+            HIP_TRY(hipEventRecord(o.ev[3].e, st));
             launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
+        }
         HIP_TRY(hipEventRecord(o.ev[4].e, st));
     }
     HIP_TRY(hipGetLastError());
@@ -1510,9 +1572,11 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
     float a = 0, r = 0, a2 = 0, r2 = 0;
     HIP_TRY(hipEventElapsedTime(&a, o.ev[0].e, o.ev[1].e));
     HIP_TRY(hipEventElapsedTime(&r, o.ev[1].e, o.ev[2].e));
-    if (o.two_pass) {
+    if (o.two_pass && o.wide_launched) {
         HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[3].e));
         HIP_TRY(hipEventElapsedTime(&r2, o.ev[3].e, o.ev[4].e));
+    } else if (o.two_pass) {
+        HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[4].e));
     }
     SageTiming& t = s->timing;
     t.prelim_ms += a + a2;
@@ -1560,7 +1624,7 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
     HIP_TRY(hipSetDevice(s->db->device));
     reset_timing(s);
     OutSet& o = s->outs[0];
-    SageFeature* direct = s->zero_copy && b->n ? (SageFeature*)device_view(out) : nullptr;
+    SageFeature* direct = s->zero_copy && b->n ? (SageFeature*)device_view_cached(out) : nullptr;
     const size_t rec_bytes = (size_t)b->n * s->params.report_psms * sizeof(SageFeature);
     for (int attempt = 0;; attempt++) {
         // A narrow-search batch in `ways` parts of the launch schedule (consecutive precursor masses), each on its own stream:
@@ -1578,48 +1642,55 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         rc = ensure_out(s, o, b->n, direct == nullptr);
         if (rc != SAGE_HIP_OK) return rc;
         SageFeature* const rec = direct ? direct : o.features.p;
-        uint32_t* const count_view = s->zero_copy && b->n ? (uint32_t*)device_view(out_count) : nullptr;
+        uint32_t* const count_view = s->zero_copy && b->n ? (uint32_t*)device_view_cached(out_count) : nullptr;
         const bool epilogue = count_view != nullptr;  // (page-locked count array: the small results go home in one launch)
         bool reset_done = false;
-        HIP_TRY(hipEventRecord(s->way_begin.e, s->stream));
-        if (ways > 1) HIP_TRY(hipEventRecord(s->way_fork.e, s->stream));
+        // No events between the parts' streams: every entry point of a scorer returns with its streams idle, so a part's
+        // stream has nothing to wait for at the start (round 4 forked the parts off the first stream with an event: the second
+        // part's first kernel started ~30 us after the first's), and at the end every part sends ITS counts and counters home
+        // with its own epilogue launch, back to back with its last kernel, and the host waits for each stream in turn (round 4
+        // joined the parts on one stream for a single epilogue: ~20 us of cross-stream wake-up behind the last kernel of every
+        // step; profiles/r05_small_step_timeline.txt).
         for (uint32_t wy = 0; wy < ways; wy++) {
             const uint32_t start = (uint32_t)((uint64_t)b->n * wy / ways), end = (uint32_t)((uint64_t)b->n * (wy + 1) / ways);
             hipStream_t st = wy ? s->way_stream[wy - 1] : s->stream;
-            if (wy) HIP_TRY(hipStreamWaitEvent(st, s->way_fork.e, 0));
             DevBatchView v = b->view;
             v.order += start;
             v.n = end - start;
             OutSet& ow = s->outs[wy];
+            if (wy == 0) HIP_TRY(hipEventRecord(s->way_begin.e, st));  // (SageTiming::total_ms: first part's start to last part's end)
             rc = enqueue_compute(s, v, ow, true, s->exact_always ? MODE_EXACT : MODE_SCORE, st, rec, b->maybe_wide, start, o.out_count.p);
             if (rc != SAGE_HIP_OK) {
                 for (uint32_t k = 0; k < wy; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
                 return rc;
             }
-            if (!epilogue) HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
-            // The step ends on the LAST part's stream: that part started last and finishes last, so the waits for the others are
-            // (nearly always) satisfied when it gets there and the epilogue follows its last kernel back to back — joining on the
-            // first part's stream instead cost a cross-stream wake-up (~25 us) at the end of every step.
-            if (wy + 1 < ways) HIP_TRY(hipEventRecord(s->way_join[wy].e, st));
+            if (epilogue) {  // this part's PSM counts and counters in one launch, straight into the page-locked destinations
+                EpilogueParts parts{};
+                parts.n = 1;
+                parts.src[0] = ow.counters.p;
+                parts.dst[0] = ow.h_counters_view;
+                // (the parts of a step are consecutive ranges of the launch SCHEDULE, not of the spectra, and the counts are indexed
+                // by spectrum: a part sends the counts of the spectra of its range of `order`; one part: the whole array in order)
+                launch_epilogue(o.out_count.p, v.n, count_view, ways > 1 ? v.order : nullptr, parts, st);
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
+            }
         }
         hipStream_t fin = ways > 1 ? s->way_stream[ways - 2] : s->stream;
-        for (uint32_t wy = 0; wy + 1 < ways; wy++) HIP_TRY(hipStreamWaitEvent(fin, s->way_join[wy].e, 0));
         HIP_TRY(hipEventRecord(s->way_end.e, fin));
-        if (epilogue) {  // the PSM counts and every part's counters in one launch, straight into the page-locked destinations
-            EpilogueParts parts{};
-            parts.n = ways;
-            for (uint32_t wy = 0; wy < ways; wy++) {
-                parts.src[wy] = s->outs[wy].counters.p;
-                parts.dst[wy] = s->outs[wy].h_counters_view;
-            }
-            launch_epilogue(o.out_count.p, b->n, count_view, parts, fin);
-            HIP_TRY(hipGetLastError());
+        if (epilogue) {
             reset_done = true;
         } else if (b->n) {
+            for (uint32_t wy = 0; wy + 1 < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
             HIP_TRY(hipMemcpyAsync(out_count, o.out_count.p, (size_t)b->n * 4, hipMemcpyDeviceToHost, fin));
         }
-        if (b->n && !direct) HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, fin));
-        HIP_TRY(wait_for_stream(fin));
+        if (b->n && !direct) {
+            for (uint32_t wy = 0; wy + 1 < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
+            HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, fin));
+        }
+        // the first parts first (they were launched first), the last one — the one that carries the counts — at the end
+        for (uint32_t wy = 0; wy < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
         if (reset_done)
             for (uint32_t wy = 0; wy < ways; wy++) s->outs[wy].counters_clean = true;
         bool redo = false;
@@ -1960,6 +2031,7 @@ int sage_hip_host_alloc(uint64_t bytes, void** out) {
 }
 void sage_hip_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+    g_view_epoch.fetch_add(1, std::memory_order_acq_rel);  // (device_view_cached: the address may come back as something else)
 }
 
 int sage_hip_last_timing(const SageScorer* s, SageTiming* out) {

@@ -53,12 +53,23 @@ struct DevDbView {
     uint32_t n_kinds;
 };
 
+// Layout of the large tiles' position table (tm_lut).  0: row-major, lut[t][c].  1: transposed, lut[c][t] (round 4's experiment:
+// the words one window needs from consecutive tiles share lines — and are evicted from L2 before the next tile asks).  2: QUADS,
+// lut[t / 4][c][t % 4] (round 5): the words of a cell for four consecutive tiles are one aligned 16-byte load, so the count
+// kernel reads a window's table words once per FOUR tiles (kernels.hip: issue_lut) — a quarter of the table's line requests.
+// The table has tm_lut_rows(n_tiles) rows; rows beyond n_tiles describe empty tiles.
 #ifndef SAGE_TM_LUT_TRANSPOSED
 #define SAGE_TM_LUT_TRANSPOSED 0
 #endif
-constexpr bool TM_LUT_TRANSPOSED = SAGE_TM_LUT_TRANSPOSED != 0;
+#ifndef SAGE_TM_LUT_QUAD
+#define SAGE_TM_LUT_QUAD 0
+#endif
+constexpr int TM_LUT_LAYOUT = SAGE_TM_LUT_QUAD != 0 ? 2 : SAGE_TM_LUT_TRANSPOSED != 0 ? 1 : 0;
+constexpr bool TM_LUT_TRANSPOSED = TM_LUT_LAYOUT == 1;
+__host__ __device__ inline uint32_t tm_lut_rows(uint32_t n_tiles) { return TM_LUT_LAYOUT == 2 ? (n_tiles + 3u) & ~3u : n_tiles; }
 __host__ __device__ inline size_t tm_lut_index(uint32_t t, uint32_t c, uint32_t n_tiles, uint32_t lut_stride) {
-    return TM_LUT_TRANSPOSED ? (size_t)c * n_tiles + t : (size_t)t * lut_stride + c;
+    return TM_LUT_LAYOUT == 2 ? (((size_t)(t >> 2) * lut_stride + c) << 2) + (t & 3u)
+           : TM_LUT_LAYOUT == 1 ? (size_t)c * n_tiles + t : (size_t)t * lut_stride + c;
 }
 
 struct DevScorer {
@@ -224,7 +235,7 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
                                  void* stream);
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
-                              uint32_t* lut_stride_out, void* stream, bool transposed = false);
+                              uint32_t* lut_stride_out, void* stream, int layout = 0);
 int build_peptide_mass_lut(const float* d_pep_mono, uint32_t np, float top_mass, uint32_t** d_lut_out, uint32_t* bins_out, float* inv_w_out,
                            void* stream);
 // rescore.hip
@@ -255,7 +266,8 @@ struct EpilogueParts {
     uint32_t* dst[4];
     uint32_t n;
 };
-void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream);
+void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const uint32_t* order, const EpilogueParts& parts, void* stream);
+void launch_window_max(const DevScorer& sc, const DevBatchView& b, const float* pep_mono, uint32_t np, uint32_t* out_max, void* stream);
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream);
 void launch_annotate(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const SageFeature* feats,
                      const uint32_t* counts, const uint64_t* psm_off, const DevFragments& out, void* stream);

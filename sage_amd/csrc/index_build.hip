@@ -106,14 +106,18 @@ __global__ __launch_bounds__(256) void decode_kernel(uint64_t nf, uint32_t tile_
 // or TRANSPOSED, lut[c][t] — the large tiles of the open-search kernel, where ONE window is looked up in the ~100 consecutive
 // tiles of a precursor window: the words of consecutive tiles then share a cache line (32 tiles per 128 bytes) instead of
 // costing a line each.
-template <bool TRANSPOSED>
+template <int LAYOUT>  // device_types.h: TM_LUT_LAYOUT (0 row-major, 1 transposed, 2 quads of tiles)
 __global__ __launch_bounds__(256) void lut_kernel(uint32_t n_tiles, uint32_t lut_stride, float lut_scale,
                                                   const uint64_t* __restrict__ tile_off, const SageTheoretical* __restrict__ tm,
                                                   uint32_t* __restrict__ lut) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_tiles * lut_stride) return;
+    const uint32_t rows = LAYOUT == 2 ? (n_tiles + 3u) & ~3u : n_tiles;
+    if (gid >= (uint64_t)rows * lut_stride) return;
     uint32_t t, c;
-    if (TRANSPOSED) {
+    if (LAYOUT == 2) {
+        t = (uint32_t)((gid >> 2) / lut_stride) * 4u + (uint32_t)(gid & 3u);
+        c = (uint32_t)((gid >> 2) % lut_stride);
+    } else if (LAYOUT == 1) {
         c = (uint32_t)(gid / n_tiles);
         t = (uint32_t)(gid - (uint64_t)c * n_tiles);
     } else {
@@ -121,7 +125,9 @@ __global__ __launch_bounds__(256) void lut_kernel(uint32_t n_tiles, uint32_t lut
         c = (uint32_t)(gid - (uint64_t)t * lut_stride);
     }
     static_assert(sizeof(SageTheoretical) == 8, "m/z is every second float of the entry array");
-    lut[gid] = sagecore::lut_entry(&tm[0].fragment_mz, 2, tile_off[t], tile_off[t + 1], c, lut_stride, lut_scale);
+    // (a row beyond the last tile — padding of the last quad — is an empty tile at the end of the array)
+    lut[gid] = t < n_tiles ? sagecore::lut_entry(&tm[0].fragment_mz, 2, tile_off[t], tile_off[t + 1], c, lut_stride, lut_scale)
+                           : (uint32_t)tile_off[n_tiles];
 }
 
 __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheoretical* __restrict__ pm, uint32_t* __restrict__ out) {
@@ -205,7 +211,7 @@ int build_peptide_mass_lut(const float* d_pep_mono, uint32_t np, float top_mass,
 // the table is allocated here (its width depends on the largest fragment m/z).
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
-                              uint32_t* lut_stride_out, void* stream_, bool transposed) {
+                              uint32_t* lut_stride_out, void* stream_, int layout) {
     hipStream_t stream = (hipStream_t)stream_;
     // largest finite fragment m/z -> table width
     uint32_t* d_max = nullptr;
@@ -238,14 +244,15 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
     hipLaunchKernelGGL(decode_kernel, dim3((uint32_t)((nf + 2 + 255) / 256)), dim3(256), 0, stream, nf, tile_shift, k_out, d_tm_frag);
     BUILD_TRY(hipGetLastError());
     uint32_t* d_lut = nullptr;
-    const uint64_t lut_n = (uint64_t)n_tiles * lut_stride;
+    const uint64_t lut_n = (uint64_t)(layout == 2 ? (n_tiles + 3u) & ~3u : n_tiles) * lut_stride;
     BUILD_TRY(hipMalloc((void**)&d_lut, (lut_n ? lut_n : 1) * 4));
-    if (transposed)
-        hipLaunchKernelGGL(lut_kernel<true>, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
-                           d_tile_off, d_tm_frag, d_lut);
+    const dim3 lut_grid((uint32_t)((lut_n + 255) / 256));
+    if (layout == 2)
+        hipLaunchKernelGGL(lut_kernel<2>, lut_grid, dim3(256), 0, stream, n_tiles, lut_stride, lut_scale, d_tile_off, d_tm_frag, d_lut);
+    else if (layout == 1)
+        hipLaunchKernelGGL(lut_kernel<1>, lut_grid, dim3(256), 0, stream, n_tiles, lut_stride, lut_scale, d_tile_off, d_tm_frag, d_lut);
     else
-        hipLaunchKernelGGL(lut_kernel<false>, dim3((uint32_t)((lut_n + 255) / 256)), dim3(256), 0, stream, n_tiles, lut_stride, lut_scale,
-                           d_tile_off, d_tm_frag, d_lut);
+        hipLaunchKernelGGL(lut_kernel<0>, lut_grid, dim3(256), 0, stream, n_tiles, lut_stride, lut_scale, d_tile_off, d_tm_frag, d_lut);
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipStreamSynchronize(stream));
     (void)hipFree(k_in);

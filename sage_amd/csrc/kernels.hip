@@ -1397,7 +1397,30 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 const uint32_t nb = nprobe ? (nprobe + TILE_THREADS - 1) / TILE_THREADS : 1;  // units per tile (1 up to 512 windows)
                 const uint32_t n_units = (t1 - t0 + 1) * nb;
                 uint32_t np0 = 0, np1 = 0;  // table values of this thread's window in the NEXT unit (in flight)
+                // Quad layout of the table (device_types.h: TM_LUT_LAYOUT == 2), one unit per tile (up to 512 windows — every
+                // configuration of BASELINE.json): a thread reads the two table words of its window for FOUR consecutive tiles
+                // with two 16-byte loads when the walk enters a quad of tiles, and hands them out tile by tile (x is the tile
+                // about to be published; publish rotates).  The table's line requests — most of this kernel's HBM traffic: one
+                // line per (window, tile), against ~0.3 for the index entries themselves — fall to a quarter.
+                constexpr bool QUAD = TM_LUT_LAYOUT == 2;
+                uint4 qa = make_uint4(0u, 0u, 0u, 0u), qb = qa;
+                const bool quads = QUAD && nb == 1;
                 auto issue_lut = [&](uint32_t u) {
+                    if (quads) {
+                        const uint32_t t = t0 + u;
+                        if (u >= n_units || (u != 0 && (t & 3u) != 0)) return;  // (inside a quad: the words are there already)
+                        float lo, hi;
+                        uint32_t icl, ich;
+                        probe_bounds(tid, lo, hi);
+                        probe_cells(lo, hi, icl, ich);
+                        qa = qb = make_uint4(0u, 0u, 0u, 0u);
+                        if (tid < nprobe && first < end && lo <= hi) {
+                            const uint4* __restrict__ lut4 = (const uint4*)db.tm_lut + (size_t)(t >> 2) * db.lut_stride;
+                            qa = lut4[icl];
+                            qb = lut4[ich];
+                        }
+                        return;
+                    }
                     np0 = np1 = 0;
                     if (u >= n_units) return;
                     const uint32_t t = t0 + u / nb, pr = (u % nb) * TILE_THREADS + tid;
@@ -1487,6 +1510,17 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 // publish unit u (its table values have arrived in np0 / np1) and put the table reads of unit u + 1 in flight.
                 // One barrier inside; the caller has made sure nobody still reads the previous unit's run table.
                 auto publish = [&](uint32_t u) {
+                    if (quads) {
+                        if (u == 0)  // (a walk that starts inside a quad: bring its first tile to the front)
+                            for (uint32_t r = 0; r < (t0 & 3u); r++) {
+                                qa = make_uint4(qa.y, qa.z, qa.w, 0u);
+                                qb = make_uint4(qb.y, qb.z, qb.w, 0u);
+                            }
+                        np0 = qa.x;
+                        np1 = qb.x;
+                        qa = make_uint4(qa.y, qa.z, qa.w, 0u);
+                        qb = make_uint4(qb.y, qb.z, qb.w, 0u);
+                    }
                     const uint32_t p0 = np0, p1 = np1;
                     const uint32_t ncell = p1 > p0 ? ((p1 - 1) >> 1) - (p0 >> 1) + 1 : 0;
                     const uint32_t incl = wave_incl_scan_dpp(ncell);  // inclusive prefix over the lanes
@@ -3595,9 +3629,14 @@ __global__ __launch_bounds__(64) SAGE_NARROW_WAVES_ATTR void narrow_kernel(Resco
 // The way home of a step's small results in ONE launch (page-locked, mapped destinations): the PSM counts of every spectrum and
 // the counter blocks of the step's parts.  Three copy commands at the end of a 1 ms step cost ~60 us of command gaps.
 // The counter blocks are left ZEROED for the next step (its first command is then a kernel, not a fill).
+// `order` (may be null): the spectra this launch answers for — a part of a step sends the counts of ITS spectra (a range of the
+// launch schedule, scattered over the count array), so that no part has to wait for another one's kernels.
 __global__ __launch_bounds__(256) void epilogue_kernel(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ h_counts,
-                                                       EpilogueParts parts) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) h_counts[i] = counts[i];
+                                                       const uint32_t* __restrict__ order, EpilogueParts parts) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t spec = order ? order[i] : i;
+        h_counts[spec] = counts[spec];
+    }
     if (blockIdx.x == 0)
         for (uint32_t p = 0; p < parts.n; p++)
             for (uint32_t i = threadIdx.x; i < 2 * CTR_COUNT; i += blockDim.x) {
@@ -3811,10 +3850,60 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
     const RescoreKernargs args{db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep};
     hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, args);
 }
-void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const EpilogueParts& parts, void* stream) {
+void launch_epilogue(const uint32_t* counts, uint32_t n, uint32_t* h_counts, const uint32_t* order, const EpilogueParts& parts, void* stream) {
     const uint32_t blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(epilogue_kernel, dim3(blocks ? (blocks < 512u ? blocks : 512u) : 1u), dim3(256), 0, (hipStream_t)stream, counts, n, h_counts,
-                       parts);
+                       order, parts);
+}
+// The largest candidate-slot count (scoring.rs:351: right - left + 1 of IndexedDatabase::query, database.rs:402-425) any
+// precursor-window query of the batch will see — what decides whether the large-window kernels have to be launched at all
+// (slots beyond DevScorer::wcap).  One THREAD per spectrum, two plain binary searches over the peptide masses per query: the
+// same partition points in the same total order as query_window's.
+__global__ __launch_bounds__(256) void window_max_kernel(DevScorer sc, DevBatchView b, const float* __restrict__ pep_mono, uint32_t np,
+                                                         uint32_t* __restrict__ out_max) {
+    const uint32_t spec = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t widest = 0;
+    if (spec < b.n) {
+        const uint32_t zraw = b.precursor_charge[spec];
+        const bool ranged = sc.wide_window || zraw == 0 || sc.override_precursor_charge;  // scoring.rs:423, 437, 442
+        const uint32_t z0 = ranged ? sc.min_precursor_charge : zraw, z1 = ranged ? sc.max_precursor_charge : zraw;
+        const float mzp = b.precursor_mz[spec] - PROTON;
+        Tol iso_tol{2, -2.4f, 2.4f};
+        if (b.isolation_lo && b.isolation_hi) {
+            const float a = b.isolation_lo[spec], c = b.isolation_hi[spec];
+            if (a == a && c == c) { iso_tol.lo = a; iso_tol.hi = c; }
+        }
+        const bool fold = sc.min_isotope_err != sc.max_isotope_err;
+        const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
+        for (uint32_t z = z0; z <= z1 && z != 0; z++) {
+            const Tol ptol = sc.wide_window ? tol_scaled(iso_tol, (float)z) : sc.precursor_tol;
+            for (int iso = isoA; iso <= isoB; iso++) {
+                float plo, phi;
+                tol_bounds(ptol, mzp * (float)z - (float)iso * NEUTRON, plo, phi);
+                const int32_t klo = order_key(plo), khi = order_key(phi);
+                uint32_t a = 0, e = np;  // first index with key >= klo
+                while (a < e) {
+                    const uint32_t m = a + ((e - a) >> 1);
+                    if (order_key(pep_mono[m]) < klo) a = m + 1; else e = m;
+                }
+                const uint32_t left = a ? a - 1 : 0;
+                uint32_t c = left;
+                e = np;  // first index with key > khi
+                while (c < e) {
+                    const uint32_t m = c + ((e - c) >> 1);
+                    if (order_key(pep_mono[m]) <= khi) c = m + 1; else e = m;
+                }
+                const uint32_t potential = c - left + 1;  // (right - left + 1; an inverted window gives <= 2)
+                widest = potential > widest ? potential : widest;
+            }
+        }
+    }
+    widest = (uint32_t)wave_max_i64((long long)widest);
+    if ((threadIdx.x & 63u) == 0 && widest) atomicMax(out_max, widest);
+}
+void launch_window_max(const DevScorer& sc, const DevBatchView& b, const float* pep_mono, uint32_t np, uint32_t* out_max, void* stream) {
+    if (b.n == 0) return;
+    hipLaunchKernelGGL(window_max_kernel, dim3((b.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sc, b, pep_mono, np, out_max);
 }
 void launch_quick_mark(const DevScorer& sc, const DevBatchView& b, const DevWork& w, uint8_t* keep, void* stream) {
     if (b.n == 0) return;

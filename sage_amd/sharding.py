@@ -62,6 +62,27 @@ def estimate_work(peak_off, precursor_mz, precursor_charge, params, pep_mono, is
     return (peaks + 1.0) * np.maximum(work, 64.0)
 
 
+def cost_features(peak_off, precursor_mz, precursor_charge, params, pep_mono, isolation_lo=None, isolation_hi=None):
+    """Per-spectrum quantities the two narrow-search kernels' times follow (scripts/shard_cost_probe.py fits their weights):
+    `n` 1; `windows` peaks x fragment charges (the (peak, charge) windows the preliminary kernel looks up, scoring.rs:358-375);
+    `window_cands` windows x candidates in the precursor window (index entries it walks); `ions` min(candidates, 50) x precursor
+    mass / 100 x fragment charges (the ion tables the rescoring kernel walks for the k-selected candidates: a peptide has ~ mass /
+    110 residues).  Known charges only matter here; unknown charges take the scorer's range (an estimate, not the kernels' values)."""
+    n = len(peak_off) - 1
+    peaks = np.diff(np.asarray(peak_off).astype(np.int64)).astype(np.float64)
+    z = np.asarray(precursor_charge).astype(np.int64)
+    ranged = params.wide_window or params.override_precursor_charge
+    zq = np.where((z == 0) | ranged, params.max_precursor_charge, z)
+    user = -1 if params.max_fragment_charge is None else int(params.max_fragment_charge)
+    inner = np.where(user >= 0, (user + 1) & 0xFF, zq)
+    nfz = np.maximum(np.minimum(zq, inner), 2) - 1  # scoring.rs:239-247, exclusive bound - 1
+    base = estimate_work(peak_off, precursor_mz, precursor_charge, params, pep_mono, isolation_lo, isolation_hi)
+    cands = np.maximum(base / (peaks + 1.0) - 64.0, 0.0)  # (sum over the queries of the window sizes)
+    mass = (np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)) * np.maximum(zq, 1)
+    return {"n": np.ones(n), "windows": peaks * nfz, "window_cands": peaks * nfz * cands,
+            "ions": np.minimum(cands, 50.0) * np.nan_to_num(mass) / 100.0 * nfz}
+
+
 def plan_shards(peak_off: np.ndarray, world: int, weights=None):
     """Contiguous, work-balanced shards: split the spectrum list where the cumulative work crosses k/world of the total.
     `weights`: per-spectrum work (estimate_work: peaks x queries x candidates in the precursor window); without it the peak
@@ -95,14 +116,20 @@ def precursor_sort_mass(precursor_mz, precursor_charge, params):
     return (np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)) * z
 
 
-def plan_mass_shards(sort_mass, world: int, weights=None):
-    """Shards that are contiguous in PRECURSOR MASS, not in input position (VERDICT r04 task 2): the spectra are ordered by
-    mass (stable: input position breaks ties), the ordered list is cut where the cumulative work crosses k / world of the total,
-    and rank r scores the spectra of slice r.  The peptide list is mass sorted and a precursor window is a run of it
-    (database.rs:402-425), so rank r touches ~1 / world of every per-peptide structure of the replicated index — position-table
-    rows, fragment tiles, ion tables — with the same spectrum density per Dalton as a single GPU scoring the whole batch sees,
-    instead of the whole index at 1 / world of the density.  Returns `world` index arrays (global input positions, ascending
-    inside a shard, so a shard's records keep their relative input order); they partition range(n)."""
+def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 8):
+    """Shards made of runs that are contiguous in PRECURSOR MASS, not in input position (VERDICT r04 task 2): the spectra are
+    ordered by mass (stable: input position breaks ties), the ordered list is cut into world x blocks_per_rank blocks of equal
+    cumulative work, and rank r scores blocks r, r + world, r + 2 world, ...  The peptide list is mass sorted and a precursor
+    window is a run of it (database.rs:402-425), so inside each of its blocks a rank sees the same spectrum density per Dalton as
+    a single GPU scoring the whole batch — neighbouring spectra share position-table rows, fragment tiles and ion tables in
+    cache — and it touches ~1 / world of every per-peptide structure of the replicated index; input-contiguous shards see the
+    whole index at 1 / world of the density.  Why blocks and not ONE mass range per rank: what a spectrum costs changes with its
+    mass in ways the work estimate does not capture (measured on C3, profiles/r05_shard_sizes.txt: equal estimated work put
+    65 000 spectra into the lightest octile and 82 000 into the heaviest, 0.79 / 0.54 / 1.05 ms per step for octiles 0 / 1 / 7);
+    a rank that takes every world-th block samples the whole mass axis, so the shards balance whatever the cost profile, and a
+    block of 1 / 64 of a run is still tens of times larger than the kernels' reuse distance.  blocks_per_rank=1 gives one range
+    per rank.  Returns `world` index arrays (global input positions, ascending inside a shard, so a shard's records keep their
+    relative input order); they partition range(n)."""
     m = np.asarray(sort_mass, dtype=np.float64)
     n = len(m)
     if world <= 1 or n == 0:
@@ -111,9 +138,10 @@ def plan_mass_shards(sort_mass, world: int, weights=None):
     w = np.ones(n) if weights is None else np.maximum(np.asarray(weights, dtype=np.float64), 1e-9)
     assert len(w) == n
     cum = np.cumsum(w[order])
-    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * k / world, side="left")) for k in range(1, world)] + [n]
+    nb = world * max(1, int(blocks_per_rank))
+    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * k / nb, side="left")) for k in range(1, nb)] + [n]
     cuts = np.maximum.accumulate(np.array(cuts))
-    return [np.sort(order[cuts[i]:cuts[i + 1]]).astype(np.int64) for i in range(world)]
+    return [np.sort(np.concatenate([order[cuts[b]:cuts[b + 1]] for b in range(r, nb, world)])).astype(np.int64) for r in range(world)]
 
 
 def gather_features_by_index(feats: np.ndarray, counts: np.ndarray, index: np.ndarray, n_total: int, group=None):

@@ -3,8 +3,9 @@
     python scripts/ab_multi.py C3 --sizes 62500,500000 --steps 30 -- base "" "newfilter" "newfilter:SAGE_HIP_WAYS=1"
 
 Each variant is `<lib>[:ENV=V,ENV=V]`; lib `base` (or empty) = sage_amd/libsage_hip.so, else sage_amd/libsage_hip_<lib>.so
-(scripts/variants.sh builds those).  A size is a spectrum count (a prefix of the run) or `m3/8` / `i3/8`: the shard rank 3 of 8 gets
-under sharding.plan_mass_shards (contiguous in precursor mass) / plan_shards (contiguous in the input).  The workload is generated once and handed to one child process per variant through an
+(scripts/variants.sh builds those).  A size is a spectrum count (a prefix of the run) or `b3/8` / `m3/8` / `e3/8` / `i3/8`: the shard rank 3 of 8 gets
+under sharding.plan_mass_shards (8 strided blocks of the mass axis — the default plan; one mass range; one range of equal counts) /
+plan_shards (contiguous in the input).  The workload is generated once and handed to one child process per variant through an
 .npz file (a process can load only one build of the library).  Per (variant, size): wall ms per step over `steps` calls of
 score_resident, the HIP-event phase times of the last call, and an md5 of the PSM records — equal across variants or it says so."""
 import hashlib
@@ -38,8 +39,9 @@ def child(cfg_name, path, sizes, steps, h2h):
             k_, w_ = (int(x) for x in n[1:].split("/"))
             wts = estimate_work(batch_all.peak_off, batch_all.precursor_mz, batch_all.precursor_charge, params, host.pep_mono,
                                 batch_all.isolation_lo, batch_all.isolation_hi)
-            if n[0] == "m":
-                idx = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params), w_, wts)[k_]
+            if n[0] in "mbec":  # m: one mass range per rank, equal estimated work; e: one range, equal counts; b / c: 8 strided blocks
+                idx = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params), w_,  # per rank (c: the default plan)
+                                       None if n[0] in "ec" else wts, blocks_per_rank=8 if n[0] in "bc" else 1)[k_]
             else:
                 b_, e_ = plan_shards(batch_all.peak_off, w_, wts)[k_]
                 idx = np.arange(b_, e_)
@@ -75,7 +77,7 @@ def child(cfg_name, path, sizes, steps, h2h):
             extra = f" h2h {batch.n * max(steps // 3, 3) / (time.perf_counter() - t0) / 1e6:.2f}M/s"
             del locked
         print(f"RESULT n={batch.n:>7} ms/step best {best:.4f} mean {tot / 3:.4f}  {batch.n / best / 1e3:7.2f} M/s  prelim {t['prelim_ms']:.3f} "
-              f"rescore {t['rescore_ms']:.3f} retry {t['retry_ms']:.3f} wall {t['total_ms']:.3f} n_retry {t['n_retry']} ways {t['n_ways']} "
+              f"rescore {t['rescore_ms']:.3f} retry {t['retry_ms']:.3f} wall {t['total_ms']:.3f} n_retry {t['n_retry']} n_wide {t['n_wide']} ways {t['n_ways']} "
               f"psms {int(c.sum())} md5 {digest}{extra}", flush=True)
         db.close()
     scorer.close()

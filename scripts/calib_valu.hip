@@ -3,7 +3,8 @@
 // DESIGN.md prices the two narrow-search kernels against "VALU issue": instructions per spectrum x cycles per instruction.  The
 // CDNA4 guide says a wave64 f32 instruction takes two passes of a 32-wide SIMD; round 3 assumed four (SQ_ACTIVE_INST_VALU /
 // SQ_INSTS_VALU ~ 1.03 quad-cycles).  This program measures it: a kernel of N independent v_add_f32 / v_fma_f32 / v_lshl_or_b32 /
-// v_readlane per wavefront (eight accumulators: no dependency stalls), launched with W = 1..8 wavefronts per SIMD on every SIMD
+// v_readlane / v_writelane / s_add_u32 / s_load_dword per wavefront (eight accumulators: no dependency stalls), and mixes of 64 v_fma_f32
+// with 0..64 s_add_u32 (is the scalar pipe a co-limiter of a vector-bound kernel?  profiles/r05_valu_calibration.md), launched with W = 1..8 wavefronts per SIMD on every SIMD
 // of the chip, timed with s_memtime (shader-clock cycles on gfx9) inside the kernel and with HIP events outside.
 //   cycles per instruction = (cycles a SIMD was busy) / (W x N)
 //

@@ -69,13 +69,17 @@ def test_bench_two_ranks_strong_scaling_through_torchrun(gpu_required):
     them, so the rehearsal backend (gloo; ranks share the device) stands in: everything else — env parsing, the one workload cut
     with plan_shards, per-rank scoring, barrier, max-over-ranks, whole-job aggregate, the ordered gather and its check against
     rank 0's single-GPU pass, rank-0-only output — is the code the real run executes."""
-    j = _torchrun(2, ["--spectra", "3000"])
+    j = _torchrun(2, ["--spectra", "3000"])  # the default: shards contiguous in precursor mass (sharding.plan_mass_shards)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["cpu_baseline"] is None
     sh = j["sharding"]
-    assert sh["identical_to_single_gpu"] is True and len(sh["shards"]) == 2 and sh["shards"][0][1] == sh["shards"][1][0]
     total = j["config"]["spectra_total"]
-    assert 2500 < total <= 3000 and sh["shards"][1][1] == total and 0 < j["config"]["spectra_this_rank"] < total
+    assert sh["identical_to_single_gpu"] is True and sh["shard_by"] == "mass" and len(sh["spectra_per_rank"]) == 2
+    assert 2500 < total <= 3000 and sum(sh["spectra_per_rank"]) == total and 0 < j["config"]["spectra_this_rank"] < total
     assert abs(j["value"] - total * 3 / (j["ms_per_step"] * 3 / 1000.0)) / j["value"] < 0.05
+    j = _torchrun(2, ["--spectra", "3000", "--shard-by", "input"])  # round 4's plan: contiguous ranges of the input
+    sh = j["sharding"]
+    assert sh["identical_to_single_gpu"] is True and len(sh["shards"]) == 2 and sh["shards"][0][1] == sh["shards"][1][0]
+    assert sh["shards"][1][1] == j["config"]["spectra_total"] == total
 
 
 @pytest.mark.gpu

@@ -451,9 +451,9 @@ def test_equal_hyperscores_take_the_exact_path(gpu_required, monkeypatch):
     # a slot capacity whose window counts no longer fit the LDS the in-line replay stages them in (rows of up to
     # wcap / 2 words against the 5 KB of bitmap + peak table): cheap ties are off for such a scorer, the retry pass settles them
     monkeypatch.setenv("SAGE_HIP_WCAP", "8192")
-    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -700.0, 700.0)), "one PSM, windows of thousands of slots in the narrow kernel",
+    n, t = w.check(ScorerParams(precursor_tol=Tolerance("da", -400.0, 400.0)), "one PSM, windows of thousands of slots in the narrow kernel",
                    batch=w.batch.subset(np.arange(0, 300, 2)))
-    assert t["n_wide"] == 0 and t["n_tied"] == 0 and t["n_retry"] > 20
+    assert t["n_tied"] == 0 and t["n_retry"] > 20 and t["n_wide"] < 75  # (narrow-kernel windows well beyond 2560 slots among them)
     monkeypatch.delenv("SAGE_HIP_WCAP")
     b0 = w.batch  # no charge annotation: several queries per spectrum — no stored counts, the retry pass settles the tie
     unknown = SpectrumBatch(b0.peak_off, b0.masses, b0.intensities, b0.precursor_mz, np.zeros(b0.n, np.uint8), b0.total_ion_current,

@@ -126,8 +126,9 @@ def test_shards_weighted_by_window_size():
 
 
 def test_plan_mass_shards_properties():
-    """A partition of the input into `world` slices of the mass axis with equal estimated work: every spectrum in exactly one shard,
-    shard r's masses all <= shard r + 1's, ascending input positions inside a shard, NaN masses (no precursor) at the heavy end."""
+    """A partition of the input into `world` shards of equal estimated work, each made of blocks_per_rank runs of the mass axis
+    (rank r: blocks r, r + world, ...): every spectrum in exactly one shard, ascending input positions inside a shard, NaN masses
+    (no precursor) at the heavy end; with one block per rank shard r's masses all <= shard r + 1's."""
     from sage_amd.sharding import plan_mass_shards
     rng = np.random.default_rng(5)
     for world in (1, 2, 3, 8):
@@ -136,16 +137,28 @@ def test_plan_mass_shards_properties():
             if n > 10:
                 m[::97] = np.nan
                 m[5:9] = m[4]  # equal masses: input position breaks the tie
-            w = rng.uniform(1.0, 50.0, n) * (m if n else 1.0) if n <= 10 else rng.uniform(1.0, 50.0, n)
-            shards = plan_mass_shards(m, world, w)
-            assert len(shards) == world
-            assert sorted(np.concatenate(shards).tolist()) == list(range(n))
-            for sh in shards:
-                assert np.all(np.diff(sh) > 0)
+            w = rng.uniform(1.0, 50.0, n)
             key = np.where(np.isnan(m), np.inf, m)
-            tops = [key[sh].max() for sh in shards if len(sh)]
-            bots = [key[sh].min() for sh in shards if len(sh)]
-            assert all(t <= b for t, b in zip(tops, bots[1:]))
-            if n == 5000 and world > 1:
-                load = np.array([w[sh].sum() for sh in shards])
-                assert load.max() / load.mean() < 1.02
+            for bpr in (1, 8):
+                shards = plan_mass_shards(m, world, w, blocks_per_rank=bpr)
+                assert len(shards) == world
+                assert sorted(np.concatenate(shards).tolist()) == list(range(n))
+                for sh in shards:
+                    assert np.all(np.diff(sh) > 0)
+                if bpr == 1:
+                    tops = [key[sh].max() for sh in shards if len(sh)]
+                    bots = [key[sh].min() for sh in shards if len(sh)]
+                    assert all(t <= b for t, b in zip(tops, bots[1:]))
+                if n == 5000 and world > 1:
+                    load = np.array([w[sh].sum() for sh in shards])
+                    assert load.max() / load.mean() < 1.05
+                    if bpr == 8 and world == 8:  # every rank samples the whole axis: a cost the weights do not know balances too
+                        hidden = np.where(key < 1000.0, 3.0, 1.0) * np.where(key > 4000.0, 2.0, 1.0)
+                        hl = np.array([hidden[sh].sum() for sh in shards])
+                        assert hl.max() / hl.mean() < 1.15
+                        # and a shard still consists of few dense runs of the mass order: 8 runs, not thousands
+                        rank_of = np.empty(n, dtype=np.int64)
+                        for r, sh in enumerate(shards):
+                            rank_of[sh] = r
+                        runs = 1 + int(np.count_nonzero(np.diff(rank_of[np.argsort(key, kind="stable")]) != 0))
+                        assert runs <= 8 * 8
