@@ -530,16 +530,24 @@ def main():
 
     retry_ms = []
 
+    # The kernels' durations come from HIP events the library records between the kernels of a step, on the scorer's own
+    # streams (sage_hip_last_timing).  Every step of a full-size run; on every 4th step of a run whose steps are short (a shard of
+    # an N-GPU run: <= 98 304 spectra) — the records and elapsed-time queries cost such a step ~15 us, 2 % of it
+    # (profiles/r05_shard_sizes.txt) — and the averages below are over the steps that were timed.
+    timing_every = 1 if batch.n > 98304 else 4
+
     def run(steps):
         pm, rm = [], []
+        scorer.set_timing_interval(timing_every)  # (also restarts the count: step 0 of the region is a timed one)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             feats, counts = scorer.score_resident(dbatch)
-            t = scorer.last_timing()
-            pm.append(t["prelim_ms"])
-            rm.append(t["rescore_ms"])
-            retry_ms.append(t["retry_ms"])
+            if i % timing_every == 0:
+                t = scorer.last_timing()
+                pm.append(t["prelim_ms"])
+                rm.append(t["rescore_ms"])
+                retry_ms.append(t["retry_ms"])
         barrier()
         return time.perf_counter() - t0, pm, rm, feats, counts
 
@@ -828,7 +836,8 @@ def main():
                     # the fourth figure, and for an issue-bound kernel the one that IS its roofline (VERDICT r04 task 7): the
                     # instruction-issue slots the kernel's wavefronts take of the slots its SIMDs had (issue_slot_model)
                     "issue": issue, "frac_issue_slots": None if not issue else issue["frac_issue_slots"],
-                    "kernel_ms": {"prelim": pm, "rescore": rm, "of_which_exact_retry_pass": retry_pass_ms},
+                    "kernel_ms": {"prelim": pm, "rescore": rm, "of_which_exact_retry_pass": retry_pass_ms,
+                                  "timed_steps": f"every {timing_every}. step of the timed region" if timing_every > 1 else "every step of the timed region"},
                     # both phases, each against the HBM roofline with the same three byte counts (the top-level fields repeat
                     # the entry of the phase that takes longer)
                     "by_kernel": {k: {"ms": ms_k,

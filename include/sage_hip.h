@@ -307,6 +307,12 @@ typedef struct SageTiming {
                         * prelim_ms / rescore_ms are sums over parts that overlap in time; total_ms is the wall span) */
 } SageTiming;
 int sage_hip_last_timing(const SageScorer* scorer, SageTiming* out);
+/* The per-kernel times of SageTiming (prelim_ms / rescore_ms / retry_ms / total_ms) come from HIP events recorded between the
+ * kernels of a sage_hip_score_resident call: eight records and six elapsed-time queries, ~15 us of a call — nothing next to a
+ * 500 000-spectrum step, 2 % of a 62 500-spectrum one.  `every` = 1 (the default): every call is timed; n > 1: every n-th call,
+ * the calls in between report the kernel times of the last timed call and total_ms == 0; 0: never.  The counters (n_retry, n_wide,
+ * ...) are always the call's own.  No counterpart in the reference (runner.rs:327-330 times the whole search with a wall clock). */
+int sage_hip_scorer_set_timing_interval(SageScorer* scorer, uint32_t every);
 
 /* Page-locked host memory for `out` / `out_count`: results then arrive by DMA at full PCIe rate instead of
  * through the runtime's staging copy.  Optional — any host pointer is accepted by the scoring calls. */

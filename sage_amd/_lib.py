@@ -256,6 +256,7 @@ def load():
         "sage_hip_score_resident": (C.c_int, [vp, vp, vp, c_u32_p]),
         "sage_hip_initial_hits": (C.c_int, [vp, vp, c_u64_p, C.c_uint32, c_u32_p, c_u64_p, c_u64_p]),
         "sage_hip_last_timing": (C.c_int, [vp, C.POINTER(SageTiming)]),
+        "sage_hip_scorer_set_timing_interval": (C.c_int, [vp, C.c_uint32]),
         "sage_hip_annotate_resident": (C.c_int, [vp, vp, vp, c_u32_p, C.POINTER(SageFragments)]),
         "sage_hip_quick_score_resident": (C.c_int, [vp, vp, C.c_int, c_u8_p]),
         "sage_hip_debug_phase_cycles": (C.c_int, [vp, c_u64_p]),
@@ -292,7 +293,7 @@ EXPORTED_SYMBOLS = [
     "sage_hip_hostdb_peptide_info", "sage_hip_process_ms2", "sage_hip_device_count", "sage_hip_db_create", "sage_hip_db_destroy",
     "sage_hip_db_device_bytes", "sage_hip_scorer_create", "sage_hip_scorer_destroy", "sage_hip_scorer_clone", "sage_hip_score_batch",
     "sage_hip_batch_upload", "sage_hip_batch_free", "sage_hip_batch_process_upload", "sage_hip_batch_download", "sage_hip_score_resident", "sage_hip_initial_hits",
-    "sage_hip_last_timing", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
+    "sage_hip_last_timing", "sage_hip_scorer_set_timing_interval", "sage_hip_annotate_resident", "sage_hip_quick_score_resident", "sage_hip_debug_phase_cycles", "sage_hip_host_alloc", "sage_hip_host_free",
     "sage_hip_rescore", "sage_hip_hostdb_competition_keys", "sage_hip_fasta_num_targets", "sage_hip_prefilter_chunk_size",
     "sage_hip_hostdb_build_chunk", "sage_hip_hostdb_merge_kept", "sage_hip_predict_rt", "sage_hip_hostdb_feature_peptides",
     "sage_hip_write_results", "sage_hip_mzml_read", "sage_hip_mzml_view", "sage_hip_mzml_check_searchable", "sage_hip_mzml_spectrum_id", "sage_hip_mzml_free",

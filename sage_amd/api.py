@@ -723,6 +723,10 @@ class Scorer:
                                           L.as_ptr(sc, C.c_uint64)))
         return packed, ln, mp, sc
 
+    def set_timing_interval(self, every: int):
+        """Per-kernel HIP events on every `every`-th score_resident call only (0: never; default 1): sage_hip.h."""
+        L.check(L.load().sage_hip_scorer_set_timing_interval(self._h, int(every)))
+
     def last_timing(self) -> dict:
         t = L.SageTiming()
         L.check(L.load().sage_hip_last_timing(self._h, C.byref(t)))

@@ -162,6 +162,8 @@ struct OutSet {
     bool in_flight = false, two_pass = false, with_rescore = false;
     bool fused = false;          // the narrow spectra were scored by the fused kernel (ev[0] -> ev[1])
     bool wide_launched = true;   // the large-window kernels ran behind it (else: the batch was expected to hold narrow windows only)
+    bool timed = true;           // ev[] were recorded for this launch (SageScorer::timing_every)
+    bool retry_deferred = false; // two_pass, but the retry pass has not been launched (score_resident_locked: phase 1)
     uint32_t n = 0;
     ~OutSet() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -206,6 +208,14 @@ struct SageScorer {
     hipStream_t way_stream[3] = {nullptr, nullptr, nullptr};
     Event way_fork, way_join[3], way_begin, way_end;
     DevBuf<uint32_t> win_max;   // exact_window_check's result word
+    bool retry_likely = false;  // the last resident step had spectra to retry: the next one launches its retry pass unconditionally
+    // per-kernel HIP events of a step (SageTiming::prelim_ms / rescore_ms / retry_ms): on every `timing_every`-th scoring call
+    // (sage_hip_scorer_set_timing_interval; 1: every call, 0: never).  Eight event records and six elapsed-time queries cost a
+    // 0.65 ms step ~15 us; a step without them reports the last timed step's kernel times.
+    uint32_t timing_every = 1;
+    uint64_t timing_calls = 0;
+    bool timed = true;          // this call records events
+    float kept_prelim_ms = 0.f, kept_rescore_ms = 0.f, kept_retry_ms = 0.f;
     DevBuf<double> lnfact;
     DevBuf<unsigned long long> dbg;  // SAGE_HIP_PHASE_CLOCKS=1: per-phase cycle accumulators
     uint32_t tile_blocks = 0;        // persistent workgroups of the large-window kernel (u16 counters)
@@ -1462,7 +1472,9 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
 // stream is lane 0's).
 static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st,
                            SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr,
-                           int lane = 0) {
+                           int lane = 0, int phase = 0) {
+    // `phase` (resident steps, score_resident_locked): 0 both passes; 1 the first pass only — the exact retry pass is launched
+    // later if it turns out to have anything to do; 2 that retry pass alone (the first pass of this very launch has completed).
     if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
     WorkSet& wset = lane ? s->ws2 : s->ws;
     DevScorer sc = s->dev;
@@ -1519,10 +1531,20 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     sc1.fast_log = o.two_pass ? 1u : 0u;  // (an undecided logarithm is settled by the retry pass: launch_rescore)
     sc2.exact = 1u;
     sc2.fast_log = 0u;
+    const bool no_timing = !s->timed;  // (sage_hip_scorer_set_timing_interval)
+    o.timed = s->timed;
+    o.retry_deferred = phase == 1 && o.two_pass;
+    if (phase == 2) {
+        // the retry list's length: the first pass left it in the counter block, the epilogue sent it home and zeroed the block
+        HIP_TRY(hipMemcpyAsync(o.counters.p + CTR_RETRY, o.h_counters + CTR_RETRY, 4, hipMemcpyHostToDevice, st));
+        o.counters_clean = false;
+        if (!no_timing) HIP_TRY(hipEventRecord(o.ev[2].e, st));
+        goto retry_pass;
+    }
     // (score_resident's epilogue kernel leaves the counters zeroed for the next step: one command less ahead of the first kernel)
     if (!o.counters_clean) HIP_TRY(hipMemsetAsync(o.counters.p, 0, 2 * CTR_COUNT * 4, st));
     o.counters_clean = false;
-    HIP_TRY(hipEventRecord(o.ev[0].e, st));
+    if (!no_timing) HIP_TRY(hipEventRecord(o.ev[0].e, st));
     if (fused)
         launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
     else if (one_launch)
@@ -1534,11 +1556,12 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
         launch_prelim_tile(s->db->view, sc1, view, w1, st, &side);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(o.ev[1].e, st));
+    if (!no_timing) HIP_TRY(hipEventRecord(o.ev[1].e, st));
     if (with_rescore && (wide || !(fused || one_launch)))  // (behind search_kernel / the fused kernel: only the spectra the large-window kernels assembled)
         launch_rescore(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
-    HIP_TRY(hipEventRecord(o.ev[2].e, st));
-    if (o.two_pass) {
+    if (!no_timing) HIP_TRY(hipEventRecord(o.ev[2].e, st));
+retry_pass:
+    if (o.two_pass && phase != 1) {
         launch_narrow(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
         HIP_TRY(hipGetLastError());
         if (wide) {
@@ -1546,10 +1569,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
             HIP_TRY(hipGetLastError());
         }
         if (wide) {  // (without the large-window kernels the retry pass is ONE launch: no marker inside it)
-            HIP_TRY(hipEventRecord(o.ev[3].e, st));
+            if (!no_timing) HIP_TRY(hipEventRecord(o.ev[3].e, st));
             launch_rescore(s->db->view, sc2, v2, w2, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, rec, count_buf, nullptr, st);
         }
-        HIP_TRY(hipEventRecord(o.ev[4].e, st));
+        if (!no_timing) HIP_TRY(hipEventRecord(o.ev[4].e, st));
     }
     HIP_TRY(hipGetLastError());
     o.in_flight = true;
@@ -1570,21 +1593,25 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
         return fail(SAGE_HIP_ERR_INTERNAL, "spectra queued for the large-window kernels, which were not launched");
     }
     float a = 0, r = 0, a2 = 0, r2 = 0;
+    if (!o.timed) goto counters;
     HIP_TRY(hipEventElapsedTime(&a, o.ev[0].e, o.ev[1].e));
     HIP_TRY(hipEventElapsedTime(&r, o.ev[1].e, o.ev[2].e));
-    if (o.two_pass && o.wide_launched) {
+    if (o.two_pass && o.retry_deferred) {
+        // (the retry pass has not run: collect_retry adds its share if it does)
+    } else if (o.two_pass && o.wide_launched) {
         HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[3].e));
         HIP_TRY(hipEventElapsedTime(&r2, o.ev[3].e, o.ev[4].e));
     } else if (o.two_pass) {
         HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[4].e));
     }
+counters:
     SageTiming& t = s->timing;
     t.prelim_ms += a + a2;
     t.rescore_ms += o.with_rescore ? r + r2 : 0.f;
     t.total_ms += a + a2 + (o.with_rescore ? r + r2 : 0.f);
     t.retry_ms += a2 + r2;
     t.n_launches += 1 + (o.wide_launched ? 4 : 0) + (o.with_rescore && (o.wide_launched || !o.fused) ? 1 : 0) +
-                    (o.two_pass ? 1 + (o.wide_launched ? 5 : 0) : 0);
+                    (o.two_pass && !o.retry_deferred ? 1 + (o.wide_launched ? 5 : 0) : 0);
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
@@ -1600,6 +1627,35 @@ static int collect(SageScorer* s, OutSet& o, bool* arena_overflow, bool* redo_wi
     if (c1[CTR_LIST_OVERFLOW] || c2[CTR_LIST_OVERFLOW])
         return fail(SAGE_HIP_ERR_UNSUPPORTED, "preliminary candidate list capacity exceeded (" +
                                                   std::to_string(c1[CTR_LIST_OVERFLOW] + c2[CTR_LIST_OVERFLOW]) + " spectra)");
+    return SAGE_HIP_OK;
+}
+
+// ... of a retry pass that was launched by itself, behind a first pass that has been collected (enqueue_compute: phase 2)
+static int collect_retry(SageScorer* s, OutSet& o) {
+    o.in_flight = false;
+    o.retry_deferred = false;
+    const uint32_t* c2 = o.h_counters + CTR_COUNT;
+    SageTiming& t = s->timing;
+    if (o.timed) {
+        float a2 = 0, r2 = 0;
+        if (o.wide_launched) {
+            HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[3].e));
+            HIP_TRY(hipEventElapsedTime(&r2, o.ev[3].e, o.ev[4].e));
+        } else {
+            HIP_TRY(hipEventElapsedTime(&a2, o.ev[2].e, o.ev[4].e));
+        }
+        t.prelim_ms += a2;
+        t.rescore_ms += o.with_rescore ? r2 : 0.f;
+        t.total_ms += a2 + (o.with_rescore ? r2 : 0.f);
+        t.retry_ms += a2 + r2;
+    }
+    t.n_launches += 1 + (o.wide_launched ? 5 : 0);
+    t.arena_entries = std::max(t.arena_entries, c2[CTR_ARENA_PTR]);
+    if (c2[CTR_ARENA_OVERFLOW])
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "large-window candidate arena exhausted (" + std::to_string(s->ws.arena.n >> 18) +
+                                                  " MiB): score this batch in smaller pieces or raise SAGE_HIP_ARENA_MB");
+    if (c2[CTR_LIST_OVERFLOW])
+        return fail(SAGE_HIP_ERR_UNSUPPORTED, "preliminary candidate list capacity exceeded (" + std::to_string(c2[CTR_LIST_OVERFLOW]) + " spectra)");
     return SAGE_HIP_OK;
 }
 
@@ -1623,6 +1679,32 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
     if (b->device != s->db->device) return fail(SAGE_HIP_ERR_INVALID, "batch and scorer live on different devices");
     HIP_TRY(hipSetDevice(s->db->device));
     reset_timing(s);
+    // SAGE_HIP_STEP_TRACE=1: host-side clock of a resident step on stderr (microseconds since the call began, and since the
+    // previous call returned) — where the host's share of a small step goes (scripts/experiments/r05_lab/gpu_r5i.sh)
+    static const bool step_trace = getenv("SAGE_HIP_STEP_TRACE") != nullptr;
+    static thread_local std::chrono::steady_clock::time_point t_prev_exit{};
+    const auto t_enter = std::chrono::steady_clock::now();
+    double t_enq = 0, t_wait = 0;
+    auto us_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    struct TraceOut {
+        bool on;
+        const std::chrono::steady_clock::time_point* enter;
+        std::chrono::steady_clock::time_point* prev;
+        const double *enq, *wait;
+        ~TraceOut() {
+            if (!on) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[sage_hip] step: %.1f us since the previous call returned; enqueued at %.1f, kernels done at %.1f, returns at %.1f\n",
+                    std::chrono::duration<double, std::micro>(*enter - *prev).count(), *enq, *wait,
+                    std::chrono::duration<double, std::micro>(now - *enter).count());
+            *prev = now;
+        }
+    } trace_out{step_trace, &t_enter, &t_prev_exit, &t_enq, &t_wait};
+    s->timed = s->timing_every != 0 && (s->timing_calls++ % s->timing_every) == 0;
+    struct Restore {  // (the other entry points — streaming, quick_score, initial_hits — always record their events)
+        SageScorer* s;
+        ~Restore() { s->timed = true; }
+    } restore{s};
     OutSet& o = s->outs[0];
     SageFeature* direct = s->zero_copy && b->n ? (SageFeature*)device_view_cached(out) : nullptr;
     const size_t rec_bytes = (size_t)b->n * s->params.report_psms * sizeof(SageFeature);
@@ -1645,6 +1727,13 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         uint32_t* const count_view = s->zero_copy && b->n ? (uint32_t*)device_view_cached(out_count) : nullptr;
         const bool epilogue = count_view != nullptr;  // (page-locked count array: the small results go home in one launch)
         bool reset_done = false;
+        // The exact retry pass (spectra with equal hyperscores at a reported rank that the rescoring kernel could not settle itself,
+        // undecided logarithms) is one more launch per part behind the rescoring kernel — ~10 us of a step's tail for a list that
+        // is empty in most searches (C3, C3T: 0 of 500 000 spectra).  A narrow-search step whose predecessor had nothing to retry
+        // does not launch it: the first pass's counters come home with the epilogue, and only if they name retries is the retry
+        // pass launched then, behind a second (short) wait.  The first step of a scorer, and any step after one that did retry,
+        // launches it unconditionally, as before.
+        const bool defer_retry = epilogue && direct && !b->maybe_wide && !s->exact_always && !s->retry_likely && !s->fused && !s->one_launch;
         // No events between the parts' streams: every entry point of a scorer returns with its streams idle, so a part's
         // stream has nothing to wait for at the start (round 4 forked the parts off the first stream with an event: the second
         // part's first kernel started ~30 us after the first's), and at the end every part sends ITS counts and counters home
@@ -1658,8 +1747,16 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             v.order += start;
             v.n = end - start;
             OutSet& ow = s->outs[wy];
-            if (wy == 0) HIP_TRY(hipEventRecord(s->way_begin.e, st));  // (SageTiming::total_ms: first part's start to last part's end)
-            rc = enqueue_compute(s, v, ow, true, s->exact_always ? MODE_EXACT : MODE_SCORE, st, rec, b->maybe_wide, start, o.out_count.p);
+            if (wy == 0 && s->timed) HIP_TRY(hipEventRecord(s->way_begin.e, st));  // (SageTiming::total_ms: first part's start to last part's end)
+            // the PSM counts: a step in parts has its kernels store them straight into the caller's page-locked array, as they do
+            // the records (4-byte stores spread over the kernels' lifetime cost nothing there; a part's counts are scattered over
+            // the array — its spectra are a range of the launch SCHEDULE — and gathering them at the end of the step costs 33 us of
+            // scattered stores across the link, joining the parts for one contiguous copy 20 us of cross-stream wake-up:
+            // profiles/r05_small_step_timeline.txt); a step in one part keeps them on the device and sends them home in one
+            // contiguous run behind its last kernel
+            uint32_t* const counts_to = (epilogue && ways > 1 && direct) ? count_view : o.out_count.p;
+            rc = enqueue_compute(s, v, ow, true, s->exact_always ? MODE_EXACT : MODE_SCORE, st, rec, b->maybe_wide, start, counts_to, 0,
+                                 defer_retry ? 1 : 0);
             if (rc != SAGE_HIP_OK) {
                 for (uint32_t k = 0; k < wy; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
                 return rc;
@@ -1669,16 +1766,15 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
                 parts.n = 1;
                 parts.src[0] = ow.counters.p;
                 parts.dst[0] = ow.h_counters_view;
-                // (the parts of a step are consecutive ranges of the launch SCHEDULE, not of the spectra, and the counts are indexed
-                // by spectrum: a part sends the counts of the spectra of its range of `order`; one part: the whole array in order)
-                launch_epilogue(o.out_count.p, v.n, count_view, ways > 1 ? v.order : nullptr, parts, st);
+                const bool counts_home = counts_to == count_view;  // (the kernels stored them there already)
+                launch_epilogue(o.out_count.p, counts_home ? 0u : v.n, count_view, ways > 1 ? v.order : nullptr, parts, st);
                 HIP_TRY(hipGetLastError());
             } else {
                 HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
             }
         }
         hipStream_t fin = ways > 1 ? s->way_stream[ways - 2] : s->stream;
-        HIP_TRY(hipEventRecord(s->way_end.e, fin));
+        if (s->timed) HIP_TRY(hipEventRecord(s->way_end.e, fin));
         if (epilogue) {
             reset_done = true;
         } else if (b->n) {
@@ -1689,8 +1785,10 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             for (uint32_t wy = 0; wy + 1 < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
             HIP_TRY(hipMemcpyAsync(out, o.features.p, rec_bytes, hipMemcpyDeviceToHost, fin));
         }
-        // the first parts first (they were launched first), the last one — the one that carries the counts — at the end
+        t_enq = us_since(t_enter);
+        // the first parts first (they were launched first), the last one at the end
         for (uint32_t wy = 0; wy < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
+        t_wait = us_since(t_enter);
         if (reset_done)
             for (uint32_t wy = 0; wy < ways; wy++) s->outs[wy].counters_clean = true;
         bool redo = false;
@@ -1700,10 +1798,61 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             if (rc != SAGE_HIP_OK) return rc;
             redo = redo || r;
         }
+        if (!redo && defer_retry) {
+            bool any = false;
+            for (uint32_t wy = 0; wy < ways; wy++) any = any || s->outs[wy].h_counters[CTR_RETRY] != 0;
+            if (any) {  // the retry pass after all: the parts that have something to retry, each on its stream
+                for (uint32_t wy = 0; wy < ways; wy++) {
+                    OutSet& ow = s->outs[wy];
+                    if (ow.h_counters[CTR_RETRY] == 0) {
+                        ow.retry_deferred = false;
+                        continue;
+                    }
+                    const uint32_t start = (uint32_t)((uint64_t)b->n * wy / ways), end = (uint32_t)((uint64_t)b->n * (wy + 1) / ways);
+                    hipStream_t st = wy ? s->way_stream[wy - 1] : s->stream;
+                    DevBatchView v = b->view;
+                    v.order += start;
+                    v.n = end - start;
+                    uint32_t* const counts_to = (ways > 1) ? count_view : o.out_count.p;
+                    rc = enqueue_compute(s, v, ow, true, MODE_SCORE, st, rec, false, start, counts_to, 0, 2);
+                    if (rc != SAGE_HIP_OK) {
+                        for (uint32_t k = 0; k < ways; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
+                        return rc;
+                    }
+                    EpilogueParts parts{};
+                    parts.n = 1;
+                    parts.src[0] = ow.counters.p;
+                    parts.dst[0] = ow.h_counters_view;
+                    launch_epilogue(o.out_count.p, counts_to == count_view ? 0u : v.n, count_view, nullptr, parts, st);
+                    HIP_TRY(hipGetLastError());
+                }
+                for (uint32_t wy = 0; wy < ways; wy++) HIP_TRY(wait_for_stream(wy ? s->way_stream[wy - 1] : s->stream));
+                for (uint32_t wy = 0; wy < ways; wy++) {
+                    OutSet& ow = s->outs[wy];
+                    ow.counters_clean = true;
+                    if (!ow.retry_deferred) continue;
+                    rc = collect_retry(s, ow);
+                    if (rc != SAGE_HIP_OK) return rc;
+                }
+            } else {
+                for (uint32_t wy = 0; wy < ways; wy++) s->outs[wy].retry_deferred = false;
+            }
+        }
         if (!redo) {
-            float wall = 0.f;
-            HIP_TRY(hipEventElapsedTime(&wall, s->way_begin.e, s->way_end.e));
-            s->timing.total_ms = wall;  // (prelim_ms / rescore_ms: summed over the parts, which overlap in time)
+            s->retry_likely = s->timing.n_retry != 0;
+            if (s->timed) {
+                float wall = 0.f;
+                HIP_TRY(hipEventElapsedTime(&wall, s->way_begin.e, s->way_end.e));
+                s->timing.total_ms = wall;  // (prelim_ms / rescore_ms: summed over the parts, which overlap in time)
+                s->kept_prelim_ms = s->timing.prelim_ms;
+                s->kept_rescore_ms = s->timing.rescore_ms;
+                s->kept_retry_ms = s->timing.retry_ms;
+            } else {  // (an untimed step reports the kernel times of the last timed one; total_ms 0 says so)
+                s->timing.prelim_ms = s->kept_prelim_ms;
+                s->timing.rescore_ms = s->kept_rescore_ms;
+                s->timing.retry_ms = s->kept_retry_ms;
+                s->timing.total_ms = 0.f;
+            }
             s->timing.n_ways = ways;
             return SAGE_HIP_OK;
         }
@@ -2032,6 +2181,14 @@ int sage_hip_host_alloc(uint64_t bytes, void** out) {
 void sage_hip_host_free(void* p) {
     if (p) (void)hipHostFree(p);
     g_view_epoch.fetch_add(1, std::memory_order_acq_rel);  // (device_view_cached: the address may come back as something else)
+}
+
+int sage_hip_scorer_set_timing_interval(SageScorer* s, uint32_t every) {
+    if (!s) return fail(SAGE_HIP_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->timing_every = every;
+    s->timing_calls = 0;
+    return SAGE_HIP_OK;
 }
 
 int sage_hip_last_timing(const SageScorer* s, SageTiming* out) {

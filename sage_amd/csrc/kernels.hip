@@ -1343,7 +1343,11 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 const size_t qid = (size_t)slot * w.qmax + query_index(sc, si, z, iso);
                 // ---- IndexedDatabase::query by wavefront 0, shared through LDS; the query's candidate directory ----
                 if (w0) {
-                    const Window q = query_window<false>(db.pep_mono, db.np, ptol, precursor_mass - (float)iso * NEUTRON);  // scoring.rs:344
+                    // (through the position table of the peptide masses, like the narrow kernel since round 4: 3 dependent round trips
+                    // instead of ~9 while the other seven wavefronts wait — a third of this kernel's time per spectrum in a wide-window
+                    // search, whose three charge-state queries span one or two tiles each: scripts/tile_probe.py wide)
+                    const Window q = query_window<false>(db.pep_mono, db.np, ptol, precursor_mass - (float)iso * NEUTRON, db.pep_lut,
+                                                         db.pep_lut_bins, db.pep_lut_inv_w);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
                         l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0; l_sh[SH_NCAND] = 0;

@@ -116,10 +116,11 @@ def precursor_sort_mass(precursor_mz, precursor_charge, params):
     return (np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)) * z
 
 
-def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 8):
+def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 16):
     """Shards made of runs that are contiguous in PRECURSOR MASS, not in input position (VERDICT r04 task 2): the spectra are
     ordered by mass (stable: input position breaks ties), the ordered list is cut into world x blocks_per_rank blocks of equal
-    cumulative work, and rank r scores blocks r, r + world, r + 2 world, ...  The peptide list is mass sorted and a precursor
+    cumulative work, and rank r scores one block of every stride of `world` blocks (the r-th, and in every other stride the r-th
+    from the end).  The peptide list is mass sorted and a precursor
     window is a run of it (database.rs:402-425), so inside each of its blocks a rank sees the same spectrum density per Dalton as
     a single GPU scoring the whole batch — neighbouring spectra share position-table rows, fragment tiles and ion tables in
     cache — and it touches ~1 / world of every per-peptide structure of the replicated index; input-contiguous shards see the
@@ -141,7 +142,12 @@ def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int =
     nb = world * max(1, int(blocks_per_rank))
     cuts = [0] + [int(np.searchsorted(cum, cum[-1] * k / nb, side="left")) for k in range(1, nb)] + [n]
     cuts = np.maximum.accumulate(np.array(cuts))
-    return [np.sort(np.concatenate([order[cuts[b]:cuts[b + 1]] for b in range(r, nb, world)])).astype(np.int64) for r in range(world)]
+    # boustrophedon: in every other stride of `world` blocks the ranks take their block in reverse order — a rank that always took
+    # the r-th block of a stride would be systematically lighter than rank r + 1 (measured on C3 with 8 x 8 blocks: 0.629 ms for
+    # rank 0 against 0.673 ms for rank 7 per 62 500 spectra)
+    def blocks_of(r):
+        return [j * world + (r if j % 2 == 0 else world - 1 - r) for j in range(nb // world)]
+    return [np.sort(np.concatenate([order[cuts[b]:cuts[b + 1]] for b in blocks_of(r)])).astype(np.int64) for r in range(world)]
 
 
 def gather_features_by_index(feats: np.ndarray, counts: np.ndarray, index: np.ndarray, n_total: int, group=None):

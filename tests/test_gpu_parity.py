@@ -38,12 +38,19 @@ class World:
         if hits:
             assert_initial_hits_equal(scorer, dbatch, self.orc, params, batch, context, every)
         gf, gc = scorer.score_resident(dbatch)
+        gf, gc = gf.copy(), gc.copy()
+        t_first = scorer.last_timing()
         of, oc, _, _ = self.orc.score(params, batch)
         n = assert_features_equal(gf, gc, of, oc, context, rel_tol)
+        # once more on the same handle: a narrow-search step launches its exact retry pass only when the step before had something
+        # to retry (the first step of a handle finds out from the counters and launches it late) — both routes, same records
+        gfb, gcb = scorer.score_resident(dbatch)
+        assert np.array_equal(gc, gcb) and gf[np.arange(gf.shape[1])[None, :] < gc[:, None]].tobytes() == \
+            gfb[np.arange(gf.shape[1])[None, :] < gc[:, None]].tobytes(), f"{context}: the second step on the same scorer differs"
+        assert scorer.last_timing()["n_retry"] == t_first["n_retry"], context
         gf2, gc2 = scorer.score(batch)  # the upload+score+download entry point
         assert_features_equal(gf2, gc2, of, oc, context + " (score_batch)", rel_tol)
-        t = scorer.last_timing()
-        return n, t
+        return n, t_first
 
 
 @pytest.fixture(scope="module")
