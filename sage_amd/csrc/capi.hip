@@ -126,6 +126,7 @@ struct SageDeviceDb {
     DevBuf<SageTheoretical> tm2_frag; // small-tile copy + table for the narrow kernel's per-peak lookups
     DevBuf<uint32_t> tm2_lut;
     uint32_t max_ions = 0;
+    uint32_t max_len = 0;   // residues of the longest peptide (> 1023: DevScorer::long_runs)
     DevDbView view{};
     uint64_t bytes = 0;
 };
@@ -142,6 +143,7 @@ struct WorkSet {
     DevBuf<uint32_t> arena;
     // cheap ties (device_types.h: DevWork::cnt_store): the window counts of every narrow single-query spectrum
     DevBuf<uint32_t> cnt_store;
+    DevBuf<float> winbuf;   // tile_count_wing_kernel's windows (DevWork::winbuf), when a batch needs them
     uint32_t cap_tie = 0;
     uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
     uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
@@ -497,11 +499,13 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     // complete ion table for rescoring (IonSeries for every configured kind, ion_series.rs:36-85)
     std::vector<uint64_t> ion_off(np + 1, 0);
     std::vector<uint32_t> info(np);
-    uint32_t max_ions = 0;
+    uint32_t max_ions = 0, max_len = 0;
     for (uint64_t i = 0; i < np; i++) {
         const uint64_t len = v->seq_off[i + 1] - v->seq_off[i];
-        // (the rescoring kernel keeps a candidate's longest-run state in 10-bit fields: kernels.hip, run_matched_packed)
-        if (len > 1023) return fail(SAGE_HIP_ERR_UNSUPPORTED, "peptide longer than 1023 residues");
+        // (the production rescoring kernel keeps a candidate's longest-run state in 10-bit fields — kernels.hip, run_matched_packed —;
+        // a database with longer peptides is scored by the general instances: scorer_init, DevScorer::long_runs)
+        if (len > 65535) return fail(SAGE_HIP_ERR_UNSUPPORTED, "peptide longer than 65535 residues");  // (pep_info: 16 bits)
+        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
         const uint64_t cnt = (len ? len - 1 : 0) * nk;
         ion_off[i + 1] = ion_off[i] + cnt;
         max_ions = std::max<uint32_t>(max_ions, (uint32_t)cnt);
@@ -660,6 +664,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
         d->view.lut2_scale = lut2_scale;
     }
     d->max_ions = max_ions;
+    d->max_len = max_len;
     {  // the position table of the precursor-window search key
         uint32_t* lut_p = nullptr;
         uint32_t bins = 0;
@@ -765,7 +770,12 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     // settle their ties through the exact retry pass.
     if ((d.wcap + 1) / 2 > fast_tie_lds_words()) s->fast_ties = false;
     s->cnt_stride = 4u + (((d.wcap + 1) / 2 + 3u) & ~3u);  // (kernels.hip: CNT_ROW_HEADER)
-    if (d.kmax > 64) {
+    // Peptides of more than 1023 residues (the reference has no limit: database.rs:96-115 `max_len` is the user's): their ion
+    // indices do not fit the one-register Run state of the production rescoring kernel, so such a database takes the same slow,
+    // general instances as lists wider than a wavefront, with rescore_big_kernel's two-register Run form.
+    d.long_runs = db->max_len > 1023 ? 1u : 0u;
+    d.big_path = (d.kmax > 64 || d.long_runs) ? 1u : 0u;
+    if (d.big_path) {
         // report_psms > 32: preliminary lists of up to 256 candidates, wider than a wavefront.  The BIGK kernels (kernels.hip): heaps
         // in LDS, every trim exact (no order-free trims, hence no retry pass), rescoring 64 candidates at a time.
         s->kstride = ((d.kmax + 63) / 64) * 64;
@@ -815,6 +825,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
         if (const char* e = getenv("SAGE_HIP_NO_U8")) s->cnt8 = atoi(e) == 0;
         if (const char* e = getenv("SAGE_HIP_NO_REUSE")) s->reuse_counts = atoi(e) == 0;
         HIP_TRY((hipError_t)tile_kernel_prepare(160 * 1024));
+        HIP_TRY((hipError_t)spectrum_kernel_prepare(160 * 1024));
     }
     s->qmax = queries_per_spectrum(d);
     if (const char* e = getenv("SAGE_HIP_PHASE_CLOCKS")) {
@@ -1470,7 +1481,7 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
 // at that offset of the shared arrays, and the PSM counts of all parts go to one buffer (they are indexed by spectrum).
 // `lane`: which of the scorer's two working sets (a lane-1 batch never takes the large-window path: the replay kernels' side
 // stream is lane 0's).
-static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, bool with_rescore, int mode, hipStream_t st,
+static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o, bool with_rescore, int mode, hipStream_t st,
                            SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr,
                            int lane = 0, int phase = 0) {
     // `phase` (resident steps, score_resident_locked): 0 both passes; 1 the first pass only — the exact retry pass is launched
@@ -1478,6 +1489,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
     WorkSet& wset = lane ? s->ws2 : s->ws;
     DevScorer sc = s->dev;
+    DevBatchView view = view_in;
+    // (the stream variant of the preliminary kernels keeps a window per (peak, fragment charge) in LDS, the probe variant the peak
+    // masses only: a batch of very large spectra is probed whatever the estimate said)
+    if (!view.probe && (size_t)view.fzcap * view.pcap * 8 > 48 * 1024) view.probe = 1;
     const bool production = mode == MODE_SCORE && with_rescore;
     const bool fused = s->fused && production;
     if (!production) wide = true;
@@ -1490,15 +1505,25 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     const bool one_launch = production && !fused && s->one_launch;
     const size_t lds_p = std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
                  lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
-    const size_t lds_t = tile_lds_bytes(s->db->view, sc, view);
-    // (the instances for lists wider than a wavefront may take a whole CU's LDS: bigk_kernel_prepare at scorer creation)
-    const size_t lds_cap = sc.kmax > 64 ? (size_t)160 * 1024 : (size_t)64 * 1024;
-    const size_t lds_a = sc.kmax > 64 ? assemble_lds_bytes(sc) : 0;
+    // the large-window count kernel keeps a window per (peak, fragment charge) in LDS next to a tile's counters; when that does not
+    // fit a compute unit, the instance with the windows in global memory takes the batch (tile_count_wing_kernel)
+    const bool wing = wide && tile_lds_bytes(s->db->view, sc, view) > 160 * 1024;
+    const size_t lds_t = wide ? tile_lds_bytes(s->db->view, sc, view, false, wing) : 0;
+    // (every per-spectrum kernel may take a whole CU's LDS: spectrum_kernel_prepare / bigk_kernel_prepare at scorer creation)
+    const size_t lds_cap = (size_t)160 * 1024;
+    const size_t lds_a = sc.big_path ? assemble_lds_bytes(sc) : 0;
     if (lds_p > lds_cap || lds_r > lds_cap || lds_a > lds_cap || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED,
-                    sc.kmax > 64 ? "candidate lists too long for the LDS of a compute unit (report_psms x precursor-window queries per spectrum, or peaks x "
+                    sc.big_path ? "candidate lists too long for the LDS of a compute unit (report_psms x precursor-window queries per spectrum, or peaks x "
                                    "fragment charges): lower report_psms or narrow the charge / isotope-error ranges"
-                                 : "spectrum too large for the LDS staging of this build (peaks x fragment charges)");
+                                 : "spectrum too large for the LDS of a compute unit (~15 000 peaks per processed spectrum): lower max_peaks");
+    if (wing) {  // [tile_blocks][2][fzcap * pcap] floats
+        const size_t need = (size_t)std::max(s->tile_blocks, s->tile_blocks8) * 2 * view.fzcap * view.pcap;
+        if (wset.winbuf.n < need) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(wset.winbuf.reserve(need));
+        }
+    }
     o.two_pass = production && !(fused && !wide);  // (the fused first pass settles the ties of narrow spectra itself)
     o.with_rescore = with_rescore;
     o.fused = fused || one_launch;
@@ -1517,7 +1542,8 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view, OutSet& o, b
     if (fast_ties) {  // (each part of a step owns the rows / entries [list_off, list_off + n) of these arrays)
         w1.cnt_store = wset.cnt_store.p + (size_t)list_off * s->cnt_stride;  // (rows by schedule position within the part)
     }
-    if (production && s->cnt8) {  // (only a pass that is followed by the retry pass may count in u8)
+    if (wing) w1.winbuf = w2.winbuf = wset.winbuf.p;
+    if (production && s->cnt8 && !wing) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
     }

@@ -328,6 +328,15 @@ SAGE_HD void run_matched_packed(uint32_t& r, uint32_t index) {
     r = (index + 1u) | (nl << 10) | ((nl > longest ? nl : longest) << 20);
 }
 SAGE_HD uint32_t run_longest_packed(uint32_t r) { return r >> 20; }
+// ... and in TWO registers, 21 bits per field, for databases with peptides of more than 1023 residues (the instance of the
+// rescoring kernel such a database is scored with; peptide lengths are 16-bit in the device records): same update, wider fields.
+SAGE_HD void run_matched_packed(uint64_t& r, uint32_t index) {
+    const uint32_t next = (uint32_t)(r & 0x1FFFFFu), length = (uint32_t)((r >> 21) & 0x1FFFFFu), longest = (uint32_t)(r >> 42);
+    if ((next ? next - 1u : 0u) == index) return;  // self.last == index
+    const uint32_t nl = next == index ? length + 1u : 1u;
+    r = (uint64_t)(index + 1u) | ((uint64_t)nl << 21) | ((uint64_t)(nl > longest ? nl : longest) << 42);
+}
+SAGE_HD uint32_t run_longest_packed(uint64_t r) { return (uint32_t)(r >> 42); }
 
 // ---- Score (scoring.rs:17-30) -------------------------------------------------------------------
 struct Score {

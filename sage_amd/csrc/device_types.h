@@ -85,6 +85,10 @@ struct DevScorer {
     uint32_t wide_window;
     int score_type;
     uint32_t kmax;       // max(50, 2*report_psms): upper bound of every trim_k()
+    uint32_t big_path;   // 1: the instances for lists wider than a wavefront (report_psms > 32: heaps in LDS, every trim exact,
+                         //    rescore_big_kernel) — also taken by a database with peptides of more than 1023 residues, whose
+                         //    Run states need the two-register form (long_runs; core.h: run_matched_packed)
+    uint32_t long_runs;  // 1: ion indices beyond 1023 occur
     uint32_t list_cap;   // capacity (entries) of each of the two CLists
     uint32_t wcap;       // candidate-slot capacity of the LDS counter array of the narrow kernel: spectra with a
                          // larger precursor window go to the tiled large-window kernel
@@ -155,6 +159,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     struct QueryRec* qrec; // [n * qmax]
     uint16_t* seeds;       // [n * qmax * kstride] matched counts of the first min(k, potential) candidate slots
     uint64_t* qres;        // [n * qmax * kstride] heap of each k-selected query, in the reference's layout order
+    float* winbuf;         // non-null: tile_count_wing_kernel — [tile_blocks][2][fzcap * pcap] the spectrum's windows in global memory
     uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
     uint32_t arena_cap;    // entries
     uint32_t qmax;
@@ -204,8 +209,9 @@ struct TileParams {
 
 // launch wrappers (kernels.hip)
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
-size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false);
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false, bool wing = false);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
+int spectrum_kernel_prepare(size_t max_lds_bytes);  // ... of the per-spectrum kernels (spectra of thousands of peaks)
 int bigk_kernel_prepare(size_t max_lds_bytes);  // ... of the instances for lists wider than a wavefront (report_psms > 32)
 size_t assemble_lds_bytes(const DevScorer& sc);
 uint32_t fast_tie_lds_words();  // words of LDS rescore_kernel can stage a spectrum's window counts in ((wcap + 1) / 2 must fit)

@@ -1185,16 +1185,19 @@ struct TileLds {
     uint32_t* pcs;      // [TILE_THREADS]
     uint32_t* psum;     // [TILE_WAVES]
 };
-__host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem, bool cnt8) {
+// `wing`: the windows of the spectrum live in a global-memory workspace instead (tile_count_wing_kernel: spectra whose peaks x
+// fragment charges do not fit a compute unit's LDS next to the counters)
+__host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem, bool cnt8,
+                                                  bool wing = false) {
     size_t off = 0;
     if (l) l->cnt = (uint32_t*)(smem + off);
     off += ((size_t)1 << tile_shift) * (cnt8 ? 1 : 2);
     if (l) l->bm = (uint32_t*)(smem + off);
     off += (((size_t)1 << tile_shift) / 32 + 3) / 4 * 16;
     if (l) l->win_lo = (float*)(smem + off);
-    off += (size_t)b.fzcap * b.pcap * 4;
+    off += wing ? 0 : (size_t)b.fzcap * b.pcap * 4;
     if (l) l->win_hi = (float*)(smem + off);
-    off += (size_t)b.fzcap * b.pcap * 4;
+    off += wing ? 0 : (size_t)b.fzcap * b.pcap * 4;
     off = (off + 15) & ~(size_t)15;  // (what follows is read in 16-byte pieces)
     if (l) l->hist = (uint32_t*)(smem + off);
     off += HIST_BINS * 4;
@@ -1237,7 +1240,7 @@ constexpr uint32_t DIR_WORDS = 2;
 // counters, four per word — 46 KB, 3 workgroups per CU (6 wavefronts per SIMD for a kernel that is bound by latency).  A u8
 // counter that reaches 255 flags its query (SH_OVF): the spectrum is not trusted and goes to the retry pass, which always counts
 // in u16 — so the first pass of a search may use u8 and nothing else does (DevWork::cnt8).
-template <bool C8>
+template <bool C8, bool WING = false>
 __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned char* smem) {
     constexpr uint32_t SPW = C8 ? 4 : 2;            // slots per counter word
     constexpr uint32_t CSH = C8 ? 2 : 1;            // slot -> word
@@ -1260,11 +1263,13 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     if (n_queued == 0) return;
     // (the LDS arrays as plain locals: a struct of pointers captured by the lambdas below would live in scratch memory)
     TileLds lds_;
-    tile_lds_layout(db.tile_shift, b, &lds_, smem, C8);
+    tile_lds_layout(db.tile_shift, b, &lds_, smem, C8, WING);
     uint32_t* const l_cnt = lds_.cnt;
     uint32_t* const l_bm = lds_.bm;
-    float* const l_win_lo = lds_.win_lo;
-    float* const l_win_hi = lds_.win_hi;
+    // (WING: this workgroup's slice of DevWork::winbuf — global memory, written and read by the wavefronts of one workgroup
+    // between workgroup barriers; the compute unit's L1 is theirs alone)
+    float* const l_win_lo = WING ? kp.w.winbuf + (size_t)blockIdx.x * 2 * b.fzcap * b.pcap : lds_.win_lo;
+    float* const l_win_hi = WING ? l_win_lo + (size_t)b.fzcap * b.pcap : lds_.win_hi;
     uint32_t* const l_hist = lds_.hist;
     uint32_t* const l_sh = lds_.sh;
     uint32_t* const l_pp0 = lds_.pp0;
@@ -1781,6 +1786,13 @@ __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void tile_count8_kernel(const TileParams kp) {
     extern __shared__ __align__(16) unsigned char smem[];
     tile_count_body<true>(kp, smem);
+}
+// Spectra of thousands of peaks (`max_peaks` is the user's: sage-cli input.rs:366): the (peak, fragment charge) windows no longer fit
+// the LDS next to a tile's counters — 8 bytes per window, 130 KB for 5 400 peaks x 3 charges — and live in global memory instead.
+// Slow next to the LDS instances, and rare.
+__global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void tile_count_wing_kernel(const TileParams kp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    tile_count_body<false, true>(kp, smem);
 }
 
 // A query's candidates are read back through its directory (QueryRec::head / n_dir), defensively: a position outside the
@@ -2517,7 +2529,7 @@ struct RescoreLds {
 constexpr uint32_t FEATURE_WORDS = sizeof(SageFeature) / 4;
 static_assert(sizeof(SageFeature) == 120, "Feature records leave LDS as 30 dwords");
 // (none for lists wider than a wavefront: rescore_big_kernel's records leave lane by lane — and 512 of them would be 60 KB)
-__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.kmax > 64u ? 0u : sc.chimera ? 1u : sc.report_psms; }
+__host__ __device__ inline uint32_t stage_records(const DevScorer& sc) { return sc.big_path ? 0u : sc.chimera ? 1u : sc.report_psms; }
 __host__ __device__ inline size_t rescore_scratch_bytes(bool quick) {
     // (the sort keys of a multi-PSM round live in the bitmap's bytes: carve_rescore)
     static_assert(PBM_WORDS * 4 >= 64 * 8 + 64 * 8, "s_sorted + s_key fit the bitmap");
@@ -2571,7 +2583,11 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
 //      long after the others are done, so the wavefront takes such a chunk TOGETHER: lane i looks up ion i (all
 //      charges), then the matches are accumulated in item order by a wave-uniform loop (two readlanes and a few
 //      adds per match) and handed back to the candidate's lane.
-template <class PC>
+__device__ __forceinline__ uint32_t lane_run(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane); }
+__device__ __forceinline__ uint64_t lane_run(uint64_t v, uint32_t src_lane) { return lane_value(v, src_lane); }
+// LONG: the two Run states of a candidate in 64-bit registers (ion indices beyond 1023: core.h) — rescore_big_kernel's second
+// instance; every other caller keeps the one-register form.
+template <class PC, bool LONG = false>
 __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
                                                  const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
@@ -2580,7 +2596,8 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
                                                  const float first1 = 0.f, const float first2 = 0.f, const float first3 = 0.f) {
     // (have_first: the candidate's first four ions were requested by the caller, ahead of its LDS table builds)
     const uint32_t lane = lane_id();
-    uint32_t b_run = 0, y_run = 0;  // (run_matched_packed)
+    typedef typename std::conditional<LONG, uint64_t, uint32_t>::type RunReg;
+    RunReg b_run = 0, y_run = 0;  // (run_matched_packed)
     uint32_t mm = 0;                // matched_b | matched_y << 16 (u16 in the reference)
     const bool scored = valid && lm1 && nfz;
     const float* __restrict__ my = db.ions + ion_base;
@@ -2656,8 +2673,8 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             // the candidate's accumulators, wave-uniform while its matches are added in (ion, charge) order
             float u_sb = lane_valuef(s.summed_b, L), u_sy = lane_valuef(s.summed_y, L), u_pp = lane_valuef(s.ppm_difference, L);
             uint32_t u_mm = (uint32_t)__builtin_amdgcn_readlane((int)mm, (int)L);
-            uint32_t u_b = (uint32_t)__builtin_amdgcn_readlane((int)b_run, (int)L);
-            uint32_t u_y = (uint32_t)__builtin_amdgcn_readlane((int)y_run, (int)L);
+            RunReg u_b = lane_run(b_run, L);
+            RunReg u_y = lane_run(y_run, L);
             uint64_t anyK = K1 | K2 | K3;
             while (anyK) {
                 const uint32_t bit = (uint32_t)__ffsll((long long)anyK) - 1;
@@ -3186,6 +3203,7 @@ __host__ __device__ inline size_t rescore_big_bytes(bool quick) {
     // total_cmp keys of the hyperscores by list position (lowest: did not pass), hyperscores by rank, the scores; quick_score's keys
     return (size_t)BIG_K * (8 + 8 + sizeof(BigScore)) + (quick ? (size_t)BIG_K * sizeof(QuickKey) : 0);
 }
+template <bool LONG>
 __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                          const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                          SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
@@ -3268,7 +3286,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
                 s.ppm_difference = 0.0f;
                 s.longest_b = s.longest_y = 0;
                 NoClock nc;
-                score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, nc);
+                score_candidates<NoClock, LONG>(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, nc);
                 double h = 0.0;
                 bool pass = false;
                 bool ln_undecided;  // (never: both phases)
@@ -3728,8 +3746,8 @@ __global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc
 }  // namespace
 
 size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return prelim_layout_bytes(sc, b); }
-size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8) {
-    return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8);
+size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8, bool wing) {
+    return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8, wing);
 }
 // report_psms > 128: lists, heaps and per-candidate scores of up to 1024 entries need more than the 64 KB a kernel gets by default
 size_t assemble_lds_bytes(const DevScorer& sc) {
@@ -3739,23 +3757,38 @@ size_t assemble_lds_bytes(const DevScorer& sc) {
 uint32_t fast_tie_lds_words() { return FAST_TIE_WORDS; }
 int bigk_kernel_prepare(size_t max_lds_bytes) {
     for (const void* f : {(const void*)prelim_kernel<true, false, true>, (const void*)prelim_kernel<false, false, true>,
-                          (const void*)rescore_big_kernel, (const void*)tile_assemble_kernel<true>}) {
+                          (const void*)rescore_big_kernel<false>, (const void*)rescore_big_kernel<true>, (const void*)tile_assemble_kernel<true>}) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     return (int)hipSuccess;
 }
 int tile_kernel_prepare(size_t max_lds_bytes) {
-    const hipError_t e = hipFuncSetAttribute((const void*)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
-    if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute((const void*)tile_count8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+    for (const void* f : {(const void*)tile_count_kernel, (const void*)tile_count8_kernel, (const void*)tile_count_wing_kernel}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipSuccess;
+}
+// ... and of the per-spectrum kernels: a spectrum of thousands of peaks needs more than the 64 KB a launch gets by default (10 bytes
+// of LDS per peak in the rescoring kernels, 4 in the preliminary kernel's probe variant).  Raising the limit changes nothing for the
+// launches that stay below it.
+int spectrum_kernel_prepare(size_t max_lds_bytes) {
+    for (const void* f : {(const void*)prelim_kernel<true, true>, (const void*)prelim_kernel<true, false>, (const void*)prelim_kernel<false, true>,
+                          (const void*)prelim_kernel<false, false>, (const void*)rescore_kernel<true, true>, (const void*)rescore_kernel<false, false>,
+                          (const void*)rescore_kernel<false, true>, (const void*)narrow_kernel<true, true>, (const void*)narrow_kernel<true, false>,
+                          (const void*)narrow_kernel<false, true>, (const void*)narrow_kernel<false, false>, (const void*)annotate_kernel}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipSuccess;
 }
 uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
 size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, bool quick) {
-    if (sc.kmax > WAVE)  // report_psms > 32: rescore_big_kernel
+    if (sc.big_path)  // report_psms > 32 (or long peptides): rescore_big_kernel
         return ((rescore_scratch_bytes(false) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b) + rescore_big_bytes(quick);
     return ((rescore_scratch_bytes(quick) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b);
 }
@@ -3792,14 +3825,17 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     if (b.n == 0) return;
     auto k = b.probe ? (w.dbg ? prelim_kernel<true, true> : prelim_kernel<true, false>)
                      : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
-    if (sc.kmax > WAVE) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
+    if (sc.big_path) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
     hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
                         const SideStream* side) {
     if (b.n == 0 || w.tile_blocks == 0) return;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    if (w.cnt8)
+    if (w.winbuf)
+        hipLaunchKernelGGL(tile_count_wing_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
+                           tile_lds_bytes(db, sc, b, false, true), (hipStream_t)stream, TileParams{db, sc, b, w});
+    else if (w.cnt8)
         hipLaunchKernelGGL(tile_count8_kernel, dim3(w.tile_blocks < b.n ? w.tile_blocks : b.n), dim3(TILE_THREADS),
                            tile_lds_bytes(db, sc, b, true), (hipStream_t)stream, TileParams{db, sc, b, w});
     else
@@ -3810,7 +3846,7 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
     const size_t assemble_lds = assemble_lds_bytes(sc);
     (void)fold;
-    if (sc.kmax > WAVE) {  // report_psms > 32: heaps in LDS, always exact
+    if (sc.big_path) {  // report_psms > 32: heaps in LDS, always exact
         hipLaunchKernelGGL(tile_replay_big_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
         hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
         return;
@@ -3843,8 +3879,8 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     const double* lnfact_table, uint32_t lnfact_n, uint32_t max_ions, SageFeature* out,
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
-    if (sc.kmax > WAVE) {  // report_psms > 32
-        hipLaunchKernelGGL(rescore_big_kernel, dim3(b.n < TILE_GRID_CAP ? b.n : TILE_GRID_CAP), dim3(64),
+    if (sc.big_path) {  // report_psms > 32, or peptides of more than 1023 residues
+        hipLaunchKernelGGL(sc.long_runs ? rescore_big_kernel<true> : rescore_big_kernel<false>, dim3(b.n < TILE_GRID_CAP ? b.n : TILE_GRID_CAP), dim3(64),
                            rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out,
                            out_count, keep);
         return;

@@ -175,4 +175,17 @@ uint32_t emu_run_packed_mismatches(const uint32_t* indices, uint32_t n) {
     return bad;
 }
 
+// ... and the two-register form (21-bit fields) of the instance that scores databases with peptides of more than 1023 residues
+uint32_t emu_run_packed64_mismatches(const uint32_t* indices, uint32_t n) {
+    Run r{0, 0, 0, 0};
+    uint64_t p = 0;
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        run_matched(r, indices[i]);
+        run_matched_packed(p, indices[i]);
+        bad += run_longest_packed(p) != r.longest || (uint32_t)(p & 0x1FFFFFu) != r.start + r.length || (uint32_t)((p >> 21) & 0x1FFFFFu) != r.length;
+    }
+    return bad;
+}
+
 }  // extern "C"

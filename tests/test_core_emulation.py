@@ -43,6 +43,8 @@ def emu():
     lib.emu_select_peak_lut.argtypes = [f32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.emu_run_packed_mismatches.restype = C.c_uint32
     lib.emu_run_packed_mismatches.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+    lib.emu_run_packed64_mismatches.restype = C.c_uint32
+    lib.emu_run_packed64_mismatches.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
     lib.emu_peak_bitmap_violations.restype = C.c_uint32
     lib.emu_peak_bitmap_violations.argtypes = [f32p, C.c_uint32, C.c_int, C.c_float, C.c_float, f32p, C.c_uint32,
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
@@ -307,6 +309,16 @@ def test_packed_run_state_equals_run_matched(emu):
     for q in seqs:
         a = np.asarray(q, dtype=np.uint32)
         assert emu.emu_run_packed_mismatches(a.ctypes.data_as(C.POINTER(C.c_uint32)), len(a)) == 0, q
+        assert emu.emu_run_packed64_mismatches(a.ctypes.data_as(C.POINTER(C.c_uint32)), len(a)) == 0, q
+    # the two-register form (peptides of more than 1023 residues: 21-bit fields): long ladders far beyond index 1023
+    for q in ([1022, 1023, 1024, 1025], list(range(0, 5000)), list(range(60000, 65534)), [1500] * 3 + list(range(1501, 1700)) + [4000, 4001]):
+        a = np.asarray(q, dtype=np.uint32)
+        assert emu.emu_run_packed64_mismatches(a.ctypes.data_as(C.POINTER(C.c_uint32)), len(a)) == 0, q[:4]
+    for _ in range(100):
+        n = int(rng.integers(1, 400))
+        idx = np.sort(rng.integers(0, int(rng.integers(2, 70000)), n))
+        a = np.repeat(idx, rng.integers(1, 4, n)).astype(np.uint32)
+        assert emu.emu_run_packed64_mismatches(a.ctypes.data_as(C.POINTER(C.c_uint32)), len(a)) == 0
 
 
 def test_wave_partition_point_every_span_and_answer(emu):

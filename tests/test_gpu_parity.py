@@ -388,6 +388,58 @@ def test_annotate_matches_fragments(small_world):
                       "annotate + chimera (peaks removed between PSMs)")
 
 
+def test_peptides_beyond_1023_residues(gpu_required):
+    """The reference puts no limit on a peptide's length (database.rs:96-115: `max_len` is the user's); the production rescoring
+    kernel keeps a candidate's longest-run state in 10-bit fields.  A database with longer peptides is scored by the general
+    instances (DevScorer::long_runs: the two-register Run form): undigested proteins of 1100-2300 residues, spectra whose most
+    intense peaks are a long ladder of consecutive b / y ions far beyond index 1023 — runs, matched counts, Fragments ordinals."""
+    from sage_amd.synthetic import _MASS_LUT, PROTON
+    rng = np.random.default_rng(91)
+    letters = list("ADEFGHILMNQSTVWY")  # no K / R: trypsin finds nothing to cut
+    prot = lambda n: "".join(rng.choice(letters, n))  # noqa: E731
+    fasta = "".join(f">sp|LONG{i}|LONG{i}\n{prot(n)}\n" for i, n in enumerate((1100, 1300, 1600, 2050, 2300, 2300, 1024, 1023)))
+    dbp = DatabaseParameters(bucket_size=1024, enzyme=dict(missed_cleavages=0, min_len=1000, max_len=3000, cleave_at="KR", restrict="P"),
+                             peptide_min_mass=500.0, peptide_max_mass=400000.0, static_mods={"C": 57.0215})
+    w = World(fasta, dbp, {}, 4, seed=3)  # (the world's own synthetic spectra stop at 2 500 Th: replaced below)
+    host = w.host
+    assert host.n_peptides == 16 and int(np.diff(host.seq_off.astype(np.int64)).max()) == 2300
+    spectra = []
+    seq_off = host.seq_off.astype(np.int64)
+    for i in range(48):
+        pep = int(np.flatnonzero(host.decoy == 0)[i % 8])
+        a, b = seq_off[pep], seq_off[pep + 1]
+        res = _MASS_LUT[host.seq[a:b]] + host.mods[a:b].astype(np.float64)
+        mono = float(host.pep_mono[pep])
+        z = int(rng.choice([2, 3, 4]))
+        bs = np.cumsum(res)[:-1]
+        ys = mono - bs
+        L = len(bs)
+        lo = int(rng.integers(L // 2, L - 120))  # a ladder of ~100 consecutive ions beyond the middle of the peptide
+        n_lad = int(rng.integers(60, 110))
+        lad = np.arange(lo, lo + n_lad)
+        lad = lad[rng.random(n_lad) < 0.9]  # (with gaps: several runs, one of them the longest)
+        mz = np.concatenate([bs[lad] + PROTON, ys[lad[: len(lad) // 3]] + PROTON, (bs[lad[::5]] + 2 * PROTON) / 2.0,
+                             rng.uniform(150.0, mono, 60)])
+        mz = mz * (1.0 + rng.normal(0.0, 2.0, len(mz)) * 1e-6)
+        it = np.concatenate([rng.lognormal(9.0, 0.5, len(mz) - 60), rng.lognormal(6.0, 1.0, 60)])
+        order = np.argsort(mz, kind="stable")
+        spectra.append(RawSpectrum(mz[order].astype(np.float32), it[order].astype(np.float32),
+                                   float(np.float32((mono + z * PROTON) / z)), z, None, scan_start_time=float(i), file_id=0, id=f"scan={i}"))
+    sp = SpectrumProcessor(150, False, 0.0)
+    w.batch = SpectrumBatch.from_spectra([sp.process(r) for r in spectra])
+    tol = Tolerance("da", -200000.0, 200000.0)  # every peptide is a candidate of every spectrum
+    n, t = w.check(ScorerParams(precursor_tol=tol, fragment_tol=Tolerance("ppm", -20.0, 20.0), report_psms=3), "long peptides, three PSMs")
+    scorer = Scorer(w.dev, ScorerParams(precursor_tol=tol, fragment_tol=Tolerance("ppm", -20.0, 20.0)))
+    gf, gc = scorer.score(w.batch)
+    best = gf[np.arange(w.batch.n), 0]
+    assert int(gc.min()) == 1 and int(best["longest_b"].max()) > 40 and int(best["matched_peaks"].min()) > 50
+    w.check(ScorerParams(precursor_tol=tol, fragment_tol=Tolerance("ppm", -20.0, 20.0), chimera=True, report_psms=2, max_fragment_charge=3),
+            "long peptides, chimera")
+    w.check(ScorerParams(fragment_tol=Tolerance("ppm", -20.0, 20.0)), "long peptides, narrow windows")
+    _check_annotation(w, ScorerParams(annotate_matches=True, precursor_tol=tol, fragment_tol=Tolerance("ppm", -20.0, 20.0), report_psms=2),
+                      w.batch, "long peptides, annotate")
+
+
 @pytest.mark.parametrize("low_memory", [False, True])
 def test_quick_score_prefilter(small_world, low_memory):
     """Scorer::quick_score (scoring.rs:255-298), both flavours; the low-memory one keeps the report_psms largest
@@ -647,6 +699,41 @@ def test_large_raw_spectra_and_a_thousand_peaks(small_world, deisotope):
     gf, gc = scorer2.score(hb)
     of, oc, _, _ = small_world.orc.score(params, hb)
     assert_features_equal(gf, gc, of, oc, "1000-peak spectra, large windows")
+
+
+def test_spectra_of_five_thousand_peaks(small_world):
+    """`max_peaks` is the user's (sage-cli input.rs:366).  5 400 peaks x fragment charges 1..3 = 16 200 (peak, charge) windows per
+    spectrum — twice what rounds 1-4 could stage in LDS (they answered SAGE_HIP_ERR_UNSUPPORTED): the preliminary kernel probes
+    (peak masses only in LDS), the rescoring kernels take more than the default 64 KB of a compute unit's LDS, and the large-window
+    count kernel keeps the windows in global memory (tile_count_wing_kernel).  Narrow, open, chimera + unknown charge, annotation."""
+    rng = np.random.default_rng(43)
+    raws = []
+    for k, r in enumerate(synthetic_spectra(small_world.host, 10, seed=79, charges=((4, 1.0),))):
+        n_extra = 9000 if k < 8 else 200  # (two ordinary spectra in the batch as well)
+        mz = np.concatenate([r.mz, rng.uniform(120.0, 1900.0, n_extra).astype(np.float32)])
+        it = np.concatenate([r.intensity * np.float32(50.0), rng.gamma(2.0, 20.0, n_extra).astype(np.float32)])
+        o = np.argsort(mz, kind="stable")
+        raws.append(RawSpectrum(mz[o], it[o], r.precursor_mz, r.precursor_charge, r.isolation_window, r.scan_start_time, None, 0, f"big{k}"))
+    top_n = 5400
+    sp = SpectrumProcessor(top_n, False, 0.0)
+    hb = SpectrumBatch.from_spectra([sp.process(r) for r in raws])
+    assert int(np.diff(hb.peak_off.astype(np.int64)).max()) == top_n
+    w = small_world
+    n, t = w.check(ScorerParams(max_fragment_charge=3), "5400 peaks, narrow", batch=hb, every=3)
+    assert n >= 8 and t["n_wide"] == 0
+    n, t = w.check(ScorerParams(max_fragment_charge=3, precursor_tol=Tolerance("da", -300.0, 300.0), report_psms=2), "5400 peaks, large windows",
+                   batch=hb, every=3)
+    assert t["n_wide"] > 0
+    unknown = SpectrumBatch(hb.peak_off, hb.masses, hb.intensities, hb.precursor_mz, np.zeros(hb.n, np.uint8), hb.total_ion_current)
+    w.check(ScorerParams(chimera=True, report_psms=2, precursor_tol=Tolerance("da", -2.0, 2.0)), "5400 peaks, unknown charge, chimera",
+            batch=unknown, every=3)
+    _check_annotation(w, ScorerParams(annotate_matches=True, max_fragment_charge=3), hb, "5400 peaks, annotate")
+    # the device's own preprocessing feeds the same kernels
+    scorer = Scorer(w.dev, ScorerParams(max_fragment_charge=3))
+    dbatch, npk = scorer.process_upload(RawBatch(raws), take_top_n=top_n, deisotope=False, min_deisotope_mz=0.0, min_peaks=0)
+    gf, gc = scorer.score_resident(dbatch)
+    of, oc, _, _ = w.orc.score(ScorerParams(max_fragment_charge=3), hb)
+    assert_features_equal(gf, gc, of, oc, "5400 peaks, device preprocessing")
 
 
 def test_error_paths(small_world):
