@@ -226,12 +226,11 @@ def run(cfg: dict, mzml_paths, output_directory: str, device: int = 0, log=print
     dbp = DatabaseParameters.from_json(cfg["database"])
     if not dbp.fasta:
         raise SystemExit("`database.fasta` must be set. For more information try '--help'")
-    # preliminary lists hold max(50, 2 * report_psms) <= 1024 candidates (the prefilter pass scores with report_psms + 1)
+    # (any report_psms the library takes: lists of max(50, 2 * report_psms) candidates live in LDS while they fit a compute unit,
+    # in a global-memory workspace beyond — capi.hip: enqueue_compute; the prefilter pass scores with report_psms + 1)
     need = sp["report_psms"] + (1 if dbp.prefilter else 0)
-    if need > 512:
-        raise SystemExit(f"sage_amd.cli: report_psms = {sp['report_psms']}" + (" with database.prefilter" if dbp.prefilter else "") +
-                         " needs preliminary lists of more than 1024 candidates per spectrum; this build supports report_psms <= " +
-                         ("511 with the prefilter" if dbp.prefilter else "512"))
+    if need > 32767:
+        raise SystemExit(f"sage_amd.cli: report_psms = {sp['report_psms']}: this build supports report_psms <= 32767")
     devices = list(devices) if devices else [device]
     device = devices[0]
     t0 = time.time()

@@ -144,6 +144,7 @@ struct WorkSet {
     // cheap ties (device_types.h: DevWork::cnt_store): the window counts of every narrow single-query spectrum
     DevBuf<uint32_t> cnt_store;
     DevBuf<float> winbuf;   // tile_count_wing_kernel's windows (DevWork::winbuf), when a batch needs them
+    DevBuf<unsigned char> hugebuf;  // the wide-list kernels' lists in global memory (DevWork::hugebuf), when a configuration needs them
     uint32_t cap_tie = 0;
     uint32_t cap_n = 0;     // spectra the narrow-path buffers hold
     uint32_t cap_wide = 0;  // spectra the large-window buffers hold (0 on the second compute lane, always)
@@ -166,6 +167,7 @@ struct OutSet {
     bool wide_launched = true;   // the large-window kernels ran behind it (else: the batch was expected to hold narrow windows only)
     bool timed = true;           // ev[] were recorded for this launch (SageScorer::timing_every)
     bool retry_deferred = false; // two_pass, but the retry pass has not been launched (score_resident_locked: phase 1)
+    bool huge = false;           // this launch's wide-list kernels kept their lists in WorkSet::hugebuf
     uint32_t n = 0;
     ~OutSet() {
         if (h_counters) (void)hipHostFree(h_counters);
@@ -850,7 +852,10 @@ static void scorer_release(SageScorer* s) {
 int sage_hip_scorer_create(SageDeviceDb* db, const SageScorerParams* p, SageScorer** out) {
     if (!db || !p || !out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     if (p->report_psms == 0) return fail(SAGE_HIP_ERR_INVALID, "report_psms must be >= 1");
-    if (p->report_psms > 512) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 512 (preliminary lists longer than 1024 candidates)");
+    // (trim_hits keeps max(50, 2 * report_psms) candidates, scoring.rs:322-329, and the reference has no cap; lists that no longer fit
+    // a compute unit's LDS live in a global-memory workspace — enqueue_compute: hugebuf.  16-bit fields of the large-window
+    // records bound the list at 65 534 entries.)
+    if (p->report_psms > 32767) return fail(SAGE_HIP_ERR_UNSUPPORTED, "report_psms > 32767");
     if (p->min_isotope_err > p->max_isotope_err) return fail(SAGE_HIP_ERR_INVALID, "min_isotope_err > max_isotope_err");
     if (p->min_precursor_charge > p->max_precursor_charge || p->min_precursor_charge == 0)
         return fail(SAGE_HIP_ERR_INVALID, "precursor charge range must be [lo >= 1, hi >= lo]");
@@ -1503,20 +1508,38 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
     if (!rec) rec = o.features.p;
     if (!count_buf) count_buf = o.out_count.p;
     const bool one_launch = production && !fused && s->one_launch;
-    const size_t lds_p = std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
-                 lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true);
+    // Lists wider than a wavefront (report_psms > 32) live in LDS while they fit a compute unit's 160 KB; a configuration whose
+    // lists, heaps or per-candidate arrays do not — report_psms in the hundreds x many precursor-window queries per spectrum,
+    // report_psms beyond ~500, thousands of peaks on top — gets them in a global-memory workspace, a slice per workgroup of the
+    // (then capped) grids.  Slower again, and never a refusal.
+    bool huge = false;
+    if (sc.big_path) {
+        const size_t cap = (size_t)160 * 1024;
+        huge = prelim_lds_bytes(sc, view) > cap || rescore_lds_bytes(sc, view, s->db->max_ions, true) > cap || assemble_lds_bytes(sc) > cap ||
+               (size_t)s->kstride * 8 > cap || getenv("SAGE_HIP_FORCE_HUGE") != nullptr;  // (tests force the workspace on small lists)
+    }
+    const size_t lds_p = sc.big_path ? prelim_lds_bytes(sc, view, huge)
+                                     : std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
+                 lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true, huge);
     // the large-window count kernel keeps a window per (peak, fragment charge) in LDS next to a tile's counters; when that does not
     // fit a compute unit, the instance with the windows in global memory takes the batch (tile_count_wing_kernel)
     const bool wing = wide && tile_lds_bytes(s->db->view, sc, view) > 160 * 1024;
     const size_t lds_t = wide ? tile_lds_bytes(s->db->view, sc, view, false, wing) : 0;
     // (every per-spectrum kernel may take a whole CU's LDS: spectrum_kernel_prepare / bigk_kernel_prepare at scorer creation)
     const size_t lds_cap = (size_t)160 * 1024;
-    const size_t lds_a = sc.big_path ? assemble_lds_bytes(sc) : 0;
+    const size_t lds_a = sc.big_path && !huge ? assemble_lds_bytes(sc) : 0;
     if (lds_p > lds_cap || lds_r > lds_cap || lds_a > lds_cap || lds_t > 160 * 1024)
         return fail(SAGE_HIP_ERR_UNSUPPORTED,
                     sc.big_path ? "candidate lists too long for the LDS of a compute unit (report_psms x precursor-window queries per spectrum, or peaks x "
                                    "fragment charges): lower report_psms or narrow the charge / isotope-error ranges"
                                  : "spectrum too large for the LDS of a compute unit (~15 000 peaks per processed spectrum): lower max_peaks");
+    if (huge) {
+        const size_t need = (size_t)huge_grid() * huge_stride_bytes(sc);
+        if (wset.hugebuf.n < need) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(wset.hugebuf.reserve(need));
+        }
+    }
     if (wing) {  // [tile_blocks][2][fzcap * pcap] floats
         const size_t need = (size_t)std::max(s->tile_blocks, s->tile_blocks8) * 2 * view.fzcap * view.pcap;
         if (wset.winbuf.n < need) {
@@ -1543,6 +1566,11 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
         w1.cnt_store = wset.cnt_store.p + (size_t)list_off * s->cnt_stride;  // (rows by schedule position within the part)
     }
     if (wing) w1.winbuf = w2.winbuf = wset.winbuf.p;
+    o.huge = huge;
+    if (huge) {
+        w1.hugebuf = w2.hugebuf = wset.hugebuf.p;
+        w1.huge_stride = w2.huge_stride = (uint32_t)huge_stride_bytes(sc);
+    }
     if (production && s->cnt8 && !wing) {  // (only a pass that is followed by the retry pass may count in u8)
         w1.cnt8 = 1;
         w1.tile_blocks = s->tile_blocks8;
@@ -2139,7 +2167,11 @@ int sage_hip_quick_score_resident(SageScorer* s, SageDeviceBatch* b, int prefilt
     const uint64_t np = s->db->view.np;
     HIP_TRY(s->keep.reserve(np));
     HIP_TRY(hipMemsetAsync(s->keep.p, 0, std::max<uint64_t>(np, 1), s->stream));
-    const DevWork w = make_work(s, o, 0);
+    DevWork w = make_work(s, o, 0);
+    if (s->ws.hugebuf.p && o.huge) {  // (enqueue_compute above decided: the wide-list kernels' arrays live in the global workspace)
+        w.hugebuf = s->ws.hugebuf.p;
+        w.huge_stride = (uint32_t)huge_stride_bytes(s->dev);
+    }
     if (prefilter_low_memory)
         launch_rescore(s->db->view, s->dev, b->view, w, s->lnfact.p, (uint32_t)s->lnfact.n, s->db->max_ions, o.features.p,
                        o.out_count.p, s->keep.p, s->stream);

@@ -159,6 +159,8 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     struct QueryRec* qrec; // [n * qmax]
     uint16_t* seeds;       // [n * qmax * kstride] matched counts of the first min(k, potential) candidate slots
     uint64_t* qres;        // [n * qmax * kstride] heap of each k-selected query, in the reference's layout order
+    unsigned char* hugebuf;  // non-null: the lists / heaps / per-candidate arrays of the wide-list kernels (report_psms > 32) in global
+    uint32_t huge_stride;    //     memory, [huge_grid()] slices of huge_stride bytes, one per workgroup (they no longer fit a CU's LDS)
     float* winbuf;         // non-null: tile_count_wing_kernel — [tile_blocks][2][fzcap * pcap] the spectrum's windows in global memory
     uint32_t* arena;       // candidate segments: {next, n, tile_base, 0} then n entries `count << 16 | slot in tile`
     uint32_t arena_cap;    // entries
@@ -208,14 +210,16 @@ struct TileParams {
 };
 
 // launch wrappers (kernels.hip)
-size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b);
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool huge = false);
+size_t huge_stride_bytes(const DevScorer& sc);  // bytes of DevWork::hugebuf per workgroup of the wide-list kernels
+uint32_t huge_grid();
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, bool cnt8 = false, bool wing = false);
 int tile_kernel_prepare(size_t max_lds_bytes);  // raises the kernel's dynamic-LDS limit; returns a hipError_t
 int spectrum_kernel_prepare(size_t max_lds_bytes);  // ... of the per-spectrum kernels (spectra of thousands of peaks)
 int bigk_kernel_prepare(size_t max_lds_bytes);  // ... of the instances for lists wider than a wavefront (report_psms > 32)
 size_t assemble_lds_bytes(const DevScorer& sc);
 uint32_t fast_tie_lds_words();  // words of LDS rescore_kernel can stage a spectrum's window counts in ((wcap + 1) / 2 must fit)
-size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick);
+size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t max_ions, bool quick, bool huge = false);
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b);
 // the narrow search as ONE launch of two kinds of workgroups (preliminary / rescoring, kernels.hip: search_kernel)
 size_t search_lds_bytes(const DevScorer& sc, const DevBatchView& b);

@@ -454,13 +454,22 @@ struct PrelimLds {
     uint32_t* cnt;
 };
 
-__device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const DevScorer& sc, const DevBatchView& b) {
+// `big` (the instances for lists wider than a wavefront only; null: LDS): the lists and the heap in a global-memory workspace of the
+// workgroup (DevWork::hugebuf) — preliminary lists that no longer fit a compute unit's LDS (report_psms in the hundreds x many
+// precursor-window queries per spectrum; report_psms beyond 512)
+__device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const DevScorer& sc, const DevBatchView& b, unsigned char* big = nullptr) {
     PrelimLds l;
     size_t off = 0;
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    l.listA = (uint64_t*)(smem + off); off += fold ? (size_t)sc.list_cap * 8 : 0;
-    l.listB = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
-    l.heap = (uint64_t*)(smem + off); off += (size_t)sc.kmax * 8;
+    if (big) {
+        l.listA = (uint64_t*)big;
+        l.listB = l.listA + (fold ? (size_t)sc.list_cap : 0);
+        l.heap = l.listB + sc.list_cap;
+    } else {
+        l.listA = (uint64_t*)(smem + off); off += fold ? (size_t)sc.list_cap * 8 : 0;
+        l.listB = (uint64_t*)(smem + off); off += (size_t)sc.list_cap * 8;
+        l.heap = (uint64_t*)(smem + off); off += (size_t)sc.kmax * 8;
+    }
     // probe variant: only the peak masses are staged (win_lo[0..pcap)); each lane derives its window bounds on the fly
     const size_t win = b.probe ? (size_t)b.pcap * 4 : (size_t)b.fzcap * b.pcap * 4;
     l.win_lo = (float*)(smem + off); off += win;
@@ -471,9 +480,12 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     return l;
 }
 
-__host__ __device__ inline size_t prelim_layout_bytes(const DevScorer& sc, const DevBatchView& b) {
+__host__ __device__ inline size_t prelim_big_bytes(const DevScorer& sc) {  // the lists and the heap (carve_prelim)
     const bool fold = sc.min_isotope_err != sc.max_isotope_err;
-    size_t n = (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8 +
+    return (size_t)sc.list_cap * (fold ? 16 : 8) + (size_t)sc.kmax * 8;
+}
+__host__ __device__ inline size_t prelim_layout_bytes(const DevScorer& sc, const DevBatchView& b, bool huge = false) {
+    size_t n = (huge ? 0 : prelim_big_bytes(sc)) +
                (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)3 * PROBE_BATCH_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
     n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
@@ -1075,7 +1087,9 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
     return res;
 }
 
-template <bool PROBE, bool PROF, bool BIGK = false>
+// HUGE (wide lists only): the lists and the heap in the workgroup's slice of DevWork::hugebuf — an instance of its own, so that the
+// LDS instance keeps LDS pointers (one instance choosing at run time makes them generic: flat accesses, 3x the kernel time)
+template <bool PROBE, bool PROF, bool BIGK = false, bool HUGE = false>
 __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(PrelimKernargs A) {
     // (ONE argument: prelim_spectrum and the output below read what they need from the kernarg segment, phase by phase — ArgRef)
     const DevDbView& db = A.db;
@@ -1086,7 +1100,7 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(Preli
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = lane_id();
     staggered_start(blockIdx.x);
-    const PrelimLds L = carve_prelim(smem, sc, b);
+    const PrelimLds L = carve_prelim(smem, sc, b, BIGK && HUGE ? w.hugebuf + (size_t)blockIdx.x * w.huge_stride : nullptr);
 
     uint32_t n_batch = b.n;
     if (b.n_dev) {  // retry pass: the count is a device-side counter of the first pass
@@ -2144,9 +2158,11 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
 }
 
 // The replay for k > 64 (report_psms > 32): a wavefront per query, the heap in LDS (lh_build / lh_offer_batch), 64-bit keys.
-constexpr uint32_t BIG_K = 1024;  // the longest preliminary list: max(50, 2 * report_psms) for report_psms <= 512 (capi.hip refuses more)
+// (the heap: w.kstride entries of dynamic LDS, or of the workgroup's global workspace — DevWork::hugebuf)
+template <bool HUGE>
 __global__ __launch_bounds__(64) void tile_replay_big_kernel(DevScorer sc, DevWork w) {
-    __shared__ uint64_t heap[BIG_K];
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* const heap = HUGE ? (uint64_t*)(w.hugebuf + (size_t)blockIdx.x * w.huge_stride) : (uint64_t*)smem;
     const uint32_t lane = lane_id();
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
     for (uint64_t qid_in = blockIdx.x; qid_in < n_q; qid_in += gridDim.x) {
@@ -2252,9 +2268,10 @@ __device__ __forceinline__ void tile_assemble_item(const DevScorer& sc, const De
     }
     for (uint32_t i = lane; i < B.stored; i += WAVE) w.cand[(size_t)spec * sc.kmax + i] = listB[i];
 }
-template <bool BIGK>
+template <bool BIGK, bool HUGE = false>
 __global__ __launch_bounds__(64) void tile_assemble_kernel(DevScorer sc, DevBatchView b, DevWork w) {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char smem_[];
+    unsigned char* const smem = BIGK && HUGE ? w.hugebuf + (size_t)blockIdx.x * w.huge_stride : smem_;  // (the two lists)
     const uint32_t n_items = w.n_deferred[CTR_QUEUED];
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         tile_assemble_item<BIGK>(sc, b, w, smem, item);
@@ -2401,6 +2418,7 @@ __device__ __forceinline__ void build_peak_lut(uint32_t* plut, float& inv_w, con
 // million — every lane is busy anyway and the lanes work on their own)
 constexpr uint32_t COOP_MIN_HITS = SAGE_COOP_MIN_HITS, COOP_MAX_LANES = SAGE_COOP_MAX_LANES;
 constexpr uint32_t TILE_GRID_CAP = 32768;
+constexpr uint32_t HUGE_GRID = 2048;        // workgroups of a wide-list kernel whose lists live in DevWork::hugebuf (one slice each)
 constexpr uint32_t RETRY_GRID_CAP = 8192;   // blocks of the narrow exact retry pass  // blocks of the per-query / per-item kernels of the large-window path
 __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm, uint32_t P, const PbmReach& reach) {
     const uint32_t lane = lane_id();
@@ -3199,11 +3217,13 @@ struct BigScore {  // what a Feature needs of a candidate's Score
     float summed_b, summed_y, ppm_difference;
     uint32_t longest_b, longest_y;
 };
-__host__ __device__ inline size_t rescore_big_bytes(bool quick) {
+__host__ __device__ inline size_t rescore_big_bytes(bool quick, uint32_t kstride) {
     // total_cmp keys of the hyperscores by list position (lowest: did not pass), hyperscores by rank, the scores; quick_score's keys
-    return (size_t)BIG_K * (8 + 8 + sizeof(BigScore)) + (quick ? (size_t)BIG_K * sizeof(QuickKey) : 0);
+    // — per entry of the preliminary list (kstride: its length rounded up to a wavefront)
+    static_assert(sizeof(BigScore) % 4 == 0 && sizeof(QuickKey) % 8 == 0, "array alignment");
+    return (size_t)kstride * (8 + 8 + sizeof(BigScore)) + (quick ? (size_t)kstride * sizeof(QuickKey) : 0) + 8;
 }
-template <bool LONG>
+template <bool LONG, bool HUGE>
 __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer sc, DevBatchView b, DevWork w,
                                                          const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                          SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
@@ -3221,12 +3241,12 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
             continue;
         }
         const RescoreLds R = carve_rescore(smem, smem + scratch, b);
-        unsigned char* gp = smem + scratch + fixed;
+        const uint32_t ks = w.kstride;  // (a multiple of 64)
+        unsigned char* gp = HUGE ? w.hugebuf + (size_t)blockIdx.x * w.huge_stride : smem + scratch + fixed;
         long long* const g_key = (long long*)gp;
-        double* const g_sorted = (double*)(g_key + BIG_K);
-        BigScore* const g_score = (BigScore*)(g_sorted + BIG_K);
-        static_assert((sizeof(BigScore) * BIG_K) % 8 == 0, "QuickKey array aligned");
-        QuickKey* const g_qk = (QuickKey*)(g_score + BIG_K);
+        double* const g_sorted = (double*)(g_key + ks);
+        BigScore* const g_score = (BigScore*)(g_sorted + ks);
+        QuickKey* const g_qk = (QuickKey*)(((uintptr_t)(g_score + ks) + 7) & ~(uintptr_t)7);
         uint32_t* const pbm = R.pbm;
         uint32_t* const plut = R.plut;
         float* const pm = R.pm;
@@ -3237,7 +3257,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
             pm[i] = b.masses[p0 + i];
             pi[i] = b.intensities[p0 + i];
         }
-        const uint32_t ncand = w.cand_len[spec] < BIG_K ? w.cand_len[spec] : BIG_K;
+        const uint32_t ncand = w.cand_len[spec] < ks ? w.cand_len[spec] : ks;
         const uint64_t* __restrict__ list = w.cand + (size_t)spec * sc.kmax;
         const uint32_t tot_matched = w.totals[2 * spec], tot_scored = w.totals[2 * spec + 1];
         float tic = b.tic[spec];
@@ -3745,7 +3765,17 @@ __global__ __launch_bounds__(64) void annotate_kernel(DevDbView db, DevScorer sc
 
 }  // namespace
 
-size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return prelim_layout_bytes(sc, b); }
+size_t prelim_lds_bytes(const DevScorer& sc, const DevBatchView& b, bool huge) { return prelim_layout_bytes(sc, b, huge); }
+// bytes of DevWork::hugebuf one workgroup of the wide-list kernels needs (the largest of: the preliminary kernel's lists + heap,
+// the assembler's lists, the replay's heap, the rescoring kernel's per-candidate arrays), a multiple of 256
+size_t huge_stride_bytes(const DevScorer& sc) {
+    const uint32_t ks = ((sc.kmax + 63u) / 64u) * 64u;
+    size_t n = prelim_big_bytes(sc);
+    n = n > assemble_lds_bytes(sc) ? n : assemble_lds_bytes(sc);
+    n = n > rescore_big_bytes(true, ks) ? n : rescore_big_bytes(true, ks);
+    n = n > (size_t)ks * 8 ? n : (size_t)ks * 8;
+    return (n + 255) & ~(size_t)255;
+}
 size_t tile_lds_bytes(const DevDbView& db, const DevScorer&, const DevBatchView& b, bool cnt8, bool wing) {
     return tile_lds_layout(db.tile_shift, b, nullptr, nullptr, cnt8, wing);
 }
@@ -3755,9 +3785,14 @@ size_t assemble_lds_bytes(const DevScorer& sc) {
     return ((size_t)sc.list_cap * (fold ? 16 : 8) + 15) & ~(size_t)15;
 }
 uint32_t fast_tie_lds_words() { return FAST_TIE_WORDS; }
+uint32_t huge_grid() { return HUGE_GRID; }
 int bigk_kernel_prepare(size_t max_lds_bytes) {
     for (const void* f : {(const void*)prelim_kernel<true, false, true>, (const void*)prelim_kernel<false, false, true>,
-                          (const void*)rescore_big_kernel<false>, (const void*)rescore_big_kernel<true>, (const void*)tile_assemble_kernel<true>}) {
+                          (const void*)prelim_kernel<true, false, true, true>, (const void*)prelim_kernel<false, false, true, true>,
+                          (const void*)rescore_big_kernel<false, false>, (const void*)rescore_big_kernel<true, false>,
+                          (const void*)rescore_big_kernel<false, true>, (const void*)rescore_big_kernel<true, true>,
+                          (const void*)tile_assemble_kernel<true>, (const void*)tile_assemble_kernel<true, true>,
+                          (const void*)tile_replay_big_kernel<false>, (const void*)tile_replay_big_kernel<true>}) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
@@ -3787,9 +3822,10 @@ uint32_t queries_per_spectrum(const DevScorer& sc) {
     const uint32_t n_iso = sc.min_isotope_err != sc.max_isotope_err ? (uint32_t)(sc.max_isotope_err - sc.min_isotope_err) + 1 : 1;
     return (sc.max_precursor_charge - sc.min_precursor_charge + 1) * n_iso;
 }
-size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, bool quick) {
+size_t rescore_lds_bytes(const DevScorer& sc, const DevBatchView& b, uint32_t, bool quick, bool huge) {
     if (sc.big_path)  // report_psms > 32 (or long peptides): rescore_big_kernel
-        return ((rescore_scratch_bytes(false) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b) + rescore_big_bytes(quick);
+        return ((rescore_scratch_bytes(false) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b) +
+               (huge ? 0 : rescore_big_bytes(quick, ((sc.kmax + 63u) / 64u) * 64u));
     return ((rescore_scratch_bytes(quick) + 15) & ~(size_t)15) + rescore_fixed_bytes(sc, b);
 }
 size_t narrow_lds_bytes(const DevScorer& sc, const DevBatchView& b) { return narrow_scratch_bytes(sc, b) + rescore_fixed_bytes(sc, b); }
@@ -3826,7 +3862,10 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     auto k = b.probe ? (w.dbg ? prelim_kernel<true, true> : prelim_kernel<true, false>)
                      : (w.dbg ? prelim_kernel<false, true> : prelim_kernel<false, false>);
     if (sc.big_path) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
-    hipLaunchKernelGGL(k, dim3(b.n), dim3(64), prelim_lds_bytes(sc, b), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
+    if (sc.big_path && w.hugebuf) k = b.probe ? prelim_kernel<true, false, true, true> : prelim_kernel<false, false, true, true>;
+    // (lists in global memory: a workspace slice per workgroup, so the grid is capped and strides over the batch)
+    const uint32_t grid = sc.big_path && w.hugebuf && b.n > HUGE_GRID ? HUGE_GRID : b.n;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), prelim_lds_bytes(sc, b, sc.big_path && w.hugebuf), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
                         const SideStream* side) {
@@ -3843,12 +3882,18 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
                            tile_lds_bytes(db, sc, b, false), (hipStream_t)stream, TileParams{db, sc, b, w});
     if (hipPeekAtLastError() != hipSuccess) return;  // (never let the kernels below walk records the count kernel did not write)
     const uint64_t nq = (uint64_t)b.n * w.qmax;
-    auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < TILE_GRID_CAP ? blocks : TILE_GRID_CAP); };
-    const size_t assemble_lds = assemble_lds_bytes(sc);
+    const uint32_t grid_cap = sc.big_path && w.hugebuf ? HUGE_GRID : TILE_GRID_CAP;
+    auto capped = [grid_cap](uint64_t blocks) { return (uint32_t)(blocks < grid_cap ? blocks : grid_cap); };
+    const size_t assemble_lds = sc.big_path && w.hugebuf ? 0 : assemble_lds_bytes(sc);
     (void)fold;
-    if (sc.big_path) {  // report_psms > 32: heaps in LDS, always exact
-        hipLaunchKernelGGL(tile_replay_big_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
-        hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
+    if (sc.big_path) {  // report_psms > 32: heaps in LDS (or in the global workspace), always exact
+        if (w.hugebuf) {
+            hipLaunchKernelGGL(tile_replay_big_kernel<true>, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
+            hipLaunchKernelGGL((tile_assemble_kernel<true, true>), dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
+        } else {
+            hipLaunchKernelGGL(tile_replay_big_kernel<false>, dim3(capped(nq)), dim3(64), (size_t)w.kstride * 8, (hipStream_t)stream, sc, w);
+            hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
+        }
         return;
     }
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
@@ -3880,9 +3925,12 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
                     uint32_t* out_count, uint8_t* keep, void* stream) {
     if (b.n == 0) return;
     if (sc.big_path) {  // report_psms > 32, or peptides of more than 1023 residues
-        hipLaunchKernelGGL(sc.long_runs ? rescore_big_kernel<true> : rescore_big_kernel<false>, dim3(b.n < TILE_GRID_CAP ? b.n : TILE_GRID_CAP), dim3(64),
-                           rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, db, sc, b, w, lnfact_table, lnfact_n, out,
-                           out_count, keep);
+        const uint32_t cap = w.hugebuf ? HUGE_GRID : TILE_GRID_CAP;
+        const auto big = w.hugebuf ? (sc.long_runs ? rescore_big_kernel<true, true> : rescore_big_kernel<false, true>)
+                                   : (sc.long_runs ? rescore_big_kernel<true, false> : rescore_big_kernel<false, false>);
+        hipLaunchKernelGGL(big, dim3(b.n < cap ? b.n : cap), dim3(64),
+                           rescore_lds_bytes(sc, b, max_ions, keep != nullptr, w.hugebuf != nullptr), (hipStream_t)stream, db, sc, b, w,
+                           lnfact_table, lnfact_n, out, out_count, keep);
         return;
     }
     // the first pass of a two-pass search (sc.fast_log) runs the instance with the logarithm's fast phase only (crlog.h)

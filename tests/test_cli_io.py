@@ -582,7 +582,7 @@ def test_cli_on_several_devices(tmp_path, gpu_required):
     for name in ("results.sage.tsv", "matched_fragments.sage.tsv"):
         assert open(os.path.join(one, name), "rb").read() == open(os.path.join(two, name), "rb").read(), name
     with pytest.raises(SystemExit, match="report_psms"):
-        cli.run(dict(cfg, report_psms=513), files, str(tmp_path / "x"))
+        cli.run(dict(cfg, report_psms=40000), files, str(tmp_path / "x"))
     # 40 PSMs per spectrum (lists of 80 candidates: wider than a wavefront), on one device and on "three"
     cfg40 = dict(cfg, report_psms=40, annotate_matches=False)
     r1 = cli.run(cfg40, files, str(tmp_path / "k1"))

@@ -208,15 +208,40 @@ def test_report_psms_beyond_a_wavefront(small_world, monkeypatch):
         scorer = Scorer(w.dev, params)
         gk = scorer.quick_score(scorer.upload(few), low_memory)
         np.testing.assert_array_equal(gk, w.orc.quick_score(params, few, low_memory), err_msg=f"quick_score report_psms=400 low_memory={low_memory}")
-    with pytest.raises(L.SageHipError):
-        Scorer(w.dev, ScorerParams(report_psms=513))
-    # folded lists of 15 queries per spectrum x 1000 candidates (110 KB of LDS) still fit ...
+    # folded lists of 15 queries per spectrum x 1000 candidates (110 KB of LDS) still fit a compute unit ...
     unknown_few = unknown.subset(np.arange(0, b.n, 50))
     w.check(ScorerParams(report_psms=500, precursor_tol=Tolerance("da", -30.0, 30.0), min_isotope_err=-1, max_isotope_err=3, min_matched_peaks=1),
             "report_psms=500, iso -1..3 x charges 2..4", batch=unknown_few)
-    # ... and where even a whole compute unit's LDS cannot hold them (eleven isotope errors), a clear refusal
-    with pytest.raises(L.SageHipError, match="lower report_psms"):
-        Scorer(w.dev, ScorerParams(report_psms=500, min_isotope_err=-1, max_isotope_err=9)).score(unknown_few)
+    # ... and where they do not (round 5; rounds 3-4 refused): the lists, heaps and per-candidate arrays of the same kernels in a
+    # global-memory workspace, a slice per workgroup of the capped grids — eleven isotope errors x 500 PSMs; 1100 PSMs per
+    # spectrum, twice the old cap of 512 (scoring.rs:322-329 has none), narrow, tiled, folded, chimera, quick_score
+    w.check(ScorerParams(report_psms=500, precursor_tol=Tolerance("da", -30.0, 30.0), min_isotope_err=-1, max_isotope_err=9, min_matched_peaks=1),
+            "report_psms=500, iso -1..9 x charges 2..4: lists in global memory", batch=unknown_few)
+    monkeypatch.setenv("SAGE_HIP_WCAP", "8192")
+    n, t = w.check(ScorerParams(report_psms=1100, precursor_tol=Tolerance("da", -300.0, 300.0), min_matched_peaks=1,
+                                fragment_tol=Tolerance("da", -0.3, 0.3)), "report_psms=1100 (k=2200), narrow kernel", batch=few)
+    assert n > few.n * 300
+    monkeypatch.delenv("SAGE_HIP_WCAP")
+    n, t = w.check(ScorerParams(report_psms=1100, precursor_tol=Tolerance("da", -300.0, 300.0), min_matched_peaks=1,
+                                fragment_tol=Tolerance("da", -0.3, 0.3)), "report_psms=1100, tile kernels", batch=few)
+    assert n > few.n * 300 and t["n_wide"] > few.n // 2
+    w.check(ScorerParams(report_psms=600, precursor_tol=Tolerance("da", -100.0, 100.0), min_isotope_err=0, max_isotope_err=1, min_matched_peaks=1),
+            "report_psms=600, iso 0..1 x charges 2..4, folded", batch=unknown_few)
+    w.check(ScorerParams(report_psms=520, chimera=True, precursor_tol=Tolerance("da", -200.0, 200.0), min_matched_peaks=3), "report_psms=520, chimera",
+            batch=b.subset(np.arange(0, b.n, 100)))
+    for low_memory in (True, False):
+        params = ScorerParams(report_psms=700, precursor_tol=Tolerance("da", -200.0, 200.0))
+        scorer = Scorer(w.dev, params)
+        gk = scorer.quick_score(scorer.upload(few), low_memory)
+        np.testing.assert_array_equal(gk, w.orc.quick_score(params, few, low_memory), err_msg=f"quick_score report_psms=700 low_memory={low_memory}")
+    # the workspace forced on lists that would fit LDS (every wide-list test above through the other memory)
+    monkeypatch.setenv("SAGE_HIP_FORCE_HUGE", "1")
+    w.check(ScorerParams(report_psms=50, precursor_tol=Tolerance("da", -8.0, 8.0), min_isotope_err=-1, max_isotope_err=2),
+            "report_psms=50, folded, forced workspace", batch=unknown.subset(np.arange(0, b.n, 2)))
+    w.check(ScorerParams(report_psms=100, precursor_tol=Tolerance("da", -150.0, 150.0)), "report_psms=100, tiles, forced workspace", batch=few)
+    monkeypatch.delenv("SAGE_HIP_FORCE_HUGE")
+    with pytest.raises(L.SageHipError):
+        Scorer(w.dev, ScorerParams(report_psms=40000))
 
 
 def test_isotope_errors_and_fragment_charge(small_world):
