@@ -506,11 +506,15 @@ SAGE_HD uint32_t wpp_step(uint32_t span) { return span / 65u + 1u; }
 constexpr uint32_t PBM_BITS = 1u << SAGE_PBM_LOG2_BITS, PBM_WORDS = PBM_BITS / 32;
 constexpr float PBM_INV_W = (float)(1u << SAGE_PBM_LOG2_INV_W);  // bins per Da (a power of two: mass * PBM_INV_W is exact)
 constexpr float PBM_MAX_D = 4.0f;  // 64 bins either side
-// x of an ion: floor(8 ion), saturating (a negative or NaN ion gives 0, an absurd one 2^32 - 1: such ions match no peak of a
-// spectrum the filter is active for)
+// x of an ion: floor(PBM_INV_W ion), saturating (a negative or NaN ion gives 0, an absurd one 2^32 - 1: such ions match no peak
+// of a spectrum the filter is active for).  On the device the conversion is v_cvt_u32_f32 BY NAME: a C++ cast of an out-of-range
+// float is undefined (poison to the optimiser), the instruction saturates by definition.
 SAGE_HD uint32_t pbm_index(float ion) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)(ion * PBM_INV_W);  // v_mul_f32 + v_cvt_u32_f32 (saturating, NaN -> 0)
+    const float f = ion * PBM_INV_W;
+    uint32_t x;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(x) : "v"(f));
+    return x;
 #else
     const float f = ion * PBM_INV_W;
     return f >= 4294967296.0f ? 0xFFFFFFFFu : f > 0.0f ? (uint32_t)f : 0u;  // (also maps NaN to 0)

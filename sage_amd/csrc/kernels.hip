@@ -2449,7 +2449,8 @@ __device__ __forceinline__ void build_peak_bitmap(uint32_t* bm, const float* pm,
 }
 // The bit of bin `x` modulo PBM_BITS (x: pbm_index of the ion, halved or divided by three for charges 2 and 3).  The bitmap sits at
 // LDS address 0 (the scratch part of the rescoring LDS comes first in every kernel that rescores, none of which has static LDS;
-// build_peak_bitmap checks it), so the word's byte offset IS its LDS address: (x >> 3) & 0x7FC, ds_read_b32, v_bfe_u32.
+// build_peak_bitmap checks it), so the word's byte offset IS its LDS address: (x >> 3) & ((PBM_WORDS - 1) << 2), ds_read_b32, v_bfe_u32.  spectrum_kernel_prepare refuses
+// (at scorer creation) a build in which one of these kernels has static LDS, which would push the bitmap off address 0.
 typedef const __attribute__((address_space(3))) uint32_t* LdsWordPtr;
 __device__ __forceinline__ uint32_t pbm_bit(uint32_t x) {
     const uint32_t w = *(LdsWordPtr)(uintptr_t)((x >> 3) & ((PBM_WORDS - 1u) << 2));
@@ -3815,6 +3816,9 @@ int spectrum_kernel_prepare(size_t max_lds_bytes) {
                           (const void*)narrow_kernel<false, true>, (const void*)narrow_kernel<false, false>, (const void*)annotate_kernel}) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
         if (e != hipSuccess) return (int)e;
+        // (pbm_bit reads the peak bitmap through LDS address 0: the dynamic LDS of these kernels must start there)
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, f) == hipSuccess && at.sharedSizeBytes != 0) return (int)hipErrorInvalidConfiguration;
     }
     return (int)hipSuccess;
 }
