@@ -11,11 +11,13 @@ rescoring + Feature assembly + the exact retry pass over tied spectra, PSM recor
 (sage_hip_score_resident: the rescoring kernels store them there themselves; one host synchronisation per step).
 
 Multi-GPU (one process per GPU, index replicated, no collective on the data path):
-  --scaling strong (default): THE workload (all 500 000 spectra of C3) is cut into N contiguous shards of equal spectrum counts
-      (each rank generates its own spectra [total r / N, total (r + 1) / N) of the synthetic run: the run is shuffled, so equal
-      counts are equal work; a real run is cut by sage_amd.sharding.plan_shards with estimate_work's weights — cli.py), rank r
-      scores shard r; N = 1 scores all of it.  After the timed region the ranks' records are gathered in input order and
-      rank 0 generates the whole run and checks the gathered result against its own single-GPU pass over it.
+  --scaling strong (default): THE workload (all 500 000 spectra of C3) is cut into N shards, rank r scores shard r; N = 1 scores all
+      of it.  --shard-by mass (default): sharding.plan_mass_shards — 16 blocks of the precursor-MASS axis per rank, equal counts,
+      snake order: a rank walks ~1/N of the mass-sorted index at the full batch's spectrum density (every rank generates its
+      contiguous span of the synthetic run, the ranks agree on the plan from the exchanged masses and hand the spectra over through
+      node-local files before the timed region).  --shard-by input: contiguous ranges of the input (round 4).  After the timed
+      region the ranks' records are gathered in input order and rank 0 generates the whole run and checks the gathered result
+      against its own single-GPU pass over it.  --slice K/N (one GPU): score only the shard rank K of N would get.
   --scaling weak: every rank scores its own full-size copy of the workload (different seeds).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--scaling strong|weak]
@@ -281,35 +283,35 @@ def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
     return shard, index, n_total
 
 
-# cycles of a SIMD per wave64 instruction at 5 wavefronts per SIMD with all four SIMDs of every compute unit busy — the rescoring
-# kernel's occupancy — from scripts/calib_valu.hip on this hardware (profiles/r05_valu_calibration.md, s_memtime column): a vector
-# instruction 2.39 (v_fma_f32; v_add_f32 1.58, v_lshl_or_b32 2.83, v_fma_f64 5.0), and what a scalar instruction ADDS to a
-# stream of vector ones: (193.0 - 152.8) / 48 = 0.84 (the mix of 64 v_fma_f32 + 48 s_add_u32 against 64 v_fma_f32 alone; alone
-# an s_add_u32 takes 2.6).
-CYCLES_PER_VALU, CYCLES_PER_SALU_ADDED, N_SIMDS = 2.39, 0.84, 1024
+# wavefronts a SIMD holds of each kernel (the compiler's table, profiles/r05_kernel_resources.txt: registers / LDS / waves_per_eu)
+WAVES_PER_SIMD = {"rescore_kernel": 5, "prelim_kernel": 5, "narrow_kernel": 5, "tile_count8_kernel": 6, "tile_count_kernel": 4}
 
 
 def issue_slot_model(issue, dom):
-    """The dominant kernel's instruction-issue fraction: (VALU x 2.39 + SALU x 0.84 cycles) x spectra over (the kernel's GPU-active
-    cycles, GRBM_GUI_ACTIVE, x 1024 SIMDs).  One wavefront scores one spectrum, so the counters divide by the spectra of the
-    profiled run.  A model — the vector mix is priced as v_fma_f32 — but calibrated on this chip, and the denominator is measured."""
+    """The dominant kernel against the roofline that actually bounds a vector-issue-bound kernel: the fraction of its SIMDs' time the
+    vector ALU was executing its instructions, from the SQ counters of a live rocprofv3 --pmc pass —
+        SQ_ACTIVE_INST_VALU x (wavefronts per SIMD) / SQ_WAVE_CYCLES
+    (both in quad-cycles, summed over the wavefronts; a wavefront's share of its SIMD is its resident time / the wavefronts resident
+    with it).  Counted while wavefronts are resident only, so the profiler's own dispatch overhead does not enter.  Beside it the
+    instruction counts per spectrum (one wavefront scores one spectrum) and the same fraction for the scalar unit."""
     if not issue or not issue.get("by_name"):
         return None
-    cands = {k: v for k, v in issue["by_name"].items() if k.startswith("rescore_kernel" if dom == "rescore" else ("prelim_kernel", "tile_count"))
-             and all(c in v for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"))}
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES", "SQ_WAVES")
+    want = ("rescore_kernel",) if dom == "rescore" else ("prelim_kernel", "tile_count")
+    cands = {k: v for k, v in issue["by_name"].items() if k.startswith(want) and all(c in v for c in need)}
     if not cands:
         return None
-    name = max(cands, key=lambda k: cands[k]["GRBM_GUI_ACTIVE"])
+    name = max(cands, key=lambda k: cands[k]["SQ_WAVE_CYCLES"])
     v = cands[name]
+    occ = next((w for k, w in WAVES_PER_SIMD.items() if name.startswith(k)), 5)
     n = issue["n"]
-    valu, salu = v["SQ_INSTS_VALU"] / n, v["SQ_INSTS_SALU"] / n
-    need = valu * CYCLES_PER_VALU + salu * CYCLES_PER_SALU_ADDED
-    have = v["GRBM_GUI_ACTIVE"] * N_SIMDS / n
-    return {"kernel": name, "valu_per_spectrum": valu, "salu_per_spectrum": salu, "cycles_per_valu": CYCLES_PER_VALU,
-            "cycles_per_salu_added": CYCLES_PER_SALU_ADDED, "issue_cycles_per_spectrum": need,
-            "simd_cycles_available_per_spectrum": have, "frac_issue_slots": need / have if have else None,
-            "source": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE in this run over {n} spectra; cycles per instruction: "
-                      "profiles/r05_valu_calibration.md (5 wavefronts per SIMD)"}
+    return {"kernel": name, "valu_per_spectrum": v["SQ_INSTS_VALU"] / n, "salu_per_spectrum": v["SQ_INSTS_SALU"] / n,
+            "cycles_per_valu_instruction": 4.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"] if v["SQ_INSTS_VALU"] else None,
+            "wave_cycles_per_wavefront": 4.0 * v["SQ_WAVE_CYCLES"] / v["SQ_WAVES"] if v["SQ_WAVES"] else None,
+            "waves_per_simd": occ,
+            "frac_issue_slots": v["SQ_ACTIVE_INST_VALU"] * occ / v["SQ_WAVE_CYCLES"] if v["SQ_WAVE_CYCLES"] else None,
+            "frac_scalar_unit": v["SQ_ACTIVE_INST_SCA"] * occ / v["SQ_WAVE_CYCLES"] if v["SQ_WAVE_CYCLES"] else None,
+            "source": f"rocprofv3 --pmc {' '.join(need)} in this run over {n} spectra (one dispatch per kernel and step: SAGE_HIP_WAYS=1)"}
 
 
 def gpu_algorithm_bytes(dev, params, batch, n_sample=8192):
@@ -354,7 +356,7 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
     tmp = tempfile.mkdtemp(prefix="sage_pmc_", dir="/tmp")
     res = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_WAVES"):
             d = os.path.join(tmp, ctr.split()[0])
             cmd = ["rocprofv3", "--pmc", *ctr.split(), "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config",
                    args.config, "--spectra", str(n_spec), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
@@ -379,9 +381,7 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
                 if key and cname in ctr.split():  # the full-pass dispatch is the largest one of each kernel (the retry pass is small)
                     res.setdefault(key, {}).setdefault(cname, 0.0)
                     res[key][cname] += mx
-                    if cname == "GRBM_GUI_ACTIVE":  # per kernel NAME as well: the issue figures belong to the one dominant kernel
-                        res.setdefault("by_name", {}).setdefault(short.split("(")[0], {})
-                    if cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
+                    if cname.startswith("SQ_"):  # per kernel NAME as well: the issue figures belong to the one dominant kernel
                         res.setdefault("by_name", {}).setdefault(short.split("(")[0], {})[cname] = mx
             res["n"] = n_scored
     except subprocess.TimeoutExpired as e:
@@ -572,7 +572,7 @@ def main():
     # ---- a second, longer timed region (>= 1 s of steps) : the same number over a sustained run ----
     sustained = None
     if not args.no_extras:
-        n_more = max(args.steps, int(np.ceil(1.2 / max(elapsed / args.steps, 1e-6))))
+        n_more = max(args.steps, int(np.ceil(1.6 / max(elapsed / args.steps, 1e-6))))  # (>= 1 s also when the longer run's steps come out faster)
         if dist is not None:
             nm = torch.tensor([n_more], dtype=torch.int64, device=coll_device)
             dist.all_reduce(nm, op=dist.ReduceOp.MAX)
@@ -847,9 +847,10 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": "rescore_kernel is bound by instruction ISSUE at 5 wavefronts per SIMD, not by HBM: `frac_issue_slots` "
-                                "(vector + scalar instructions per spectrum from a live rocprofv3 --pmc pass, priced with the cycles per "
-                                "instruction of profiles/r05_valu_calibration.md, over the cycles its SIMDs had) is its roofline fraction; "
+                    "limiters": "rescore_kernel is bound by vector-instruction ISSUE at 5 wavefronts per SIMD, not by HBM: `frac_issue_slots` "
+                                "(the share of its SIMDs' time the vector ALU executes its instructions: SQ_ACTIVE_INST_VALU x 5 / "
+                                "SQ_WAVE_CYCLES from a live rocprofv3 --pmc pass; what a scalar instruction adds: "
+                                "profiles/r05_valu_calibration.md) is its roofline fraction; "
                                 "its byte fractions are small by construction.  The whole path's SURVEY 8(d) bytes over the step time "
                                 "(`whole_path_achieved_GBs`) approach the HBM SPEC peak — 96 % of those bytes are the reference's binary-search "
                                 "probes, which a table-driven kernel never issues: that figure is an algorithmic-work rate, NOT bandwidth, "

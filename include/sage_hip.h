@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAGE_HIP_ABI_VERSION 5
+#define SAGE_HIP_ABI_VERSION 6
 
 enum {
     SAGE_HIP_OK = 0,
@@ -155,7 +155,8 @@ int sage_hip_device_count(void);
  * Stands in for the `&'db IndexedDatabase` borrow of Scorer (scoring.rs:211).
  * With view->fragments == NULL the fragment index is generated ON THE DEVICE from the peptide list
  * (Parameters::build_from_peptides, database.rs:265-346: ion series, stored-ion filter by view->min_ion_index, sort).
- * Peptides of more than 1023 residues: SAGE_HIP_ERR_UNSUPPORTED (the reference's default max_len is 50). */
+ * Peptides of any length up to 65 535 residues (beyond 1023 the general, slower rescoring instance scores the database: DESIGN.md 4.8;
+ * the reference's default max_len is 50). */
 int sage_hip_db_create(const SageDbView* view, int device, SageDeviceDb** out);
 void sage_hip_db_destroy(SageDeviceDb* db);
 uint64_t sage_hip_db_device_bytes(const SageDeviceDb* db);
@@ -171,7 +172,8 @@ typedef struct SageScorerParams {
     int16_t max_fragment_charge; /* Option<u8>: -1 == None */
     uint8_t wide_window;
     uint8_t annotate_matches;    /* the Fragments themselves are fetched with sage_hip_annotate_resident */
-    uint32_t report_psms;        /* 1..512 (above 32: the wider, slower kernels of DESIGN.md 4.8; above 512: SAGE_HIP_ERR_UNSUPPORTED) */
+    uint32_t report_psms;        /* 1..32767 (above 32: the wider, slower kernels of DESIGN.md 4.8; lists that do not fit a compute unit's
+                                  * LDS live in a global-memory workspace) */
     int32_t score_type;          /* 0 SageHyperScore, 1 OpenMSHyperScore (scoring.rs:10-14) */
 } SageScorerParams;
 

@@ -1263,6 +1263,18 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 #ifndef SAGE_TILE8_CELLS
 #define SAGE_TILE8_CELLS 3
 #endif
+// Round 5 experiments on the count kernel's instruction count (it executes vector instructions 80 % of its SIMDs' time), A/B'd on C4
+// / C5 (scripts/experiments/r05_lab/gpu_r5q.sh, gpu_r5r.sh): the owner wavefront of a cell by BISECTION over the running totals (14
+// instructions instead of 35) and both index ranges of an entry as one unsigned compare each — 20 % SLOWER on C4 (58.0 -> 69.6 ms:
+// the selects spill, scratch 128 -> 160 bytes per lane); a linear walk over the running totals (21 instructions) with the old
+// predicates: -1 % (57.0 ms), the default now; with the one-compare ranges: 0.  Fewer instructions buy nothing here unless the
+// register allocation holds still.
+#ifndef SAGE_HIT_RANGES
+#define SAGE_HIT_RANGES 0
+#endif
+#ifndef SAGE_LOCATE_LINEAR
+#define SAGE_LOCATE_LINEAR 1
+#endif
     // cells a thread keeps in flight: the u8 instance runs 6 wavefronts per SIMD in 80 VGPRs, the u16 one 4 in 128
     constexpr uint32_t CPT = C8 ? SAGE_TILE8_CELLS : CELLS_PER_THREAD;
     const DevDbView& db = kp.db;
@@ -1407,6 +1419,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     lut_cells(lo, hi, db.lut_scale, db.lut_stride, icl, ich);
                 };
                 pc.mark(0);
+                const uint32_t span_fe = end > first ? end - first : 0u;  // (peptides [first, end): `p - first < span_fe`)
                 const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it
                 const uint32_t t0 = left >> TSH, t1 = db.np ? (last_pep >> TSH) : 0;
                 // ---- stream: scoring.rs:358-375 over database.rs:480-536 --------------------------------------------------
@@ -1466,17 +1479,30 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 #undef SAGE_DECL_CELL
                 uint32_t unit_cells = 0;  // cells of the current unit (uniform)
                 // locate flattened cell k of the published unit: wavefront by the wave totals, window by a 6-step search
-                uint4 psA = make_uint4(0u, 0u, 0u, 0u), psB = psA;  // the eight wave totals of the published unit (two LDS reads)
+                // the running totals of the eight wavefronts' cell counts of the published unit: e1 .. e7 and the unit's total (publish)
+                uint4 psA = make_uint4(0u, 0u, 0u, 0u), psB = psA;
                 auto locate = [&](uint32_t k, uint32_t& pr, uint32_t& j) {
+#if SAGE_LOCATE_LINEAR
                     uint32_t wv = 0, base = 0;
-                    const uint32_t pv[TILE_WAVES - 1] = {psA.x, psA.y, psA.z, psA.w, psB.x, psB.y, psB.z};
+                    const uint32_t pe[TILE_WAVES - 1] = {psA.x, psA.y, psA.z, psA.w, psB.x, psB.y, psB.z};
 #pragma unroll
                     for (uint32_t i = 0; i + 1 < TILE_WAVES; i++) {
-                        const uint32_t v = pv[i];
-                        const bool past = k >= base + v && wv == i;
-                        base += past ? v : 0;
+                        const bool past = k >= pe[i];
+                        base = past ? pe[i] : base;
                         wv += past ? 1 : 0;
                     }
+#else
+                    // the wavefront that owns flattened cell k: the number of running totals <= k, by bisection (the kernel is bound
+                    // by vector issue — r05_C4_bench.json: roofline.issue — and this runs once per cell: 14 instructions, 35 before)
+                    const bool b4 = k >= psA.w;                                                        // e4
+                    const uint32_t m2 = b4 ? psB.y : psA.y;                                            // e6 : e2
+                    const bool b2 = k >= m2;
+                    const uint32_t m1 = b4 ? (b2 ? psB.z : psB.x) : (b2 ? psA.z : psA.x);              // e7 : e5 : e3 : e1
+                    const bool b1 = k >= m1;
+                    const uint32_t wv = (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
+                    const uint32_t lo2 = b4 ? psA.w : 0u;                                              // e4 : e0
+                    const uint32_t base = b1 ? m1 : (b2 ? m2 : lo2);                                   // e_wv
+#endif
                     const uint32_t kk = k - base;
                     uint32_t a = 0;  // largest lane with pcs[wv * 64 + lane] <= kk: the owner of cell kk (pcs ascends inside a
                                      // wavefront and lanes with empty runs share their successor's start)
@@ -1502,8 +1528,10 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 // and whether it just reached the tile's pruning threshold (then its bit in the candidate bitmap is set — a count crosses
 // the threshold once).  The scan after the tile only has to visit the set bits.
 #define SAGE_HIT(I, H, PEP, MZ, JJ)                                                                                  \
-    const bool hit##I##H = cpr##I != NONE32 && (JJ) >= p0_##I && (JJ) < p1_##I && (MZ) >= lo_##I && (MZ) <= hi_##I && \
-                           (PEP) >= first && (PEP) < end;                                                            \
+    /* (SAGE_HIT_RANGES=1: an empty slot has p0 == p1 and lo > hi; both ranges as one unsigned compare each) */       \
+    const bool hit##I##H = SAGE_HIT_RANGES ? ((JJ) - p0_##I < pl_##I && (MZ) >= lo_##I && (MZ) <= hi_##I && (PEP) - first < span_fe) \
+                                           : (cpr##I != NONE32 && (JJ) >= p0_##I && (JJ) < p1_##I && (MZ) >= lo_##I && (MZ) <= hi_##I && \
+                                              (PEP) >= first && (PEP) < end);                                       \
     const uint32_t x##I##H = hit##I##H ? (PEP) - tb_ : 0u;                                                           \
     /* no hit: add 0 to a counter word of this thread's own (distinct addresses, no branch, nothing changes) */       \
     const uint32_t old##I##H = atomicAdd(&l_cnt[hit##I##H ? x##I##H >> CSH : tid & idle_mask], hit##I##H ? 1u << ((x##I##H & (SPW - 1u)) * CBITS) : 0u);
@@ -1515,6 +1543,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         p0_##I = l_pp0[cpr##I];                                                 \
         p1_##I = l_pp1[cpr##I];                                                 \
     }                                                                           \
+    const uint32_t pl_##I = p1_##I - p0_##I;                                    \
     SAGE_HIT(I, a, ce##I.x, __uint_as_float(ce##I.y), cjj##I)                   \
     SAGE_HIT(I, b, ce##I.z, __uint_as_float(ce##I.w), cjj##I + 1)
 #define SAGE_ACCOUNT(I, H)                                                                             \
@@ -1556,7 +1585,9 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     static_assert(TILE_WAVES == 8, "psA / psB hold the eight wave totals");
                     psA = *(const uint4*)l_psum;
                     psB = *(const uint4*)(l_psum + 4);
-                    unit_cells = uni(psA.x + psA.y + psA.z + psA.w + psB.x + psB.y + psB.z + psB.w);
+                    psA.y += psA.x; psA.z += psA.y; psA.w += psA.z;  // running totals e1 .. e4
+                    psB.x += psA.w; psB.y += psB.x; psB.z += psB.y; psB.w += psB.z;  // e5 .. e7, the unit's total
+                    unit_cells = uni(psB.w);
                     if (pc.slot && tid == 0) {
                         const uint32_t pb = (u % nb) * TILE_THREADS;
                         if (!(sc.dbg_flags & 1024u)) {

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libsage_hip.so does not export {name}"
     assert sorted(L.EXPORTED_SYMBOLS) == declared
-    assert lib.sage_hip_abi_version() == 5
+    assert lib.sage_hip_abi_version() == 6
     assert C.sizeof(L.SageScorerParams) == 44 and L.FEATURE_DTYPE.itemsize == 120
 
 
