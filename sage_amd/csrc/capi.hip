@@ -896,34 +896,25 @@ static void* device_view(const void* p) {
     }
     return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
 }
-// ... remembered per thread for the last few pointers asked about: a caller that scores batch after batch into the same result
-// arrays (every step of a resident loop) otherwise pays two driver queries (~5 us each) in front of the step's first launch.
-// (Keyed by address: a buffer that is freed and another mapped at the same address would have to hit the same slot within the
-// same thread — sage_hip_host_free forgets the entry.)
-struct ViewCache {
-    const void* host[4] = {nullptr, nullptr, nullptr, nullptr};
-    void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned next = 0;
+// ... without asking the driver, for memory this library page-locked itself (sage_hip_host_alloc keeps a registry of its blocks: a
+// caller that scores batch after batch into the same result arrays — every step of a resident loop — otherwise pays two driver
+// queries, ~5 us each, in front of the step's first launch).  Only those blocks: for page-locked memory of any other origin the
+// library cannot know when it is unpinned or freed, so it asks every time.
+struct HostBlock {
+    const unsigned char* host;
+    unsigned char* dev;
+    size_t bytes;
 };
-static thread_local ViewCache g_views;
-static std::atomic<uint64_t> g_view_epoch{0};  // bumped by sage_hip_host_free: every thread's cache is stale
-static thread_local uint64_t g_view_seen = 0;
+static std::mutex g_blocks_mu;
+static std::vector<HostBlock> g_blocks;
 static void* device_view_cached(const void* p) {
     if (!p) return nullptr;
-    const uint64_t ep = g_view_epoch.load(std::memory_order_acquire);
-    if (ep != g_view_seen) {
-        g_views = ViewCache{};
-        g_view_seen = ep;
+    {
+        std::lock_guard<std::mutex> lock(g_blocks_mu);
+        for (const HostBlock& b : g_blocks)
+            if ((const unsigned char*)p >= b.host && (const unsigned char*)p < b.host + b.bytes) return b.dev + ((const unsigned char*)p - b.host);
     }
-    for (int i = 0; i < 4; i++)
-        if (g_views.host[i] == p) return g_views.dev[i];
-    void* d = device_view(p);
-    if (d) {  // (only page-locked memory is remembered: a pageable array may be page-locked later)
-        g_views.host[g_views.next & 3u] = p;
-        g_views.dev[g_views.next & 3u] = d;
-        g_views.next++;
-    }
-    return d;
+    return device_view(p);
 }
 static bool is_page_locked(const void* p) {
     if (!p) return false;
@@ -2234,11 +2225,23 @@ int sage_hip_debug_phase_cycles(SageScorer* s, unsigned long long* out32) {
 int sage_hip_host_alloc(uint64_t bytes, void** out) {
     if (!out) return fail(SAGE_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    if (void* d = device_view(*out)) {  // (device_view_cached's registry)
+        std::lock_guard<std::mutex> lock(g_blocks_mu);
+        g_blocks.push_back(HostBlock{(const unsigned char*)*out, (unsigned char*)d, (size_t)(bytes ? bytes : 1)});
+    }
     return SAGE_HIP_OK;
 }
 void sage_hip_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
-    g_view_epoch.fetch_add(1, std::memory_order_acq_rel);  // (device_view_cached: the address may come back as something else)
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_blocks_mu);
+        for (size_t i = 0; i < g_blocks.size(); i++)
+            if (g_blocks[i].host == (const unsigned char*)p) {
+                g_blocks.erase(g_blocks.begin() + (long)i);
+                break;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 int sage_hip_scorer_set_timing_interval(SageScorer* s, uint32_t every) {
