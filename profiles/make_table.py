@@ -10,7 +10,7 @@ print("| config | spectra (1 GPU) | spectra/s resident | sustained | ms/step | p
       "asked for by the kernels / moved from HBM (PMC) | fraction of 8 TB/s, same three counts (prelim phase) | host to host, page-locked | "
       "CPU port: best (threads), 1 thread | tied spectra re-run exactly |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
-for c in ("C3", "C2", "C4", "C5"):
+for c in ("C3", "C2", "C3T", "C4", "C5"):
     path = os.path.join(here, f"{tag}_{c}_bench.json")
     if not os.path.exists(path):
         continue
@@ -27,4 +27,6 @@ for c in ("C3", "C2", "C4", "C5"):
           f"{fr(p['frac'])} / {fr(p['frac_gpu_algorithm'])} / {fr(p['frac_traffic'])} | "
           f"{j['host_to_host_value']['page_locked'] / 1e6:.2f} M | "
           f"{cpu['value'] / 1e3:.1f} k ({cpu['cores']}), {cpu['threads_table']['1']['spectra_per_s'] / 1e3:.2f} k | "
-          f"{100.0 * rf['routing']['exact_retry_for_tied_hyperscores'] / n:.1f} % |")
+          f"{100.0 * rf['routing']['exact_retry_for_tied_hyperscores'] / n:.1f} % |" +
+          (f" issue slots {rf['frac_issue_slots']:.2f} ({rf['issue']['kernel'].split('<')[0]}); parity {j['parity']['spectra_checked']:,} spectra / "
+           f"{j['parity']['psms']:,} PSMs |" if rf.get("frac_issue_slots") is not None and j.get("parity") else ""))

@@ -1272,6 +1272,9 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 #ifndef SAGE_HIT_RANGES
 #define SAGE_HIT_RANGES 0
 #endif
+#ifndef SAGE_SCAN_SKIP
+#define SAGE_SCAN_SKIP 1  // (a wavefront without candidate bits in a tile skips the prefix sum of the scan: C4 -0.4 %, C5 -0.6 %)
+#endif
 #ifndef SAGE_LOCATE_LINEAR
 #define SAGE_LOCATE_LINEAR 1
 #endif
@@ -1682,7 +1685,10 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                     (void)bwt;
                     const uint32_t mine = (uint32_t)__popcll(mask);
-                    const uint32_t incl = wave_incl_scan_dpp(mine);
+                    // (past the first tiles of a window the pruning threshold leaves most wavefronts of most tiles without a single
+                    // candidate: no prefix sum then — SAGE_SCAN_SKIP)
+                    uint32_t incl = mine;
+                    if (!SAGE_SCAN_SKIP || __ballot(mine != 0u) != 0ull) incl = wave_incl_scan_dpp(mine);
                     const uint32_t excl = incl - mine;
                     const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     // this wavefront's run of candidates: one LDS atomic on the workgroup's bump pointer (room for a whole tile
