@@ -8,8 +8,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 here = os.path.dirname(os.path.abspath(__file__))
 print("| config | spectra (1 GPU) | spectra/s resident | sustained | ms/step | prelim / rescore ms | bytes/spectrum: reference algorithm (§8d) / "
       "asked for by the kernels / moved from HBM (PMC) | fraction of 8 TB/s, same three counts (prelim phase) | host to host, page-locked | "
-      "CPU port: best (threads), 1 thread | tied spectra re-run exactly |")
-print("|---|---|---|---|---|---|---|---|---|---|---|")
+      "CPU port: best (threads), 1 thread | tied spectra re-run exactly |" + (" issue slots of the dominant kernel; whole-workload parity |" if tag >= "r05" else ""))
+print("|---|---|---|---|---|---|---|---|---|---|---|" + ("---|" if tag >= "r05" else ""))
 for c in ("C3", "C2", "C3T", "C4", "C5"):
     path = os.path.join(here, f"{tag}_{c}_bench.json")
     if not os.path.exists(path):
