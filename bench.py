@@ -359,8 +359,11 @@ def measure_traffic(args, kernels=("prelim", "rescore")):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_WAVES"):
             d = os.path.join(tmp, ctr.split()[0])
             cmd = ["rocprofv3", "--pmc", *ctr.split(), "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config",
-                   args.config, "--spectra", str(n_spec), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
+                   args.config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
                    "--no-extras"] + (["--proteins", str(args.proteins)] if args.proteins else [])
+            # (a --slice run is profiled on the very shard it times: the whole run is generated and cut again in the child)
+            cmd += ["--slice", args.slice, "--shard-by", args.shard_by] + (["--spectra", str(args.spectra)] if args.spectra else []) \
+                if args.slice else ["--spectra", str(n_spec)]
             # (SAGE_HIP_WAYS=1: a step of this size would run as two parts — two dispatches per kernel, each over half the
             # spectra — and the largest dispatch below would no longer be the whole pass)
             env = dict(os.environ, TMPDIR="/tmp", SAGE_HIP_WAYS="1")
