@@ -162,3 +162,52 @@ def test_plan_mass_shards_properties():
                             rank_of[sh] = r
                         runs = 1 + int(np.count_nonzero(np.diff(rank_of[np.argsort(key, kind="stable")]) != 0))
                         assert runs <= 8 * 8
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import bench
+    from sage_amd.api import DatabaseParameters, ScorerParams, SpectrumBatch, SpectrumProcessor
+    from sage_amd.sharding import plan_mass_shards, precursor_sort_mass
+    from sage_amd.synthetic import synthetic_fasta, synthetic_spectra
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = DatabaseParameters(static_mods={"C": 57.0215}).build(synthetic_fasta(40, seed=5), peptides_only=True)
+    sp = SpectrumProcessor(150, True, 0.0)
+    whole = SpectrumBatch.from_spectra([sp.process(r) for r in synthetic_spectra(host, 203, seed=6)])  # (every rank: the same run)
+    params = ScorerParams()
+    lo, hi = whole.n * rank // world, whole.n * (rank + 1) // world  # ... of which a rank holds its contiguous span, as bench.py's ranks do
+    shard, index, n_total = bench.exchange_by_mass(whole.subset(np.arange(lo, hi)), params, host.pep_mono, rank, world, dist)
+    plan = plan_mass_shards(precursor_sort_mass(whole.precursor_mz, whole.precursor_charge, params), world)
+    want = whole.subset(plan[rank])
+    same = n_total == whole.n and np.array_equal(index, plan[rank]) and shard.n == want.n
+    for k in bench._BATCH_FIELDS:
+        a, b = getattr(shard, k), getattr(want, k)
+        same = same and ((a is None and b is None) or (a is not None and b is not None and a.tobytes() == b.tobytes()))
+    ok = [None] * world
+    dist.all_gather_object(ok, bool(same))
+    if rank == 0:
+        q.put(all(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_exchange_by_mass_hands_every_rank_its_planned_shard(world):
+    """bench.py's strong-scaling set-up without a GPU: every rank holds a contiguous span of THE run, the ranks agree on
+    sharding.plan_mass_shards from the exchanged masses and hand the spectra over through node-local files; each rank ends up with
+    exactly the planned shard — the same spectra, peaks and all, that a cut of the whole run would give it."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res is True
