@@ -116,7 +116,7 @@ def precursor_sort_mass(precursor_mz, precursor_charge, params):
     return (np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)) * z
 
 
-def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 16):
+def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 16, light_refine: int = 8):
     """Shards made of runs that are contiguous in PRECURSOR MASS, not in input position (VERDICT r04 task 2): the spectra are
     ordered by mass (stable: input position breaks ties), the ordered list is cut into world x blocks_per_rank blocks of equal
     cumulative work, and rank r scores one block of every stride of `world` blocks (the r-th, and in every other stride the r-th
@@ -129,7 +129,7 @@ def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int =
     65 000 spectra into the lightest octile and 82 000 into the heaviest, 0.79 / 0.54 / 1.05 ms per step for octiles 0 / 1 / 7);
     a rank that takes every world-th block samples the whole mass axis, so the shards balance whatever the cost profile, and a
     block of 1 / 64 of a run is still tens of times larger than the kernels' reuse distance.  blocks_per_rank=1 gives one range
-    per rank.  Returns `world` index arrays (global input positions, ascending inside a shard, so a shard's records keep their
+    per rank; light_refine: see below.  Returns `world` index arrays (global input positions, ascending inside a shard, so a shard's records keep their
     relative input order); they partition range(n)."""
     m = np.asarray(sort_mass, dtype=np.float64)
     n = len(m)
@@ -140,7 +140,18 @@ def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int =
     assert len(w) == n
     cum = np.cumsum(w[order])
     nb = world * max(1, int(blocks_per_rank))
-    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * k / nb, side="left")) for k in range(1, nb)] + [n]
+    # the lightest two strides of blocks are cut `light_refine` times finer: what a spectrum costs changes fastest at the light end of
+    # the axis (short peptides tie in hyperscore and pay for the replay of their heap: 2-3x the middle's cost below ~750 Da on C3),
+    # and a rank that holds a whole coarse block of it is the slowest shard (measured, 8 shards of C3, ms per step: slowest 0.659 /
+    # 0.654 / 0.649 with 1 / 4 / 8, profiles/r05_shard_sizes.txt section 11)
+    fr = [k / nb for k in range(1, nb)]
+    if light_refine > 1 and blocks_per_rank >= 4:
+        fine = [(k / light_refine) / nb for k in range(1, 2 * world * light_refine)]
+        fr = sorted(set(fine + [k / nb for k in range(2 * world, nb)]))
+        nb = len(fr) + 1
+        nb -= nb % world  # (whole strides only: the last few cuts of the fine part merge into their neighbours)
+        fr = fr[:nb - 1]
+    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * f, side="left")) for f in fr] + [n]
     cuts = np.maximum.accumulate(np.array(cuts))
     # boustrophedon: in every other stride of `world` blocks the ranks take their block in reverse order — a rank that always took
     # the r-th block of a stride would be systematically lighter than rank r + 1 (measured on C3 with 8 x 8 blocks: 0.629 ms for

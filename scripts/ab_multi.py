@@ -43,7 +43,8 @@ def child(cfg_name, path, sizes, steps, h2h):
                                 batch_all.isolation_lo, batch_all.isolation_hi)
             if n[0] in "mbec":  # m: one mass range per rank, equal estimated work; e: one range, equal counts; b / c: 8 strided blocks
                 idx = plan_mass_shards(precursor_sort_mass(batch_all.precursor_mz, batch_all.precursor_charge, params), w_,  # per rank (c: the default plan)
-                                       None if n[0] in "ec" else wts, blocks_per_rank=int(os.environ.get("AB_BLOCKS", "16")) if n[0] in "bc" else 1)[k_]
+                                       None if n[0] in "ec" else wts, blocks_per_rank=int(os.environ.get("AB_BLOCKS", "16")) if n[0] in "bc" else 1,
+                                       light_refine=int(os.environ.get("AB_LIGHT_REFINE", "1")))[k_]
             else:
                 b_, e_ = plan_shards(batch_all.peak_off, w_, wts)[k_]
                 idx = np.arange(b_, e_)

@@ -161,7 +161,7 @@ def test_plan_mass_shards_properties():
                         for r, sh in enumerate(shards):
                             rank_of[sh] = r
                         runs = 1 + int(np.count_nonzero(np.diff(rank_of[np.argsort(key, kind="stable")]) != 0))
-                        assert runs <= 8 * 8
+                        assert runs <= 8 * 8 + 2 * 8 * 8  # (+ the lightest two strides cut eight times finer)
 
 
 def _exchange_worker(rank, world, port, q):
