@@ -57,6 +57,53 @@ SAGE_HD void tol_bounds_sym(const Tol& t, bool symmetric, float center, float& l
     }
 }
 
+// ---- x / 1e6 and x / 3 without the IEEE division sequence (12 vector instructions on gfx950, v_rcp_f32 and the div_scale /
+// div_fmas / div_fixup trio among them): q0 = x * RN(1 / c); e = fma(-q0, c, x), the exact remainder; q = fma(e, RN(1 / c), q0).
+// For c = 1e6 and c = 3 the result is the correctly rounded quotient — the bits of `x / c` — for EVERY f32 x except +-inf (NaN
+// instead of inf), -0 (+0 instead of -0) and, for 1e6, 536 values of |x| <= 0x1.feb14ep-121: tests/hostemu/div_const_proof.c
+// walks all 2^32 inputs (tests/test_core_emulation.py runs it).  The callers use it only where the host has shown that every
+// dividend lies in FAST_DIV_LO <= |x| <= FAST_DIV_HI (capi.hip: scorer_tol_mode, from the range of the ion table and the
+// tolerance), far inside — no zero, no infinity, no denormal quotient, remainder or product on the way.
+constexpr float FAST_DIV_LO = 0x1p-60f, FAST_DIV_HI = 0x1p100f;
+SAGE_HD float div_const_fast(float x, float c, float rc) {
+    const float q0 = x * rc;
+    const float e = __builtin_fmaf(-q0, c, x);
+    return __builtin_fmaf(e, rc, q0);
+}
+SAGE_HD float div_1e6_fast(float x) { return div_const_fast(x, 1000000.0f, 1.0f / 1000000.0f); }
+SAGE_HD float div_3_fast(float x) { return div_const_fast(x, 3.0f, 1.0f / 3.0f); }
+
+// Tolerance::bounds as the rescoring kernels call it, once per (candidate ion, charge) that passed the bitmap, and the m/z of the
+// fragment at that charge.  FAST is a property of the kernel INSTANCE (kernels.hip: rescore_kernel<.., .., true>), chosen by the
+// host once per scorer (TOL_FAST of DevScorer::tol_mode): every division by 1e6 and by 3 takes the short form, and the instance
+// carries no IEEE sequence for them at all — a run-time choice between the two forms at the four call sites cost the kernel more
+// (registers, code) than the short form saves.  `symmetric`: lo == -hi of a ppm tolerance (one division: tol_bounds_sym).
+enum TolMode : uint32_t { TOL_SYM = 1u, TOL_FAST = 2u };
+template <bool FAST>
+SAGE_HD void tol_bounds_mode(const Tol& t, bool symmetric, float center, float& lo, float& hi) {
+    if (FAST && t.kind == 0) {
+        if (symmetric) {
+            const float d = div_1e6_fast(center * t.hi);
+            lo = center + -d;
+            hi = center + d;
+        } else {
+            lo = center + div_1e6_fast(center * t.lo);
+            hi = center + div_1e6_fast(center * t.hi);
+        }
+    } else {
+        tol_bounds_sym(t, symmetric, center, lo, hi);
+    }
+}
+// theoretical m/z of a fragment at charge c: monoisotopic_mass / charge as f32 (scoring.rs:707) — x / 1 and x / 2 are x and
+// x * 0.5 bit for bit
+template <bool FAST>
+SAGE_HD float fragment_mz(float ion, uint32_t c) {
+    if (c == 1) return ion;
+    if (c == 2) return ion * 0.5f;
+    if (FAST && c == 3) return div_3_fast(ion);
+    return ion / (float)c;
+}
+
 SAGE_HD Tol tol_scaled(const Tol& t, float rhs) {  // impl Mul<f32>, mass.rs:47-57
     Tol r;
     r.kind = t.kind;

@@ -89,6 +89,8 @@ struct DevScorer {
                          //    rescore_big_kernel) — also taken by a database with peptides of more than 1023 residues, whose
                          //    Run states need the two-register form (long_runs; core.h: run_matched_packed)
     uint32_t long_runs;  // 1: ion indices beyond 1023 occur
+    uint32_t tol_mode;   // core.h: TolMode bits — how the rescoring kernels may evaluate Tolerance::bounds of a fragment and the m/z of
+                         //    a charge-3 fragment (capi.hip: scorer_tol_mode)
     uint32_t list_cap;   // capacity (entries) of each of the two CLists
     uint32_t wcap;       // candidate-slot capacity of the LDS counter array of the narrow kernel: spectra with a
                          // larger precursor window go to the tiled large-window kernel
@@ -243,6 +245,7 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
                                  const float* d_mods, const float* d_nterm, const float* d_mono, uint64_t min_ion_index,
                                  const uint64_t* d_ion_off, const uint64_t* d_pm_off, float* d_ions, SageTheoretical* d_pm_frag,
                                  void* stream);
+int ion_abs_range_on_device(const float* d_ions, uint64_t n, uint32_t* lo_bits, uint32_t* hi_bits);
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
                               uint32_t* lut_stride_out, void* stream, int layout = 0);

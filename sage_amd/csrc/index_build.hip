@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheor
     if ((threadIdx.x & 63u) == 0 && v > 0.0f) atomicMax(out + (blockIdx.x & 255u), __float_as_uint(v));  // (256 slots: no hot address)
 }
 
+// smallest and largest |ion| of the rescoring table, as bit patterns (non-negative floats order like their bits; a NaN sorts above
+// +inf, so it shows in the maximum): out[0] = min, out[1] = max
+__global__ __launch_bounds__(256) void ion_range_kernel(uint64_t n, const float* __restrict__ ions, uint32_t* __restrict__ out) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = __float_as_uint(ions[i]) & 0x7FFFFFFFu;
+        lo = a < lo ? a : lo;
+        hi = a > hi ? a : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l = (uint32_t)__shfl_xor((int)lo, off, 64), h = (uint32_t)__shfl_xor((int)hi, off, 64);
+        lo = l < lo ? l : lo;
+        hi = h > hi ? h : hi;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMin(out, lo);
+        atomicMax(out + 1, hi);
+    }
+}
+
 }  // namespace
 
 #define BUILD_TRY(expr)                  \
@@ -155,6 +176,24 @@ __global__ __launch_bounds__(256) void maxmz_kernel(uint64_t nf, const SageTheor
     } while (0)
 
 // Both functions return a hipError_t; all pointers are device pointers.
+
+// The range of |ion| over the n entries of the rescoring table (bit patterns of f32; n == 0: {0xFFFFFFFF, 0}).
+int ion_abs_range_on_device(const float* d_ions, uint64_t n, uint32_t* lo_bits, uint32_t* hi_bits) {
+    uint32_t* d_out = nullptr;
+    uint32_t h[2] = {0xFFFFFFFFu, 0u};
+    BUILD_TRY(hipMalloc(&d_out, sizeof(h)));
+    hipError_t e = hipMemcpy(d_out, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(ion_range_kernel, dim3(grid), dim3(256), 0, 0, n, d_ions, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    *lo_bits = h[0];
+    *hi_bits = h[1];
+    return e;
+}
 
 // IonSeries of every peptide and kind -> d_ions; the stored subset -> d_pm_frag (peptide-major).  Buffers are the caller's.
 int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kinds, const uint64_t* d_seq_off, const uint8_t* d_seq,

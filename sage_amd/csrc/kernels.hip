@@ -2642,8 +2642,9 @@ __device__ __forceinline__ RescoreLds carve_rescore(unsigned char* scratch, unsi
 __device__ __forceinline__ uint32_t lane_run(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_lane); }
 __device__ __forceinline__ uint64_t lane_run(uint64_t v, uint32_t src_lane) { return lane_value(v, src_lane); }
 // LONG: the two Run states of a candidate in 64-bit registers (ion indices beyond 1023: core.h) — rescore_big_kernel's second
-// instance; every other caller keeps the one-register form.
-template <class PC, bool LONG = false>
+// instance; every other caller keeps the one-register form.  FAST: the short divisions (core.h: div_const_fast) — an instance of
+// rescore_kernel the host picks when it has bounded the dividends.
+template <class PC, bool LONG = false, bool FAST = false>
 __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
                                                  const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
@@ -2709,9 +2710,9 @@ __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevS
                 const float ionv = db.ions[base_L + j0 + lane];
 #define SAGE_COOP_LOOKUP(C, ON, OK, IT, TM)                                                              \
     if (ON) {                                                                                            \
-        const float mz = (C) == 1 ? ionv : ionv / (float)(C);                                            \
+        const float mz = fragment_mz<FAST>(ionv, (C));                                                   \
         float flo, fhi;                                                                                  \
-        tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);                                          \
+        tol_bounds_mode<FAST>(sc.fragment_tol, sym_tol, mz, flo, fhi);                                   \
         const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);                                \
         if (pk >= 0) {                                                                                   \
 const float peak_mass = pm[pk], peak_intensity = pi[pk];                                     \
@@ -2773,12 +2774,9 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             for (uint32_t c = 1; c <= nfz; c++) {
                 if (c <= 3 && !(((c == 1 ? m1 : c == 2 ? m2 : m3) >> bit) & 1ull)) continue;
                 // (x / 1.0 == x, x / 2.0 == x * 0.5 bit for bit: the IEEE division only for charges 3 and up; c is wave-uniform)
-                float mz;
-                if (c == 1) mz = ionv;
-                else if (c == 2) mz = ionv * 0.5f;
-                else mz = ionv / (float)c;
+                const float mz = fragment_mz<FAST>(ionv, c);
                 float flo, fhi;
-                tol_bounds_sym(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                tol_bounds_mode<FAST>(sc.fragment_tol, sym_tol, mz, flo, fhi);
                 const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
                 if (pk < 0) continue;
                 const float peak_mass = pm[pk], peak_intensity = pi[pk];
@@ -2943,7 +2941,7 @@ struct LateArgs<RescoreKernargs> {
     __device__ __forceinline__ uint8_t* keep(uint8_t*) const { return ka->keep; }
 };
 
-template <bool ACC, class KA, class PC>
+template <bool ACC, class KA, bool FAST = false, class PC>
 __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w,
                                                  const double* __restrict__ lnfact_table, uint32_t lnfact_n,
                                                  SageFeature* __restrict__ out, uint32_t* __restrict__ out_count,
@@ -2985,7 +2983,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
     double ln_lambda = 0.0;  // (cr_log_pair, first round)
     lds_sync();  // (the peaks are in LDS; the gathers above stay in flight)
     pc.mark(0);
-    const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
+    const bool sym_tol = (sc.tol_mode & TOL_SYM) != 0u;  // (core.h: TolMode — the host's, once per scorer)
     uint32_t nterm_mask = 0;  // bit k: ion kind k is a / b / c (counts towards matched_b, scoring.rs:727-731)
     for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
     uint32_t n_emitted = 0;
@@ -3033,8 +3031,8 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.ppm_difference = 0.0f;
         s.longest_b = s.longest_y = 0;
         pc.mark(5);  // (... the peak table and the bitmap)
-        score_candidates(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol, s, pc,
-                         SAGE_ION_PREFETCH && round == 0, first0, first1, first2, first3);
+        score_candidates<PC, false, FAST>(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol,
+                                          s, pc, SAGE_ION_PREFETCH && round == 0, first0, first1, first2, first3);
         pc.mark(1);  // (... the lanes' own hits)
         // ---- from here on: the arguments through `la`, the spectrum's scalars from R.hdr (see LateArgs) ----
         LateArgs<KA> la(db, sc, b, w, lnfact_table, lnfact_n, out, out_count);
@@ -3308,7 +3306,7 @@ __global__ __launch_bounds__(64) void rescore_big_kernel(DevDbView db, DevScorer
         const uint32_t fid = b.file_id ? b.file_id[spec] : 0;
         const uint32_t rounds = sc.chimera ? sc.report_psms : 1;
         const uint32_t per_round = sc.chimera ? 1 : sc.report_psms;
-        const bool sym_tol = sc.fragment_tol.lo == -sc.fragment_tol.hi;
+        const bool sym_tol = (sc.tol_mode & TOL_SYM) != 0u;
         uint32_t nterm_mask = 0;
         for (uint32_t k = 0; k < db.n_kinds; k++) nterm_mask |= (db.ion_kinds[k] <= 2 ? 1u : 0u) << k;
         const long long lowest = (long long)0x8000000000000000ull;
@@ -3455,7 +3453,8 @@ __host__ __device__ inline size_t narrow_scratch_bytes(const DevScorer& sc, cons
 // reported ranks tie in hyperscore is queued for the exact retry pass.  (Settling the tie here — the preliminary phase once more
 // with exact trims, inline or behind a call — was measured: the extra code costs the hot path its registers, rescoring went
 // from 3.7 to 6.0 resp. 7.2 ms per 500 000 C3 spectra.  DESIGN.md 4.7.)
-template <bool PROF, bool ACC>
+// FAST: the instance with the short divisions (core.h: div_const_fast), for scorers whose dividends the host has bounded.
+template <bool PROF, bool ACC, bool FAST = false>
 __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(RescoreKernargs A) {
     // (ONE argument: rescore_spectrum reads what it needs late straight from the kernarg segment — LateArgs<RescoreKernargs>)
     const DevDbView& db = A.db;
@@ -3503,8 +3502,8 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     }
     const uint64_t mine = lane < ncand ? row_word : PRESCORE_EMPTY;
     // (a list no trim touched is the reference's list already: equal hyperscores are ranked by it, no retry)
-    rescore_spectrum<ACC, RescoreKernargs>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, tot_m, tot_s,
-                     sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
+    rescore_spectrum<ACC, RescoreKernargs, FAST>(db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep, R, spec, P, mine, tot_m, tot_s,
+                                                 sc.exact != 0 || st == ST_OK_ORDERED, true, pc);
 }
 
 #ifdef SAGE_HIP_EXPERIMENTS  // (measured slower than the two kernels, DESIGN.md 4.7: compiled only into experiment builds)
@@ -3849,6 +3848,7 @@ int tile_kernel_prepare(size_t max_lds_bytes) {
 int spectrum_kernel_prepare(size_t max_lds_bytes) {
     for (const void* f : {(const void*)prelim_kernel<true, true>, (const void*)prelim_kernel<true, false>, (const void*)prelim_kernel<false, true>,
                           (const void*)prelim_kernel<false, false>, (const void*)rescore_kernel<true, true>, (const void*)rescore_kernel<false, false>,
+                          (const void*)rescore_kernel<false, false, true>,
                           (const void*)rescore_kernel<false, true>, (const void*)narrow_kernel<true, true>, (const void*)narrow_kernel<true, false>,
                           (const void*)narrow_kernel<false, true>, (const void*)narrow_kernel<false, false>, (const void*)annotate_kernel}) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
@@ -3975,7 +3975,10 @@ void launch_rescore(const DevDbView& db, const DevScorer& sc, const DevBatchView
         return;
     }
     // the first pass of a two-pass search (sc.fast_log) runs the instance with the logarithm's fast phase only (crlog.h)
-    const auto kern = w.dbg ? rescore_kernel<true, true> : (sc.fast_log && !keep) ? rescore_kernel<false, false> : rescore_kernel<false, true>;
+    // (the production instance comes in two forms: with the short divisions where the host allows them — DevScorer::tol_mode)
+    const auto kern = w.dbg ? rescore_kernel<true, true>
+                      : (sc.fast_log && !keep) ? ((sc.tol_mode & TOL_FAST) ? rescore_kernel<false, false, true> : rescore_kernel<false, false>)
+                                               : rescore_kernel<false, true>;
     const RescoreKernargs args{db, sc, b, w, lnfact_table, lnfact_n, out, out_count, keep};
     hipLaunchKernelGGL(kern, dim3(b.n), dim3(64), rescore_lds_bytes(sc, b, max_ions, keep != nullptr), (hipStream_t)stream, args);
 }

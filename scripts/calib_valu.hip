@@ -68,6 +68,58 @@ __global__ __launch_bounds__(64) void valu_kernel(uint32_t trips, float* sink, u
                              "s_load_dword %4, %8, 0x10\n\ts_load_dword %5, %8, 0x14\n\ts_load_dword %6, %8, 0x18\n\ts_load_dword %7, %8, 0x1c\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) : "s"(cycles) : "memory");
+            } else if (OP >= 20 && OP < 40) {  // round 5, second sheet: the integer / compare / conversion instructions rescore_kernel is made of
+#define U8(INSTR) asm volatile(INSTR(0) INSTR(1) INSTR(2) INSTR(3) INSTR(4) INSTR(5) INSTR(6) INSTR(7) \
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(u0 ^ 5u), "v"(k) : "vcc")
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n\t"
+#define I_LSHR(i) "v_lshrrev_b32 %" #i ", 1, %" #i "\n\t"
+#define I_ADDU(i) "v_add_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n\t"
+#define I_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 3, 5\n\t"
+#define I_CMP(i) "v_cmp_lt_u32 vcc, %" #i ", %8\n\t"
+#define I_CMPSEL(i) "v_cmp_lt_u32 vcc, %" #i ", %8\n\tv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
+#define I_CVT(i) "v_cvt_u32_f32 %" #i ", %" #i "\n\t"
+#define I_RCP(i) "v_rcp_f32 %" #i ", %" #i "\n\t"
+#define I_FFBL(i) "v_ffbl_b32 %" #i ", %" #i "\n\t"
+#define I_BCNT(i) "v_bcnt_u32_b32 %" #i ", %" #i ", %8\n\t"
+#define I_MBCNT(i) "v_mbcnt_lo_u32_b32 %" #i ", %" #i ", %8\n\t"
+#define I_MULF(i) "v_mul_f32 %" #i ", %" #i ", %9\n\t"
+#define I_MAXF(i) "v_max_f32 %" #i ", %" #i ", %9\n\t"
+#define I_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n\t"
+#define I_XOR3(i) "v_xad_u32 %" #i ", %" #i ", %8, %8\n\t"
+#define I_DSREAD(i) "ds_read_b32 %" #i ", %8\n\t"
+                if (OP == 20) U8(I_AND);
+                else if (OP == 21) U8(I_LSHR);
+                else if (OP == 22) U8(I_ADDU);
+                else if (OP == 23) U8(I_MULHI);
+                else if (OP == 24) U8(I_MULLO);
+                else if (OP == 25) U8(I_MAD24);
+                else if (OP == 26) U8(I_BFE);
+                else if (OP == 27) U8(I_CMP);
+                else if (OP == 28) U8(I_CMPSEL);  // (two instructions per item: the row counts 128 per group)
+                else if (OP == 29) U8(I_CVT);
+                else if (OP == 30) U8(I_RCP);
+                else if (OP == 31) U8(I_FFBL);
+                else if (OP == 32) U8(I_BCNT);
+                else if (OP == 33) U8(I_MBCNT);
+                else if (OP == 34) U8(I_MULF);
+                else if (OP == 35) U8(I_MAXF);
+                else if (OP == 36) U8(I_ADDCO);
+                else if (OP == 37) U8(I_XOR3);
+                else if (OP == 38) {  // LDS reads issued by the vector memory path: eight in flight, one wait
+                    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:256\n\tds_read_b32 %2, %8 offset:512\n\tds_read_b32 %3, %8 offset:768\n\t"
+                                 "ds_read_b32 %4, %8 offset:1024\n\tds_read_b32 %5, %8 offset:1280\n\tds_read_b32 %6, %8 offset:1536\n\tds_read_b32 %7, %8 offset:1792\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3), "=v"(u4), "=v"(u5), "=v"(u6), "=v"(u7) : "v"((uint32_t)threadIdx.x * 4u) : "memory");
+                } else {  // 39: 64-bit shift (two registers per operand: four accumulators, twice)
+                    uint64_t q0 = u0, q1 = u1, q2 = u2, q3 = u3;
+                    asm volatile("v_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %1, 1, %1\n\tv_lshlrev_b64 %2, 1, %2\n\tv_lshlrev_b64 %3, 1, %3\n\t"
+                                 "v_lshlrev_b64 %0, 1, %0\n\tv_lshlrev_b64 %1, 1, %1\n\tv_lshlrev_b64 %2, 1, %2\n\tv_lshlrev_b64 %3, 1, %3"
+                                 : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                    u0 = (uint32_t)q0 | 1u; u1 = (uint32_t)q1 | 1u; u2 = (uint32_t)q2 | 1u; u3 = (uint32_t)q3 | 1u;
+                }
             } else if (OP >= 10) {  // the rescoring kernel's MIX: eight v_fma_f32 + (OP - 10) s_add_u32 per group (64 : 0 / 16 / 32 / 48 / 64)
                 asm volatile("v_fma_f32 %0, %0, %8, %8\n\tv_fma_f32 %1, %1, %8, %8\n\tv_fma_f32 %2, %2, %8, %8\n\tv_fma_f32 %3, %3, %8, %8\n\t"
                              "v_fma_f32 %4, %4, %8, %8\n\tv_fma_f32 %5, %5, %8, %8\n\tv_fma_f32 %6, %6, %8, %8\n\tv_fma_f32 %7, %7, %8, %8"
@@ -110,16 +162,26 @@ int main() {
                       {"s_add_u32", 4, 0, 64}, {"v_readlane_b32", 5, 64, 0}, {"v_writelane_b32", 6, 64, 0}, {"s_load_dword (8 in flight + wait)", 7, 0, 64},
                       {"mix 64 v_fma_f32 + 0 s_add_u32", 10, 64, 0}, {"mix 64 v_fma_f32 + 16 s_add_u32", 12, 64, 16},
                       {"mix 64 v_fma_f32 + 32 s_add_u32", 14, 64, 32}, {"mix 64 v_fma_f32 + 48 s_add_u32", 16, 64, 48},
-                      {"mix 64 v_fma_f32 + 64 s_add_u32", 18, 64, 64}};
+                      {"mix 64 v_fma_f32 + 64 s_add_u32", 18, 64, 64},
+                      {"v_and_b32", 20, 64, 0}, {"v_lshrrev_b32", 21, 64, 0}, {"v_add_u32", 22, 64, 0}, {"v_mul_hi_u32", 23, 64, 0},
+                      {"v_mul_lo_u32", 24, 64, 0}, {"v_mad_u32_u24", 25, 64, 0}, {"v_bfe_u32", 26, 64, 0}, {"v_cmp_lt_u32", 27, 64, 0},
+                      {"v_cmp_lt_u32 + v_cndmask_b32", 28, 128, 0}, {"v_cvt_u32_f32", 29, 64, 0}, {"v_rcp_f32", 30, 64, 0}, {"v_ffbl_b32", 31, 64, 0},
+                      {"v_bcnt_u32_b32", 32, 64, 0}, {"v_mbcnt_lo_u32_b32", 33, 64, 0}, {"v_mul_f32", 34, 64, 0}, {"v_max_f32", 35, 64, 0},
+                      {"v_add_co_u32", 36, 64, 0}, {"v_xad_u32", 37, 64, 0}, {"ds_read_b32 (8 in flight + wait)", 38, 64, 0},
+                      {"v_lshlrev_b64", 39, 64, 0}};
+    const bool second_sheet_only = std::getenv("CALIB_SECOND_SHEET") != nullptr;
     std::printf("| instruction | waves/SIMD | instr per wave (vector + scalar) | wave cycles (s_memtime, median) | SIMD cycles per 64-instruction "
                 "group per wave (s_memtime) | wall ms | CU cycles per group at clockRate (wall), all four SIMDs busy |\n|---|---|---|---|---|---|---|\n");
     for (const Op& op : ops)
         for (int w : {1, 2, 4, 5, 8}) {
+            if (second_sheet_only && (op.id < 20 || (w != 1 && w != 5))) continue;
             const int blocks = n_simd * w;  // single-wavefront workgroups: the dispatcher deals them round-robin over CUs and SIMDs
             auto launch = [&]() {
                 switch (op.id) {
 #define CASE(N) case N: hipLaunchKernelGGL(valu_kernel<N>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
                     CASE(0) CASE(1) CASE(2) CASE(4) CASE(5) CASE(6) CASE(7) CASE(10) CASE(12) CASE(14) CASE(16) CASE(18)
+                    CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29) CASE(30) CASE(31) CASE(32)
+                    CASE(33) CASE(34) CASE(35) CASE(36) CASE(37) CASE(38) CASE(39)
 #undef CASE
                     default: hipLaunchKernelGGL(valu_kernel<3>, dim3(blocks), dim3(64), 0, 0, trips, sink, cyc); break;
                 }

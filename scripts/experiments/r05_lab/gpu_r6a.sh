@@ -1,0 +1,5 @@
+#!/bin/bash
+# the short divisions (core.h: div_const_fast) wired into the rescoring kernels: the new test, the suite, C3 with and without them
+OUT=gpurun_out/r6a; mkdir -p $OUT; export TMPDIR=/tmp
+( time timeout 900 python -m pytest tests -m gpu -q -x ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
+timeout 1200 python scripts/ab_multi.py C3 --sizes c0/8,500000 --steps 40 -- base:AB_TIMING_EVERY=4 base:AB_TIMING_EVERY=4,SAGE_HIP_TOL_MODE_MASK=1 base:AB_TIMING_EVERY=4 > $OUT/c3_div.txt 2>&1; cat $OUT/c3_div.txt

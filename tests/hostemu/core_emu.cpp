@@ -17,6 +17,15 @@ void emu_tol_bounds_sym(float thi, float center, float* lo, float* hi) {  // the
     Tol t{0, -thi, thi};
     tol_bounds_sym(t, t.lo == -t.hi, center, *lo, *hi);
 }
+// the rescoring kernels' forms (core.h: the FAST instance's short divisions)
+void emu_tol_bounds_mode(int kind, float tlo, float thi, uint32_t fast, float center, float* lo, float* hi) {
+    Tol t{kind, tlo, thi};
+    if (fast) tol_bounds_mode<true>(t, kind == 0 && tlo == -thi, center, *lo, *hi);
+    else tol_bounds_mode<false>(t, kind == 0 && tlo == -thi, center, *lo, *hi);
+}
+float emu_fragment_mz(float ion, uint32_t c, uint32_t fast) { return fast ? fragment_mz<true>(ion, c) : fragment_mz<false>(ion, c); }
+float emu_fast_div_lo() { return FAST_DIV_LO; }
+float emu_fast_div_hi() { return FAST_DIV_HI; }
 uint32_t emu_trim_k(uint64_t len, uint32_t report_psms) { return trim_k(len, report_psms); }
 uint32_t emu_max_fragment_charge(int user, uint32_t z) { return max_fragment_charge(user, z); }
 int32_t emu_order_key(float f) { return order_key(f); }

@@ -25,6 +25,11 @@ def emu():
     lib = C.CDLL(LIB)
     lib.emu_tol_bounds.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]
     lib.emu_tol_bounds_sym.argtypes = [C.c_float, C.c_float, f32p, f32p]
+    lib.emu_tol_bounds_mode.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_float, f32p, f32p]
+    lib.emu_fragment_mz.restype = C.c_float
+    lib.emu_fragment_mz.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
+    lib.emu_fast_div_lo.restype = C.c_float
+    lib.emu_fast_div_hi.restype = C.c_float
     lib.emu_trim_k.restype = C.c_uint32
     lib.emu_trim_k.argtypes = [C.c_uint64, C.c_uint32]
     lib.emu_max_fragment_charge.restype = C.c_uint32
@@ -254,6 +259,70 @@ def test_symmetric_ppm_shortcut_is_bit_identical_to_tolerance_bounds(emu):
             emu.emu_tol_bounds_sym(thi, float(c), fp(lo2), fp(hi2))
             for a, b in ((lo1, lo2), (hi1, hi2)):
                 assert a.view(np.uint32)[0] == b.view(np.uint32)[0] or (np.isnan(a[0]) and np.isnan(b[0])), (thi, float(c))
+
+
+def test_short_divisions_are_the_ieee_quotient_for_every_dividend(emu, tmp_path):
+    """core.h: div_const_fast — x / 1e6 and x / 3 as reciprocal multiply + two fused multiply-adds, what the rescoring kernels use
+    for Tolerance::bounds (mass.rs:21-35) and charge-3 fragments (scoring.rs:707) where the host has bounded the dividends
+    (capi.hip: scorer_tol_mode).  tests/hostemu/div_const_proof.c compares it with the IEEE division for ALL 2^32 dividends; what
+    differs must be exactly: -0 (sign of the zero), +-inf (NaN), and for 1e6 a few hundred values far below FAST_DIV_LO."""
+    flags = open("/proc/cpuinfo").read()
+    if " fma" not in flags or " avx2" not in flags:
+        pytest.skip("the exhaustive pass takes minutes without a hardware fused multiply-add")
+    exe = str(tmp_path / "div_const_proof")
+    subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", os.path.join(HERE, "hostemu", "div_const_proof.c"),
+                           "-o", exe, "-lm"])
+    out = subprocess.check_output([exe], text=True, timeout=1200).strip().splitlines()
+    rows = {}
+    for line in out:
+        kv = dict(item.split("=") for item in line.split())
+        rows[float(kv["c"])] = kv
+    assert sorted(rows) == [3.0, 1e6]
+    lo, hi = emu.emu_fast_div_lo(), emu.emu_fast_div_hi()
+    assert 0.0 < lo < 1e-15 and 1e25 < hi < np.inf
+    for c, kv in rows.items():
+        assert int(kv["zero_sign_only"]) == 1 and int(kv["infinite"]) == 2, kv           # -0.0; +inf and -inf
+        largest = float.fromhex(kv["largest_finite_abs_x"])
+        assert largest < lo * 2.0 ** -50, kv                                              # nothing near the range the kernels use
+    assert int(rows[3.0]["differ"]) == 3 and 3 < int(rows[1e6]["differ"]) < 1000
+
+
+def test_rescoring_tolerance_modes_are_tolerance_bounds(emu):
+    """tol_bounds_mode / fragment_mz of the rescoring instance with the short divisions (core.h: FAST) against Tolerance::bounds and
+    the plain division, bit for bit, over the range of dividends the host admits — its edges included."""
+    rng = np.random.default_rng(77)
+    lo_edge, hi_edge = emu.emu_fast_div_lo(), emu.emu_fast_div_hi()
+    centres = np.concatenate([rng.uniform(50.0, 6000.0, 3000), 10.0 ** rng.uniform(-3, 8, 1500), -rng.uniform(50.0, 6000.0, 100),
+                              np.float32(147.11281) * np.arange(1, 40)]).astype(np.float32)
+    lo1, hi1, lo2, hi2 = (np.zeros(1, np.float32) for _ in range(4))
+    same = lambda a, b: a.view(np.uint32)[0] == b.view(np.uint32)[0]
+    for tlo, thi in ((-10.0, 10.0), (-20.0, 5.0), (5.0, 20.0), (-50.0, 10.0), (-0.37, 0.37), (-1e4, 333.333), (-2.5e5, 1e6)):
+        for fast in (1, 0):
+            for c in centres:
+                emu.emu_tol_bounds(0, tlo, thi, float(c), fp(lo1), fp(hi1))
+                emu.emu_tol_bounds_mode(0, tlo, thi, fast, float(c), fp(lo2), fp(hi2))
+                assert same(lo1, lo2) and same(hi1, hi2), (tlo, thi, fast, float(c))
+    # dividends at the edges of the admitted range (centre x bound = FAST_DIV_LO .. FAST_DIV_HI), a few thousand each
+    for edge, bound in ((lo_edge, 1e-3), (hi_edge, 1e6)):
+        base = np.float32(edge / bound)
+        scale = rng.uniform(1.0, 4.0, 2000) if edge == lo_edge else rng.uniform(0.25, 1.0, 2000)
+        for c in base * scale.astype(np.float32):
+            emu.emu_tol_bounds(0, -bound, bound, float(c), fp(lo1), fp(hi1))
+            emu.emu_tol_bounds_mode(0, -bound, bound, 1, float(c), fp(lo2), fp(hi2))
+            assert same(lo1, lo2) and same(hi1, hi2), (bound, float(c))
+    # kinds other than ppm have no division by 1e6 to shorten
+    for kind, tlo, thi in ((1, -0.5, 0.5), (2, -0.3, 0.3), (2, 0.01, 0.3)):
+        for c in centres[::50]:
+            emu.emu_tol_bounds(kind, tlo, thi, float(c), fp(lo1), fp(hi1))
+            emu.emu_tol_bounds_mode(kind, tlo, thi, 1, float(c), fp(lo2), fp(hi2))
+            assert same(lo1, lo2) and same(hi1, hi2)
+    ions = np.concatenate([centres, [lo_edge, hi_edge, np.float32(3.0), np.float32(1e-17), np.float32(2.9999998)]]).astype(np.float32)
+    for ion in ions:
+        for z in (1, 2, 3, 4, 5, 7):
+            want = np.float32(ion) / np.float32(z)
+            for fast in (0, 1):
+                got = np.float32(emu.emu_fragment_mz(float(ion), z, fast))
+                assert got.view(np.uint32) == want.view(np.uint32), (float(ion), z, fast)
 
 
 def test_position_table_windows_need_no_safety_margin(emu):

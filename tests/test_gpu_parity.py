@@ -130,6 +130,28 @@ def test_rescoring_with_and_without_cooperative_matching(small_world, monkeypatc
                           f"coop flags={flags}: ±0.6 Da fragments, chimera")
 
 
+def test_rescoring_with_short_and_ieee_divisions(small_world, monkeypatch):
+    """Tolerance::bounds (mass.rs:21-35) and the m/z of charge-3 fragments (scoring.rs:707) in the rescoring kernel: the instance
+    with the short division forms (core.h: div_const_fast; opt-in, SAGE_HIP_SHORT_DIVISIONS=1) where the host has bounded the
+    dividends (capi.hip: scorer_tol_mode — ppm tolerances with non-zero bounds over a sane ion table), the IEEE sequence otherwise
+    (a zero bound) and by default.  Same Features either way — the oracle's."""
+    for short in (None, "1"):
+        if short:
+            monkeypatch.setenv("SAGE_HIP_SHORT_DIVISIONS", short)
+        small_world.check(ScorerParams(report_psms=1), f"short={short}: ppm[-10, 10]")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("ppm", -20.0, 5.0)), f"short={short}: ppm[-20, 5]")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("ppm", 0.0, 20.0)), f"short={short}: ppm[0, 20] (a zero bound)")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("pct", -0.002, 0.002)), f"short={short}: pct")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("da", -0.02, 0.02), max_fragment_charge=3, override_precursor_charge=True,
+                                       min_precursor_charge=4, max_precursor_charge=4, precursor_tol=Tolerance("da", -2.0, 2.0)),
+                          f"short={short}: Da fragments, fragment charges 1..3")
+        small_world.check(ScorerParams(max_fragment_charge=4, override_precursor_charge=True, min_precursor_charge=4,
+                                       max_precursor_charge=5, precursor_tol=Tolerance("da", -3.0, 3.0),
+                                       fragment_tol=Tolerance("ppm", -15.0, 15.0)), f"short={short}: fragment charges 1..4")
+        small_world.check(ScorerParams(chimera=True, report_psms=3, fragment_tol=Tolerance("ppm", -7.0, 12.0), max_fragment_charge=3),
+                          f"short={short}: chimera, ppm[-7, 12]")
+
+
 def test_report_psms_and_score_types(small_world):
     small_world.check(ScorerParams(report_psms=5, precursor_tol=Tolerance("ppm", -50.0, 50.0)), "report_psms=5")
     small_world.check(ScorerParams(score_type="OpenMSHyperScore", min_matched_peaks=2), "OpenMS score")
