@@ -1280,40 +1280,50 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 #endif
     // cells a thread keeps in flight: the u8 instance runs 6 wavefronts per SIMD in 80 VGPRs, the u16 one 4 in 128
     constexpr uint32_t CPT = C8 ? SAGE_TILE8_CELLS : CELLS_PER_THREAD;
-    const DevDbView& db = kp.db;
-    const DevScorer& sc = kp.sc;
-    const DevBatchView& b = kp.b;
+    // Arguments where they are used (the ArgRef idea of prelim_kernel): the four views are ~110 scalar registers' worth of pointers
+    // and parameters in a kernel that has 100 and keeps a dozen phase-local scalars live per tile.  Read once at the entry they were
+    // spilled to VGPR lanes at once and read back tile after tile — v_readlane / scratch loads inside the tile loop, vector-ALU issue
+    // slots of a kernel that is bound by exactly those (round 5: 143 scalar + 33 vector spills, 128 bytes of scratch).  A kernel's
+    // arguments never need saving: they sit in the kernarg segment, one scalar load away.  `ka` is that segment behind a pointer the
+    // compiler cannot see through; TILE_ARGS() re-derives it at the head of every phase, so the loads stay in the phase that uses them.
+    typedef const __attribute__((address_space(4))) TileParams* Segment;
+    Segment ka = (Segment)__builtin_amdgcn_kernarg_segment_ptr();
+#define TILE_ARGS()                                               \
+    do {                                                          \
+        ka = (Segment)__builtin_amdgcn_kernarg_segment_ptr();     \
+        asm volatile("" : "+s"(ka));                              \
+    } while (0)
+    TILE_ARGS();
     // entries per query of `seeds` (the u8 instance only runs in the two-pass production mode, never with report_psms > 32)
     const uint32_t kstride = C8 ? WAVE : kp.w.kstride;
-    const DevWork& w = kp.w;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool w0 = wave == 0;
-    const uint32_t n_queued = uni(w.n_deferred[CTR_QUEUED]);
+    const uint32_t n_queued = uni(ka->w.n_deferred[CTR_QUEUED]);
     if (n_queued == 0) return;
     // (the LDS arrays as plain locals: a struct of pointers captured by the lambdas below would live in scratch memory)
     TileLds lds_;
-    tile_lds_layout(db.tile_shift, b, &lds_, smem, C8, WING);
+    tile_lds_layout(kp.db.tile_shift, kp.b, &lds_, smem, C8, WING);
     uint32_t* const l_cnt = lds_.cnt;
     uint32_t* const l_bm = lds_.bm;
     // (WING: this workgroup's slice of DevWork::winbuf — global memory, written and read by the wavefronts of one workgroup
     // between workgroup barriers; the compute unit's L1 is theirs alone)
-    float* const l_win_lo = WING ? kp.w.winbuf + (size_t)blockIdx.x * 2 * b.fzcap * b.pcap : lds_.win_lo;
-    float* const l_win_hi = WING ? l_win_lo + (size_t)b.fzcap * b.pcap : lds_.win_hi;
+    float* const l_win_lo = WING ? kp.w.winbuf + (size_t)blockIdx.x * 2 * kp.b.fzcap * kp.b.pcap : lds_.win_lo;
+    float* const l_win_hi = WING ? l_win_lo + (size_t)kp.b.fzcap * kp.b.pcap : lds_.win_hi;
     uint32_t* const l_hist = lds_.hist;
     uint32_t* const l_sh = lds_.sh;
     uint32_t* const l_pp0 = lds_.pp0;
     uint32_t* const l_pp1 = lds_.pp1;
     uint32_t* const l_pcs = lds_.pcs;
     uint32_t* const l_psum = lds_.psum;
-    const uint32_t TSH = db.tile_shift, TS = 1u << TSH;
+    const uint32_t TSH = ka->db.tile_shift, TS = 1u << TSH;
     // counter words (SPW slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [SPW * tid * wpt, ...), so thread
     // order == slot order.  tile_shift 15, u16: 32 words = eight 16-byte quads per thread.
     const uint32_t wpt = (TS / SPW + TILE_THREADS - 1) / TILE_THREADS;
-    const uint32_t ovf_at = (sc.dbg_flags & 16u) ? 2u : 254u;  // (SAGE_HIP_DEBUG_FLAGS=16: tests send every slot with 3+ matches through the overflow path)
+    const uint32_t ovf_at = (ka->sc.dbg_flags & 16u) ? 2u : 254u;  // (SAGE_HIP_DEBUG_FLAGS=16: tests send every slot with 3+ matches through the overflow path)
     const uint32_t idle_mask = (TS / SPW < TILE_THREADS ? TS / SPW : TILE_THREADS) - 1u;  // (word a thread without a hit adds 0 to)
-    const bool fold = sc.min_isotope_err != sc.max_isotope_err;  // scoring.rs:391
-    const int isoA = fold ? sc.min_isotope_err : 0, isoB = fold ? sc.max_isotope_err : 0;
-    const uint4* __restrict__ frag2 = (const uint4*)db.tm_frag;  // two entries per 16-byte load
+    const bool fold = ka->sc.min_isotope_err != ka->sc.max_isotope_err;  // scoring.rs:391
+    const int isoA = fold ? ka->sc.min_isotope_err : 0, isoB = fold ? ka->sc.max_isotope_err : 0;
+    const uint4* __restrict__ frag2 = (const uint4*)ka->db.tm_frag;  // two entries per 16-byte load
 
     for (uint32_t i = tid; i < TS / SPW; i += TILE_THREADS) l_cnt[i] = 0;  // all-zero between tiles: every scan clears them
     for (uint32_t i = tid; i < TS / 32; i += TILE_THREADS) l_bm[i] = 0;
@@ -1324,8 +1334,8 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         const uint32_t cur = l_sh[SH_CHUNK_CUR], lim = l_sh[SH_CHUNK_LIM];
         if (l_sh[SH_ARENA_OK] && lim - cur >= need) return;
         const uint32_t chunk = need > ARENA_CHUNK ? need : ARENA_CHUNK;
-        const uint32_t got = atomicAdd(w.arena_ptr, chunk);
-        const bool fits = (uint64_t)got + chunk <= w.arena_cap;
+        const uint32_t got = atomicAdd(ka->w.arena_ptr, chunk);
+        const bool fits = (uint64_t)got + chunk <= ka->w.arena_cap;
         l_sh[SH_CHUNK_CUR] = fits ? got : 0;
         l_sh[SH_CHUNK_LIM] = fits ? got + chunk : 0;
         l_sh[SH_ARENA_OK] = fits ? 1u : 0u;
@@ -1337,56 +1347,59 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) l_sh[SH_ITEM] = atomicAdd(w.n_deferred + CTR_QUEUE_HEAD, 1u);
+        TILE_ARGS();
+        if (tid == 0) l_sh[SH_ITEM] = atomicAdd(ka->w.n_deferred + CTR_QUEUE_HEAD, 1u);
         __syncthreads();
         const uint32_t item = uni(l_sh[SH_ITEM]);
         if (item >= n_queued) break;
-        const uint32_t spec = uni(w.queue[item]);
+        const uint32_t spec = uni(ka->w.queue[item]);
         // Retry pass of a two-pass search (DevWork::reuse): the first pass counted this spectrum already and its records —
         // QueryRec, verbatim head, candidate directory in the arena, all of them independent of the trim mode — are still
         // there, in the slot item_of[spec] names.  Only a spectrum whose u8 counters might have wrapped (bit 31) is counted
         // again, in u16, into the same slot.
         uint32_t slot = item;
-        if (w.reuse) {
-            const uint32_t v = uni(w.item_of[spec]);
+        if (ka->w.reuse) {
+            const uint32_t v = uni(ka->w.item_of[spec]);
             if (!(v >> 31)) continue;
             slot = v & 0x7FFFFFFFu;
         }
         PhaseClock pc;
-        pc.start(w0 ? w.dbg : nullptr, item, 2);
-        const SpecInfo si = load_spec(sc, b, spec);
+        pc.start(w0 ? ka->w.dbg : nullptr, item, 2);
+        const SpecInfo si = load_spec(kp.sc, kp.b, spec);
         const uint32_t P = si.P;
-        const float* __restrict__ masses = b.masses + si.p0;
+        const float* __restrict__ masses = ka->b.masses + si.p0;
+        const Tol ftol_ = SAGE_LOAD_TOL(ka->sc.fragment_tol);
         for (uint32_t i = tid; i < P; i += TILE_THREADS) {  // database.rs:481 on peak*charge (scoring.rs:360)
             const float m = masses[i];
             for (uint32_t fz = 1; fz <= si.nfz_max; fz++) {
                 float lo, hi;
-                tol_bounds(sc.fragment_tol, m * (float)fz, lo, hi);
+                tol_bounds(ftol_, m * (float)fz, lo, hi);
                 l_win_lo[(size_t)(fz - 1) * P + i] = lo;  // stride P: the array index IS the window number fz * P + i
                 l_win_hi[(size_t)(fz - 1) * P + i] = hi;
             }
         }
-        if (tid < w.qmax) w.qrec[(size_t)slot * w.qmax + tid].potential = 0;  // queries this spectrum does not run
+        if (tid < ka->w.qmax) ka->w.qrec[(size_t)slot * ka->w.qmax + tid].potential = 0;  // queries this spectrum does not run
 
         for (uint32_t z = si.z0; z <= si.z1; z++) {
-            const uint32_t nfz = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+            const uint32_t nfz = max_fragment_charge(ka->sc.max_fragment_charge, z) - 1;
             const uint32_t nprobe = P * (nfz < si.nfz_max ? nfz : si.nfz_max);
             const float precursor_mass = si.mzp * (float)z;
-            const Tol ptol = sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : sc.precursor_tol;
+            const Tol ptol = ka->sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : SAGE_LOAD_TOL(ka->sc.precursor_tol);
             for (int iso = isoA; iso <= isoB; iso++) {
-                const size_t qid = (size_t)slot * w.qmax + query_index(sc, si, z, iso);
+                TILE_ARGS();
+                const size_t qid = (size_t)slot * ka->w.qmax + query_index(kp.sc, si, z, iso);
                 // ---- IndexedDatabase::query by wavefront 0, shared through LDS; the query's candidate directory ----
                 if (w0) {
                     // (through the position table of the peptide masses, like the narrow kernel since round 4: 3 dependent round trips
                     // instead of ~9 while the other seven wavefronts wait — a third of this kernel's time per spectrum in a wide-window
                     // search, whose three charge-state queries span one or two tiles each: scripts/tile_probe.py wide)
-                    const Window q = query_window<false>(db.pep_mono, db.np, ptol, precursor_mass - (float)iso * NEUTRON, db.pep_lut,
-                                                         db.pep_lut_bins, db.pep_lut_inv_w);  // scoring.rs:344
+                    const Window q = query_window<false>(ka->db.pep_mono, ka->db.np, ptol, precursor_mass - (float)iso * NEUTRON, ka->db.pep_lut,
+                                                         ka->db.pep_lut_bins, ka->db.pep_lut_inv_w);  // scoring.rs:344
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
                         l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0; l_sh[SH_NCAND] = 0;
-                        const uint32_t lp = q.right < db.np ? q.right : db.np - 1;
-                        const uint32_t nt = db.np ? (lp >> TSH) - (q.left >> TSH) + 1 : 1;
+                        const uint32_t lp = q.right < ka->db.np ? q.right : ka->db.np - 1;
+                        const uint32_t nt = ka->db.np ? (lp >> TSH) - (q.left >> TSH) + 1 : 1;
                         const uint32_t words = (nt * TILE_WAVES * DIR_WORDS + 3u) & ~3u;
                         refill(words + TS + 8u);
                         uint32_t dir = NONE32;
@@ -1394,18 +1407,18 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             dir = l_sh[SH_CHUNK_CUR];
                             l_sh[SH_CHUNK_CUR] = dir + words;
                         } else {
-                            atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
+                            atomicAdd(ka->w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
                         }
                         l_sh[SH_DIR] = dir;
                     }
                     l_hist[lane] = 0;
-                    for (uint32_t i = lane; i < kstride; i += WAVE) w.seeds[qid * kstride + i] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
+                    for (uint32_t i = lane; i < kstride; i += WAVE) ka->w.seeds[qid * kstride + i] = 0;  // (the scan of any wavefront may overwrite these: the __syncthreads below drains them first)
                 }
                 __syncthreads();  // also orders win_lo/win_hi and the previous query's reads of sh[]
                 const uint32_t left = uni(l_sh[SH_LEFT]), right = uni(l_sh[SH_RIGHT]), first = uni(l_sh[SH_FIRST]), end = uni(l_sh[SH_END]);
                 const uint32_t dir = uni(l_sh[SH_DIR]);
                 const uint32_t potential = right - left + 1;  // scoring.rs:351
-                const uint32_t k = trim_k(potential, sc.report_psms);
+                const uint32_t k = trim_k(potential, ka->sc.report_psms);
                 const bool select = potential > k;
                 const uint32_t nseed = select ? k : potential;  // slots kept verbatim (<= 64)
                 uint32_t acc = 0;
@@ -1419,12 +1432,12 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                 };
                 auto probe_cells = [&](float lo, float hi, uint32_t& icl, uint32_t& ich) {
-                    lut_cells(lo, hi, db.lut_scale, db.lut_stride, icl, ich);
+                    lut_cells(lo, hi, ka->db.lut_scale, ka->db.lut_stride, icl, ich);
                 };
                 pc.mark(0);
                 const uint32_t span_fe = end > first ? end - first : 0u;  // (peptides [first, end): `p - first < span_fe`)
-                const uint32_t last_pep = right < db.np ? right : db.np - 1;  // slot `right == np` has no peptide behind it
-                const uint32_t t0 = left >> TSH, t1 = db.np ? (last_pep >> TSH) : 0;
+                const uint32_t last_pep = right < ka->db.np ? right : ka->db.np - 1;  // slot `right == np` has no peptide behind it
+                const uint32_t t0 = left >> TSH, t1 = ka->db.np ? (last_pep >> TSH) : 0;
                 // ---- stream: scoring.rs:358-375 over database.rs:480-536 --------------------------------------------------
                 // The work of a tile is its RUNS — for every (peak, fragment charge) window the index entries of the tile whose
                 // m/z falls into the window's table cells — and run lengths are extremely skewed: fragment masses sit in narrow
@@ -1454,7 +1467,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         probe_cells(lo, hi, icl, ich);
                         qa = qb = make_uint4(0u, 0u, 0u, 0u);
                         if (tid < nprobe && first < end && lo <= hi) {
-                            const uint4* __restrict__ lut4 = (const uint4*)db.tm_lut + (size_t)(t >> 2) * db.lut_stride;
+                            const uint4* __restrict__ lut4 = (const uint4*)ka->db.tm_lut + (size_t)(t >> 2) * ka->db.lut_stride;
                             qa = lut4[icl];
                             qb = lut4[ich];
                         }
@@ -1468,8 +1481,8 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     probe_bounds(pr, lo, hi);
                     probe_cells(lo, hi, icl, ich);
                     if (pr < nprobe && first < end && lo <= hi) {
-                        np0 = db.tm_lut[tm_lut_index(t, icl, db.n_tiles, db.lut_stride)];
-                        np1 = db.tm_lut[tm_lut_index(t, ich, db.n_tiles, db.lut_stride)];
+                        np0 = ka->db.tm_lut[tm_lut_index(t, icl, ka->db.n_tiles, ka->db.lut_stride)];
+                        np1 = ka->db.tm_lut[tm_lut_index(t, ich, ka->db.n_tiles, ka->db.lut_stride)];
                     }
                 };
                 // cells of the CURRENT unit in flight — named scalars, not arrays (arrays captured by the lambdas below end up in
@@ -1593,7 +1606,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     unit_cells = uni(psB.w);
                     if (pc.slot && tid == 0) {
                         const uint32_t pb = (u % nb) * TILE_THREADS;
-                        if (!(sc.dbg_flags & 1024u)) {
+                        if (!(ka->sc.dbg_flags & 1024u)) {
                             pc.bytes(DBG_TILE_LUT, 8ull * (nprobe - pb < TILE_THREADS ? nprobe - pb : TILE_THREADS));
                             pc.bytes(DBG_TILE_CELLS, 16ull * unit_cells);
                         }
@@ -1607,6 +1620,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 }
                 uint32_t trans = 0, t01 = 0, t12 = 0, t23 = 0;  // slots this thread moved from count 0 -> 1, 1 -> 2, 2 -> 3 (histogram transitions)
                 for (uint32_t u = 0; u < n_units; u++) {
+                    TILE_ARGS();
                     const uint32_t t = t0 + u / nb;
                     const uint32_t tb = t << TSH;
                     // the tile's pruning threshold (wavefront 0 derived it from the histogram of all EARLIER tiles, see below):
@@ -1646,6 +1660,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     pc.mark(1);
                     lds_barrier();  // every hit of the unit is counted; its run table is free
                     pc.mark(2);
+                    TILE_ARGS();
                     if (u + 1 < n_units) {
                         publish(u + 1);
                         const uint32_t kbase_ = 0;
@@ -1653,16 +1668,17 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                     if (!last_unit) continue;  // (more windows of this tile to come)
                     pc.mark(3);
+                    TILE_ARGS();
                     // ---- the NEXT tile's threshold, by wavefront 0: the histogram now holds every slot up to this tile and
                     //      stays put until the next tile's hits (two barriers away).  The k-th largest count so far is a lower
                     //      bound of the heap minimum for every later slot.
                     if (w0) {
-                        uint32_t suffix = l_hist[lane];
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const uint32_t o = __shfl_down(suffix, off, 64);
-                            if ((int)lane + off < 64) suffix += o;
-                        }
+                        // slots with count >= lane: the suffix sum as total - inclusive prefix + own (DPP scan: no LDS-crossbar trips —
+                        // six dependent ds_bpermute of ~100 cycles each stood here, once per tile, on the wavefront the other seven
+                        // wait for at the next barrier)
+                        const uint32_t hown = l_hist[lane];
+                        const uint32_t hincl = wave_incl_scan_dpp(hown);
+                        const uint32_t suffix = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63) - hincl + hown;
                         const uint64_t ok = __ballot(lane >= 1 && suffix >= k);
                         const uint32_t hmin = ok ? 63u - (uint32_t)__clzll((long long)ok) : 0u;
                         if (lane == 0) l_sh[SH_THR] = hmin > 1 ? hmin : 1;
@@ -1702,16 +1718,16 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                                 if (l_sh[SH_ARENA_OK]) {
                                     at = atomicAdd(&l_sh[SH_CHUNK_CUR], (wave_total + 3u) & ~3u);
                                 } else {  // the global arena ran out between two tiles: candidates are dropped, the host is told
-                                    atomicAdd(w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
+                                    atomicAdd(ka->w.n_deferred + CTR_ARENA_OVERFLOW, 1u);
                                     at = NONE32;
                                     n_out = 0;
                                 }
                             }
                             const uint32_t d = dir + ((t - t0) * TILE_WAVES + wave) * DIR_WORDS;
-                            w.arena[d] = at;
-                            w.arena[d + 1] = n_out;
+                            ka->w.arena[d] = at;
+                            ka->w.arena[d + 1] = n_out;
                             if (n_out) atomicAdd(&l_sh[SH_NCAND], n_out);
-                            if (w.dbg) atomicAdd(w.dbg + (size_t)(item % DBG_BLOCKS) * 32 + DBG_TILE_CAND, 4ull * n_out + 8ull);
+                            if (ka->w.dbg) atomicAdd(ka->w.dbg + (size_t)(item % DBG_BLOCKS) * 32 + DBG_TILE_CAND, 4ull * n_out + 8ull);
                         }
                         run_at = uni(at);
                     }
@@ -1738,14 +1754,14 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             const uint32_t c = (cs[i] >> ((xs[i] & (SPW - 1u)) * CBITS)) & CMAX;
                             const uint64_t g = (uint64_t)tb + xs[i] - left;  // candidate slot
                             // (the verbatim head of the window is written below from the counters; here it leaves a hole)
-                            w.arena[pos++] = g < nseed ? 0u : (c << 16) | xs[i];
+                            ka->w.arena[pos++] = g < nseed ? 0u : (c << 16) | xs[i];
                         }
                         while (m) {
                             const uint32_t x = x_base + (uint32_t)__ffsll((long long)m) - 1;
                             m &= m - 1;
                             const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
                             const uint64_t g = (uint64_t)tb + x - left;
-                            w.arena[pos++] = g < nseed ? 0u : (c << 16) | x;
+                            ka->w.arena[pos++] = g < nseed ? 0u : (c << 16) | x;
                         }
                     }
                     // the first min(k, potential) slots of the window go to the k-select verbatim, whatever their count
@@ -1756,11 +1772,12 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             if (gx >= left && gx - left < nseed && x_lo + i < TS) {
                                 const uint32_t x = x_lo + i;
                                 const uint32_t c = (l_cnt[x >> CSH] >> ((x & (SPW - 1u)) * CBITS)) & CMAX;
-                                if (c) w.seeds[qid * kstride + (gx - left)] = (uint16_t)c;
+                                if (c) ka->w.seeds[qid * kstride + (gx - left)] = (uint16_t)c;
                             }
                         }
                     }
                     pc.mark(4);
+                    TILE_ARGS();
                     // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them)
                     {
                         const uint32_t w_lo = tid * wpt;
@@ -1789,6 +1806,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 #undef SAGE_ACCOUNT
 #undef SAGE_HIT
 #undef SAGE_FOR_CELLS
+                TILE_ARGS();
                 // ---- totals of this query ----
                 acc = wave_sum_dpp(acc);
                 if (lane == 0 && acc) atomicAdd(&l_sh[SH_MATCHED], acc);
@@ -1797,17 +1815,13 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     // the k-th largest count T of the whole window and how many of the slots equal to T (the first ones) do
                     // NOT make the cut: all an order-free trim_hits needs (tile_select_kernel)
                     const uint32_t hmine = l_hist[lane];
-                    uint32_t suffix = hmine;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t o = __shfl_down(suffix, off, 64);
-                        if ((int)lane + off < 64) suffix += o;
-                    }
+                    const uint32_t hincl = wave_incl_scan_dpp(hmine);
+                    const uint32_t suffix = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63) - hincl + hmine;
                     const uint64_t okm = __ballot(lane >= 1 && suffix >= k);
-                    const uint32_t T = okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u;
-                    const uint32_t n_gt = __shfl(suffix, (int)(T + 1 < 64 ? T + 1 : 63), 64);
-                    const uint32_t n_eq = T ? __shfl(hmine, (int)(T < 64 ? T : 63), 64) : 0;
-                    const uint32_t big = __shfl(hmine, 63, 64) != 0;  // some slot matched >= 63 peaks: bins are clipped
+                    const uint32_t T = uni(okm ? 63u - (uint32_t)__clzll((long long)okm) : 0u);
+                    const uint32_t n_gt = (uint32_t)__builtin_amdgcn_readlane((int)suffix, (int)(T + 1 < 64 ? T + 1 : 63));
+                    const uint32_t n_eq = T ? (uint32_t)__builtin_amdgcn_readlane((int)hmine, (int)(T < 64 ? T : 63)) : 0;
+                    const uint32_t big = (uint32_t)__builtin_amdgcn_readlane((int)hmine, 63) != 0;  // some slot matched >= 63 peaks: bins are clipped
                     if (lane == 0) {
                         QueryRec r;
                         r.left = left;
@@ -1822,13 +1836,15 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         r.n_dir = dir != NONE32 ? (t1 - t0 + 1) * TILE_WAVES : 0;
                         r.t0 = t0;
                         r.n_cand = l_sh[SH_NCAND];
-                        w.qrec[qid] = r;
+                        ka->w.qrec[qid] = r;
                     }
                 }
             }
         }
     }
 }
+
+#undef TILE_ARGS
 
 __global__ __launch_bounds__(TILE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void tile_count_kernel(const TileParams kp) {
     extern __shared__ __align__(16) unsigned char smem[];
