@@ -1270,7 +1270,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
 // predicates: -1 % (57.0 ms), the default now; with the one-compare ranges: 0.  Fewer instructions buy nothing here unless the
 // register allocation holds still.
 #ifndef SAGE_HIT_RANGES
-#define SAGE_HIT_RANGES 0
+#define SAGE_HIT_RANGES 1  // (round 6, with the arguments out of the registers: the allocation holds still — 64 / 18 spills either way —, C4 -1 %, C5 -0.7 %)
 #endif
 #ifndef SAGE_SCAN_SKIP
 #define SAGE_SCAN_SKIP 1  // (a wavefront without candidate bits in a tile skips the prefix sum of the scan: C4 -0.4 %, C5 -0.6 %)
@@ -1638,6 +1638,12 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             t01 += trans & 0xFFu; t12 += (trans >> 8) & 0xFFu; t23 += (trans >> 16) & 0xFFu; trans = 0;
                         }
                         for (uint32_t kbase_ = CPT * TILE_THREADS; kbase_ < unit_cells; kbase_ += CPT * TILE_THREADS) {
+                            // (the wave totals again from LDS — still the published unit's —, so that the eight registers they
+                            // take are dead across the apply phase above instead of spilled around it)
+                            psA = *(const uint4*)l_psum;
+                            psB = *(const uint4*)(l_psum + 4);
+                            psA.y += psA.x; psA.z += psA.y; psA.w += psA.z;
+                            psB.x += psA.w; psB.y += psB.x; psB.z += psB.y; psB.w += psB.z;
                             SAGE_FOR_CELLS(SAGE_LOAD_CELL)  // (a unit with more cells than fit in flight: the rest synchronously)
                             SAGE_FOR_CELLS(SAGE_APPLY_CELL)
                             SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)
