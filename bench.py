@@ -231,19 +231,36 @@ def generate_workload(cfg, host, total, seed_shift=0, workers=None, span=None):
     return batch, np.concatenate([p[2] for p in parts])
 
 
-def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
+def shared_directory(dist, rank, coll_device):
+    """A fresh directory every rank of this launch agrees on: rank 0 makes it (tempfile.mkdtemp — unique per launch, whatever
+    MASTER_PORT is reused), its path goes round as a fixed-size byte tensor through ONE broadcast — a plain tensor collective
+    like the barrier and the max-over-ranks, nothing that pickles.  The ranks of a bench.py launch share a node (the driver's
+    contract: --nnodes=1)."""
+    import torch
+    buf = torch.zeros(512, dtype=torch.uint8)
+    if rank == 0:
+        path = tempfile.mkdtemp(prefix="sage_bench_xchg_").encode()
+        assert len(path) < 512
+        buf[:len(path)] = torch.tensor(list(path), dtype=torch.uint8)
+    buf = buf.to(coll_device)
+    dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().tolist()).rstrip(b"\0").decode()
+
+
+def exchange_by_mass(batch, params, pep_mono, rank, world, xchg):
     """Strong scaling, --shard-by mass: every rank has generated a contiguous span of THE run; the ranks agree on
     sharding.plan_mass_shards over the whole run (per-spectrum sort mass exchanged: 8 bytes per spectrum) and
     hand each other the spectra through node-local files (the ranks of one node — the driver's contract; workload distribution
     before the timed region, not a data-path collective: a search process that reads the mzML itself, cli.py --devices, cuts its
-    in-memory spectrum list instead).  Returns (this rank's shard, the global input positions of its spectra, spectra in the run)."""
+    in-memory spectrum list instead).  `xchg`: a sharding.FileExchange over the launch's shared directory — the only thing this
+    needs from torch.distributed is its barrier.  Returns (this rank's shard, the global input positions of its spectra, spectra
+    in the run)."""
     import numpy as np
 
     from sage_amd.api import SpectrumBatch
     from sage_amd.sharding import plan_mass_shards, precursor_sort_mass
     mass = precursor_sort_mass(batch.precursor_mz, batch.precursor_charge, params)
-    parts = [None] * world
-    dist.all_gather_object(parts, (rank, mass))
+    parts = xchg.all_gather((rank, mass), "mass")
     parts.sort(key=lambda p: p[0])
     sizes = [len(p[1]) for p in parts]
     base = int(sum(sizes[:rank]))
@@ -251,19 +268,18 @@ def exchange_by_mass(batch, params, pep_mono, rank, world, dist):
     # (equal spectrum counts per block: a rank takes every world-th block of the mass axis, so its blocks sample every mass and
     # the shards balance without a cost model — sharding.plan_mass_shards)
     plan = plan_mass_shards(np.concatenate([p[1] for p in parts]), world)
-    xdir = os.path.join(tempfile.gettempdir(), f"sage_bench_xchg_{os.environ.get('MASTER_PORT', '0')}")
-    os.makedirs(xdir, exist_ok=True)
+    xdir = xchg.dir
     for j in range(world):
         mine = plan[j][(plan[j] >= base) & (plan[j] < base + batch.n)]
         sub = batch.subset(mine - base)
         np.savez(os.path.join(xdir, f"from{rank}_to{j}.npz"), index=mine,
                  **{k: getattr(sub, k) for k in _BATCH_FIELDS if getattr(sub, k) is not None})
-    dist.barrier()
+    xchg.barrier()
     got = []
     for i in range(world):
         z = np.load(os.path.join(xdir, f"from{i}_to{rank}.npz"))
         got.append((z["index"], SpectrumBatch(*[z[k] if k in z.files else None for k in _BATCH_FIELDS])))
-    dist.barrier()
+    xchg.barrier()
     for j in range(world):
         try:
             os.unlink(os.path.join(xdir, f"from{rank}_to{j}.npz"))
@@ -521,15 +537,26 @@ def main():
     dev = DeviceDatabase(host, local_rank, build_on_device=True)  # index_build.hip: the fragment index is generated in HBM
     t_dev = time.time() - t0
     scorer = Scorer(dev, params)
-    if world > 1 and args.scaling == "strong" and args.shard_by == "mass":
-        batch, my_index, n_run = exchange_by_mass(batch, params, host.pep_mono, rank, world, dist)
-    dbatch = scorer.upload(batch)  # inputs resident in HBM before the timed region
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Host-side exchanges between the ranks (the mass plan and the spectra before the timed region, the ordered gather of the records
+    # after it) go through files in a directory of this launch — sharding.FileExchange: the only collectives a run depends on are
+    # tensor ones (this broadcast, the barrier, the max / sum over ranks).
+    xchg = None
+    t_exchange = 0.0
+    if world > 1:
+        from sage_amd.sharding import FileExchange
+        xchg = FileExchange(shared_directory(dist, rank, coll_device), rank, world, barrier)
+    if world > 1 and args.scaling == "strong" and args.shard_by == "mass":
+        t0 = time.perf_counter()
+        batch, my_index, n_run = exchange_by_mass(batch, params, host.pep_mono, rank, world, xchg)
+        t_exchange = time.perf_counter() - t0
+    dbatch = scorer.upload(batch)  # inputs resident in HBM before the timed region
 
     retry_ms = []
 
@@ -627,21 +654,22 @@ def main():
                       "value": total_spectra * per_thread * n_threads / e3}
         del handles
 
+    # how many ranks took part, as counted by the exchange itself (every rank reads every rank's file): in the line as n_ranks_seen
+    ranks_seen = len(xchg.all_gather(int(batch.n), "alive")) if xchg is not None else 1
     # ---- strong scaling: ordered gather of the ranks' records, checked against rank 0's own pass over everything ----
     sharding = None
     if world > 1 and args.scaling == "strong":
         from sage_amd.sharding import gather_features, gather_features_by_index
         t0 = time.perf_counter()
-        sizes = [None] * world
-        dist.all_gather_object(sizes, int(batch.n))
+        sizes = xchg.all_gather(int(batch.n), "sizes")
         if my_index is not None:  # shards by precursor mass: a permutation back into input order
-            gf, gc = gather_features_by_index(feats, counts, my_index, n_run)
+            gf, gc = gather_features_by_index(feats, counts, my_index, n_run, exchange=xchg)
             shards = [(0, n_run)]  # (not ranges of the input: sharding.spectra_per_rank has the counts)
         else:
             lo = int(sum(sizes[:rank]))
             hi = lo + int(batch.n)
             shards = [(int(sum(sizes[:r])), int(sum(sizes[:r + 1]))) for r in range(world)]
-            gf, gc = gather_features(feats, counts, lo)  # host-side, input order, spec_index rebased
+            gf, gc = gather_features(feats, counts, lo, exchange=xchg)  # host-side, input order, spec_index rebased
         t_gather = time.perf_counter() - t0
         if rank == 0:
             whole_conn.send("go")
@@ -656,8 +684,8 @@ def main():
             rf, rc = ref_scorer.score(batch_all)  # the N = 1 result, through the streaming entry point
             same = same_psms(gf, gc, rf, rc)
             sharding = {"shard_by": args.shard_by if args.scaling == "strong" else None, "spectra_per_rank": [int(x) for x in sizes],
-                        "shards": [list(s_) for s_ in shards], "gather_s": t_gather, "psms": int(gc.sum()),
-                        "identical_to_single_gpu": same}
+                        "shards": [list(s_) for s_ in shards], "gather_s": t_gather, "exchange_by_mass_s": t_exchange,
+                        "n_ranks_seen": int(xchg.ranks_seen), "psms": int(gc.sum()), "identical_to_single_gpu": same}
             if not same:
                 raise SystemExit(f"bench.py: the gathered {world}-GPU result differs from the single-GPU result")
 
@@ -901,12 +929,16 @@ def main():
             "host_link": link,  # measured link rates and the host-to-host ceiling they imply for this workload
             "pcie_inclusive_value": extras.get("page_locked") if extras else None,
             "sharding": sharding,
+            "n_ranks_seen": ranks_seen,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
+        if rank == 0 and xchg is not None:
+            import shutil
+            shutil.rmtree(xchg.dir, ignore_errors=True)
         dist.destroy_process_group()
 
 

@@ -116,7 +116,7 @@ def precursor_sort_mass(precursor_mz, precursor_charge, params):
     return (np.asarray(precursor_mz, dtype=np.float64) - float(PROTON)) * z
 
 
-def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 16, light_refine: int = 8):
+def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int = 16, light_refine: int = 1):
     """Shards made of runs that are contiguous in PRECURSOR MASS, not in input position (VERDICT r04 task 2): the spectra are
     ordered by mass (stable: input position breaks ties), the ordered list is cut into world x blocks_per_rank blocks of equal
     cumulative work, and rank r scores one block of every stride of `world` blocks (the r-th, and in every other stride the r-th
@@ -140,17 +140,21 @@ def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int =
     assert len(w) == n
     cum = np.cumsum(w[order])
     nb = world * max(1, int(blocks_per_rank))
-    # the lightest two strides of blocks are cut `light_refine` times finer: what a spectrum costs changes fastest at the light end of
-    # the axis (short peptides tie in hyperscore and pay for the replay of their heap: 2-3x the middle's cost below ~750 Da on C3),
-    # and a rank that holds a whole coarse block of it is the slowest shard (measured, 8 shards of C3, ms per step: slowest 0.659 /
-    # 0.654 / 0.649 with 1 / 4 / 8, profiles/r05_shard_sizes.txt section 11)
+    # light_refine > 1 (NOT the default since round 6): the lightest two strides of blocks cut that many times finer.  Round 5 fitted it
+    # on C3 — what a spectrum costs changes fastest at the light end of the axis, and the slowest of eight shards went from 0.659 to
+    # 0.649 ms per step with 8 — and made it the default; held against workloads it was not fitted on (profiles/r06_shard_sizes.txt:
+    # slowest / mean shard of eight, plain | refined: C3 1.034 | 1.020, the tie-rich C3T 1.010 | 1.014, C2 within the noise of a
+    # 0.15 ms step) it buys a per cent on the workload it came from and nothing elsewhere: a constant of one benchmark, so the plan
+    # is back to equal blocks.  The snake order below and "every rank samples the whole axis" are what balance the shards.
     fr = [k / nb for k in range(1, nb)]
     if light_refine > 1 and blocks_per_rank >= 4:
-        fine = [(k / light_refine) / nb for k in range(1, 2 * world * light_refine)]
-        fr = sorted(set(fine + [k / nb for k in range(2 * world, nb)]))
+        # (cut positions as integers over the common denominator nb * light_refine: no two equal floats to deduplicate, and the
+        # block count stays a multiple of `world` by construction — ADVICE r05)
+        den = nb * light_refine
+        nums = sorted(set(range(1, 2 * world * light_refine)) | set(k * light_refine for k in range(2 * world, nb)))
+        fr = [k / den for k in nums]
         nb = len(fr) + 1
-        nb -= nb % world  # (whole strides only: the last few cuts of the fine part merge into their neighbours)
-        fr = fr[:nb - 1]
+        assert nb % world == 0, (nb, world)
     cuts = [0] + [int(np.searchsorted(cum, cum[-1] * f, side="left")) for f in fr] + [n]
     cuts = np.maximum.accumulate(np.array(cuts))
     # boustrophedon: in every other stride of `world` blocks the ranks take their block in reverse order — a rank that always took
@@ -161,20 +165,67 @@ def plan_mass_shards(sort_mass, world: int, weights=None, blocks_per_rank: int =
     return [np.sort(np.concatenate([order[cuts[b]:cuts[b + 1]] for b in blocks_of(r)])).astype(np.int64) for r in range(world)]
 
 
-def gather_features_by_index(feats: np.ndarray, counts: np.ndarray, index: np.ndarray, n_total: int, group=None):
+class FileExchange:
+    """all_gather of Python objects between the ranks of ONE node through files in a directory they share, with nothing but a
+    barrier from torch.distributed (bench.py hands its RCCL barrier in).  torch's all_gather_object pickles into device tensors and
+    runs two collectives per call; this is the plumbing-proof alternative for the few host-side exchanges of a multi-GPU run (the
+    mass plan before the timed region, the ordered gather of the records after it — `runner.rs:325`'s collect()): an exchange that
+    cannot fail on a communicator's object path.  Every rank writes `<tag>_<rank>.pkl` (atomically: rename), all wait, every rank
+    reads all `world` files, all wait, every rank removes its own."""
+
+    def __init__(self, directory: str, rank: int, world: int, barrier):
+        self.dir, self.rank, self.world, self.barrier = directory, int(rank), int(world), barrier
+        self.calls = 0
+        self.ranks_seen = 0  # files read by the last all_gather (== world, or the call raised)
+        self.seconds = 0.0   # wall time spent in all_gather calls so far
+
+    def all_gather(self, obj, tag: str = "x"):
+        import os
+        import pickle
+        import time
+        t0 = time.perf_counter()
+        name = f"{tag}{self.calls}"
+        self.calls += 1
+        mine = os.path.join(self.dir, f"{name}_{self.rank}.pkl")
+        with open(mine + ".tmp", "wb") as fh:
+            pickle.dump(obj, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(mine + ".tmp", mine)
+        self.barrier()
+        out = []
+        for r in range(self.world):
+            with open(os.path.join(self.dir, f"{name}_{r}.pkl"), "rb") as fh:
+                out.append(pickle.load(fh))
+        self.ranks_seen = len(out)
+        self.barrier()
+        try:
+            os.unlink(mine)
+        except OSError:
+            pass
+        self.seconds += time.perf_counter() - t0
+        return out
+
+
+def _all_gather(obj, group, exchange):
+    """torch.distributed.all_gather_object, or the node-local file exchange when one is handed in"""
+    if exchange is not None:
+        return exchange.all_gather(obj, "gather")
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, obj, group=group)
+    return parts
+
+
+def gather_features_by_index(feats: np.ndarray, counts: np.ndarray, index: np.ndarray, n_total: int, group=None, exchange=None):
     """The gather for shards that are NOT contiguous in the input (plan_mass_shards): rank r holds (features[n_r, report],
     counts[n_r]) of the spectra at global input positions index[n_r]; every rank gets the whole result in input order — the
     reference's `collect()` order (runner.rs:325) — with spec_index rebased to the global batch.  A permutation on the host,
-    no reduction; torch.distributed (RCCL on GPUs, gloo on CPU) only carries the records."""
-    import torch.distributed as dist
+    no reduction; torch.distributed (RCCL on GPUs, gloo on CPU) — or `exchange`, a FileExchange — only carries the records."""
     f = feats.copy()
     index = np.asarray(index, dtype=np.int64)
     assert len(index) == len(counts) == f.shape[0]
     valid = np.arange(f.shape[1])[None, :] < counts[:, None]
     f["spec_index"] = np.where(valid, index[:, None].astype(np.uint32), f["spec_index"])
-    world = dist.get_world_size(group)
-    parts = [None] * world
-    dist.all_gather_object(parts, (index, f, counts), group=group)
+    parts = _all_gather((index, f, counts), group, exchange)
     out_f = np.zeros((n_total, f.shape[1]), dtype=f.dtype)
     out_c = np.zeros(n_total, dtype=counts.dtype)
     seen = np.zeros(n_total, dtype=bool)
@@ -191,15 +242,13 @@ def shard_indices(peak_off: np.ndarray, rank: int, world: int) -> np.ndarray:
     return np.arange(b, e)
 
 
-def gather_features(feats: np.ndarray, counts: np.ndarray, begin: int, group=None):
+def gather_features(feats: np.ndarray, counts: np.ndarray, begin: int, group=None, exchange=None):
     """Gather per-rank (features[n_r, report], counts[n_r]) to every rank, concatenated in input order, with
-    spec_index rebased to the global batch.  Uses torch.distributed (RCCL on GPUs, gloo on CPU); host-side only."""
-    import torch.distributed as dist
+    spec_index rebased to the global batch.  Uses torch.distributed (RCCL on GPUs, gloo on CPU) or `exchange` (a FileExchange);
+    host-side only."""
     f = feats.copy()
     valid = np.arange(f.shape[1])[None, :] < counts[:, None]  # slots beyond counts[i] stay zeroed
     f["spec_index"][valid] += np.uint32(begin)
-    world = dist.get_world_size(group)
-    parts = [None] * world
-    dist.all_gather_object(parts, (begin, f, counts), group=group)
+    parts = _all_gather((begin, f, counts), group, exchange)
     parts.sort(key=lambda p: p[0])
     return np.concatenate([p[1] for p in parts], axis=0), np.concatenate([p[2] for p in parts], axis=0)

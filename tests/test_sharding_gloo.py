@@ -179,17 +179,30 @@ def _exchange_worker(rank, world, port, q):
     whole = SpectrumBatch.from_spectra([sp.process(r) for r in synthetic_spectra(host, 203, seed=6)])  # (every rank: the same run)
     params = ScorerParams()
     lo, hi = whole.n * rank // world, whole.n * (rank + 1) // world  # ... of which a rank holds its contiguous span, as bench.py's ranks do
-    shard, index, n_total = bench.exchange_by_mass(whole.subset(np.arange(lo, hi)), params, host.pep_mono, rank, world, dist)
+    # (as bench.py does it: a directory of the launch agreed on through one tensor broadcast, then files + barriers only)
+    from sage_amd.sharding import FileExchange, gather_features_by_index
+    xchg = FileExchange(bench.shared_directory(dist, rank, "cpu"), rank, world, dist.barrier)
+    shard, index, n_total = bench.exchange_by_mass(whole.subset(np.arange(lo, hi)), params, host.pep_mono, rank, world, xchg)
     plan = plan_mass_shards(precursor_sort_mass(whole.precursor_mz, whole.precursor_charge, params), world)
     want = whole.subset(plan[rank])
     same = n_total == whole.n and np.array_equal(index, plan[rank]) and shard.n == want.n
     for k in bench._BATCH_FIELDS:
         a, b = getattr(shard, k), getattr(want, k)
         same = same and ((a is None and b is None) or (a is not None and b is not None and a.tobytes() == b.tobytes()))
-    ok = [None] * world
-    dist.all_gather_object(ok, bool(same))
+    # ... and the ordered gather through the same exchange gives what torch's own object collective gives
+    from sage_amd import _lib as L
+    f = np.zeros((shard.n, 1), dtype=L.FEATURE_DTYPE)
+    f["peptide_idx"][:, 0] = (index % 97).astype(np.uint32)
+    c = (index % 2).astype(np.uint32)
+    gf1, gc1 = gather_features_by_index(f, c, index, n_total, exchange=xchg)
+    gf2, gc2 = gather_features_by_index(f, c, index, n_total)
+    same = same and gf1.tobytes() == gf2.tobytes() and gc1.tobytes() == gc2.tobytes() and xchg.ranks_seen == world
+    same = same and np.array_equal(gc1, (np.arange(n_total) % 2).astype(np.uint32))
+    ok = xchg.all_gather(bool(same), "ok")
     if rank == 0:
-        q.put(all(ok))
+        import shutil
+        shutil.rmtree(xchg.dir, ignore_errors=True)
+        q.put(all(ok) and len(ok) == world)
     dist.barrier()
     dist.destroy_process_group()
 
