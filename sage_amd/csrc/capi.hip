@@ -211,9 +211,10 @@ struct SageScorer {
     uint32_t ways = 0;               // SAGE_HIP_WAYS=1..4; 0: by batch size (score_resident_locked).  Measured on C3: two parts
                                      // -1 % wall at 500 000 spectra, -6 % at 62 500, nothing more with three or four
     hipStream_t way_stream[3] = {nullptr, nullptr, nullptr};
-    Event way_fork, way_join[3], way_begin, way_end;
+    Event way_fork, way_join[3], way_begin, way_end[4];  // (way_end[p]: behind the last command of part p)
     DevBuf<uint32_t> win_max;   // exact_window_check's result word
-    bool retry_likely = false;  // the last resident step had spectra to retry: the next one launches its retry pass unconditionally
+    bool retry_likely = true;   // the last resident step had spectra to retry (or there was none yet): the next one launches its
+                                // retry pass unconditionally
     // per-kernel HIP events of a step (SageTiming::prelim_ms / rescore_ms / retry_ms): on every `timing_every`-th scoring call
     // (sage_hip_scorer_set_timing_interval; 1: every call, 0: never).  Eight event records and six elapsed-time queries cost a
     // 0.65 ms step ~15 us; a step without them reports the last timed step's kernel times.
@@ -821,7 +822,7 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     HIP_TRY(s->way_fork.create(false));
     for (Event& e : s->way_join) HIP_TRY(e.create(false));
     HIP_TRY(s->way_begin.create(true));
-    HIP_TRY(s->way_end.create(true));
+    for (Event& e : s->way_end) HIP_TRY(e.create(true));
     HIP_TRY(s->side_fork.create(false));
     HIP_TRY(s->side_join.create(false));
     for (OutSet& o : s->outs) {
@@ -1541,7 +1542,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
                (size_t)s->kstride * 8 > cap || getenv("SAGE_HIP_FORCE_HUGE") != nullptr;  // (tests force the workspace on small lists)
     }
     const size_t lds_p = sc.big_path ? prelim_lds_bytes(sc, view, huge)
-                                     : std::max(production ? std::max(narrow_lds_bytes(sc, view), search_lds_bytes(sc, view)) : (size_t)0, prelim_lds_bytes(sc, view)),
+                                     : std::max(production ? std::max(narrow_lds_bytes(sc, view), one_launch ? search_lds_bytes(sc, view) : (size_t)0) : (size_t)0, prelim_lds_bytes(sc, view)),
                  lds_r = rescore_lds_bytes(sc, view, s->db->max_ions, true, huge);
     // the large-window count kernel keeps a window per (peak, fragment charge) in LDS next to a tile's counters; when that does not
     // fit a compute unit, the instance with the windows in global memory takes the batch (tile_count_wing_kernel)
@@ -1556,7 +1557,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
                                    "fragment charges): lower report_psms or narrow the charge / isotope-error ranges"
                                  : "spectrum too large for the LDS of a compute unit (~15 000 peaks per processed spectrum): lower max_peaks");
     if (huge) {
-        const size_t need = (size_t)huge_grid() * huge_stride_bytes(sc);
+        // (a slice per workgroup of the capped grids — and a batch of fewer spectra launches fewer workgroups: ADVICE r05)
+        // (the per-query kernels launch min(spectra x queries per spectrum, cap) workgroups, the per-spectrum ones fewer)
+        const uint64_t blocks = std::max<uint64_t>((uint64_t)view.n * std::max<uint32_t>(s->qmax, 1u), 1u);
+        const size_t need = (size_t)std::min<uint64_t>(huge_grid(), blocks) * huge_stride_bytes(sc);
         if (wset.hugebuf.n < need) {
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(wset.hugebuf.reserve(need));
@@ -1848,9 +1852,12 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             } else {
                 HIP_TRY(hipMemcpyAsync(ow.h_counters, ow.counters.p, 2 * CTR_COUNT * 4, hipMemcpyDeviceToHost, st));
             }
+            // (every part's end: the parts run side by side and any of them may finish last — SageTiming::total_ms is the first
+            // part's start to the LATEST end; round 5 recorded the last part's only and under-reported a step whose first part
+            // outlasted it: ADVICE r05)
+            if (s->timed) HIP_TRY(hipEventRecord(s->way_end[wy].e, st));
         }
         hipStream_t fin = ways > 1 ? s->way_stream[ways - 2] : s->stream;
-        if (s->timed) HIP_TRY(hipEventRecord(s->way_end.e, fin));
         if (epilogue) {
             reset_done = true;
         } else if (b->n) {
@@ -1918,7 +1925,11 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             s->retry_likely = s->timing.n_retry != 0;
             if (s->timed) {
                 float wall = 0.f;
-                HIP_TRY(hipEventElapsedTime(&wall, s->way_begin.e, s->way_end.e));
+                for (uint32_t wy = 0; wy < ways; wy++) {
+                    float w1 = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&w1, s->way_begin.e, s->way_end[wy].e));
+                    wall = std::max(wall, w1);
+                }
                 s->timing.total_ms = wall;  // (prelim_ms / rescore_ms: summed over the parts, which overlap in time)
                 s->kept_prelim_ms = s->timing.prelim_ms;
                 s->kept_rescore_ms = s->timing.rescore_ms;

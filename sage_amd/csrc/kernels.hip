@@ -3879,6 +3879,13 @@ int spectrum_kernel_prepare(size_t max_lds_bytes) {
         hipFuncAttributes at;
         if (hipFuncGetAttributes(&at, f) == hipSuccess && at.sharedSizeBytes != 0) return (int)hipErrorInvalidConfiguration;
     }
+#ifdef SAGE_HIP_EXPERIMENTS  // (the one-launch experiment's instances take the same limit: ADVICE r05)
+    for (const void* f : {(const void*)search_kernel<true, true>, (const void*)search_kernel<true, false>, (const void*)search_kernel<false, true>,
+                          (const void*)search_kernel<false, false>}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+#endif
     return (int)hipSuccess;
 }
 uint32_t queries_per_spectrum(const DevScorer& sc) {
