@@ -718,13 +718,21 @@ def main():
             # rank's share — reported beside `value`, never as `value`.  Page-locked arrays (what a caller that allocates its
             # spectrum arena with sage_hip_host_alloc hands over) and plain pageable numpy arrays.
             locked = batch.page_locked()
+            host_cpu = {}
             for name, b_in in (("page_locked", locked), ("pageable", batch)):
                 scorer.score(b_in)
                 reps = max(3, int(0.5 / max(ms_per_step * 1e-3, 1e-4) / 4))
+                c0 = time.process_time()  # (user + system CPU time of every thread of this process: the library's staging threads too)
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     sf, sc_ = scorer.score(b_in)
-                extras[name] = batch.n * reps / (time.perf_counter() - t0)
+                dt = time.perf_counter() - t0
+                extras[name] = batch.n * reps / dt
+                # what the host pays for a host-to-host call: CPU-seconds per million spectra, and how many CPUs that keeps busy
+                # at the measured rate — N ranks of a node need N times that from one cgroup (VERDICT r05 task 6)
+                cpu_s = time.process_time() - c0
+                host_cpu[name] = {"cpu_s_per_million_spectra": cpu_s / (batch.n * reps / 1e6), "cpus_busy": cpu_s / dt}
+            extras["host_cpu"] = host_cpu
             if not same_psms(sf, sc_, feats, counts):
                 raise SystemExit("bench.py: the streaming entry point and the resident one disagree")
             del locked
@@ -928,6 +936,10 @@ def main():
             "host_to_host_value": extras or None,  # PCIe-inclusive: sage_hip_score_batch, this rank's share
             "host_link": link,  # measured link rates and the host-to-host ceiling they imply for this workload
             "pcie_inclusive_value": extras.get("page_locked") if extras else None,
+            # the like-for-like figure against the reference's own clock (runner.rs:327-330 starts and ends in host memory), as a
+            # fraction of what the measured link allows for this workload's input bytes
+            "host_to_host_frac_of_link": (extras["page_locked"] / link["host_to_host_ceiling"]
+                                          if extras and link and link.get("host_to_host_ceiling") else None),
             "sharding": sharding,
             "n_ranks_seen": ranks_seen,
         }
