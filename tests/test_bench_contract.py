@@ -37,7 +37,7 @@ def test_bench_single_rank_line(gpu_required):
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "spectra/s" and j["value"] > 0
     assert j["scaling"] == "strong" and j["vs_baseline"] is None and j["higher_is_better"] is True and j["data"] == "synthetic"
     rf = j["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] in ("hbm", "valu_issue") and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "traffic" in rf and rf["traffic_source"]  # measured now (rocprofv3 --pmc passes) or says why not
     if rf["traffic"] is not None:
         assert abs(rf["frac_traffic"] - rf["achieved_traffic"] / rf["peak"]) < 1e-9
