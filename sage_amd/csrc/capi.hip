@@ -124,7 +124,8 @@ struct SageDeviceDb {
     DevBuf<SageTheoretical> tm_frag;  // tile-major copy + position table for the large-window kernel
     DevBuf<uint32_t> tm_lut;
     DevBuf<SageTheoretical> tm2_frag; // small-tile copy + table for the narrow kernel's per-peak lookups
-    DevBuf<uint32_t> tm2_lut;
+    DevBuf<sagecore::LutWord> tm2_l1;  // its position table in succinct form (core.h: LutWord): occupancy + rank per 32 cells ...
+    DevBuf<uint32_t> tm2_pos;          // ... and the run starts of the non-empty cells
     uint32_t max_ions = 0;
     uint32_t max_len = 0;   // residues of the longest peptide (> 1023: DevScorer::long_runs)
     uint32_t ion_lo_bits = 0xFFFFFFFFu, ion_hi_bits = 0;  // smallest / largest |ion| of the rescoring table, as f32 bits (scorer_tol_mode)
@@ -658,10 +659,24 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
                                                                     lut2_scale, d->tm2_frag.p, &lut2_p, &lut2_stride, nullptr);
         if (be != hipSuccess)
             return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build: ") + hipGetErrorString(be));
-        d->tm2_lut.p = lut2_p;
-        d->tm2_lut.n = (size_t)n_tiles2 * lut2_stride;
+        // the table in succinct form (index_build.hip: build_succinct_lut_on_device; the row-major table is its input only —
+        // 1.5 GB for C3 that the narrow kernel no longer reads a line of per lookup)
+        sagecore::LutWord* l1_p = nullptr;
+        uint32_t* pos_p = nullptr;
+        uint32_t lut2_words = 0;
+        uint64_t n_pos = 0;
+        const hipError_t se = (hipError_t)build_succinct_lut_on_device(lut2_p, (uint32_t)n_tiles2, lut2_stride, &l1_p, &pos_p, &lut2_words, &n_pos, nullptr);
+        (void)hipFree(lut2_p);
+        if (se != hipSuccess)
+            return fail(se == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("device index build (succinct table): ") + hipGetErrorString(se));
+        d->tm2_l1.p = l1_p;
+        d->tm2_l1.n = (size_t)n_tiles2 * lut2_words;
+        d->tm2_pos.p = pos_p;
+        d->tm2_pos.n = (size_t)std::max<uint64_t>(n_pos, 1);
         d->view.tm2_frag = d->tm2_frag.p;
-        d->view.tm2_lut = d->tm2_lut.p;
+        d->view.tm2_l1 = d->tm2_l1.p;
+        d->view.tm2_pos = d->tm2_pos.p;
+        d->view.lut2_words = lut2_words;
         d->view.tile2_shift = tile2_shift;
         d->view.n_tiles2 = (uint32_t)n_tiles2;
         d->view.lut2_stride = lut2_stride;
@@ -704,7 +719,7 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
     d->bytes = d->pep_mono.bytes() + d->pep_lut.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
-               d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes() + d->tm2_frag.bytes() + d->tm2_lut.bytes();
+               d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes() + d->tm2_frag.bytes() + d->tm2_l1.bytes() + d->tm2_pos.bytes();
     *out = d.release();
     return SAGE_HIP_OK;
 }

@@ -465,6 +465,30 @@ SAGE_HD uint32_t lut_entry(const float* mz, uint32_t step, uint64_t begin, uint6
     return (uint32_t)lo;
 }
 
+// ---- the small tiles' position table in succinct form (round 6) ---------------------------------------------------------------
+// A row of the table above answers lut[c] = first position of the tile whose m/z is >= c / scale.  For the narrow kernel's small
+// tiles most cells are EMPTY (a tile of 2 048 peptides holds ~60 000 entries in ~160 000 cells, and they cluster in mass-defect
+// bands) and most (peak, charge) windows find nothing — yet every lookup cost a 128-byte line of a 640 KB row.  The same function
+// from two levels: per 32 cells one word of occupancy bits (bit b: cell 32 w + b holds an entry) and the RANK of the word — the
+// number of non-empty cells before it, as an index into `pos`, the tile's run starts in cell order with the tile's end as the
+// last entry.  Then
+//     lut[c] == pos[rank(c)],   rank(c) = l1[c >> 5].rank + popcount(l1[c >> 5].bits & ((1 << (c & 31)) - 1))
+// (the first non-empty cell at or after c starts where lut[c] points; no such cell: the tile's end), so a window's run is
+// [pos[rank(icl)], pos[rank(ich)]) — and rank(icl) == rank(ich) says "empty" without touching `pos` at all.  The first level is
+// 40 KB per tile (it stays in the caches while the tile's spectra are scored), `pos` a third of the old row.  Exactly the old
+// function: tests/test_core_emulation.py builds both from random entries and compares every cell.
+struct LutWord {
+    uint32_t bits, rank;
+};
+SAGE_HD uint32_t lut_rank(const LutWord& w, uint32_t c) {
+    const uint32_t below = w.bits & ((1u << (c & 31u)) - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return w.rank + (uint32_t)__popc(below);
+#else
+    return w.rank + (uint32_t)__builtin_popcount(below);
+#endif
+}
+
 // ---- select_most_intense_peak through a direct-index table (rescore_kernel) ------------------------------------------------
 // plut[b] = number of peaks with mass < b * W (total order).  W is a power of two, so bin(lo) = floor(lo / W) and b * W are
 // exact and plut[bin(lo)] <= partition_point(mass < lo): a short forward walk finishes the job.  Same peaks considered and

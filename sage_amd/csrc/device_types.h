@@ -43,7 +43,12 @@ struct DevDbView {
     // a second tile-major copy with SMALL tiles (2^tile2_shift peptides, coarser cells) for the narrow kernel's per-peak
     // lookups: a +-10 ppm window holds a few hundred candidates, and a run of a small tile is ~3 entries instead of ~30
     const SageTheoretical* tm2_frag;  // [nf + 2]
-    const uint32_t* tm2_lut;          // [n_tiles2 * lut2_stride]
+    // its position table in succinct form (core.h: LutWord / lut_rank): lut2_words words per tile, each {occupancy bits of 32 cells,
+    // rank = index into tm2_pos of the first non-empty cell at or after the word's first cell}; tm2_pos: the run starts of a tile's
+    // non-empty cells in cell order, then the tile's end
+    const sagecore::LutWord* tm2_l1;  // [n_tiles2 * lut2_words]
+    const uint32_t* tm2_pos;          // [non-empty cells of all tiles + n_tiles2]
+    uint32_t lut2_words;              // ceil(lut2_stride / 32)
     uint32_t tile2_shift;
     uint32_t n_tiles2;
     uint32_t lut2_stride;
@@ -249,6 +254,9 @@ int ion_abs_range_on_device(const float* d_ions, uint64_t n, uint32_t* lo_bits, 
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
                               uint32_t* lut_stride_out, void* stream, int layout = 0);
+// lut[n_tiles][lut_stride] (row-major, as build_tile_copy_on_device makes it) -> its succinct form; the arrays are allocated here
+int build_succinct_lut_on_device(const uint32_t* d_lut, uint32_t n_tiles, uint32_t lut_stride, sagecore::LutWord** d_l1_out, uint32_t** d_pos_out,
+                                 uint32_t* words_out, uint64_t* n_pos_out, void* stream);
 int build_peptide_mass_lut(const float* d_pep_mono, uint32_t np, float top_mass, uint32_t** d_lut_out, uint32_t* bins_out, float* inv_w_out,
                            void* stream);
 // rescore.hip

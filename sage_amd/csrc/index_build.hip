@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "device_types.h"
 
@@ -302,6 +303,88 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
     return (int)hipSuccess;
 }
 
+
+// ---- the succinct form of a row-major position table (core.h: LutWord) -----------------------------------------------------------
+namespace {
+// one thread per (tile, word): the occupancy bits of its 32 cells — cell c holds an entry iff lut[c + 1] != lut[c] (the table
+// ascends; its last entry, c == stride - 1, is the tile's end and has no cell behind it) — and their count; the last word of a
+// tile counts one more: the slot of the tile's end in `pos`
+__global__ __launch_bounds__(256) void lut_bits_kernel(const uint32_t* __restrict__ lut, uint32_t n_tiles, uint32_t stride, uint32_t words,
+                                                       sagecore::LutWord* __restrict__ l1, uint32_t* __restrict__ counts) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_tiles * words) return;
+    const uint32_t t = (uint32_t)(gid / words), w = (uint32_t)(gid - (uint64_t)t * words);
+    const uint32_t* __restrict__ row = lut + (size_t)t * stride;
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        const uint32_t c = w * 32 + b;
+        if (c + 1 < stride && row[c + 1] != row[c]) bits |= 1u << b;
+    }
+    l1[gid].bits = bits;
+    counts[gid] = (uint32_t)__popc(bits) + (w + 1 == words ? 1u : 0u);
+}
+// ... then, with the exclusive prefix of the counts as every word's rank: the run starts of its non-empty cells, and behind a
+// tile's last word the tile's end
+__global__ __launch_bounds__(256) void lut_fill_kernel(const uint32_t* __restrict__ lut, uint32_t n_tiles, uint32_t stride, uint32_t words,
+                                                       const uint32_t* __restrict__ ranks, sagecore::LutWord* __restrict__ l1,
+                                                       uint32_t* __restrict__ pos) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_tiles * words) return;
+    const uint32_t t = (uint32_t)(gid / words), w = (uint32_t)(gid - (uint64_t)t * words);
+    const uint32_t* __restrict__ row = lut + (size_t)t * stride;
+    uint32_t r = ranks[gid];
+    l1[gid].rank = r;
+    uint32_t bits = l1[gid].bits;
+    while (bits) {
+        const uint32_t b = (uint32_t)__ffs((int)bits) - 1;
+        bits &= bits - 1;
+        pos[r++] = row[w * 32 + b];
+    }
+    if (w + 1 == words) pos[r] = row[stride - 1];
+}
+}  // namespace
+
+int build_succinct_lut_on_device(const uint32_t* d_lut, uint32_t n_tiles, uint32_t lut_stride, sagecore::LutWord** d_l1_out, uint32_t** d_pos_out,
+                                 uint32_t* words_out, uint64_t* n_pos_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t words = (lut_stride + 31) / 32;
+    const uint64_t n = (uint64_t)n_tiles * words;
+    sagecore::LutWord* d_l1 = nullptr;
+    uint32_t *d_counts = nullptr, *d_ranks = nullptr, *d_pos = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    BUILD_TRY(hipMalloc((void**)&d_l1, (n ? n : 1) * sizeof(sagecore::LutWord)));
+    BUILD_TRY(hipMalloc((void**)&d_counts, (n ? n : 1) * 4));
+    BUILD_TRY(hipMalloc((void**)&d_ranks, (n ? n : 1) * 4));
+    uint64_t total = 0;
+    if (n) {
+        const dim3 grid((uint32_t)((n + 255) / 256));
+        hipLaunchKernelGGL(lut_bits_kernel, grid, dim3(256), 0, stream, d_lut, n_tiles, lut_stride, words, d_l1, d_counts);
+        BUILD_TRY(hipGetLastError());
+        BUILD_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, d_counts, d_ranks, 0u, n, rocprim::plus<uint32_t>(), stream));
+        BUILD_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+        BUILD_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, d_counts, d_ranks, 0u, n, rocprim::plus<uint32_t>(), stream));
+        uint32_t last_rank = 0, last_count = 0;
+        BUILD_TRY(hipMemcpyAsync(&last_rank, d_ranks + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        BUILD_TRY(hipMemcpyAsync(&last_count, d_counts + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        BUILD_TRY(hipStreamSynchronize(stream));
+        total = (uint64_t)last_rank + last_count;  // (<= entries + tiles < 2^32: capi.hip refuses more fragments)
+        BUILD_TRY(hipMalloc((void**)&d_pos, (total ? total : 1) * 4));
+        hipLaunchKernelGGL(lut_fill_kernel, grid, dim3(256), 0, stream, d_lut, n_tiles, lut_stride, words, d_ranks, d_l1, d_pos);
+        BUILD_TRY(hipGetLastError());
+        BUILD_TRY(hipStreamSynchronize(stream));
+    } else {
+        BUILD_TRY(hipMalloc((void**)&d_pos, 4));
+    }
+    (void)hipFree(d_counts);
+    (void)hipFree(d_ranks);
+    if (tmp) (void)hipFree(tmp);
+    *d_l1_out = d_l1;
+    *d_pos_out = d_pos;
+    *words_out = words;
+    *n_pos_out = total;
+    return (int)hipSuccess;
+}
 
 // ---- launch schedule of a spectrum batch -------------------------------------------------------------------------------
 // Spectra are scored in ascending order of their neutral precursor mass, so that wavefronts resident together read

@@ -878,8 +878,9 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                     // the table, one for the entries, no lane waiting on another lane's long run.
                     av.refresh();
                     const uint4* __restrict__ frag2 = (const uint4*)av.db().tm2_frag;
-                    const uint32_t* __restrict__ tm2_lut = av.db().tm2_lut;
-                    const uint32_t tile2_shift = av.db().tile2_shift, lut2_stride = av.db().lut2_stride;
+                    const LutWord* __restrict__ tm2_l1 = av.db().tm2_l1;
+                    const uint32_t* __restrict__ tm2_pos = av.db().tm2_pos;
+                    const uint32_t tile2_shift = av.db().tile2_shift, lut2_stride = av.db().lut2_stride, lut2_words = av.db().lut2_words;
                     const float lut2_scale = av.db().lut2_scale;
                     const Tol ftol = SAGE_LOAD_TOL(av.sc().fragment_tol);
                     const uint32_t t0 = q.first >> tile2_shift, t1 = (q.end - 1) >> tile2_shift;
@@ -895,7 +896,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                         }
                     };
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
-                        const uint32_t* __restrict__ lut = tm2_lut + (size_t)t * lut2_stride;
+                        const LutWord* __restrict__ l1 = tm2_l1 + (size_t)t * lut2_words;
                         // table reads of up to PROBE_BATCH windows, PROBE_PER_LANE per lane, all in flight together; window q of the
                         // flattened order (lane-major) is window pbase + (q % PPL) * 64 + q / PPL.  The reads of batch b + 1 are
                         // issued before the cells of batch b are walked (SAGE_PROBE_PIPELINE): one round trip less per further batch.
@@ -903,15 +904,30 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
 #define SAGE_PROBE_PIPELINE 1
 #endif
                         uint32_t np0[PROBE_PER_LANE], np1[PROBE_PER_LANE];
+                        // The table in succinct form (core.h: LutWord): a window's run is [pos[rank(icl)], pos[rank(ich)]), the ranks from
+                        // the occupancy word(s) of its cells — 40 KB per tile, resident in the caches while the tile's spectra are
+                        // scored — and equal ranks say "empty" (most windows) without a second read.  The words of all of a lane's
+                        // windows first, then the run starts of the non-empty ones: two dependent trips, the first a short one.
                         auto issue = [&](uint32_t pbase) {
+                            uint32_t icl[PROBE_PER_LANE], ich[PROBE_PER_LANE];
+                            LutWord wa[PROBE_PER_LANE], wb[PROBE_PER_LANE];
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
                                 float flo, fhi;
                                 window_of(pbase + i * WAVE + lane, flo, fhi);
-                                uint32_t icl, ich;  // (core.h: the scale is a power of two, no safety margin needed)
-                                lut_cells(flo, fhi, lut2_scale, lut2_stride, icl, ich);
-                                np0[i] = lut[icl];
-                                np1[i] = lut[ich];
+                                // (core.h: the scale is a power of two, no safety margin needed)
+                                lut_cells(flo, fhi, lut2_scale, lut2_stride, icl[i], ich[i]);
+                                wa[i] = l1[icl[i] >> 5];
+                                wb[i] = l1[ich[i] >> 5];
+                            }
+#pragma unroll
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
+                                const uint32_t r0 = lut_rank(wa[i], icl[i]), r1 = lut_rank(wb[i], ich[i]);
+                                np0[i] = np1[i] = 0;
+                                if (r1 > r0) {
+                                    np0[i] = tm2_pos[r0];
+                                    np1[i] = tm2_pos[r1];
+                                }
                             }
                         };
                         if (SAGE_PROBE_PIPELINE) issue(0);

@@ -171,6 +171,35 @@ uint32_t emu_peak_bitmap_violations(const float* masses, uint32_t n, int kind, f
     return bad;
 }
 
+// The succinct form of a position-table row (core.h: LutWord / lut_rank; built the way index_build.hip builds it: occupancy bit of
+// cell c = lut[c + 1] != lut[c], rank = exclusive count of the bits + `base`, pos = the run starts of the non-empty cells, then the
+// tile's end) against the row itself: pos[rank(c)] must be lut[c] for EVERY cell c, the end marker included.  `mz`: one tile's
+// entries, ascending in the total order.  Returns the number of cells where the two differ.
+uint64_t emu_succinct_lut_mismatches(const float* mz, uint32_t n, float scale, uint32_t stride, uint32_t base, uint64_t* n_nonempty) {
+    std::vector<uint32_t> lut(stride);
+    for (uint32_t c = 0; c < stride; c++) lut[c] = lut_entry(mz, 1, 0, n, c, stride, scale);
+    const uint32_t words = (stride + 31) / 32;
+    std::vector<LutWord> l1(words);
+    std::vector<uint32_t> pos;
+    uint32_t r = base;
+    for (uint32_t w = 0; w < words; w++) {
+        uint32_t bits = 0;
+        for (uint32_t b = 0; b < 32; b++) {
+            const uint32_t c = w * 32 + b;
+            if (c + 1 < stride && lut[c + 1] != lut[c]) bits |= 1u << b;
+        }
+        l1[w].bits = bits;
+        l1[w].rank = r;
+        for (uint32_t b = 0; b < 32; b++)
+            if ((bits >> b) & 1u) { pos.push_back(lut[w * 32 + b]); r++; }
+    }
+    pos.push_back(lut[stride - 1]);
+    *n_nonempty = pos.size() - 1;
+    uint64_t bad = 0;
+    for (uint32_t c = 0; c < stride; c++) bad += pos[lut_rank(l1[c >> 5], c) - base] != lut[c];
+    return bad;
+}
+
 // Run::matched (scoring.rs:771-793) fed the same index sequence through core.h's four-field Run and the one-register form the
 // rescoring kernel keeps: returns the number of steps after which `longest` differs (0 = equivalent on this sequence).
 uint32_t emu_run_packed_mismatches(const uint32_t* indices, uint32_t n) {

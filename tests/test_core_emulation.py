@@ -53,6 +53,8 @@ def emu():
     lib.emu_peak_bitmap_violations.restype = C.c_uint32
     lib.emu_peak_bitmap_violations.argtypes = [f32p, C.c_uint32, C.c_int, C.c_float, C.c_float, f32p, C.c_uint32,
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    lib.emu_succinct_lut_mismatches.restype = C.c_uint64
+    lib.emu_succinct_lut_mismatches.argtypes = [f32p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -191,6 +193,34 @@ def test_select_peak_lut_equals_the_reference_scan(emu):
             want = emu.emu_select_peak(fp(m), fp(it), n, np.float32(c), kinds[kind], tlo, thi, 0)
             got = emu.emu_select_peak_lut(fp(m), fp(it), n, np.float32(c), kinds[kind], tlo, thi)
             assert got == want, (trial, n, top, kind, tlo, thi, float(c), got, want)
+
+
+def test_succinct_position_table_is_the_position_table(emu):
+    """The narrow kernel reads the small tiles' position table in succinct form (core.h: LutWord — occupancy bits + rank per 32
+    cells, and the run starts of the non-empty cells).  It must be the same FUNCTION as the row it replaces: pos[rank(c)] == lut[c]
+    for every cell, for sparse and dense tiles, entries in the first and the last cell, entries beyond the table, negative and NaN
+    m/z, empty tiles, strides that are and are not multiples of 32, a non-zero rank base (a tile in the middle of the index)."""
+    rng = np.random.default_rng(23)
+    for trial in range(60):
+        n = int(rng.choice([0, 1, 2, 7, 50, 400, 3000]))
+        top = float(rng.choice([3.0, 40.0, 700.0]))
+        mz = rng.uniform(0.0, top, n).astype(np.float32)
+        if trial % 4 == 1 and n >= 7:
+            mz[:3] = [-1.0, 0.0, np.float32(top * 2)]          # below the first cell, in it, beyond the table
+        if trial % 4 == 2 and n >= 7:
+            mz[:2] = [np.nan, np.inf]
+        if trial % 5 == 3 and n >= 50:
+            mz[: n // 2] = mz[0]                                # a mass-defect band: many entries in one cell
+        key = mz.view(np.int32).astype(np.int64)
+        key = np.where(key < 0, key ^ 0x7FFFFFFF, key)          # f32::total_cmp order (negatives and -NaN first, +NaN last)
+        mz = mz[np.argsort(key, kind="stable")]
+        scale = float(rng.choice([8.0, 32.0, 256.0]))
+        stride = int(rng.choice([3, 32, 33, 64, 65, int(top * scale) + 3, int(top * scale * 0.5) + 3]))
+        stride = max(stride, 3)
+        nn = C.c_uint64()
+        bad = emu.emu_succinct_lut_mismatches(fp(mz), n, scale, stride, int(rng.integers(0, 1 << 20)), C.byref(nn))
+        assert bad == 0, (trial, n, top, scale, stride)
+        assert nn.value <= max(n, 0)
 
 
 def test_peak_bitmap_filter_never_drops_a_match(emu):
