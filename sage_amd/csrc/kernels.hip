@@ -330,6 +330,41 @@ __device__ __forceinline__ void wh32_offer(Heap32& H, uint32_t k, uint32_t v) { 
     if (k && v > wh32_get(H, 0)) wh32_sift_from(H, k, 0, v);
 }
 
+// heap.rs:24-25 + :40-60 for a value that enters at the root, ALL LANES AT ONCE (round 6: the replay of a large-window query is
+// one serial chain of thousands of these — the longest query of a retry pass IS the pass's duration — and the loop above spends
+// ~1 200 cycles per offer on six levels of readlane / compare / writelane that depend on each other).  sift_down always descends
+// to the smaller child, the left one on a tie (heap.rs:43-51): which child that is does not depend on the value being sifted, so
+// every node looks at its two children once (two ds_bpermute, in flight together), one ballot gives the "right child is
+// strictly smaller" bit of every node, the root-to-leaf path follows from bit operations on scalars, and — values along a heap
+// path never decrease — the new value stops behind the path nodes that are smaller (a prefix of the path: one more ballot).  A path
+// node above the stop takes its smaller child's value (it has it already), the node at the stop takes `v`; a node's depth is a
+// function of its lane.  Same array as the loop, every time (the GPU suite's exact paths and the config-scale parity run through it).
+__device__ __forceinline__ void wh32_replace_root(Heap32& H, uint32_t k, uint32_t v) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = 2 * lane + 1, r = l + 1;
+    const uint32_t hl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l & 63u) << 2), (int)H.h);
+    const uint32_t hr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)H.h);
+    const bool right = r < k && hr < hl;
+    const uint64_t rm = __ballot(right);
+    uint64_t pm = 1ull;  // nodes on the path the sift takes
+    uint32_t p = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 6; i++) {
+        const uint32_t c = 2 * p + 1;
+        if (c < k) {
+            p = c + (uint32_t)((rm >> p) & 1ull);
+            pm |= 1ull << p;
+        }
+    }
+    const bool onpath = (pm >> lane) & 1ull;
+    const uint32_t depth = 31u - (uint32_t)__clz((int)(lane + 1u));
+    const uint32_t stop = (uint32_t)__popcll(__ballot(onpath && lane != 0u && H.h < v));  // path nodes below the root that move up
+    if (onpath) H.h = depth < stop ? (right ? hr : hl) : depth == stop ? v : H.h;
+}
+__device__ __forceinline__ void wh32_offer_par(Heap32& H, uint32_t k, uint32_t v) {  // heap.rs:21-27
+    if (k && v > wh32_get(H, 0)) wh32_replace_root(H, k, v);
+}
+
 // CList (core.h) with wave-uniform bookkeeping: every lane holds the same stored/len, appends are
 // lane-parallel (ballot prefix), trims run on a WaveHeap.
 struct UList {
@@ -2195,7 +2230,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
             while (mask) {
                 const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                wh32_offer_par(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
             }
         });
         if (lane < k) w.qres[qid * w.kstride + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
