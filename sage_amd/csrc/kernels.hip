@@ -1249,7 +1249,9 @@ struct TileLds {
     uint32_t* pp1;      // [TILE_THREADS]
     uint32_t* pcs;      // [TILE_THREADS]
     uint32_t* psum;     // [TILE_WAVES]
+    uint32_t* qw;       // [TILE_QW_MAX * 4] {left, right, first, end} of the spectrum's precursor-window queries, searched up front
 };
+constexpr uint32_t TILE_QW_MAX = 64;  // queries per spectrum whose windows are searched up front, a wavefront each (more: one by one)
 // `wing`: the windows of the spectrum live in a global-memory workspace instead (tile_count_wing_kernel: spectra whose peaks x
 // fragment charges do not fit a compute unit's LDS next to the counters)
 __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem, bool cnt8,
@@ -1276,6 +1278,9 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     off += TILE_THREADS * 4;
     if (l) l->psum = (uint32_t*)(smem + off);
     off += TILE_WAVES * 4;
+    off = (off + 15) & ~(size_t)15;
+    if (l) l->qw = (uint32_t*)(smem + off);
+    off += 64 * 4 * 4;  // (TILE_QW_MAX, declared below the struct)
     return (off + 15) & ~(size_t)15;
 }
 
@@ -1366,6 +1371,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     uint32_t* const l_pp1 = lds_.pp1;
     uint32_t* const l_pcs = lds_.pcs;
     uint32_t* const l_psum = lds_.psum;
+    uint32_t* const l_qw = lds_.qw;
     const uint32_t TSH = ka->db.tile_shift, TS = 1u << TSH;
     // counter words (SPW slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [SPW * tid * wpt, ...), so thread
     // order == slot order.  tile_shift 15, u16: 32 words = eight 16-byte quads per thread.
@@ -1430,6 +1436,23 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
             }
         }
         if (tid < ka->w.qmax) ka->w.qrec[(size_t)slot * ka->w.qmax + tid].potential = 0;  // queries this spectrum does not run
+        // IndexedDatabase::query (database.rs:402-425) of EVERY query of the spectrum up front, a wavefront each: three dependent
+        // round trips that wavefront 0 used to make query after query while the other seven waited — 18 % of this kernel's time in
+        // a wide-window search (three charge states per spectrum, one or two tiles each: profiles/r06_C5_count_phase_clocks.txt)
+        const uint32_t n_iso_ = fold ? (uint32_t)(isoB - isoA) + 1u : 1u;
+        const uint32_t nq_ = (si.z1 >= si.z0 ? si.z1 - si.z0 + 1u : 0u) * n_iso_;
+        const bool windows_ahead = nq_ <= TILE_QW_MAX;
+        if (windows_ahead) {
+            for (uint32_t q = wave; q < nq_; q += TILE_WAVES) {
+                const uint32_t z = si.z0 + q / n_iso_;
+                const int iso = isoA + (int)(q % n_iso_);
+                const Tol ptol = ka->sc.wide_window ? tol_scaled(si.iso_tol, (float)z) : SAGE_LOAD_TOL(ka->sc.precursor_tol);
+                const Window qq = query_window<false>(ka->db.pep_mono, ka->db.np, ptol, si.mzp * (float)z - (float)iso * NEUTRON, ka->db.pep_lut,
+                                                      ka->db.pep_lut_bins, ka->db.pep_lut_inv_w);  // scoring.rs:344
+                if (lane == 0) *(uint4*)(l_qw + 4 * q) = make_uint4(qq.left, qq.right, qq.first, qq.end);
+            }
+            __syncthreads();
+        }
 
         for (uint32_t z = si.z0; z <= si.z1; z++) {
             const uint32_t nfz = max_fragment_charge(ka->sc.max_fragment_charge, z) - 1;
@@ -1444,8 +1467,14 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     // (through the position table of the peptide masses, like the narrow kernel since round 4: 3 dependent round trips
                     // instead of ~9 while the other seven wavefronts wait — a third of this kernel's time per spectrum in a wide-window
                     // search, whose three charge-state queries span one or two tiles each: scripts/tile_probe.py wide)
-                    const Window q = query_window<false>(ka->db.pep_mono, ka->db.np, ptol, precursor_mass - (float)iso * NEUTRON, ka->db.pep_lut,
-                                                         ka->db.pep_lut_bins, ka->db.pep_lut_inv_w);  // scoring.rs:344
+                    Window q;
+                    if (windows_ahead) {
+                        const uint4 v = *(const uint4*)(l_qw + 4 * query_index(kp.sc, si, z, iso));
+                        q.left = v.x; q.right = v.y; q.first = v.z; q.end = v.w;
+                    } else {
+                        q = query_window<false>(ka->db.pep_mono, ka->db.np, ptol, precursor_mass - (float)iso * NEUTRON, ka->db.pep_lut,
+                                                ka->db.pep_lut_bins, ka->db.pep_lut_inv_w);  // scoring.rs:344
+                    }
                     if (lane == 0) {
                         l_sh[SH_LEFT] = q.left; l_sh[SH_RIGHT] = q.right; l_sh[SH_FIRST] = q.first; l_sh[SH_END] = q.end;
                         l_sh[SH_MATCHED] = 0; l_sh[SH_SCORED] = 0; l_sh[SH_THR] = 1; l_sh[SH_OVF] = 0; l_sh[SH_NCAND] = 0;
@@ -1743,20 +1772,48 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     // ---- scan: only the candidate bits.  Thread tid owns slots [tid * spt, (tid + 1) * spt): lane order == slot
                     //      order, a wavefront owns one contiguous slot range, so the candidates of a wavefront, ranked through a
                     //      prefix sum of popcounts, ARE in slot order.
-                    const uint32_t spt = SPW * wpt;               // slots per thread (64 at tile_shift 15)
-                    const uint32_t bwt = (spt + 31) / 32;         // bitmap words per thread (2), or a part of one (spt < 32)
+                    const uint32_t spt = SPW * wpt;               // slots per thread when the window covers the tile (64 at tile_shift 15)
+                    // Round 6: a NARROW window inside the tile — a wide-window / DIA query holds ~10^4 candidates, a third of a tile —
+                    // used to leave its candidates with the quarter of the threads that own its slots while the rest idled at the
+                    // next barrier (20 % of this kernel's time on C5).  Only slots [ws, we) of the tile can have been touched (a hit's
+                    // peptide lies in [first, end)), so the threads share THAT range: from vs = ws rounded down to a bitmap word,
+                    // spt_v slots each — the smallest power of two whose 512 pieces reach we.  Thread order is still slot order, a
+                    // wavefront still owns one contiguous slot range; counters and bits outside the range are clear as they are.
+                    const uint32_t ws = first > tb ? first - tb : 0u;
+                    const uint32_t we = end < tb + TS ? (end > tb ? end - tb : 0u) : TS;
+                    const uint32_t vs = ws & ~31u;
+                    const uint32_t span_v = we > vs ? we - vs : 0u;
+                    uint32_t spt_v = spt;
+                    while (spt_v > SPW && (spt_v >> 1) * TILE_THREADS >= span_v) spt_v >>= 1;
+                    const uint32_t x0 = vs + tid * spt_v;  // this thread's first slot (a multiple of spt_v: bits never straddle a word)
+                    // (a window that covers the tile — every tile but the two ends of an open search's window — keeps round 5's forms:
+                    // thread tid owns [tid * spt, (tid + 1) * spt), one 8-byte read, 16-byte clears)
+#ifndef SAGE_TILE_WHOLE_FAST
+#define SAGE_TILE_WHOLE_FAST 1
+#endif
+                    const bool whole_tile = SAGE_TILE_WHOLE_FAST && vs == 0u && spt_v == spt;
                     uint64_t mask = 0;
-                    if (tid * spt < TS) {
-                        if (spt >= 64) {
-                            const uint2 mw = *(const uint2*)(l_bm + tid * 2);
-                            mask = ((uint64_t)mw.y << 32) | mw.x;
-                        } else if (spt == 32) {
-                            mask = l_bm[tid];
+                    if (whole_tile) {
+                        if (tid * spt < TS) {
+                            if (spt >= 64) {
+                                const uint2 mw = *(const uint2*)(l_bm + tid * 2);
+                                mask = ((uint64_t)mw.y << 32) | mw.x;
+                            } else if (spt == 32) {
+                                mask = l_bm[tid];
+                            } else {
+                                mask = (l_bm[(tid * spt) >> 5] >> ((tid * spt) & 31u)) & ((1u << spt) - 1u);
+                            }
+                        }
+                    } else if (x0 < TS) {
+                        if (spt_v >= 64) {
+                            const uint32_t wlo = l_bm[x0 >> 5], whi = (x0 >> 5) + 1 < TS / 32 ? l_bm[(x0 >> 5) + 1] : 0u;
+                            mask = ((uint64_t)whi << 32) | wlo;
+                        } else if (spt_v == 32) {
+                            mask = l_bm[x0 >> 5];
                         } else {
-                            mask = (l_bm[(tid * spt) >> 5] >> ((tid * spt) & 31u)) & ((1u << spt) - 1u);
+                            mask = (l_bm[x0 >> 5] >> (x0 & 31u)) & ((1u << spt_v) - 1u);
                         }
                     }
-                    (void)bwt;
                     const uint32_t mine = (uint32_t)__popcll(mask);
                     // (past the first tiles of a window the pruning threshold leaves most wavefronts of most tiles without a single
                     // candidate: no prefix sum then — SAGE_SCAN_SKIP)
@@ -1791,7 +1848,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     // every lane writes ITS candidates (the set bits of its mask, in slot order) at run position excl + j: lane
                     // order == slot order, so the run is in slot order.  The counters of the first four are read together.
                     if (mine && run_at != NONE32) {
-                        const uint32_t x_base = tid * spt;
+                        const uint32_t x_base = x0;
                         uint64_t m = mask;
                         uint32_t pos = run_at + excl;
                         uint32_t xs[4], cs[4];
@@ -1823,8 +1880,8 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                     // the first min(k, potential) slots of the window go to the k-select verbatim, whatever their count
                     if ((uint64_t)tb < (uint64_t)left + nseed && (uint64_t)tb + TS > left) {
-                        const uint32_t x_lo = tid * spt;
-                        for (uint32_t i = 0; i < spt; i++) {
+                        const uint32_t x_lo = x0;
+                        for (uint32_t i = 0; i < spt_v; i++) {
                             const uint64_t gx = (uint64_t)tb + x_lo + i;
                             if (gx >= left && gx - left < nseed && x_lo + i < TS) {
                                 const uint32_t x = x_lo + i;
@@ -1835,8 +1892,9 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     }
                     pc.mark(4);
                     TILE_ARGS();
-                    // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them)
-                    {
+                    // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them; what lies
+                    // outside [vs, vs + 512 spt_v) was never touched)
+                    if (whole_tile) {
                         const uint32_t w_lo = tid * wpt;
                         if (w_lo < TS / SPW) {
                             if (wpt >= 4) {
@@ -1845,11 +1903,24 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                                 for (uint32_t i = 0; i < wpt; i++) l_cnt[w_lo + i] = 0;
                             }
                         }
-                        // (a bitmap word shared by several threads — fewer than 32 slots per thread — belongs to lanes of one
-                        // wavefront, which all read their masks above before any of them gets here)
                         if (tid * spt < TS) {
                             if (spt >= 64) *(uint2*)(l_bm + tid * 2) = make_uint2(0u, 0u);
                             else if (((tid * spt) & 31u) == 0) l_bm[(tid * spt) >> 5] = 0;
+                        }
+                    } else if (x0 < TS) {
+                        const uint32_t w_lo = x0 / SPW;                                   // (x0 is a multiple of spt_v >= SPW)
+                        const uint32_t w_n = x0 + spt_v <= TS ? spt_v / SPW : (TS - x0) / SPW;  // (the last piece may end with the tile)
+                        if (spt_v / SPW >= 4 && w_n == spt_v / SPW) {
+                            for (uint32_t i = 0; i < w_n; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(0u, 0u, 0u, 0u);
+                        } else {
+                            for (uint32_t i = 0; i < w_n; i++) l_cnt[w_lo + i] = 0;
+                        }
+                        // (a bitmap word shared by several threads — fewer than 32 slots per thread — belongs to lanes of one
+                        // wavefront, which all read their masks above before any of them gets here)
+                        if (spt_v >= 32) {
+                            for (uint32_t i = 0; i < spt_v / 32 && (x0 >> 5) + i < TS / 32; i++) l_bm[(x0 >> 5) + i] = 0;
+                        } else if ((x0 & 31u) == 0) {
+                            l_bm[x0 >> 5] = 0;
                         }
                     }
                     pc.mark(5);
