@@ -985,10 +985,15 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                                 run += rp1[i] > rp0[i] ? ((rp1[i] - 1) >> 1) - (rp0[i] >> 1) + 1 : 0;
                             }
                             const uint32_t n_cells = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                            if (pc.slot && lane == 0) {
-                                const uint32_t nw = nprobe - pbase < PROBE_BATCH ? nprobe - pbase : PROBE_BATCH;
-                                pc.bytes(DBG_NARROW_LUT, 8ull * nw);
-                                pc.bytes(DBG_NARROW_CELLS, 16ull * n_cells);
+                            if (pc.slot) {  // (profiling instance: bytes asked for — two 8-byte occupancy words per window, two run starts per non-empty one)
+                                uint32_t nonempty = 0;
+#pragma unroll
+                                for (uint32_t i = 0; i < PROBE_PER_LANE; i++) nonempty += (uint32_t)__popcll(__ballot(rp1[i] > rp0[i]));
+                                if (lane == 0) {
+                                    const uint32_t nw = nprobe - pbase < PROBE_BATCH ? nprobe - pbase : PROBE_BATCH;
+                                    pc.bytes(DBG_NARROW_LUT, 16ull * nw + 8ull * nonempty);
+                                    pc.bytes(DBG_NARROW_CELLS, 16ull * n_cells);
+                                }
                             }
                             wave_sync();
                             for (uint32_t cb = 0; cb < n_cells; cb += WAVE * PROBE_CELLS) {
