@@ -2270,7 +2270,9 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
 // Which of the two replay kernels takes a query when both are launched (more queries than `wave_max`): the lane-per-query
 // kernel lasts as long as the longest stream among its 64 lanes, one word per round, so streams above LANE_MAX_CAND words go
 // to the wavefront-per-query kernel, which skims 64 words per step and only pays for the offers that enter the heap.
-constexpr uint32_t LANE_MAX_CAND = 4096;  // (SAGE_HIP_REPLAY_LANE_MAX overrides it: the upper 32 bits of the kernels' `wave_max`)
+// (Round 6: 4096 -> 2048 — the wavefront kernel's offers are 2.5x cheaper since wh32_replace_root, and the two kernels run side by
+// side: C5's retry pass 13.7 -> 11.7 ms with 2048, 14.3 / 14.9 ms with 1024 / 512: scripts/experiments/r06_lab/gpu_r6r.sh.)
+constexpr uint32_t LANE_MAX_CAND = 2048;  // (SAGE_HIP_REPLAY_LANE_MAX overrides it: the upper 32 bits of the kernels' `wave_max`)
 __device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_t n_q, uint64_t wave_max) {
     const uint32_t lane_max = (uint32_t)(wave_max >> 32) ? (uint32_t)(wave_max >> 32) : LANE_MAX_CAND;
     wave_max &= 0xFFFFFFFFull;
