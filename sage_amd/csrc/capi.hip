@@ -1554,7 +1554,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
     if (sc.big_path) {
         const size_t cap = (size_t)160 * 1024;
         huge = prelim_lds_bytes(sc, view) > cap || rescore_lds_bytes(sc, view, s->db->max_ions, true) > cap || assemble_lds_bytes(sc) > cap ||
-               (size_t)s->kstride * 8 > cap || getenv("SAGE_HIP_FORCE_HUGE") != nullptr;  // (tests force the workspace on small lists)
+               (size_t)s->kstride * 8 + 256 > cap || getenv("SAGE_HIP_FORCE_HUGE") != nullptr;  // (tests force the workspace on small lists)
     }
     const size_t lds_p = sc.big_path ? prelim_lds_bytes(sc, view, huge)
                                      : std::max(production ? std::max(narrow_lds_bytes(sc, view), one_launch ? search_lds_bytes(sc, view) : (size_t)0) : (size_t)0, prelim_lds_bytes(sc, view)),

@@ -148,6 +148,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     return v;
 }
 
+// wave64 inclusive prefix MAXIMUM of unsigned values (identity 0): the same DPP pattern
+__device__ __forceinline__ uint32_t wave_incl_scan_max_dpp(uint32_t v) {
+#define SAGE_SMAX(CTRL, ROWS, BC)                                                                  \
+    {                                                                                              \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, BC);  \
+        v = t > v ? t : v;                                                                         \
+    }
+    SAGE_SMAX(0x111, 0xf, true)   // row_shr:1
+    SAGE_SMAX(0x112, 0xf, true)   // row_shr:2
+    SAGE_SMAX(0x114, 0xf, true)   // row_shr:4
+    SAGE_SMAX(0x118, 0xf, true)   // row_shr:8
+    SAGE_SMAX(0x142, 0xa, false)  // row_bcast:15 into rows 1 and 3
+    SAGE_SMAX(0x143, 0xc, false)  // row_bcast:31 into rows 2 and 3
+#undef SAGE_SMAX
+    return v;
+}
 // (the total = the scan's last lane: six DPP adds and one v_readlane instead of six ds_bpermute round trips through the LDS crossbar)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(v), 63); }
 
@@ -2016,19 +2032,31 @@ __device__ __forceinline__ DirRun dir_run(const DevWork& w, const QueryRec& rec,
 // dependent HBM round trips per run.  Here 64 directory entries are read at once (a lane each), a prefix sum of their lengths
 // turns "word k of the block" into (run, offset) — the owner search is six cross-lane reads — and the next 64 words are in
 // flight while f(word, tile base of the word's run) works on the current ones.  Holes (words with count 0) are passed on.
+// `marks` (round 6): 64 words of LDS of the calling wavefront.  The owner of word k of a block of runs — the last non-empty run
+// that starts at or before it — used to be a six-step binary search over the lanes' run starts, six ds_bpermute that depend on each
+// other per 64 words; the words of a fetch are consecutive, so every non-empty run that starts inside the fetch marks its first
+// word with its lane + 1 and a prefix maximum through DPP (carried from fetch to fetch: starts ascend) names every word's owner —
+// two LDS writes and a read instead of the six crossbar trips (tile_select_kernel 3.0 -> ... ms on C5).
 template <class F>
-__device__ __forceinline__ void for_each_candidate_batch(const DevWork& w, const QueryRec& rec, F&& f) {
+__device__ __forceinline__ void for_each_candidate_batch(const DevWork& w, const QueryRec& rec, uint32_t* marks, F&& f) {
     const uint32_t lane = lane_id();
     for (uint32_t d0 = 0; d0 < rec.n_dir; d0 += WAVE) {
         DirRun r{0u, 0u, 0u};
         if (d0 + lane < rec.n_dir) r = dir_run(w, rec, d0 + lane);
         const uint32_t incl = wave_incl_scan_dpp(r.n), excl = incl - r.n;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t carry = 0;  // owner + 1 of the last word of the fetch before (fetches go up in `base`)
         auto fetch = [&](uint32_t base, uint32_t& e, uint32_t& tb) {
             const uint32_t k = base + lane;
-            uint32_t own = 0;  // the largest lane whose run starts at or before word k (empty runs share their successor's start)
-#pragma unroll
-            for (uint32_t step = WAVE / 2; step; step >>= 1) own += (uint32_t)__shfl((int)excl, (int)(own + step), 64) <= k ? step : 0u;
+            lds_sync();
+            marks[lane] = 0u;
+            lds_sync();
+            if (r.n != 0u && excl - base < WAVE) marks[excl - base] = lane + 1u;  // (unsigned: false for runs that start before `base`)
+            lds_sync();
+            uint32_t own1 = wave_incl_scan_max_dpp(marks[lane]);
+            own1 = own1 > carry ? own1 : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
+            const uint32_t own = own1 ? own1 - 1u : 0u;
             const uint32_t at = (uint32_t)__shfl((int)r.at, (int)own, 64), first = (uint32_t)__shfl((int)excl, (int)own, 64);
             tb = (uint32_t)__shfl((int)r.tile_base, (int)own, 64);
             e = k < total ? w.arena[at + (k - first)] : 0u;
@@ -2230,7 +2258,7 @@ __global__ __launch_bounds__(64) void tile_replay_kernel(DevScorer sc, DevWork w
 // trim_hits of a large-window query WITHOUT replaying the heap (DevScorer::exact == 0): one wavefront walks the verbatim
 // slots and the candidate stream in slot order and keeps every slot above the k-th largest count T, plus the last
 // (k - #above) slots equal to T — the same k candidates bounded_min_heapify keeps — in slot order.
-__device__ __forceinline__ void tile_select_query(const DevScorer& sc, const DevWork& w, const uint64_t qid) {
+__device__ __forceinline__ void tile_select_query(const DevScorer& sc, const DevWork& w, const uint64_t qid, uint32_t* marks) {
     const uint32_t lane = lane_id();
     const QueryRec rec = w.qrec[qid];
     const uint32_t k = trim_k(rec.potential, sc.report_psms);
@@ -2252,7 +2280,7 @@ __device__ __forceinline__ void tile_select_query(const DevScorer& sc, const Dev
         eq_seen += (uint32_t)__popcll(eqm);
     };
     offer(lane < k ? w.seeds[qid * w.kstride + lane] : 0u, rec.left + lane);  // the first k slots
-    for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+    for_each_candidate_batch(w, rec, marks, [&](uint32_t e, uint32_t tile_base) {
         // (a candidate below T can never be taken: skip the wavefront's bookkeeping when the whole batch is below)
         if (__ballot((e >> 16) >= T && e != 0u) == 0ull) return;
         offer(e >> 16, tile_base + (e & 0xFFFFu));
@@ -2261,7 +2289,8 @@ __device__ __forceinline__ void tile_select_query(const DevScorer& sc, const Dev
 }
 __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w) {
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_select_query(sc, w, qid);
+    __shared__ uint32_t marks[WAVE];  // (for_each_candidate_batch)
+    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_select_query(sc, w, qid, marks);
 }
 
 // The same replay with ONE WAVEFRONT per query (heap one element per lane, wh32_* / wh_* above): ~10x more work per
@@ -2279,7 +2308,8 @@ __device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_
     if (wave_max == 0) return false;  // (SAGE_HIP_REPLAY_WAVE_MAX=0: tests force the lane-per-query kernel)
     return n_q <= wave_max || rec.n_cand > lane_max;
 }
-__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in, uint64_t n_q, uint64_t wave_max) {
+__device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, const DevWork& w, const uint64_t qid_in, uint64_t n_q, uint64_t wave_max,
+                                                       uint32_t* marks) {
     const uint32_t lane = lane_id();
     const uint64_t qid = query_slot(w, qid_in);
     const QueryRec rec = w.qrec[qid];
@@ -2299,7 +2329,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
         Heap32 hp;
         wh32_init(hp, seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u, k);
         wh32_build(hp, k);
-        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+        for_each_candidate_batch(w, rec, marks, [&](uint32_t e, uint32_t tile_base) {
             const uint32_t c = e >> 16;
             const uint32_t v = (c << K32_SLOT_BITS) | (tile_base + (e & 0xFFFFu) - rec.left);
             // in slot order; heap.rs:22 — later slots have larger peptide indices, so a count equal to the root's enters
@@ -2318,7 +2348,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
         h.lo = (uint32_t)sv;
         h.hi = (uint32_t)(sv >> 32);
         wh_build(h, k);
-        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+        for_each_candidate_batch(w, rec, marks, [&](uint32_t e, uint32_t tile_base) {
             const uint32_t c = e >> 16;
             const uint64_t v = pack_prescore(c, tile_base + (e & 0xFFFFu), z, iso);
             uint64_t mask = __ballot(c > 0 && c >= prescore_matched(wh_get(h, 0)));
@@ -2342,7 +2372,8 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
 }
 __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevWork w, uint64_t wave_max) {
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
-    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid, n_q, wave_max);
+    __shared__ uint32_t marks[WAVE];  // (for_each_candidate_batch)
+    for (uint64_t qid = blockIdx.x; qid < n_q; qid += gridDim.x) tile_replay_wave_query(sc, w, qid, n_q, wave_max, marks);
 }
 
 // The replay for k > 64 (report_psms > 32): a wavefront per query, the heap in LDS (lh_build / lh_offer_batch), 64-bit keys.
@@ -2350,7 +2381,10 @@ __global__ __launch_bounds__(64) void tile_replay_wave_kernel(DevScorer sc, DevW
 template <bool HUGE>
 __global__ __launch_bounds__(64) void tile_replay_big_kernel(DevScorer sc, DevWork w) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t* const heap = HUGE ? (uint64_t*)(w.hugebuf + (size_t)blockIdx.x * w.huge_stride) : (uint64_t*)smem;
+    // (dynamic LDS: 256 bytes of marks for for_each_candidate_batch, then — unless the lists live in the global workspace — the heap;
+    // no static LDS: the instance may take a compute unit's whole 160 KB)
+    uint32_t* const marks = (uint32_t*)smem;
+    uint64_t* const heap = HUGE ? (uint64_t*)(w.hugebuf + (size_t)blockIdx.x * w.huge_stride) : (uint64_t*)(smem + WAVE * 4);
     const uint32_t lane = lane_id();
     const uint64_t n_q = (uint64_t)w.n_deferred[CTR_QUEUED] * w.qmax;
     for (uint64_t qid_in = blockIdx.x; qid_in < n_q; qid_in += gridDim.x) {
@@ -2366,7 +2400,7 @@ __global__ __launch_bounds__(64) void tile_replay_big_kernel(DevScorer sc, DevWo
             heap[i] = c ? pack_prescore(c, rec.left + i, z, iso) : PRESCORE_EMPTY;
         }
         lh_build(heap, k);
-        for_each_candidate_batch(w, rec, [&](uint32_t e, uint32_t tile_base) {
+        for_each_candidate_batch(w, rec, marks, [&](uint32_t e, uint32_t tile_base) {
             const uint32_t c = e >> 16;
             lh_offer_batch(heap, k, pack_prescore(c, tile_base + (e & 0xFFFFu), z, iso), c > 0);
         });
@@ -4087,10 +4121,10 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
     (void)fold;
     if (sc.big_path) {  // report_psms > 32: heaps in LDS (or in the global workspace), always exact
         if (w.hugebuf) {
-            hipLaunchKernelGGL(tile_replay_big_kernel<true>, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
+            hipLaunchKernelGGL(tile_replay_big_kernel<true>, dim3(capped(nq)), dim3(64), WAVE * 4, (hipStream_t)stream, sc, w);
             hipLaunchKernelGGL((tile_assemble_kernel<true, true>), dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
         } else {
-            hipLaunchKernelGGL(tile_replay_big_kernel<false>, dim3(capped(nq)), dim3(64), (size_t)w.kstride * 8, (hipStream_t)stream, sc, w);
+            hipLaunchKernelGGL(tile_replay_big_kernel<false>, dim3(capped(nq)), dim3(64), (size_t)w.kstride * 8 + WAVE * 4, (hipStream_t)stream, sc, w);
             hipLaunchKernelGGL(tile_assemble_kernel<true>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
         }
         return;
