@@ -369,6 +369,14 @@ def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     n, t2 = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -500.0, 100.0), report_psms=3), "open, u16 counters only",
                               batch=sub, dev=dev)
     assert t2["n_retry"] < t["n_retry"]
+    if tile_shift == 12:
+        # more precursor-window queries per spectrum than the count kernel searches up front (kernels.hip: TILE_QW_MAX = 64): 21 isotope
+        # errors x 4 charge states = 84 — the windows are then searched query by query, as before round 6
+        monkeypatch.delenv("SAGE_HIP_NO_U8")
+        small_world.check(ScorerParams(precursor_tol=Tolerance("da", -30.0, 30.0), min_isotope_err=-10, max_isotope_err=10,
+                                       min_precursor_charge=1, max_precursor_charge=4, report_psms=2), "84 queries per spectrum",
+                          batch=SpectrumBatch(unknown.peak_off, unknown.masses, unknown.intensities, unknown.precursor_mz,
+                                              unknown.precursor_charge, unknown.total_ion_current).subset(np.arange(0, 24)), dev=dev)
     dev.close()
 
 
