@@ -38,6 +38,10 @@ constexpr uint32_t CNT_ROW_HEADER = 4;  // DevWork::cnt_store: words in front of
 #define SAGE_PROBE_PER_LANE 2   // windows whose table reads a lane of the probe kernel keeps in flight (x 64 lanes = one batch); 2 measured best on C3 (LDS footprint vs loads in flight)
 #endif
 constexpr uint32_t PROBE_BATCH_WORDS = SAGE_PROBE_PER_LANE * 64;
+// the run table of a batch: run first / end entry, window lo / hi (PROBE_BATCH_WORDS words each) and the first cell of every run, padded
+// with sentinels to a power of two (the owner search halves it)
+constexpr uint32_t PROBE_TCS_WORDS = PROBE_BATCH_WORDS <= 64 ? 64 : PROBE_BATCH_WORDS <= 128 ? 128 : PROBE_BATCH_WORDS <= 256 ? 256 : 512;
+constexpr uint32_t PROBE_TABLE_WORDS = 4 * PROBE_BATCH_WORDS + PROBE_TCS_WORDS;
 
 // optional per-phase cycle accounting (DevWork::dbg != null): every work item of a launch adds its clock deltas to slot
 // [item mod DBG_BLOCKS][kernel*8 + phase] (debug builds of the numbers only; atomics, so slightly perturbing);
@@ -501,7 +505,7 @@ struct PrelimLds {
     uint64_t* listA;
     uint64_t* listB;
     uint64_t* heap;
-    uint32_t* ptab;  // probe variant: run table of one batch of windows, 3 x PROBE_BATCH words
+    uint32_t* ptab;  // probe variant: run table of one batch of windows, PROBE_TABLE_WORDS words
     uint32_t* cnt;
 };
 
@@ -526,7 +530,7 @@ __device__ __forceinline__ PrelimLds carve_prelim(unsigned char* smem, const Dev
     l.win_lo = (float*)(smem + off); off += win;
     l.win_hi = (float*)(smem + off); off += b.probe ? 0 : win;
     off = (off + 3) & ~(size_t)3;
-    l.ptab = (uint32_t*)(smem + off); off += b.probe ? (size_t)3 * PROBE_BATCH_WORDS * 4 : 0;
+    l.ptab = (uint32_t*)(smem + off); off += b.probe ? (size_t)PROBE_TABLE_WORDS * 4 : 0;
     l.cnt = (uint32_t*)(smem + off);
     return l;
 }
@@ -537,7 +541,7 @@ __host__ __device__ inline size_t prelim_big_bytes(const DevScorer& sc) {  // th
 }
 __host__ __device__ inline size_t prelim_layout_bytes(const DevScorer& sc, const DevBatchView& b, bool huge = false) {
     size_t n = (huge ? 0 : prelim_big_bytes(sc)) +
-               (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)3 * PROBE_BATCH_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
+               (b.probe ? (size_t)b.pcap * 4 + 4 + (size_t)PROBE_TABLE_WORDS * 4 : (size_t)b.fzcap * b.pcap * 8);
     n += ((size_t)sc.wcap / 2 + 1) * 4;
     return (n + 15) & ~(size_t)15;
 }
@@ -595,6 +599,34 @@ __device__ __forceinline__ Window query_window(const float* __restrict__ pep_mon
     if (lut && plo >= 0.0f && phi >= plo && phi * inv_w < (float)bins) {
         const uint32_t b0 = uni((uint32_t)(plo * inv_w)), b1 = uni((uint32_t)(phi * inv_w));  // (the scaling is exact: floor)
         const uint32_t l0 = lut[b0], l1 = lut[b0 + 1], r0 = lut[b1], r1 = lut[b1 + 1];
+#ifndef SAGE_QUERY_ONE_TRIP
+#define SAGE_QUERY_ONE_TRIP 1
+#endif
+        if (SAGE_QUERY_ONE_TRIP && l1 - l0 < WAVE && r1 - r0 < WAVE) {
+            // Both brackets fit a wavefront (the usual case: a bin of 1/128 Da): ONE trip to pep_mono instead of four in a row — the
+            // two partition points from two reads in flight together, and the edge rule's two masses (below) out of the same
+            // registers: lanes of `vl` hold [l0 - 1, l0 + 63), lanes of `vr` [r0, r0 + 64); `left` is l0 - 1 .. l1 - 1 and `right`
+            // r0 .. r1, both inside.  Same comparisons on the same values as the searches of the other branch.
+            const uint32_t lane = lane_id();
+            const uint32_t base_l = l0 ? l0 - 1 : 0;
+            const uint32_t il = base_l + lane, ir = r0 + lane;
+            const float vl = il < np ? pep_mono[il] : 0.0f, vr = ir < np ? pep_mono[ir] : 0.0f;
+            const uint32_t ppl = l0 + (uint32_t)__popcll(__ballot(il >= l0 && il < l1 && order_key(vl) < order_key(plo)));
+            const uint32_t ppr = r0 + (uint32_t)__popcll(__ballot(ir < r1 && order_key(vr) <= order_key(phi)));
+            left = ppl ? ppl - 1 : 0;
+            // (the search of the other branch starts at max(r0, left): everything in front of `left` is below plo <= phi, so its
+            // result is the full bracket's, or `left` where that is larger)
+            right = ppr > left ? ppr : left;
+            q.left = left;
+            q.right = right;
+            q.first = left;
+            q.end = right;
+            const float m_left = lane_valuef(vl, left - base_l);
+            const float m_right = right == left ? m_left : lane_valuef(vr, right - r0);
+            if (left < np && !(m_left >= plo)) q.first = left + 1;
+            if (right < np && m_right <= phi) q.end = right + 1;
+            return q;
+        }
         left = wave_partition_point<true>(pep_mono, l0, l1, order_key(plo));
         left = left ? left - 1 : 0;
         right = wave_partition_point<false>(pep_mono, r0 > left ? r0 : left, r1, order_key(phi));
@@ -695,10 +727,11 @@ __device__ __forceinline__ bool fast_select(const PrelimLds& L, const Counters& 
 #define SAGE_PROBE_CELLS 4      // 16-byte index cells a lane keeps in flight per pass over the flattened runs
 #endif
 constexpr uint32_t PROBE_PER_LANE = SAGE_PROBE_PER_LANE;
-constexpr uint32_t PROBE_BATCH = PROBE_PER_LANE * 64;  // (a power of two: the owner search halves it)
+constexpr uint32_t PROBE_BATCH = PROBE_PER_LANE * 64;
 constexpr uint32_t PROBE_CELLS = SAGE_PROBE_CELLS;
 constexpr uint32_t NO_WINDOW = 0xFFFFFFFFu;
-static_assert((PROBE_BATCH & (PROBE_BATCH - 1)) == 0, "PROBE_BATCH must be a power of two");
+static_assert(PROBE_BATCH == PROBE_BATCH_WORDS && PROBE_BATCH <= 512, "the run table's layout (carve_prelim) is the kernel's");
+static_assert(PROBE_TCS_WORDS - PROBE_BATCH <= WAVE, "one sentinel per lane pads the run starts");
 #ifndef SAGE_NARROW_WAVES
 #define SAGE_NARROW_WAVES 5  // the fused narrow kernel
 #endif
@@ -938,12 +971,39 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                     const uint32_t nprobe = P * nfz;
                     uint32_t* const tp0 = L.ptab;                      // [PROBE_BATCH] first entry of the run
                     uint32_t* const tp1 = L.ptab + PROBE_BATCH;        // [PROBE_BATCH] end entry
-                    uint32_t* const tcs = L.ptab + 2 * PROBE_BATCH;    // [PROBE_BATCH] first cell in the flattened list
+                    uint32_t* const tcs = L.ptab + 4 * PROBE_BATCH;    // [PROBE_TCS_WORDS] first cell in the flattened list, then sentinels
+                    // [PROBE_BATCH] each: the window's bounds, worked out once where its table cells are (round 6: a cell's lane
+                    // repeated window_of — an integer division by P, Tolerance::bounds' two divisions — for every cell it walked)
+                    float* const tlo = (float*)(L.ptab + 2 * PROBE_BATCH);
+                    float* const thi = (float*)(L.ptab + 3 * PROBE_BATCH);
+                    if (PROBE_TCS_WORDS > PROBE_BATCH && lane < PROBE_TCS_WORDS - PROBE_BATCH) tcs[PROBE_BATCH + lane] = NO_WINDOW;  // (never rewritten)
+#ifndef SAGE_PROBE_SYM
+#define SAGE_PROBE_SYM 1      // a symmetric ppm tolerance: one division per window (core.h: tol_bounds_sym, the same bits)
+#endif
+#ifndef SAGE_PROBE_FASTDIV
+#define SAGE_PROBE_FASTDIV 1  // ... and that division in the short form where every lane's dividend is in its proven range
+#endif
+                    const bool sym_ppm = SAGE_PROBE_SYM && (av.sc().tol_mode & TOL_SYM) != 0u && ftol.kind == 0;
                     auto window_of = [&](uint32_t pr, float& flo, float& fhi) {
                         flo = 1.0f; fhi = 0.0f;  // (no such window: empty)
-                        if (pr < nprobe) {
+                        const bool has = pr < nprobe;
+                        float center = 0.f;
+                        if (has) {
                             const uint32_t fz = pr / P, i = pr - fz * P;
-                            tol_bounds(ftol, L.win_lo[i] * (float)(fz + 1), flo, fhi);
+                            center = L.win_lo[i] * (float)(fz + 1);
+                        }
+                        if (sym_ppm) {  // (wave-uniform)
+                            // x / 1e6 of core.h: div_1e6_fast is the IEEE quotient for every x of FAST_DIV_LO <= |x| <= FAST_DIV_HI
+                            // (tests/hostemu/div_const_proof.c walks all 2^32 dividends); here the dividends are the caller's peaks,
+                            // which no host code has bounded — so the lanes look: one window outside (a zero, a NaN, an infinity)
+                            // and the whole wavefront takes the IEEE sequence for this batch
+                            const float x = center * ftol.hi, ax = __builtin_fabsf(x);
+                            float d;
+                            if (SAGE_PROBE_FASTDIV && __ballot(has && !(ax >= FAST_DIV_LO && ax <= FAST_DIV_HI)) == 0ull) d = div_1e6_fast(x);
+                            else d = x / 1000000.0f;
+                            if (has) { flo = center + -d; fhi = center + d; }
+                        } else if (has) {
+                            tol_bounds(ftol, center, flo, fhi);
                         }
                     };
                     for (uint32_t t = t0; t <= t1; t++) {  // (one tile unless the window straddles a tile boundary)
@@ -955,6 +1015,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
 #define SAGE_PROBE_PIPELINE 1
 #endif
                         uint32_t np0[PROBE_PER_LANE], np1[PROBE_PER_LANE];
+                        float nlo[PROBE_PER_LANE], nhi[PROBE_PER_LANE];
                         // The table in succinct form (core.h: LutWord): a window's run is [pos[rank(icl)], pos[rank(ich)]), the ranks from
                         // the occupancy word(s) of its cells — 40 KB per tile, resident in the caches while the tile's spectra are
                         // scored — and equal ranks say "empty" (most windows) without a second read.  The words of all of a lane's
@@ -964,10 +1025,9 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                             LutWord wa[PROBE_PER_LANE], wb[PROBE_PER_LANE];
 #pragma unroll
                             for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
-                                float flo, fhi;
-                                window_of(pbase + i * WAVE + lane, flo, fhi);
+                                window_of(pbase + i * WAVE + lane, nlo[i], nhi[i]);
                                 // (core.h: the scale is a power of two, no safety margin needed)
-                                lut_cells(flo, fhi, lut2_scale, lut2_stride, icl[i], ich[i]);
+                                lut_cells(nlo[i], nhi[i], lut2_scale, lut2_stride, icl[i], ich[i]);
                                 wa[i] = l1[icl[i] >> 5];
                                 wb[i] = l1[ich[i] >> 5];
                             }
@@ -986,7 +1046,11 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                             if (!SAGE_PROBE_PIPELINE) issue(pbase);
                             uint32_t rp0[PROBE_PER_LANE], rp1[PROBE_PER_LANE];
 #pragma unroll
-                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) { rp0[i] = np0[i]; rp1[i] = np1[i]; }
+                            for (uint32_t i = 0; i < PROBE_PER_LANE; i++) {
+                                rp0[i] = np0[i]; rp1[i] = np1[i];
+                                tlo[lane * PROBE_PER_LANE + i] = nlo[i];  // (the previous batch's cells are done: wave_sync below)
+                                thi[lane * PROBE_PER_LANE + i] = nhi[i];
+                            }
                             if (SAGE_PROBE_PIPELINE && pbase + PROBE_BATCH < nprobe) issue(pbase + PROBE_BATCH);
                             uint32_t tot = 0;
 #pragma unroll
@@ -1025,7 +1089,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                                         uint32_t a = 0;  // the owner of cell k: the largest q with tcs[q] <= k (tcs ascends; windows
                                                          // with an empty run share their successor's start)
 #pragma unroll
-                                        for (uint32_t step = PROBE_BATCH / 2; step; step >>= 1) a += (tcs[a + step] <= k) ? step : 0;
+                                        for (uint32_t step = PROBE_TCS_WORDS / 2; step; step >>= 1) a += (tcs[a + step] <= k) ? step : 0;
                                         eq[c] = a;
                                         ej[c] = ((tp0[a] >> 1) + (k - tcs[a])) << 1;
                                         e[c] = frag2[ej[c] >> 1];  // (tm2_frag is padded by 2 entries)
@@ -1035,8 +1099,7 @@ __device__ __forceinline__ PrelimResult prelim_spectrum(const DevDbView& db_, co
                                 for (uint32_t c = 0; c < PROBE_CELLS; c++) {
                                     if (eq[c] == NO_WINDOW) continue;
                                     const uint32_t a = eq[c];
-                                    float lo, hi;
-                                    window_of(pbase + (a % PROBE_PER_LANE) * WAVE + a / PROBE_PER_LANE, lo, hi);
+                                    const float lo = tlo[a], hi = thi[a];
                                     const uint32_t p0 = tp0[a], p1 = tp1[a], j = ej[c];
                                     const float mz0 = __uint_as_float(e[c].y), mz1 = __uint_as_float(e[c].w);
                                     if (j >= p0 && j < p1 && mz0 >= lo && mz0 <= hi && e[c].x >= q.first && e[c].x < q.end) { cnt.add(e[c].x - left, 1); acc++; }
@@ -4105,7 +4168,11 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     if (sc.big_path) k = b.probe ? prelim_kernel<true, false, true> : prelim_kernel<false, false, true>;  // report_psms > 32
     if (sc.big_path && w.hugebuf) k = b.probe ? prelim_kernel<true, false, true, true> : prelim_kernel<false, false, true, true>;
     // (lists in global memory: a workspace slice per workgroup, so the grid is capped and strides over the batch)
-    const uint32_t grid = sc.big_path && w.hugebuf && b.n > HUGE_GRID ? HUGE_GRID : b.n;
+    uint32_t grid = sc.big_path && w.hugebuf && b.n > HUGE_GRID ? HUGE_GRID : b.n;
+    // (SAGE_HIP_PRELIM_GRID: workgroups that stride over the batch instead of one per spectrum — an experiment knob, a multiple of 8
+    // so that a workgroup's spectra stay on its XCD's share of the schedule)
+    static const uint32_t grid_cap = [] { const char* e = getenv("SAGE_HIP_PRELIM_GRID"); return e ? (uint32_t)strtoul(e, nullptr, 10) & ~7u : 0u; }();
+    if (grid_cap && grid > grid_cap) grid = grid_cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), prelim_lds_bytes(sc, b, sc.big_path && w.hugebuf), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
