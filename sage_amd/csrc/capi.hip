@@ -237,7 +237,7 @@ struct SageScorer {
     uint32_t kstride = 64;           // entries per query of the large-window pipeline's seed / heap arrays (DevWork::kstride)
     bool two_lanes = true;           // streaming pipeline: two chunks of a narrow batch side by side (SAGE_HIP_ONE_LANE=1: one at a time)
     uint32_t search_lag = 0;         // SAGE_HIP_SEARCH_LAG (DevWork::search_lag)
-    uint64_t replay_split = 32768;   // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split)
+    uint64_t replay_split = 0xFFFFFFFFull;  // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split); default: every query by wavefront
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
     bool zero_copy = true;      // records go straight to page-locked result arrays (SAGE_HIP_NO_ZEROCOPY=1: device buffer + copy)

@@ -149,7 +149,7 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t* ready;       // [n] search_kernel: == epoch once the spectrum's preliminary list is in HBM (written with agent-scope release)
     uint32_t epoch;        //     of this launch (never 0; the array is zeroed when it is allocated)
     uint64_t replay_split; // which heap-replay kernel takes a query: low 32 bits = queries up to which every query gets a wavefront
-                           //     (SAGE_HIP_REPLAY_WAVE_MAX, default 32768), high 32 bits = stream words above which a query does
+                           //     (SAGE_HIP_REPLAY_WAVE_MAX; default 0xFFFFFFFF: every query, the lane-per-query kernel is not launched), high 32 bits = stream words above which a query does
                            //     anyway (SAGE_HIP_REPLAY_LANE_MAX, 0: the default of kernels.hip)
     uint32_t kstride;      // entries per query of `seeds` / `qres`: kmax rounded up to a multiple of 64 (64 unless report_psms > 32)
     uint32_t search_lag;   //     workgroup ids by which a spectrum's rescoring trails its preliminary workgroup (0: the default)

@@ -359,30 +359,38 @@ __device__ __forceinline__ void wh32_offer(Heap32& H, uint32_t k, uint32_t v) { 
 // path never decrease — the new value stops behind the path nodes that are smaller (a prefix of the path: one more ballot).  A path
 // node above the stop takes its smaller child's value (it has it already), the node at the stop takes `v`; a node's depth is a
 // function of its lane.  Same array as the loop, every time (the GPU suite's exact paths and the config-scale parity run through it).
-__device__ __forceinline__ void wh32_replace_root(Heap32& H, uint32_t k, uint32_t v) {
+// (round 6, second step: the path was a scalar loop, ~12 dependent scalar instructions for each of six levels — 43 scalar instructions
+// per offer, the replay's time.  Which nodes lie on the path is a question every lane answers for itself: lane L is on it iff every
+// ancestor of L chose the child that leads to L, i.e. `rm` restricted to L's ancestors equals a constant of the lane — two 64-bit
+// masks per lane, made once per kernel: HeapPath.)
+struct HeapPath {
+    uint64_t anc, want;  // bit a: node a is an ancestor of this lane's node / ... and the way down to it takes a's RIGHT child
+    uint32_t depth;
+};
+__device__ __forceinline__ HeapPath heap_path_of_lane() {
+    HeapPath hp{0ull, 0ull, 0u};
+    const uint32_t n = lane_id() + 1u;  // (1-based: the children of m are 2m and 2m + 1)
+    for (uint32_t c = n; c > 1u; c >>= 1) {
+        const uint32_t a = (c >> 1) - 1u;
+        hp.anc |= 1ull << a;
+        if (c & 1u) hp.want |= 1ull << a;
+    }
+    hp.depth = 31u - (uint32_t)__clz((int)n);
+    return hp;
+}
+__device__ __forceinline__ void wh32_replace_root(Heap32& H, uint32_t k, uint32_t v, const HeapPath& path) {
     const uint32_t lane = lane_id();
     const uint32_t l = 2 * lane + 1, r = l + 1;
     const uint32_t hl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l & 63u) << 2), (int)H.h);
     const uint32_t hr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) << 2), (int)H.h);
     const bool right = r < k && hr < hl;
     const uint64_t rm = __ballot(right);
-    uint64_t pm = 1ull;  // nodes on the path the sift takes
-    uint32_t p = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 6; i++) {
-        const uint32_t c = 2 * p + 1;
-        if (c < k) {
-            p = c + (uint32_t)((rm >> p) & 1ull);
-            pm |= 1ull << p;
-        }
-    }
-    const bool onpath = (pm >> lane) & 1ull;
-    const uint32_t depth = 31u - (uint32_t)__clz((int)(lane + 1u));
+    const bool onpath = lane < k && (rm & path.anc) == path.want;
     const uint32_t stop = (uint32_t)__popcll(__ballot(onpath && lane != 0u && H.h < v));  // path nodes below the root that move up
-    if (onpath) H.h = depth < stop ? (right ? hr : hl) : depth == stop ? v : H.h;
+    if (onpath) H.h = path.depth < stop ? (right ? hr : hl) : path.depth == stop ? v : H.h;
 }
-__device__ __forceinline__ void wh32_offer_par(Heap32& H, uint32_t k, uint32_t v) {  // heap.rs:21-27
-    if (k && v > wh32_get(H, 0)) wh32_replace_root(H, k, v);
+__device__ __forceinline__ void wh32_offer_par(Heap32& H, uint32_t k, uint32_t v, const HeapPath& path) {  // heap.rs:21-27
+    if (k && v > wh32_get(H, 0)) wh32_replace_root(H, k, v, path);
 }
 
 // CList (core.h) with wave-uniform bookkeeping: every lane holds the same stored/len, appends are
@@ -2371,7 +2379,10 @@ __global__ __launch_bounds__(64) void tile_select_kernel(DevScorer sc, DevWork w
 // kernel lasts as long as the longest stream among its 64 lanes, one word per round, so streams above LANE_MAX_CAND words go
 // to the wavefront-per-query kernel, which skims 64 words per step and only pays for the offers that enter the heap.
 // (Round 6: 4096 -> 2048 — the wavefront kernel's offers are 2.5x cheaper since wh32_replace_root, and the two kernels run side by
-// side: C5's retry pass 13.7 -> 11.7 ms with 2048, 14.3 / 14.9 ms with 1024 / 512: scripts/experiments/r06_lab/gpu_r6r.sh.)
+// side: C5's retry pass 13.7 -> 11.7 ms with 2048, 14.3 / 14.9 ms with 1024 / 512: scripts/experiments/r06_lab/gpu_r6r.sh.  Then the
+// path of the root replacement from per-lane masks: 11.5 -> 9.0 ms at 2048, 6.6 ms at 512 .. 64 and with every query by wavefront —
+// gpu_r7i.sh / gpu_r7j.sh — and DevWork::replay_split's default became "every query by wavefront": this constant only matters when
+// SAGE_HIP_REPLAY_WAVE_MAX asks for the split.)
 constexpr uint32_t LANE_MAX_CAND = 2048;  // (SAGE_HIP_REPLAY_LANE_MAX overrides it: the upper 32 bits of the kernels' `wave_max`)
 __device__ __forceinline__ bool replay_by_wavefront(const QueryRec& rec, uint64_t n_q, uint64_t wave_max) {
     const uint32_t lane_max = (uint32_t)(wave_max >> 32) ? (uint32_t)(wave_max >> 32) : LANE_MAX_CAND;
@@ -2398,6 +2409,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
     uint32_t n_offers = 0;
     if (small_keys) {  // keys `matched << 21 | slot`, 0 == empty (ReplayKey<uint32_t>)
         Heap32 hp;
+        const HeapPath path = heap_path_of_lane();
         wh32_init(hp, seed_c ? (seed_c << K32_SLOT_BITS) | lane : 0u, k);
         wh32_build(hp, k);
         for_each_candidate_batch(w, rec, marks, [&](uint32_t e, uint32_t tile_base) {
@@ -2409,7 +2421,7 @@ __device__ __forceinline__ void tile_replay_wave_query(const DevScorer& sc, cons
             while (mask) {
                 const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                 mask &= mask - 1;
-                wh32_offer_par(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                wh32_offer_par(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)), path);
             }
         });
         if (lane < k) w.qres[qid * w.kstride + lane] = ReplayKey<uint32_t>::unpack(hp.h, rec.left, z, iso);
@@ -4205,15 +4217,14 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
         return;
     }
     if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
-    // bounded_min_heapify replay: a wavefront per query while the queries to replay are fewer than the wavefront slots — always
-    // the case with order-free trims, where only queries with a clipped histogram are replayed; with more queries than that, a
-    // lane per query (far fewer instructions per offer, but a wavefront lasts as long as its longest stream) for all but the
-    // long streams
+    // bounded_min_heapify replay: a wavefront per query (the default for every query since the round-6 root replacement —
+    // wh32_replace_root: ~12 vector instructions per offer —, which made the lane-per-query kernel's best case, many short streams,
+    // no faster: C5's retry pass 6.6 ms whichever way the queries are split below 512 stream words).  The lane-per-query kernel
+    // stays for DevWork::replay_split settings that ask for it (tests; SAGE_HIP_REPLAY_WAVE_MAX / _LANE_MAX).
     uint64_t wave_max = w.replay_split;
     if (!sc.exact && (wave_max & 0xFFFFFFFFull)) wave_max |= 0xFFFFFFFFull;
-    // (the two take disjoint sets of queries: side by side when the caller lends a second stream — the long streams of the one
-    // are a few serial wavefronts, the other fills the rest of the GPU)
-    const bool both = sc.exact || !(wave_max & 0xFFFFFFFFull);
+    // (the two take disjoint sets of queries: side by side when the caller lends a second stream)
+    const bool both = (wave_max & 0xFFFFFFFFull) != 0xFFFFFFFFull && (sc.exact || !(wave_max & 0xFFFFFFFFull));
     hipStream_t lane_stream = (hipStream_t)stream;
     if (both && side) {
         lane_stream = (hipStream_t)side->stream;

@@ -318,15 +318,18 @@ def test_wide_tolerance_hits_large_window_path(small_world):
     assert t["n_wide"] > 0
 
 
-@pytest.mark.parametrize("tile_shift,replay", [(11, "wave"), (12, "lane"), (15, "wave"), (15, "lane")])
+@pytest.mark.parametrize("tile_shift,replay", [(11, "wave"), (12, "lane"), (15, "wave"), (15, "lane"), (12, "both")])
 def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     """The tiled large-window kernel with small tiles (2048 / 4096 peptides) so that every window spans many
     tiles, the first k slots straddle tile boundaries, and partial first/last tiles occur: ±500 Da, isotope
     folding, unknown charge, report_psms > 1 — every branch of the nested k-selects."""
     monkeypatch.setenv("SAGE_HIP_TILE_SHIFT", str(tile_shift))
     monkeypatch.setenv("SAGE_HIP_WCAP", "64")
-    if replay == "lane":  # the heap replay kernel with one lane per query (normally picked for > 32768 queries)
+    if replay == "lane":  # the heap replay kernel with one lane per query (since round 6 only where these knobs ask for it)
         monkeypatch.setenv("SAGE_HIP_REPLAY_WAVE_MAX", "0")
+    if replay == "both":  # ... and the two side by side: streams above 64 words by wavefront, the rest a lane each
+        monkeypatch.setenv("SAGE_HIP_REPLAY_WAVE_MAX", "4")
+        monkeypatch.setenv("SAGE_HIP_REPLAY_LANE_MAX", "64")
     dev = DeviceDatabase(small_world.host, 0)
     idx = np.arange(0, small_world.batch.n, 5)
     sub = small_world.batch.subset(idx)
@@ -412,6 +415,15 @@ def test_edge_cases(small_world):
     small_world.check(ScorerParams(), "edge cases", batch=eb)
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -5000.0, 5000.0), min_matched_peaks=1), "edge, all peptides",
                       batch=eb)
+    # a zero and a tiny peak mass in front of a real spectrum: dividends outside the range the short division by 1e6 is proved for
+    # (core.h: FAST_DIV_LO) — prelim_kernel's probe takes the IEEE sequence for that batch of windows (kernels.hip: window_of)
+    s5 = slice(int(b.peak_off[5]), int(b.peak_off[6]))
+    zm = np.concatenate([np.array([0.0, 1e-30], np.float32), b.masses[s5]])
+    zi = np.concatenate([np.array([3.0, 4.0], np.float32), b.intensities[s5]])
+    zb = SpectrumBatch([0, len(zm), len(zm) + (s5.stop - s5.start)], np.concatenate([zm, b.masses[s5]]),
+                       np.concatenate([zi, b.intensities[s5]]), [float(b.precursor_mz[5])] * 2, [int(b.precursor_charge[5])] * 2,
+                       [float(np.sum(zi, dtype=np.float32)), float(np.sum(b.intensities[s5], dtype=np.float32))])
+    assert small_world.check(ScorerParams(report_psms=2), "zero and tiny peak masses", batch=zb)[0] >= 2
     # empty batch
     scorer = Scorer(small_world.dev, ScorerParams())
     feats, counts = scorer.score(SpectrumBatch([0], [], [], [], [], []))
