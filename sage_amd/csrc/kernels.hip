@@ -3427,6 +3427,10 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                             wh32_init(hp, c ? (c << 16) | lane : 0u, k);
                         }
                         wh32_build(hp, k);
+#ifndef SAGE_TIE_REPLAY_PAR
+#define SAGE_TIE_REPLAY_PAR 1  // the offers' root replacement by all lanes at once (wh32_replace_root with its per-lane path masks)
+#endif
+                        const HeapPath path = heap_path_of_lane();
                         for (uint32_t base = k; base < potential; base += WAVE) {
                             const uint32_t i = base + lane;
                             const uint32_t c = i < potential ? cnt.get(i) : 0;
@@ -3435,7 +3439,9 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                             while (mask) {
                                 const uint32_t bit = (uint32_t)__ffsll((long long)mask) - 1;
                                 mask &= mask - 1;
-                                wh32_offer(hp, k, (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit)));
+                                const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane(bit));
+                                if (SAGE_TIE_REPLAY_PAR) wh32_offer_par(hp, k, vv, path);
+                                else wh32_offer(hp, k, vv);
                             }
                         }
                         hl = hp.h;
