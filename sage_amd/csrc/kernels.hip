@@ -125,6 +125,14 @@ __device__ __forceinline__ uint32_t xcd_position(uint32_t b, uint32_t n, uint32_
 }
 
 // wave-uniform values that come out of memory land in VGPRs; these move them to SGPRs (the value must be uniform)
+// A zero register made on the spot: a literal 0 that feeds a store inside a loop is hoisted out of the loop and — in a kernel that is
+// out of registers — SPILLED there; it comes back as a scratch load in front of the store, and the s_waitcnt vmcnt(0) behind that load
+// also waits for every index cell the kernel has in flight (tile_count_body's clears; rescore_kernel: fresh_zero4).
+__device__ __forceinline__ uint32_t fresh_zero() {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
@@ -1339,11 +1347,28 @@ struct TileLds {
     // wavefront's flattened cell list; psum[w] = cells of wavefront w's windows
     uint32_t* pp0;      // [TILE_THREADS]
     uint32_t* pp1;      // [TILE_THREADS]
-    uint32_t* pcs;      // [TILE_THREADS]
-    uint32_t* psum;     // [TILE_WAVES]
+    uint32_t* pcs;      // [TILE_THREADS] first cell of the window's run in the UNIT's flattened cell list
+    uint32_t* psum;     // [TILE_WAVES] cells of wavefront w's windows
+    uint32_t* nz;       // [TILE_WAVES] windows of wavefront w with a non-empty run
+    // where the runs start (round 6: a cell's owner by rank, not by search — tile_count_body: locate): per block of 64 flattened cells
+    // one 64-bit word, bit j = a run starts at cell 64 b + j (two sets, units alternate: the idle one is cleared while the other is
+    // marked), and the rank — index among the unit's non-empty runs — of the run that owns the block's first cell; cpid: rank -> window
+    uint32_t* mbits;    // [2][mark_blocks][2]
+    uint32_t* mbase;    // [mark_blocks]
+    uint16_t* cpid;     // [TILE_THREADS]
     uint32_t* qw;       // [TILE_QW_MAX * 4] {left, right, first, end} of the spectrum's precursor-window queries, searched up front
 };
 constexpr uint32_t TILE_QW_MAX = 64;  // queries per spectrum whose windows are searched up front, a wavefront each (more: one by one)
+// blocks of 64 flattened cells the run-start marks of a unit cover at a time (a unit with more cells re-marks, a rare and slow path):
+// the u8 instance keeps 3 cells per thread in flight (1 536 per round, 24 blocks), the u16 one 4 (2 048, 32 blocks) and has the LDS of
+// two workgroups per compute unit to fit
+#ifndef SAGE_MARK_BLOCKS8
+#define SAGE_MARK_BLOCKS8 96
+#endif
+#ifndef SAGE_MARK_BLOCKS16
+#define SAGE_MARK_BLOCKS16 40
+#endif
+__host__ __device__ constexpr uint32_t tile_mark_blocks(bool cnt8) { return cnt8 ? SAGE_MARK_BLOCKS8 : SAGE_MARK_BLOCKS16; }
 // `wing`: the windows of the spectrum live in a global-memory workspace instead (tile_count_wing_kernel: spectra whose peaks x
 // fragment charges do not fit a compute unit's LDS next to the counters)
 __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const DevBatchView& b, TileLds* l, unsigned char* smem, bool cnt8,
@@ -1370,6 +1395,15 @@ __host__ __device__ inline size_t tile_lds_layout(uint32_t tile_shift, const Dev
     off += TILE_THREADS * 4;
     if (l) l->psum = (uint32_t*)(smem + off);
     off += TILE_WAVES * 4;
+    if (l) l->nz = (uint32_t*)(smem + off);
+    off += TILE_WAVES * 4;
+    static_assert((2 * TILE_WAVES * 4) % 16 == 0, "psum, nz, mbits, mbase, cpid back to back (tile_count_body derives them from psum)");
+    if (l) l->mbits = (uint32_t*)(smem + off);
+    off += (size_t)2 * tile_mark_blocks(cnt8) * 8;
+    if (l) l->mbase = (uint32_t*)(smem + off);
+    off += (size_t)tile_mark_blocks(cnt8) * 4;
+    if (l) l->cpid = (uint16_t*)(smem + off);
+    off += TILE_THREADS * 2;
     off = (off + 15) & ~(size_t)15;
     if (l) l->qw = (uint32_t*)(smem + off);
     off += 64 * 4 * 4;  // (TILE_QW_MAX, declared below the struct)
@@ -1463,6 +1497,12 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     uint32_t* const l_pp1 = lds_.pp1;
     uint32_t* const l_pcs = lds_.pcs;
     uint32_t* const l_psum = lds_.psum;
+    constexpr uint32_t MARK_BLOCKS = tile_mark_blocks(C8);
+    // (constant distances from l_psum — tile_lds_layout lays them out back to back — so that they cost address offsets, not registers)
+    uint32_t* const l_nz = l_psum + TILE_WAVES;
+    uint32_t* const l_mbits = l_psum + 2 * TILE_WAVES;
+    uint32_t* const l_mbase = l_mbits + 4 * MARK_BLOCKS;
+    uint16_t* const l_cpid = (uint16_t*)(l_mbase + MARK_BLOCKS);
     uint32_t* const l_qw = lds_.qw;
     const uint32_t TSH = ka->db.tile_shift, TS = 1u << TSH;
     // counter words (SPW slots each) a thread scans: words [tid * wpt, (tid + 1) * wpt) == slots [SPW * tid * wpt, ...), so thread
@@ -1666,38 +1706,35 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                 SAGE_FOR_CELLS(SAGE_DECL_CELL)
 #undef SAGE_DECL_CELL
                 uint32_t unit_cells = 0;  // cells of the current unit (uniform)
-                // locate flattened cell k of the published unit: wavefront by the wave totals, window by a 6-step search
-                // the running totals of the eight wavefronts' cell counts of the published unit: e1 .. e7 and the unit's total (publish)
-                uint4 psA = make_uint4(0u, 0u, 0u, 0u), psB = psA;
-                auto locate = [&](uint32_t k, uint32_t& pr, uint32_t& j) {
-#if SAGE_LOCATE_LINEAR
-                    uint32_t wv = 0, base = 0;
-                    const uint32_t pe[TILE_WAVES - 1] = {psA.x, psA.y, psA.z, psA.w, psB.x, psB.y, psB.z};
-#pragma unroll
-                    for (uint32_t i = 0; i + 1 < TILE_WAVES; i++) {
-                        const bool past = k >= pe[i];
-                        base = past ? pe[i] : base;
-                        wv += past ? 1 : 0;
-                    }
-#else
-                    // the wavefront that owns flattened cell k: the number of running totals <= k, by bisection (the kernel is bound
-                    // by vector issue — r05_C4_bench.json: roofline.issue — and this runs once per cell: 14 instructions, 35 before)
-                    const bool b4 = k >= psA.w;                                                        // e4
-                    const uint32_t m2 = b4 ? psB.y : psA.y;                                            // e6 : e2
-                    const bool b2 = k >= m2;
-                    const uint32_t m1 = b4 ? (b2 ? psB.z : psB.x) : (b2 ? psA.z : psA.x);              // e7 : e5 : e3 : e1
-                    const bool b1 = k >= m1;
-                    const uint32_t wv = (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
-                    const uint32_t lo2 = b4 ? psA.w : 0u;                                              // e4 : e0
-                    const uint32_t base = b1 ? m1 : (b2 ? m2 : lo2);                                   // e_wv
-#endif
-                    const uint32_t kk = k - base;
-                    uint32_t a = 0;  // largest lane with pcs[wv * 64 + lane] <= kk: the owner of cell kk (pcs ascends inside a
-                                     // wavefront and lanes with empty runs share their successor's start)
-#pragma unroll
-                    for (uint32_t step = 32; step; step >>= 1) a += (l_pcs[wv * 64 + a + step] <= kk) ? step : 0;
-                    pr = wv * 64 + a;
-                    j = ((l_pp0[pr] >> 1) + (kk - l_pcs[pr])) << 1;
+                // locate flattened cell k of the published unit (round 6).  Until then: the owner wavefront by a walk over the eight
+                // wave totals, the window by a 6-step search over that wavefront's run starts in LDS — 60 vector instructions and seven
+                // dependent LDS reads per cell, 40 % of the instructions of a kernel that is bound by their issue.  A wavefront's 64 cells
+                // of one slot are 64 CONSECUTIVE cells, one aligned block of the unit's flattened list: with one bit per cell, set where a
+                // run starts, and the rank of the run that owns the block's first cell (published by that run), the owner of cell 64 b + j
+                // is base[b] + popcount(bits 1..j of word b) — one uniform LDS read, two v_mbcnt — and `cpid` names its window.
+                // (unit u uses the set of mark words u & 1; `mark_lo`: the first flattened cell the marks cover, a multiple of 64 — 0
+                // except in a unit that re-marked)
+                static_assert(MARK_BLOCKS * 64u >= (C8 ? SAGE_TILE8_CELLS : CELLS_PER_THREAD) * TILE_THREADS, "the marks cover a round of cells");
+                static_assert(MARK_BLOCKS * 2u <= TILE_THREADS, "a thread clears one word of the idle set");
+                auto locate = [&](uint32_t k, uint32_t mset, uint32_t blk, uint32_t& pr, uint32_t& j) {
+                    const uint2 bw = *(const uint2*)(l_mbits + (mset * MARK_BLOCKS + blk) * 2u);  // (one address per wavefront)
+                    const uint32_t b_lo = (bw.x >> 1) | (bw.y << 31), b_hi = bw.y >> 1;             // bits 1.. of the word: starts behind the block's first cell
+                    const uint32_t r = l_mbase[blk] + __builtin_amdgcn_mbcnt_hi(b_hi, __builtin_amdgcn_mbcnt_lo(b_lo, 0u));
+                    pr = l_cpid[r];
+                    j = ((l_pp0[pr] >> 1) + (k - l_pcs[pr])) << 1;
+                };
+                // run-start marks of the windows of the published unit for cells [mark_lo, mark_lo + 64 MARK_BLOCKS): this thread's run
+                // is cells [g, g + ncell), the rank-th non-empty run of the unit
+                auto mark_run = [&](uint32_t g, uint32_t ncell, uint32_t rank, uint32_t mset, uint32_t mark_lo) {
+                    if (ncell == 0u) return;
+                    uint32_t* const bits = l_mbits + mset * MARK_BLOCKS * 2u;
+                    if (g >= mark_lo && g - mark_lo < MARK_BLOCKS * 64u) atomicOr(&bits[(g - mark_lo) >> 5], 1u << ((g - mark_lo) & 31u));
+                    // the blocks whose first cell lies inside the run (most runs: none)
+                    const uint32_t b0 = g <= mark_lo ? 0u : (g - mark_lo + 63u) >> 6;
+                    const uint32_t last = g + ncell - 1u;  // (>= g)
+                    if (last < mark_lo) return;
+                    const uint32_t b1 = (last - mark_lo) >> 6;
+                    for (uint32_t bb = b0; bb <= b1 && bb < MARK_BLOCKS; bb++) l_mbase[bb] = rank;
                 };
 #define SAGE_LOAD_CELL(I)                                                        \
     {                                                                            \
@@ -1705,7 +1742,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         cpr##I = NONE32;                                                         \
         ce##I = make_uint4(0u, 0u, 0u, 0u);                                      \
         if (I < CPT && k_ < unit_cells) {                                        \
-            locate(k_, cpr##I, cjj##I);                                          \
+            locate(k_, mset_, ((kbase_ - mark_lo_) >> 6) + I * TILE_WAVES + wave, cpr##I, cjj##I); \
             ce##I = frag2[cjj##I >> 1]; /* (tm_frag is padded by 2 entries) */   \
         }                                                                        \
     }
@@ -1755,9 +1792,12 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
         if (hit##I##H && c_ + 1 == thr) atomicOr(&l_bm[x##I##H >> 5], 1u << (x##I##H & 31u));          \
     }
 #define SAGE_ACCOUNT_CELL(I) if (any_##I) { SAGE_ACCOUNT(I, a) SAGE_ACCOUNT(I, b) }
-                // publish unit u (its table values have arrived in np0 / np1) and put the table reads of unit u + 1 in flight.
-                // One barrier inside; the caller has made sure nobody still reads the previous unit's run table.
-                auto publish = [&](uint32_t u) {
+                // publish unit u (its table values have arrived in np0 / np1) and put the table reads of unit u + 1 in flight — in two
+                // steps with a workgroup barrier between them (the caller's: the one behind the previous unit's hits) and one behind.
+                // Step 1: this window's run, the wavefront's totals.  Step 2, when all eight wavefronts' totals are there: where the
+                // run lies in the unit's flattened cell list and which of the non-empty runs it is; its marks (locate).  The caller
+                // has made sure nobody still reads the previous unit's run table.
+                auto publish_totals = [&](uint32_t u) {
                     if (quads) {
                         if (u == 0)  // (a walk that starts inside a quad: bring its first tile to the front)
                             for (uint32_t r = 0; r < (t0 & 3u); r++) {
@@ -1769,21 +1809,39 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         qa = make_uint4(qa.y, qa.z, qa.w, 0u);
                         qb = make_uint4(qb.y, qb.z, qb.w, 0u);
                     }
+                    const uint32_t ncell = np1 > np0 ? ((np1 - 1) >> 1) - (np0 >> 1) + 1 : 0;
+                    const uint32_t total = wave_sum_dpp(ncell);
+                    const uint64_t nzm = __ballot(ncell != 0u);
+                    if (lane == 0) {
+                        l_psum[wave] = total;
+                        l_nz[wave] = (uint32_t)__popcll(nzm);
+                    }
+                };
+                auto publish = [&](uint32_t u) {
+                    static_assert(TILE_WAVES == 8, "eight wave totals");
+                    // (nothing of step 1 is kept in registers across the barrier: the scan again — 12 instructions against three live values
+                    // in a kernel that spills)
                     const uint32_t p0 = np0, p1 = np1;
                     const uint32_t ncell = p1 > p0 ? ((p1 - 1) >> 1) - (p0 >> 1) + 1 : 0;
-                    const uint32_t incl = wave_incl_scan_dpp(ncell);  // inclusive prefix over the lanes
+                    const uint32_t pub_incl = wave_incl_scan_dpp(ncell);  // inclusive prefix over the lanes
+                    // exclusive prefixes of the eight wavefronts' totals (cells, non-empty runs), this wavefront's picked by a lane read
+                    const uint32_t tc = lane < TILE_WAVES ? l_psum[lane] : 0u, tn = lane < TILE_WAVES ? l_nz[lane] : 0u;
+                    const uint32_t ic = wave_incl_scan_dpp(tc), in = wave_incl_scan_dpp(tn);
+                    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readlane((int)(ic - tc), (int)uni(wave));
+                    const uint32_t nbase = (uint32_t)__builtin_amdgcn_readlane((int)(in - tn), (int)uni(wave));
+                    const uint32_t g = wbase + pub_incl - ncell;
+                    const uint64_t nzm = __ballot(ncell != 0u);
+                    const uint32_t rank = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
+                    const uint32_t mset = u & 1u;
                     l_pp0[tid] = p0;
                     l_pp1[tid] = p1;
-                    l_pcs[tid] = incl - ncell;
-                    if (lane == 63) l_psum[wave] = incl;
+                    l_pcs[tid] = g;
+                    if (ncell) l_cpid[rank] = (uint16_t)tid;
+                    mark_run(g, ncell, rank, mset, 0u);
+                    if (tid < MARK_BLOCKS * 2u) l_mbits[(mset ^ 1u) * MARK_BLOCKS * 2u + tid] = fresh_zero();  // (the previous unit's: read for the last time two barriers ago)
                     issue_lut(u + 1);
                     lds_barrier();
-                    static_assert(TILE_WAVES == 8, "psA / psB hold the eight wave totals");
-                    psA = *(const uint4*)l_psum;
-                    psB = *(const uint4*)(l_psum + 4);
-                    psA.y += psA.x; psA.z += psA.y; psA.w += psA.z;  // running totals e1 .. e4
-                    psB.x += psA.w; psB.y += psB.x; psB.z += psB.y; psB.w += psB.z;  // e5 .. e7, the unit's total
-                    unit_cells = uni(psB.w);
+                    unit_cells = (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
                     if (pc.slot && tid == 0) {
                         const uint32_t pb = (u % nb) * TILE_THREADS;
                         if (!(ka->sc.dbg_flags & 1024u)) {
@@ -1792,10 +1850,29 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         }
                     }
                 };
+                // a unit with more cells than the marks cover (cold): the marks again, from cell `from` on — every thread's run from
+                // the run table, between barriers of the whole workgroup (the condition is workgroup-uniform)
+                auto remark = [&](uint32_t from, uint32_t mset) {
+                    lds_barrier();  // (every wavefront is done with the marks as they are)
+                    if (tid < MARK_BLOCKS * 2u) l_mbits[mset * MARK_BLOCKS * 2u + tid] = 0;
+                    lds_barrier();
+                    const uint32_t p0 = l_pp0[tid], p1 = l_pp1[tid];
+                    const uint32_t ncell = p1 > p0 ? ((p1 - 1) >> 1) - (p0 >> 1) + 1 : 0;
+                    const uint32_t tn = lane < TILE_WAVES ? l_nz[lane] : 0u;
+                    const uint32_t in = wave_incl_scan_dpp(tn);
+                    const uint32_t nbase = (uint32_t)__builtin_amdgcn_readlane((int)(in - tn), (int)uni(wave));
+                    const uint64_t nzm = __ballot(ncell != 0u);
+                    const uint32_t rank = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
+                    mark_run(l_pcs[tid], ncell, rank, mset, from);
+                    lds_barrier();
+                };
+                if (tid < MARK_BLOCKS * 4u) l_mbits[tid] = 0;  // (both sets of marks; ordered by the barrier below)
                 issue_lut(0);
+                publish_totals(0);
+                lds_barrier();
                 publish(0);
                 {
-                    const uint32_t kbase_ = 0;
+                    const uint32_t kbase_ = 0, mset_ = 0, mark_lo_ = 0;
                     SAGE_FOR_CELLS(SAGE_LOAD_CELL)
                 }
                 uint32_t trans = 0, t01 = 0, t12 = 0, t23 = 0;  // slots this thread moved from count 0 -> 1, 1 -> 2, 2 -> 3 (histogram transitions)
@@ -1817,13 +1894,15 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                             SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)    // ... then the bookkeeping of the hits
                             t01 += trans & 0xFFu; t12 += (trans >> 8) & 0xFFu; t23 += (trans >> 16) & 0xFFu; trans = 0;
                         }
+                        uint32_t mark_lo_ = 0;
+                        const uint32_t mset_ = u & 1u;
                         for (uint32_t kbase_ = CPT * TILE_THREADS; kbase_ < unit_cells; kbase_ += CPT * TILE_THREADS) {
-                            // (the wave totals again from LDS — still the published unit's —, so that the eight registers they
-                            // take are dead across the apply phase above instead of spilled around it)
-                            psA = *(const uint4*)l_psum;
-                            psB = *(const uint4*)(l_psum + 4);
-                            psA.y += psA.x; psA.z += psA.y; psA.w += psA.z;
-                            psB.x += psA.w; psB.y += psB.x; psB.z += psB.y; psB.w += psB.z;
+                            // (SAGE_HIP_DEBUG_FLAGS=2048: tests let the marks cover one round only, so that every further round re-marks)
+                            const uint32_t cover = (ka->sc.dbg_flags & 2048u) ? CPT * TILE_THREADS : MARK_BLOCKS * 64u;
+                            if (kbase_ + CPT * TILE_THREADS > mark_lo_ + cover) {  // (workgroup-uniform)
+                                remark(kbase_, mset_);
+                                mark_lo_ = kbase_;
+                            }
                             SAGE_FOR_CELLS(SAGE_LOAD_CELL)  // (a unit with more cells than fit in flight: the rest synchronously)
                             SAGE_FOR_CELLS(SAGE_APPLY_CELL)
                             SAGE_FOR_CELLS(SAGE_ACCOUNT_CELL)
@@ -1843,13 +1922,14 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                         }
                         t01 = t12 = t23 = 0;
                     }
+                    if (u + 1 < n_units) publish_totals(u + 1);
                     pc.mark(1);
-                    lds_barrier();  // every hit of the unit is counted; its run table is free
+                    lds_barrier();  // every hit of the unit is counted; its run table is free; the next unit's wave totals are there
                     pc.mark(2);
                     TILE_ARGS();
                     if (u + 1 < n_units) {
                         publish(u + 1);
-                        const uint32_t kbase_ = 0;
+                        const uint32_t kbase_ = 0, mset_ = (u + 1) & 1u, mark_lo_ = 0;
                         SAGE_FOR_CELLS(SAGE_LOAD_CELL)
                     }
                     if (!last_unit) continue;  // (more windows of this tile to come)
@@ -1994,33 +2074,34 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
                     TILE_ARGS();
                     // clear this thread's counters and candidate bits (its own range only: no other wavefront reads them; what lies
                     // outside [vs, vs + 512 spt_v) was never touched)
+                    const uint32_t zr = fresh_zero();  // (not a literal: see fresh_zero)
                     if (whole_tile) {
                         const uint32_t w_lo = tid * wpt;
                         if (w_lo < TS / SPW) {
                             if (wpt >= 4) {
-                                for (uint32_t i = 0; i < wpt; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(0u, 0u, 0u, 0u);
+                                for (uint32_t i = 0; i < wpt; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(zr, zr, zr, zr);
                             } else {
-                                for (uint32_t i = 0; i < wpt; i++) l_cnt[w_lo + i] = 0;
+                                for (uint32_t i = 0; i < wpt; i++) l_cnt[w_lo + i] = zr;
                             }
                         }
                         if (tid * spt < TS) {
-                            if (spt >= 64) *(uint2*)(l_bm + tid * 2) = make_uint2(0u, 0u);
-                            else if (((tid * spt) & 31u) == 0) l_bm[(tid * spt) >> 5] = 0;
+                            if (spt >= 64) *(uint2*)(l_bm + tid * 2) = make_uint2(zr, zr);
+                            else if (((tid * spt) & 31u) == 0) l_bm[(tid * spt) >> 5] = zr;
                         }
                     } else if (x0 < TS) {
                         const uint32_t w_lo = x0 / SPW;                                   // (x0 is a multiple of spt_v >= SPW)
                         const uint32_t w_n = x0 + spt_v <= TS ? spt_v / SPW : (TS - x0) / SPW;  // (the last piece may end with the tile)
                         if (spt_v / SPW >= 4 && w_n == spt_v / SPW) {
-                            for (uint32_t i = 0; i < w_n; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(0u, 0u, 0u, 0u);
+                            for (uint32_t i = 0; i < w_n; i += 4) *(uint4*)(l_cnt + w_lo + i) = make_uint4(zr, zr, zr, zr);
                         } else {
-                            for (uint32_t i = 0; i < w_n; i++) l_cnt[w_lo + i] = 0;
+                            for (uint32_t i = 0; i < w_n; i++) l_cnt[w_lo + i] = zr;
                         }
                         // (a bitmap word shared by several threads — fewer than 32 slots per thread — belongs to lanes of one
                         // wavefront, which all read their masks above before any of them gets here)
                         if (spt_v >= 32) {
-                            for (uint32_t i = 0; i < spt_v / 32 && (x0 >> 5) + i < TS / 32; i++) l_bm[(x0 >> 5) + i] = 0;
+                            for (uint32_t i = 0; i < spt_v / 32 && (x0 >> 5) + i < TS / 32; i++) l_bm[(x0 >> 5) + i] = zr;
                         } else if ((x0 & 31u) == 0) {
-                            l_bm[x0 >> 5] = 0;
+                            l_bm[x0 >> 5] = zr;
                         }
                     }
                     pc.mark(5);

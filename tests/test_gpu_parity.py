@@ -330,6 +330,8 @@ def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     if replay == "both":  # ... and the two side by side: streams above 64 words by wavefront, the rest a lane each
         monkeypatch.setenv("SAGE_HIP_REPLAY_WAVE_MAX", "4")
         monkeypatch.setenv("SAGE_HIP_REPLAY_LANE_MAX", "64")
+        # (and the count kernel's run-start marks cover one round of cells only: every further round of a unit re-marks)
+        monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", "2048")
     dev = DeviceDatabase(small_world.host, 0)
     idx = np.arange(0, small_world.batch.n, 5)
     sub = small_world.batch.subset(idx)
@@ -346,6 +348,11 @@ def test_large_window_tile_kernel(small_world, monkeypatch, tile_shift, replay):
     n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0)), "mixed narrow / tiled routing",
                              batch=sub, dev=dev)
     assert 0 < t["n_wide"] < sub.n
+    # half-Dalton fragment windows: runs of dozens of cells, units of several thousand — more than a thread's cells in flight (the
+    # synchronous rounds of a unit) and, with SAGE_HIP_DEBUG_FLAGS=2048 (the "both" case), more than the run-start marks cover at a
+    # time (the count kernel's re-mark path; a build with that path left empty fails here: scripts/experiments/r06_lab/gpu_r7u.sh)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -300.0, 300.0), fragment_tol=Tolerance("da", -0.5, 0.5), report_psms=2),
+                      "open ±300 Da, fragment ±0.5 Da", batch=sub.subset(np.arange(0, sub.n, 3)), dev=dev)
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -5000.0, 5000.0), min_matched_peaks=1,
                                    report_psms=30), "every peptide in the window, k = 60", batch=small_world.batch.subset(np.arange(0, 40)),
                       dev=dev)
