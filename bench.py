@@ -562,9 +562,9 @@ def main():
 
     # The kernels' durations come from HIP events the library records between the kernels of a step, on the scorer's own
     # streams (sage_hip_last_timing).  Every step of a full-size run; on every 4th step of a run whose steps are short (a shard of
-    # an N-GPU run: <= 98 304 spectra) — the records and elapsed-time queries cost such a step ~15 us, 2 % of it
+    # an N-GPU run: <= 196 608 spectra) — the records and elapsed-time queries cost such a step ~15 us, 2 % of it
     # (profiles/r05_shard_sizes.txt) — and the averages below are over the steps that were timed.
-    timing_every = 1 if batch.n > 98304 else 4
+    timing_every = 1 if batch.n > 196608 else 4
 
     def run(steps):
         pm, rm = [], []
@@ -912,7 +912,7 @@ def main():
                                 # pass keeps (one reported PSM), the rest through the exact retry pass
                                 "ties_settled_from_stored_counts": last_t["n_tied"],
                                 "exact_retry_for_tied_hyperscores": last_t["n_retry"], "launches_per_step": last_t["n_launches"],
-                                # > 1: the step ran as that many parts on their own streams (steps of up to 98 304 spectra without
+                                # > 1: the step ran as that many parts on their own streams (steps of up to 196 608 spectra without
                                 # large windows) and kernel_ms are sums over launches that overlap in time
                                 "parts_per_step": last_t["n_ways"]},
                     "note": "achieved / frac: SURVEY 8(d) algorithmic bytes of the reference's algorithm (binary-search probes "

@@ -237,6 +237,7 @@ struct SageScorer {
     uint32_t kstride = 64;           // entries per query of the large-window pipeline's seed / heap arrays (DevWork::kstride)
     bool two_lanes = true;           // streaming pipeline: two chunks of a narrow batch side by side (SAGE_HIP_ONE_LANE=1: one at a time)
     uint32_t search_lag = 0;         // SAGE_HIP_SEARCH_LAG (DevWork::search_lag)
+    bool sched_desc_forced = false;  // SAGE_HIP_SCHED_DESC was given (else: heaviest precursors first for narrow batches only)
     uint64_t replay_split = 0xFFFFFFFFull;  // SAGE_HIP_REPLAY_WAVE_MAX | SAGE_HIP_REPLAY_LANE_MAX << 32 (DevWork::replay_split); default: every query by wavefront
     bool fused = false;         // SAGE_HIP_FUSED=1: the first pass of narrow windows through the fused kernel as well (measured slower
                                 // than the two kernels on MI355X — register pressure, DESIGN.md 4.7 — kept for that comparison)
@@ -785,7 +786,15 @@ static int scorer_init(SageScorer* sp, SageDeviceDb* db, const SageScorerParams*
     d.exact = 0;
     d.xcd_chunk = 1024;
     if (const char* e = getenv("SAGE_HIP_XCD_CHUNK")) d.xcd_chunk = (uint32_t)std::max(0, atoi(e));
-    if (const char* e = getenv("SAGE_HIP_SCHED_DESC")) d.xcd_chunk |= atoi(e) ? 0x80000000u : 0u;
+    // (bit 31: heaviest precursors first — the default since round 6: the expensive spectra start first and the step's tail is made
+    // of cheap ones; a rank's 62 500-spectrum C3 shard -7 %, C2 -4 %, 500 000 spectra -1 %: scripts/experiments/r06_lab/gpu_r7y.sh)
+    // Batches that may hold large windows keep the ascending order unless the variable asks (C4 +1 % with it, C5 -0.5 %: their
+    // steps are the count kernel's, which takes the spectra in queue order): enqueue_compute.
+    {
+        const char* e = getenv("SAGE_HIP_SCHED_DESC");
+        if (!e || atoi(e)) d.xcd_chunk |= 0x80000000u;
+        s->sched_desc_forced = e != nullptr;
+    }
     if (const char* e = getenv("SAGE_HIP_EXACT")) s->exact_always = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_FUSED")) s->fused = atoi(e) != 0;
     if (const char* e = getenv("SAGE_HIP_ONE_LANE")) s->two_lanes = atoi(e) == 0;
@@ -1532,6 +1541,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
     if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
     WorkSet& wset = lane ? s->ws2 : s->ws;
     DevScorer sc = s->dev;
+    if (wide && !s->sched_desc_forced) sc.xcd_chunk &= 0x7FFFFFFFu;  // (heaviest-first is the narrow search's default: scorer_init)
     DevBatchView view = view_in;
     // (the stream variant of the preliminary kernels keeps a window per (peak, fragment charge) in LDS, the probe variant the peak
     // masses only: a batch of very large spectra is probed whatever the estimate said)
@@ -1807,10 +1817,11 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
         // A narrow-search batch in `ways` parts of the launch schedule (consecutive precursor masses), each on its own stream:
         // a part's kernels fill the GPU while another part's kernel starts cold, drains, or waits on the few wavefronts of its
         // retry pass.  Large-window batches go as one (their steps are long; the parts would fight over the candidate arena).
-        // Default (no SAGE_HIP_WAYS): two parts for batches up to 98 304 spectra — the shard of a rank of an 8-GPU strong-scaling
-        // run — where a third of the step is cold starts, tails and the retry pass's handful of wavefronts (C3, 62 500 spectra:
-        // -6 %); one part above (125 000: -1 %), where the kernels' durations are what the roofline is held against.
-        const uint32_t want = s->ways ? s->ways : (b->n <= 98304u ? 2u : 1u);
+        // Default (no SAGE_HIP_WAYS): two parts for batches up to 196 608 spectra — the shards of a rank of a 3- to 8-GPU
+        // strong-scaling run — where a good part of the step is cold starts, tails and the retry pass's handful of wavefronts (C3,
+        // 62 500 spectra: -6 %; 125 000 .. 170 000 with the heaviest-first schedule of round 6: -1 .. -1.6 %); one part above, where
+        // the kernels' durations are what the roofline is held against.
+        const uint32_t want = s->ways ? s->ways : (b->n <= 196608u ? 2u : 1u);
         const uint32_t ways = (!b->maybe_wide && !s->exact_always && b->n >= 8192u * want) ? want : 1u;
         // (sized for the whole batch: the parts of a step index the working set by spectrum and share outs[0]'s count buffer and,
         // if any, its record buffer)
