@@ -185,6 +185,7 @@ struct SageDeviceBatch {
     DevBuf<uint32_t> file_id, order, sort_a, sort_b, sort_idx;
     DevBuf<uint8_t> sort_tmp;
     DevBuf<uint8_t> meta;    // streaming pipeline: the per-spectrum arrays in one block, the image of the staging block (one copy)
+    uint32_t widest = 0xFFFFFFFFu;  // candidate slots of the batch's widest precursor window (exact_window_check; else unknown)
     bool maybe_wide = true;  // some precursor window may exceed the narrow kernel's LDS counters (estimated at upload; a wrong
                              // "no" is noticed after the step — the queue counter — and the step is repeated with the
                              // large-window kernels)
@@ -1215,6 +1216,7 @@ static int exact_window_check(SageScorer* s, SageDeviceBatch* d, hipStream_t st)
     HIP_TRY(hipMemcpyAsync(&widest, s->win_max.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     d->maybe_wide = widest > s->dev.wcap;
+    d->widest = widest;
     return SAGE_HIP_OK;
 }
 
@@ -1535,7 +1537,7 @@ enum { MODE_SCORE = 0,  // order-free trims, then the exact retry pass over the 
 // stream is lane 0's).
 static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o, bool with_rescore, int mode, hipStream_t st,
                            SageFeature* rec = nullptr, bool wide = true, uint32_t list_off = 0, uint32_t* count_buf = nullptr,
-                           int lane = 0, int phase = 0) {
+                           int lane = 0, int phase = 0, uint32_t widest = 0xFFFFFFFFu) {
     // `phase` (resident steps, score_resident_locked): 0 both passes; 1 the first pass only — the exact retry pass is launched
     // later if it turns out to have anything to do; 2 that retry pass alone (the first pass of this very launch has completed).
     if (lane && wide) return fail(SAGE_HIP_ERR_INTERNAL, "large windows on the second working set");
@@ -1654,8 +1656,22 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
         launch_narrow(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
     else if (one_launch)
         launch_search(s->db->view, sc1, view, w1, s->lnfact.p, (uint32_t)s->lnfact.n, rec, count_buf, st);
-    else
+    else {
+        // With the large-window kernels behind it the preliminary kernel may only MARK the spectra it hands over, one small kernel
+        // building their queue in ascending precursor mass (DevWork::queue_later) — where the batch's windows are known to lie
+        // within a few tiles (a wide-window / DIA search).  One returning atomic per spectrum on the queue's counter costs
+        // ~11 ns each (2.3 ms of C5's step, where every spectrum is handed over), and neighbours in the sorted queue share their
+        // tiles: C5 44.3 -> 43.2 ms.  Not for windows of dozens of tiles (an open search): there the count kernel runs 6 % SLOWER
+        // behind ANY sorted or regularly permuted queue than behind the atomics' arrival order (C4 33.6 -> 35.8 ms of
+        // tile_count8_kernel; its workgroups, all on the same tiles with the same work, fall into step: starting the three of a
+        // compute unit 2 000 cycles apart gives a third of it back) — scripts/experiments/r06_lab/RESULTS.md, r8e - r8i.
+        // (the line between the two: 16 tiles — C5's widest window, charge 4 of a 12 Da isolation window, holds ~4 tiles' worth of
+        // candidates, C4's +-500 Da ~55)
+        const bool later = wide && widest <= (16u << s->db->view.tile_shift);
+        w1.queue_later = later ? 1u : 0u;
         launch_prelim(s->db->view, sc1, view, w1, st);
+        if (later) launch_queue(sc1, view, w1, st);
+    }
     HIP_TRY(hipGetLastError());  // (a failed launch must not let the kernels downstream of it run on stale records)
     if (wide) {
         launch_prelim_tile(s->db->view, sc1, view, w1, st, &side);
@@ -1862,7 +1878,7 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             // contiguous run behind its last kernel
             uint32_t* const counts_to = (epilogue && ways > 1 && direct) ? count_view : o.out_count.p;
             rc = enqueue_compute(s, v, ow, true, s->exact_always ? MODE_EXACT : MODE_SCORE, st, rec, b->maybe_wide, start, counts_to, 0,
-                                 defer_retry ? 1 : 0);
+                                 defer_retry ? 1 : 0, b->widest);
             if (rc != SAGE_HIP_OK) {
                 for (uint32_t k = 0; k < wy; k++) (void)hipStreamSynchronize(k ? s->way_stream[k - 1] : s->stream);
                 return rc;

@@ -145,6 +145,8 @@ struct DevWork {  // per-spectrum outputs of the preliminary pass
     uint32_t tile_blocks;  // persistent workgroups of the large-window counting kernel
     uint32_t cnt8;         // count in u8 (first pass of a two-pass search only: overflowing spectra go to the u16 retry pass)
     uint32_t reuse;        // retry pass: the large-window counts of the first pass are reused through item_of (kernels.hip: query_slot)
+    uint32_t queue_later;  // prelim_kernel only marks a spectrum it hands to the large-window kernels (status); queue_kernel appends the
+                           //     marked ones to `queue` behind it, a wavefront's worth per atomic (kernels.hip: queue_kernel)
     uint32_t* item_of;     // [n] spectrum -> its item in the first pass's queue; bit 31: count again (a u8 counter may have wrapped)
     uint32_t* ready;       // [n] search_kernel: == epoch once the spectrum's preliminary list is in HBM (written with agent-scope release)
     uint32_t epoch;        //     of this launch (never 0; the array is zeroed when it is allocated)
@@ -236,6 +238,7 @@ void launch_search(const DevDbView& db, const DevScorer& sc, const DevBatchView&
 void launch_narrow(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, const double* lnfact_table,
                    uint32_t lnfact_n, SageFeature* out, uint32_t* out_count, void* stream);
 void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);
+void launch_queue(const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream);  // (DevWork::queue_later)
 // `side`: a second stream + two events (hipStream_t, hipEvent_t x 2) for the launches that may run next to each other, or null
 struct SideStream {
     void* stream;

@@ -1292,9 +1292,13 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(Preli
         if (r.deferred) {
             if (lane == 0) {
                 ka->w.status[spec] = ST_DEFERRED;
-                const uint32_t it = atomicAdd(ka->w.n_deferred + CTR_QUEUED, 1u);
-                ka->w.queue[it] = spec;
-                if (!ka->w.reuse) ka->w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
+                // (queue_later: queue_kernel appends the marked spectra behind this kernel.  One returning atomic per spectrum on ONE
+                // address is ~11 ns each whatever else the workgroup does: 2.3 ms of C5's step, where every spectrum ends up here)
+                if (!ka->w.queue_later) {
+                    const uint32_t it = atomicAdd(ka->w.n_deferred + CTR_QUEUED, 1u);
+                    ka->w.queue[it] = spec;
+                    if (!ka->w.reuse) ka->w.item_of[spec] = it;  // (the retry pass finds the first pass's records of this spectrum through it)
+                }
             }
             continue;
         }
@@ -1310,6 +1314,39 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(Preli
             for (uint32_t i = lane; i < r.stored; i += WAVE) dst[i] = L.listB[i];
         }
         pc.mark(4);
+    }
+}
+
+// The queue of the large-window kernels behind a prelim_kernel that only marked the spectra it hands over (DevWork::queue_later): one
+// thread per schedule position, a wavefront's marked spectra per atomic on the queue's counter.
+__global__ __launch_bounds__(256) void queue_kernel(DevScorer sc, DevBatchView b, DevWork w) {
+    uint32_t n_batch = b.n;
+    if (b.n_dev) {
+        const uint32_t nd = *b.n_dev;
+        n_batch = nd < n_batch ? nd : n_batch;
+    }
+    const uint32_t lane = lane_id();
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_batch; base += gridDim.x * blockDim.x) {  // (whole wavefronts stay together)
+        const uint32_t blk = base + threadIdx.x;
+        uint32_t spec = 0;
+        bool marked = false;
+        if (blk < n_batch) {
+            // (ascending precursor mass, whatever prelim_kernel's own schedule: neighbours in the queue share their tiles —
+            // C5 43.8 ms in the schedule's XCD-chunked order, 43.2 ms so)
+            const uint32_t pos = blk;
+            spec = b.order ? b.order[pos] : pos;
+            marked = w.status[spec] == ST_DEFERRED;
+        }
+        const uint64_t m = __ballot(marked);
+        if (m == 0ull) continue;
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(w.n_deferred + CTR_QUEUED, (uint32_t)__popcll(m));
+        first = uni(first);
+        if (marked) {
+            const uint32_t it = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            w.queue[it] = spec;
+            if (!w.reuse) w.item_of[spec] = it;
+        }
     }
 }
 
@@ -4273,6 +4310,11 @@ void launch_prelim(const DevDbView& db, const DevScorer& sc, const DevBatchView&
     static const uint32_t grid_cap = [] { const char* e = getenv("SAGE_HIP_PRELIM_GRID"); return e ? (uint32_t)strtoul(e, nullptr, 10) & ~7u : 0u; }();
     if (grid_cap && grid > grid_cap) grid = grid_cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), prelim_lds_bytes(sc, b, sc.big_path && w.hugebuf), (hipStream_t)stream, PrelimKernargs{db, sc, b, w});
+}
+void launch_queue(const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream) {
+    if (b.n == 0) return;
+    const uint32_t blocks = (b.n + 255u) / 256u;
+    hipLaunchKernelGGL(queue_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, (hipStream_t)stream, sc, b, w);
 }
 void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatchView& b, const DevWork& w, void* stream,
                         const SideStream* side) {
