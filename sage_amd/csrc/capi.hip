@@ -1736,7 +1736,8 @@ counters:
     t.n_wide += c1[CTR_QUEUED];
     t.arena_entries = std::max(t.arena_entries, std::max(c1[CTR_ARENA_PTR], c2[CTR_ARENA_PTR]));
     t.n_retry += o.two_pass ? c1[CTR_RETRY] : 0;
-    t.n_tied += c1[CTR_TIED] + c1[CTR_FAST_TIE];
+    t.n_tied += c1[CTR_TIED];
+    for (uint32_t k = 0; k < CTR_TIE_STRIPES; k++) t.n_tied += c1[CTR_TIE_STRIPE0 + k * CTR_TIE_STRIDE];
     if (c1[CTR_ARENA_OVERFLOW] || c2[CTR_ARENA_OVERFLOW]) {
         if (arena_overflow) {
             *arena_overflow = true;

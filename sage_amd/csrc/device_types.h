@@ -183,8 +183,12 @@ enum { ST_OK = 0, ST_DEFERRED = 1, ST_OVERFLOW = 2, ST_RETRY = 3,
        ST_OK_ORDERED = 5 };  // ST_OK, and no trim_hits of the spectrum dropped anything: the order-free list IS the reference's list  // reported by the fused narrow kernel: nothing left to do for the per-phase kernels of the same pass
 enum { CTR_QUEUED = 0, CTR_LIST_OVERFLOW = 1, CTR_QUEUE_HEAD = 2, CTR_ARENA_PTR = 3, CTR_ARENA_OVERFLOW = 4, CTR_RETRY = 5,
        CTR_TIED = 6,  // narrow spectra whose tie at a reported rank the fused kernel settled in place
-       CTR_FAST_TIE = 7,  // spectra whose tie at the top rescore_kernel settled from the stored window counts (statistics)
-       CTR_COUNT = 8 };
+       CTR_FAST_TIE = 7,  // (unused since round 6: the stripes below)
+       // spectra whose tie at the top rescore_kernel settled from the stored window counts (statistics: SageTiming::n_tied), in
+       // CTR_TIE_STRIPES counters 64 bytes apart, a workgroup's by its id: one counter took one atomic per tied spectrum on ONE
+       // address — 312 816 per step of the tie-rich C3T, and same-address atomics retire at ~87 M/s: 5.5 % of its rescoring kernel
+       CTR_TIE_STRIPE0 = 16, CTR_TIE_STRIPES = 16, CTR_TIE_STRIDE = 16,
+       CTR_COUNT = CTR_TIE_STRIPE0 + CTR_TIE_STRIPES * CTR_TIE_STRIDE };
 
 // one precursor-window query (scoring.rs:335-382) of a spectrum handled by the large-window pipeline
 struct QueryRec {

@@ -3578,7 +3578,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
                     }
                     rank = pass && lane == win ? 0u : 1u;  // (next_h == best_h already: the runner-up has the same hyperscore)
                     tie = false;
-                    if (lane == 0) atomicAdd(la.counters() + CTR_FAST_TIE, 1u);  // (statistics: SageTiming::n_tied)
+                    if (lane == 0) atomicAdd(la.counters() + CTR_TIE_STRIPE0 + CTR_TIE_STRIDE * (blockIdx.x % CTR_TIE_STRIPES), 1u);  // (statistics: SageTiming::n_tied)
                 }
             }
             if (__ballot(tie) != 0ull) {
