@@ -1663,8 +1663,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
         // ~11 ns each (2.3 ms of C5's step, where every spectrum is handed over), and neighbours in the sorted queue share their
         // tiles: C5 44.3 -> 43.2 ms.  Not for windows of dozens of tiles (an open search): there the count kernel runs 6 % SLOWER
         // behind ANY sorted or regularly permuted queue than behind the atomics' arrival order (C4 33.6 -> 35.8 ms of
-        // tile_count8_kernel; its workgroups, all on the same tiles with the same work, fall into step: starting the three of a
-        // compute unit 2 000 cycles apart gives a third of it back) — scripts/experiments/r06_lab/RESULTS.md, r8e - r8i.
+        // tile_count8_kernel, the same binary: not understood) — scripts/experiments/r06_lab/RESULTS.md, r8e - r8m.
         // (the line between the two: 16 tiles — C5's widest window, charge 4 of a 12 Da isolation window, holds ~4 tiles' worth of
         // candidates, C4's +-500 Da ~55)
         const bool later = wide && widest <= (16u << s->db->view.tile_shift);
