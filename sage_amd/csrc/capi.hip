@@ -1666,7 +1666,8 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
         // tile_count8_kernel, the same binary: not understood) — scripts/experiments/r06_lab/RESULTS.md, r8e - r8m.
         // (the line between the two: 16 tiles — C5's widest window, charge 4 of a 12 Da isolation window, holds ~4 tiles' worth of
         // candidates, C4's +-500 Da ~55)
-        const bool later = wide && widest <= (16u << s->db->view.tile_shift);
+        bool later = wide && widest <= (16u << s->db->view.tile_shift);
+        if (const char* e = getenv("SAGE_HIP_QUEUE_LATER")) later = wide && atoi(e) != 0;  // (tests and experiments force either way)
         w1.queue_later = later ? 1u : 0u;
         launch_prelim(s->db->view, sc1, view, w1, st);
         if (later) launch_queue(sc1, view, w1, st);

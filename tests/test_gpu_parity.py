@@ -309,13 +309,20 @@ def test_unknown_and_overridden_precursor_charge(small_world):
                                    min_isotope_err=-1, max_isotope_err=1), "override charge 1..5 x iso -1..1")
 
 
-def test_wide_tolerance_hits_large_window_path(small_world):
+@pytest.mark.parametrize("queue_later", ["0", "1"])
+def test_wide_tolerance_hits_large_window_path(small_world, monkeypatch, queue_later):
     """±150 Da on a small database: the window exceeds the LDS counter capacity for many spectra, so the
-    large-window kernel runs; results must still be identical."""
+    large-window kernel runs; results must still be identical — with the spectra queued by prelim_kernel itself (one atomic each)
+    and by queue_kernel behind it (round 6; the default depends on the batch's widest window)."""
+    monkeypatch.setenv("SAGE_HIP_QUEUE_LATER", queue_later)
     idx = np.arange(0, small_world.batch.n, 6)
     sub = small_world.batch.subset(idx)
     n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -300.0, 300.0)), "open ±300 Da", batch=sub)
     assert t["n_wide"] > 0
+    # a mixed batch: narrow spectra beside queued ones
+    monkeypatch.setenv("SAGE_HIP_WCAP", "64")
+    n, t = small_world.check(ScorerParams(precursor_tol=Tolerance("da", -2.0, 2.0)), "mixed narrow / queued", batch=sub)
+    assert 0 < t["n_wide"] < sub.n
 
 
 @pytest.mark.parametrize("tile_shift,replay", [(11, "wave"), (12, "lane"), (15, "wave"), (15, "lane"), (12, "both")])
