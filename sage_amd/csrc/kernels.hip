@@ -2258,13 +2258,42 @@ __device__ __forceinline__ void for_each_candidate_batch(const DevWork& w, const
             tb = (uint32_t)__shfl((int)r.tile_base, (int)own, 64);
             e = k < total ? w.arena[at + (k - first)] : 0u;
         };
-        uint32_t e = 0, tb = 0, e_next = 0, tb_next = 0;
-        if (total) fetch(0, e, tb);
-        for (uint32_t base = 0; base < total; base += WAVE) {
-            if (base + WAVE < total) fetch(base + WAVE, e_next, tb_next);
-            f(e, tb);
-            e = e_next;
-            tb = tb_next;
+#ifndef SAGE_CAND_FETCH_DEPTH
+#define SAGE_CAND_FETCH_DEPTH 3  // fetches of 64 words in flight (round 6: 1 -> 3; the consumers do little per word, a fetch is a round trip to HBM)
+#endif
+        if (SAGE_CAND_FETCH_DEPTH > 1) {
+            // DEPTH fetches in flight, issued in ascending order (the owner carry goes from fetch to fetch), consumed in the same order
+            // (named scalars, not arrays: an array captured by `fetch` would live in scratch memory)
+#if SAGE_CAND_FETCH_DEPTH == 6
+#define SAGE_FETCH_SLOTS(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#elif SAGE_CAND_FETCH_DEPTH == 4
+#define SAGE_FETCH_SLOTS(X) X(0) X(1) X(2) X(3)
+#else
+#define SAGE_FETCH_SLOTS(X) X(0) X(1) X(2)
+#endif
+            constexpr uint32_t DEPTH = SAGE_CAND_FETCH_DEPTH == 6 ? 6 : SAGE_CAND_FETCH_DEPTH == 4 ? 4 : 3;
+#define SAGE_FETCH_FIRST(I) uint32_t e##I = 0, t##I = 0; if (I * WAVE < total) fetch(I * WAVE, e##I, t##I);
+            SAGE_FETCH_SLOTS(SAGE_FETCH_FIRST)
+#undef SAGE_FETCH_FIRST
+            for (uint32_t base = 0; base < total; base += DEPTH * WAVE) {
+#define SAGE_FETCH_TURN(I)                                                                        \
+    if (base + I * WAVE < total) {                                                                \
+        f(e##I, t##I);                                                                            \
+        if (base + (DEPTH + I) * WAVE < total) fetch(base + (DEPTH + I) * WAVE, e##I, t##I);      \
+    }
+                SAGE_FETCH_SLOTS(SAGE_FETCH_TURN)
+#undef SAGE_FETCH_TURN
+            }
+#undef SAGE_FETCH_SLOTS
+        } else {
+            uint32_t e = 0, tb = 0, e_next = 0, tb_next = 0;
+            if (total) fetch(0, e, tb);
+            for (uint32_t base = 0; base < total; base += WAVE) {
+                if (base + WAVE < total) fetch(base + WAVE, e_next, tb_next);
+                f(e, tb);
+                e = e_next;
+                tb = tb_next;
+            }
         }
     }
 }
