@@ -4374,25 +4374,29 @@ void launch_prelim_tile(const DevDbView& db, const DevScorer& sc, const DevBatch
         }
         return;
     }
-    if (!sc.exact) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w);
     // bounded_min_heapify replay: a wavefront per query (the default for every query since the round-6 root replacement —
     // wh32_replace_root: ~12 vector instructions per offer —, which made the lane-per-query kernel's best case, many short streams,
     // no faster: C5's retry pass 6.6 ms whichever way the queries are split below 512 stream words).  The lane-per-query kernel
     // stays for DevWork::replay_split settings that ask for it (tests; SAGE_HIP_REPLAY_WAVE_MAX / _LANE_MAX).
     uint64_t wave_max = w.replay_split;
     if (!sc.exact && (wave_max & 0xFFFFFFFFull)) wave_max |= 0xFFFFFFFFull;
-    // (the two take disjoint sets of queries: side by side when the caller lends a second stream)
     const bool both = (wave_max & 0xFFFFFFFFull) != 0xFFFFFFFFull && (sc.exact || !(wave_max & 0xFFFFFFFFull));
-    hipStream_t lane_stream = (hipStream_t)stream;
-    if (both && side) {
-        lane_stream = (hipStream_t)side->stream;
+    // The kernels of this stage take disjoint sets of queries (order-free mode: tile_select_kernel every query whose histogram is
+    // whole, the replay the few whose histogram is clipped — a few hundred serial wavefronts that used to run alone on the GPU for
+    // 0.7 - 1.1 ms behind the select; the two replay kernels: see replay_by_wavefront): side by side when the caller lends a second
+    // stream.
+    const bool select = !sc.exact;
+    hipStream_t side_stream = (hipStream_t)stream;
+    if ((select || both) && side) {
+        side_stream = (hipStream_t)side->stream;
         if (hipEventRecord((hipEvent_t)side->fork, (hipStream_t)stream) != hipSuccess) return;
-        if (hipStreamWaitEvent(lane_stream, (hipEvent_t)side->fork, 0) != hipSuccess) return;
+        if (hipStreamWaitEvent(side_stream, (hipEvent_t)side->fork, 0) != hipSuccess) return;
     }
-    if (both) hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, lane_stream, sc, w, wave_max);
+    if (select) hipLaunchKernelGGL(tile_select_kernel, dim3(capped(nq)), dim3(64), 0, side_stream, sc, w);
+    if (both) hipLaunchKernelGGL(tile_replay_kernel, dim3(capped((nq + 63) / 64)), dim3(64), 0, side_stream, sc, w, wave_max);
     hipLaunchKernelGGL(tile_replay_wave_kernel, dim3(capped(nq)), dim3(64), 0, (hipStream_t)stream, sc, w, wave_max);
-    if (both && side) {
-        if (hipEventRecord((hipEvent_t)side->join, lane_stream) != hipSuccess) return;
+    if ((select || both) && side) {
+        if (hipEventRecord((hipEvent_t)side->join, side_stream) != hipSuccess) return;
         if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)side->join, 0) != hipSuccess) return;
     }
     hipLaunchKernelGGL(tile_assemble_kernel<false>, dim3(capped(b.n)), dim3(64), assemble_lds, (hipStream_t)stream, sc, b, w);
