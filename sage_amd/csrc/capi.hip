@@ -118,7 +118,11 @@ struct SageDeviceDb {
     DevBuf<float> ions;
     DevBuf<uint64_t> ion_off;
     DevBuf<uint32_t> pep_info;
-    DevBuf<SageTheoretical> pm_frag;  // peptide-major copy (narrow kernel, small windows)
+    // peptide-major copy: the source of the tile copies while the index is built, afterwards read by the STREAM variant of the
+    // preliminary kernels only (windows of a handful of candidates) — released when the build is done (1.16 GB of C3's HBM) and
+    // made again, from a tile copy, by the first batch that takes the stream variant (ensure_pm_frag; SAGE_HIP_KEEP_PM_FRAG=1 keeps it)
+    DevBuf<SageTheoretical> pm_frag;
+    std::mutex pm_mu;
     DevBuf<uint64_t> pm_off;
     std::vector<float> h_pep_mono;    // host copy: window-size estimate at batch upload
     DevBuf<SageTheoretical> tm_frag;  // tile-major copy + position table for the large-window kernel
@@ -720,9 +724,28 @@ int sage_hip_db_create(const SageDbView* v, int device, SageDeviceDb** out) {
     std::memset(d->view.ion_kinds, 0, sizeof d->view.ion_kinds);
     for (uint32_t k = 0; k < nk; k++) d->view.ion_kinds[k] = v->ion_kinds[k];
     d->view.n_kinds = nk;
+    if (!getenv("SAGE_HIP_KEEP_PM_FRAG")) {
+        d->pm_frag.release();
+        d->view.pm_frag = nullptr;
+    }
     d->bytes = d->pep_mono.bytes() + d->pep_lut.bytes() + d->pm_frag.bytes() + d->pm_off.bytes() + d->ions.bytes() + d->ion_off.bytes() +
                d->pep_info.bytes() + d->tm_frag.bytes() + d->tm_lut.bytes() + d->tm2_frag.bytes() + d->tm2_l1.bytes() + d->tm2_pos.bytes();
     *out = d.release();
+    return SAGE_HIP_OK;
+}
+
+// the peptide-major fragment list for a batch that takes the stream variant of the preliminary kernels (SageDeviceDb::pm_frag)
+static int ensure_pm_frag(SageDeviceDb* db) {
+    std::lock_guard<std::mutex> lock(db->pm_mu);
+    if (db->view.pm_frag) return SAGE_HIP_OK;
+    HIP_TRY(db->pm_frag.alloc((size_t)db->view.nf + 2));
+    const hipError_t be = (hipError_t)rebuild_peptide_major_on_device(db->tm_frag.p, db->view.nf, db->pm_frag.p, nullptr);
+    if (be != hipSuccess) {
+        db->pm_frag.release();
+        return fail(be == hipErrorOutOfMemory ? SAGE_HIP_ERR_OOM : SAGE_HIP_ERR_HIP, std::string("peptide-major fragment list: ") + hipGetErrorString(be));
+    }
+    db->bytes += db->pm_frag.bytes();
+    db->view.pm_frag = db->pm_frag.p;
     return SAGE_HIP_OK;
 }
 
@@ -1548,6 +1571,10 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
     // (the stream variant of the preliminary kernels keeps a window per (peak, fragment charge) in LDS, the probe variant the peak
     // masses only: a batch of very large spectra is probed whatever the estimate said)
     if (!view.probe && (size_t)view.fzcap * view.pcap * 8 > 48 * 1024) view.probe = 1;
+    if (!view.probe) {  // (the stream variant reads the peptide-major fragment list, which an index keeps only once asked for)
+        const int rc_pm = ensure_pm_frag(s->db);
+        if (rc_pm != SAGE_HIP_OK) return rc_pm;
+    }
     const bool production = mode == MODE_SCORE && with_rescore;
     const bool fused = s->fused && production;
     if (!production) wide = true;

@@ -258,6 +258,7 @@ int generate_fragments_on_device(uint64_t np, uint32_t nk, const uint8_t* d_kind
                                  const uint64_t* d_ion_off, const uint64_t* d_pm_off, float* d_ions, SageTheoretical* d_pm_frag,
                                  void* stream);
 int ion_abs_range_on_device(const float* d_ions, uint64_t n, uint32_t* lo_bits, uint32_t* hi_bits);
+int rebuild_peptide_major_on_device(const SageTheoretical* d_tm_frag, uint64_t nf, SageTheoretical* d_pm_frag, void* stream);
 int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uint32_t tile_shift, uint32_t n_tiles,
                               const uint64_t* d_tile_off, float lut_scale, SageTheoretical* d_tm_frag, uint32_t** d_lut_out,
                               uint32_t* lut_stride_out, void* stream, int layout = 0);

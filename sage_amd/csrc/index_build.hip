@@ -304,6 +304,31 @@ int build_tile_copy_on_device(const SageTheoretical* d_pm_frag, uint64_t nf, uin
 }
 
 
+// The peptide-major fragment list out of a tile-major copy (either one: they hold the same entries): the tile copy's own sort with
+// tiles of ONE peptide — the key is (peptide, m/z).  The order inside a peptide is by m/z, not by (kind, ion index) as generated; the
+// stream variant of the preliminary kernels, the list's only reader, counts matches and does not care.  d_pm_frag: [nf + 2].
+int rebuild_peptide_major_on_device(const SageTheoretical* d_tm_frag, uint64_t nf, SageTheoretical* d_pm_frag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    BUILD_TRY(hipMalloc((void**)&k_in, (nf ? nf : 1) * 8));
+    BUILD_TRY(hipMalloc((void**)&k_out, (nf ? nf : 1) * 8));
+    if (nf) {
+        hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, stream, nf, 0u, d_tm_frag, k_in);
+        BUILD_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, k_in, k_out, nf, 0, 64, stream));
+        BUILD_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+        BUILD_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, k_in, k_out, nf, 0, 64, stream));
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3((uint32_t)((nf + 2 + 255) / 256)), dim3(256), 0, stream, nf, 0u, k_out, d_pm_frag);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(k_in);
+    (void)hipFree(k_out);
+    if (tmp) (void)hipFree(tmp);
+    return (int)hipSuccess;
+}
+
 // ---- the succinct form of a row-major position table (core.h: LutWord) -----------------------------------------------------------
 namespace {
 // one thread per (tile, word): the occupancy bits of its 32 cells — cell c holds an entry iff lut[c + 1] != lut[c] (the table
