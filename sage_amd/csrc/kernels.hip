@@ -1480,7 +1480,7 @@ __device__ __forceinline__ void tile_count_body(const TileParams& kp, unsigned c
     constexpr uint32_t CBITS = C8 ? 8 : 16;         // bits per counter
     constexpr uint32_t CMAX = C8 ? 0xFFu : 0xFFFFu;
 #ifndef SAGE_TILE8_CELLS
-#define SAGE_TILE8_CELLS 3
+#define SAGE_TILE8_CELLS 2  // (round 6, after the rank locate: 2 cells per thread in flight spill 7 vector registers instead of 18 — C5 41.8 -> 40.8 ms, C4 unchanged; 3 before)
 #endif
 // Round 5 experiments on the count kernel's instruction count (it executes vector instructions 80 % of its SIMDs' time), A/B'd on C4
 // / C5 (scripts/experiments/r05_lab/gpu_r5q.sh, gpu_r5r.sh): the owner wavefront of a cell by BISECTION over the running totals (14
