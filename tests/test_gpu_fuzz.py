@@ -76,6 +76,30 @@ def _params(rng):
     return p, open_search
 
 
+def _coarse_peaks(batch, rng, zeros):
+    """The same spectra as a coarse instrument would report them: intensities on a few levels (so that equally intense peaks meet
+    inside a fragment window — spectrum.rs:147-157 keeps the LAST of them — and candidates tie in summed intensity), every ~12th
+    peak's mass repeated by its neighbour (equal masses side by side: the order stays ascending), optionally some intensities at
+    zero.  total_ion_current is re-summed in peak order, as SpectrumProcessor does."""
+    it = batch.intensities.copy()
+    top = float(it.max()) if len(it) else 1.0
+    levels = int(rng.integers(3, 9))
+    it = (np.ceil(it / np.float32(top) * levels) * np.float32(top / levels)).astype(np.float32)
+    if zeros:
+        it[rng.random(len(it)) < 0.1] = 0.0
+    m = batch.masses.copy()
+    off = batch.peak_off.astype(np.int64)
+    dup = np.flatnonzero(rng.random(len(m)) < 0.08)
+    last = np.zeros(len(m) + 1, bool)
+    last[off[1:] - 1] = True  # (a spectrum's last peak has no right neighbour inside the spectrum)
+    dup = dup[~last[dup]]
+    m[dup + 1] = m[dup]
+    # (in peak order, f32 — the running sum of spectrum.rs:396-400; a cumulative sum accumulates sequentially)
+    tic = np.array([np.cumsum(it[off[i]:off[i + 1]], dtype=np.float32)[-1] if off[i + 1] > off[i] else 0.0 for i in range(batch.n)], np.float32)
+    return SpectrumBatch(batch.peak_off, m, it, batch.precursor_mz, batch.precursor_charge, tic, batch.isolation_lo, batch.isolation_hi,
+                         batch.scan_start_time, batch.inverse_ion_mobility, batch.file_id)
+
+
 @pytest.fixture(scope="module", params=sorted(WORLDS))
 def world(request, gpu_required):
     db, spectra, n, peaks = WORLDS[request.param]
@@ -96,4 +120,7 @@ def test_random_scorer_configuration(world, case):
         batch = SpectrumBatch(batch.peak_off, batch.masses, batch.intensities, batch.precursor_mz, np.zeros(batch.n, np.uint8),
                               batch.total_ion_current, batch.isolation_lo, batch.isolation_hi, batch.scan_start_time,
                               batch.inverse_ion_mobility, batch.file_id)
+    how = rng.random()
+    if how < 0.35:
+        batch = _coarse_peaks(batch, rng, zeros=how < 0.1)
     world.check(params, f"{world.name}/{case}: {params}", batch=batch)
