@@ -3059,16 +3059,23 @@ __device__ __forceinline__ uint64_t lane_run(uint64_t v, uint32_t src_lane) { re
 // LONG: the two Run states of a candidate in 64-bit registers (ion indices beyond 1023: core.h) — rescore_big_kernel's second
 // instance; every other caller keeps the one-register form.  FAST: the short divisions (core.h: div_const_fast) — an instance of
 // rescore_kernel the host picks when it has bounded the dividends.
+#ifndef SAGE_DENSE_HITS
+#define SAGE_DENSE_HITS 1  // 1: the lanes' own hits of a round's last chunk through a dense work list in the bitmap's bytes
+#endif
+constexpr uint32_t DENSE_CAP = 384;  // items of the dense work list: 2 x 4 + 2 bytes each and a flag bit, inside the bitmap's 4 KB
+static_assert(DENSE_CAP % 64 == 0 && DENSE_CAP * 10 + DENSE_CAP / 8 <= PBM_WORDS * 4, "the dense work list fits the bitmap");
 template <class PC, bool LONG = false, bool FAST = false>
 __device__ __forceinline__ void score_candidates(const DevDbView& db, const DevScorer& sc, const uint32_t* pbm, const uint32_t* plut,
                                                  const float* pm, const float* pi, const uint32_t P, const float inv_w,
                                                  const bool valid, const uint64_t ion_base, const uint32_t lm1, const uint32_t nfz,
                                                  const bool any_fz2, const bool any_fz3, const uint32_t nterm_mask, const bool sym_tol,
                                                  Score& s, PC& pc, const bool have_first = false, const float first0 = 0.f,
-                                                 const float first1 = 0.f, const float first2 = 0.f, const float first3 = 0.f) {
+                                                 const float first1 = 0.f, const float first2 = 0.f, const float first3 = 0.f,
+                                                 const bool dense_ok = false) {
     // (have_first: the candidate's first four ions were requested by the caller, ahead of its LDS table builds)
     const uint32_t lane = lane_id();
     typedef typename std::conditional<LONG, uint64_t, uint32_t>::type RunReg;
+    constexpr bool DENSE = !LONG;  // (the tags of the dense work list hold ion indices below 2^15)
     RunReg b_run = 0, y_run = 0;  // (run_matched_packed)
     uint32_t mm = 0;                // matched_b | matched_y << 16 (u16 in the reference)
     const bool scored = valid && lm1 && nfz;
@@ -3174,6 +3181,90 @@ TM = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
             }
         }
         pc.mark(7);  // (... the heavy candidates, wavefront-wide)
+#if SAGE_DENSE_HITS
+        // ---- everybody else, DENSE: the lanes' hits of the LAST chunk of a scoring round no other round follows go through
+        //      select_most_intense_peak 64 at a time instead of lane by lane behind the lane with the most hits.  The work list lives in
+        //      the bitmap's bytes — dead by now: the filter above was its last reader (no later chunk, and only a chimera search
+        //      scores a second round against the same bitmap: `dense_ok` is false there).  Three phases: (A) a lane writes one word per
+        //      item — its lane, the ion's place in the chunk, the charge, the (series, index) tag — at its prefix-sum position, in
+        //      the reference's (ion, charge) order; (B) item i is fetched and looked up by lane i % 64 (the ions of 64 items in flight
+        //      together), intensity and ppm term left in place, a flag per item; (C) a lane adds its matched items up in order — the
+        //      same f32 additions in the same order as the walk below.
+        if (DENSE && dense_ok && !(sc.dbg_flags & 128u) && __ballot(j0 + 64u < nions) == 0ull && __ballot(act && nfz > 3u) == 0ull) {  // (128: tests take the walk)
+            const uint32_t hcnt = act ? (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3)) : 0u;
+            const uint32_t incl = wave_incl_scan_dpp(hcnt);
+            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (T == 0u) continue;
+            if (T <= ((sc.dbg_flags & 256u) ? 64u : DENSE_CAP)) {  // (256: tests cap the list at 64 items — longer ones take the walk)
+                uint32_t* const dW = (uint32_t*)pbm;                 // [DENSE_CAP] the item's word -> the matched peak's intensity
+                float* const dB = (float*)(dW + DENSE_CAP);          // [DENSE_CAP] its ppm term
+                uint16_t* const dT = (uint16_t*)(dB + DENSE_CAP);    // [DENSE_CAP] ion index | n-terminal series << 15
+                uint32_t* const dF = (uint32_t*)(dT + DENSE_CAP);    // [DENSE_CAP / 32] item matched a peak
+                uint32_t pos = incl - hcnt;
+                uint64_t any = m1 | m2 | m3;
+                while (any) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)any) - 1;
+                    any &= any - 1;
+                    uint32_t kind_i = 0, idx = j0 + bit;
+                    while (idx >= lm1) { idx -= lm1; kind_i++; }
+                    const uint32_t word = idx | (((nterm_mask >> kind_i) & 1u) << 15) | (bit << 16) | (lane << 24);
+                    if ((m1 >> bit) & 1ull) dW[pos++] = word | (1u << 22);
+                    if (any_fz2 && ((m2 >> bit) & 1ull)) dW[pos++] = word | (2u << 22);
+                    if (any_fz3 && ((m3 >> bit) & 1ull)) dW[pos++] = word | (3u << 22);
+                }
+                lds_sync();
+                for (uint32_t base = 0; base < T; base += WAVE) {
+                    const uint32_t i = base + lane;
+                    const uint32_t word = i < T ? dW[i] : 0u;
+                    // (the ion table of the item's candidate: its lane's ion_base, through the crossbar — every lane takes part)
+                    const uint32_t src = (word >> 24) << 2;
+                    const uint64_t ib = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)(uint32_t)(ion_base >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)(uint32_t)ion_base);
+                    bool ok = false;
+                    if (i < T) {
+                        const float ionv = db.ions[ib + j0 + ((word >> 16) & 63u)];
+                        const uint32_t c = (word >> 22) & 3u;
+                        float mz = c == 2u ? ionv * 0.5f : ionv;  // (core.h: fragment_mz — x / 1 and x / 2 bit for bit)
+                        if (any_fz3 && c == 3u) mz = fragment_mz<FAST>(ionv, 3u);
+                        float flo, fhi;
+                        tol_bounds_mode<FAST>(sc.fragment_tol, sym_tol, mz, flo, fhi);
+                        const int pk = select_peak_lut(pm, pi, P, plut, inv_w, flo, fhi);
+                        if (pk >= 0) {
+                            const float peak_mass = pm[pk], peak_intensity = pi[pk];
+                            ok = true;
+                            dW[i] = __float_as_uint(peak_intensity);
+                            dB[i] = peak_intensity * __builtin_fabsf(mz - peak_mass) * 2E6f / (mz + peak_mass);
+                            dT[i] = (uint16_t)word;
+                        }
+                    }
+                    const uint64_t K = __ballot(ok);
+                    if (lane == 0) *(uint2*)(dF + (base >> 5)) = make_uint2((uint32_t)K, (uint32_t)(K >> 32));
+                }
+                lds_sync();
+#define SAGE_DENSE_ADD(Q)                                          \
+    {                                                              \
+        const float it = __uint_as_float(dW[Q]), tm = dB[Q];       \
+        const uint32_t tag = dT[Q];                                \
+        s.ppm_difference += tm;                                    \
+        if (tag & 0x8000u) {                                       \
+            mm += 1u;                                              \
+            s.summed_b += it;                                      \
+            run_matched_packed(b_run, tag & 0x7FFFu);              \
+        } else {                                                   \
+            mm += 0x10000u;                                        \
+            s.summed_y += it;                                      \
+            run_matched_packed(y_run, tag & 0x7FFFu);              \
+        }                                                          \
+    }
+                for (pos = incl - hcnt; pos < incl; pos++) {
+                    if (!((dF[pos >> 5] >> (pos & 31u)) & 1u)) continue;
+                    SAGE_DENSE_ADD(pos)
+                }
+#undef SAGE_DENSE_ADD
+                continue;
+            }
+        }
+#endif
         // ---- everybody else: the lane walks its own hits
         uint64_t any = m1 | m2 | m3;
         if (!any) continue;
@@ -3447,7 +3538,7 @@ __device__ __forceinline__ bool rescore_spectrum(const DevDbView& db, const DevS
         s.longest_b = s.longest_y = 0;
         pc.mark(5);  // (... the peak table and the bitmap)
         score_candidates<PC, false, FAST>(db, sc, pbm, plut, pm, pi, P, inv_w, valid, ion_base, lm1, nfz, any_fz2, any_fz3, nterm_mask, sym_tol,
-                                          s, pc, SAGE_ION_PREFETCH && round == 0, first0, first1, first2, first3);
+                                          s, pc, SAGE_ION_PREFETCH && round == 0, first0, first1, first2, first3, !sc.chimera);
         pc.mark(1);  // (... the lanes' own hits)
         // ---- from here on: the arguments through `la`, the spectrum's scalars from R.hdr (see LateArgs) ----
         LateArgs<KA> la(db, sc, b, w, lnfact_table, lnfact_n, out, out_count);

@@ -130,6 +130,25 @@ def test_rescoring_with_and_without_cooperative_matching(small_world, monkeypatc
                           f"coop flags={flags}: ±0.6 Da fragments, chimera")
 
 
+def test_rescoring_with_the_dense_work_list_and_the_walk(small_world, monkeypatch):
+    """The lanes' own filter hits of a scoring round's last 64-ion chunk go through select_most_intense_peak 64 items at a time
+    (a work list in the bitmap's bytes: kernels.hip, score_candidates) unless another round will read the bitmap again (chimera),
+    another chunk follows, a fragment charge above 3 is unfiltered or the list overflows; SAGE_HIP_DEBUG_FLAGS=128 takes the
+    lane-by-lane walk everywhere, 256 caps the list at 64 items (spectra on both routes), and with 32 the heavy candidates'
+    dozens of hits go through the list as well.  Same Features on every route."""
+    for flags in (None, "128", "256", "32", "288"):
+        if flags:
+            monkeypatch.setenv("SAGE_HIP_DEBUG_FLAGS", flags)
+        small_world.check(ScorerParams(report_psms=3), f"dense flags={flags}: narrow")
+        small_world.check(ScorerParams(max_fragment_charge=3, precursor_tol=Tolerance("da", -3.0, 3.0), report_psms=2,
+                                       override_precursor_charge=True, min_precursor_charge=3, max_precursor_charge=4),
+                          f"dense flags={flags}: fragment charges 1..3, ±3 Da")
+        small_world.check(ScorerParams(fragment_tol=Tolerance("da", -0.6, 0.6), min_matched_peaks=2),
+                          f"dense flags={flags}: ±0.6 Da fragments (every bin of the bitmap set: lists beyond the cap)")
+        small_world.check(ScorerParams(max_fragment_charge=5, override_precursor_charge=True, min_precursor_charge=5,
+                                       max_precursor_charge=6), f"dense flags={flags}: fragment charges above 3 (the walk)")
+
+
 def test_rescoring_with_short_and_ieee_divisions(small_world, monkeypatch):
     """Tolerance::bounds (mass.rs:21-35) and the m/z of charge-3 fragments (scoring.rs:707) in the rescoring kernel: the instance
     with the short division forms (core.h: div_const_fast; opt-in, SAGE_HIP_SHORT_DIVISIONS=1) where the host has bounded the
