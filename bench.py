@@ -303,6 +303,39 @@ def exchange_by_mass(batch, params, pep_mono, rank, world, xchg):
 WAVES_PER_SIMD = {"rescore_kernel": 5, "prelim_kernel": 5, "narrow_kernel": 5, "tile_count8_kernel": 6, "tile_count_kernel": 4}
 
 
+def limiters_text(dom, bound, issue, f_lines, f_alg, traffic_ps, gab, bytes_per_spec, pm, rm, n, n_wide):
+    """What bounds the two phases of THIS run, in words, from this run's own figures (the text used to be a constant and went stale
+    when the kernels changed)."""
+    def pct(x):
+        return "n/a" if x is None else f"{x:.2f}"
+    kname = issue["kernel"].split("<")[0] if issue else ("rescore_kernel" if dom == "rescore" else "the dominant first-pass kernel")
+    f_issue = issue["frac_issue_slots"] if issue else None
+    out = [f"dominant: {kname} ({dom} phase, {max(pm, rm):.3f} of {pm + rm:.3f} ms of kernel time per step).  Against the three ceilings: "
+           f"vector-instruction issue {pct(f_issue)} of its SIMDs' slots (SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES, live "
+           f"rocprofv3 --pmc pass; what a scalar instruction adds: profiles/r05_valu_calibration.md), HBM line traffic {pct(f_lines)} of the "
+           f"8 TB/s peak (PMC bytes), SURVEY 8(d) algorithmic bytes {pct(f_alg)} of it -> `bound` = {bound}."]
+    if issue:
+        out.append(f"{issue['valu_per_spectrum']:.0f} vector + {issue['salu_per_spectrum']:.0f} scalar instructions per spectrum at "
+                   f"{issue['waves_per_simd']} wavefronts per SIMD: for an issue-bound kernel the lever is instructions per spectrum, not bytes.")
+    ok = traffic_ps and gab and "error" not in gab
+    if n_wide:
+        if ok and gab.get("prelim"):
+            out.append(f"Large windows: the count kernel asks for {gab['prelim'] / 1e6:.2f} MB of table words, 16-byte index cells and candidate words "
+                       f"per spectrum and moves {traffic_ps.get('prelim', 0) / 1e6:.2f} MB in lines ({traffic_ps.get('prelim', 0) / gab['prelim']:.1f}x); "
+                       f"SURVEY 8(d) prices the same scan at {bytes_per_spec['prelim'] / 1e6:.2f} MB (the reference's entries + probes), so here `frac` IS a "
+                       f"bandwidth-like figure and issue slots and bytes are co-limiters.")
+    else:
+        if ok and gab.get("prelim") and pm > 0:
+            out.append(f"prelim_kernel ({pm:.3f} ms) asks for {gab['prelim'] / 1e3:.1f} KB per spectrum (table words, index cells, peaks) and moves "
+                       f"{traffic_ps.get('prelim', 0) / 1e3:.1f} KB in lines ({traffic_ps.get('prelim', 0) / gab['prelim']:.1f}x), "
+                       f"{traffic_ps.get('prelim', 0) * n / (pm * 1e-3) / 1e9 / HBM_PEAK_GBS:.2f} of the HBM peak: neither pipe is full, it waits on "
+                       f"~11 dependent round trips per spectrum (DESIGN.md 4.1).")
+        out.append("by_kernel.prelim.frac above 1 and whole_path_achieved_GBs near or above the HBM peak are NOT bandwidth: 96 % of SURVEY 8(d)'s "
+                   "bytes for a narrow search are the reference's binary-search probes, which a table-driven kernel never issues — an "
+                   "algorithmic-work rate, not to be read against 8 TB/s.")
+    return "  ".join(out)
+
+
 def issue_slot_model(issue, dom):
     """The dominant kernel against the roofline that actually bounds a vector-issue-bound kernel: the fraction of its SIMDs' time the
     vector ALU was executing its instructions, from the SQ counters of a live rocprofv3 --pmc pass —
@@ -893,18 +926,8 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": "rescore_kernel is bound by vector-instruction ISSUE at 5 wavefronts per SIMD, not by HBM: `frac_issue_slots` "
-                                "(the share of its SIMDs' time the vector ALU executes its instructions: SQ_ACTIVE_INST_VALU x 5 / "
-                                "SQ_WAVE_CYCLES from a live rocprofv3 --pmc pass; what a scalar instruction adds: "
-                                "profiles/r05_valu_calibration.md) is its roofline fraction; "
-                                "its byte fractions are small by construction.  The whole path's SURVEY 8(d) bytes over the step time "
-                                "(`whole_path_achieved_GBs`) approach the HBM SPEC peak — 96 % of those bytes are the reference's binary-search "
-                                "probes, which a table-driven kernel never issues: that figure is an algorithmic-work rate, NOT bandwidth, "
-                                "and must not be read against 8 TB/s. "
-                                "prelim_kernel follows its HBM LINE traffic (by_kernel.prelim.frac_traffic: ~0.75 of the 8 TB/s peak, ~0.95 "
-                                "of the 6.29 TB/s MI355X_MICROARCH.md calls achievable): a 4-byte table word and a 16-byte index cell each "
-                                "cost a 128-byte line, so it moves three times the bytes it asks for; its `frac` above 1 only says that "
-                                "96 % of SURVEY 8(d)'s bytes are binary-search probes a table-driven kernel never issues",
+                    "limiters": limiters_text(dom, bound, issue, f_lines, achieved / HBM_PEAK_GBS, traffic_ps, gab, bytes_per_spec, pm, rm, batch.n,
+                                              last_t["n_wide"]),
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],
