@@ -303,6 +303,14 @@ def exchange_by_mass(batch, params, pep_mono, rank, world, xchg):
 WAVES_PER_SIMD = {"rescore_kernel": 5, "prelim_kernel": 5, "narrow_kernel": 5, "tile_count8_kernel": 6, "tile_count_kernel": 4}
 
 
+def safe_text(fn, *a):
+    """A descriptive field must not take the bench line down."""
+    try:
+        return fn(*a)
+    except Exception as e:  # noqa: BLE001
+        return f"unavailable ({e!r})"
+
+
 def limiters_text(dom, bound, issue, f_lines, f_alg, traffic_ps, gab, bytes_per_spec, pm, rm, n, n_wide):
     """What bounds the two phases of THIS run, in words, from this run's own figures (the text used to be a constant and went stale
     when the kernels changed)."""
@@ -926,8 +934,8 @@ def main():
                                       "frac_gpu_algorithm": None if not gab or "error" in gab else
                                       gab[k] * batch.n / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                   for k, ms_k in (("prelim", pm), ("rescore", rm)) if ms_k > 0},
-                    "limiters": limiters_text(dom, bound, issue, f_lines, achieved / HBM_PEAK_GBS, traffic_ps, gab, bytes_per_spec, pm, rm, batch.n,
-                                              last_t["n_wide"]),
+                    "limiters": safe_text(limiters_text, dom, bound, issue, f_lines, achieved / HBM_PEAK_GBS, traffic_ps, gab, bytes_per_spec, pm, rm,
+                                          batch.n, last_t["n_wide"]),
                     "algorithmic_bytes_per_spectrum": bytes_per_spec,
                     "whole_path_achieved_GBs": bytes_per_spec["total"] * batch.n / ((pm + rm) * 1e-3) / 1e9,
                     "routing": {"spectra": batch.n, "large_window_kernel": last_t["n_wide"],
