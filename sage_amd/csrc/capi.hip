@@ -188,6 +188,7 @@ struct SageDeviceBatch {
     DevBuf<uint8_t> charge;
     DevBuf<uint32_t> file_id, order, sort_a, sort_b, sort_idx;
     DevBuf<uint8_t> sort_tmp;
+    DevBuf<uint4> sched;     // DevBatchView::sched (SAGE_HIP_NO_SCHED=1: not built — the kernels go through `order`)
     DevBuf<uint8_t> meta;    // streaming pipeline: the per-spectrum arrays in one block, the image of the staging block (one copy)
     uint32_t widest = 0xFFFFFFFFu;  // candidate slots of the batch's widest precursor window (exact_window_check; else unknown)
     bool maybe_wide = true;  // some precursor window may exceed the narrow kernel's LDS counters (estimated at upload; a wrong
@@ -1115,6 +1116,8 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     HIP_TRY(d->sort_idx.reserve(n));
     const size_t sort_bytes = schedule_temp_bytes(n);
     HIP_TRY(d->sort_tmp.reserve(sort_bytes));
+    const bool use_sched = !getenv("SAGE_HIP_NO_SCHED");
+    if (use_sched) { HIP_TRY(d->sched.reserve(2 * (size_t)n)); }
     const size_t small = ((size_t)n + 1) * 8 + (size_t)n * (4 * 7 + 1) + 64 * 12;
     HIP_TRY(d->stage.reserve(small + (peaks_locked ? 0 : total * 8 + 128)));
     HIP_TRY(d->meta.reserve(small));
@@ -1184,6 +1187,9 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
         HIP_TRY(hipMemcpyAsync(d->meta.p, d->stage.p, meta_bytes, hipMemcpyHostToDevice, s->side_stream));
         HIP_TRY((hipError_t)schedule_on_device(n, (const float*)image(h_mz), (const uint8_t*)image(h_z), s->params.min_precursor_charge,
                                                d->sort_a.p, d->sort_b.p, d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, s->side_stream));
+        if (use_sched)
+            schedule_records_on_device(n, d->order.p, (const uint64_t*)image(h_off), (const float*)image(h_mz), (const uint8_t*)image(h_z),
+                                       (const float*)image(h_lo), (const float*)image(h_hi), d->sched.p, s->side_stream);
         HIP_TRY(hipEventRecord(d->sort_done.e, s->side_stream));
         if (total && !peaks_first) {
             HIP_TRY(hipMemcpyAsync(d->masses.p, src_m, total * 4, hipMemcpyHostToDevice, up));
@@ -1209,6 +1215,7 @@ static int stage_and_upload(SageScorer* s, SageDeviceBatch* d, const SageSpectru
     v.ims = (const float*)image(h_ims);
     v.file_id = (const uint32_t*)image(h_fid);
     v.order = d->order.p;
+    v.sched = use_sched && n ? d->sched.p : nullptr;
     v.probe = probe;
     v.pcap = pcap;
     v.fzcap = batch_fzcap(s->params, zmax, any_unknown);
@@ -1401,6 +1408,12 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     HIP_TRY(d->sort_tmp.alloc(sort_bytes));
     HIP_TRY((hipError_t)schedule_on_device(n, d->precursor_mz.p, d->charge.p, s->params.min_precursor_charge, d->sort_a.p, d->sort_b.p,
                                            d->sort_idx.p, d->order.p, d->sort_tmp.p, sort_bytes, s->stream));
+    const bool use_sched = !getenv("SAGE_HIP_NO_SCHED");
+    if (use_sched) {
+        HIP_TRY(d->sched.alloc(2 * (size_t)n));
+        schedule_records_on_device(n, d->order.p, d->peak_off.p, d->precursor_mz.p, d->charge.p, has_iso ? d->iso_lo.p : nullptr,
+                                   has_iso ? d->iso_hi.p : nullptr, d->sched.p, s->stream);
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     DevBatchView& v = d->view;
     v = DevBatchView{};
@@ -1417,6 +1430,7 @@ int sage_hip_batch_process_upload(SageScorer* s, const SageRawBatch* raw, uint64
     v.ims = raw->inverse_ion_mobility ? d->ims.p : nullptr;
     v.file_id = raw->file_id ? d->file_id.p : nullptr;
     v.order = d->order.p;
+    v.sched = use_sched && n ? d->sched.p : nullptr;
     const WindowEstimate est = choose_probe(s, n, raw->precursor_mz, raw->precursor_charge, raw->isolation_lo, raw->isolation_hi);
     v.probe = est.probe;
     d->maybe_wide = est.maybe_wide;
@@ -1633,6 +1647,7 @@ static int enqueue_compute(SageScorer* s, const DevBatchView& view_in, OutSet& o
     o.wide_launched = wide;
     o.n = view.n;
     DevBatchView v2 = view;
+    v2.sched = nullptr;  // (the retry list is not the schedule)
     v2.order = wset.retry.p + list_off;  // filled by the rescoring kernel of the first pass, in no particular order
     v2.n_dev = o.counters.p + CTR_RETRY;
     if (one_launch && ++wset.epoch == 0) wset.epoch = 1;
@@ -1895,6 +1910,7 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
             hipStream_t st = wy ? s->way_stream[wy - 1] : s->stream;
             DevBatchView v = b->view;
             v.order += start;
+            if (v.sched) v.sched += 2 * (size_t)start;
             v.n = end - start;
             OutSet& ow = s->outs[wy];
             if (wy == 0 && s->timed) HIP_TRY(hipEventRecord(s->way_begin.e, st));  // (SageTiming::total_ms: first part's start to last part's end)
@@ -1965,6 +1981,7 @@ static int score_resident_locked(SageScorer* s, SageDeviceBatch* b, SageFeature*
                     hipStream_t st = wy ? s->way_stream[wy - 1] : s->stream;
                     DevBatchView v = b->view;
                     v.order += start;
+                    if (v.sched) v.sched += 2 * (size_t)start;
                     v.n = end - start;
                     uint32_t* const counts_to = (ways > 1) ? count_view : o.out_count.p;
                     rc = enqueue_compute(s, v, ow, true, MODE_SCORE, st, rec, false, start, counts_to, 0, 2);

@@ -130,6 +130,9 @@ struct DevBatchView {
     uint32_t probe;             // narrow kernel variant: 1 = per-peak table lookups (large windows), 0 = peptide-major stream
     uint32_t pcap;              // max peaks per spectrum in this batch
     uint32_t fzcap;             // max (max_fragment_charge - 1) over the charges this batch can use
+    const uint4* sched;         // may be null.  [2 n] what a block needs of the spectrum it scores, IN SCHEDULE ORDER: record b =
+                                //     {order[b], peaks, peak_off lo, hi}, {charge, precursor m/z, isolation lo, hi (NaN: none)} — one
+                                //     trip to a line its neighbours share instead of order[b] and then five random reads
 };
 
 struct DevWork {  // per-spectrum outputs of the preliminary pass
@@ -275,6 +278,8 @@ int predict_rt_on_device(int device, const SageRtInput& in, SageRtOutput& out, s
 size_t schedule_temp_bytes(uint32_t n);
 int schedule_on_device(uint32_t n, const float* d_precursor_mz, const uint8_t* d_charge, uint32_t min_charge, uint32_t* d_keys_a,
                        uint32_t* d_keys_b, uint32_t* d_idx, uint32_t* d_order, void* d_temp, size_t temp_bytes, void* stream);
+void schedule_records_on_device(uint32_t n, const uint32_t* d_order, const uint64_t* d_peak_off, const float* d_precursor_mz,
+                                const uint8_t* d_charge, const float* d_iso_lo, const float* d_iso_hi, uint4* d_sched, void* stream);
 size_t process_lds_bytes(uint32_t rcap, uint32_t rpow2);
 int process_kernel_prepare(size_t max_lds_bytes);
 void launch_process(uint32_t n, const uint64_t* raw_off, const float* raw_mz, const float* raw_int, const uint8_t* charge,

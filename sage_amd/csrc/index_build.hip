@@ -427,6 +427,20 @@ __global__ __launch_bounds__(256) void schedule_keys_kernel(uint32_t n, const fl
     keys[i] = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // ascending u32 == ascending f32 (total order)
     idx[i] = i;
 }
+// DevBatchView::sched: the per-spectrum words a scoring block starts from, gathered once per upload into schedule order
+__global__ __launch_bounds__(256) void schedule_records_kernel(uint32_t n, const uint32_t* __restrict__ order, const uint64_t* __restrict__ peak_off,
+                                                               const float* __restrict__ precursor_mz, const uint8_t* __restrict__ charge,
+                                                               const float* __restrict__ iso_lo, const float* __restrict__ iso_hi,
+                                                               uint4* __restrict__ sched) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = order[k];
+    const uint64_t p0 = peak_off[i];
+    const uint32_t nan_bits = 0x7FC00000u;
+    sched[2 * (size_t)k] = make_uint4(i, (uint32_t)(peak_off[i + 1] - p0), (uint32_t)p0, (uint32_t)(p0 >> 32));
+    sched[2 * (size_t)k + 1] = make_uint4(charge[i], __float_as_uint(precursor_mz[i]), iso_lo && iso_hi ? __float_as_uint(iso_lo[i]) : nan_bits,
+                                          iso_lo && iso_hi ? __float_as_uint(iso_hi[i]) : nan_bits);
+}
 }  // namespace
 
 size_t schedule_temp_bytes(uint32_t n) {
@@ -444,6 +458,13 @@ int schedule_on_device(uint32_t n, const float* d_precursor_mz, const uint8_t* d
                        d_keys_a, d_idx);
     size_t bytes = temp_bytes;
     return (int)rocprim::radix_sort_pairs(d_temp, bytes, d_keys_a, d_keys_b, d_idx, d_order, n, 0, 32, stream);
+}
+
+void schedule_records_on_device(uint32_t n, const uint32_t* d_order, const uint64_t* d_peak_off, const float* d_precursor_mz,
+                                const uint8_t* d_charge, const float* d_iso_lo, const float* d_iso_hi, uint4* d_sched, void* stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(schedule_records_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_order, d_peak_off,
+                       d_precursor_mz, d_charge, d_iso_lo, d_iso_hi, d_sched);
 }
 
 }  // namespace sagehip

@@ -597,6 +597,36 @@ __device__ __forceinline__ SpecInfo load_spec(const DevScorer& sc, const DevBatc
     return s;
 }
 
+// The same from the batch's schedule records (DevBatchView::sched): record `pos` holds what load_spec reads of spectrum order[pos] — one
+// trip, to a line the neighbouring blocks of the XCD share, instead of order[pos] and then five reads at random places.
+__device__ __forceinline__ SpecInfo load_spec_sched(const DevScorer& sc, const DevBatchView& b, uint32_t pos, uint32_t& spec) {
+    const uint4 r0 = b.sched[2 * (size_t)pos], r1 = b.sched[2 * (size_t)pos + 1];
+    spec = uni(r0.x);
+    SpecInfo s;
+    s.p0 = ((uint64_t)uni(r0.w) << 32) | uni(r0.z);
+    s.P = uni(r0.y);
+    const uint32_t zraw = uni(r1.x);
+    if (sc.wide_window || zraw == 0 || sc.override_precursor_charge) {  // scoring.rs:423, 437, 442
+        s.z0 = sc.min_precursor_charge;
+        s.z1 = sc.max_precursor_charge;
+    } else {
+        s.z0 = s.z1 = zraw;
+    }
+    s.nfz_max = 0;
+    for (uint32_t z = s.z0; z <= s.z1; z++) {
+        const uint32_t m = max_fragment_charge(sc.max_fragment_charge, z) - 1;
+        s.nfz_max = m > s.nfz_max ? m : s.nfz_max;
+    }
+    if (s.nfz_max > b.fzcap) s.nfz_max = b.fzcap;
+    s.mzp = unif(__uint_as_float(r1.y)) - PROTON;  // scoring.rs:420
+    s.iso_tol.kind = 2;
+    s.iso_tol.lo = -2.4f;
+    s.iso_tol.hi = 2.4f;  // scoring.rs:430
+    const float a = unif(__uint_as_float(r1.z)), c = unif(__uint_as_float(r1.w));  // (NaN bits where the batch has no isolation windows)
+    if (a == a && c == c) { s.iso_tol.lo = a; s.iso_tol.hi = c; }
+    return s;
+}
+
 // IndexedDatabase::query (database.rs:402-425) by one wavefront: [left, right] candidate slots and the
 // [first, end) peptide range after the edge rule of database.rs:526-531
 struct Window {
@@ -1260,11 +1290,11 @@ __global__ __launch_bounds__(64) SAGE_PRELIM_WAVES_ATTR void prelim_kernel(Preli
     }
     for (uint32_t blk = blockIdx.x; blk < n_batch; blk += gridDim.x) {
         const uint32_t pos = xcd_position(blk, n_batch, sc.xcd_chunk);
-        const uint32_t spec = b.order ? uni(b.order[pos]) : pos;
+        uint32_t spec = b.sched ? 0u : b.order ? uni(b.order[pos]) : pos;
         __syncthreads();
         Clock pc;
         pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blk, 0);  // (SAGE_HIP_DEBUG_FLAGS=512: clocks of the exact retry pass only)
-        const SpecInfo si = load_spec(sc, b, spec);
+        const SpecInfo si = b.sched ? load_spec_sched(sc, b, pos, spec) : load_spec(sc, b, spec);
         const PrelimResult r = prelim_spectrum<PROBE, BIGK, PrelimKernargs>(db, sc, b, L, si, sc.exact != 0, pc);
         // ---- the results leave: the work-set pointers come from the kernarg segment HERE (they were not kept across the matching) ----
         typedef const __attribute__((address_space(4))) PrelimKernargs* Segment;
@@ -3989,7 +4019,11 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
         if (blockIdx.x >= n_batch) return;
     }
     const uint32_t pos = xcd_position(blockIdx.x, n_batch, sc.xcd_chunk);
-    const uint32_t spec = b.order ? b.order[pos] : pos;
+    // (with schedule records — DevBatchView::sched — the block's spectrum and its peak range come in one trip, and the peaks are
+    // requested beside the status and the list instead of behind peak_off[spec])
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (b.sched) rec = b.sched[2 * (size_t)pos];
+    const uint32_t spec = b.sched ? uni(rec.x) : b.order ? b.order[pos] : pos;
     // Everything that hangs on `spec` alone is requested together, ahead of the first use: the spectrum's status, the whole row
     // of its preliminary list (unconditionally — the array is padded by a wavefront — so that the load does not wait for the
     // list's length), the length, the totals, the peak range.  The chain of dependent round trips is then
@@ -3998,8 +4032,8 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     const uint64_t row_word = w.cand[(size_t)spec * sc.kmax + lane];
     const uint32_t ncand = w.cand_len[spec];
     const uint32_t tot_m = w.totals[2 * spec], tot_s = w.totals[2 * spec + 1];
-    const uint64_t p0 = b.peak_off[spec];
-    const uint32_t P = (uint32_t)(b.peak_off[spec + 1] - p0);
+    const uint64_t p0 = b.sched ? ((uint64_t)uni(rec.w) << 32) | uni(rec.z) : b.peak_off[spec];
+    const uint32_t P = b.sched ? uni(rec.y) : (uint32_t)(b.peak_off[spec + 1] - p0);
     if (st == ST_DONE) return;  // reported by the fused narrow kernel of this pass
     if (st != ST_OK && st != ST_OK_ORDERED) {
         if (lane == 0 && !keep) out_count[spec] = 0;
