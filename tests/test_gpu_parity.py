@@ -114,6 +114,30 @@ def test_narrow_kernel_variants(small_world, monkeypatch, variant):
     small_world.check(ScorerParams(precursor_tol=Tolerance("da", -0.5, 0.5)), f"{variant}: charge None", batch=unknown)
 
 
+@pytest.mark.parametrize("no_sched", [None, "1"])
+def test_schedule_records_and_the_order_array(small_world, monkeypatch, no_sched):
+    """prelim_kernel / rescore_kernel start a block from the batch's schedule records (DevBatchView::sched: spectrum, peak range,
+    charge, m/z, isolation window in schedule order — built at upload) or, with SAGE_HIP_NO_SCHED=1 and in every retry pass, from
+    order[b] and the per-spectrum arrays: the same Features either way — with isolation windows (wide-window search), unknown
+    charges, isotope folding, and in parts on several streams."""
+    if no_sched:
+        monkeypatch.setenv("SAGE_HIP_NO_SCHED", no_sched)
+    small_world.check(ScorerParams(report_psms=2), f"no_sched={no_sched}: narrow")
+    small_world.check(ScorerParams(min_isotope_err=-1, max_isotope_err=2, precursor_tol=Tolerance("ppm", -20.0, 20.0)),
+                      f"no_sched={no_sched}: isotope -1..2")
+    b = small_world.batch
+    unknown = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, np.zeros(b.n, np.uint8), b.total_ion_current)
+    small_world.check(ScorerParams(precursor_tol=Tolerance("da", -0.5, 0.5)), f"no_sched={no_sched}: charge None", batch=unknown)
+    rng = np.random.default_rng(11)
+    lo = -rng.uniform(0.3, 1.2, b.n).astype(np.float32)
+    hi = rng.uniform(0.3, 1.2, b.n).astype(np.float32)
+    lo[::7] = np.nan  # (spectrum.rs: no isolation window recorded -> the +-2.4 default of scoring.rs:430)
+    windows = SpectrumBatch(b.peak_off, b.masses, b.intensities, b.precursor_mz, b.precursor_charge, b.total_ion_current, lo, hi)
+    small_world.check(ScorerParams(wide_window=True, chimera=True, report_psms=2), f"no_sched={no_sched}: wide window", batch=windows)
+    monkeypatch.setenv("SAGE_HIP_WAYS", "3")
+    small_world.check(ScorerParams(), f"no_sched={no_sched}: three parts")
+
+
 def test_rescoring_with_and_without_cooperative_matching(small_world, monkeypatch):
     """score_candidate takes a candidate with many filter hits with the whole wavefront (lookups in parallel, sums in item
     order) when few candidates are that heavy; SAGE_HIP_DEBUG_FLAGS=32 leaves every candidate to its own lane, 64 takes every
