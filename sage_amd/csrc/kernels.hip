@@ -4027,7 +4027,8 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     // Everything that hangs on `spec` alone is requested together, ahead of the first use: the spectrum's status, the whole row
     // of its preliminary list (unconditionally — the array is padded by a wavefront — so that the load does not wait for the
     // list's length), the length, the totals, the peak range.  The chain of dependent round trips is then
-    // order -> {status, list, peak range} -> {peaks, ion offsets} -> ions.
+    // schedule record -> {status, list, peaks} -> ion offsets -> ions (without the records: order -> {status, list, peak range} ->
+    // {peaks, ion offsets} -> ions).
     const uint32_t st = w.status[spec];
     const uint64_t row_word = w.cand[(size_t)spec * sc.kmax + lane];
     const uint32_t ncand = w.cand_len[spec];
