@@ -4035,6 +4035,19 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     const uint32_t tot_m = w.totals[2 * spec], tot_s = w.totals[2 * spec + 1];
     const uint64_t p0 = b.sched ? ((uint64_t)uni(rec.w) << 32) | uni(rec.z) : b.peak_off[spec];
     const uint32_t P = b.sched ? uni(rec.y) : (uint32_t)(b.peak_off[spec + 1] - p0);
+#ifndef SAGE_EARLY_PEAKS
+#define SAGE_EARLY_PEAKS 1  // with schedule records: the first 192 peaks requested HERE, in front of the branches on the status
+#endif
+    // (the compiler does not move a load above the early returns below, so the peaks used to wait for the status to arrive)
+    float em0 = 0.f, em1 = 0.f, em2 = 0.f, ei0 = 0.f, ei1 = 0.f, ei2 = 0.f;
+    const bool early = SAGE_EARLY_PEAKS && b.sched != nullptr;
+    if (early) {
+        const float* __restrict__ gm = b.masses + p0;
+        const float* __restrict__ gi = b.intensities + p0;
+        if (lane < P) { em0 = gm[lane]; ei0 = gi[lane]; }
+        if (lane + WAVE < P) { em1 = gm[lane + WAVE]; ei1 = gi[lane + WAVE]; }
+        if (lane + 2 * WAVE < P) { em2 = gm[lane + 2 * WAVE]; ei2 = gi[lane + 2 * WAVE]; }
+    }
     if (st == ST_DONE) return;  // reported by the fused narrow kernel of this pass
     if (st != ST_OK && st != ST_OK_ORDERED) {
         if (lane == 0 && !keep) out_count[spec] = 0;
@@ -4043,7 +4056,12 @@ __global__ __launch_bounds__(64) SAGE_RESCORE_WAVES_ATTR void rescore_kernel(Res
     const RescoreLds R = carve_rescore(smem, smem + ((rescore_scratch_bytes(keep != nullptr) + 15) & ~(size_t)15), b);
     Clock pc;
     pc.start((sc.dbg_flags & 512u) && !sc.exact ? nullptr : w.dbg, blockIdx.x, 1);
-    for (uint32_t i = lane; i < P; i += WAVE) {
+    if (early) {
+        if (lane < P) { R.pm[lane] = em0; R.pi[lane] = ei0; }
+        if (lane + WAVE < P) { R.pm[lane + WAVE] = em1; R.pi[lane + WAVE] = ei1; }
+        if (lane + 2 * WAVE < P) { R.pm[lane + 2 * WAVE] = em2; R.pi[lane + 2 * WAVE] = ei2; }
+    }
+    for (uint32_t i = early ? lane + 3 * WAVE : lane; i < P; i += WAVE) {
         R.pm[i] = b.masses[p0 + i];
         R.pi[i] = b.intensities[p0 + i];
     }
